@@ -1,0 +1,227 @@
+/*
+ * transcar_hip.h -- C ABI of the MI355X-native (gfx950) TransCAR fusion decoder.
+ *
+ * The reference (pangsu0613/TransCAR) has no native code and no FFI: its
+ * boundary is Python (`nn.Module.forward` signatures + state_dict keys, see
+ * SURVEY.md section 8(b)).  This header is the boundary a maintainer binds
+ * with ctypes from those Python call sites (INTEGRATION.md shows the stubs).
+ * Every entry point names the reference interface it replaces; paths are
+ * relative to the reference root:
+ *   XFMR  = projects/mmdet3d_plugin/models/utils/detr3d_transformer.py
+ *   HEAD  = projects/mmdet3d_plugin/models/dense_heads/detr3d_head.py
+ *   CODER = projects/mmdet3d_plugin/core/bbox/coders/nms_free_coder.py
+ *   UTIL  = projects/mmdet3d_plugin/core/bbox/util.py
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers to fp32 row-major arrays unless a
+ *     parameter is documented as "host";
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues
+ *     work on that stream (no allocation, no synchronisation, capturable in
+ *     a hipGraph);
+ *   - return value: 0 on success, otherwise a hipError_t (or -1 for an
+ *     argument error); tc_last_error() gives the message;
+ *   - nn.Linear weights are [out, in] row-major exactly as in the checkpoint.
+ */
+#ifndef TRANSCAR_HIP_H
+#define TRANSCAR_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TC_MAX_LEVELS 4
+#define TC_MAX_LAYERS 8
+#define TC_MAX_RADAR_LAYERS 3
+#define TC_ABI_VERSION 1
+
+typedef void* tc_stream_t;
+
+/* ---- parameter views (pointers into the caller's state_dict tensors) ---- */
+typedef struct { const float* w; const float* b; } tc_linear;   /* nn.Linear   */
+typedef struct { const float* g; const float* b; } tc_lnorm;    /* nn.LayerNorm, eps 1e-5 */
+/* Linear(3,C)-LN-ReLU-Linear(C,C)-LN-ReLU  (XFMR:285-292, HEAD:173-180) */
+typedef struct { tc_linear l0; tc_lnorm n1; tc_linear l3; tc_lnorm n4; } tc_pos_encoder;
+/* Linear-LN-ReLU x2 + Linear(C,num_classes)  (HEAD:200-206, HEAD:74-82) */
+typedef struct { tc_linear l0; tc_lnorm n1; tc_linear l3; tc_lnorm n4; tc_linear l6; } tc_cls_branch;
+/* Linear-ReLU x2 + Linear(C,code_size)  (HEAD:208-213, HEAD:84-90) */
+typedef struct { tc_linear l0; tc_linear l2; tc_linear l4; } tc_reg_branch;
+/* torch.nn.MultiheadAttention: packed in_proj [3C,C] rows (Wq;Wk;Wv) + out_proj */
+typedef struct { tc_linear in_proj; tc_linear out_proj; } tc_mha;
+
+/* one DetrTransformerDecoderLayer (CFG:65-82) + its reg_branches[lid] (XFMR:191) */
+typedef struct {
+  tc_mha self_attn;                 /* attentions.0.attn                      */
+  tc_lnorm norm0;
+  tc_linear attention_weights;      /* attentions.1.attention_weights [N*L,C] */
+  tc_linear output_proj;            /* attentions.1.output_proj               */
+  tc_pos_encoder position_encoder;  /* attentions.1.position_encoder          */
+  tc_lnorm norm1;
+  tc_linear ffn0;                   /* ffns.0.layers.0.0 [F,C]                */
+  tc_linear ffn1;                   /* ffns.0.layers.1   [C,F]                */
+  tc_lnorm norm2;
+  tc_reg_branch reg;                /* reg_branches.{lid}                     */
+} tc_decoder_layer;
+
+/* one radar fusion layer (HEAD:538-611 / :613-668 / :670-729) */
+typedef struct {
+  tc_mha attn;                      /* rf_multihead_attn{,2,3}                */
+  tc_lnorm norm2;                   /* rf_norm2{,_2,_3}                       */
+  tc_linear linear1;                /* rf_linear1{,_2,_3} [F,C]               */
+  tc_linear linear2;                /* rf_linear2{,_2,_3} [C,F]               */
+  tc_lnorm norm3;                   /* rf_norm3{,_2,_3}                       */
+  tc_cls_branch final_cls;          /* final_cls{,2,3}                        */
+  tc_reg_branch final_reg;          /* final_reg{,2,3}                        */
+  float radius_min, radius_max;     /* clamp: (1,2),(1,2),(0.5,1)  HEAD:567,635,693 */
+} tc_radar_layer;
+
+/* All parameters Detr3DHead.forward reads (HEAD:43-238), in eval mode. */
+typedef struct {
+  int abi_version;                  /* TC_ABI_VERSION                         */
+  int num_query, embed_dims, num_heads, ffn_dims, num_layers;
+  int num_cams, num_levels, num_classes, code_size;
+  int radar_in_dims, num_radar_layers, num_radar_tokens_ref; /* 36, 3, 1500   */
+  float pc_range[6];
+  const float* query_embedding;     /* [Q, 2C]: (query_pos | query) XFMR:119  */
+  tc_linear reference_points;       /* transformer.reference_points [3,C]     */
+  tc_decoder_layer layers[TC_MAX_LAYERS];
+  tc_pos_encoder radar_position_encoder;
+  tc_linear radar_feat0, radar_feat2, radar_feat4;  /* radar_feat_encoder.{0,2,4} */
+  tc_radar_layer radar[TC_MAX_RADAR_LAYERS];
+} tc_head_weights;
+
+/* multi-view FPN feature maps, channels-last: level l is [B*num_cams, H, W, C] */
+typedef struct {
+  int num_levels;
+  const float* data[TC_MAX_LEVELS];
+  int H[TC_MAX_LEVELS];
+  int W[TC_MAX_LEVELS];
+} tc_feats_nhwc;
+
+/* optional intermediate outputs of tc_head_forward (NULL pointers are skipped) */
+typedef struct {
+  float* inter_states;        /* hs            [L, B, Q, C]  (HEAD:274 layout)        */
+  float* init_reference;      /*               [B, Q, 3]                              */
+  float* inter_references;    /*               [L, B, Q, 3]                           */
+  int*   radar_hit_counts;    /* per radar layer [R, B, Q]: radar tokens inside the gate */
+  unsigned long long* sample_pairs; /* [1]: += number of visible (query,cam) pairs sampled */
+} tc_head_aux;
+
+/* ---- library ---- */
+int tc_abi_version(void);
+const char* tc_last_error(void);
+/* number of HIP devices visible; does not initialise a context */
+int tc_device_count(void);
+
+/* ---- layout ---- */
+/* FPN handoff (DET:62-66 hands the head NCHW [B,N,C,H,W]): NCHW -> NHWC. */
+int tc_nchw_to_nhwc(const float* src, float* dst, int n_img, int C, int H, int W,
+                    tc_stream_t stream);
+
+/* ---- operators, one per reference call site ---- */
+
+/* nn.Linear (+ optional fused pieces).  y[M,N] = act((x (+x2)) W^T + b) (+res)
+ * act: 0 none, 1 ReLU, 2 sigmoid (XFMR:122-123).  x2/res may be NULL. */
+int tc_linear_fwd(const float* x, const float* x2, const float* w, const float* b,
+                  const float* res, float* y, int M, int K, int N, int act,
+                  tc_stream_t stream);
+
+/* y = LayerNorm(a (+ b))*g + beta, optional ReLU; eps 1e-5 (mmcv `norms[i]`,
+ * HEAD:583,586).  b may be NULL. */
+int tc_add_layernorm_fwd(const float* a, const float* b, const float* gamma,
+                         const float* beta, float* y, int M, int C, int relu,
+                         tc_stream_t stream);
+
+/* Iterative reference-point refinement of Detr3DTransformerDecoder.forward
+ * (XFMR:195-203): new_ref = sigmoid(reg_out[...,{0,1,4}] + inverse_sigmoid(ref)).
+ * reg_out [M,code_size], ref/new_ref [M,3]. */
+int tc_refine_reference_fwd(const float* reg_out, int code_size, const float* ref,
+                            float* new_ref, int M, tc_stream_t stream);
+
+/* feature_sampling + the weighting/reduction of Detr3DCrossAtten.forward
+ * (XFMR:365-373, XFMR:381-422): projection of the reference points into every
+ * camera, visibility mask, bilinear 4-level sampling (align_corners=False,
+ * zeros padding), NaN->0, sigmoid(attn_logits)*mask weighting, sum over
+ * (cam, level).  out [B,Q,C];  vis_mask [B,Q,num_cams] (bytes) may be NULL. */
+int tc_cam_sample_fuse_fwd(const tc_feats_nhwc* feats, int B, int Q, int C, int num_cams,
+                           const float* lidar2img /*[B,N,4,4]*/, const float* ref /*[B,Q,3]*/,
+                           const float* attn_logits /*[B,Q,N*L]*/,
+                           const float* pc_range /*host[6]*/, float img_h, float img_w,
+                           float* out, unsigned char* vis_mask,
+                           unsigned long long* pair_counter /*may be NULL*/,
+                           tc_stream_t stream);
+
+/* Detr3DCrossAtten.forward (XFMR:302-378), eval mode: returns
+ * output_proj(sampled) + query + position_encoder(inverse_sigmoid(ref)).
+ * query/query_pos/out are [B,Q,C] (the reference's [Q,B,C] with B folded
+ * first).  workspace: tc_cross_atten_workspace_bytes(). */
+size_t tc_cross_atten_workspace_bytes(int B, int Q, int C, int num_cams, int num_levels);
+int tc_cross_atten_fwd(const tc_linear* attention_weights, const tc_linear* output_proj,
+                       const tc_pos_encoder* position_encoder,
+                       const tc_feats_nhwc* feats, int B, int Q, int C, int num_cams,
+                       const float* query, const float* query_pos,
+                       const float* lidar2img, const float* ref,
+                       const float* pc_range /*host[6]*/, float img_h, float img_w,
+                       float* out, void* workspace, size_t workspace_bytes,
+                       tc_stream_t stream);
+
+/* mmcv MultiheadAttention wrapper as used for decoder self-attention
+ * (CFG:68-72): out = x + out_proj(MHA(q=k=x+pos, v=x)).
+ * x/pos/out [B,Q,C]. */
+size_t tc_self_attn_workspace_bytes(int B, int Q, int C);
+int tc_self_attn_fwd(const tc_mha* w, const float* x, const float* pos, float* out,
+                     int B, int Q, int C, int num_heads,
+                     void* workspace, size_t workspace_bytes, tc_stream_t stream);
+
+/* Distance-gated radar cross-attention, one fusion layer's attention step
+ * (HEAD:549-581 / :619-653 / :675-711): three-circle gate around
+ * (centre, front, rear), masked nn.MultiheadAttention of the gated queries
+ * over the radar tokens, residual add on the rows that have at least one hit.
+ *   query      [B,Q,C]   query_feat before the layer
+ *   centre_xy  [B,Q,2]   metres;  box [B,Q,code]: log-length at [3], sin/cos at [6],[7]
+ *   radar_feat [B,T,C]   encoded tokens; radar_xy [B,T,2]
+ *   pad_mult   multiplicity of the LAST token (the reference always attends
+ *              over 1500 tokens, HEAD:526; identical pad tokens beyond T are
+ *              folded into token T-1)
+ *   out        [B,Q,C] = query (+ attention output on hit rows)
+ *   hit_counts [B,Q] (may be NULL) */
+size_t tc_radar_xattn_workspace_bytes(int B, int Q, int T, int C);
+int tc_radar_gated_xattn_fwd(const tc_mha* w, const float* query, const float* centre_xy,
+                             const float* box, int code_size,
+                             const float* radar_feat, const float* radar_xy,
+                             int B, int Q, int T, int C, int num_heads, int pad_mult,
+                             float radius_min, float radius_max,
+                             float* out, int* hit_counts,
+                             void* workspace, size_t workspace_bytes, tc_stream_t stream);
+
+/* NMSFreeCoder.decode_single + get_bboxes z-shift (CODER:39-90, UTIL:26-52,
+ * HEAD:1018): sigmoid, top-`max_num` of Q*num_classes scores, gather,
+ * denormalise, centre-range mask, z -= h/2.
+ *   boxes [B,max_num,9], scores [B,max_num], labels [B,max_num] (int),
+ *   valid [B,max_num] (bytes: 1 = inside post_center_range) */
+size_t tc_box_decode_workspace_bytes(int B, int Q, int num_classes);
+int tc_box_decode_topk(const float* cls_scores /*[B,Q,num_classes]*/,
+                       const float* bbox_preds /*[B,Q,code]*/, int B, int Q,
+                       int num_classes, int code_size, int max_num,
+                       const float* post_center_range /*host[6]*/,
+                       float* boxes, float* scores, int* labels, unsigned char* valid,
+                       void* workspace, size_t workspace_bytes, tc_stream_t stream);
+
+/* ---- the whole hot path: Detr3DHead.forward (HEAD:248-740), eval mode ----
+ *   radar_tokens [B,T,36]: rows of the 36 hand-built features (HEAD:499-510),
+ *                padded with 500.0 rows (HEAD:527); T <= 1500
+ *   pad_mult     see tc_radar_gated_xattn_fwd
+ *   all_cls_scores / all_bbox_preds [3,B,Q,10] */
+size_t tc_head_workspace_bytes(const tc_head_weights* w, int B, int T);
+int tc_head_forward(const tc_head_weights* w, const tc_feats_nhwc* feats, int B,
+                    const float* lidar2img /*[B,N,4,4]*/, float img_h, float img_w,
+                    const float* radar_tokens, int T, int pad_mult,
+                    float* all_cls_scores, float* all_bbox_preds,
+                    const tc_head_aux* aux /*may be NULL*/,
+                    void* workspace, size_t workspace_bytes, tc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRANSCAR_HIP_H */

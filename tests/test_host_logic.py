@@ -1,0 +1,158 @@
+"""CPU tests of the host side: registry/config building, checkpoint contract,
+radar ingest, C-ABI surface, frame sharding (gloo, world size 2)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import transcar_amd as T
+from oracle import transcar_oracle as O
+from transcar_amd import _lib, configs, radar, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_head_builds_from_reference_config_and_loads_checkpoint_keys():
+    head = T.build_head(configs.head_cfg())
+    sd = synth.make_state_dict(seed=3)
+    assert {k: tuple(v.shape) for k, v in head.state_dict().items()} == \
+        {k: tuple(v.shape) for k, v in sd.items()}
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    # trainable set of the reference recipe (tools/train.py:238-252): everything
+    # outside transformer / cls_branches / reg_branches / query_embedding
+    frozen = ('transformer.', 'cls_branches.', 'reg_branches.', 'query_embedding.')
+    n = sum(p.numel() for k, p in head.named_parameters()
+            if not k.startswith(frozen) and k != 'code_weights')
+    assert n == 2646316
+    assert sum(p.numel() for p in head.parameters()) == 8728385 
+
+
+def test_registry_names_match_reference():
+    from transcar_amd import registry as R
+    assert 'Detr3DHead' in R.HEADS.module_dict
+    assert 'Detr3DTransformer' in R.TRANSFORMER.module_dict
+    assert 'Detr3DTransformerDecoder' in R.TRANSFORMER_LAYER_SEQUENCE.module_dict
+    assert {'Detr3DCrossAtten', 'MultiheadAttention'} <= set(R.ATTENTION.module_dict)
+    assert 'DetrTransformerDecoderLayer' in R.TRANSFORMER_LAYER.module_dict
+    assert 'NMSFreeCoder' in R.BBOX_CODERS.module_dict
+    with pytest.raises(KeyError):
+        R.HEADS.build(dict(type='NoSuchHead'))
+
+
+def test_no_cpu_fallback():
+    head = T.build_head(configs.head_cfg()).eval()
+    feats = [torch.from_numpy(f) for f in synth.make_feats('tiny')]
+    metas = synth.make_img_metas(1, radar=synth.make_radar_frame())
+    with pytest.raises(T.TransCARHipError):
+        head(feats, metas)
+    with pytest.raises(T.TransCARHipError):
+        T.ops.linear(torch.zeros(4, 256), torch.zeros(8, 256), torch.zeros(8))
+
+
+def test_radar_ingest_matches_reference_fixture(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g5_head_tiny.npz'))
+    frame = synth.make_radar_frame(seed=2, n_per_radar=51, centres=g['radar_centres'])
+    f36 = radar.build_radar_features(frame)
+    assert f36.shape == (int(g['fill_in']), 36)
+    np.testing.assert_allclose(f36.astype(np.float32), g['radar_tokens'], atol=1e-6, rtol=1e-6)
+    # and equals the oracle's independent restatement bit for bit
+    assert np.array_equal(f36, O.build_radar_features(frame))
+    g4 = np.load(os.path.join(golden_dir, 'g4_radar_ragged.npz'))
+    f = radar.build_radar_features(synth.make_radar_frame(seed=5, n_per_radar=[7, 0, 3, 0, 12]))
+    np.testing.assert_allclose(f.astype(np.float32), g4['radar_tokens'], atol=1e-6, rtol=1e-6)
+
+
+def test_pack_tokens_padding_and_multiplicity():
+    f = [np.ones((255, 36)), np.ones((10, 36)) * 2, np.zeros((0, 36))]
+    tok, pad_mult = radar.pack_tokens(f)
+    assert tok.shape == (3, 256, 36) and pad_mult == 1500 - 256 + 1
+    assert (tok[0, :255] == 1).all() and (tok[0, 255] == 500).all()
+    assert (tok[1, 10:] == 500).all() and (tok[2] == 500).all()
+    big = [np.ones((1700, 36))]
+    tok, pad_mult = radar.pack_tokens(big)                 # HEAD:528: min(1500, n)
+    assert tok.shape == (1, 1500, 36) and pad_mult == 1
+    # every sample keeps 1500 - n_i pad tokens in total
+    for b, n in enumerate((255, 10, 0)):
+        pads_in_T = 256 - n
+        assert pads_in_T - 1 + (1500 - 256 + 1) == 1500 - n
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, 'include', 'transcar_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(tc_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    names = _header_functions()
+    assert len(names) >= 15
+    dll = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(dll, n), 'library does not export %s' % n
+    assert sorted(_lib.SIGNATURES) == names          # binding covers the header
+    lib = T.lib()
+    assert lib.tc_abi_version() == _lib.TC_ABI_VERSION
+    # struct layouts: sizes the C side and the ctypes mirror must agree on are
+    # checked through the workspace query (a wrong layout gives a wrong answer)
+    assert ctypes.sizeof(_lib.tc_decoder_layer) == 8 * (4 + 2 + 2 + 2 + 8 + 2 + 2 + 2 + 2 + 6)
+
+
+def test_workspace_query_runs_without_gpu():
+    head = T.build_head(configs.head_cfg())
+    w = _lib.tc_head_weights()
+    w.abi_version = _lib.TC_ABI_VERSION
+    w.num_query, w.embed_dims, w.num_heads, w.ffn_dims = 900, 256, 8, 512
+    w.num_layers, w.num_cams, w.num_levels = 6, 6, 4
+    w.num_classes, w.code_size, w.radar_in_dims, w.num_radar_layers = 10, 10, 36, 3
+    n1 = T.lib().tc_head_workspace_bytes(ctypes.byref(w), 1, 256)
+    n2 = T.lib().tc_head_workspace_bytes(ctypes.byref(w), 2, 256)
+    assert 10e6 < n1 < 64e6 and 1.9 * n1 < n2 < 2.1 * n1
+    w.embed_dims = 128                                   # unsupported -> 0 + message
+    assert T.lib().tc_head_workspace_bytes(ctypes.byref(w), 1, 256) == 0
+    assert b'embed_dims' in T.lib().tc_last_error()
+
+
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, %r)
+import torch.distributed as dist
+from transcar_amd import dist as D
+rank, world = D.init_process_group('gloo')
+mine = D.shard_frames(7, rank, world)
+res = {i: ('frame%%d' %% i, rank) for i in mine}
+allr = D.gather_results(res, 7)
+assert [a[0] for a in allr] == ['frame%%d' %% i for i in range(7)]
+assert [a[1] for a in allr] == [i %% world for i in range(7)]
+assert D.max_over_ranks(1.0 + rank) == float(world)
+D.barrier()
+dist.destroy_process_group()
+print('ok', rank)
+'''
+
+
+def test_frame_sharding_gloo_world2(tmp_path):
+    script = tmp_path / 'w.py'
+    script.write_text(_WORKER % ROOT)
+    port = 29500 + os.getpid() % 2000
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=120)
+        assert p.returncode == 0, out.decode()
+        assert b'ok' in out
+
+
+def test_shard_frames_partition():
+    from transcar_amd import dist as D
+    for world in (1, 2, 4, 8):
+        seen = sorted(i for r in range(world) for i in D.shard_frames(37, r, world))
+        assert seen == list(range(37))

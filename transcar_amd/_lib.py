@@ -1,0 +1,166 @@
+"""ctypes binding of the C ABI in include/transcar_hip.h.
+
+The HIP library is the product; there is no CPU fallback.  ``lib()`` raises
+``TransCARHipError`` if ``transcar_amd/lib/libtranscar_hip.so`` is missing
+(build it with ``python -c 'import __graft_entry__ as g; g.build()'`` or
+``make -C transcar_amd/csrc``), and every call checks the returned status.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libtranscar_hip.so')
+
+TC_MAX_LEVELS = 4
+TC_MAX_LAYERS = 8
+TC_MAX_RADAR_LAYERS = 3
+TC_ABI_VERSION = 1
+
+c_fp = C.c_void_p      # device pointers travel as integers
+
+
+class TransCARHipError(RuntimeError):
+    pass
+
+
+class tc_linear(C.Structure):
+    _fields_ = [('w', c_fp), ('b', c_fp)]
+
+
+class tc_lnorm(C.Structure):
+    _fields_ = [('g', c_fp), ('b', c_fp)]
+
+
+class tc_pos_encoder(C.Structure):
+    _fields_ = [('l0', tc_linear), ('n1', tc_lnorm), ('l3', tc_linear),
+                ('n4', tc_lnorm)]
+
+
+class tc_cls_branch(C.Structure):
+    _fields_ = [('l0', tc_linear), ('n1', tc_lnorm), ('l3', tc_linear),
+                ('n4', tc_lnorm), ('l6', tc_linear)]
+
+
+class tc_reg_branch(C.Structure):
+    _fields_ = [('l0', tc_linear), ('l2', tc_linear), ('l4', tc_linear)]
+
+
+class tc_mha(C.Structure):
+    _fields_ = [('in_proj', tc_linear), ('out_proj', tc_linear)]
+
+
+class tc_decoder_layer(C.Structure):
+    _fields_ = [('self_attn', tc_mha), ('norm0', tc_lnorm),
+                ('attention_weights', tc_linear), ('output_proj', tc_linear),
+                ('position_encoder', tc_pos_encoder), ('norm1', tc_lnorm),
+                ('ffn0', tc_linear), ('ffn1', tc_linear), ('norm2', tc_lnorm),
+                ('reg', tc_reg_branch)]
+
+
+class tc_radar_layer(C.Structure):
+    _fields_ = [('attn', tc_mha), ('norm2', tc_lnorm), ('linear1', tc_linear),
+                ('linear2', tc_linear), ('norm3', tc_lnorm),
+                ('final_cls', tc_cls_branch), ('final_reg', tc_reg_branch),
+                ('radius_min', C.c_float), ('radius_max', C.c_float)]
+
+
+class tc_head_weights(C.Structure):
+    _fields_ = [('abi_version', C.c_int),
+                ('num_query', C.c_int), ('embed_dims', C.c_int),
+                ('num_heads', C.c_int), ('ffn_dims', C.c_int),
+                ('num_layers', C.c_int),
+                ('num_cams', C.c_int), ('num_levels', C.c_int),
+                ('num_classes', C.c_int), ('code_size', C.c_int),
+                ('radar_in_dims', C.c_int), ('num_radar_layers', C.c_int),
+                ('num_radar_tokens_ref', C.c_int),
+                ('pc_range', C.c_float * 6),
+                ('query_embedding', c_fp),
+                ('reference_points', tc_linear),
+                ('layers', tc_decoder_layer * TC_MAX_LAYERS),
+                ('radar_position_encoder', tc_pos_encoder),
+                ('radar_feat0', tc_linear), ('radar_feat2', tc_linear),
+                ('radar_feat4', tc_linear),
+                ('radar', tc_radar_layer * TC_MAX_RADAR_LAYERS)]
+
+
+class tc_feats_nhwc(C.Structure):
+    _fields_ = [('num_levels', C.c_int),
+                ('data', c_fp * TC_MAX_LEVELS),
+                ('H', C.c_int * TC_MAX_LEVELS),
+                ('W', C.c_int * TC_MAX_LEVELS)]
+
+
+class tc_head_aux(C.Structure):
+    _fields_ = [('inter_states', c_fp), ('init_reference', c_fp),
+                ('inter_references', c_fp), ('radar_hit_counts', c_fp),
+                ('sample_pairs', c_fp)]
+
+
+_P = C.POINTER
+_i, _f, _sz, _vp = C.c_int, C.c_float, C.c_size_t, C.c_void_p
+
+#: name -> (restype, argtypes); mirrors include/transcar_hip.h one to one
+SIGNATURES = {
+    'tc_abi_version': (_i, []),
+    'tc_last_error': (C.c_char_p, []),
+    'tc_device_count': (_i, []),
+    'tc_nchw_to_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'tc_linear_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'tc_add_layernorm_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'tc_refine_reference_fwd': (_i, [_vp, _i, _vp, _vp, _i, _vp]),
+    'tc_cam_sample_fuse_fwd': (_i, [_P(tc_feats_nhwc), _i, _i, _i, _i, _vp,
+                                    _vp, _vp, _P(_f), _f, _f, _vp, _vp, _vp,
+                                    _vp]),
+    'tc_cross_atten_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
+    'tc_cross_atten_fwd': (_i, [_P(tc_linear), _P(tc_linear),
+                                _P(tc_pos_encoder), _P(tc_feats_nhwc), _i, _i,
+                                _i, _i, _vp, _vp, _vp, _vp, _P(_f), _f, _f,
+                                _vp, _vp, _sz, _vp]),
+    'tc_self_attn_workspace_bytes': (_sz, [_i, _i, _i]),
+    'tc_self_attn_fwd': (_i, [_P(tc_mha), _vp, _vp, _vp, _i, _i, _i, _i, _vp,
+                              _sz, _vp]),
+    'tc_radar_xattn_workspace_bytes': (_sz, [_i, _i, _i, _i]),
+    'tc_radar_gated_xattn_fwd': (_i, [_P(tc_mha), _vp, _vp, _vp, _i, _vp, _vp,
+                                      _i, _i, _i, _i, _i, _i, _f, _f, _vp,
+                                      _vp, _vp, _sz, _vp]),
+    'tc_box_decode_workspace_bytes': (_sz, [_i, _i, _i]),
+    'tc_box_decode_topk': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _P(_f), _vp,
+                                _vp, _vp, _vp, _vp, _sz, _vp]),
+    'tc_head_workspace_bytes': (_sz, [_P(tc_head_weights), _i, _i]),
+    'tc_head_forward': (_i, [_P(tc_head_weights), _P(tc_feats_nhwc), _i, _vp,
+                             _f, _f, _vp, _i, _i, _vp, _vp, _P(tc_head_aux),
+                             _vp, _sz, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library (cached).  Fails loudly when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise TransCARHipError(
+                'HIP library not built: %s is missing.  transcar_amd has no '
+                'CPU fallback; run __graft_entry__.build() or '
+                '`make -C transcar_amd/csrc`.' % LIB_PATH)
+        dll = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(dll, name)        # AttributeError if a symbol is gone
+            fn.restype = res
+            fn.argtypes = args
+        if dll.tc_abi_version() != TC_ABI_VERSION:
+            raise TransCARHipError('ABI mismatch: library %d, binding %d' % (
+                dll.tc_abi_version(), TC_ABI_VERSION))
+        _lib = dll
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().tc_last_error().decode('utf-8', 'replace')
+        raise TransCARHipError('%s failed (status %d): %s' % (what, rc, msg))
+
+
+def f6(values):
+    return (C.c_float * 6)(*[float(v) for v in values])

@@ -1,0 +1,447 @@
+// C ABI (include/transcar_hip.h) and the launch sequence of the whole hot path:
+// Detr3DHead.forward of the reference (HEAD:248-740) in eval mode = 6 decoder
+// layers (self-attn, camera cross-attn, FFN, box refinement) + radar encoders +
+// 3 distance-gated radar fusion layers.  Every function only enqueues kernels
+// on the caller's stream; all scratch comes from the caller's workspace, so a
+// forward is capturable into a hipGraph and replayable.
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include "kernels.hpp"
+
+namespace tc {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+#define TC_TRY(expr)          \
+  do {                        \
+    int _rc = (expr);         \
+    if (_rc != 0) return _rc; \
+  } while (0)
+
+#define TC_HIP(expr)                                          \
+  do {                                                        \
+    hipError_t _e = (expr);                                   \
+    if (_e != hipSuccess) {                                   \
+      tc::set_error("%s: %s", #expr, hipGetErrorString(_e)); \
+      return (int)_e;                                         \
+    }                                                         \
+  } while (0)
+
+static int linear(const float* x, int ldx, const tc_linear& w, int M, int K, int N, int act,
+                  float* y, int ldy, hipStream_t s, const float* x2 = nullptr,
+                  const float* res = nullptr, int ldr = 0, const int* rowgate = nullptr) {
+  GemmArgs g;
+  g.X = x; g.ldx = ldx; g.X2 = x2; g.x2_cols = x2 ? ((N + 15) / 16) * 16 : 0;
+  g.W = w.w; g.ldw = K; g.bias = w.b; g.R = res; g.ldr = ldr; g.rowgate = rowgate;
+  g.Y = y; g.ldy = ldy; g.M = M; g.K = K; g.N = N; g.act = act;
+  return launch_gemm(g, s);
+}
+
+static int layernorm(const float* a, const tc_lnorm& n, float* y, int M, int relu, hipStream_t s) {
+  LnArgs l;
+  l.a = a; l.gamma = n.g; l.beta = n.b; l.y = y; l.M = M; l.relu = relu;
+  return launch_ln256(l, s);
+}
+
+// mmcv MultiheadAttention wrapper for decoder self-attention:
+// out = x + out_proj(MHA(q = k = x + pos, v = x))
+static int self_attn(const tc_mha& w, const float* x, const float* pos, float* out, int B, int Q,
+                     int C, int H, float* qk, float* vt, int qpad, float* attn_o, hipStream_t s) {
+  const int rows = B * Q;
+  GemmArgs g;
+  g.X = x; g.ldx = C; g.X2 = pos; g.x2_cols = 2 * C;
+  g.W = w.in_proj.w; g.ldw = C; g.bias = w.in_proj.b;
+  g.Y = qk; g.ldy = 2 * C;
+  g.Yt = vt; g.t_col0 = 2 * C; g.t_ld = qpad; g.t_rows_per_batch = Q;
+  g.M = rows; g.K = C; g.N = 3 * C;
+  g.scale = 1.0f / sqrtf((float)(C / H)); g.scale_cols = C;
+  TC_TRY(launch_gemm(g, s));
+  TC_TRY(launch_self_attn_core(qk, qk + C, 2 * C, vt, qpad, attn_o, C, B, Q, H, s));
+  return linear(attn_o, C, w.out_proj, rows, C, C, 0, out, C, s, nullptr, x, C);
+}
+
+struct CrossWs { float *logits, *sampled, *t0, *pe0, *pe1; };
+
+// Detr3DCrossAtten.forward; returns the pieces the caller fuses with the next
+// LayerNorm: t0 = output_proj(sampled) + query, pe1 = position_encoder.3(...)
+static int cross_atten_parts(const tc_linear& aw, const tc_linear& oproj, const tc_pos_encoder& pe,
+                             const tc_feats_nhwc* feats, int B, int Q, int C, int ncams,
+                             const float* query, const float* pos, const float* l2i,
+                             const float* ref, const float* pc, float img_h, float img_w,
+                             const CrossWs& ws, unsigned long long* pair_counter, hipStream_t s) {
+  const int rows = B * Q;
+  const int NL = ncams * feats->num_levels;
+  TC_TRY(linear(query, C, aw, rows, C, NL, 0, ws.logits, NL, s, pos));
+  CamSampleArgs c;
+  c.feats = *feats; c.B = B; c.Q = Q; c.C = C; c.num_cams = ncams;
+  c.lidar2img = l2i; c.ref = ref; c.logits = ws.logits;
+  for (int i = 0; i < 6; ++i) c.pc[i] = pc[i];
+  c.img_h = img_h; c.img_w = img_w; c.out = ws.sampled; c.vis = nullptr; c.pair_counter = pair_counter;
+  TC_TRY(launch_cam_sample(c, s));
+  TC_TRY(linear(ws.sampled, C, oproj, rows, C, C, 0, ws.t0, C, s, nullptr, query, C));
+  TC_TRY(launch_posenc_l1(ref, 3, 1, pe.l0.w, pe.l0.b, pe.n1.g, pe.n1.b, ws.pe0, rows, s));
+  return linear(ws.pe0, C, pe.l3, rows, C, C, 0, ws.pe1, C, s);
+}
+
+static int check_dims(const tc_head_weights* w) {
+  TC_REQUIRE(w != nullptr, "weights pointer is null");
+  TC_REQUIRE(w->abi_version == TC_ABI_VERSION, "tc_head_weights.abi_version=%d, library=%d",
+             w->abi_version, TC_ABI_VERSION);
+  TC_REQUIRE(w->embed_dims == 256 && w->num_heads == 8, "embed_dims=%d num_heads=%d (256/8 supported)",
+             w->embed_dims, w->num_heads);
+  TC_REQUIRE(w->num_layers >= 1 && w->num_layers <= TC_MAX_LAYERS, "num_layers=%d", w->num_layers);
+  TC_REQUIRE(w->num_radar_layers >= 0 && w->num_radar_layers <= TC_MAX_RADAR_LAYERS,
+             "num_radar_layers=%d", w->num_radar_layers);
+  TC_REQUIRE(w->num_levels == 4, "num_levels=%d (4 supported)", w->num_levels);
+  TC_REQUIRE((w->ffn_dims & 31) == 0 && (w->radar_in_dims & 3) == 0, "ffn_dims/radar_in_dims alignment");
+  TC_REQUIRE((w->num_query & 3) == 0, "num_query=%d must be a multiple of 4", w->num_query);
+  return 0;
+}
+
+struct HeadWs {
+  float *pos, *x, *qk, *vt, *attn_o, *t0, *t1, *t2, *ffn_h, *logits, *sampled;
+  float *init_ref, *inter_refs, *hs, *reg_tmp, *box_m;
+  float *tp0, *tp1, *f0, *f1, *f2, *radar_feat, *kv, *qproj, *rattn, *cxy, *addref, *qf;
+  int* hits;
+  int qpad;
+};
+
+static size_t head_ws_layout(const tc_head_weights* w, int B, int T, void* base, size_t cap,
+                             HeadWs* out) {
+  const int Q = w->num_query, C = w->embed_dims, F = w->ffn_dims, L = w->num_layers;
+  const size_t rows = (size_t)B * Q, rt = (size_t)B * T;
+  const int qpad = ((Q + 15) / 16) * 16;
+  Arena a(base, cap);
+  HeadWs h;
+  h.qpad = qpad;
+  h.pos = a.take<float>(rows * C); h.x = a.take<float>(rows * C);
+  h.qk = a.take<float>(rows * 2 * C); h.vt = a.take<float>((size_t)B * C * qpad);
+  h.attn_o = a.take<float>(rows * C);
+  h.t0 = a.take<float>(rows * C); h.t1 = a.take<float>(rows * C); h.t2 = a.take<float>(rows * C);
+  h.ffn_h = a.take<float>(rows * F);
+  h.logits = a.take<float>(rows * w->num_cams * w->num_levels);
+  h.sampled = a.take<float>(rows * C);
+  h.init_ref = a.take<float>(rows * 3); h.inter_refs = a.take<float>((size_t)L * rows * 3);
+  h.hs = a.take<float>((size_t)L * rows * C);
+  h.reg_tmp = a.take<float>(rows * w->code_size); h.box_m = a.take<float>(rows * w->code_size);
+  h.tp0 = a.take<float>(rt * C); h.tp1 = a.take<float>(rt * C);
+  h.f0 = a.take<float>(rt * 64); h.f1 = a.take<float>(rt * 128); h.f2 = a.take<float>(rt * C);
+  h.radar_feat = a.take<float>(rt * C); h.kv = a.take<float>(rt * 2 * C);
+  h.qproj = a.take<float>(rows * C); h.rattn = a.take<float>(rows * C);
+  h.cxy = a.take<float>(rows * 2); h.addref = a.take<float>(rows * 3);
+  h.qf = a.take<float>(rows * C);
+  h.hits = a.take<int>((size_t)TC_MAX_RADAR_LAYERS * rows);
+  if (out) *out = h;
+  return a.off;
+}
+
+}  // namespace tc
+
+using namespace tc;
+
+extern "C" {
+
+int tc_abi_version(void) { return TC_ABI_VERSION; }
+const char* tc_last_error(void) { return g_err; }
+
+int tc_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+
+int tc_nchw_to_nhwc(const float* src, float* dst, int n_img, int C, int H, int W, tc_stream_t stream) {
+  return launch_nchw_to_nhwc(src, dst, n_img, C, H, W, as_stream(stream));
+}
+
+int tc_linear_fwd(const float* x, const float* x2, const float* w, const float* b, const float* res,
+                  float* y, int M, int K, int N, int act, tc_stream_t stream) {
+  tc_linear lw{w, b};
+  return linear(x, K, lw, M, K, N, act, y, N, as_stream(stream), x2, res, N);
+}
+
+int tc_add_layernorm_fwd(const float* a, const float* b, const float* gamma, const float* beta,
+                         float* y, int M, int C, int relu, tc_stream_t stream) {
+  TC_REQUIRE(C == 256, "add_layernorm: C=%d (256 supported)", C);
+  LnArgs l;
+  l.a = a; l.b = b; l.gamma = gamma; l.beta = beta; l.y = y; l.M = M; l.relu = relu;
+  return launch_ln256(l, as_stream(stream));
+}
+
+int tc_refine_reference_fwd(const float* reg_out, int code_size, const float* ref, float* new_ref,
+                            int M, tc_stream_t stream) {
+  TC_REQUIRE(code_size >= 5, "refine_reference: code_size=%d", code_size);
+  const float pc0[6] = {0, 0, 0, 1, 1, 1};
+  return launch_ref_update(reg_out, code_size, ref, new_ref, nullptr, pc0, M, as_stream(stream));
+}
+
+int tc_cam_sample_fuse_fwd(const tc_feats_nhwc* feats, int B, int Q, int C, int num_cams,
+                           const float* lidar2img, const float* ref, const float* attn_logits,
+                           const float* pc_range, float img_h, float img_w, float* out,
+                           unsigned char* vis_mask, unsigned long long* pair_counter,
+                           tc_stream_t stream) {
+  TC_REQUIRE(feats != nullptr, "feats is null");
+  CamSampleArgs c;
+  c.feats = *feats; c.B = B; c.Q = Q; c.C = C; c.num_cams = num_cams;
+  c.lidar2img = lidar2img; c.ref = ref; c.logits = attn_logits;
+  for (int i = 0; i < 6; ++i) c.pc[i] = pc_range[i];
+  c.img_h = img_h; c.img_w = img_w; c.out = out; c.vis = vis_mask; c.pair_counter = pair_counter;
+  return launch_cam_sample(c, as_stream(stream));
+}
+
+size_t tc_cross_atten_workspace_bytes(int B, int Q, int C, int num_cams, int num_levels) {
+  const size_t rows = (size_t)B * Q;
+  return arena_slice(rows * num_cams * num_levels, 4) + 4 * arena_slice(rows * C, 4);
+}
+
+int tc_cross_atten_fwd(const tc_linear* attention_weights, const tc_linear* output_proj,
+                       const tc_pos_encoder* position_encoder, const tc_feats_nhwc* feats, int B,
+                       int Q, int C, int num_cams, const float* query, const float* query_pos,
+                       const float* lidar2img, const float* ref, const float* pc_range, float img_h,
+                       float img_w, float* out, void* workspace, size_t workspace_bytes,
+                       tc_stream_t stream) {
+  TC_REQUIRE(C == 256, "cross_atten: C=%d (256 supported)", C);
+  TC_REQUIRE(workspace_bytes >= tc_cross_atten_workspace_bytes(B, Q, C, num_cams, feats->num_levels),
+             "cross_atten: workspace too small");
+  const size_t rows = (size_t)B * Q;
+  Arena a(workspace, workspace_bytes);
+  CrossWs ws;
+  ws.logits = a.take<float>(rows * num_cams * feats->num_levels);
+  ws.sampled = a.take<float>(rows * C); ws.t0 = a.take<float>(rows * C);
+  ws.pe0 = a.take<float>(rows * C); ws.pe1 = a.take<float>(rows * C);
+  hipStream_t s = as_stream(stream);
+  TC_TRY(cross_atten_parts(*attention_weights, *output_proj, *position_encoder, feats, B, Q, C,
+                           num_cams, query, query_pos, lidar2img, ref, pc_range, img_h, img_w, ws,
+                           nullptr, s));
+  // XFMR:378: output + inp_residual + relu(LN(position_encoder.3(.)))
+  LnArgs l;
+  l.a = ws.t0; l.c = ws.pe1; l.g2 = position_encoder->n4.g; l.b2 = position_encoder->n4.b;
+  l.y = out; l.M = (int)rows;
+  return launch_ln256(l, s);
+}
+
+size_t tc_self_attn_workspace_bytes(int B, int Q, int C) {
+  const size_t rows = (size_t)B * Q;
+  const size_t qpad = ((Q + 15) / 16) * 16;
+  return arena_slice(rows * 2 * C, 4) + arena_slice((size_t)B * C * qpad, 4) + arena_slice(rows * C, 4);
+}
+
+int tc_self_attn_fwd(const tc_mha* w, const float* x, const float* pos, float* out, int B, int Q,
+                     int C, int num_heads, void* workspace, size_t workspace_bytes,
+                     tc_stream_t stream) {
+  TC_REQUIRE(C == 256 && num_heads == 8, "self_attn: C=%d heads=%d (256/8 supported)", C, num_heads);
+  TC_REQUIRE(workspace_bytes >= tc_self_attn_workspace_bytes(B, Q, C), "self_attn: workspace too small");
+  const size_t rows = (size_t)B * Q;
+  const int qpad = ((Q + 15) / 16) * 16;
+  Arena a(workspace, workspace_bytes);
+  float* qk = a.take<float>(rows * 2 * C);
+  float* vt = a.take<float>((size_t)B * C * qpad);
+  float* ao = a.take<float>(rows * C);
+  return self_attn(*w, x, pos, out, B, Q, C, num_heads, qk, vt, qpad, ao, as_stream(stream));
+}
+
+size_t tc_radar_xattn_workspace_bytes(int B, int Q, int T, int C) {
+  return arena_slice((size_t)B * T * 2 * C, 4) + 2 * arena_slice((size_t)B * Q * C, 4) +
+         arena_slice((size_t)B * Q, 4);
+}
+
+int tc_radar_gated_xattn_fwd(const tc_mha* w, const float* query, const float* centre_xy,
+                             const float* box, int code_size, const float* radar_feat,
+                             const float* radar_xy, int B, int Q, int T, int C, int num_heads,
+                             int pad_mult, float radius_min, float radius_max, float* out,
+                             int* hit_counts, void* workspace, size_t workspace_bytes,
+                             tc_stream_t stream) {
+  TC_REQUIRE(C == 256 && num_heads == 8, "radar_xattn: C=%d heads=%d (256/8 supported)", C, num_heads);
+  TC_REQUIRE(workspace_bytes >= tc_radar_xattn_workspace_bytes(B, Q, T, C), "radar_xattn: workspace too small");
+  hipStream_t s = as_stream(stream);
+  const int rows = B * Q, rt = B * T;
+  Arena a(workspace, workspace_bytes);
+  float* kv = a.take<float>((size_t)rt * 2 * C);
+  float* qproj = a.take<float>((size_t)rows * C);
+  float* rattn = a.take<float>((size_t)rows * C);
+  int* hits = hit_counts ? hit_counts : a.take<int>(rows);
+  tc_linear wkv{w->in_proj.w + (size_t)C * C, w->in_proj.b + C};
+  TC_TRY(linear(radar_feat, C, wkv, rt, C, 2 * C, 0, kv, 2 * C, s));
+  GemmArgs g;
+  g.X = query; g.ldx = C; g.W = w->in_proj.w; g.ldw = C; g.bias = w->in_proj.b;
+  g.Y = qproj; g.ldy = C; g.M = rows; g.K = C; g.N = C;
+  g.scale = 1.0f / sqrtf((float)(C / num_heads)); g.scale_cols = C;
+  TC_TRY(launch_gemm(g, s));
+  RadarAttnArgs r;
+  r.qproj = qproj; r.ldq = C; r.kv = kv; r.ldkv = 2 * C; r.centre_xy = centre_xy; r.ld_c = 2;
+  r.box = box; r.code = code_size; r.radar_xy = radar_xy; r.ld_xy = 2;
+  r.B = B; r.Q = Q; r.T = T; r.C = C; r.H = num_heads; r.pad_mult = pad_mult;
+  r.rmin = radius_min; r.rmax = radius_max; r.attn_out = rattn; r.hit_counts = hits;
+  TC_TRY(launch_radar_attn(r, s));
+  return linear(rattn, C, w->out_proj, rows, C, C, 0, out, C, s, nullptr, query, C, hits);
+}
+
+size_t tc_box_decode_workspace_bytes(int B, int Q, int num_classes) {
+  return box_decode_ws_bytes(B, Q, num_classes);
+}
+
+int tc_box_decode_topk(const float* cls_scores, const float* bbox_preds, int B, int Q,
+                       int num_classes, int code_size, int max_num, const float* post_center_range,
+                       float* boxes, float* scores, int* labels, unsigned char* valid,
+                       void* workspace, size_t workspace_bytes, tc_stream_t stream) {
+  return launch_box_decode(cls_scores, bbox_preds, B, Q, num_classes, code_size, max_num,
+                           post_center_range, boxes, scores, labels, valid, workspace,
+                           workspace_bytes, as_stream(stream));
+}
+
+size_t tc_head_workspace_bytes(const tc_head_weights* w, int B, int T) {
+  if (check_dims(w) != 0) return 0;
+  return head_ws_layout(w, B, T, nullptr, ~size_t(0), nullptr);
+}
+
+int tc_head_forward(const tc_head_weights* w, const tc_feats_nhwc* feats, int B,
+                    const float* lidar2img, float img_h, float img_w, const float* radar_tokens,
+                    int T, int pad_mult, float* all_cls_scores, float* all_bbox_preds,
+                    const tc_head_aux* aux, void* workspace, size_t workspace_bytes,
+                    tc_stream_t stream) {
+  TC_TRY(check_dims(w));
+  TC_REQUIRE(feats != nullptr && feats->num_levels == w->num_levels, "feats: num_levels mismatch");
+  TC_REQUIRE(B >= 1, "B=%d", B);
+  TC_REQUIRE(w->num_radar_layers == 0 || (radar_tokens != nullptr && T >= 1 && pad_mult >= 1),
+             "radar tokens missing (T=%d pad_mult=%d)", T, pad_mult);
+  HeadWs h;
+  const size_t need = head_ws_layout(w, B, T, workspace, workspace_bytes, &h);
+  TC_REQUIRE(need <= workspace_bytes, "workspace too small: need %zu, have %zu", need, workspace_bytes);
+  hipStream_t s = as_stream(stream);
+  const int Q = w->num_query, C = w->embed_dims, F = w->ffn_dims, L = w->num_layers, H = w->num_heads;
+  const int code = w->code_size, ncls = w->num_classes;
+  const int rows = B * Q, rt = B * T;
+  const float* pc = w->pc_range;
+  unsigned long long* pairs = aux ? aux->sample_pairs : nullptr;
+
+  // XFMR:119-123
+  TC_TRY(launch_split_embed(w->query_embedding, Q, C, B, h.pos, h.x, s));
+  TC_TRY(launch_init_ref(w->query_embedding, Q, C, w->reference_points.w, w->reference_points.b,
+                         h.init_ref, B, s));
+  const float* x = h.x;
+  for (int lid = 0; lid < L; ++lid) {
+    const tc_decoder_layer& ly = w->layers[lid];
+    const float* ref_in = lid == 0 ? h.init_ref : h.inter_refs + (size_t)(lid - 1) * rows * 3;
+    float* ref_out = h.inter_refs + (size_t)lid * rows * 3;
+    float* hs_l = h.hs + (size_t)lid * rows * C;
+    // self_attn, norm
+    TC_TRY(self_attn(ly.self_attn, x, h.pos, h.t0, B, Q, C, H, h.qk, h.vt, h.qpad, h.attn_o, s));
+    TC_TRY(layernorm(h.t0, ly.norm0, h.t1, rows, 0, s));
+    // cross_attn, norm   (XFMR:346-378)
+    CrossWs cw{h.logits, h.sampled, h.t0, h.t2, h.attn_o};
+    TC_TRY(cross_atten_parts(ly.attention_weights, ly.output_proj, ly.position_encoder, feats, B, Q,
+                             C, w->num_cams, h.t1, h.pos, lidar2img, ref_in, pc, img_h, img_w, cw,
+                             pairs, s));
+    {
+      LnArgs l;
+      l.a = h.t0; l.c = h.attn_o; l.g2 = ly.position_encoder.n4.g; l.b2 = ly.position_encoder.n4.b;
+      l.gamma = ly.norm1.g; l.beta = ly.norm1.b; l.y = h.t1; l.M = rows;
+      TC_TRY(launch_ln256(l, s));
+    }
+    // ffn, norm
+    TC_TRY(linear(h.t1, C, ly.ffn0, rows, C, F, 1, h.ffn_h, F, s));
+    TC_TRY(linear(h.ffn_h, F, ly.ffn1, rows, F, C, 0, h.t0, C, s, nullptr, h.t1, C));
+    TC_TRY(layernorm(h.t0, ly.norm2, hs_l, rows, 0, s));
+    x = hs_l;
+    // XFMR:190-203 box refinement of the reference points
+    TC_TRY(linear(hs_l, C, ly.reg.l0, rows, C, C, 1, h.t0, C, s));
+    TC_TRY(linear(h.t0, C, ly.reg.l2, rows, C, C, 1, h.t2, C, s));
+    TC_TRY(linear(h.t2, C, ly.reg.l4, rows, C, code, 0, h.reg_tmp, code, s));
+    TC_TRY(launch_ref_update(h.reg_tmp, code, ref_in, ref_out, lid == L - 1 ? h.box_m : nullptr, pc,
+                             rows, s));
+  }
+  if (aux) {
+    if (aux->inter_states)
+      TC_HIP(hipMemcpyAsync(aux->inter_states, h.hs, (size_t)L * rows * C * 4, hipMemcpyDeviceToDevice, s));
+    if (aux->init_reference)
+      TC_HIP(hipMemcpyAsync(aux->init_reference, h.init_ref, (size_t)rows * 3 * 4, hipMemcpyDeviceToDevice, s));
+    if (aux->inter_references)
+      TC_HIP(hipMemcpyAsync(aux->inter_references, h.inter_refs, (size_t)L * rows * 3 * 4,
+                            hipMemcpyDeviceToDevice, s));
+  }
+  if (w->num_radar_layers == 0) return 0;
+
+  // radar encoders, HEAD:531-536
+  const int RI = w->radar_in_dims;
+  const tc_pos_encoder& rpe = w->radar_position_encoder;
+  TC_TRY(launch_posenc_l1(radar_tokens, RI, 0, rpe.l0.w, rpe.l0.b, rpe.n1.g, rpe.n1.b, h.tp0, rt, s));
+  TC_TRY(linear(h.tp0, C, rpe.l3, rt, C, C, 0, h.tp1, C, s));
+  TC_TRY(linear(radar_tokens, RI, w->radar_feat0, rt, RI, 64, 1, h.f0, 64, s));
+  TC_TRY(linear(h.f0, 64, w->radar_feat2, rt, 64, 128, 1, h.f1, 128, s));
+  TC_TRY(linear(h.f1, 128, w->radar_feat4, rt, 128, C, 1, h.f2, C, s));
+  {
+    LnArgs l;
+    l.a = h.tp1; l.gamma = rpe.n4.g; l.beta = rpe.n4.b; l.relu = 1; l.d = h.f2; l.y = h.radar_feat;
+    l.M = rt;
+    TC_TRY(launch_ln256(l, s));
+  }
+  // HEAD:543-547, 596-598
+  TC_TRY(launch_radar_ref_l1(h.inter_refs + (size_t)(L - 1) * rows * 3, pc, h.cxy, h.addref, rows, s));
+  const float* qf = h.hs + (size_t)(L - 1) * rows * C;
+  const float qscale = 1.0f / sqrtf((float)(C / H));
+  for (int r = 0; r < w->num_radar_layers; ++r) {
+    const tc_radar_layer& rl = w->radar[r];
+    float* cls_out = all_cls_scores + (size_t)r * rows * ncls;
+    float* box_out = all_bbox_preds + (size_t)r * rows * code;
+    const float* box_prev = r == 0 ? h.box_m : all_bbox_preds + (size_t)(r - 1) * rows * code;
+    int* hits = h.hits + (size_t)r * rows;
+    tc_linear wkv{rl.attn.in_proj.w + (size_t)C * C, rl.attn.in_proj.b + C};
+    TC_TRY(linear(h.radar_feat, C, wkv, rt, C, 2 * C, 0, h.kv, 2 * C, s));
+    GemmArgs g;
+    g.X = qf; g.ldx = C; g.W = rl.attn.in_proj.w; g.ldw = C; g.bias = rl.attn.in_proj.b;
+    g.Y = h.qproj; g.ldy = C; g.M = rows; g.K = C; g.N = C; g.scale = qscale; g.scale_cols = C;
+    TC_TRY(launch_gemm(g, s));
+    RadarAttnArgs ra;
+    ra.qproj = h.qproj; ra.ldq = C; ra.kv = h.kv; ra.ldkv = 2 * C;
+    ra.centre_xy = r == 0 ? h.cxy : box_prev; ra.ld_c = r == 0 ? 2 : code;
+    ra.box = box_prev; ra.code = code; ra.radar_xy = radar_tokens; ra.ld_xy = RI;
+    ra.B = B; ra.Q = Q; ra.T = T; ra.C = C; ra.H = H; ra.pad_mult = pad_mult;
+    ra.rmin = rl.radius_min; ra.rmax = rl.radius_max; ra.attn_out = h.rattn; ra.hit_counts = hits;
+    TC_TRY(launch_radar_attn(ra, s));
+    // HEAD:581-586
+    TC_TRY(linear(h.rattn, C, rl.attn.out_proj, rows, C, C, 0, h.t0, C, s, nullptr, qf, C, hits));
+    TC_TRY(layernorm(h.t0, rl.norm2, h.t1, rows, 0, s));
+    TC_TRY(linear(h.t1, C, rl.linear1, rows, C, F, 1, h.ffn_h, F, s));
+    TC_TRY(linear(h.ffn_h, F, rl.linear2, rows, F, C, 0, h.t0, C, s, nullptr, h.t1, C));
+    TC_TRY(layernorm(h.t0, rl.norm3, h.qf, rows, 0, s));
+    qf = h.qf;
+    // final_cls / final_reg, HEAD:592-600
+    TC_TRY(linear(h.qf, C, rl.final_cls.l0, rows, C, C, 0, h.t0, C, s));
+    TC_TRY(layernorm(h.t0, rl.final_cls.n1, h.t2, rows, 1, s));
+    TC_TRY(linear(h.t2, C, rl.final_cls.l3, rows, C, C, 0, h.t0, C, s));
+    TC_TRY(layernorm(h.t0, rl.final_cls.n4, h.t2, rows, 1, s));
+    TC_TRY(linear(h.t2, C, rl.final_cls.l6, rows, C, ncls, 0, cls_out, ncls, s));
+    TC_TRY(linear(h.qf, C, rl.final_reg.l0, rows, C, C, 1, h.t0, C, s));
+    TC_TRY(linear(h.t0, C, rl.final_reg.l2, rows, C, C, 1, h.t2, C, s));
+    TC_TRY(linear(h.t2, C, rl.final_reg.l4, rows, C, code, 0, h.reg_tmp, code, s));
+    if (r == 0)
+      TC_TRY(launch_box_add_ref(h.reg_tmp, code, h.addref, 3, h.addref + 2, 3, box_out, nullptr, rows, s));
+    else
+      TC_TRY(launch_box_add_ref(h.reg_tmp, code, box_prev, code, box_prev + 4, code, box_out, nullptr,
+                                rows, s));
+  }
+  if (aux && aux->radar_hit_counts)
+    TC_HIP(hipMemcpyAsync(aux->radar_hit_counts, h.hits, (size_t)w->num_radar_layers * rows * 4,
+                          hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
+}  // extern "C"

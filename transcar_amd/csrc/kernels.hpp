@@ -1,0 +1,106 @@
+// Host-side launchers of the gfx950 kernels (one translation unit each).
+#pragma once
+#include "common.hpp"
+#include "../../include/transcar_hip.h"
+
+namespace tc {
+
+// ---- gemm.hip: token-wise linear on the f32 MFMA (v_mfma_f32_16x16x4_f32) --
+struct GemmArgs {
+  const float* X = nullptr;  int ldx = 0;      // [M,K]
+  const float* X2 = nullptr; int x2_cols = 0;  // prologue: X+X2 for output cols < x2_cols
+  const float* W = nullptr;  int ldw = 0;      // [N,K] (nn.Linear weight)
+  const float* bias = nullptr;
+  const float* R = nullptr;  int ldr = 0;      // residual added last (may be null)
+  const int* rowgate = nullptr;                // [M]: 0 => drop the linear term (y = R)
+  float* Y = nullptr;        int ldy = 0;      // [M,N] (cols < t_col0 when Yt is set)
+  float* Yt = nullptr;                         // transposed store of cols >= t_col0:
+  int t_col0 = 0, t_ld = 0, t_rows_per_batch = 1;  //   Yt[(b*(N-t_col0)+c)*t_ld + q]
+  int M = 0, K = 0, N = 0;
+  int act = 0;                                 // 0 none, 1 relu, 2 sigmoid
+  float scale = 1.0f; int scale_cols = 0;      // (acc+bias)*scale for cols < scale_cols
+};
+int launch_gemm(const GemmArgs& a, hipStream_t s);
+
+// ---- rowops.hip: wave-per-row kernels -------------------------------------
+// y = LN(a (+b gated by rowgate) (+ relu(LN(c; g2,b2))))*g + beta, optional relu
+struct LnArgs {
+  const float* a = nullptr;
+  const float* b = nullptr;          // optional addend
+  const float* c = nullptr;          // optional addend that first goes through LN(g2,b2)+ReLU
+  const float* g2 = nullptr; const float* b2 = nullptr;
+  const float* gamma = nullptr; const float* beta = nullptr;  // null => no final LN (plain sum)
+  float* y = nullptr;
+  int M = 0; int relu = 0;
+  const float* d = nullptr;          // optional addend after the final LN/ReLU (y += d)
+  int d_relu = 0;                    // apply relu to d first
+};
+int launch_ln256(const LnArgs& a, hipStream_t s);
+
+// y = relu(LN(W0 p + b0)), p = inverse_sigmoid(src[row,0:3]) or raw src[row*ld+0:3]
+int launch_posenc_l1(const float* src, int ld, int inv_sigmoid, const float* w0, const float* b0,
+                     const float* g, const float* beta, float* y, int M, hipStream_t s);
+
+// initial reference points: sigmoid(query_pos W^T + b), XFMR:122-123.  out [B,Q,3]
+int launch_init_ref(const float* query_embedding, int Q, int C, const float* w, const float* b,
+                    float* ref, int B, hipStream_t s);
+
+// expand query_embedding [Q,2C] into pos [B,Q,C], x [B,Q,C] (XFMR:119-121)
+int launch_split_embed(const float* query_embedding, int Q, int C, int B, float* pos, float* x,
+                       hipStream_t s);
+
+// XFMR:195-203: new_ref = sigmoid(tmp[...,{0,1,4}] + inverse_sigmoid(ref)); also (optionally)
+// the head's surviving `tmp` of HEAD:287-293 (xy,z in metres) into box_m [M,code]
+int launch_ref_update(const float* tmp, int code, const float* ref, float* new_ref,
+                      float* box_m, const float* pc_range6_host, int M, hipStream_t s);
+
+// radar layer epilogue: box = reg_out; box[0:2] += ref_xy; box[4] += ref_z  (HEAD:599-600 etc.)
+// and next-layer reference (xy = box[0:2], z = box[4])  (HEAD:615-617)
+int launch_box_add_ref(const float* reg_out, int code, const float* ref_xy, int ld_xy,
+                       const float* ref_z, int ld_z, float* box, float* next_ref3, int M,
+                       hipStream_t s);
+
+// layer-1 radar reference (HEAD:544-547, 596-598): from normalised ref [M,3]:
+// centre_xy (metres) [M,2] and the quirky add-reference (x_m, y_m, z_NORMALISED) [M,3]
+int launch_radar_ref_l1(const float* ref, const float* pc_range6_host, float* centre_xy,
+                        float* addref3, int M, hipStream_t s);
+
+// ---- cam_sample.hip --------------------------------------------------------
+struct CamSampleArgs {
+  tc_feats_nhwc feats;
+  int B, Q, C, num_cams;
+  const float* lidar2img; const float* ref; const float* logits;
+  float pc[6]; float img_h, img_w;
+  float* out; unsigned char* vis; unsigned long long* pair_counter;
+};
+int launch_cam_sample(const CamSampleArgs& a, hipStream_t s);
+
+// ---- self_attn.hip ---------------------------------------------------------
+// q,k: [B*Q, ld] token-major with head h at column h*32; vt: [B, C, ldt] (V transposed)
+int launch_self_attn_core(const float* q, const float* k, int ld, const float* vt, int ldt,
+                          float* out, int ldo, int B, int Q, int H, hipStream_t s);
+
+// ---- radar_attn.hip --------------------------------------------------------
+struct RadarAttnArgs {
+  const float* qproj; int ldq;         // [B*Q, C] projected+scaled queries
+  const float* kv; int ldkv;           // [B*T, 2C]: K | V
+  const float* centre_xy; int ld_c;    // centre at centre_xy[row*ld_c + {0,1}]
+  const float* box; int code;          // [B*Q,code]
+  const float* radar_xy; int ld_xy;    // token xy at radar_xy[(b*T+t)*ld_xy + {0,1}]
+  int B, Q, T, C, H, pad_mult;
+  float rmin, rmax;
+  float* attn_out;                     // [B*Q, C] (zero rows where no hit)
+  int* hit_counts;                     // [B*Q]
+};
+int launch_radar_attn(const RadarAttnArgs& a, hipStream_t s);
+
+// ---- transpose.hip ---------------------------------------------------------
+int launch_nchw_to_nhwc(const float* src, float* dst, int n_img, int C, int H, int W, hipStream_t s);
+
+// ---- decode.hip ------------------------------------------------------------
+int launch_box_decode(const float* cls, const float* box, int B, int Q, int ncls, int code,
+                      int max_num, const float* pcr6_host, float* boxes, float* scores, int* labels,
+                      unsigned char* valid, void* ws, size_t ws_bytes, hipStream_t s);
+size_t box_decode_ws_bytes(int B, int Q, int ncls);
+
+}  // namespace tc

@@ -1,0 +1,208 @@
+"""Tensor-level wrappers over the C ABI (torch is only plumbing here: device
+memory, the current HIP stream).  Every function requires fp32 tensors on a
+HIP device and raises if the library is missing -- there is no CPU path.
+
+Each wrapper names the reference operator it replaces; see
+include/transcar_hip.h for the exact contracts.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def _chk(t, name):
+    if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32
+            and t.is_contiguous()):
+        raise L.TransCARHipError(
+            '%s must be a contiguous fp32 tensor on the GPU (got %s)' % (
+                name, (t.dtype, t.device, t.is_contiguous())
+                if torch.is_tensor(t) else type(t)))
+    return t
+
+
+def linear_view(weight, bias):
+    return L.tc_linear(_p(weight), _p(bias))
+
+
+def lnorm_view(weight, bias):
+    return L.tc_lnorm(_p(weight), _p(bias))
+
+
+# --------------------------------------------------------------------------
+# layout
+# --------------------------------------------------------------------------
+def to_nhwc(feat, out=None):
+    """[B,N,C,H,W] (or [BN,C,H,W]) NCHW fp32 -> [B*N,H,W,C] contiguous.
+
+    A tensor that is already channels-last in memory (the FPN ran in
+    ``torch.channels_last``) is reinterpreted without a copy."""
+    if feat.dim() == 5:
+        feat = feat.reshape(-1, *feat.shape[2:])
+    n, c, h, w = feat.shape
+    if feat.is_contiguous(memory_format=torch.channels_last) and \
+            not feat.is_contiguous():
+        return feat.permute(0, 2, 3, 1)           # zero-copy NHWC view
+    _chk(feat, 'feat')
+    if out is None:
+        out = torch.empty((n, h, w, c), dtype=torch.float32,
+                          device=feat.device)
+    L.check(L.lib().tc_nchw_to_nhwc(_p(feat), _p(out), n, c, h, w, _stream()),
+            'tc_nchw_to_nhwc')
+    return out
+
+
+def feats_view(feats_nhwc):
+    """list of [B*N,H,W,C] -> tc_feats_nhwc."""
+    fv = L.tc_feats_nhwc()
+    fv.num_levels = len(feats_nhwc)
+    for i, f in enumerate(feats_nhwc):
+        if not (f.is_cuda and f.dtype == torch.float32 and f.is_contiguous()):
+            raise L.TransCARHipError('NHWC level %d must be contiguous fp32 '
+                                     'on the GPU' % i)
+        fv.data[i] = f.data_ptr()
+        fv.H[i] = f.shape[1]
+        fv.W[i] = f.shape[2]
+    return fv
+
+
+# --------------------------------------------------------------------------
+# operators
+# --------------------------------------------------------------------------
+def linear(x, weight, bias, x2=None, res=None, act=0):
+    """nn.Linear (+ optional x2 added to the input, residual, ReLU)."""
+    _chk(x, 'x'); _chk(weight, 'weight')
+    M = x.numel() // x.shape[-1]
+    K, N = x.shape[-1], weight.shape[0]
+    y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
+    L.check(L.lib().tc_linear_fwd(_p(x), _p(x2), _p(weight), _p(bias), _p(res),
+                                  _p(y), M, K, N, act, _stream()),
+            'tc_linear_fwd')
+    return y
+
+
+def add_layernorm(a, b, gamma, beta, relu=False):
+    """LayerNorm(a (+ b)), eps 1e-5, optional ReLU."""
+    _chk(a, 'a')
+    Cdim = a.shape[-1]
+    y = torch.empty_like(a)
+    L.check(L.lib().tc_add_layernorm_fwd(_p(a), _p(b), _p(gamma), _p(beta),
+                                         _p(y), a.numel() // Cdim, Cdim,
+                                         1 if relu else 0, _stream()),
+            'tc_add_layernorm_fwd')
+    return y
+
+
+def refine_reference(reg_out, ref):
+    """XFMR:195-203: sigmoid(reg_out[..., {0,1,4}] + inverse_sigmoid(ref))."""
+    _chk(reg_out, 'reg_out'); _chk(ref, 'ref')
+    new_ref = torch.empty_like(ref)
+    L.check(L.lib().tc_refine_reference_fwd(
+        _p(reg_out), reg_out.shape[-1], _p(ref), _p(new_ref),
+        ref.numel() // 3, _stream()), 'tc_refine_reference_fwd')
+    return new_ref
+
+
+def cam_sample_fuse(feats_nhwc, lidar2img, ref, attn_logits, pc_range, img_hw,
+                    num_cams=6, return_mask=False):
+    """feature_sampling + sigmoid-weighted (cam, level) reduction
+    (XFMR:365-373, 381-422).  ref [B,Q,3], attn_logits [B,Q,N*L] -> [B,Q,C]."""
+    _chk(ref, 'ref'); _chk(attn_logits, 'attn_logits'); _chk(lidar2img, 'l2i')
+    B, Q = ref.shape[:2]
+    Cdim = feats_nhwc[0].shape[-1]
+    fv = feats_view(feats_nhwc)
+    out = torch.empty((B, Q, Cdim), dtype=torch.float32, device=ref.device)
+    vis = torch.empty((B, Q, num_cams), dtype=torch.uint8,
+                      device=ref.device) if return_mask else None
+    L.check(L.lib().tc_cam_sample_fuse_fwd(
+        C.byref(fv), B, Q, Cdim, num_cams, _p(lidar2img), _p(ref),
+        _p(attn_logits), L.f6(pc_range), float(img_hw[0]), float(img_hw[1]),
+        _p(out), _p(vis), None, _stream()), 'tc_cam_sample_fuse_fwd')
+    return (out, vis) if return_mask else out
+
+
+def cross_atten(aw, oproj, pe, feats_nhwc, query, query_pos, lidar2img, ref,
+                pc_range, img_hw, num_cams=6):
+    """Detr3DCrossAtten.forward (XFMR:302-378); query/query_pos [B,Q,C]."""
+    _chk(query, 'query'); _chk(query_pos, 'query_pos'); _chk(ref, 'ref')
+    B, Q, Cdim = query.shape
+    fv = feats_view(feats_nhwc)
+    nbytes = L.lib().tc_cross_atten_workspace_bytes(B, Q, Cdim, num_cams,
+                                                    fv.num_levels)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=query.device)
+    out = torch.empty_like(query)
+    L.check(L.lib().tc_cross_atten_fwd(
+        C.byref(aw), C.byref(oproj), C.byref(pe), C.byref(fv), B, Q, Cdim,
+        num_cams, _p(query), _p(query_pos), _p(lidar2img), _p(ref),
+        L.f6(pc_range), float(img_hw[0]), float(img_hw[1]), _p(out), _p(ws),
+        nbytes, _stream()), 'tc_cross_atten_fwd')
+    return out
+
+
+def self_attn(mha, x, pos, num_heads=8):
+    """mmcv MultiheadAttention wrapper: x + out_proj(MHA(x+pos, x+pos, x))."""
+    _chk(x, 'x'); _chk(pos, 'pos')
+    B, Q, Cdim = x.shape
+    nbytes = L.lib().tc_self_attn_workspace_bytes(B, Q, Cdim)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    out = torch.empty_like(x)
+    L.check(L.lib().tc_self_attn_fwd(C.byref(mha), _p(x), _p(pos), _p(out), B,
+                                     Q, Cdim, num_heads, _p(ws), nbytes,
+                                     _stream()), 'tc_self_attn_fwd')
+    return out
+
+
+def radar_gated_xattn(mha, query, centre_xy, box, radar_feat, radar_xy,
+                      pad_mult, rmin, rmax, num_heads=8):
+    """One radar fusion layer's gated attention step (HEAD:549-581).
+    Returns (query + attention on hit rows, hit_counts [B,Q])."""
+    for n, t in (('query', query), ('centre_xy', centre_xy), ('box', box),
+                 ('radar_feat', radar_feat), ('radar_xy', radar_xy)):
+        _chk(t, n)
+    B, Q, Cdim = query.shape
+    T = radar_feat.shape[1]
+    nbytes = L.lib().tc_radar_xattn_workspace_bytes(B, Q, T, Cdim)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=query.device)
+    out = torch.empty_like(query)
+    hits = torch.empty((B, Q), dtype=torch.int32, device=query.device)
+    L.check(L.lib().tc_radar_gated_xattn_fwd(
+        C.byref(mha), _p(query), _p(centre_xy), _p(box), box.shape[-1],
+        _p(radar_feat), _p(radar_xy), B, Q, T, Cdim, num_heads, int(pad_mult),
+        float(rmin), float(rmax), _p(out), _p(hits), _p(ws), nbytes,
+        _stream()), 'tc_radar_gated_xattn_fwd')
+    return out, hits
+
+
+def box_decode_topk(cls_scores, bbox_preds, post_center_range, max_num=300):
+    """NMSFreeCoder.decode_single + z-shift (CODER:39-90, HEAD:1018) for a
+    batch: fixed-size outputs + a validity mask."""
+    _chk(cls_scores, 'cls_scores'); _chk(bbox_preds, 'bbox_preds')
+    B, Q, ncls = cls_scores.shape
+    dev = cls_scores.device
+    boxes = torch.empty((B, max_num, 9), dtype=torch.float32, device=dev)
+    scores = torch.empty((B, max_num), dtype=torch.float32, device=dev)
+    labels = torch.empty((B, max_num), dtype=torch.int32, device=dev)
+    valid = torch.empty((B, max_num), dtype=torch.uint8, device=dev)
+    L.check(L.lib().tc_box_decode_topk(
+        _p(cls_scores), _p(bbox_preds), B, Q, ncls, bbox_preds.shape[-1],
+        max_num, L.f6(post_center_range), _p(boxes), _p(scores), _p(labels),
+        _p(valid), None, 0, _stream()), 'tc_box_decode_topk')
+    return boxes, scores, labels, valid
+
+
+def lidar2img_tensor(img_metas, device):
+    """XFMR:382-386: stack img_metas[i]['lidar2img'] -> [B,N,4,4] fp32."""
+    l2i = np.asarray([m['lidar2img'] for m in img_metas])
+    return torch.from_numpy(l2i.astype(np.float32)).to(device).contiguous()
