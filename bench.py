@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""Benchmark of the TransCAR fusion-decoder hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one synthetic frame:
+Detr3DHead.forward (6 decoder layers + radar encoders + 3 gated radar fusion
+layers) + the NMS-free box decode, with the FPN feature maps (BASELINE.json
+configs[1]: 6 cameras, ResNet-101 FPN shapes, 900 queries, 255 radar points)
+already resident in HBM in channels-last layout.  One process per GPU, frames
+are independent (data parallel, no collective on the data path): "weak"
+scaling.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import transcar_amd as T                                   # noqa: E402
+from transcar_amd import _lib as L                         # noqa: E402
+from transcar_amd import configs, dist as D, ops, synth    # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+F32_MFMA_PEAK_TFLOPS = 157.3   # dense f32 matrix peak (v_mfma_f32_*_f32)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--shapes', default='res101', choices=['res101', 'vovnet', 'tiny'])
+    ap.add_argument('--batch', type=int, default=1, help='frames per step and GPU')
+    ap.add_argument('--no-graph', action='store_true', help='eager launches (no hipGraph)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    return ap.parse_args()
+
+
+def build_head(dev):
+    sd = synth.make_state_dict(seed=3)
+    head = T.build_head(configs.head_cfg())
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return head.to(dev).eval(), sd
+
+
+def make_inputs(head, dev, shapes, batch, seed):
+    """Synthetic frame(s) of BASELINE.md section 3, resident on the device."""
+    feats = synth.make_feats(shapes, seed=seed, batch=batch)      # iid N(0,1)
+    nhwc = [ops.to_nhwc(torch.from_numpy(f).to(dev)) for f in feats]
+    l2i_np = synth.make_lidar2img()
+    l2i = torch.from_numpy(np.stack([l2i_np] * batch).astype(np.float32)).to(dev)
+    hw = configs.IMG_SHAPE[:2]
+    # pass 1 (uniform radar) to learn where the decoder puts its boxes, then
+    # 80 % of the 255 radar returns are placed near predicted centres so the
+    # gated attention has realistic work
+    from transcar_amd import radar as R
+    f0 = [R.build_radar_features(synth.make_radar_frame(seed=2 + b)) for b in range(batch)]
+    tok0, pm0 = R.pack_tokens(f0)
+    o = head.forward_nhwc(nhwc, l2i, hw, torch.from_numpy(tok0).to(dev), pm0, aux=True)
+    r = o['aux']['inter_references'][-1].cpu().numpy().astype(np.float64)
+    pcr = configs.point_cloud_range
+    fl = []
+    for b in range(batch):
+        c = np.round(np.stack([r[b, :, 0] * (pcr[3] - pcr[0]) + pcr[0],
+                               r[b, :, 1] * (pcr[4] - pcr[1]) + pcr[1]], 1), 2)
+        fl.append(R.build_radar_features(synth.make_radar_frame(seed=2 + b, centres=c)))
+    tok, pm = R.pack_tokens(fl)
+    return dict(feats_np=feats, nhwc=nhwc, l2i=l2i, l2i_np=l2i_np, hw=hw,
+                tokens=torch.from_numpy(tok).to(dev), pad_mult=pm, radar_feats=fl)
+
+
+def one_step(head, inp):
+    outs = head.forward_nhwc(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'], inp['pad_mult'])
+    dec = ops.box_decode_topk(outs['all_cls_scores'][-1], outs['all_bbox_preds'][-1],
+                              head.bbox_coder.post_center_range, head.bbox_coder.max_num)
+    return outs, dec
+
+
+def time_events(fn, iters, warm=5):
+    """Average device time of fn() in ms, HIP events on the launch stream."""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def roofline(head, inp, dev):
+    """Live timing of the path's two heavy kernels; the one with the larger
+    share of a frame is reported as the dominant kernel."""
+    B = inp['l2i'].shape[0]
+    Q, Cd = head.num_query, head.embed_dims
+    # -- camera sampling (HBM/L2 gather bound): algorithmic bytes are
+    #    visibility-aware: visible (query,cam) pairs x 4 levels x 4 taps x 256 ch x 4 B
+    o = head.forward_nhwc(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'], inp['pad_mult'], aux=True)
+    ref = o['aux']['inter_references'][2].contiguous()
+    logits = torch.randn((B, Q, 24), device=dev)
+    fv = ops.feats_view(inp['nhwc'])
+    out = torch.empty((B, Q, Cd), device=dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    pc = L.f6(head.pc_range)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run_cam(counter=None):
+        L.check(L.lib().tc_cam_sample_fuse_fwd(
+            C.byref(fv), B, Q, Cd, 6, inp['l2i'].data_ptr(), ref.data_ptr(), logits.data_ptr(),
+            pc, float(inp['hw'][0]), float(inp['hw'][1]), out.data_ptr(), None,
+            counter, st), 'cam_sample')
+    run_cam(C.c_void_p(cnt.data_ptr()))
+    torch.cuda.synchronize()
+    pairs = int(cnt.item())
+    cam_ms = time_events(run_cam, 200)
+    cam_bytes = pairs * 16 * Cd * 4 + B * Q * Cd * 4
+    # -- self-attention core (f32 MFMA bound): 4*Q*Q*32 flop per head
+    H = 8
+    qpad = ((Q + 15) // 16) * 16
+    qk = torch.randn((B * Q, 2 * Cd), device=dev)
+    vt = torch.randn((B, Cd, qpad), device=dev)
+    ao = torch.empty((B * Q, Cd), device=dev)
+
+    def run_attn():
+        L.check(L.lib().tc_sdpa_fwd(qk.data_ptr(), qk.data_ptr() + Cd * 4, 2 * Cd, vt.data_ptr(),
+                                    qpad, ao.data_ptr(), Cd, B, Q, H, st), 'sdpa')
+    attn_ms = time_events(run_attn, 200)
+    attn_flop = 4.0 * Q * Q * 32 * H * B
+    # -- token GEMM 900x256x256 (f32 MFMA)
+    x = torch.randn((B * Q, Cd), device=dev)
+    w = torch.randn((Cd, Cd), device=dev)
+    bb = torch.randn(Cd, device=dev)
+    y = torch.empty((B * Q, Cd), device=dev)
+
+    def run_gemm():
+        L.check(L.lib().tc_linear_fwd(x.data_ptr(), None, w.data_ptr(), bb.data_ptr(), None,
+                                      y.data_ptr(), B * Q, Cd, Cd, 0, st), 'linear')
+    gemm_ms = time_events(run_gemm, 200)
+    gemm_flop = 2.0 * B * Q * Cd * Cd
+    kern = {
+        'cam_sample_kernel': dict(bound='hbm', achieved=cam_bytes / cam_ms / 1e6, peak=HBM_PEAK_GBS,
+                                  unit='GB/s', ms=cam_ms, per_frame=6, alg_bytes=cam_bytes,
+                                  visible_pairs=pairs),
+        'self_attn_kernel': dict(bound='mfma', achieved=attn_flop / attn_ms / 1e9,
+                                 peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', ms=attn_ms,
+                                 per_frame=6, alg_flop=attn_flop),
+        'gemm16_kernel': dict(bound='mfma', achieved=gemm_flop / gemm_ms / 1e9,
+                              peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', ms=gemm_ms,
+                              per_frame=None, alg_flop=gemm_flop),
+    }
+    for k in kern.values():
+        k['frac'] = k['achieved'] / k['peak']
+    dom = max(('cam_sample_kernel', 'self_attn_kernel'),
+              key=lambda n: kern[n]['ms'] * kern[n]['per_frame'])
+    r = dict(kern[dom])
+    r.update(kernel=dom, traffic=None,
+             others={n: {kk: v[kk] for kk in ('bound', 'achieved', 'peak', 'unit', 'frac', 'ms')}
+                     for n, v in kern.items() if n != dom})
+    return r
+
+
+def cpu_baseline(sd, inp, seconds):
+    """The CPU oracle (oracle/transcar_oracle.py, a port of the reference's
+    PyTorch path, proven equal to it on the golden fixtures) timed on this
+    box's host cores on the same frame."""
+    from oracle import transcar_oracle as O
+    tsd = O.to_torch_sd(sd)
+    feats = [torch.from_numpy(f[:1]) for f in inp['feats_np']]
+    l2i = torch.from_numpy(inp['l2i_np']).float()[None]
+    f36 = inp['radar_feats'][0]
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    pcr = configs.point_cloud_range
+    with torch.no_grad():
+        O.head_forward(tsd, feats, l2i, inp['hw'], f36, pcr)          # warm-up
+        times = []
+        t_end = time.perf_counter() + seconds
+        while time.perf_counter() < t_end and len(times) < 50:
+            t0 = time.perf_counter()
+            outs = O.head_forward(tsd, feats, l2i, inp['hw'], f36, pcr)
+            O.get_bboxes(outs, configs.pts_bbox_head['bbox_coder']['post_center_range'])
+            times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return dict(value=1.0 / med, unit='frames/s', cores=cores, kind='port',
+                ms_per_frame=med * 1e3, min_ms_per_frame=float(np.min(times)) * 1e3,
+                sample='%d frames of the bench workload (B=1), torch CPU fp32, %d threads'
+                       % (len(times), cores))
+
+
+def main():
+    args = parse()
+    rank, world = D.init_process_group()
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    torch.set_grad_enabled(False)
+    head, sd = build_head(dev)
+    inp = make_inputs(head, dev, args.shapes, args.batch, seed=1 + rank)
+
+    graph = None
+    if not args.no_graph:
+        # the ~150 kernel launches of a frame are captured once into a hipGraph
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                one_step(head, inp)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_out = one_step(head, inp)
+
+    def step():
+        if graph is not None:
+            graph.replay()
+            return static_out
+        return one_step(head, inp)
+
+    for _ in range(args.warmup):
+        step()
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    D.barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, dev if world > 1 else None)
+
+    frames = args.steps * args.batch * world
+    line = {
+        'metric': 'nuScenes frames/sec (6-cam+radar, 900 queries): fusion decoder '
+                  '(Detr3DHead.forward + box decode), FPN features resident in HBM',
+        'value': frames / elapsed,
+        'unit': 'frames/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': elapsed / args.steps * 1e3,
+        'decoder_ms_per_frame': elapsed / args.steps * 1e3 / args.batch,
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'f32',
+        'data': 'synthetic',
+        'config': {'workload': 'BASELINE.json configs[1]: synthetic 6 cameras, ResNet-101 FPN '
+                               'levels %s x 256 ch (fp32, channels-last), 900 queries, 255 radar '
+                               'points, %d frame(s)/step/GPU, 1xMI355X inference'
+                               % (configs.LEVEL_SHAPES[args.shapes], args.batch),
+                   'shapes': args.shapes, 'frames_per_step_per_gpu': args.batch,
+                   'launch': 'eager' if graph is None else 'hipGraph replay',
+                   'parallelism': 'dp%d (frames sharded, no data-path collective)' % world},
+    }
+    if rank == 0:
+        if world == 1:
+            line['roofline'] = roofline(head, inp, dev)
+            if not args.no_cpu_baseline:
+                line['cpu_baseline'] = cpu_baseline(sd, inp, args.cpu_seconds)
+        print(json.dumps(line))
+    D.barrier()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -174,6 +174,14 @@ int tc_self_attn_fwd(const tc_mha* w, const float* x, const float* pos, float* o
                      int B, int Q, int C, int num_heads,
                      void* workspace, size_t workspace_bytes, tc_stream_t stream);
 
+/* The attention core of the above on already projected operands (the kernel
+ * the roofline is quoted on): out = softmax(q k^T) v per (batch, head).
+ *   q, k [B*Q, ld] token-major, head h at columns h*32.. (q pre-scaled by
+ *   1/sqrt(32)); vt [B, H*32, ldt] = V transposed, ldt >= round_up(Q,16);
+ *   out [B*Q, ldo]. */
+int tc_sdpa_fwd(const float* q, const float* k, int ld, const float* vt, int ldt,
+                float* out, int ldo, int B, int Q, int num_heads, tc_stream_t stream);
+
 /* Distance-gated radar cross-attention, one fusion layer's attention step
  * (HEAD:549-581 / :619-653 / :675-711): three-circle gate around
  * (centre, front, rear), masked nn.MultiheadAttention of the gated queries

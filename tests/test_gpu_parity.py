@@ -107,11 +107,15 @@ def test_nchw_to_nhwc_roundtrip(T):
     assert yc.data_ptr() == xc.data_ptr() and torch.equal(yc.cpu(), y.cpu())
 
 
-@pytest.mark.parametrize('shapes,C', [('tiny', 256), ('res101', 256)])
-def test_cam_sample_vs_oracle(T, shapes, C):
+@pytest.mark.parametrize('shapes,smooth,atol', [
+    ('tiny', None, 3e-5), ('res101', SMOOTH, 1e-4),
+    # iid-noise maps at stride 8: the fp32 rounding of the projected pixel
+    # coordinate (~1e-4 px at |u| ~ 1600) times an O(1)/px feature gradient
+    ('res101', None, 1e-3)])
+def test_cam_sample_vs_oracle(T, shapes, smooth, atol):
     """feature_sampling + weighting (XFMR:365-373) on identical inputs."""
     rng = np.random.RandomState(31)
-    feats = synth.make_feats(shapes, seed=32, channels=C)
+    feats = synth.make_feats(shapes, seed=32, smooth=smooth)
     l2i = synth.make_lidar2img()
     Q = 900
     ref = rng.uniform(0, 1, (1, Q, 3)).astype(np.float32)
@@ -130,7 +134,7 @@ def test_cam_sample_vs_oracle(T, shapes, C):
     assert flips.sum() <= 1, 'visibility mask differs on %d queries' % flips.sum()
     ok = ~flips
     np.testing.assert_allclose(got[0].cpu().numpy()[ok], want[0].numpy()[ok],
-                               atol=3e-5, rtol=1e-5)
+                               atol=atol, rtol=1e-5)
 
 
 def test_cam_sample_nan_and_linearity(T):

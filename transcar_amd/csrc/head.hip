@@ -258,6 +258,11 @@ int tc_self_attn_fwd(const tc_mha* w, const float* x, const float* pos, float* o
   return self_attn(*w, x, pos, out, B, Q, C, num_heads, qk, vt, qpad, ao, as_stream(stream));
 }
 
+int tc_sdpa_fwd(const float* q, const float* k, int ld, const float* vt, int ldt, float* out, int ldo,
+                int B, int Q, int num_heads, tc_stream_t stream) {
+  return launch_self_attn_core(q, k, ld, vt, ldt, out, ldo, B, Q, num_heads, as_stream(stream));
+}
+
 size_t tc_radar_xattn_workspace_bytes(int B, int Q, int T, int C) {
   return arena_slice((size_t)B * T * 2 * C, 4) + 2 * arena_slice((size_t)B * Q * C, 4) +
          arena_slice((size_t)B * Q, 4);
