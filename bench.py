@@ -186,10 +186,24 @@ def cpu_baseline(sd, inp, seconds):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    torch.set_num_threads(cores)
     pcr = configs.point_cloud_range
     with torch.no_grad():
-        O.head_forward(tsd, feats, l2i, inp['hw'], f36, pcr)          # warm-up
+        # the ops are small (900 x 256): all hardware threads of a big host
+        # thrash (73 s/frame at 256 threads measured); pick the best of a
+        # few thread counts on one frame each, then time with that count
+        best = None
+        for n in sorted({min(cores, c) for c in (8, 16, 32, 64)}):
+            torch.set_num_threads(n)
+            O.head_forward(tsd, feats, l2i, inp['hw'], f36, pcr)      # warm-up
+            t0 = time.perf_counter()
+            O.head_forward(tsd, feats, l2i, inp['hw'], f36, pcr)
+            dt = time.perf_counter() - t0
+            if best is None or dt < best[0]:
+                best = (dt, n)
+            if dt > 5.0:
+                break
+        cores = best[1]
+        torch.set_num_threads(cores)
         times = []
         t_end = time.perf_counter() + seconds
         while time.perf_counter() < t_end and len(times) < 50:

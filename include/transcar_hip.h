@@ -177,7 +177,8 @@ int tc_self_attn_fwd(const tc_mha* w, const float* x, const float* pos, float* o
 /* The attention core of the above on already projected operands (the kernel
  * the roofline is quoted on): out = softmax(q k^T) v per (batch, head).
  *   q, k [B*Q, ld] token-major, head h at columns h*32.. (q pre-scaled by
- *   1/sqrt(32)); vt [B, H*32, ldt] = V transposed, ldt >= round_up(Q,16);
+ *   log2(e)/sqrt(32): the kernel exponentiates with 2^x);
+ *   vt [B, H*32, ldt] = V transposed, ldt >= round_up(Q,16);
  *   out [B*Q, ldo]. */
 int tc_sdpa_fwd(const float* q, const float* k, int ld, const float* vt, int ldt,
                 float* out, int ldo, int B, int Q, int num_heads, tc_stream_t stream);

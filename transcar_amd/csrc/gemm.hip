@@ -6,14 +6,23 @@
 // the products run on v_mfma_f32_16x16x4_f32: exact f32 FMA chains at the f32
 // matrix rate (157 TF/s dense on MI355X).
 //
-// Decomposition (B=1 makes every GEMM tiny, so the launch must spread over the
-// chip): one workgroup = 4 waves = a 16-row x 64-column output tile, each wave
-// one 16x16 tile over the full K.  900x256 -> 57 x 4 = 228 workgroups.
-// Operands go global -> VGPR directly: lane (r = lane&15, g = lane>>4) reads
-// 8 consecutive k of row r (two 16-byte loads, four lanes cover one 128-byte
-// line) and feeds them to 8 MFMAs; the k -> MFMA-slot assignment is the same
-// permutation on A and B, so the sum is unchanged.  A (16 x K, <=32 KB) is
-// re-read by the 4 waves through L1; W panels stream from L2.
+// B = 1 makes every GEMM tiny (900x256x256 = 118 MFLOP), so a launch is bound
+// by latency, not by the matrix pipe.  The decomposition is chosen for that:
+//   * one workgroup = a 16-row x 64-column output tile -> 57 x 4 = 228
+//     workgroups for 900x256, about one per CU;
+//   * the NW waves of a workgroup SPLIT K: wave w owns 32-wide k-chunks
+//     w*NCH .. w*NCH+NCH-1 for all four 16x16 column tiles, so each wave issues
+//     ALL of its operand loads (<= 40 16-byte loads per lane) before the first
+//     MFMA and the L2 latency is paid once per launch, not once per k-step;
+//     A is read exactly once per workgroup (no redundancy between waves);
+//   * operands go global -> VGPR directly: lane (r = lane&15, g = lane>>4)
+//     reads 8 consecutive k of row r (two 16-byte loads; the four g-lanes cover
+//     one 128-byte line) and feeds them to 8 MFMAs; the k -> MFMA-slot map is
+//     the same permutation on A and B, so the dot product is unchanged;
+//   * the NW partial tiles meet in LDS (16-32 KB), waves 0..3 each finalise
+//     one column tile: bias, q-scaling, activation, row gate, residual, and
+//     either a row-major store or a transposed float4 store (V^T for the
+//     attention core).
 #include "kernels.hpp"
 
 namespace tc {
@@ -30,52 +39,90 @@ __device__ __forceinline__ float4 ldk(const float* row, int k, int K) {
   if (k + 4 <= K) return ld4(row + k);
   return make_float4(0.f, 0.f, 0.f, 0.f);
 }
+__device__ __forceinline__ float comp(const float4& v, int i) {
+  return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w;
+}
 
-template <bool KFULL>
-__global__ __launch_bounds__(256) void gemm16_kernel(GemmK p) {
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+template <int NW, int NCH>
+__global__ __launch_bounds__(NW * 64) void gemm16_kernel(GemmK p) {
+  __shared__ float4 red[NW][4][64];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int m0 = blockIdx.y * 16;
-  const int n0 = blockIdx.x * 64 + wave * 16;
-  if (n0 >= p.N) return;
-  const int arow = min(m0 + r, p.M - 1);
-  const int bcol = min(n0 + r, p.N - 1);
-  const float* xa = p.X + (size_t)arow * p.ldx;
-  const float* xb = (p.X2 != nullptr && n0 < p.x2_cols) ? p.X2 + (size_t)arow * p.ldx : nullptr;
-  const float* wb = p.W + (size_t)bcol * p.ldw;
-
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int nb = blockIdx.x * 64;
   const int K = p.K;
-#pragma unroll 2
-  for (int k0 = 0; k0 < K; k0 += 32) {
-    const int k = k0 + 8 * g;
-    float4 a0, a1, b0, b1;
-    if (KFULL) {
-      a0 = ld4(xa + k); a1 = ld4(xa + k + 4);
-      b0 = ld4(wb + k); b1 = ld4(wb + k + 4);
-    } else {
-      a0 = ldk(xa, k, K); a1 = ldk(xa, k + 4, K);
-      b0 = ldk(wb, k, K); b1 = ldk(wb, k + 4, K);
+  const int arow = min(m0 + r, p.M - 1);
+  const float* xa = p.X + (size_t)arow * p.ldx;
+  const bool use_x2 = (p.X2 != nullptr) && (nb < p.x2_cols);
+  const float* xb = use_x2 ? p.X2 + (size_t)arow * p.ldx : xa;
+  const int ntile = min(4, (p.N - nb + 15) / 16);      // valid 16-col tiles of this block
+
+  float4 a[NCH][2];
+  float4 b[4][NCH][2];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int k = (wave * NCH + c) * 32 + 8 * g;
+    a[c][0] = ldk(xa, k, K);
+    a[c][1] = ldk(xa, k + 4, K);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const float* wb = p.W + (size_t)min(nb + 16 * t + r, p.N - 1) * p.ldw;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int k = (wave * NCH + c) * 32 + 8 * g;
+      if (t < ntile) {
+        b[t][c][0] = ldk(wb, k, K);
+        b[t][c][1] = ldk(wb, k + 4, K);
+      } else {
+        b[t][c][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        b[t][c][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
-    if (xb != nullptr) {
-      float4 c0, c1;
-      if (KFULL) { c0 = ld4(xb + k); c1 = ld4(xb + k + 4); }
-      else { c0 = ldk(xb, k, K); c1 = ldk(xb, k + 4, K); }
-      a0.x += c0.x; a0.y += c0.y; a0.z += c0.z; a0.w += c0.w;
-      a1.x += c1.x; a1.y += c1.y; a1.z += c1.z; a1.w += c1.w;
+  }
+  if (use_x2) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int k = (wave * NCH + c) * 32 + 8 * g;
+      const float4 c0 = ldk(xb, k, K), c1 = ldk(xb, k + 4, K);
+      a[c][0].x += c0.x; a[c][0].y += c0.y; a[c][0].z += c0.z; a[c][0].w += c0.w;
+      a[c][1].x += c1.x; a[c][1].y += c1.y; a[c][1].z += c1.z; a[c][1].w += c1.w;
     }
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc, 0, 0, 0);
   }
 
-  // C layout: col = lane&15, row = 4*(lane>>4) + reg
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float av = comp(a[c][h], i);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = MFMA4(av, comp(b[t][c][h], i), acc[t]);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    red[wave][t][lane] = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+  __syncthreads();
+  if (wave >= ntile) return;
+
+  // wave t finalises column tile t.  C layout: col = lane&15, row = 4*(lane>>4) + reg
+  const int t = wave;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    const float4 v = red[w][t][lane];
+    s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+  }
+  const int n0 = nb + 16 * t;
   const int col = n0 + r;
   if (col >= p.N) return;
   const float bv = p.bias ? p.bias[col] : 0.0f;
@@ -84,29 +131,29 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmK p) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = m0 + 4 * g + i;
-    float t = (acc[i] + bv) * sc;
-    if (p.act == 1) t = fmaxf(t, 0.0f);
-    else if (p.act == 2) t = sigmoidf_(t);
+    float y = (s[i] + bv) * sc;
+    if (p.act == 1) y = fmaxf(y, 0.0f);
+    else if (p.act == 2) y = sigmoidf_(y);
     if (row < p.M) {
-      if (p.rowgate != nullptr && p.rowgate[row] == 0) t = 0.0f;
-      if (p.R != nullptr) t += p.R[(size_t)row * p.ldr + col];
+      if (p.rowgate != nullptr && p.rowgate[row] == 0) y = 0.0f;
+      if (p.R != nullptr) y += p.R[(size_t)row * p.ldr + col];
     }
-    v[i] = t;
+    v[i] = y;
   }
   if (p.Yt != nullptr && col >= p.t_col0) {
     const int c = col - p.t_col0;
     const int nct = p.N - p.t_col0;
     const int row0 = m0 + 4 * g;
     if (row0 + 3 < p.M && (p.t_rpb & 3) == 0) {
-      const int b = row0 / p.t_rpb, q = row0 - b * p.t_rpb;
-      st4(p.Yt + ((size_t)b * nct + c) * p.t_ld + q, make_float4(v[0], v[1], v[2], v[3]));
+      const int bb = row0 / p.t_rpb, q = row0 - bb * p.t_rpb;
+      st4(p.Yt + ((size_t)bb * nct + c) * p.t_ld + q, make_float4(v[0], v[1], v[2], v[3]));
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = row0 + i;
         if (row < p.M) {
-          const int b = row / p.t_rpb, q = row - b * p.t_rpb;
-          p.Yt[((size_t)b * nct + c) * p.t_ld + q] = v[i];
+          const int bb = row / p.t_rpb, q = row - bb * p.t_rpb;
+          p.Yt[((size_t)bb * nct + c) * p.t_ld + q] = v[i];
         }
       }
     }
@@ -123,7 +170,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
   TC_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
   TC_REQUIRE((a.K & 3) == 0 && (a.ldx & 3) == 0 && (a.ldw & 3) == 0,
              "gemm: K/ldx/ldw must be multiples of 4 (K=%d ldx=%d ldw=%d)", a.K, a.ldx, a.ldw);
-  TC_REQUIRE((a.x2_cols & 15) == 0 || a.x2_cols >= a.N, "gemm: x2_cols must be 16-aligned");
+  TC_REQUIRE((a.x2_cols & 63) == 0 || a.x2_cols >= a.N, "gemm: x2_cols must be 64-aligned");
+  TC_REQUIRE(a.K <= 1024, "gemm: K=%d > 1024 not supported", a.K);
   GemmK p;
   p.X = a.X; p.X2 = a.X2; p.W = a.W; p.bias = a.bias; p.R = a.R; p.rowgate = a.rowgate;
   p.Y = a.Y; p.Yt = a.Yt;
@@ -131,10 +179,15 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
   p.t_col0 = a.t_col0; p.t_ld = a.t_ld; p.t_rpb = a.t_rows_per_batch > 0 ? a.t_rows_per_batch : 1;
   p.M = a.M; p.K = a.K; p.N = a.N; p.act = a.act; p.scale_cols = a.scale_cols; p.scale = a.scale;
   dim3 grid((a.N + 63) / 64, (a.M + 15) / 16);
-  if ((a.K & 31) == 0)
-    hipLaunchKernelGGL(gemm16_kernel<true>, grid, dim3(256), 0, s, p);
+  const int chunks = (a.K + 31) / 32;
+  if (chunks <= 4)
+    hipLaunchKernelGGL((gemm16_kernel<4, 1>), grid, dim3(256), 0, s, p);
+  else if (chunks <= 8)
+    hipLaunchKernelGGL((gemm16_kernel<8, 1>), grid, dim3(512), 0, s, p);
+  else if (chunks <= 16)
+    hipLaunchKernelGGL((gemm16_kernel<8, 2>), grid, dim3(512), 0, s, p);
   else
-    hipLaunchKernelGGL(gemm16_kernel<false>, grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((gemm16_kernel<8, 4>), grid, dim3(512), 0, s, p);
   return check_launch("gemm16");
 }
 

@@ -72,7 +72,8 @@ static int self_attn(const tc_mha& w, const float* x, const float* pos, float* o
   g.Y = qk; g.ldy = 2 * C;
   g.Yt = vt; g.t_col0 = 2 * C; g.t_ld = qpad; g.t_rows_per_batch = Q;
   g.M = rows; g.K = C; g.N = 3 * C;
-  g.scale = 1.0f / sqrtf((float)(C / H)); g.scale_cols = C;
+  // q * log2(e)/sqrt(head_dim): the attention core exponentiates with 2^x
+  g.scale = 1.4426950408889634f / sqrtf((float)(C / H)); g.scale_cols = C;
   TC_TRY(launch_gemm(g, s));
   TC_TRY(launch_self_attn_core(qk, qk + C, 2 * C, vt, qpad, attn_o, C, B, Q, H, s));
   return linear(attn_o, C, w.out_proj, rows, C, C, 0, out, C, s, nullptr, x, C);
