@@ -43,6 +43,8 @@ def parse():
     ap.add_argument('--batch', type=int, default=1, help='frames per step and GPU')
     ap.add_argument('--no-graph', action='store_true', help='eager launches (no hipGraph)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--unfused', action='store_true',
+                    help='operator-by-operator launches instead of the fused row chains')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     return ap.parse_args()
 
@@ -220,6 +222,8 @@ def cpu_baseline(sd, inp, seconds):
 
 def main():
     args = parse()
+    if args.unfused:
+        os.environ['TRANSCAR_UNFUSED'] = '1'
     rank, world = D.init_process_group()
     local = int(os.environ.get('LOCAL_RANK', 0))
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'

@@ -34,7 +34,7 @@ extern "C" {
 #define TC_MAX_LEVELS 4
 #define TC_MAX_LAYERS 8
 #define TC_MAX_RADAR_LAYERS 3
-#define TC_ABI_VERSION 1
+#define TC_ABI_VERSION 2
 
 typedef void* tc_stream_t;
 
@@ -223,7 +223,18 @@ int tc_box_decode_topk(const float* cls_scores /*[B,Q,num_classes]*/,
  *   pad_mult     see tc_radar_gated_xattn_fwd
  *   all_cls_scores / all_bbox_preds [3,B,Q,10] */
 size_t tc_head_workspace_bytes(const tc_head_weights* w, int B, int T);
-int tc_head_forward(const tc_head_weights* w, const tc_feats_nhwc* feats, int B,
+/* One-time re-layout of the nn.Linear weights into MFMA fragment order for the
+ * fused row-chain kernels (1 KiB-coalesced weight streaming): call once per
+ * checkpoint load / after an optimizer step changes the weights.  `packed` is a
+ * device buffer of tc_head_packed_bytes(w) bytes that must outlive
+ * `packed_view`, a copy of `w` whose linear-weight pointers point into it. */
+size_t tc_head_packed_bytes(const tc_head_weights* w);
+int tc_head_pack_weights(const tc_head_weights* w, void* packed, size_t packed_bytes,
+                         tc_head_weights* packed_view, tc_stream_t stream);
+/* packed_view == NULL selects the operator-by-operator launch sequence (~160
+ * launches instead of 16); results agree to fp32 rounding. */
+int tc_head_forward(const tc_head_weights* w, const tc_head_weights* packed_view,
+                    const tc_feats_nhwc* feats, int B,
                     const float* lidar2img /*[B,N,4,4]*/, float img_h, float img_w,
                     const float* radar_tokens, int T, int pad_mult,
                     float* all_cls_scores, float* all_bbox_preds,

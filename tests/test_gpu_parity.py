@@ -357,7 +357,33 @@ def test_module_api_matches_fused_head(T, head):
     np.testing.assert_allclose(inter_refs.cpu().numpy(),
                                outs['aux']['inter_references'].cpu().numpy(), atol=2e-5)
     np.testing.assert_allclose(hs.permute(0, 2, 1, 3).cpu().numpy(),
-                               outs['aux']['inter_states'].cpu().numpy(), atol=3e-4)
+                               outs['aux']['inter_states'].cpu().numpy(), atol=E2E_TOL)
+
+
+def test_fused_chains_match_operator_path(T, head):
+    """tc_head_forward's fused row-chain kernels (16 launches) against the same
+    forward run operator by operator (TRANSCAR_UNFUSED=1, ~160 launches)."""
+    gold, frame = _radar_inputs('res101')
+    feats = [gpu(f) for f in synth.make_feats('res101', seed=1, smooth=SMOOTH)]
+    metas = synth.make_img_metas(1, radar=frame)
+    fused = head(feats, metas, aux=True)
+    os.environ['TRANSCAR_UNFUSED'] = '1'
+    try:
+        plain = head(feats, metas, aux=True)
+    finally:
+        os.environ.pop('TRANSCAR_UNFUSED')
+    np.testing.assert_allclose(fused['aux']['inter_references'].cpu().numpy(),
+                               plain['aux']['inter_references'].cpu().numpy(), atol=2e-5)
+    np.testing.assert_allclose(fused['aux']['inter_states'].cpu().numpy(),
+                               plain['aux']['inter_states'].cpu().numpy(), atol=E2E_TOL)
+    hf = fused['aux']['radar_hit_counts'][:, 0].cpu().numpy()
+    hp = plain['aux']['radar_hit_counts'][:, 0].cpu().numpy()
+    agree = np.all(hf == hp, axis=0)
+    assert (~agree).sum() <= 4
+    for k in ('all_cls_scores', 'all_bbox_preds'):
+        np.testing.assert_allclose(fused[k][:, 0].cpu().numpy()[:, agree],
+                                   plain[k][:, 0].cpu().numpy()[:, agree], atol=E2E_TOL)
+    assert int(fused['aux']['sample_pairs']) == int(plain['aux']['sample_pairs'])
 
 
 def test_box_decode_vs_oracle(T, head):

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libtranscar_hip.so')
 TC_MAX_LEVELS = 4
 TC_MAX_LAYERS = 8
 TC_MAX_RADAR_LAYERS = 3
-TC_ABI_VERSION = 1
+TC_ABI_VERSION = 2
 
 c_fp = C.c_void_p      # device pointers travel as integers
 
@@ -128,7 +128,11 @@ SIGNATURES = {
     'tc_box_decode_topk': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _P(_f), _vp,
                                 _vp, _vp, _vp, _vp, _sz, _vp]),
     'tc_head_workspace_bytes': (_sz, [_P(tc_head_weights), _i, _i]),
-    'tc_head_forward': (_i, [_P(tc_head_weights), _P(tc_feats_nhwc), _i, _vp,
+    'tc_head_packed_bytes': (_sz, [_P(tc_head_weights)]),
+    'tc_head_pack_weights': (_i, [_P(tc_head_weights), _vp, _sz,
+                                  _P(tc_head_weights), _vp]),
+    'tc_head_forward': (_i, [_P(tc_head_weights), _P(tc_head_weights),
+                             _P(tc_feats_nhwc), _i, _vp,
                              _f, _f, _vp, _i, _i, _vp, _vp, _P(tc_head_aux),
                              _vp, _sz, _vp]),
 }

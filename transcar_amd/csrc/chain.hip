@@ -1,0 +1,697 @@
+// Fused row-chain kernel: the launch-count fix for the B = 1 hot path.
+//
+// Everything in Detr3DHead.forward except the 900x900 self-attention is
+// ROW-LOCAL: a query's out_proj, LayerNorms, camera sampling, FFN, box
+// refinement, next-layer QKV projection, and the whole 3-layer radar fusion
+// stack only ever touch that query's own 256 channels (plus read-only feature
+// maps / radar K,V).  The first build ran them as ~160 dependent launches per
+// frame; on MI355X a dependent launch costs ~4-5 us even when the kernel is
+// trivial, so the frame was launch-bound (profiles/r1_v1_*).  Here a workgroup
+// of 4 waves owns R = 4 / 8 / 16 rows (queries or radar tokens), keeps them in
+// LDS and walks a whole chain; weights stream from L2 into MFMA operands.
+//
+// ONE kernel, four programs (step tables in constant memory), so a frame is
+// 16 launches instead of 163:
+//   PROG_PROLOGUE   embedding split, initial reference points, layer-0 QKV
+//   PROG_DECODER    per decoder layer, everything after the attention core up
+//                   to and including the next layer's QKV
+//   PROG_RADAR_ENC  radar MLP encoders + the K/V projections of the three
+//                   fusion layers (independent of the decoder: side stream)
+//   PROG_RADAR      the three radar fusion layers incl. gated attention,
+//                   class / box MLPs and reference bookkeeping
+//
+// Design notes, every one of them measured on MI355X (tools/*_probe.hip and
+// in-kernel s_memtime stamps; DESIGN.md "Row chains"):
+//  * v_mfma_f32_4x4x1_16B_f32 instead of 16x16x4.  With 16x16x4 a row tile must
+//    hold 16 queries = 57 workgroups for 900 queries, i.e. 57 CUs' worth of f32
+//    matrix pipe, and the chain was bound by exactly that.  The 4x4x1 form is a
+//    [4 queries] x [64 output columns] outer product per instruction with the A
+//    operand BROADCAST from one 4-lane block (cbsz = 4, abid = row group): 4-row
+//    tiles give 225 workgroups at full MFMA efficiency (9.0-9.3 cycles per MFMA
+//    measured in the loop, 9.6 in isolation), and with R = 8 / 16 each weight
+//    register feeds 2 / 4 MFMAs.  Exact fp32: f32 FMA chains, two k-interleaved
+//    accumulators per row group so the pipe is issue- not latency-bound.
+//  * Weights are PRE-PACKED (pack.hip) so one wave-instruction reads 1 KiB
+//    contiguous: from the nn.Linear [N][K] layout a CU streams fragments at
+//    36 GB/s, packed at 124 GB/s; loads of item i+1 fly under the MFMAs of item i.
+//  * The A operand goes LDS -> registers with 16 UNGUARDED ds_read_b128 before
+//    the MFMA burst: a bounds check per read turned them into 16 dependent round
+//    trips (1350 cycles per item, more than the MFMAs).
+//  * __builtin_amdgcn_sched_barrier(0) around load groups: hipcc's scheduler
+//    otherwise sinks each load next to its first use (1-2 loads in flight).
+//  * Instruction-cache capacity is NOT an issue (128 KB of straight-line MFMAs
+//    runs at full rate: tools/icache_probe.hip); the step table exists to keep
+//    ONE code image for all four programs.
+#include <stdlib.h>
+#include <string.h>
+
+#include "kernels.hpp"
+#include "rowdev.hpp"
+
+namespace tc {
+
+namespace {
+
+constexpr int CH_NW = 4;
+constexpr int CH_NT = CH_NW * 64;
+constexpr int LD5 = 516;   // 512 + 4 floats
+constexpr int LD2 = 260;   // 256 + 4
+constexpr int LDL = 36;
+
+template <int R>
+struct ChainLds {
+  float a[R][LD5];
+  float x[R][LD2];
+  float r[R][LD2];
+  float t[R][LD2];
+  float u[R][LD2];
+  float p[R][LD2];
+  float l[R][LDL];
+  float box[R][12];
+  float cen[R][4];
+  int gate[R];
+};
+
+#define MFMA44(a, b, c, grp) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 4, (grp), 0)
+
+// ---- step tables -----------------------------------------------------------
+enum Buf : short { B_NONE = -1, B_A = 0, B_X, B_R, B_T, B_U, B_P, B_L };
+enum Kind : short {
+  K_END = 0, K_LOAD, K_LINEAR, K_LN, K_POSENC, K_SAMPLE, K_REFUPD, K_TOKENS, K_RADAR_ATTN, K_BOXADD
+};
+enum NSpecial : short { N_LOGITS = -1, N_CODE = -2, N_CLS = -3 };
+enum Flags : short {
+  F_GATE = 1,         // linear: row gate from LDS (radar hit counts)
+  F_SCALEQ = 2,       // linear: scale the first 256 output columns by qscale
+  F_WOFF = 4,         // linear: weights start 512 rows into the pair (V part of a packed in_proj)
+  F_LN_RELU = 8,      // ln: relu after the outer LN
+  F_SKIP_NONEXT = 16  // skip the step when there is no next layer
+};
+// global tensors, indices into ChainK::g
+enum GSel : short {
+  G_NONE = -1, G_HS = 0, G_QK, G_VT, G_INITREF, G_ATTN_O, G_XIN, G_POS, G_CLS, G_KV0, G_KV1, G_KV2,
+  G_QF, G_COUNT
+};
+
+struct StepDesc {
+  short kind, wp, wp2, K, N, src, src2, dst, res, act, flags, gsel, gtsel, sync;
+};
+//   kind      wp wp2   K    N        src   src2    dst    res  act flags gsel gtsel sync
+// decoder layer pairs: 0 in_proj 1 out_proj 2 norm0 3 attw 4 output_proj 5 pe.l0 6 pe.n1 7 pe.l3
+//   8 pe.n4 9 norm1 10 ffn0 11 ffn1 12 norm2 13 reg.l0 14 reg.l2 15 reg.l4 ; 16 next in_proj
+__constant__ StepDesc PROG_DECODER_T[] = {
+    {K_LOAD, 0, 0, 0, 0, B_NONE, B_NONE, B_T, B_NONE, 0, 0, G_ATTN_O, G_NONE, 0},
+    {K_LOAD, 0, 0, 0, 0, B_NONE, B_NONE, B_X, B_NONE, 0, 0, G_XIN, G_NONE, 0},
+    {K_LOAD, 0, 0, 0, 0, B_NONE, B_NONE, B_P, B_NONE, 0, 0, G_POS, G_NONE, 1},
+    {K_LINEAR, 1, -1, 256, 256, B_T, B_NONE, B_U, B_X, 0, 0, G_NONE, G_NONE, 1},          // x + out_proj(attn)
+    {K_LN, 2, -1, 0, 0, B_U, B_NONE, B_X, B_NONE, 0, 0, G_NONE, G_NONE, 1},               // norm0
+    {K_LINEAR, 3, -1, 256, N_LOGITS, B_X, B_P, B_L, B_NONE, 0, 0, G_NONE, G_NONE, 0},     // attention_weights
+    {K_POSENC, 5, 6, 0, 0, B_NONE, B_NONE, B_T, B_NONE, 0, 0, G_NONE, G_NONE, 1},         // pe.0-2
+    {K_SAMPLE, 0, 0, 0, 0, B_L, B_NONE, B_R, B_NONE, 0, 0, G_NONE, G_NONE, 1},            // camera sampling
+    {K_LINEAR, 7, -1, 256, 256, B_T, B_NONE, B_A, B_NONE, 0, 0, G_NONE, G_NONE, 0},       // pe.3
+    {K_LINEAR, 4, -1, 256, 256, B_R, B_NONE, B_U, B_X, 0, 0, G_NONE, G_NONE, 1},          // x + output_proj
+    {K_LN, 9, 8, 0, 0, B_U, B_A, B_X, B_NONE, 0, 0, G_NONE, G_NONE, 1},                   // norm1(u + relu(LN(a)))
+    {K_LINEAR, 10, -1, 256, 512, B_X, B_NONE, B_A, B_NONE, 1, 0, G_NONE, G_NONE, 1},      // ffn0
+    {K_LINEAR, 11, -1, 512, 256, B_A, B_NONE, B_U, B_X, 0, 0, G_NONE, G_NONE, 1},         // x + ffn1
+    {K_LN, 12, -1, 0, 0, B_U, B_NONE, B_X, B_NONE, 0, 0, G_HS, G_NONE, 1},                // norm2 -> hs
+    {K_LINEAR, 13, -1, 256, 256, B_X, B_NONE, B_T, B_NONE, 1, 0, G_NONE, G_NONE, 0},      // reg.0
+    {K_LINEAR, 16, -1, 256, 512, B_X, B_P, B_NONE, B_NONE, 0, F_SCALEQ | F_SKIP_NONEXT, G_QK, G_NONE, 0},
+    {K_LINEAR, 16, -1, 256, 256, B_X, B_NONE, B_NONE, B_NONE, 0, F_WOFF | F_SKIP_NONEXT, G_NONE, G_VT, 1},
+    {K_LINEAR, 14, -1, 256, 256, B_T, B_NONE, B_U, B_NONE, 1, 0, G_NONE, G_NONE, 1},      // reg.2
+    {K_LINEAR, 15, -1, 256, N_CODE, B_U, B_NONE, B_L, B_NONE, 0, 0, G_NONE, G_NONE, 1},   // reg.4
+    {K_REFUPD, 0, 0, 0, 0, B_L, B_NONE, B_NONE, B_NONE, 0, 0, G_NONE, G_NONE, 0},
+    {K_END, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
+// prologue pairs: 0 reference_points 16 layer-0 in_proj
+__constant__ StepDesc PROG_PROLOGUE_T[] = {
+    {K_LOAD, 0, 0, 0, 0, B_NONE, B_NONE, B_P, B_NONE, 0, 0, G_POS, G_NONE, 0},
+    {K_LOAD, 0, 0, 0, 0, B_NONE, B_NONE, B_X, B_NONE, 0, 0, G_XIN, G_NONE, 1},
+    {K_LINEAR, 0, -1, 256, 3, B_P, B_NONE, B_NONE, B_NONE, 2, 0, G_INITREF, G_NONE, 0},
+    {K_LINEAR, 16, -1, 256, 512, B_X, B_P, B_NONE, B_NONE, 0, F_SCALEQ, G_QK, G_NONE, 0},
+    {K_LINEAR, 16, -1, 256, 256, B_X, B_NONE, B_NONE, B_NONE, 0, F_WOFF, G_NONE, G_VT, 0},
+    {K_END, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
+// radar encoder pairs: 0 rpe.l0 1 rpe.n1 2 rpe.l3 3 rpe.n4 4 f0 5 f2 6 f4 7..9 kv proj of layer 0..2
+__constant__ StepDesc PROG_RADAR_ENC_T[] = {
+    {K_TOKENS, 0, 0, 0, 0, B_NONE, B_NONE, B_A, B_NONE, 0, 0, G_NONE, G_NONE, 1},
+    {K_POSENC, 0, 1, 0, 0, B_A, B_NONE, B_T, B_NONE, 0, 0, G_NONE, G_NONE, 0},            // raw xyz from the tile
+    {K_LINEAR, 4, -1, 36, 64, B_A, B_NONE, B_R, B_NONE, 1, 0, G_NONE, G_NONE, 1},         // feat.0 (K = RI)
+    {K_LINEAR, 2, -1, 256, 256, B_T, B_NONE, B_U, B_NONE, 0, 0, G_NONE, G_NONE, 0},       // rpe.3
+    {K_LINEAR, 5, -1, 64, 128, B_R, B_NONE, B_X, B_NONE, 1, 0, G_NONE, G_NONE, 1},        // feat.2
+    {K_LINEAR, 6, -1, 128, 256, B_X, B_NONE, B_P, B_NONE, 1, 0, G_NONE, G_NONE, 1},       // feat.4
+    {K_LN, 3, -1, 0, 0, B_U, B_NONE, B_X, B_P, 0, F_LN_RELU, G_NONE, G_NONE, 1},          // relu(LN(u)) + p
+    {K_LINEAR, 7, -1, 256, 512, B_X, B_NONE, B_NONE, B_NONE, 0, 0, G_KV0, G_NONE, 0},
+    {K_LINEAR, 8, -1, 256, 512, B_X, B_NONE, B_NONE, B_NONE, 0, 0, G_KV1, G_NONE, 0},
+    {K_LINEAR, 9, -1, 256, 512, B_X, B_NONE, B_NONE, B_NONE, 0, 0, G_KV2, G_NONE, 0},
+    {K_END, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
+// radar layer pairs (+14*r): 0 attn.in_proj 1 attn.out_proj 2 norm2 3 linear1 4 linear2 5 norm3
+//   6 cls.0 7 cls.n1 8 cls.3 9 cls.n4 10 cls.6 11 reg.0 12 reg.2 13 reg.4
+__constant__ StepDesc PROG_RADAR_LAYER_T[] = {
+    {K_LINEAR, 0, -1, 256, 256, B_X, B_NONE, B_T, B_NONE, 0, F_SCALEQ, G_NONE, G_NONE, 1},   // q projection
+    {K_RADAR_ATTN, 0, 0, 0, 0, B_T, B_NONE, B_U, B_NONE, 0, 0, G_NONE, G_NONE, 1},
+    {K_LINEAR, 1, -1, 256, 256, B_U, B_NONE, B_R, B_X, 0, F_GATE, G_NONE, G_NONE, 1},        // x + gate*out_proj
+    {K_LN, 2, -1, 0, 0, B_R, B_NONE, B_X, B_NONE, 0, 0, G_NONE, G_NONE, 1},                  // rf_norm2
+    {K_LINEAR, 3, -1, 256, 512, B_X, B_NONE, B_A, B_NONE, 1, 0, G_NONE, G_NONE, 1},
+    {K_LINEAR, 4, -1, 512, 256, B_A, B_NONE, B_U, B_X, 0, 0, G_NONE, G_NONE, 1},
+    {K_LN, 5, -1, 0, 0, B_U, B_NONE, B_X, B_NONE, 0, 0, G_NONE, G_NONE, 1},                  // rf_norm3
+    {K_LINEAR, 6, -1, 256, 256, B_X, B_NONE, B_T, B_NONE, 0, 0, G_NONE, G_NONE, 0},          // final_cls.0
+    {K_LINEAR, 11, -1, 256, 256, B_X, B_NONE, B_R, B_NONE, 1, 0, G_NONE, G_NONE, 1},         // final_reg.0
+    {K_LN, 7, -1, 0, 0, B_T, B_NONE, B_T, B_NONE, 0, F_LN_RELU, G_NONE, G_NONE, 0},          // in place
+    {K_LINEAR, 12, -1, 256, 256, B_R, B_NONE, B_U, B_NONE, 1, 0, G_NONE, G_NONE, 1},         // final_reg.2
+    {K_LINEAR, 8, -1, 256, 256, B_T, B_NONE, B_P, B_NONE, 0, 0, G_NONE, G_NONE, 0},          // final_cls.3
+    {K_LINEAR, 13, -1, 256, N_CODE, B_U, B_NONE, B_L, B_NONE, 0, 0, G_NONE, G_NONE, 1},      // final_reg.4
+    {K_LN, 9, -1, 0, 0, B_P, B_NONE, B_P, B_NONE, 0, F_LN_RELU, G_NONE, G_NONE, 0},          // in place
+    {K_BOXADD, 0, 0, 0, 0, B_L, B_NONE, B_NONE, B_NONE, 0, 0, G_NONE, G_NONE, 1},
+    {K_LINEAR, 10, -1, 256, N_CLS, B_P, B_NONE, B_NONE, B_NONE, 0, 0, G_CLS, G_NONE, 1},     // final_cls.6
+    {K_END, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
+
+enum Program : int { PROG_PROLOGUE = 0, PROG_DECODER, PROG_RADAR_ENC, PROG_RADAR };
+constexpr int MAX_PAIRS = 48;
+constexpr int RADAR_PAIRS = 14;
+
+struct ChainK {
+  int program, M, Q, code, ncls, nlogits, has_next, nlayers;
+  tc_linear pairs[MAX_PAIRS];
+  float* g[G_COUNT]; int g_ld[G_COUNT]; int g_mod[G_COUNT];   // global tensors by GSel
+  float qscale; int qpad;
+  // decoder
+  const float* ref_in; float* ref_out; float* box_m;
+  CamK cam; unsigned long long* pair_counter;
+  // radar
+  const float* tokens; int RI, T, pad_mult;
+  const float* ref_last; const float* box_in;
+  float rmin[TC_MAX_RADAR_LAYERS], rmax[TC_MAX_RADAR_LAYERS];
+  float* all_box; int* hits;
+};
+
+__device__ __forceinline__ float comp4(const float4& v, int i) {
+  return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w;
+}
+
+// runtime view of a linear step
+struct LinSpec {
+  const float* W; const float* bias; int K, N;
+  const float* src; int src_ld;
+  const float* src2; int src2_ld;
+  float* dst; int dst_ld;
+  const float* res; int res_ld;
+  const int* gate;
+  int act; float scale; int scale_cols;
+  float* gdst; int gdst_ld;
+  float* gt; int gt_ld, gt_rpb;
+  int m0, M;
+};
+
+// One work item = (64-column output tile, 64-deep k block): 16 x 16-byte weight
+// loads per lane (1 KiB contiguous per wave-instruction from the packed layout
+// P[tile][k/4][lane][4]: lane n owns output column 64*tile + n), then
+// 64 * R/4 MFMAs.  Lane q < R supplies row q of the activations (A operand of
+// row group q/4, broadcast to the 16 column blocks by cbsz/abid).
+constexpr int KB = 64;
+struct WBuf { float4 b[16]; };
+
+__device__ __forceinline__ void wload(WBuf& wb, const float* w, int nq) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    wb.b[i] = i < nq ? ld4(w + i * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+template <int NG>
+struct Acc { f32x4 v[NG][2]; };
+
+template <int NG>
+__device__ __forceinline__ void acc_zero(Acc<NG>& a) {
+#pragma unroll
+  for (int g = 0; g < NG; ++g) { a.v[g][0] = f32x4{0.f, 0.f, 0.f, 0.f}; a.v[g][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+}
+
+template <int NG, int G>
+struct MfmaGroups {
+  static __device__ __forceinline__ void run(Acc<NG>& acc, float a, float b, int par) {
+    if (par == 0) acc.v[G][0] = MFMA44(a, b, acc.v[G][0], G);
+    else acc.v[G][1] = MFMA44(a, b, acc.v[G][1], G);
+    MfmaGroups<NG, G + 1>::run(acc, a, b, par);
+  }
+};
+template <int NG>
+struct MfmaGroups<NG, NG> {
+  static __device__ __forceinline__ void run(Acc<NG>&, float, float, int) {}
+};
+
+// The A operand (this lane's activation row, 64 k of it) is read from LDS into
+// registers BEFORE the MFMA burst: issued just in time, every one of the 16
+// ds_read_b128 exposed its ~120-cycle latency to the matrix pipe (measured:
+// +2000 cycles per item, more than the 128 MFMAs themselves).
+struct ABuf { float4 a[16]; };
+
+// No per-read guards: a conditional around each ds_read_b128 turned the 16 reads
+// into 16 dependent round trips (1350 cycles per item, measured).  Reading past
+// K is safe: the LDS tile is zero filled up to the next multiple of 64 wherever
+// K is not one, and the packed weights are zero there.
+template <bool ADD2>
+__device__ __forceinline__ void aload(ABuf& ab, const float* arow, const float* a2row) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    float4 av = *reinterpret_cast<const float4*>(arow + 4 * i);
+    if (ADD2) av = add4(av, *reinterpret_cast<const float4*>(a2row + 4 * i));
+    ab.a[i] = av;
+  }
+}
+
+template <int NG>
+__device__ __forceinline__ void wcompute(Acc<NG>& acc, const WBuf& wb, const ABuf& ab) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    MfmaGroups<NG, 0>::run(acc, ab.a[i].x, wb.b[i].x, 0);
+    MfmaGroups<NG, 0>::run(acc, ab.a[i].y, wb.b[i].y, 1);
+    MfmaGroups<NG, 0>::run(acc, ab.a[i].z, wb.b[i].z, 0);
+    MfmaGroups<NG, 0>::run(acc, ab.a[i].w, wb.b[i].w, 1);
+  }
+}
+
+// lane n holds y[4g + i][64*tile + n] in acc.v[g][*][i]
+template <int NG>
+__device__ __forceinline__ void lin_epilogue(const LinSpec& s, int tile, const Acc<NG>& acc, int lane, float bv) {
+  const int col = tile * 64 + lane;
+  if (col >= s.N) return;
+  const float sc = (col < s.scale_cols) ? s.scale : 1.0f;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 4 * g + i;
+      float y = ((acc.v[g][0][i] + acc.v[g][1][i]) + bv) * sc;
+      if (s.act == 1) y = fmaxf(y, 0.0f);
+      else if (s.act == 2) y = sigmoidf_(y);
+      if (s.gate != nullptr && s.gate[row] == 0) y = 0.0f;
+      if (s.res != nullptr) y += s.res[row * s.res_ld + col];
+      if (s.dst != nullptr) s.dst[row * s.dst_ld + col] = y;
+      v[i] = y;
+    }
+    if (s.gdst != nullptr) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = s.m0 + 4 * g + i;
+        if (row < s.M) s.gdst[(size_t)row * s.gdst_ld + col] = v[i];
+      }
+    }
+    if (s.gt != nullptr) {
+      const int row0 = s.m0 + 4 * g;
+      if (row0 + 3 < s.M && (s.gt_rpb & 3) == 0) {
+        const int bb = row0 / s.gt_rpb, q = row0 - bb * s.gt_rpb;
+        st4(s.gt + ((size_t)bb * s.N + col) * s.gt_ld + q, make_float4(v[0], v[1], v[2], v[3]));
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = row0 + i;
+          if (row < s.M) {
+            const int bb = row / s.gt_rpb, q = row - bb * s.gt_rpb;
+            s.gt[((size_t)bb * s.N + col) * s.gt_ld + q] = v[i];
+          }
+        }
+      }
+    }
+  }
+}
+
+// y[R, N] = epilogue(src[R, K] W^T): called by all CH_NT threads, no internal barrier.
+//
+// A wave's work items (its column tiles x 64-deep k blocks) are double buffered
+// in registers: while item i issues its MFMAs, the 16 weight loads (16 KiB per
+// wave) and 16 LDS reads of item i+1 are in flight.  The tail re-loads the last
+// item (unconditional loads keep hipcc's vmcnt bookkeeping exact);
+// sched_barrier(0) stops hipcc from sinking loads next to their first use.
+template <int R>
+__device__ __forceinline__ void linear_step(const LinSpec& s) {
+  constexpr int NG = R / 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ntiles = (s.N + 63) >> 6;
+  const int kpad = (s.K + 63) & ~63;                 // packed tile = 64 * kpad floats
+  const int nkb = kpad / KB;
+  const int my_tiles = wave < ntiles ? (ntiles - wave + CH_NW - 1) / CH_NW : 0;
+  const int nitems = my_tiles * nkb;
+  if (nitems == 0) return;
+  const int arow_i = min(lane, R - 1);
+  const float* arow = s.src + arow_i * s.src_ld;
+  const float* a2row = s.src2 ? s.src2 + arow_i * s.src2_ld : nullptr;
+  const float* wbase = s.W + 4 * lane;
+  Acc<NG> acc;
+  auto wl = [&](WBuf& wb, int i) {
+    i = min(i, nitems - 1);
+    const int tt = i / nkb, kb = i - tt * nkb;
+    wload(wb, wbase + (size_t)(wave + tt * CH_NW) * 64 * kpad + (size_t)kb * (KB / 4) * 256, 16);
+  };
+  float bv = 0.0f;
+  auto run = [&](const WBuf& wb, int i) {
+    const int tt = i / nkb, kb = i - tt * nkb;
+    ABuf ab;
+    if (a2row != nullptr) aload<true>(ab, arow + kb * KB, a2row + kb * KB);
+    else aload<false>(ab, arow + kb * KB, nullptr);
+    if (kb == 0) {
+      acc_zero<NG>(acc);
+      const int col = (wave + tt * CH_NW) * 64 + lane;        // bias: in flight under the MFMAs
+      bv = (s.bias != nullptr && col < s.N) ? s.bias[col] : 0.0f;
+    }
+    wcompute<NG>(acc, wb, ab);
+    if (kb == nkb - 1) lin_epilogue<NG>(s, wave + tt * CH_NW, acc, lane, bv);
+  };
+  WBuf w0, w1;
+  wl(w0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+  for (int i = 0; i < nitems; i += 2) {
+    wl(w1, i + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    run(w0, i);
+    __builtin_amdgcn_sched_barrier(0);
+    wl(w0, i + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (i + 1 < nitems) run(w1, i + 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int R>
+__device__ __forceinline__ float* buf_ptr(ChainLds<R>& S, int id) {
+  switch (id) {
+    case B_A: return &S.a[0][0];
+    case B_X: return &S.x[0][0];
+    case B_R: return &S.r[0][0];
+    case B_T: return &S.t[0][0];
+    case B_U: return &S.u[0][0];
+    case B_P: return &S.p[0][0];
+    case B_L: return &S.l[0][0];
+    default: return nullptr;
+  }
+}
+__device__ __forceinline__ int buf_ld(int id) { return id == B_A ? LD5 : id == B_L ? LDL : LD2; }
+
+template <int R>
+__global__ __launch_bounds__(CH_NT) void chain_kernel(ChainK k) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  ChainLds<R>& S = *reinterpret_cast<ChainLds<R>*>(smem_raw);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m0 = blockIdx.x * R;
+  const int M = k.M;
+  const StepDesc* table = k.program == PROG_DECODER ? PROG_DECODER_T
+                          : k.program == PROG_PROLOGUE ? PROG_PROLOGUE_T
+                          : k.program == PROG_RADAR_ENC ? PROG_RADAR_ENC_T : PROG_RADAR_LAYER_T;
+  const int nrep = k.program == PROG_RADAR ? k.nlayers : 1;
+
+  if (k.program == PROG_RADAR) {     // HEAD:539, 543-547, 596-598
+    for (int row = wave; row < R; row += CH_NW) {
+      const int grow = min(m0 + row, M - 1);
+      *reinterpret_cast<float4*>(&S.x[row][4 * lane]) = ld4(k.g[G_QF] + (size_t)grow * 256 + 4 * lane);
+    }
+    if (threadIdx.x < R) {
+      const int row = threadIdx.x, grow = min(m0 + row, M - 1);
+      const float* rr = k.ref_last + (size_t)grow * 3;
+      const float* pc = k.cam.pc;
+      S.cen[row][0] = __fadd_rn(__fmul_rn(rr[0], pc[3] - pc[0]), pc[0]);
+      S.cen[row][1] = __fadd_rn(__fmul_rn(rr[1], pc[4] - pc[1]), pc[1]);
+      S.cen[row][2] = rr[2];          // z stays normalised (HEAD:598 indexes an empty slice)
+      for (int j = 0; j < k.code; ++j) S.box[row][j] = k.box_in[(size_t)grow * k.code + j];
+    }
+    __syncthreads();
+  }
+
+  for (int rep = 0; rep < nrep; ++rep) {
+    const int pair0 = k.program == PROG_RADAR ? rep * RADAR_PAIRS : 0;
+#pragma unroll 1
+    for (int si = 0;; ++si) {
+      const StepDesc d = table[si];
+      if (d.kind == K_END) break;
+      if ((d.flags & F_SKIP_NONEXT) && !k.has_next) {
+        if (d.sync) __syncthreads();
+        continue;
+      }
+      switch (d.kind) {
+        case K_LOAD: {
+          const float* gsrc = k.g[d.gsel];
+          const int ld = k.g_ld[d.gsel], mod = k.g_mod[d.gsel];
+          float* dst = buf_ptr<R>(S, d.dst);
+          for (int row = wave; row < R; row += CH_NW) {
+            int grow = min(m0 + row, M - 1);
+            if (mod > 0) grow = grow % mod;
+            *reinterpret_cast<float4*>(dst + row * LD2 + 4 * lane) = ld4(gsrc + (size_t)grow * ld + 4 * lane);
+          }
+        } break;
+        case K_TOKENS: {   // radar token tile, zero padded to 64 columns
+          for (int i = threadIdx.x; i < R * 64; i += CH_NT) {
+            const int row = i >> 6, c = i & 63;
+            const int grow = min(m0 + row, M - 1);
+            S.a[row][c] = c < k.RI ? k.tokens[(size_t)grow * k.RI + c] : 0.0f;
+          }
+        } break;
+        case K_LINEAR: {
+          const tc_linear& pr = k.pairs[pair0 + d.wp];
+          LinSpec s;
+          s.K = d.K == 36 ? k.RI : d.K;
+          s.N = d.N == N_LOGITS ? k.nlogits : d.N == N_CODE ? k.code : d.N == N_CLS ? k.ncls : d.N;
+          const int woff = (d.flags & F_WOFF) ? 512 : 0;
+          s.W = pr.w + (size_t)woff * ((s.K + 63) & ~63);   // packed: a 64-row tile = 64 * kpad floats
+          s.bias = pr.b ? pr.b + woff : nullptr;
+          s.src = buf_ptr<R>(S, d.src); s.src_ld = buf_ld(d.src);
+          s.src2 = buf_ptr<R>(S, d.src2); s.src2_ld = buf_ld(d.src2);
+          s.dst = buf_ptr<R>(S, d.dst); s.dst_ld = buf_ld(d.dst);
+          s.res = buf_ptr<R>(S, d.res); s.res_ld = buf_ld(d.res);
+          s.gate = (d.flags & F_GATE) ? &S.gate[0] : nullptr;
+          s.act = d.act;
+          s.scale = (d.flags & F_SCALEQ) ? k.qscale : 1.0f; s.scale_cols = (d.flags & F_SCALEQ) ? 256 : 0;
+          s.gdst = nullptr; s.gdst_ld = 0;
+          if (d.gsel != G_NONE) {
+            s.gdst = k.g[d.gsel]; s.gdst_ld = k.g_ld[d.gsel];
+            if (d.gsel == G_CLS) s.gdst += (size_t)rep * M * k.ncls;
+          }
+          s.gt = d.gtsel != G_NONE ? k.g[d.gtsel] : nullptr; s.gt_ld = k.qpad; s.gt_rpb = k.Q;
+          s.m0 = m0; s.M = M;
+          linear_step<R>(s);
+        } break;
+        case K_LN: {   // dst = [relu] LN(a (+ relu(LN(c; wp2)))) (+ d): wave w owns rows 2w, 2w+1
+          const tc_linear& n = k.pairs[pair0 + d.wp];
+          const float* a = buf_ptr<R>(S, d.src); const int lda = buf_ld(d.src);
+          const float* c = buf_ptr<R>(S, d.src2); const int ldc = buf_ld(d.src2);
+          const float* dd = buf_ptr<R>(S, d.res);
+          float* dst = buf_ptr<R>(S, d.dst);
+          float* gdst = d.gsel != G_NONE ? k.g[d.gsel] : nullptr;
+          for (int row = wave; row < R; row += CH_NW) {
+            float4 v = *reinterpret_cast<const float4*>(a + row * lda + 4 * lane);
+            if (c != nullptr) {
+              const tc_linear& n2 = k.pairs[pair0 + d.wp2];
+              v = add4(v, relu4(ln_row(*reinterpret_cast<const float4*>(c + row * ldc + 4 * lane), n2.w, n2.b, lane)));
+            }
+            v = ln_row(v, n.w, n.b, lane);
+            if (d.flags & F_LN_RELU) v = relu4(v);
+            if (dd != nullptr) v = add4(v, *reinterpret_cast<const float4*>(dd + row * LD2 + 4 * lane));
+            *reinterpret_cast<float4*>(dst + row * LD2 + 4 * lane) = v;
+            if (gdst != nullptr && m0 + row < M) st4(gdst + (size_t)(m0 + row) * 256 + 4 * lane, v);
+          }
+        } break;
+        case K_POSENC: {   // Linear(3,256) + LN + ReLU of inverse_sigmoid(ref) or of raw token xyz
+          const tc_linear& l0 = k.pairs[pair0 + d.wp];
+          const tc_linear& n1 = k.pairs[pair0 + d.wp2];
+          float* dst = buf_ptr<R>(S, d.dst);
+          for (int row = wave; row < R; row += CH_NW) {
+            float p0, p1, p2;
+            if (d.src == B_A) { p0 = S.a[row][0]; p1 = S.a[row][1]; p2 = S.a[row][2]; }
+            else {
+              const int grow = min(m0 + row, M - 1);
+              p0 = inverse_sigmoidf_(k.ref_in[(size_t)grow * 3 + 0]);
+              p1 = inverse_sigmoidf_(k.ref_in[(size_t)grow * 3 + 1]);
+              p2 = inverse_sigmoidf_(k.ref_in[(size_t)grow * 3 + 2]);
+            }
+            *reinterpret_cast<float4*>(dst + row * LD2 + 4 * lane) =
+                posenc_l0_row(p0, p1, p2, l0.w, l0.b, n1.w, n1.b, lane);
+          }
+        } break;
+        case K_SAMPLE: {   // camera sampling of this block's 16 queries (2 per wave)
+          int pairs = 0;
+#pragma unroll 1
+          for (int row = wave; row < R; row += CH_NW) {
+            const int grow = min(m0 + row, M - 1);
+            int nvis = 0;
+            const float4 o = cam_sample_row<4>(k.cam, grow, grow / k.Q, &S.l[row][0], lane, nvis);
+            *reinterpret_cast<float4*>(&S.r[row][4 * lane]) = o;
+            if (m0 + row < M) pairs += nvis;
+          }
+          if (k.pair_counter != nullptr && lane == 0 && pairs > 0)
+            atomicAdd(k.pair_counter, (unsigned long long)pairs);
+        } break;
+        case K_REFUPD: {   // XFMR:195-203, HEAD:287-293
+          if (threadIdx.x < R && m0 + (int)threadIdx.x < M) {
+            const int row = threadIdx.x, grow = m0 + row;
+            const float* t = &S.l[row][0];
+            const float* rr = k.ref_in + (size_t)grow * 3;
+            const float nx = sigmoidf_(t[0] + inverse_sigmoidf_(rr[0]));
+            const float ny = sigmoidf_(t[1] + inverse_sigmoidf_(rr[1]));
+            const float nz = sigmoidf_(t[4] + inverse_sigmoidf_(rr[2]));
+            k.ref_out[(size_t)grow * 3 + 0] = nx;
+            k.ref_out[(size_t)grow * 3 + 1] = ny;
+            k.ref_out[(size_t)grow * 3 + 2] = nz;
+            if (k.box_m != nullptr) {
+              float* o = k.box_m + (size_t)grow * k.code;
+              for (int j = 0; j < k.code; ++j) o[j] = t[j];
+              const float* pc = k.cam.pc;
+              o[0] = nx * (pc[3] - pc[0]) + pc[0];
+              o[1] = ny * (pc[4] - pc[1]) + pc[1];
+              o[4] = nz * (pc[5] - pc[2]) + pc[2];
+            }
+          }
+        } break;
+        case K_RADAR_ATTN: {   // distance-gated attention, 2 queries per wave (HEAD:549-579)
+#pragma unroll 1
+          for (int row = wave; row < R; row += CH_NW) {
+            const int grow = min(m0 + row, M - 1);
+            const int b = grow / k.Q;
+            const float4 q4 = *reinterpret_cast<const float4*>(&S.t[row][4 * lane]);
+            const float* kv = (rep == 0 ? k.g[G_KV0] : rep == 1 ? k.g[G_KV1] : k.g[G_KV2]);
+            int count = 0;
+            const float4 o = radar_attn_row(S.cen[row][0], S.cen[row][1], S.box[row][3], S.box[row][6],
+                                            S.box[row][7], k.rmin[rep], k.rmax[rep], q4,
+                                            k.tokens + (size_t)b * k.T * k.RI, k.RI,
+                                            kv + (size_t)b * k.T * 512, 512, k.T, k.pad_mult, lane, count);
+            *reinterpret_cast<float4*>(&S.u[row][4 * lane]) = o;
+            if (lane == 0) {
+              S.gate[row] = count;
+              if (m0 + row < M) k.hits[(size_t)rep * M + m0 + row] = count;
+            }
+          }
+        } break;
+        case K_BOXADD: {   // box = reg + reference (HEAD:599-600, 664-665, 722-723); next ref (HEAD:615-617)
+          if (threadIdx.x < R) {
+            const int row = threadIdx.x;
+            float bx[12];
+            for (int j = 0; j < k.code; ++j) bx[j] = S.l[row][j];
+            bx[0] += S.cen[row][0]; bx[1] += S.cen[row][1]; bx[4] += S.cen[row][2];
+            for (int j = 0; j < k.code; ++j) S.box[row][j] = bx[j];
+            S.cen[row][0] = bx[0]; S.cen[row][1] = bx[1]; S.cen[row][2] = bx[4];
+            if (m0 + row < M) {
+              float* o = k.all_box + ((size_t)rep * M + m0 + row) * k.code;
+              for (int j = 0; j < k.code; ++j) o[j] = bx[j];
+            }
+          }
+        } break;
+        default: break;
+      }
+      if (d.sync) __syncthreads();
+    }
+  }
+}
+
+template <int R>
+int launch_r(const ChainK& k, hipStream_t s, const char* what) {
+  static bool done = false;
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<R>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)sizeof(ChainLds<R>));
+    if (e != hipSuccess) { set_error("chain: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    done = true;
+  }
+  hipLaunchKernelGGL(chain_kernel<R>, dim3((k.M + R - 1) / R), dim3(CH_NT), sizeof(ChainLds<R>), s, k);
+  return check_launch(what);
+}
+
+void init_k(ChainK& k) { memset(&k, 0, sizeof(k)); }
+
+// Row-tile height (measured, bench.py --batch 1/2/4): the smallest tile that still
+// gives about one workgroup per CU wins -- 4 rows for B = 1 (225 workgroups), 8 for
+// B = 2, 16 beyond (each weight register then feeds 4 MFMAs).
+int launch(const ChainK& k, hipStream_t s, const char* what) {
+  const char* e = getenv("TRANSCAR_CHAIN_ROWS");
+  const int forced = e ? atoi(e) : 0;
+  const int rows = forced ? forced : (k.M <= 1024 ? 4 : k.M <= 2048 ? 8 : 16);
+  if (rows == 4) return launch_r<4>(k, s, what);
+  if (rows == 8) return launch_r<8>(k, s, what);
+  return launch_r<16>(k, s, what);
+}
+
+}  // namespace
+
+void fill_camk(const CamSampleArgs& a, CamK& p);   // cam_sample.hip
+
+int launch_prologue(const PrologueArgs& a, hipStream_t s) {
+  ChainK k;
+  init_k(k);
+  k.program = PROG_PROLOGUE; k.M = a.M; k.Q = a.Q; k.has_next = 1;
+  k.pairs[0] = a.refpts; k.pairs[16] = a.in_proj;
+  k.g[G_POS] = const_cast<float*>(a.qe); k.g_ld[G_POS] = 512; k.g_mod[G_POS] = a.Q;
+  k.g[G_XIN] = const_cast<float*>(a.qe) + 256; k.g_ld[G_XIN] = 512; k.g_mod[G_XIN] = a.Q;
+  k.g[G_INITREF] = a.init_ref; k.g_ld[G_INITREF] = 3;
+  k.g[G_QK] = a.qk; k.g_ld[G_QK] = 512; k.g[G_VT] = a.vt;
+  k.qscale = a.qscale; k.qpad = a.qpad;
+  return launch(k, s, "chain(prologue)");
+}
+
+int launch_decoder_chain(const DecoderChainArgs& a, hipStream_t s) {
+  TC_REQUIRE(a.code <= 12 && a.cam.num_cams * a.cam.feats.num_levels <= 32, "decoder_chain: code/logit width");
+  ChainK k;
+  init_k(k);
+  k.program = PROG_DECODER; k.M = a.M; k.Q = a.Q; k.code = a.code;
+  k.nlogits = a.cam.num_cams * a.cam.feats.num_levels;
+  const tc_decoder_layer& w = *a.w;
+  const tc_pos_encoder& pe = w.position_encoder;
+  k.pairs[0] = w.self_attn.in_proj; k.pairs[1] = w.self_attn.out_proj;
+  k.pairs[2] = tc_linear{w.norm0.g, w.norm0.b};
+  k.pairs[3] = w.attention_weights; k.pairs[4] = w.output_proj; k.pairs[5] = pe.l0;
+  k.pairs[6] = tc_linear{pe.n1.g, pe.n1.b}; k.pairs[7] = pe.l3; k.pairs[8] = tc_linear{pe.n4.g, pe.n4.b};
+  k.pairs[9] = tc_linear{w.norm1.g, w.norm1.b}; k.pairs[10] = w.ffn0; k.pairs[11] = w.ffn1;
+  k.pairs[12] = tc_linear{w.norm2.g, w.norm2.b};
+  k.pairs[13] = w.reg.l0; k.pairs[14] = w.reg.l2; k.pairs[15] = w.reg.l4;
+  k.has_next = a.next_in_proj != nullptr;
+  if (k.has_next) k.pairs[16] = *a.next_in_proj;
+  k.g[G_ATTN_O] = const_cast<float*>(a.attn_o); k.g_ld[G_ATTN_O] = 256;
+  k.g[G_XIN] = const_cast<float*>(a.x_in); k.g_ld[G_XIN] = a.x_ld; k.g_mod[G_XIN] = a.x_mod;
+  k.g[G_POS] = const_cast<float*>(a.qe); k.g_ld[G_POS] = 512; k.g_mod[G_POS] = a.Q;
+  k.g[G_HS] = a.hs; k.g_ld[G_HS] = 256;
+  k.g[G_QK] = a.qk; k.g_ld[G_QK] = 512; k.g[G_VT] = a.vt;
+  k.qscale = a.qscale; k.qpad = a.qpad;
+  k.ref_in = a.ref_in; k.ref_out = a.ref_out; k.box_m = a.box_m;
+  fill_camk(a.cam, k.cam);
+  k.pair_counter = a.cam.pair_counter;
+  return launch(k, s, "chain(decoder)");
+}
+
+int launch_radar_encode(const RadarEncodeArgs& a, hipStream_t s) {
+  TC_REQUIRE(a.RI <= 64 && (a.RI & 3) == 0, "radar_encode: radar_in_dims=%d", a.RI);
+  TC_REQUIRE(a.nlayers == TC_MAX_RADAR_LAYERS, "radar_encode: %d radar layers (3 supported)", a.nlayers);
+  ChainK k;
+  init_k(k);
+  k.program = PROG_RADAR_ENC; k.M = a.M; k.Q = 1; k.RI = a.RI; k.tokens = a.tokens; k.has_next = 1;
+  k.pairs[0] = a.rpe.l0; k.pairs[1] = tc_linear{a.rpe.n1.g, a.rpe.n1.b}; k.pairs[2] = a.rpe.l3;
+  k.pairs[3] = tc_linear{a.rpe.n4.g, a.rpe.n4.b}; k.pairs[4] = a.f0; k.pairs[5] = a.f2; k.pairs[6] = a.f4;
+  for (int r = 0; r < TC_MAX_RADAR_LAYERS; ++r) {
+    k.pairs[7 + r] = a.kvproj[r];
+    k.g[G_KV0 + r] = a.kv[r]; k.g_ld[G_KV0 + r] = 512;
+  }
+  return launch(k, s, "chain(radar_encode)");
+}
+
+int launch_radar_chain(const RadarChainArgs& a, hipStream_t s) {
+  TC_REQUIRE(a.code <= 12 && a.ncls <= 32, "radar_chain: code=%d ncls=%d", a.code, a.ncls);
+  TC_REQUIRE(a.nlayers >= 1 && a.nlayers <= TC_MAX_RADAR_LAYERS, "radar_chain: nlayers=%d", a.nlayers);
+  ChainK k;
+  init_k(k);
+  k.program = PROG_RADAR; k.M = a.M; k.Q = a.Q; k.code = a.code; k.ncls = a.ncls; k.nlayers = a.nlayers;
+  k.has_next = 1;
+  for (int r = 0; r < a.nlayers; ++r) {
+    const tc_radar_layer& w = a.w[r];
+    tc_linear* p = &k.pairs[r * RADAR_PAIRS];
+    p[0] = w.attn.in_proj; p[1] = w.attn.out_proj; p[2] = tc_linear{w.norm2.g, w.norm2.b};
+    p[3] = w.linear1; p[4] = w.linear2; p[5] = tc_linear{w.norm3.g, w.norm3.b};
+    p[6] = w.final_cls.l0; p[7] = tc_linear{w.final_cls.n1.g, w.final_cls.n1.b}; p[8] = w.final_cls.l3;
+    p[9] = tc_linear{w.final_cls.n4.g, w.final_cls.n4.b}; p[10] = w.final_cls.l6;
+    p[11] = w.final_reg.l0; p[12] = w.final_reg.l2; p[13] = w.final_reg.l4;
+    k.rmin[r] = w.radius_min; k.rmax[r] = w.radius_max;
+    k.g[G_KV0 + r] = const_cast<float*>(a.kv[r]);
+  }
+  k.g[G_QF] = const_cast<float*>(a.qf);
+  k.g[G_CLS] = a.all_cls; k.g_ld[G_CLS] = a.ncls;
+  k.qscale = a.qscale;
+  k.tokens = a.tokens; k.RI = a.RI; k.T = a.T; k.pad_mult = a.pad_mult;
+  k.ref_last = a.ref_last; k.box_in = a.box_m;
+  for (int i = 0; i < 6; ++i) k.cam.pc[i] = a.pc[i];
+  k.all_box = a.all_box; k.hits = a.hits;
+  return launch(k, s, "chain(radar)");
+}
+
+}  // namespace tc

@@ -93,6 +93,9 @@ __global__ __launch_bounds__(NW * 64) void gemm16_kernel(GemmK p) {
     }
   }
 
+  // keep every load above issued before the first MFMA (hipcc otherwise sinks
+  // each load next to its use and leaves 1-2 loads in flight per wave)
+  __builtin_amdgcn_sched_barrier(0);
   f32x4 acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};

@@ -6,6 +6,7 @@
 // forward is capturable into a hipGraph and replayable.
 #include <math.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "kernels.hpp"
@@ -121,6 +122,7 @@ struct HeadWs {
   float *pos, *x, *qk, *vt, *attn_o, *t0, *t1, *t2, *ffn_h, *logits, *sampled;
   float *init_ref, *inter_refs, *hs, *reg_tmp, *box_m;
   float *tp0, *tp1, *f0, *f1, *f2, *radar_feat, *kv, *qproj, *rattn, *cxy, *addref, *qf;
+  float* kv3[TC_MAX_RADAR_LAYERS];
   int* hits;
   int qpad;
 };
@@ -146,6 +148,7 @@ static size_t head_ws_layout(const tc_head_weights* w, int B, int T, void* base,
   h.tp0 = a.take<float>(rt * C); h.tp1 = a.take<float>(rt * C);
   h.f0 = a.take<float>(rt * 64); h.f1 = a.take<float>(rt * 128); h.f2 = a.take<float>(rt * C);
   h.radar_feat = a.take<float>(rt * C); h.kv = a.take<float>(rt * 2 * C);
+  for (int i = 0; i < TC_MAX_RADAR_LAYERS; ++i) h.kv3[i] = a.take<float>(rt * 2 * C);
   h.qproj = a.take<float>(rows * C); h.rattn = a.take<float>(rows * C);
   h.cxy = a.take<float>(rows * 2); h.addref = a.take<float>(rows * 3);
   h.qf = a.take<float>(rows * C);
@@ -153,6 +156,168 @@ static size_t head_ws_layout(const tc_head_weights* w, int B, int T, void* base,
   if (out) *out = h;
   return a.off;
 }
+
+// ---- fused path: 16 launches per frame (chain.hip) ---------------------------
+struct SideStream {
+  hipStream_t s = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  bool ready = false;
+};
+
+static SideStream& side_stream() {
+  static thread_local SideStream sd;
+  if (!sd.ready) {
+    if (hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking) == hipSuccess &&
+        hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) == hipSuccess &&
+        hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) == hipSuccess)
+      sd.ready = true;
+    else
+      (void)hipGetLastError();
+  }
+  return sd;
+}
+
+static bool use_unfused() {
+  const char* e = getenv("TRANSCAR_UNFUSED");   // read per call: tests toggle it
+  return e != nullptr && e[0] == '1';
+}
+
+static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* feats, int B,
+                              const float* lidar2img, float img_h, float img_w,
+                              const float* radar_tokens, int T, int pad_mult, float* all_cls_scores,
+                              float* all_bbox_preds, const tc_head_aux* aux, const HeadWs& h,
+                              hipStream_t s) {
+  const int Q = w->num_query, C = w->embed_dims, L = w->num_layers, H = w->num_heads;
+  const int code = w->code_size, ncls = w->num_classes;
+  const int rows = B * Q, rt = B * T;
+  const float attn_qscale = 1.4426950408889634f / sqrtf((float)(C / H));   // 2^x softmax
+  unsigned long long* pairs = aux ? aux->sample_pairs : nullptr;
+  const bool radar = w->num_radar_layers > 0;
+
+  // the radar encoders and K/V projections do not depend on the decoder: they
+  // run on a side stream (a parallel branch when the forward is graph-captured)
+  SideStream& sd = side_stream();
+  hipStream_t rs = (radar && sd.ready) ? sd.s : s;
+  if (radar) {
+    if (rs != s) {
+      TC_HIP(hipEventRecord(sd.fork, s));
+      TC_HIP(hipStreamWaitEvent(rs, sd.fork, 0));
+    }
+    RadarEncodeArgs re;
+    re.tokens = radar_tokens; re.RI = w->radar_in_dims; re.M = rt;
+    re.rpe = w->radar_position_encoder; re.f0 = w->radar_feat0; re.f2 = w->radar_feat2;
+    re.f4 = w->radar_feat4; re.nlayers = w->num_radar_layers;
+    for (int r = 0; r < TC_MAX_RADAR_LAYERS; ++r) {
+      const tc_mha& m = w->radar[r].attn;
+      re.kvproj[r] = tc_linear{m.in_proj.w ? m.in_proj.w + (size_t)C * C : nullptr,
+                               m.in_proj.b ? m.in_proj.b + C : nullptr};
+      re.kv[r] = h.kv3[r];
+    }
+    re.radar_feat = nullptr;
+    TC_TRY(launch_radar_encode(re, rs));
+    if (rs != s) TC_HIP(hipEventRecord(sd.join, rs));
+  }
+
+  PrologueArgs pa;
+  pa.qe = w->query_embedding; pa.Q = Q; pa.M = rows; pa.refpts = w->reference_points;
+  pa.in_proj = w->layers[0].self_attn.in_proj; pa.init_ref = h.init_ref; pa.qk = h.qk; pa.vt = h.vt;
+  pa.qpad = h.qpad; pa.qscale = attn_qscale;
+  TC_TRY(launch_prologue(pa, s));
+  for (int lid = 0; lid < L; ++lid) {
+    const float* ref_in = lid == 0 ? h.init_ref : h.inter_refs + (size_t)(lid - 1) * rows * 3;
+    TC_TRY(launch_self_attn_core(h.qk, h.qk + C, 2 * C, h.vt, h.qpad, h.attn_o, C, B, Q, H, s));
+    DecoderChainArgs d;
+    d.attn_o = h.attn_o;
+    if (lid == 0) { d.x_in = w->query_embedding + C; d.x_ld = 2 * C; d.x_mod = Q; }
+    else { d.x_in = h.hs + (size_t)(lid - 1) * rows * C; d.x_ld = C; d.x_mod = 0; }
+    d.qe = w->query_embedding; d.Q = Q;
+    d.ref_in = ref_in; d.ref_out = h.inter_refs + (size_t)lid * rows * 3;
+    d.box_m = lid == L - 1 ? h.box_m : nullptr;
+    d.w = &w->layers[lid];
+    d.next_in_proj = lid + 1 < L ? &w->layers[lid + 1].self_attn.in_proj : nullptr;
+    d.qscale = attn_qscale;
+    d.hs = h.hs + (size_t)lid * rows * C; d.qk = h.qk; d.vt = h.vt; d.qpad = h.qpad;
+    d.cam.feats = *feats; d.cam.B = B; d.cam.Q = Q; d.cam.C = C; d.cam.num_cams = w->num_cams;
+    d.cam.lidar2img = lidar2img; d.cam.ref = ref_in; d.cam.logits = nullptr;
+    for (int i = 0; i < 6; ++i) d.cam.pc[i] = w->pc_range[i];
+    d.cam.img_h = img_h; d.cam.img_w = img_w; d.cam.out = nullptr; d.cam.vis = nullptr;
+    d.cam.pair_counter = pairs;
+    d.code = code; d.M = rows;
+    TC_TRY(launch_decoder_chain(d, s));
+  }
+  if (aux) {
+    if (aux->inter_states)
+      TC_HIP(hipMemcpyAsync(aux->inter_states, h.hs, (size_t)L * rows * C * 4, hipMemcpyDeviceToDevice, s));
+    if (aux->init_reference)
+      TC_HIP(hipMemcpyAsync(aux->init_reference, h.init_ref, (size_t)rows * 3 * 4, hipMemcpyDeviceToDevice, s));
+    if (aux->inter_references)
+      TC_HIP(hipMemcpyAsync(aux->inter_references, h.inter_refs, (size_t)L * rows * 3 * 4,
+                            hipMemcpyDeviceToDevice, s));
+  }
+  if (!radar) return 0;
+  if (rs != s) TC_HIP(hipStreamWaitEvent(s, sd.join, 0));
+  RadarChainArgs rc;
+  rc.qf = h.hs + (size_t)(L - 1) * rows * C;
+  rc.ref_last = h.inter_refs + (size_t)(L - 1) * rows * 3;
+  rc.box_m = h.box_m; rc.tokens = radar_tokens; rc.RI = w->radar_in_dims;
+  for (int r = 0; r < TC_MAX_RADAR_LAYERS; ++r) { rc.kv[r] = h.kv3[r]; rc.w[r] = w->radar[r]; }
+  rc.nlayers = w->num_radar_layers; rc.Q = Q; rc.T = T; rc.pad_mult = pad_mult; rc.code = code;
+  rc.ncls = ncls; rc.M = rows; rc.qscale = 1.0f / sqrtf((float)(C / H));
+  for (int i = 0; i < 6; ++i) rc.pc[i] = w->pc_range[i];
+  rc.all_cls = all_cls_scores; rc.all_box = all_bbox_preds; rc.hits = h.hits;
+  TC_TRY(launch_radar_chain(rc, s));
+  if (aux && aux->radar_hit_counts)
+    TC_HIP(hipMemcpyAsync(aux->radar_hit_counts, h.hits, (size_t)w->num_radar_layers * rows * 4,
+                          hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
+// ---- packed weights for the fused chains (pack.hip) --------------------------
+struct PackItem { const float* src; int N, K; const float** slot; };
+
+static int collect_pack_items(const tc_head_weights* w, tc_head_weights* v, PackItem* it) {
+  const int C = w->embed_dims, F = w->ffn_dims, NL = w->num_cams * w->num_levels;
+  const int code = w->code_size, ncls = w->num_classes;
+  int n = 0;
+  auto add = [&](const tc_linear& src, tc_linear& dst, int N, int K) {
+    it[n].src = src.w; it[n].N = N; it[n].K = K; it[n].slot = &dst.w; ++n;
+  };
+  add(w->reference_points, v->reference_points, 3, C);
+  for (int l = 0; l < w->num_layers; ++l) {
+    const tc_decoder_layer& a = w->layers[l]; tc_decoder_layer& b = v->layers[l];
+    add(a.self_attn.in_proj, b.self_attn.in_proj, 3 * C, C);
+    add(a.self_attn.out_proj, b.self_attn.out_proj, C, C);
+    add(a.attention_weights, b.attention_weights, NL, C);
+    add(a.output_proj, b.output_proj, C, C);
+    add(a.position_encoder.l3, b.position_encoder.l3, C, C);
+    add(a.ffn0, b.ffn0, F, C);
+    add(a.ffn1, b.ffn1, C, F);
+    add(a.reg.l0, b.reg.l0, C, C);
+    add(a.reg.l2, b.reg.l2, C, C);
+    add(a.reg.l4, b.reg.l4, code, C);
+  }
+  if (w->num_radar_layers > 0) {
+    add(w->radar_position_encoder.l3, v->radar_position_encoder.l3, C, C);
+    add(w->radar_feat0, v->radar_feat0, 64, w->radar_in_dims);
+    add(w->radar_feat2, v->radar_feat2, 128, 64);
+    add(w->radar_feat4, v->radar_feat4, C, 128);
+    for (int r = 0; r < w->num_radar_layers; ++r) {
+      const tc_radar_layer& a = w->radar[r]; tc_radar_layer& b = v->radar[r];
+      add(a.attn.in_proj, b.attn.in_proj, 3 * C, C);
+      add(a.attn.out_proj, b.attn.out_proj, C, C);
+      add(a.linear1, b.linear1, F, C);
+      add(a.linear2, b.linear2, C, F);
+      add(a.final_cls.l0, b.final_cls.l0, C, C);
+      add(a.final_cls.l3, b.final_cls.l3, C, C);
+      add(a.final_cls.l6, b.final_cls.l6, ncls, C);
+      add(a.final_reg.l0, b.final_reg.l0, C, C);
+      add(a.final_reg.l2, b.final_reg.l2, C, C);
+      add(a.final_reg.l4, b.final_reg.l4, code, C);
+    }
+  }
+  return n;
+}
+constexpr int MAX_PACK_ITEMS = 1 + 10 * TC_MAX_LAYERS + 4 + 10 * TC_MAX_RADAR_LAYERS;
 
 }  // namespace tc
 
@@ -313,16 +478,44 @@ int tc_box_decode_topk(const float* cls_scores, const float* bbox_preds, int B, 
                            workspace_bytes, as_stream(stream));
 }
 
+size_t tc_head_packed_bytes(const tc_head_weights* w) {
+  if (check_dims(w) != 0) return 0;
+  tc_head_weights view = *w;
+  PackItem items[MAX_PACK_ITEMS];
+  const int n = collect_pack_items(w, &view, items);
+  size_t total = 0;
+  for (int i = 0; i < n; ++i) total += arena_slice(packed_floats(items[i].N, items[i].K), 4);
+  return total;
+}
+
+int tc_head_pack_weights(const tc_head_weights* w, void* packed, size_t packed_bytes,
+                         tc_head_weights* packed_view, tc_stream_t stream) {
+  TC_TRY(check_dims(w));
+  TC_REQUIRE(packed != nullptr && packed_view != nullptr, "pack_weights: null output");
+  TC_REQUIRE(packed_bytes >= tc_head_packed_bytes(w), "pack_weights: buffer too small");
+  *packed_view = *w;
+  PackItem items[MAX_PACK_ITEMS];
+  const int n = collect_pack_items(w, packed_view, items);
+  Arena a(packed, packed_bytes);
+  for (int i = 0; i < n; ++i) {
+    TC_REQUIRE(items[i].src != nullptr, "pack_weights: weight %d is null", i);
+    float* dst = a.take<float>(packed_floats(items[i].N, items[i].K));
+    TC_TRY(launch_pack_linear(items[i].src, items[i].N, items[i].K, dst, as_stream(stream)));
+    *items[i].slot = dst;
+  }
+  return 0;
+}
+
 size_t tc_head_workspace_bytes(const tc_head_weights* w, int B, int T) {
   if (check_dims(w) != 0) return 0;
   return head_ws_layout(w, B, T, nullptr, ~size_t(0), nullptr);
 }
 
-int tc_head_forward(const tc_head_weights* w, const tc_feats_nhwc* feats, int B,
-                    const float* lidar2img, float img_h, float img_w, const float* radar_tokens,
-                    int T, int pad_mult, float* all_cls_scores, float* all_bbox_preds,
-                    const tc_head_aux* aux, void* workspace, size_t workspace_bytes,
-                    tc_stream_t stream) {
+int tc_head_forward(const tc_head_weights* w, const tc_head_weights* packed_view,
+                    const tc_feats_nhwc* feats, int B, const float* lidar2img, float img_h,
+                    float img_w, const float* radar_tokens, int T, int pad_mult,
+                    float* all_cls_scores, float* all_bbox_preds, const tc_head_aux* aux,
+                    void* workspace, size_t workspace_bytes, tc_stream_t stream) {
   TC_TRY(check_dims(w));
   TC_REQUIRE(feats != nullptr && feats->num_levels == w->num_levels, "feats: num_levels mismatch");
   TC_REQUIRE(B >= 1, "B=%d", B);
@@ -337,8 +530,12 @@ int tc_head_forward(const tc_head_weights* w, const tc_feats_nhwc* feats, int B,
   const int rows = B * Q, rt = B * T;
   const float* pc = w->pc_range;
   unsigned long long* pairs = aux ? aux->sample_pairs : nullptr;
+  if (packed_view != nullptr && !use_unfused())
+    return head_forward_fused(packed_view, feats, B, lidar2img, img_h, img_w, radar_tokens, T, pad_mult,
+                              all_cls_scores, all_bbox_preds, aux, h, s);
 
-  // XFMR:119-123
+  // ---- operator-by-operator path (TRANSCAR_UNFUSED=1): the first build, kept
+  // as an in-tree cross-check of the fused chains.  XFMR:119-123
   TC_TRY(launch_split_embed(w->query_embedding, Q, C, B, h.pos, h.x, s));
   TC_TRY(launch_init_ref(w->query_embedding, Q, C, w->reference_points.w, w->reference_points.b,
                          h.init_ref, B, s));

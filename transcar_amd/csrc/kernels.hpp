@@ -75,6 +75,47 @@ struct CamSampleArgs {
 };
 int launch_cam_sample(const CamSampleArgs& a, hipStream_t s);
 
+// ---- chain.hip: fused row-chain kernels (16 rows per workgroup) ------------
+struct PrologueArgs {
+  const float* qe; int Q, M;                 // query_embedding [Q,512]; M = B*Q rows
+  tc_linear refpts, in_proj;                 // transformer.reference_points, layer-0 in_proj
+  float* init_ref; float* qk; float* vt; int qpad; float qscale;
+};
+int launch_prologue(const PrologueArgs& a, hipStream_t s);
+
+struct DecoderChainArgs {
+  const float* attn_o;                       // [M,256]
+  const float* x_in; int x_ld, x_mod;        // layer input rows (row % x_mod when x_mod > 0)
+  const float* qe; int Q;
+  const float* ref_in; float* ref_out; float* box_m;
+  const tc_decoder_layer* w;
+  const tc_linear* next_in_proj;             // next layer's in_proj (null after the last layer)
+  float qscale;
+  float* hs; float* qk; float* vt; int qpad;
+  CamSampleArgs cam;                         // feats, lidar2img, pc, img size (ref/logits/out unused)
+  int code, M;
+};
+int launch_decoder_chain(const DecoderChainArgs& a, hipStream_t s);
+
+struct RadarEncodeArgs {
+  const float* tokens; int RI, M;            // [M, RI]
+  tc_pos_encoder rpe; tc_linear f0, f2, f4;
+  int nlayers; tc_linear kvproj[TC_MAX_RADAR_LAYERS]; float* kv[TC_MAX_RADAR_LAYERS];
+  float* radar_feat;                         // optional [M,256]
+};
+int launch_radar_encode(const RadarEncodeArgs& a, hipStream_t s);
+
+struct RadarChainArgs {
+  const float* qf; const float* ref_last; const float* box_m;
+  const float* tokens; int RI;
+  const float* kv[TC_MAX_RADAR_LAYERS];
+  tc_radar_layer w[TC_MAX_RADAR_LAYERS];
+  int nlayers, Q, T, pad_mult, code, ncls, M;
+  float qscale; float pc[6];
+  float* all_cls; float* all_box; int* hits;
+};
+int launch_radar_chain(const RadarChainArgs& a, hipStream_t s);
+
 // ---- self_attn.hip ---------------------------------------------------------
 // q,k: [B*Q, ld] token-major with head h at column h*32; vt: [B, C, ldt] (V transposed)
 int launch_self_attn_core(const float* q, const float* k, int ld, const float* vt, int ldt,
@@ -93,6 +134,10 @@ struct RadarAttnArgs {
   int* hit_counts;                     // [B*Q]
 };
 int launch_radar_attn(const RadarAttnArgs& a, hipStream_t s);
+
+// ---- pack.hip: one-time weight re-layout for the fused chains ---------------
+size_t packed_floats(int N, int K);
+int launch_pack_linear(const float* W, int N, int K, float* P, hipStream_t s);
 
 // ---- transpose.hip ---------------------------------------------------------
 int launch_nchw_to_nhwc(const float* src, float* dst, int n_img, int C, int H, int W, hipStream_t s);

@@ -18,7 +18,9 @@
 // (|x|^2 + |y|^2 - 2 x.y as a K=4 FMA chain, clamp 1e-30, sqrt): its rounding
 // noise (up to 7e-4 m at these coordinates) is part of the reference's gate,
 // and an "exact" distance would flip more gate decisions, not fewer.
+// The per-query routine lives in rowdev.hpp (shared with chain.hip).
 #include "kernels.hpp"
+#include "rowdev.hpp"
 
 namespace tc {
 
@@ -29,76 +31,19 @@ struct RadK {
   float* attn_out; int* hits;
 };
 
-// torch.cdist(p=2) via _euclidean_dist: [-2x, |x|^2, 1] . [y, 1, |y|^2]
-__device__ __forceinline__ float cdist_mm(float x0, float x1, float xn, float y0, float y1, float yn) {
-  float t = __fmul_rn(__fmul_rn(-2.0f, x0), y0);
-  t = fmaf(__fmul_rn(-2.0f, x1), y1, t);
-  t = __fadd_rn(t, xn);
-  t = __fadd_rn(t, yn);
-  return sqrtf(fmaxf(t, 1e-30f));
-}
-__device__ __forceinline__ float sqnorm2(float a, float b) {
-  return __fadd_rn(__fmul_rn(a, a), __fmul_rn(b, b));
-}
-
 __global__ __launch_bounds__(256) void radar_attn_kernel(RadK p) {
   const int lane = threadIdx.x & 63;
   const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
   if (row >= p.B * p.Q) return;
   const int b = row / p.Q;
-  // gate geometry, HEAD:553-567
   const float cx = p.cxy[(size_t)row * p.ld_c + 0], cy = p.cxy[(size_t)row * p.ld_c + 1];
   const float* bx = p.box + (size_t)row * p.code;
-  const float len = expf(bx[3]);
-  const float rs = -bx[6], rc = -bx[7];
-  const float ox = __fmul_rn(__fmul_rn(len, 0.25f), rs), oy = __fmul_rn(__fmul_rn(len, 0.25f), rc);
-  const float fx = __fadd_rn(cx, ox), fy = __fadd_rn(cy, oy);
-  const float bxx = __fsub_rn(cx, ox), byy = __fsub_rn(cy, oy);
-  const float rad = fminf(fmaxf(len / 2.0f, p.rmin), p.rmax);
-  const float cn = sqnorm2(cx, cy), fn = sqnorm2(fx, fy), bn = sqnorm2(bxx, byy);
-
   const float4 q4 = ld4(p.qproj + (size_t)row * p.ldq + 4 * lane);
-  float m = -INFINITY, l = 0.0f;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   int count = 0;
-  for (int t0 = 0; t0 < p.T; t0 += 64) {
-    const int t = t0 + lane;
-    bool hit = false;
-    if (t < p.T) {
-      const float* y = p.rxy + ((size_t)b * p.T + t) * p.ld_xy;
-      const float y0 = y[0], y1 = y[1];
-      const float yn = sqnorm2(y0, y1);
-      hit = (cdist_mm(cx, cy, cn, y0, y1, yn) < rad) || (cdist_mm(fx, fy, fn, y0, y1, yn) < rad) ||
-            (cdist_mm(bxx, byy, bn, y0, y1, yn) < rad);
-    }
-    unsigned long long mask = __ballot(hit);
-    while (mask) {
-      const int j = __ffsll((long long)mask) - 1;
-      mask &= mask - 1;
-      const int tok = t0 + j;
-      const int mult = (tok == p.T - 1) ? p.pad_mult : 1;
-      count += mult;
-      const float* kvr = p.kv + ((size_t)b * p.T + tok) * p.ldkv + 4 * lane;
-      const float4 k4 = ld4(kvr);
-      const float4 v4 = ld4(kvr + 256);
-      float s = q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w;
-      s += __shfl_xor(s, 1, 64);
-      s += __shfl_xor(s, 2, 64);
-      s += __shfl_xor(s, 4, 64);
-      const float mnew = fmaxf(m, s);
-      const float alpha = expf(m - mnew);
-      const float pw = (float)mult * expf(s - mnew);
-      l = l * alpha + pw;
-      acc.x = acc.x * alpha + pw * v4.x; acc.y = acc.y * alpha + pw * v4.y;
-      acc.z = acc.z * alpha + pw * v4.z; acc.w = acc.w * alpha + pw * v4.w;
-      m = mnew;
-    }
-  }
-  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (count > 0) {
-    const float inv = 1.0f / l;
-    o = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
-  }
+  const float4 o = radar_attn_row(cx, cy, bx[3], bx[6], bx[7], p.rmin, p.rmax, q4,
+                                  p.rxy + (size_t)b * p.T * p.ld_xy, p.ld_xy,
+                                  p.kv + (size_t)b * p.T * p.ldkv, p.ldkv, p.T, p.pad_mult, lane,
+                                  count);
   st4(p.attn_out + (size_t)row * 256 + 4 * lane, o);
   if (lane == 0) p.hits[row] = count;
 }

@@ -1,0 +1,198 @@
+// Row-local device routines shared by the stand-alone operator kernels and the
+// fused row-chain kernels (chain.hip).  "Row" = one query (or radar token) of
+// C = 256 channels owned by ONE wavefront: lane l holds channels 4l..4l+3.
+#pragma once
+#include "common.hpp"
+#include "../../include/transcar_hip.h"
+
+namespace tc {
+
+__device__ __forceinline__ float4 relu4(float4 v) {
+  return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+}
+__device__ __forceinline__ float4 add4(float4 a, float4 b) {
+  return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+
+// LayerNorm over the 256 channels of a row held as one float4 per lane; eps 1e-5.
+__device__ __forceinline__ float4 ln_row(float4 v, const float* g, const float* b, int lane) {
+  float s = wave_sum(v.x + v.y + v.z + v.w);
+  const float mean = s * (1.0f / 256.0f);
+  float4 d = make_float4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
+  float q = wave_sum(d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w);
+  const float rstd = 1.0f / sqrtf(q * (1.0f / 256.0f) + 1e-5f);
+  const float4 gg = ld4(g + 4 * lane), bb = ld4(b + 4 * lane);
+  return make_float4(d.x * rstd * gg.x + bb.x, d.y * rstd * gg.y + bb.y,
+                     d.z * rstd * gg.z + bb.z, d.w * rstd * gg.w + bb.w);
+}
+
+// position-encoder layer 0: relu(LN(W0 p + b0)), W0 [256,3]
+__device__ __forceinline__ float4 posenc_l0_row(float p0, float p1, float p2, const float* w0,
+                                                const float* b0, const float* g, const float* beta,
+                                                int lane) {
+  float v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = 4 * lane + i;
+    v[i] = w0[c * 3 + 0] * p0 + w0[c * 3 + 1] * p1 + w0[c * 3 + 2] * p2 + b0[c];
+  }
+  return relu4(ln_row(make_float4(v[0], v[1], v[2], v[3]), g, beta, lane));
+}
+
+// ---- camera sampling of one query (XFMR:365-373, 381-422) -------------------
+struct CamK {
+  const float* data[TC_MAX_LEVELS];
+  int H[TC_MAX_LEVELS], W[TC_MAX_LEVELS];
+  int num_levels, B, Q, num_cams;
+  const float* l2i; const float* ref; const float* logits;
+  float pc[6]; float img_h, img_w;
+  float* out; unsigned char* vis; unsigned long long* pair_counter;
+};
+
+// lg: the query's num_cams*L attention logits (any address space).
+template <int L>
+__device__ __forceinline__ float4 cam_sample_row(const CamK& p, int row, int b, const float* lg,
+                                                 int lane, int& nvis) {
+  const int N = p.num_cams;
+  // XFMR:389-391
+  const float rx = p.ref[(size_t)row * 3 + 0] * (p.pc[3] - p.pc[0]) + p.pc[0];
+  const float ry = p.ref[(size_t)row * 3 + 1] * (p.pc[4] - p.pc[1]) + p.pc[1];
+  const float rz = p.ref[(size_t)row * 3 + 2] * (p.pc[5] - p.pc[2]) + p.pc[2];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  nvis = 0;
+  for (int cam = 0; cam < N; ++cam) {
+    const float* m = p.l2i + ((size_t)b * N + cam) * 16;
+    // XFMR:398-409
+    const float cx = m[0] * rx + m[1] * ry + m[2] * rz + m[3];
+    const float cy = m[4] * rx + m[5] * ry + m[6] * rz + m[7];
+    const float cz = m[8] * rx + m[9] * ry + m[10] * rz + m[11];
+    const float eps = 1e-5f;
+    const float zc = fmaxf(cz, eps);
+    float u = (cx / zc) / p.img_w;
+    float v = (cy / zc) / p.img_h;
+    u = (u - 0.5f) * 2.0f;
+    v = (v - 0.5f) * 2.0f;
+    const bool visible = (cz > eps) && (u > -1.0f) && (u < 1.0f) && (v > -1.0f) && (v < 1.0f);
+    if (p.vis != nullptr && lane == 0) p.vis[(size_t)row * N + cam] = visible ? 1 : 0;
+    if (!visible) continue;
+    ++nvis;
+
+    float4 tap[L][4];
+    float wgt[L][4];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const int H = p.H[l], W = p.W[l];
+      // F.grid_sample, bilinear, zeros padding, align_corners=False
+      const float ix = ((u + 1.0f) * (float)W - 1.0f) * 0.5f;
+      const float iy = ((v + 1.0f) * (float)H - 1.0f) * 0.5f;
+      const float xw = floorf(ix), yn = floorf(iy);
+      const float w_ = ix - xw, e_ = 1.0f - w_, n_ = iy - yn, s_ = 1.0f - n_;
+      const int x0 = (int)xw, y0 = (int)yn, x1 = x0 + 1, y1 = y0 + 1;
+      const bool vx0 = (x0 >= 0) && (x0 < W), vx1 = (x1 >= 0) && (x1 < W);
+      const bool vy0 = (y0 >= 0) && (y0 < H), vy1 = (y1 >= 0) && (y1 < H);
+      wgt[l][0] = (vx0 && vy0) ? s_ * e_ : 0.0f;   // nw
+      wgt[l][1] = (vx1 && vy0) ? s_ * w_ : 0.0f;   // ne
+      wgt[l][2] = (vx0 && vy1) ? n_ * e_ : 0.0f;   // sw
+      wgt[l][3] = (vx1 && vy1) ? n_ * w_ : 0.0f;   // se
+      const int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x1, 0), W - 1);
+      const int yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y1, 0), H - 1);
+      const float* base = p.data[l] + ((size_t)(b * N + cam) * H * W) * 256 + 4 * lane;
+      tap[l][0] = ld4(base + ((size_t)yc0 * W + xc0) * 256);
+      tap[l][1] = ld4(base + ((size_t)yc0 * W + xc1) * 256);
+      tap[l][2] = ld4(base + ((size_t)yc1 * W + xc0) * 256);
+      tap[l][3] = ld4(base + ((size_t)yc1 * W + xc1) * 256);
+    }
+    float4 camacc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      float4 s;
+      s.x = tap[l][0].x * wgt[l][0] + tap[l][1].x * wgt[l][1] + tap[l][2].x * wgt[l][2] + tap[l][3].x * wgt[l][3];
+      s.y = tap[l][0].y * wgt[l][0] + tap[l][1].y * wgt[l][1] + tap[l][2].y * wgt[l][2] + tap[l][3].y * wgt[l][3];
+      s.z = tap[l][0].z * wgt[l][0] + tap[l][1].z * wgt[l][1] + tap[l][2].z * wgt[l][2] + tap[l][3].z * wgt[l][3];
+      s.w = tap[l][0].w * wgt[l][0] + tap[l][1].w * wgt[l][1] + tap[l][2].w * wgt[l][2] + tap[l][3].w * wgt[l][3];
+      // XFMR:367 -- NaN -> 0 on the sampled value
+      if (s.x != s.x) s.x = 0.f;
+      if (s.y != s.y) s.y = 0.f;
+      if (s.z != s.z) s.z = 0.f;
+      if (s.w != s.w) s.w = 0.f;
+      const float a = sigmoidf_(lg[cam * L + l]);   // XFMR:370, mask == 1 here
+      camacc.x += s.x * a; camacc.y += s.y * a; camacc.z += s.z * a; camacc.w += s.w * a;
+    }
+    acc.x += camacc.x; acc.y += camacc.y; acc.z += camacc.z; acc.w += camacc.w;
+  }
+  return acc;
+}
+
+// ---- distance-gated radar attention of one query (HEAD:549-579) -------------
+// torch.cdist(p=2) via _euclidean_dist: [-2x, |x|^2, 1] . [y, 1, |y|^2]
+__device__ __forceinline__ float cdist_mm(float x0, float x1, float xn, float y0, float y1, float yn) {
+  float t = __fmul_rn(__fmul_rn(-2.0f, x0), y0);
+  t = fmaf(__fmul_rn(-2.0f, x1), y1, t);
+  t = __fadd_rn(t, xn);
+  t = __fadd_rn(t, yn);
+  return sqrtf(fmaxf(t, 1e-30f));
+}
+__device__ __forceinline__ float sqnorm2(float a, float b) {
+  return __fadd_rn(__fmul_rn(a, a), __fmul_rn(b, b));
+}
+
+// cx,cy: gate centre (m); b3,b6,b7: log-length, sin, cos of the previous box;
+// q4: this lane's 4 channels of the projected, scaled query;
+// rxy: xy of token t at rxy[t*ld_xy + {0,1}]; kv: token t at kv[t*ldkv]: K | V (256 each).
+// Returns the attention output (zero if no hit); count = gated tokens (with multiplicity).
+__device__ __forceinline__ float4 radar_attn_row(float cx, float cy, float b3, float b6, float b7,
+                                                 float rmin, float rmax, float4 q4,
+                                                 const float* rxy, int ld_xy, const float* kv,
+                                                 int ldkv, int T, int pad_mult, int lane, int& count) {
+  // gate geometry, HEAD:553-567
+  const float len = expf(b3);
+  const float rs = -b6, rc = -b7;
+  const float ox = __fmul_rn(__fmul_rn(len, 0.25f), rs), oy = __fmul_rn(__fmul_rn(len, 0.25f), rc);
+  const float fx = __fadd_rn(cx, ox), fy = __fadd_rn(cy, oy);
+  const float bxx = __fsub_rn(cx, ox), byy = __fsub_rn(cy, oy);
+  const float rad = fminf(fmaxf(len / 2.0f, rmin), rmax);
+  const float cn = sqnorm2(cx, cy), fn = sqnorm2(fx, fy), bn = sqnorm2(bxx, byy);
+  float m = -INFINITY, l = 0.0f;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  count = 0;
+  for (int t0 = 0; t0 < T; t0 += 64) {
+    const int t = t0 + lane;
+    bool hit = false;
+    if (t < T) {
+      const float* y = rxy + (size_t)t * ld_xy;
+      const float y0 = y[0], y1 = y[1];
+      const float yn = sqnorm2(y0, y1);
+      hit = (cdist_mm(cx, cy, cn, y0, y1, yn) < rad) || (cdist_mm(fx, fy, fn, y0, y1, yn) < rad) ||
+            (cdist_mm(bxx, byy, bn, y0, y1, yn) < rad);
+    }
+    unsigned long long mask = __ballot(hit);
+    while (mask) {
+      const int j = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      const int tok = t0 + j;
+      const int mult = (tok == T - 1) ? pad_mult : 1;
+      count += mult;
+      const float* kvr = kv + (size_t)tok * ldkv + 4 * lane;
+      const float4 k4 = ld4(kvr);
+      const float4 v4 = ld4(kvr + 256);
+      float s = q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w;
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 4, 64);
+      const float mnew = fmaxf(m, s);
+      const float alpha = expf(m - mnew);
+      const float pw = (float)mult * expf(s - mnew);
+      l = l * alpha + pw;
+      acc.x = acc.x * alpha + pw * v4.x; acc.y = acc.y * alpha + pw * v4.y;
+      acc.z = acc.z * alpha + pw * v4.z; acc.w = acc.w * alpha + pw * v4.w;
+      m = mnew;
+    }
+  }
+  if (count > 0) {
+    const float inv = 1.0f / l;
+    return make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+  }
+  return make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+}  // namespace tc

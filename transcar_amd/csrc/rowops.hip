@@ -5,27 +5,11 @@
 // access, and the LayerNorm statistics are two wave-wide shuffle reductions.
 // All of it is HBM/L2-bound elementwise work.
 #include "kernels.hpp"
+#include "rowdev.hpp"
 
 namespace tc {
 
 struct Pc6 { float v[6]; };
-
-__device__ __forceinline__ float4 ln_row(float4 v, const float* g, const float* b, int lane) {
-  float s = wave_sum(v.x + v.y + v.z + v.w);
-  const float mean = s * (1.0f / 256.0f);
-  float4 d = make_float4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
-  float q = wave_sum(d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w);
-  const float rstd = 1.0f / sqrtf(q * (1.0f / 256.0f) + 1e-5f);
-  const float4 gg = ld4(g + 4 * lane), bb = ld4(b + 4 * lane);
-  return make_float4(d.x * rstd * gg.x + bb.x, d.y * rstd * gg.y + bb.y,
-                     d.z * rstd * gg.z + bb.z, d.w * rstd * gg.w + bb.w);
-}
-__device__ __forceinline__ float4 relu4(float4 v) {
-  return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-}
-__device__ __forceinline__ float4 add4(float4 a, float4 b) {
-  return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
-}
 
 struct LnK {
   const float *a, *b, *c, *g2, *b2, *gamma, *beta, *d;
@@ -68,13 +52,7 @@ __global__ __launch_bounds__(256) void posenc_l1_kernel(const float* src, int ld
   if (row >= M) return;
   float p0 = src[(size_t)row * ld + 0], p1 = src[(size_t)row * ld + 1], p2 = src[(size_t)row * ld + 2];
   if (inv_sig) { p0 = inverse_sigmoidf_(p0); p1 = inverse_sigmoidf_(p1); p2 = inverse_sigmoidf_(p2); }
-  float v[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = 4 * lane + i;
-    v[i] = w0[c * 3 + 0] * p0 + w0[c * 3 + 1] * p1 + w0[c * 3 + 2] * p2 + b0[c];
-  }
-  float4 o = relu4(ln_row(make_float4(v[0], v[1], v[2], v[3]), g, beta, lane));
+  const float4 o = posenc_l0_row(p0, p1, p2, w0, b0, g, beta, lane);
   st4(y + (size_t)row * 256 + 4 * lane, o);
 }
 

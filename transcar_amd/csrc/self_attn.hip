@@ -69,6 +69,7 @@ __global__ __launch_bounds__(SA_NW * 64) void self_attn_kernel(const float* __re
     const int key0 = t * 16;
     KVFrag nxt = cur;
     if (t + SA_NW < ntiles) nxt = load_kv(k, vbase, ld, ldt, brow, h, (t + SA_NW) * 16, r, g, Q);
+    __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this tile's MFMAs
 
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     s = MFMA4(cur.ka.x, qa.x, s); s = MFMA4(cur.ka.y, qa.y, s);

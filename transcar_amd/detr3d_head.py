@@ -228,8 +228,27 @@ class Detr3DHead(BaseModule):
             rl.final_cls = cls_branch_view(getattr(self, 'final_cls' + asfx))
             rl.final_reg = reg_branch_view(getattr(self, 'final_reg' + asfx))
             rl.radius_min, rl.radius_max = RADAR_RADII[r]
+        # one-time re-layout for the fused row-chain kernels (tc_head_pack_weights)
+        lib = L.lib()
+        nbytes = lib.tc_head_packed_bytes(C.byref(w))
+        if nbytes == 0:
+            raise L.TransCARHipError(lib.tc_last_error().decode())
+        dev = self.query_embedding.weight.device
+        self._packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self._packed_view = L.tc_head_weights()
+        L.check(lib.tc_head_pack_weights(
+            C.byref(w), self._packed.data_ptr(), nbytes,
+            C.byref(self._packed_view),
+            C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+            'tc_head_pack_weights')
         self._weights = w
         return w
+
+    def refresh_weights(self):
+        """Re-read the parameter pointers and re-pack the weights; call after
+        the parameters were changed in place (e.g. an optimizer step)."""
+        self._weights = None
+        return self.head_weights()
 
     # ------------------------------------------------------------------
     # forward
@@ -284,7 +303,8 @@ class Detr3DHead(BaseModule):
                 sample_pairs=torch.zeros(1, dtype=torch.int64, device=dev))
             aux_s = L.tc_head_aux(*[t.data_ptr() for t in aux_t.values()])
         L.check(lib.tc_head_forward(
-            C.byref(w), C.byref(fv), B, lidar2img.data_ptr(),
+            C.byref(w), C.byref(self._packed_view), C.byref(fv), B,
+            lidar2img.data_ptr(),
             float(img_hw[0]), float(img_hw[1]), tokens.data_ptr(), T,
             int(pad_mult), cls.data_ptr(), box.data_ptr(),
             C.byref(aux_s) if aux_s is not None else None,
