@@ -89,84 +89,107 @@ def one_step(head, inp):
     return outs, dec
 
 
-def time_events(fn, iters, warm=5):
-    """Average device time of fn() in ms, HIP events on the launch stream."""
-    for _ in range(warm):
-        fn()
+def time_events(fn, iters=50, warm=3):
+    """Average device time of fn() in ms: `iters` launches are captured into one
+    hipGraph (no host launch gaps) and the replay is bracketed by HIP events on
+    the stream the kernels run on."""
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(warm):
+            fn()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            fn()
+    g.replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
-    for _ in range(iters):
-        fn()
+    g.replay()
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
 
 
+def cur_stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
 def roofline(head, inp, dev):
-    """Live timing of the path's two heavy kernels; the one with the larger
-    share of a frame is reported as the dominant kernel."""
+    """Live timing of the kernels of the path.  The dominant one (largest share
+    of a frame: the fused decoder row chain, 6 launches per frame) is reported
+    against its roofline; the others ride along under "others"."""
     B = inp['l2i'].shape[0]
-    Q, Cd = head.num_query, head.embed_dims
-    # -- camera sampling (HBM/L2 gather bound): algorithmic bytes are
-    #    visibility-aware: visible (query,cam) pairs x 4 levels x 4 taps x 256 ch x 4 B
+    Q, Cd, F = head.num_query, head.embed_dims, 512
+    M = B * Q
+    H, code, NL = 8, head.code_size, 24
+    qpad = ((Q + 15) // 16) * 16
     o = head.forward_nhwc(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'], inp['pad_mult'], aux=True)
     ref = o['aux']['inter_references'][2].contiguous()
-    logits = torch.randn((B, Q, 24), device=dev)
+    hs2 = o['aux']['inter_states'][2].contiguous()
     fv = ops.feats_view(inp['nhwc'])
+    pc = L.f6(head.pc_range)
+    lib = L.lib()
+    # -- fused decoder row chain (f32 MFMA): everything of a layer after the attention core
+    pv = head._packed_view
+    attn_o = torch.randn((M, Cd), device=dev)
+    hs_out = torch.empty((M, Cd), device=dev)
+    ref_out = torch.empty((M, 3), device=dev)
+    qk = torch.empty((M, 2 * Cd), device=dev)
+    vt = torch.zeros((B, Cd, qpad), device=dev)
+    qe = head.query_embedding.weight
+
+    def run_chain():
+        L.check(lib.tc_decoder_layer_tail_fwd(
+            C.byref(pv.layers[3]), C.byref(pv.layers[4].self_attn.in_proj), C.byref(fv), B, Q, 6,
+            code, attn_o.data_ptr(), hs2.data_ptr(), qe.data_ptr(), inp['l2i'].data_ptr(),
+            ref.data_ptr(), pc, float(inp['hw'][0]), float(inp['hw'][1]), hs_out.data_ptr(),
+            ref_out.data_ptr(), qk.data_ptr(), vt.data_ptr(), qpad, cur_stream()), 'decoder_layer_tail')
+    chain_ms = time_events(run_chain)
+    chain_flop = 2.0 * M * (5 * Cd * Cd + Cd * NL + 2 * Cd * F + 3 * Cd * Cd + Cd * code)
+    # -- camera sampling stand-alone (HBM/L2 gather): visibility-aware algorithmic bytes
+    logits = torch.randn((B, Q, NL), device=dev)
     out = torch.empty((B, Q, Cd), device=dev)
     cnt = torch.zeros(1, dtype=torch.int64, device=dev)
-    pc = L.f6(head.pc_range)
-    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def run_cam(counter=None):
-        L.check(L.lib().tc_cam_sample_fuse_fwd(
+        L.check(lib.tc_cam_sample_fuse_fwd(
             C.byref(fv), B, Q, Cd, 6, inp['l2i'].data_ptr(), ref.data_ptr(), logits.data_ptr(),
             pc, float(inp['hw'][0]), float(inp['hw'][1]), out.data_ptr(), None,
-            counter, st), 'cam_sample')
+            counter, cur_stream()), 'cam_sample')
     run_cam(C.c_void_p(cnt.data_ptr()))
     torch.cuda.synchronize()
     pairs = int(cnt.item())
-    cam_ms = time_events(run_cam, 200)
-    cam_bytes = pairs * 16 * Cd * 4 + B * Q * Cd * 4
-    # -- self-attention core (f32 MFMA bound): 4*Q*Q*32 flop per head
-    H = 8
-    qpad = ((Q + 15) // 16) * 16
-    qk = torch.randn((B * Q, 2 * Cd), device=dev)
-    vt = torch.randn((B, Cd, qpad), device=dev)
-    ao = torch.empty((B * Q, Cd), device=dev)
+    cam_ms = time_events(run_cam)
+    cam_bytes = pairs * 16 * Cd * 4 + M * Cd * 4
+    # -- self-attention core (f32 MFMA): 4*Q*Q*32 flop per (batch, head)
+    qk_in = torch.randn((M, 2 * Cd), device=dev)
+    vt_in = torch.randn((B, Cd, qpad), device=dev)
+    ao = torch.empty((M, Cd), device=dev)
 
     def run_attn():
-        L.check(L.lib().tc_sdpa_fwd(qk.data_ptr(), qk.data_ptr() + Cd * 4, 2 * Cd, vt.data_ptr(),
-                                    qpad, ao.data_ptr(), Cd, B, Q, H, st), 'sdpa')
-    attn_ms = time_events(run_attn, 200)
+        L.check(lib.tc_sdpa_fwd(qk_in.data_ptr(), qk_in.data_ptr() + Cd * 4, 2 * Cd,
+                                vt_in.data_ptr(), qpad, ao.data_ptr(), Cd, B, Q, H, cur_stream()), 'sdpa')
+    attn_ms = time_events(run_attn)
     attn_flop = 4.0 * Q * Q * 32 * H * B
-    # -- token GEMM 900x256x256 (f32 MFMA)
-    x = torch.randn((B * Q, Cd), device=dev)
-    w = torch.randn((Cd, Cd), device=dev)
-    bb = torch.randn(Cd, device=dev)
-    y = torch.empty((B * Q, Cd), device=dev)
-
-    def run_gemm():
-        L.check(L.lib().tc_linear_fwd(x.data_ptr(), None, w.data_ptr(), bb.data_ptr(), None,
-                                      y.data_ptr(), B * Q, Cd, Cd, 0, st), 'linear')
-    gemm_ms = time_events(run_gemm, 200)
-    gemm_flop = 2.0 * B * Q * Cd * Cd
     kern = {
-        'cam_sample_kernel': dict(bound='hbm', achieved=cam_bytes / cam_ms / 1e6, peak=HBM_PEAK_GBS,
-                                  unit='GB/s', ms=cam_ms, per_frame=6, alg_bytes=cam_bytes,
-                                  visible_pairs=pairs),
-        'self_attn_kernel': dict(bound='mfma', achieved=attn_flop / attn_ms / 1e9,
-                                 peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', ms=attn_ms,
-                                 per_frame=6, alg_flop=attn_flop),
-        'gemm16_kernel': dict(bound='mfma', achieved=gemm_flop / gemm_ms / 1e9,
-                              peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', ms=gemm_ms,
-                              per_frame=None, alg_flop=gemm_flop),
+        'chain_kernel(decoder layer)': dict(
+            bound='mfma', achieved=chain_flop / chain_ms / 1e9, peak=F32_MFMA_PEAK_TFLOPS,
+            unit='TFLOP/s', ms=chain_ms, per_frame=6, alg_flop=chain_flop),
+        'self_attn_kernel': dict(
+            bound='mfma', achieved=attn_flop / attn_ms / 1e9, peak=F32_MFMA_PEAK_TFLOPS,
+            unit='TFLOP/s', ms=attn_ms, per_frame=6, alg_flop=attn_flop),
+        'cam_sample_kernel': dict(
+            bound='hbm', achieved=cam_bytes / cam_ms / 1e6, peak=HBM_PEAK_GBS, unit='GB/s',
+            ms=cam_ms, per_frame=0, alg_bytes=cam_bytes, visible_pairs=pairs,
+            note='stand-alone operator; inside the fused forward it is a step of the chain'),
     }
-    for k in kern.values():
-        k['frac'] = k['achieved'] / k['peak']
-    dom = max(('cam_sample_kernel', 'self_attn_kernel'),
-              key=lambda n: kern[n]['ms'] * kern[n]['per_frame'])
+    for kk in kern.values():
+        kk['frac'] = kk['achieved'] / kk['peak']
+    dom = max(kern, key=lambda n: kern[n]['ms'] * kern[n]['per_frame'])
     r = dict(kern[dom])
     r.update(kernel=dom, traffic=None,
              others={n: {kk: v[kk] for kk in ('bound', 'achieved', 'peak', 'unit', 'frac', 'ms')}

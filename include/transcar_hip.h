@@ -174,6 +174,23 @@ int tc_self_attn_fwd(const tc_mha* w, const float* x, const float* pos, float* o
                      int B, int Q, int C, int num_heads,
                      void* workspace, size_t workspace_bytes, tc_stream_t stream);
 
+/* One decoder layer AFTER its attention core, as one fused launch (the row-chain
+ * kernel of tc_head_forward; mmcv layer order CFG:81-82, XFMR:346-378, 190-203):
+ *   x1 = norm0(x_in + out_proj(attn_o)); camera cross-attention (attention
+ *   weights, sampling, output_proj, position encoder); norm1; FFN; norm2 -> hs;
+ *   reg branch -> ref_out = refined reference points; next layer's q,k (qk) and
+ *   transposed v (vt) when next_in_proj != NULL.
+ * `layer` / `next_in_proj` must come from a tc_head_pack_weights view (packed
+ * weights).  attn_o, x_in, hs [B*Q,C]; query_embedding [Q,2C]; ref_in/ref_out
+ * [B*Q,3]; qk [B*Q,2C]; vt [B,C,qpad]. */
+int tc_decoder_layer_tail_fwd(const tc_decoder_layer* layer, const tc_linear* next_in_proj,
+                              const tc_feats_nhwc* feats, int B, int Q, int num_cams,
+                              int code_size, const float* attn_o, const float* x_in,
+                              const float* query_embedding, const float* lidar2img,
+                              const float* ref_in, const float* pc_range /*host[6]*/,
+                              float img_h, float img_w, float* hs, float* ref_out,
+                              float* qk, float* vt, int qpad, tc_stream_t stream);
+
 /* The attention core of the above on already projected operands (the kernel
  * the roofline is quoted on): out = softmax(q k^T) v per (batch, head).
  *   q, k [B*Q, ld] token-major, head h at columns h*32.. (q pre-scaled by

@@ -119,6 +119,10 @@ SIGNATURES = {
     'tc_self_attn_workspace_bytes': (_sz, [_i, _i, _i]),
     'tc_self_attn_fwd': (_i, [_P(tc_mha), _vp, _vp, _vp, _i, _i, _i, _i, _vp,
                               _sz, _vp]),
+    'tc_decoder_layer_tail_fwd': (_i, [_P(tc_decoder_layer), _P(tc_linear),
+                                       _P(tc_feats_nhwc), _i, _i, _i, _i, _vp,
+                                       _vp, _vp, _vp, _vp, _P(_f), _f, _f, _vp,
+                                       _vp, _vp, _vp, _i, _vp]),
     'tc_sdpa_fwd': (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     'tc_radar_xattn_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'tc_radar_gated_xattn_fwd': (_i, [_P(tc_mha), _vp, _vp, _vp, _i, _vp, _vp,

@@ -424,6 +424,30 @@ int tc_self_attn_fwd(const tc_mha* w, const float* x, const float* pos, float* o
   return self_attn(*w, x, pos, out, B, Q, C, num_heads, qk, vt, qpad, ao, as_stream(stream));
 }
 
+int tc_decoder_layer_tail_fwd(const tc_decoder_layer* layer, const tc_linear* next_in_proj,
+                              const tc_feats_nhwc* feats, int B, int Q, int num_cams,
+                              int code_size, const float* attn_o, const float* x_in,
+                              const float* query_embedding, const float* lidar2img,
+                              const float* ref_in, const float* pc_range, float img_h,
+                              float img_w, float* hs, float* ref_out, float* qk, float* vt,
+                              int qpad, tc_stream_t stream) {
+  TC_REQUIRE(layer != nullptr && feats != nullptr, "decoder_layer_tail: null argument");
+  const int C = 256;
+  DecoderChainArgs d;
+  d.attn_o = attn_o; d.x_in = x_in; d.x_ld = C; d.x_mod = 0;
+  d.qe = query_embedding; d.Q = Q; d.ref_in = ref_in; d.ref_out = ref_out; d.box_m = nullptr;
+  d.w = layer; d.next_in_proj = next_in_proj;
+  d.qscale = 1.4426950408889634f / sqrtf(32.0f);
+  d.hs = hs; d.qk = qk; d.vt = vt; d.qpad = qpad;
+  d.cam.feats = *feats; d.cam.B = B; d.cam.Q = Q; d.cam.C = C; d.cam.num_cams = num_cams;
+  d.cam.lidar2img = lidar2img; d.cam.ref = ref_in; d.cam.logits = nullptr;
+  for (int i = 0; i < 6; ++i) d.cam.pc[i] = pc_range[i];
+  d.cam.img_h = img_h; d.cam.img_w = img_w; d.cam.out = nullptr; d.cam.vis = nullptr;
+  d.cam.pair_counter = nullptr;
+  d.code = code_size; d.M = B * Q;
+  return launch_decoder_chain(d, as_stream(stream));
+}
+
 int tc_sdpa_fwd(const float* q, const float* k, int ld, const float* vt, int ldt, float* out, int ldo,
                 int B, int Q, int num_heads, tc_stream_t stream) {
   return launch_self_attn_core(q, k, ld, vt, ldt, out, ldo, B, Q, num_heads, as_stream(stream));
