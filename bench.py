@@ -191,7 +191,16 @@ def roofline(head, inp, dev):
         kk['frac'] = kk['achieved'] / kk['peak']
     dom = max(kern, key=lambda n: kern[n]['ms'] * kern[n]['per_frame'])
     r = dict(kern[dom])
-    r.update(kernel=dom, traffic=None,
+    # HBM-side traffic per launch comes from the committed PMC passes (rocprofv3 cannot
+    # run inside this process); null when no profile of this kernel is committed
+    traffic, src = None, None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r1_pmc.json')))
+        if dom in pmc and B == 1:
+            traffic, src = pmc[dom]['traffic_bytes'], 'profiles/r1_pmc.json'
+    except Exception:
+        pass
+    r.update(kernel=dom, traffic=traffic, traffic_source=src,
              others={n: {kk: v[kk] for kk in ('bound', 'achieved', 'peak', 'unit', 'frac', 'ms')}
                      for n, v in kern.items() if n != dom})
     return r
