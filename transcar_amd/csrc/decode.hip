@@ -41,18 +41,49 @@ __global__ __launch_bounds__(DEC_THREADS) void box_decode_kernel(DecK p) {
     for (int i = tid; i < 256; i += DEC_THREADS) hist[i] = 0;
     __syncthreads();
     const int sh = pass * 8;
-    for (int i = tid; i < n; i += DEC_THREADS) {
-      const unsigned long long k = keys[i];
-      if ((k & pmask) == prefix) atomicAdd(&hist[(unsigned)(k >> sh) & 255u], 1u);
+    if (pass == 7) {
+      // top byte = sign + exponent bits: sigmoid outputs fall into a handful of bins,
+      // so the 64 lanes of a wave would serialise on one LDS word: aggregate per wave
+      for (int i0 = 0; i0 < n; i0 += DEC_THREADS) {
+        const int i = i0 + tid;
+        const bool valid = i < n;
+        const unsigned digit = valid ? (unsigned)(keys[i] >> sh) & 255u : 0u;
+        unsigned long long active = __ballot(valid);
+        while (active) {
+          const int leader = __ffsll((long long)active) - 1;
+          const unsigned d = __shfl(digit, leader, 64);
+          const unsigned long long same = __ballot(valid && digit == d);
+          if ((tid & 63) == leader) atomicAdd(&hist[d], (unsigned)__popcll(same));
+          active &= ~same;
+        }
+      }
+    } else {
+      for (int i = tid; i < n; i += DEC_THREADS) {
+        const unsigned long long k = keys[i];
+        if ((k & pmask) == prefix) atomicAdd(&hist[(unsigned)(k >> sh) & 255u], 1u);
+      }
     }
     __syncthreads();
-    if (tid == 0) {
-      int cum = 0, bin = 255;
-      for (; bin > 0; --bin) {
-        if (cum + (int)hist[bin] >= remaining) break;
-        cum += hist[bin];
+    if (tid < 64) {
+      // wave-parallel scan from the top bin down (a serial 256-step scan by one
+      // thread cost ~7 us per pass): lane l owns descending bins 255-4l .. 252-4l
+      const int b0 = 255 - 4 * tid;
+      const int c0 = hist[b0], c1 = hist[b0 - 1], c2 = hist[b0 - 2], c3 = hist[b0 - 3];
+      const int sum = c0 + c1 + c2 + c3;
+      int incl = sum;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o, 64);
+        if (tid >= o) incl += up;
       }
-      misc[0] = bin; misc[1] = remaining - cum;
+      const int excl = incl - sum;
+      if (excl < remaining && remaining <= incl) {     // exactly one lane
+        int cum = excl, bin = b0;
+        if (cum + c0 < remaining) { cum += c0; bin = b0 - 1;
+          if (cum + c1 < remaining) { cum += c1; bin = b0 - 2;
+            if (cum + c2 < remaining) { cum += c2; bin = b0 - 3; } } }
+        misc[0] = bin; misc[1] = remaining - cum;
+      }
     }
     __syncthreads();
     prefix |= (unsigned long long)misc[0] << sh;
