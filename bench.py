@@ -256,11 +256,11 @@ def main():
     args = parse()
     if args.unfused:
         os.environ['TRANSCAR_UNFUSED'] = '1'
-    rank, world = D.init_process_group()
     local = int(os.environ.get('LOCAL_RANK', 0))
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(local)              # before the RCCL communicator is created
     dev = torch.device('cuda', local)
+    rank, world = D.init_process_group()
     torch.set_grad_enabled(False)
     head, sd = build_head(dev)
     inp = make_inputs(head, dev, args.shapes, args.batch, seed=1 + rank)

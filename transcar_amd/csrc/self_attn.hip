@@ -41,26 +41,39 @@ __device__ __forceinline__ KVFrag load_kv(const float* __restrict__ k, const flo
   return f;
 }
 
+// QT = 16-query sub-tiles per workgroup: the K/V fragments of a key tile are loaded
+// once and used for QT score / PV products (K/V re-reads from L2 are the kernel's
+// main memory traffic: 57 query tiles x 8 heads x 230 KB at QT = 1).
+template <int QT>
 __global__ __launch_bounds__(SA_NW * 64) void self_attn_kernel(const float* __restrict__ q,
                                                                const float* __restrict__ k, int ld,
                                                                const float* __restrict__ vt, int ldt,
                                                                float* __restrict__ out, int ldo,
                                                                int Q, int C) {
-  __shared__ float sm_m[SA_NW][16];
-  __shared__ float sm_l[SA_NW][64];
-  __shared__ float4 sm_o[SA_NW][2][64];
+  __shared__ float sm_m[SA_NW][QT][16];
+  __shared__ float sm_l[SA_NW][QT][64];
+  __shared__ float4 sm_o[SA_NW][QT][2][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int q0 = blockIdx.x * 16, h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 16 * QT, h = blockIdx.y, b = blockIdx.z;
   const size_t brow = (size_t)b * Q;
 
-  const int qrow = min(q0 + r, Q - 1);
-  const float* qp = q + (brow + qrow) * ld + h * 32 + 8 * g;
-  const float4 qa = ld4(qp), qb = ld4(qp + 4);
+  float4 qa[QT], qb[QT];
+#pragma unroll
+  for (int u = 0; u < QT; ++u) {
+    const int qrow = min(q0 + 16 * u + r, Q - 1);
+    const float* qp = q + (brow + qrow) * ld + h * 32 + 8 * g;
+    qa[u] = ld4(qp); qb[u] = ld4(qp + 4);
+  }
   const float* vbase = vt + ((size_t)b * C + h * 32 + r) * ldt;
 
-  f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
-  float m = -INFINITY, lpart = 0.0f;
+  f32x4 o0[QT], o1[QT];
+  float m[QT], lpart[QT];
+#pragma unroll
+  for (int u = 0; u < QT; ++u) {
+    o0[u] = f32x4{0.f, 0.f, 0.f, 0.f}; o1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    m[u] = -INFINITY; lpart[u] = 0.0f;
+  }
   const int ntiles = (Q + 15) / 16;
   int t = wave;
   KVFrag cur;
@@ -70,62 +83,75 @@ __global__ __launch_bounds__(SA_NW * 64) void self_attn_kernel(const float* __re
     KVFrag nxt = cur;
     if (t + SA_NW < ntiles) nxt = load_kv(k, vbase, ld, ldt, brow, h, (t + SA_NW) * 16, r, g, Q);
     __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this tile's MFMAs
-
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    s = MFMA4(cur.ka.x, qa.x, s); s = MFMA4(cur.ka.y, qa.y, s);
-    s = MFMA4(cur.ka.z, qa.z, s); s = MFMA4(cur.ka.w, qa.w, s);
-    s = MFMA4(cur.kb.x, qb.x, s); s = MFMA4(cur.kb.y, qb.y, s);
-    s = MFMA4(cur.kb.z, qb.z, s); s = MFMA4(cur.kb.w, qb.w, s);
-    // s[i] = log2(e) * S^T[key0 + 4g + i][q0 + r]
     float4 v0 = cur.v0, v1 = cur.v1;
-    float s0 = s[0], s1 = s[1], s2 = s[2], s3 = s[3];
-    if (key0 + 16 > Q) {          // ragged last tile (wave-uniform)
-      const int kk = key0 + 4 * g;
-      if (kk + 0 >= Q) { s0 = -INFINITY; v0.x = 0.f; v1.x = 0.f; }
-      if (kk + 1 >= Q) { s1 = -INFINITY; v0.y = 0.f; v1.y = 0.f; }
-      if (kk + 2 >= Q) { s2 = -INFINITY; v0.z = 0.f; v1.z = 0.f; }
-      if (kk + 3 >= Q) { s3 = -INFINITY; v0.w = 0.f; v1.w = 0.f; }
+    const bool ragged = key0 + 16 > Q;   // wave-uniform
+    const int kk = key0 + 4 * g;
+    if (ragged) {
+      if (kk + 0 >= Q) { v0.x = 0.f; v1.x = 0.f; }
+      if (kk + 1 >= Q) { v0.y = 0.f; v1.y = 0.f; }
+      if (kk + 2 >= Q) { v0.z = 0.f; v1.z = 0.f; }
+      if (kk + 3 >= Q) { v0.w = 0.f; v1.w = 0.f; }
     }
-    float mx = fmaxf(fmaxf(s0, s1), fmaxf(s2, s3));
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float mnew = fmaxf(m, mx);           // finite: key0 + 0 < Q in every tile
-    const float alpha = __builtin_amdgcn_exp2f(m - mnew);
-    const float p0 = __builtin_amdgcn_exp2f(s0 - mnew), p1 = __builtin_amdgcn_exp2f(s1 - mnew);
-    const float p2 = __builtin_amdgcn_exp2f(s2 - mnew), p3 = __builtin_amdgcn_exp2f(s3 - mnew);
-    lpart = lpart * alpha + ((p0 + p1) + (p2 + p3));
-    m = mnew;
-    o0 *= alpha; o1 *= alpha;
-    // O^T[d][q] += V^T[d][key] P^T[key][q]
-    o0 = MFMA4(v0.x, p0, o0); o1 = MFMA4(v1.x, p0, o1);
-    o0 = MFMA4(v0.y, p1, o0); o1 = MFMA4(v1.y, p1, o1);
-    o0 = MFMA4(v0.z, p2, o0); o1 = MFMA4(v1.z, p2, o1);
-    o0 = MFMA4(v0.w, p3, o0); o1 = MFMA4(v1.w, p3, o1);
+#pragma unroll
+    for (int u = 0; u < QT; ++u) {
+      f32x4 s = {0.f, 0.f, 0.f, 0.f};
+      s = MFMA4(cur.ka.x, qa[u].x, s); s = MFMA4(cur.ka.y, qa[u].y, s);
+      s = MFMA4(cur.ka.z, qa[u].z, s); s = MFMA4(cur.ka.w, qa[u].w, s);
+      s = MFMA4(cur.kb.x, qb[u].x, s); s = MFMA4(cur.kb.y, qb[u].y, s);
+      s = MFMA4(cur.kb.z, qb[u].z, s); s = MFMA4(cur.kb.w, qb[u].w, s);
+      // s[i] = log2(e) * S^T[key0 + 4g + i][q0 + 16u + r]
+      float s0 = s[0], s1 = s[1], s2 = s[2], s3 = s[3];
+      if (ragged) {
+        if (kk + 0 >= Q) s0 = -INFINITY;
+        if (kk + 1 >= Q) s1 = -INFINITY;
+        if (kk + 2 >= Q) s2 = -INFINITY;
+        if (kk + 3 >= Q) s3 = -INFINITY;
+      }
+      float mx = fmaxf(fmaxf(s0, s1), fmaxf(s2, s3));
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mnew = fmaxf(m[u], mx);           // finite: key0 + 0 < Q in every tile
+      const float alpha = __builtin_amdgcn_exp2f(m[u] - mnew);
+      const float p0 = __builtin_amdgcn_exp2f(s0 - mnew), p1 = __builtin_amdgcn_exp2f(s1 - mnew);
+      const float p2 = __builtin_amdgcn_exp2f(s2 - mnew), p3 = __builtin_amdgcn_exp2f(s3 - mnew);
+      lpart[u] = lpart[u] * alpha + ((p0 + p1) + (p2 + p3));
+      m[u] = mnew;
+      o0[u] *= alpha; o1[u] *= alpha;
+      // O^T[d][q] += V^T[d][key] P^T[key][q]
+      o0[u] = MFMA4(v0.x, p0, o0[u]); o1[u] = MFMA4(v1.x, p0, o1[u]);
+      o0[u] = MFMA4(v0.y, p1, o0[u]); o1[u] = MFMA4(v1.y, p1, o1[u]);
+      o0[u] = MFMA4(v0.z, p2, o0[u]); o1[u] = MFMA4(v1.z, p2, o1[u]);
+      o0[u] = MFMA4(v0.w, p3, o0[u]); o1[u] = MFMA4(v1.w, p3, o1[u]);
+    }
     cur = nxt;
   }
   // merge the key slices
-  if (g == 0) sm_m[wave][r] = m;
-  sm_l[wave][lane] = lpart;
-  sm_o[wave][0][lane] = make_float4(o0[0], o0[1], o0[2], o0[3]);
-  sm_o[wave][1][lane] = make_float4(o1[0], o1[1], o1[2], o1[3]);
-  __syncthreads();
-  if (wave >= 2) return;
-  // wave 0 finalises channels 0..15 of the head, wave 1 channels 16..31
-  float mstar = sm_m[0][r];
 #pragma unroll
-  for (int w = 1; w < SA_NW; ++w) mstar = fmaxf(mstar, sm_m[w][r]);
+  for (int u = 0; u < QT; ++u) {
+    if (g == 0) sm_m[wave][u][r] = m[u];
+    sm_l[wave][u][lane] = lpart[u];
+    sm_o[wave][u][0][lane] = make_float4(o0[u][0], o0[u][1], o0[u][2], o0[u][3]);
+    sm_o[wave][u][1][lane] = make_float4(o1[u][0], o1[u][1], o1[u][2], o1[u][3]);
+  }
+  __syncthreads();
+  // wave w finalises (sub-tile w/2, channel half w&1)
+  if (wave >= 2 * QT) return;
+  const int u = wave >> 1, half = wave & 1;
+  float mstar = sm_m[0][u][r];
+#pragma unroll
+  for (int w = 1; w < SA_NW; ++w) mstar = fmaxf(mstar, sm_m[w][u][r]);
   float l = 0.0f;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int w = 0; w < SA_NW; ++w) {
-    const float sc = __builtin_amdgcn_exp2f(sm_m[w][r] - mstar);
-    l += sc * ((sm_l[w][r] + sm_l[w][r + 16]) + (sm_l[w][r + 32] + sm_l[w][r + 48]));
-    const float4 v = sm_o[w][wave][lane];
+    const float sc = __builtin_amdgcn_exp2f(sm_m[w][u][r] - mstar);
+    l += sc * ((sm_l[w][u][r] + sm_l[w][u][r + 16]) + (sm_l[w][u][r + 32] + sm_l[w][u][r + 48]));
+    const float4 v = sm_o[w][u][half][lane];
     acc.x += sc * v.x; acc.y += sc * v.y; acc.z += sc * v.z; acc.w += sc * v.w;
   }
-  if (q0 + r < Q) {
+  if (q0 + 16 * u + r < Q) {
     const float inv = 1.0f / l;
-    float* op = out + (brow + q0 + r) * ldo + h * 32 + 16 * wave + 4 * g;
+    float* op = out + (brow + q0 + 16 * u + r) * ldo + h * 32 + 16 * half + 4 * g;
     st4(op, make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
   }
 }
@@ -134,8 +160,9 @@ int launch_self_attn_core(const float* q, const float* k, int ld, const float* v
                           float* out, int ldo, int B, int Q, int H, hipStream_t s) {
   TC_REQUIRE(Q > 0 && B > 0 && H > 0, "self_attn: empty problem");
   TC_REQUIRE((ldt & 3) == 0 && ldt >= ((Q + 15) / 16) * 16, "self_attn: ldt=%d too small for Q=%d", ldt, Q);
-  dim3 grid((Q + 15) / 16, H, B);
-  hipLaunchKernelGGL(self_attn_kernel, grid, dim3(SA_NW * 64), 0, s, q, k, ld, vt, ldt, out, ldo, Q, H * 32);
+  constexpr int QT = 2;
+  dim3 grid((Q + 16 * QT - 1) / (16 * QT), H, B);
+  hipLaunchKernelGGL(self_attn_kernel<QT>, grid, dim3(SA_NW * 64), 0, s, q, k, ld, vt, ldt, out, ldo, Q, H * 32);
   return check_launch("self_attn");
 }
 
