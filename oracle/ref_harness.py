@@ -26,6 +26,7 @@ import torch
 import torch.nn as nn
 
 from . import mmcv_bricks as B
+from . import mmdet_bricks as MD
 
 REF_ROOT = os.environ.get('TRANSCAR_REFERENCE', '/root/reference')
 PLUGIN = os.path.join(REF_ROOT, 'projects', 'mmdet3d_plugin')
@@ -138,11 +139,12 @@ class DETRHead(B.BaseModule):
         self.train_cfg = train_cfg
         self.test_cfg = test_cfg
         self.fp16_enabled = False
-        loss_cls = dict(loss_cls or {})
-        loss_cls.pop('type', None)
-        self.loss_cls = _LossStub(**loss_cls)
-        self.loss_bbox = _LossStub()
-        self.loss_iou = _LossStub()
+        self.loss_cls = MD.build_loss(loss_cls)
+        self.loss_bbox = MD.build_loss(loss_bbox)
+        self.loss_iou = MD.build_loss(loss_iou)
+        if train_cfg:
+            self.assigner = B.BBOX_ASSIGNERS.build(train_cfg['assigner'])
+            self.sampler = MD.PseudoSampler()
         self.cls_out_channels = num_classes if self.loss_cls.use_sigmoid \
             else num_classes + 1
         self.transformer = B.TRANSFORMER.build(transformer)
@@ -212,6 +214,9 @@ def load_reference():
     _mod('mmdet')
     _mod('mmdet.core', multi_apply=multi_apply, reduce_mean=reduce_mean)
     _mod('mmdet.core.bbox', BaseBBoxCoder=BaseBBoxCoder)
+    _mod('mmdet.core.bbox.assigners', AssignResult=MD.AssignResult, BaseAssigner=MD.BaseAssigner)
+    _mod('mmdet.core.bbox.match_costs', build_match_cost=MD.build_match_cost)
+    _mod('mmdet.core.bbox.match_costs.builder', MATCH_COST=B.MATCH_COST)
     _mod('mmdet.core.bbox.builder', BBOX_CODERS=B.BBOX_CODERS,
          BBOX_ASSIGNERS=B.BBOX_ASSIGNERS)
     _mod('mmdet.models', HEADS=B.HEADS)
@@ -232,6 +237,8 @@ def load_reference():
                 'projects.mmdet3d_plugin.core',
                 'projects.mmdet3d_plugin.core.bbox',
                 'projects.mmdet3d_plugin.core.bbox.coders',
+                'projects.mmdet3d_plugin.core.bbox.assigners',
+                'projects.mmdet3d_plugin.core.bbox.match_costs',
                 'projects.mmdet3d_plugin.models',
                 'projects.mmdet3d_plugin.models.utils',
                 'projects.mmdet3d_plugin.models.dense_heads']:
@@ -243,6 +250,12 @@ def load_reference():
     _LOADED['CODER'] = _load(
         P + 'core.bbox.coders.nms_free_coder',
         os.path.join(PLUGIN, 'core/bbox/coders/nms_free_coder.py'))
+    _LOADED['COST'] = _load(
+        P + 'core.bbox.match_costs.match_cost',
+        os.path.join(PLUGIN, 'core/bbox/match_costs/match_cost.py'))
+    _LOADED['ASSIGN'] = _load(
+        P + 'core.bbox.assigners.hungarian_assigner_3d',
+        os.path.join(PLUGIN, 'core/bbox/assigners/hungarian_assigner_3d.py'))
     _LOADED['XFMR'] = _load(
         P + 'models.utils.detr3d_transformer',
         os.path.join(PLUGIN, 'models/utils/detr3d_transformer.py'))
@@ -252,11 +265,27 @@ def load_reference():
     return types.SimpleNamespace(**_LOADED)
 
 
-def build_reference_head(head_cfg):
+class GtBoxes:
+    """Stand-in for mmdet3d LiDARInstance3DBoxes as the loss reads it
+    (HEAD:963-965): ``tensor`` [n,9] bottom-centre boxes, ``gravity_center``."""
+
+    def __init__(self, tensor):
+        self.tensor = tensor
+
+    @property
+    def gravity_center(self):
+        c = self.tensor[:, :3].clone()
+        c[:, 2] = c[:, 2] + self.tensor[:, 5] * 0.5
+        return c
+
+
+def build_reference_head(head_cfg, train_cfg=None):
     """Instantiate the reference's Detr3DHead from a ``pts_bbox_head`` dict."""
     ref = load_reference()
     cfg = dict(head_cfg)
     cfg.pop('type', None)
+    if train_cfg is not None:
+        cfg['train_cfg'] = train_cfg
     head = ref.HEAD.Detr3DHead(**cfg)
     head.eval()
     return head

@@ -176,6 +176,30 @@ def g4_radar_empty(head):
          Lq=np.array([cap.get('Lq%d' % i, 0) for i in range(3)]))
 
 
+def g7_loss(ref):
+    """Detr3DHead.loss (HEAD:919-1001) incl. HungarianAssigner3D / BBox3DL1Cost of the
+    reference on the G5 (tiny) head outputs and a seeded ground truth."""
+    head = RH.build_reference_head(configs.head_cfg(), configs.train_cfg_pts)
+    sd = synth.make_state_dict(seed=3)
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    g5 = np.load(os.path.join(HERE, 'g5_head_tiny.npz'))
+    outs = {'all_cls_scores': torch.from_numpy(g5['all_cls_scores']),
+            'all_bbox_preds': torch.from_numpy(g5['all_bbox_preds']),
+            'enc_cls_scores': None, 'enc_bbox_preds': None}
+    boxes, labels = synth.make_gt(seed=7, n=24)
+    gt = RH.GtBoxes(torch.from_numpy(boxes))
+    losses = head.loss([gt], [torch.from_numpy(labels)], outs)
+    gc = torch.cat((gt.gravity_center, gt.tensor[:, 3:]), 1)
+    match = [head.assigner.assign(outs['all_bbox_preds'][i, 0], outs['all_cls_scores'][i, 0],
+                                  gc, torch.from_numpy(labels)).gt_inds.numpy() for i in range(3)]
+    save('g7_loss.npz', gt_inds=np.stack(match),
+         **{k.replace('.', '_'): float(v) for k, v in losses.items()})
+    # no ground truth at all
+    e = head.loss([RH.GtBoxes(torch.zeros(0, 9))], [torch.zeros(0, dtype=torch.long)], outs)
+    save('g7_loss_empty.npz', **{k.replace('.', '_'): float(v) for k, v in e.items()})
+    print({k: float(v) for k, v in losses.items()})
+
+
 def main():
     ref = RH.load_reference()
     head, _ = ref_head()
@@ -184,6 +208,7 @@ def main():
     g345_head(head, ref, 'tiny', 'tiny')
     g345_head(head, ref, 'res101', 'res101')
     g4_radar_empty(head)
+    g7_loss(ref)
 
 
 if __name__ == '__main__':

@@ -1,0 +1,126 @@
+"""Training row: Hungarian assignment + focal / L1
+losses against the reference's own `Detr3DHead.loss` (fixture G7, produced by
+tests/golden/make_golden.py::g7_loss) -- CPU, host/PyTorch code as in the
+reference."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import transcar_amd as T
+from oracle import transcar_oracle as O
+from transcar_amd import configs, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = ['loss_cls', 'loss_bbox', 'd0.loss_cls', 'd0.loss_bbox', 'd1.loss_cls', 'd1.loss_bbox']
+
+
+def _outs(golden_dir):
+    g5 = np.load(os.path.join(golden_dir, 'g5_head_tiny.npz'))
+    return {'all_cls_scores': torch.from_numpy(g5['all_cls_scores']),
+            'all_bbox_preds': torch.from_numpy(g5['all_bbox_preds'])}
+
+
+def _head():
+    cfg = configs.head_cfg()
+    cfg['train_cfg'] = configs.train_cfg_pts
+    h = T.build_head(cfg)
+    h.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(3).items()})
+    return h
+
+
+def test_oracle_loss_matches_reference(golden_dir):
+    g7 = np.load(os.path.join(golden_dir, 'g7_loss.npz'))
+    boxes, labels = synth.make_gt(seed=7, n=24)
+    cw = torch.tensor([1.0] * 8 + [0.2, 0.2])
+    res, matches = O.loss(_outs(golden_dir), torch.from_numpy(boxes), torch.from_numpy(labels), cw)
+    for k in KEYS:
+        assert abs(float(res[k]) - float(g7[k.replace('.', '_')])) <= 1e-4 * max(1, abs(float(g7[k.replace('.', '_')]))), k
+    assert np.array_equal(np.stack([m.numpy() for m in matches]), g7['gt_inds'])
+
+
+def test_head_loss_matches_reference(golden_dir):
+    g7 = np.load(os.path.join(golden_dir, 'g7_loss.npz'))
+    boxes, labels = synth.make_gt(seed=7, n=24)
+    gt = torch.from_numpy(boxes).clone()
+    gt[:, 2] += gt[:, 5] * 0.5                     # gravity centre, HEAD:963-965
+    h = _head()
+    out = h.loss([gt], [torch.from_numpy(labels)], _outs(golden_dir))
+    assert sorted(out) == sorted(KEYS)
+    for k in KEYS:
+        ref = float(g7[k.replace('.', '_')])
+        assert abs(float(out[k]) - ref) <= 1e-5 * max(1, abs(ref)), (k, float(out[k]), ref)
+    # the assigner itself (ASSIGN:52-134)
+    res = h.assigner.assign(_outs(golden_dir)['all_bbox_preds'][2, 0],
+                            _outs(golden_dir)['all_cls_scores'][2, 0], gt, torch.from_numpy(labels))
+    assert np.array_equal(res.gt_inds.numpy(), g7['gt_inds'][2])
+    assert int((res.gt_inds > 0).sum()) == 24
+
+
+def test_head_loss_without_ground_truth(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g7_loss_empty.npz'))
+    h = _head()
+    out = h.loss([torch.zeros(0, 9)], [torch.zeros(0, dtype=torch.long)], _outs(golden_dir))
+    for k in KEYS:
+        ref = float(g[k.replace('.', '_')])
+        assert abs(float(out[k]) - ref) <= 1e-5 * max(1, abs(ref)), k
+    assert float(out['loss_bbox']) == 0.0
+
+
+def test_accepts_lidar_box_objects(golden_dir):
+    class Boxes:                                    # what mmdet3d hands over
+        def __init__(self, t):
+            self.tensor = t
+
+        @property
+        def gravity_center(self):
+            c = self.tensor[:, :3].clone()
+            c[:, 2] += self.tensor[:, 5] * 0.5
+            return c
+    boxes, labels = synth.make_gt(seed=7, n=24)
+    g7 = np.load(os.path.join(golden_dir, 'g7_loss.npz'))
+    out = _head().loss([Boxes(torch.from_numpy(boxes))], [torch.from_numpy(labels)], _outs(golden_dir))
+    assert abs(float(out['loss_cls']) - float(g7['loss_cls'])) < 1e-3
+
+
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+import transcar_amd as T
+from transcar_amd import configs, synth, dist as D
+rank, world = D.init_process_group('gloo')
+cfg = configs.head_cfg(); cfg['train_cfg'] = configs.train_cfg_pts
+h = T.build_head(cfg)
+g5 = np.load(os.path.join(%r, 'g5_head_tiny.npz'))
+outs = {'all_cls_scores': torch.from_numpy(g5['all_cls_scores']), 'all_bbox_preds': torch.from_numpy(g5['all_bbox_preds'])}
+n = 24 if rank == 0 else 8                       # different number of positives per rank
+b, l = synth.make_gt(seed=7, n=24)
+gt = torch.from_numpy(b[:n]).clone(); gt[:, 2] += gt[:, 5] * 0.5
+out = h.loss([gt], [torch.from_numpy(l[:n])], outs)
+# single-process value with the averaged normaliser (HEAD:889-902: reduce_mean)
+h.sync_cls_avg_factor = False
+solo = h.loss([gt], [torch.from_numpy(l[:n])], outs)
+ratio = float(out['loss_cls']) / float(solo['loss_cls'])
+assert abs(ratio - n / 16.0) < 1e-4, ratio          # mean positives over ranks = 16
+dist.destroy_process_group()
+print('ok', rank)
+'''
+
+
+def test_loss_normalisers_all_reduce_gloo_world2(tmp_path, golden_dir):
+    script = tmp_path / 'w.py'
+    script.write_text(_WORKER % (ROOT, golden_dir))
+    port = 31000 + os.getpid() % 2000
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=180)
+        assert p.returncode == 0, out.decode()

@@ -27,7 +27,10 @@ from . import _lib as L
 from . import ops, radar
 from .bricks import BaseModule, mha_view, require_eval
 from .detr3d_transformer import pos_encoder_view
-from .registry import HEADS, build_bbox_coder, build_transformer
+from . import hungarian_assigner_3d, losses                  # noqa: F401 (registers)
+from .bbox_util import normalize_bbox
+from .registry import (BBOX_ASSIGNERS, HEADS, build_bbox_coder,
+                       build_transformer)
 
 RADAR_RADII = ((1.0, 2.0), (1.0, 2.0), (0.5, 1.0))     # HEAD:567, 635, 693
 
@@ -101,6 +104,9 @@ class Detr3DHead(BaseModule):
         self.cls_out_channels = num_classes if use_sigmoid else num_classes + 1
         self.transformer = build_transformer(transformer)
         self.embed_dims = self.transformer.embed_dims
+        self.assigner = None
+        if train_cfg and train_cfg.get('assigner') is not None:
+            self.assigner = BBOX_ASSIGNERS.build(train_cfg['assigner'])
         self._init_layers()
         # --- HEAD:70-196
         self.code_weights = nn.Parameter(
@@ -344,8 +350,79 @@ class Detr3DHead(BaseModule):
             ret_list.append([bboxes, p['scores'], p['labels']])
         return ret_list
 
-    def loss(self, gt_bboxes_list, gt_labels_list, preds_dicts,
-             gt_bboxes_ignore=None):
-        raise NotImplementedError(
-            'training (HEAD:742-1001) is the next row of the scope table '
-            '(DESIGN.md): the inference hot path is built first')
+    # ------------------------------------------------------------------
+    # training targets and losses (HEAD:742-1001), host/PyTorch as in the reference
+    # ------------------------------------------------------------------
+    def _get_target_single(self, cls_score, bbox_pred, gt_labels, gt_bboxes):
+        """HEAD:742-796."""
+        num_bboxes = bbox_pred.size(0)
+        res = self.assigner.assign(bbox_pred, cls_score, gt_bboxes, gt_labels)
+        pos_inds = torch.nonzero(res.gt_inds > 0, as_tuple=False).squeeze(-1).unique()
+        neg_inds = torch.nonzero(res.gt_inds == 0, as_tuple=False).squeeze(-1).unique()
+        pos_gt = res.gt_inds[pos_inds] - 1
+        labels = gt_bboxes.new_full((num_bboxes,), self.num_classes, dtype=torch.long)
+        labels[pos_inds] = gt_labels[pos_gt]
+        label_weights = gt_bboxes.new_ones(num_bboxes)
+        bbox_targets = torch.zeros_like(bbox_pred)[..., :9]
+        bbox_weights = torch.zeros_like(bbox_pred)
+        bbox_weights[pos_inds] = 1.0
+        bbox_targets[pos_inds] = gt_bboxes[pos_gt]
+        return labels, label_weights, bbox_targets, bbox_weights, pos_inds, neg_inds
+
+    def get_targets(self, cls_scores_list, bbox_preds_list, gt_bboxes_list, gt_labels_list):
+        """HEAD:798-847."""
+        outs = [self._get_target_single(c, b, l, g) for c, b, l, g in
+                zip(cls_scores_list, bbox_preds_list, gt_labels_list, gt_bboxes_list)]
+        labels, lw, bt, bw, pos, neg = map(list, zip(*outs))
+        return (labels, lw, bt, bw, sum(p.numel() for p in pos), sum(n.numel() for n in neg))
+
+    def loss_single(self, cls_scores, bbox_preds, gt_bboxes_list, gt_labels_list):
+        """HEAD:849-917 for one radar-layer output [B,Q,*]."""
+        num_imgs = cls_scores.size(0)
+        labels, lw, bt, bw, num_pos, num_neg = self.get_targets(
+            [cls_scores[i] for i in range(num_imgs)], [bbox_preds[i] for i in range(num_imgs)],
+            gt_bboxes_list, gt_labels_list)
+        labels, lw = torch.cat(labels, 0), torch.cat(lw, 0)
+        bbox_targets, bbox_weights = torch.cat(bt, 0), torch.cat(bw, 0)
+        cls_scores = cls_scores.reshape(-1, self.cls_out_channels)
+        cls_avg_factor = num_pos * 1.0 + num_neg * self.bg_cls_weight
+        if self.sync_cls_avg_factor:
+            cls_avg_factor = losses.reduce_mean(cls_scores.new_tensor([cls_avg_factor])).item()
+        cls_avg_factor = max(cls_avg_factor, 1)
+        lc = self.loss_cls_cfg
+        loss_cls = losses.sigmoid_focal_loss(
+            cls_scores, labels, lw, gamma=lc.get('gamma', 2.0), alpha=lc.get('alpha', 0.25),
+            avg_factor=cls_avg_factor, loss_weight=lc.get('loss_weight', 1.0))
+        num_pos_t = torch.clamp(losses.reduce_mean(loss_cls.new_tensor([num_pos])), min=1).item()
+        bbox_preds = bbox_preds.reshape(-1, bbox_preds.size(-1))
+        ntargets = normalize_bbox(bbox_targets, self.pc_range)
+        ok = torch.isfinite(ntargets).all(dim=-1)
+        bbox_weights = bbox_weights * self.code_weights
+        loss_bbox = losses.l1_loss(bbox_preds[ok, :10], ntargets[ok, :10], bbox_weights[ok, :10],
+                                   avg_factor=num_pos_t,
+                                   loss_weight=self.loss_bbox_cfg.get('loss_weight', 1.0))
+        return torch.nan_to_num(loss_cls, nan=0.0), torch.nan_to_num(loss_bbox, nan=0.0)
+
+    def loss(self, gt_bboxes_list, gt_labels_list, preds_dicts, gt_bboxes_ignore=None):
+        """HEAD:919-1001.  gt boxes: objects with ``gravity_center`` / ``tensor``
+        (mmdet3d LiDARInstance3DBoxes) or plain [n,9] gravity-centre tensors.
+        Forward value of the losses; the backward kernels of the radar stack
+        are the next row of the scope table."""
+        assert gt_bboxes_ignore is None
+        if self.assigner is None:
+            raise L.TransCARHipError('loss() needs train_cfg=dict(assigner=...) at construction')
+        all_cls, all_box = preds_dicts['all_cls_scores'], preds_dicts['all_bbox_preds']
+        device = gt_labels_list[0].device
+        gts = []
+        for g in gt_bboxes_list:
+            if hasattr(g, 'gravity_center'):
+                g = torch.cat((g.gravity_center, g.tensor[:, 3:]), dim=1)
+            gts.append(g.to(device))
+        loss_dict = {}
+        per_layer = [self.loss_single(all_cls[i], all_box[i], gts, gt_labels_list)
+                     for i in range(len(all_cls))]
+        loss_dict['loss_cls'], loss_dict['loss_bbox'] = per_layer[-1]
+        for i, (lc, lb) in enumerate(per_layer[:-1]):
+            loss_dict['d%d.loss_cls' % i] = lc
+            loss_dict['d%d.loss_bbox' % i] = lb
+        return loss_dict

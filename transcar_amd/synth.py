@@ -290,5 +290,18 @@ def make_radar_frame(seed=2, n_per_radar=51, centres=None, near_frac=0.8,
     return frame
 
 
+def make_gt(seed=7, n=24, num_classes=10):
+    """Synthetic ground truth of one frame: boxes [n,9] = (x, y, z_bottom, w, l, h,
+    yaw, vx, vy) in the LiDAR-box convention of mmdet3d, labels [n]."""
+    rng = np.random.RandomState(seed)
+    b = np.zeros((n, 9), dtype=np.float32)
+    b[:, 0:2] = rng.uniform(-50, 50, (n, 2))
+    b[:, 2] = rng.uniform(-2.5, 0.5, n)
+    b[:, 3:6] = np.exp(rng.normal(0.5, 0.3, (n, 3)))
+    b[:, 6] = rng.uniform(-np.pi, np.pi, n)
+    b[:, 7:9] = rng.normal(0, 2, (n, 2))
+    return b, rng.randint(0, num_classes, n).astype(np.int64)
+
+
 def pc_range():
     return list(point_cloud_range)
