@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/<tag>/ (written by tools/profile_round.sh on the MI355X box)
+into the committed summaries under profiles/:
+
+    python tools/collect_profile.py r1f r1
+
+  profiles/<name>_bench.json         bench.py lines (B=1, and B=2/4 side runs)
+  profiles/<name>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary
+  profiles/<name>_frame_trace.txt    one replayed frame, kernel by kernel
+  profiles/<name>_pmc.json           FETCH_SIZE / WRITE_SIZE per launch
+                                     (separate --pmc passes) -> HBM-side bytes
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import OrderedDict, defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def one(pattern):
+    g = sorted(glob.glob(pattern))
+    if not g:
+        raise SystemExit('missing ' + pattern)
+    return g[0]
+
+
+def short(name):
+    n = name.replace('(anonymous namespace)::', '').split('(')[0]
+    n = n.replace('void ', '').replace('tc::', '')
+    return n.strip()
+
+
+def label_chain(rows, num_layers=6):
+    """chain_kernel launches are told apart by their neighbours in dispatch
+    order: the small grid is the radar encoder (side stream); a full-grid
+    launch right after self_attn is a decoder layer, one right before the first
+    self_attn of a frame is the prologue, the one after the last decoder layer
+    of a frame is the radar chain; back-to-back launches without attention in
+    between are bench.py's roofline replay of the decoder layer."""
+    for r in rows:
+        r['K'] = short(r['Kernel_Name'])
+    main_rows = []
+    for r in rows:
+        if r['K'].startswith('chain_kernel') and int(r['Grid_Size']) < 256 * 128:
+            r['K'] = 'chain_kernel(radar encoders)'
+        elif r['K'].startswith('chain_kernel') or r['K'].startswith('self_attn') or 'box_decode' in r['K']:
+            main_rows.append(r)
+    n_dec = 0
+    for i, r in enumerate(main_rows):
+        if not r['K'].startswith('chain_kernel'):
+            if 'box_decode' in r['K']:
+                n_dec = 0
+            continue
+        prev = main_rows[i - 1]['K'] if i else ''
+        nxt = main_rows[i + 1]['K'] if i + 1 < len(main_rows) else ''
+        if prev.startswith('self_attn'):
+            r['K'] = 'chain_kernel(decoder layer)'
+            n_dec += 1
+        elif nxt.startswith('self_attn'):
+            r['K'] = 'chain_kernel(prologue)'
+            n_dec = 0
+        elif n_dec == num_layers and 'box_decode' in nxt:
+            r['K'] = 'chain_kernel(radar)'
+        else:
+            r['K'] = 'chain_kernel(decoder layer)'      # roofline replay
+
+
+def main():
+    tag, name = sys.argv[1], sys.argv[2]
+    src = os.path.join(ROOT, 'gpurun_out', tag)
+    dst = os.path.join(ROOT, 'profiles')
+    os.makedirs(dst, exist_ok=True)
+
+    lines = []
+    for f in ('bench.json', 'bench_b2.json', 'bench_b4.json'):
+        p = os.path.join(src, f)
+        if os.path.exists(p):
+            for ln in open(p):
+                ln = ln.strip()
+                if ln.startswith('{'):
+                    lines.append(ln)
+    open(os.path.join(dst, name + '_bench.json'), 'w').write('\n'.join(lines) + '\n')
+
+    stats = one(os.path.join(src, 'prof', '*', '*kernel_stats.csv'))
+    open(os.path.join(dst, name + '_kernel_stats.csv'), 'w').write(open(stats).read())
+
+    # one frame of the trace: the last full graph replay
+    trace = one(os.path.join(src, 'prof', '*', '*kernel_trace.csv'))
+    rows = list(csv.DictReader(open(trace)))
+    for r in rows:       # the trace csv splits the grid per axis, the counter csv does not
+        if 'Grid_Size' not in r:
+            r['Grid_Size'] = str(int(r['Grid_Size_X']) * int(r['Grid_Size_Y']) * int(r['Grid_Size_Z']))
+    rows.sort(key=lambda r: int(r['Dispatch_Id']))
+    label_chain(rows)
+    dec = [i for i, r in enumerate(rows) if 'box_decode' in r['Kernel_Name']]
+    out = ['# one frame of `bench.py` (hipGraph replay) from rocprofv3 --kernel-trace on MI355X; us',
+           '# %-44s %10s %10s %10s' % ('kernel', 'grid', 'start', 'dur')]
+    if len(dec) >= 2:
+        a, b = dec[-2] + 1, dec[-1] + 1
+        t0 = int(rows[a]['Start_Timestamp'])
+        for r in rows[a:b]:
+            s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+            out.append('%-46s %10s %10.1f %10.1f' % (r['K'][:46], r['Grid_Size'],
+                                                     (s - t0) / 1e3, (e - s) / 1e3))
+        out.append('# frame span %.1f us' % ((int(rows[b - 1]['End_Timestamp']) - t0) / 1e3))
+    # average duration per (kernel, grid)
+    agg = defaultdict(list)
+    for r in rows:
+        agg[(r['K'], r['Grid_Size'])].append(
+            (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+    out.append('')
+    out.append('# average duration per (kernel, grid size) over the whole run')
+    for (k, g), v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        out.append('%-46s %10s  n=%-6d avg %8.1f us  total %10.1f us' % (k[:46], g, len(v), sum(v) / len(v), sum(v)))
+    open(os.path.join(dst, name + '_frame_trace.txt'), 'w').write('\n'.join(out) + '\n')
+
+    # PMC: KB per launch per (kernel, grid)
+    pmc = {}
+    for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+        d = 'pmc_fetch' if ctr == 'FETCH_SIZE' else 'pmc_write'
+        try:
+            f = one(os.path.join(src, d, '*', '*counter_collection.csv'))
+        except SystemExit:
+            continue
+        acc = defaultdict(list)
+        crow = [r for r in csv.DictReader(open(f)) if r['Counter_Name'] == ctr]
+        crow.sort(key=lambda r: int(r['Dispatch_Id']))
+        label_chain(crow)
+        for r in crow:
+            acc[r['K']].append(float(r['Counter_Value']))
+        for k, v in acc.items():
+            pmc.setdefault(k, {})[ctr] = sum(v) / len(v)
+    # name the launches the bench quotes; decoder chain = the chain_kernel grid launched 6x / frame
+    res = OrderedDict()
+    res['_comment'] = ('rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, kernel-trace only) of '
+                       '`bench.py --no-graph --steps 5`, MI355X. KB per launch as reported; traffic_bytes = '
+                       '(2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE tallies 64 B per 128-B request, '
+                       'MI355X_MICROARCH.md, HBM section).')
+    for k, v in sorted(pmc.items()):
+        nm = 'self_attn_kernel' if k.startswith('self_attn_kernel') else k
+        if nm.startswith('at::') or nm.startswith('__amd'):
+            continue
+        fk, wk = v.get('FETCH_SIZE', 0.0), v.get('WRITE_SIZE', 0.0)
+        res[nm] = {'fetch_kb': round(fk, 1), 'write_kb': round(wk, 1),
+                   'traffic_bytes': int((2 * fk + wk) * 1024)}
+    json.dump(res, open(os.path.join(dst, name + '_pmc.json'), 'w'), indent=1)
+    print(open(os.path.join(dst, name + '_frame_trace.txt')).read())
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Round profile on an MI355X box (run through gpurun from the repo root):
+#   gpurun --timeout 1500 -- 'bash tools/profile_round.sh r1'
+# Writes under gpurun_out/<tag>/ : GPU test log, bench JSON line, rocprofv3
+# kernel stats + trace of the same bench command, and the two PMC passes
+# (FETCH_SIZE / WRITE_SIZE, separate runs, kernel-trace only).  Copy what is to
+# be judged into profiles/ with tools/collect_profile.py.
+set -u
+TAG=${1:-r1}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+python -m pytest tests -x -q -m gpu > "$OUT/pytest_gpu.log" 2>&1
+echo "pytest rc=$?" >> "$OUT/pytest_gpu.log"
+python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+python bench.py --batch 2 --no-cpu-baseline > "$OUT/bench_b2.json" 2>> "$OUT/bench.err"
+python bench.py --batch 4 --no-cpu-baseline > "$OUT/bench_b4.json" 2>> "$OUT/bench.err"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python3 "$REPO/bench.py" --steps 50 --warmup 5 --no-cpu-baseline > "$OUT/prof.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-graph > "$OUT/pmc_fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-graph > "$OUT/pmc_write.log" 2>&1
+cd "$REPO"
+# keep the merge-back small: stats csv + counter csv only
+find "$OUT" -name '*.db' -delete 2>/dev/null
+find "$OUT" -name '*kernel_trace.csv' -size +20M -delete 2>/dev/null
+ls -R "$OUT" | head -50
+tail -3 "$OUT/pytest_gpu.log"; cat "$OUT/bench.json"
