@@ -200,6 +200,58 @@ def g7_loss(ref):
     print({k: float(v) for k, v in losses.items()})
 
 
+def freeze_like_train_py(head):
+    """tools/train.py:245-252: the DETR3D part of the head is frozen."""
+    for grp in (head.transformer, head.cls_branches, head.reg_branches, head.query_embedding):
+        for p in grp.parameters():
+            p.requires_grad = False
+
+
+def g8_train_grads(ref):
+    """One training iteration's gradients from the reference: Detr3DHead.forward (tiny
+    shapes, radar near the G5 centres) -> loss() -> sum of the six losses (mmdet
+    `_parse_losses`) -> backward, dropout off (eval mode), frozen groups as in
+    tools/train.py:245-252.  Stored per trainable parameter: [sum, sum|.|, l2] in
+    float64 and the first 16 entries."""
+    head = RH.build_reference_head(configs.head_cfg(), configs.train_cfg_pts)
+    sd = synth.make_state_dict(seed=3)
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    head.eval()
+    freeze_like_train_py(head)
+    g5 = np.load(os.path.join(HERE, 'g5_head_tiny.npz'))
+    feats = synth.make_feats('tiny', seed=1, smooth=SMOOTH)
+    l2i = synth.make_lidar2img()
+    frame = synth.make_radar_frame(seed=2, n_per_radar=51, centres=g5['radar_centres'])
+    boxes, labels = synth.make_gt(seed=7, n=24)
+    with torch.enable_grad():
+        outs, cap, _ = run_head(head, feats, l2i, frame)
+        d = np.abs(outs['all_cls_scores'].detach().numpy() - g5['all_cls_scores']).max()
+        assert d < 5e-4, d                      # same frame as fixture G5 (tiny)
+        losses = head.loss([RH.GtBoxes(torch.from_numpy(boxes))], [torch.from_numpy(labels)], outs)
+        total = sum(v for k, v in losses.items() if 'loss' in k)
+        total.backward()
+    out = {'total_loss': float(total),
+           'all_cls_scores': outs['all_cls_scores'].detach().numpy(),
+           'all_bbox_preds': outs['all_bbox_preds'].detach().numpy(),
+           'Lq': np.array([cap['Lq%d' % i] for i in range(3)])}
+    out.update({'loss__' + k.replace('.', '_'): float(v) for k, v in losses.items()})
+    names = []
+    for k, p in head.named_parameters():
+        if not p.requires_grad:
+            continue
+        key = k.replace('.', '__')
+        if p.grad is None:                       # attention_weights2/3, output_proj2/3
+            out[key + '__none'] = np.zeros(1)
+            continue
+        g = p.grad.detach().double().flatten()
+        out[key + '__stats'] = np.array([g.sum(), g.abs().sum(), g.norm()], np.float64)
+        out[key + '__head'] = g[:16].float().numpy()
+        names.append(k)
+    save('g8_train_grads.npz', **out)
+    print('g8: total loss', float(total), len(names), 'parameters with gradients,',
+          sum(p.numel() for p in head.parameters() if p.requires_grad), 'trainable scalars')
+
+
 def main():
     ref = RH.load_reference()
     head, _ = ref_head()
@@ -209,6 +261,7 @@ def main():
     g345_head(head, ref, 'res101', 'res101')
     g4_radar_empty(head)
     g7_loss(ref)
+    g8_train_grads(ref)
 
 
 if __name__ == '__main__':

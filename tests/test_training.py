@@ -124,3 +124,65 @@ def test_loss_normalisers_all_reduce_gloo_world2(tmp_path, golden_dir):
     for p in procs:
         out, _ = p.communicate(timeout=180)
         assert p.returncode == 0, out.decode()
+
+
+# ---------------------------------------------------------------------------
+# gradients of one training iteration (fixture G8 = the reference's backward)
+# ---------------------------------------------------------------------------
+FROZEN = ('transformer.', 'cls_branches.', 'reg_branches.', 'query_embedding.', 'code_weights')
+
+
+def trainable(name):
+    """tools/train.py:245-252 freezes the DETR3D part of the head."""
+    return not name.startswith(FROZEN)
+
+
+def g8_inputs(golden_dir):
+    g5 = np.load(os.path.join(golden_dir, 'g5_head_tiny.npz'))
+    feats = synth.make_feats('tiny', seed=1, smooth=(4, 6))
+    l2i = synth.make_lidar2img()
+    frame = synth.make_radar_frame(seed=2, n_per_radar=51, centres=g5['radar_centres'])
+    boxes, labels = synth.make_gt(seed=7, n=24)
+    return feats, l2i, frame, boxes, labels
+
+
+def check_grads_against_g8(grads, g8, rtol, what):
+    """grads: {state_dict key: tensor or None}."""
+    checked = 0
+    for k, g in grads.items():
+        key = k.replace('.', '__')
+        if key + '__none' in g8.files:
+            assert g is None or float(g.abs().max()) == 0.0, k
+            continue
+        ref = g8[key + '__stats']
+        gd = g.detach().double().flatten().cpu()
+        got = np.array([gd.sum(), gd.abs().sum(), gd.norm()])
+        scale = ref[1]                      # sum |g|: the natural magnitude for all three
+        assert abs(got[1] - ref[1]) <= rtol * scale, (what, k, got, ref)
+        assert abs(got[2] - ref[2]) <= rtol * max(ref[2], 1e-12), (what, k, got, ref)
+        assert abs(got[0] - ref[0]) <= rtol * scale, (what, k, got, ref)
+        head = g8[key + '__head']
+        tol = rtol * max(np.abs(head).max(), ref[2] / np.sqrt(gd.numel()))
+        assert np.abs(gd[:16].float().numpy() - head).max() <= 4 * tol, (what, k)
+        checked += 1
+    assert checked == 98
+    return checked
+
+
+def test_oracle_backward_matches_reference(golden_dir):
+    g8 = np.load(os.path.join(golden_dir, 'g8_train_grads.npz'))
+    feats, l2i, frame, boxes, labels = g8_inputs(golden_dir)
+    sd = O.to_torch_sd(synth.make_state_dict(3))
+    for k, v in sd.items():
+        if trainable(k):
+            v.requires_grad_(True)
+    f36 = O.build_radar_features(frame)
+    outs = O.head_forward(sd, [torch.from_numpy(f) for f in feats],
+                          torch.from_numpy(l2i).float()[None], configs.IMG_SHAPE[:2], f36,
+                          configs.point_cloud_range)
+    assert np.abs(outs['all_cls_scores'].detach().numpy() - g8['all_cls_scores']).max() < 5e-4
+    res, _ = O.loss(outs, torch.from_numpy(boxes), torch.from_numpy(labels), sd['code_weights'])
+    total = sum(res.values())
+    assert abs(float(total) - float(g8['total_loss'])) < 1e-4 * float(g8['total_loss'])
+    total.backward()
+    check_grads_against_g8({k: v.grad for k, v in sd.items() if trainable(k)}, g8, 2e-3, 'oracle')
