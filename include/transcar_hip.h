@@ -34,7 +34,7 @@ extern "C" {
 #define TC_MAX_LEVELS 4
 #define TC_MAX_LAYERS 8
 #define TC_MAX_RADAR_LAYERS 3
-#define TC_ABI_VERSION 2
+#define TC_ABI_VERSION 3
 
 typedef void* tc_stream_t;
 
@@ -105,6 +105,8 @@ typedef struct {
   float* init_reference;      /*               [B, Q, 3]                              */
   float* inter_references;    /*               [L, B, Q, 3]                           */
   int*   radar_hit_counts;    /* per radar layer [R, B, Q]: radar tokens inside the gate */
+  float* last_box;            /* `tmp` of the last decoder level, xy/z in metres
+                                 (HEAD:287-293) [B, Q, code_size]: gate geometry of radar layer 1 */
   unsigned long long* sample_pairs; /* [1]: += number of visible (query,cam) pairs sampled */
 } tc_head_aux;
 
@@ -257,6 +259,85 @@ int tc_head_forward(const tc_head_weights* w, const tc_head_weights* packed_view
                     float* all_cls_scores, float* all_bbox_preds,
                     const tc_head_aux* aux /*may be NULL*/,
                     void* workspace, size_t workspace_bytes, tc_stream_t stream);
+
+
+/* ======================================================================
+ * Training.  tools/train.py:245-252
+ * freezes the DETR3D decoder, so one iteration differentiates the radar
+ * encoders, the three gated radar fusion layers and final_cls* / final_reg*
+ * (HEAD:531-729).  The frozen decoder runs through tc_head_forward (aux gives
+ * hs, references, last_box); the trainable stack runs operator by operator so
+ * that the host autograd (the reference's own boundary for training: plain
+ * nn.Modules, `loss.backward()`) can save activations, with these backward
+ * entry points behind torch.autograd.Function (transcar_amd/autograd_ops.py).
+ * Gradient outputs named "+=" accumulate with fp32 atomics: zero them first.
+ * ====================================================================== */
+
+/* y = res + (row_gate[m] > 0 ? x W^T + b : 0): the row-subset update of
+ * HEAD:581 (`query_feat[nan_row_index] += tgt2`).  row_gate [M] may be NULL. */
+int tc_linear_gated_fwd(const float* x, const float* w, const float* b, const float* res,
+                        const int* row_gate, float* y, int M, int K, int N, tc_stream_t stream);
+
+/* nn.Linear backward.  dY~ = dY masked by the layer's own ReLU (y_relu = its
+ * saved output, NULL if none) and by row_gate (NULL if none).
+ *   data:   dx[M,K] (=|+=) alpha * dY~ W     (x_relu: zero dx where the saved
+ *           ReLU output that fed this layer is <= 0; may be NULL)
+ *   weight: dw[N,K] += alpha * dY~^T x ; db[N] += alpha-less column sums of dY~
+ *           (db may be NULL) */
+int tc_linear_bwd_data(const float* dy, const float* y_relu, const int* row_gate,
+                       const float* w, const float* x_relu, float* dx, int M, int K, int N,
+                       float alpha, int accumulate, tc_stream_t stream);
+int tc_linear_bwd_weight(const float* x, const float* dy, const float* y_relu,
+                         const int* row_gate, float* dw, float* db, int M, int K, int N,
+                         float alpha, tc_stream_t stream);
+
+/* backward of tc_add_layernorm_fwd: y = LN(a (+b)) (ReLU if y_relu != NULL, the
+ * saved output).  dz [M,C] = grad of a (and of b); dgamma/dbeta [C] += . C = 256 */
+int tc_add_layernorm_bwd(const float* a, const float* b, const float* gamma, const float* dy,
+                         const float* y_relu, float* dz, float* dgamma, float* dbeta, int M,
+                         int C, tc_stream_t stream);
+
+/* HEAD:544-547 / 596-598: from the normalised last reference [M,3]:
+ * centre_xy [M,2] in metres and the add-reference (x_m, y_m, z NORMALISED). */
+int tc_radar_reference_l1(const float* ref, const float* pc_range /*host[6]*/, float* centre_xy,
+                          float* add_ref, int M, tc_stream_t stream);
+
+/* HEAD:599-600 (661-662, 719-720): box = reg_out; box[0:2] += ref_xy; box[4] += ref_z.
+ * ref_xy at ref_xy[m*ld_xy + {0,1}], ref_z at ref_z[m*ld_z].  Backward into the
+ * previous layer's box (layers 2, 3: the reference IS the previous box):
+ * d_prev[{0,1,4}] += d_box[{0,1,4}]. */
+int tc_box_add_ref_fwd(const float* reg_out, int code_size, const float* ref_xy, int ld_xy,
+                       const float* ref_z, int ld_z, float* box, int M, tc_stream_t stream);
+int tc_box_add_ref_bwd(const float* d_box, int code_size, float* d_prev_box, int M,
+                       tc_stream_t stream);
+
+/* The gated attention core of tc_radar_gated_xattn_fwd on projected operands:
+ *   qproj [B*Q,C] (unscaled: q_scale = 1/sqrt(C/H) is applied inside),
+ *   kv [B*T,2C] = K | V, centre at centre_xy[m*ld_c + {0,1}], box [B*Q,code],
+ *   token xy at radar_xy[(b*T+t)*ld_xy + {0,1}]
+ *   -> attn_out [B*Q,C] (zero rows without a hit), hit_counts [B*Q].
+ * Backward: dq [B*Q,C] (=), dkv [B*T,2C] (+=). */
+int tc_radar_attn_core_fwd(const float* qproj, float q_scale, const float* kv,
+                           const float* centre_xy, int ld_c, const float* box, int code_size,
+                           const float* radar_xy, int ld_xy, int B, int Q, int T, int C,
+                           int num_heads, int pad_mult, float radius_min, float radius_max,
+                           float* attn_out, int* hit_counts, tc_stream_t stream);
+int tc_radar_attn_core_bwd(const float* qproj, float q_scale, const float* kv,
+                           const float* centre_xy, int ld_c, const float* box, int code_size,
+                           const float* radar_xy, int ld_xy, int B, int Q, int T, int C,
+                           int num_heads, int pad_mult, float radius_min, float radius_max,
+                           const float* attn_out, const float* d_attn, float* dq, float* dkv,
+                           tc_stream_t stream);
+
+/* Optimizer on the flat fp32 bucket of the trainable parameters (one RCCL
+ * all-reduce): out[0] += sum g^2;  torch.optim.AdamW step with
+ * mmcv's grad clip (CFG:214 max_norm=35; coef = max_norm/(norm+1e-6) if < 1)
+ * evaluated on the device from sq_norm[0] (NULL or max_norm <= 0: no clip);
+ * g is multiplied by grad_scale first (1/world_size after a SUM all-reduce). */
+int tc_sq_norm(const float* g, size_t n, float* out, tc_stream_t stream);
+int tc_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, int step,
+                  float grad_scale, float max_norm, const float* sq_norm, tc_stream_t stream);
 
 #ifdef __cplusplus
 }

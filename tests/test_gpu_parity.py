@@ -18,7 +18,12 @@ from parity_util import assert_rows_match, frac_within
 from transcar_amd import configs, synth
 
 pytestmark = pytest.mark.gpu
-torch.set_grad_enabled(False)
+
+
+@pytest.fixture(autouse=True)
+def _no_grad():
+    with torch.no_grad():
+        yield
 
 PCR = configs.point_cloud_range
 HW = configs.IMG_SHAPE[:2]

@@ -1,0 +1,292 @@
+"""Backward kernels and one training iteration on the MI355X (pytest -m gpu).
+
+* every backward entry point of the C ABI against a plain PyTorch fp32
+  reference of the same operator (CPU autograd) on identical inputs;
+* the whole iteration (frozen decoder -> radar stack -> loss -> backward)
+  against fixture G8 = the REFERENCE's own gradients, and against the oracle;
+* AdamW + grad clip on the flat bucket against torch.optim.AdamW.
+Tolerances are relative to the gradient's magnitude: 1e-4 per operator (fp32,
+different summation order, atomics), 2e-3 end to end (as the oracle-vs-reference
+check in tests/test_training.py).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import transcar_oracle as O
+from test_training import check_grads_against_g8, g8_inputs, trainable
+from transcar_amd import configs, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def A():
+    import transcar_amd
+    assert torch.cuda.is_available(), 'gpu tests need a GPU'
+    transcar_amd.lib()
+    from transcar_amd import autograd_ops
+    return autograd_ops
+
+
+def rel(a, b):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-12))
+
+
+def leaf(arr, grad=True):
+    t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32))
+    return t.requires_grad_(grad)
+
+
+def on_gpu(t):
+    return t.detach().clone().to(dev()).requires_grad_(t.requires_grad)
+
+
+@pytest.mark.parametrize('M,K,N,act', [(900, 256, 512, 1), (900, 512, 256, 0), (255, 36, 64, 1),
+                                       (255, 4, 256, 0), (900, 256, 10, 0), (1800, 256, 256, 1),
+                                       (7, 128, 256, 1)])
+def test_linear_backward(A, M, K, N, act):
+    rng = np.random.RandomState(M + K + N)
+    x, w = leaf(rng.standard_normal((M, K))), leaf(rng.standard_normal((N, K)) / np.sqrt(K))
+    b = leaf(rng.standard_normal(N))
+    dy = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32))
+    y = F.linear(x, w, b)
+    if act:
+        y = F.relu(y)
+    y.backward(dy)
+    xg, wg, bg = on_gpu(x), on_gpu(w), on_gpu(b)
+    yg = A.linear(xg, wg, bg, act)
+    assert rel(yg, y) < 2e-5
+    yg.backward(dy.to(dev()))
+    assert rel(xg.grad, x.grad) < 1e-4
+    assert rel(wg.grad, w.grad) < 1e-4
+    assert rel(bg.grad, b.grad) < 1e-4
+
+
+def test_linear_backward_frozen_weight_and_no_input_grad(A):
+    rng = np.random.RandomState(5)
+    x, w, b = leaf(rng.standard_normal((64, 36)), False), leaf(rng.standard_normal((64, 36))), leaf(rng.standard_normal(64))
+    xg, wg, bg = on_gpu(x), on_gpu(w), on_gpu(b)
+    A.linear(xg, wg, bg, 1).sum().backward()
+    F.relu(F.linear(x, w, b)).sum().backward()
+    assert xg.grad is None and rel(wg.grad, w.grad) < 1e-4 and rel(bg.grad, b.grad) < 1e-4
+
+
+def test_gated_linear_residual_backward(A):
+    rng = np.random.RandomState(9)
+    M, C = 900, 256
+    x, w, b = leaf(rng.standard_normal((M, C))), leaf(rng.standard_normal((C, C)) / 16), leaf(rng.standard_normal(C))
+    res = leaf(rng.standard_normal((M, C)))
+    gate = torch.from_numpy((rng.uniform(size=M) < 0.3).astype(np.int32) * rng.randint(1, 5, M).astype(np.int32))
+    dy = torch.from_numpy(rng.standard_normal((M, C)).astype(np.float32))
+    y = res + (gate > 0).float()[:, None] * F.linear(x, w, b)
+    y.backward(dy)
+    g = [on_gpu(t) for t in (x, w, b, res)]
+    yg = A.gated_linear_residual(g[0], g[1], g[2], g[3], gate.to(dev()))
+    assert rel(yg, y) < 2e-5
+    yg.backward(dy.to(dev()))
+    for a, r in zip(g, (x, w, b, res)):
+        assert rel(a.grad, r.grad) < 1e-4
+
+
+@pytest.mark.parametrize('M,relu,addend', [(900, False, True), (900, True, False), (255, True, False),
+                                           (3, False, False)])
+def test_layernorm_backward(A, M, relu, addend):
+    rng = np.random.RandomState(M)
+    a = leaf(rng.standard_normal((M, 256)) * 2 + 0.3)
+    b = leaf(rng.standard_normal((M, 256))) if addend else None
+    gam, bet = leaf(rng.standard_normal(256)), leaf(rng.standard_normal(256))
+    dy = torch.from_numpy(rng.standard_normal((M, 256)).astype(np.float32))
+    y = F.layer_norm(a + b if addend else a, (256,), gam, bet, 1e-5)
+    if relu:
+        y = F.relu(y)
+    y.backward(dy)
+    ag, gg, bg = on_gpu(a), on_gpu(gam), on_gpu(bet)
+    b2 = on_gpu(b) if addend else None
+    yg = A.add_layernorm(ag, b2, gg, bg, relu)
+    assert rel(yg, y) < 2e-5
+    yg.backward(dy.to(dev()))
+    assert rel(ag.grad, a.grad) < 1e-4
+    assert rel(gg.grad, gam.grad) < 1e-4 and rel(bg.grad, bet.grad) < 1e-4
+    if addend:
+        assert rel(b2.grad, b.grad) < 1e-4
+
+
+def _attn_reference(qproj, kv, centre_xy, box, radar_xy, rmin, rmax, pad_mult, heads=8):
+    """Masked multi-head attention on projected operands, torch CPU."""
+    Bn, Q, C = qproj.shape
+    T = kv.shape[1]
+    hd = C // heads
+    outs, hit_counts = [], []
+    for b in range(Bn):
+        mask = O.circle_mask(centre_xy[b:b + 1], box[b:b + 1, :, 3], box[b:b + 1, :, 6],
+                             box[b:b + 1, :, 7], radar_xy[b:b + 1], rmin, rmax)      # True = masked
+        q = (qproj[b] / hd ** 0.5).view(Q, heads, hd).transpose(0, 1)
+        k = kv[b, :, :C].view(T, heads, hd).transpose(0, 1)
+        v = kv[b, :, C:].view(T, heads, hd).transpose(0, 1)
+        s = q @ k.transpose(1, 2)
+        mult = torch.ones(T)
+        mult[-1] = pad_mult
+        s = s + torch.log(mult)[None, None]
+        s = s.masked_fill(mask[None], float('-inf'))
+        any_hit = (~mask).any(1)
+        p = torch.softmax(s, -1)
+        p = torch.where(any_hit[None, :, None], p, torch.zeros_like(p))
+        outs.append((p @ v).transpose(0, 1).reshape(Q, C))
+        hit_counts.append(((~mask).float() * mult[None]).sum(1))
+    return torch.stack(outs), torch.stack(hit_counts)
+
+
+@pytest.mark.parametrize('Bn,T,pad_mult,ld_c', [(1, 255, 1, 2), (2, 130, 1, 10), (1, 64, 1245, 2)])
+def test_radar_attn_core_backward(A, Bn, T, pad_mult, ld_c):
+    rng = np.random.RandomState(T)
+    Q, C = 900, 256
+    centres = rng.uniform(-40, 40, (Bn, Q, 2)).astype(np.float32)
+    box = rng.standard_normal((Bn, Q, 10)).astype(np.float32) * 0.5
+    box[..., 3] = rng.uniform(0.0, 1.8, (Bn, Q))
+    if ld_c == 10:
+        box[..., :2] = centres
+    tokens = rng.standard_normal((Bn, T, 36)).astype(np.float32)
+    idx = rng.randint(0, Q, (Bn, T))
+    for b in range(Bn):                        # most radar returns sit near a query centre
+        tokens[b, :, :2] = centres[b, idx[b]] + rng.uniform(-1.2, 1.2, (T, 2))
+    if pad_mult > 1:
+        tokens[:, -1, :] = 500.0
+        centres[0, 5] = [499.5, 500.2]         # one query that does hit the pad tokens
+        if ld_c == 10:
+            box[0, 5, :2] = centres[0, 5]
+    qp = leaf(rng.standard_normal((Bn, Q, C)))
+    kv = leaf(rng.standard_normal((Bn, T, 2 * C)))
+    d_out = torch.from_numpy(rng.standard_normal((Bn, Q, C)).astype(np.float32))
+    cen_t, box_t, tok_t = torch.from_numpy(centres), torch.from_numpy(box), torch.from_numpy(tokens)
+    ref, hits_ref = _attn_reference(qp, kv, cen_t, box_t, tok_t[..., :2].contiguous(), 1.0, 2.0, pad_mult)
+    ref.backward(d_out)
+    qg, kg = on_gpu(qp), on_gpu(kv)
+    centre_arg = box_t.to(dev()) if ld_c == 10 else cen_t.to(dev())
+    out, hits = A.radar_attn_core(qg, kg, centre_arg, ld_c, box_t.to(dev()), tok_t.to(dev()),
+                                  pad_mult, 1.0, 2.0)
+    agree = (hits.cpu().float() == hits_ref)
+    assert float(agree.float().mean()) > 0.995          # cdist rounding at the gate edge
+    assert int((hits_ref > 0).sum()) > 100
+    d = (out.detach().cpu() - ref.detach()).abs().amax(-1)
+    assert float(d[agree].max()) < 2e-5
+    if bool(agree.all()):
+        out.backward(d_out.to(dev()))
+        assert rel(qg.grad, qp.grad) < 1e-4
+        assert rel(kg.grad, kv.grad) < 1e-4
+    else:                                               # compare on the agreeing rows only
+        w = agree.float()[..., None]
+        ref2, _ = _attn_reference(qp, kv, cen_t, box_t, tok_t[..., :2].contiguous(), 1.0, 2.0, pad_mult)
+        qp.grad = None
+        kv.grad = None
+        ref2.backward(d_out * w)
+        out.backward((d_out * w).to(dev()))
+        assert rel(qg.grad, qp.grad) < 1e-4
+        assert rel(kg.grad, kv.grad) < 1e-4
+
+
+def test_box_add_ref_backward(A):
+    rng = np.random.RandomState(3)
+    reg, prev = leaf(rng.standard_normal((1, 900, 10))), leaf(rng.standard_normal((1, 900, 10)))
+    dy = torch.from_numpy(rng.standard_normal((1, 900, 10)).astype(np.float32))
+    ref = reg.clone()
+    ref[..., 0:2] = ref[..., 0:2] + prev[..., 0:2]
+    ref[..., 4:5] = ref[..., 4:5] + prev[..., 4:5]
+    ref.backward(dy)
+    rg, pg = on_gpu(reg), on_gpu(prev)
+    out = A.box_add_ref(rg, pg, None)
+    assert rel(out, ref) < 1e-6
+    out.backward(dy.to(dev()))
+    assert rel(rg.grad, reg.grad) == 0.0 and rel(pg.grad, prev.grad) == 0.0
+    addref = torch.from_numpy(rng.standard_normal((1, 900, 3)).astype(np.float32))
+    out = A.box_add_ref(on_gpu(reg), None, addref.to(dev()))
+    exp = reg.detach().clone()
+    exp[..., 0:2] += addref[..., 0:2]
+    exp[..., 4] += addref[..., 2]
+    assert rel(out, exp) < 1e-6
+
+
+# --------------------------------------------------------------------------
+# one training iteration
+# --------------------------------------------------------------------------
+def train_head(golden_dir):
+    import transcar_amd as T
+    cfg = configs.head_cfg()
+    cfg['train_cfg'] = configs.train_cfg_pts
+    h = T.build_head(cfg)
+    h.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(3).items()})
+    return h.to(dev()).freeze_decoder()
+
+
+def frame_inputs(golden_dir):
+    feats, l2i, frame, boxes, labels = g8_inputs(golden_dir)
+    metas = synth.make_img_metas(1, l2i)
+    metas[0]['radar'] = frame
+    gt = torch.from_numpy(boxes).clone()
+    gt[:, 2] += gt[:, 5] * 0.5
+    return [torch.from_numpy(f).to(dev()) for f in feats], metas, gt.to(dev()), torch.from_numpy(labels).to(dev())
+
+
+def test_train_forward_equals_eval_forward(A, golden_dir):
+    h = train_head(golden_dir)
+    feats, metas, _, _ = frame_inputs(golden_dir)
+    with torch.no_grad():
+        e = h.eval()(feats, metas)
+    t = h.train()(feats, metas)
+    assert t['all_cls_scores'].requires_grad and t['all_bbox_preds'].requires_grad
+    assert float((t['all_cls_scores'] - e['all_cls_scores']).abs().max()) < 2e-4
+    assert float((t['all_bbox_preds'] - e['all_bbox_preds']).abs().max()) < 2e-4
+
+
+def test_training_iteration_gradients_match_reference(A, golden_dir):
+    g8 = np.load(os.path.join(golden_dir, 'g8_train_grads.npz'))
+    h = train_head(golden_dir).train()
+    feats, metas, gt, labels = frame_inputs(golden_dir)
+    outs = h(feats, metas)
+    assert float((outs['all_cls_scores'].detach().cpu() - torch.from_numpy(g8['all_cls_scores'])).abs().max()) < 1e-3
+    losses = h.loss([gt], [labels], outs)
+    for k, v in losses.items():
+        ref = float(g8['loss__' + k.replace('.', '_')])
+        assert abs(float(v) - ref) < 2e-3 * max(1.0, abs(ref)), (k, float(v), ref)
+    total = sum(v for k, v in losses.items() if 'loss' in k)
+    total.backward()
+    grads = {k: p.grad for k, p in h.named_parameters() if trainable(k)}
+    assert check_grads_against_g8(grads, g8, 4e-3, 'hip') == 98
+    used = dict(h.trainable_parameters())
+    assert len(used) == 98 and sum(p.numel() for p in used.values()) == 2646316 - 2 * 256 * 3 \
+        - 2 * (24 * 256 + 24) - 2 * (256 * 256 + 256)
+
+
+def test_adamw_step_matches_torch(A):
+    import ctypes as C
+    from transcar_amd import _lib as L
+    rng = np.random.RandomState(0)
+    n = 100003
+    p0 = rng.standard_normal(n).astype(np.float32)
+    p_ref = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    opt = torch.optim.AdamW([p_ref], lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    p = torch.from_numpy(p0.copy()).to(dev())
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for step in range(1, 4):
+        g = rng.standard_normal(n).astype(np.float32) * (1.0 if step != 2 else 0.01)
+        p_ref.grad = torch.from_numpy(g.copy())
+        torch.nn.utils.clip_grad_norm_([p_ref], 35.0)
+        opt.step()
+        gd = torch.from_numpy(g * 2.0).to(dev())        # SUM over 2 ranks, averaged by grad_scale
+        sq = torch.zeros(1, device=dev())
+        L.check(L.lib().tc_sq_norm(gd.data_ptr(), n, sq.data_ptr(), s), 'tc_sq_norm')
+        assert abs(float(sq) - float((g.astype(np.float64) * 2) ** 2 @ np.ones(n))) < 1e-3 * float(sq)
+        L.check(L.lib().tc_adamw_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n,
+                                      2e-4, 0.9, 0.999, 1e-8, 0.01, step, 0.5, 35.0, sq.data_ptr(), s),
+                'tc_adamw_step')
+        assert float((p.cpu() - p_ref.detach()).abs().max()) < 2e-6

@@ -10,7 +10,14 @@ from oracle import transcar_oracle as O
 from transcar_amd import configs, synth
 from parity_util import assert_rows_match
 
-torch.set_grad_enabled(False)
+
+
+@pytest.fixture(autouse=True)
+def _no_grad():
+    with torch.no_grad():
+        yield
+
+
 PCR = configs.point_cloud_range
 HW = configs.IMG_SHAPE[:2]
 #: oracle vs reference, end to end through 6 decoder + 3 radar layers, fp32

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libtranscar_hip.so')
 TC_MAX_LEVELS = 4
 TC_MAX_LAYERS = 8
 TC_MAX_RADAR_LAYERS = 3
-TC_ABI_VERSION = 2
+TC_ABI_VERSION = 3
 
 c_fp = C.c_void_p      # device pointers travel as integers
 
@@ -93,7 +93,7 @@ class tc_feats_nhwc(C.Structure):
 class tc_head_aux(C.Structure):
     _fields_ = [('inter_states', c_fp), ('init_reference', c_fp),
                 ('inter_references', c_fp), ('radar_hit_counts', c_fp),
-                ('sample_pairs', c_fp)]
+                ('last_box', c_fp), ('sample_pairs', c_fp)]
 
 
 _P = C.POINTER
@@ -139,6 +139,26 @@ SIGNATURES = {
                              _P(tc_feats_nhwc), _i, _vp,
                              _f, _f, _vp, _i, _i, _vp, _vp, _P(tc_head_aux),
                              _vp, _sz, _vp]),
+    # training (backward of the trainable radar stack + optimizer)
+    'tc_linear_gated_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'tc_linear_bwd_data': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f,
+                                _i, _vp]),
+    'tc_linear_bwd_weight': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f,
+                                  _vp]),
+    'tc_add_layernorm_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i,
+                                  _i, _vp]),
+    'tc_radar_reference_l1': (_i, [_vp, _P(_f), _vp, _vp, _i, _vp]),
+    'tc_box_add_ref_fwd': (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp]),
+    'tc_box_add_ref_bwd': (_i, [_vp, _i, _vp, _i, _vp]),
+    'tc_radar_attn_core_fwd': (_i, [_vp, _f, _vp, _vp, _i, _vp, _i, _vp, _i,
+                                    _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp,
+                                    _vp]),
+    'tc_radar_attn_core_bwd': (_i, [_vp, _f, _vp, _vp, _i, _vp, _i, _vp, _i,
+                                    _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp,
+                                    _vp, _vp, _vp]),
+    'tc_sq_norm': (_i, [_vp, _sz, _vp, _vp]),
+    'tc_adamw_step': (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _f,
+                           _f, _vp, _vp]),
 }
 
 _lib = None

@@ -253,6 +253,8 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
     if (aux->inter_references)
       TC_HIP(hipMemcpyAsync(aux->inter_references, h.inter_refs, (size_t)L * rows * 3 * 4,
                             hipMemcpyDeviceToDevice, s));
+    if (aux->last_box)
+      TC_HIP(hipMemcpyAsync(aux->last_box, h.box_m, (size_t)rows * code * 4, hipMemcpyDeviceToDevice, s));
   }
   if (!radar) return 0;
   if (rs != s) TC_HIP(hipStreamWaitEvent(s, sd.join, 0));
@@ -603,6 +605,8 @@ int tc_head_forward(const tc_head_weights* w, const tc_head_weights* packed_view
     if (aux->inter_references)
       TC_HIP(hipMemcpyAsync(aux->inter_references, h.inter_refs, (size_t)L * rows * 3 * 4,
                             hipMemcpyDeviceToDevice, s));
+    if (aux->last_box)
+      TC_HIP(hipMemcpyAsync(aux->last_box, h.box_m, (size_t)rows * code * 4, hipMemcpyDeviceToDevice, s));
   }
   if (w->num_radar_layers == 0) return 0;
 
@@ -669,6 +673,98 @@ int tc_head_forward(const tc_head_weights* w, const tc_head_weights* packed_view
     TC_HIP(hipMemcpyAsync(aux->radar_hit_counts, h.hits, (size_t)w->num_radar_layers * rows * 4,
                           hipMemcpyDeviceToDevice, s));
   return 0;
+}
+
+// ---- training entry points (train.hip) ---------------------------------------
+int tc_linear_gated_fwd(const float* x, const float* w, const float* b, const float* res,
+                        const int* row_gate, float* y, int M, int K, int N, tc_stream_t stream) {
+  tc_linear lw{w, b};
+  return linear(x, K, lw, M, K, N, 0, y, N, as_stream(stream), nullptr, res, N, row_gate);
+}
+
+int tc_linear_bwd_data(const float* dy, const float* y_relu, const int* row_gate, const float* w,
+                       const float* x_relu, float* dx, int M, int K, int N, float alpha,
+                       int accumulate, tc_stream_t stream) {
+  return launch_linear_bwd_data(dy, y_relu, row_gate, w, x_relu, dx, M, K, N, alpha, accumulate,
+                                as_stream(stream));
+}
+
+int tc_linear_bwd_weight(const float* x, const float* dy, const float* y_relu, const int* row_gate,
+                         float* dw, float* db, int M, int K, int N, float alpha,
+                         tc_stream_t stream) {
+  return launch_linear_bwd_weight(x, dy, y_relu, row_gate, dw, db, M, K, N, alpha, as_stream(stream));
+}
+
+int tc_add_layernorm_bwd(const float* a, const float* b, const float* gamma, const float* dy,
+                         const float* y_relu, float* dz, float* dgamma, float* dbeta, int M, int C,
+                         tc_stream_t stream) {
+  TC_REQUIRE(C == 256, "layernorm_bwd: C=%d (256 supported)", C);
+  return launch_ln256_bwd(a, b, gamma, dy, y_relu, dz, dgamma, dbeta, M, as_stream(stream));
+}
+
+int tc_radar_reference_l1(const float* ref, const float* pc_range, float* centre_xy, float* add_ref,
+                          int M, tc_stream_t stream) {
+  return launch_radar_ref_l1(ref, pc_range, centre_xy, add_ref, M, as_stream(stream));
+}
+
+int tc_box_add_ref_fwd(const float* reg_out, int code_size, const float* ref_xy, int ld_xy,
+                       const float* ref_z, int ld_z, float* box, int M, tc_stream_t stream) {
+  return launch_box_add_ref(reg_out, code_size, ref_xy, ld_xy, ref_z, ld_z, box, nullptr, M,
+                            as_stream(stream));
+}
+
+int tc_box_add_ref_bwd(const float* d_box, int code_size, float* d_prev_box, int M,
+                       tc_stream_t stream) {
+  return launch_box_ref_bwd(d_box, code_size, d_prev_box, M, as_stream(stream));
+}
+
+static RadarAttnArgs radar_core_args(const float* qproj, float q_scale, const float* kv,
+                                     const float* centre_xy, int ld_c, const float* box,
+                                     int code_size, const float* radar_xy, int ld_xy, int B, int Q,
+                                     int T, int C, int num_heads, int pad_mult, float radius_min,
+                                     float radius_max) {
+  RadarAttnArgs r;
+  r.qproj = qproj; r.ldq = C; r.kv = kv; r.ldkv = 2 * C; r.centre_xy = centre_xy; r.ld_c = ld_c;
+  r.box = box; r.code = code_size; r.radar_xy = radar_xy; r.ld_xy = ld_xy;
+  r.B = B; r.Q = Q; r.T = T; r.C = C; r.H = num_heads; r.pad_mult = pad_mult;
+  r.rmin = radius_min; r.rmax = radius_max; r.attn_out = nullptr; r.hit_counts = nullptr;
+  r.qscale = q_scale;
+  return r;
+}
+
+int tc_radar_attn_core_fwd(const float* qproj, float q_scale, const float* kv,
+                           const float* centre_xy, int ld_c, const float* box, int code_size,
+                           const float* radar_xy, int ld_xy, int B, int Q, int T, int C,
+                           int num_heads, int pad_mult, float radius_min, float radius_max,
+                           float* attn_out, int* hit_counts, tc_stream_t stream) {
+  TC_REQUIRE(attn_out != nullptr && hit_counts != nullptr, "radar_attn_core: NULL output");
+  RadarAttnArgs r = radar_core_args(qproj, q_scale, kv, centre_xy, ld_c, box, code_size, radar_xy,
+                                    ld_xy, B, Q, T, C, num_heads, pad_mult, radius_min, radius_max);
+  r.attn_out = attn_out; r.hit_counts = hit_counts;
+  return launch_radar_attn(r, as_stream(stream));
+}
+
+int tc_radar_attn_core_bwd(const float* qproj, float q_scale, const float* kv,
+                           const float* centre_xy, int ld_c, const float* box, int code_size,
+                           const float* radar_xy, int ld_xy, int B, int Q, int T, int C,
+                           int num_heads, int pad_mult, float radius_min, float radius_max,
+                           const float* attn_out, const float* d_attn, float* dq, float* dkv,
+                           tc_stream_t stream) {
+  RadarAttnArgs r = radar_core_args(qproj, 1.0f, kv, centre_xy, ld_c, box, code_size, radar_xy,
+                                    ld_xy, B, Q, T, C, num_heads, pad_mult, radius_min, radius_max);
+  r.attn_out = const_cast<float*>(attn_out);
+  return launch_radar_attn_bwd(r, q_scale, d_attn, dq, dkv, as_stream(stream));
+}
+
+int tc_sq_norm(const float* g, size_t n, float* out, tc_stream_t stream) {
+  return launch_sqnorm(g, n, out, as_stream(stream));
+}
+
+int tc_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int step, float grad_scale,
+                  float max_norm, const float* sq_norm, tc_stream_t stream) {
+  return launch_adamw(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, max_norm,
+                      sq_norm, as_stream(stream));
 }
 
 }  // extern "C"

@@ -132,8 +132,27 @@ struct RadarAttnArgs {
   float rmin, rmax;
   float* attn_out;                     // [B*Q, C] (zero rows where no hit)
   int* hit_counts;                     // [B*Q]
+  float qscale = 1.0f;                 // applied to qproj on load (1 when pre-scaled)
 };
 int launch_radar_attn(const RadarAttnArgs& a, hipStream_t s);
+
+// ---- train.hip: backward of the trainable (radar) part + optimizer ----------
+int launch_linear_bwd_data(const float* dy, const float* relu_out, const int* row_gate,
+                           const float* w, const float* in_relu_mask, float* dx, int M, int K,
+                           int N, float alpha, int accumulate, hipStream_t s);
+int launch_linear_bwd_weight(const float* x, const float* dy, const float* relu_out,
+                             const int* row_gate, float* dw, float* db, int M, int K, int N,
+                             float alpha, hipStream_t s);
+int launch_ln256_bwd(const float* a, const float* b, const float* gamma, const float* dy,
+                     const float* relu_out, float* dz, float* dgamma, float* dbeta, int M,
+                     hipStream_t s);
+int launch_radar_attn_bwd(const RadarAttnArgs& a, float qscale, const float* d_attn, float* dq,
+                          float* dkv, hipStream_t s);
+int launch_box_ref_bwd(const float* d_box, int code, float* d_prev, int M, hipStream_t s);
+int launch_sqnorm(const float* g, size_t n, float* out, hipStream_t s);
+int launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1,
+                 float b2, float eps, float wd, int step, float grad_scale, float max_norm,
+                 const float* sqnorm, hipStream_t s);
 
 // ---- pack.hip: one-time weight re-layout for the fused chains ---------------
 size_t packed_floats(int N, int K);

@@ -27,7 +27,7 @@ namespace tc {
 struct RadK {
   const float* qproj; const float* kv; const float* cxy; const float* box; const float* rxy;
   int ldq, ldkv, code, ld_xy, ld_c, B, Q, T, pad_mult;
-  float rmin, rmax;
+  float rmin, rmax, qscale;
   float* attn_out; int* hits;
 };
 
@@ -38,7 +38,8 @@ __global__ __launch_bounds__(256) void radar_attn_kernel(RadK p) {
   const int b = row / p.Q;
   const float cx = p.cxy[(size_t)row * p.ld_c + 0], cy = p.cxy[(size_t)row * p.ld_c + 1];
   const float* bx = p.box + (size_t)row * p.code;
-  const float4 q4 = ld4(p.qproj + (size_t)row * p.ldq + 4 * lane);
+  float4 q4 = ld4(p.qproj + (size_t)row * p.ldq + 4 * lane);
+  q4.x *= p.qscale; q4.y *= p.qscale; q4.z *= p.qscale; q4.w *= p.qscale;
   int count = 0;
   const float4 o = radar_attn_row(cx, cy, bx[3], bx[6], bx[7], p.rmin, p.rmax, q4,
                                   p.rxy + (size_t)b * p.T * p.ld_xy, p.ld_xy,
@@ -54,7 +55,7 @@ int launch_radar_attn(const RadarAttnArgs& a, hipStream_t s) {
   RadK p;
   p.qproj = a.qproj; p.kv = a.kv; p.cxy = a.centre_xy; p.box = a.box; p.rxy = a.radar_xy;
   p.ldq = a.ldq; p.ldkv = a.ldkv; p.code = a.code; p.ld_xy = a.ld_xy; p.ld_c = a.ld_c;
-  p.B = a.B; p.Q = a.Q; p.T = a.T; p.pad_mult = a.pad_mult; p.rmin = a.rmin; p.rmax = a.rmax;
+  p.B = a.B; p.Q = a.Q; p.T = a.T; p.pad_mult = a.pad_mult; p.rmin = a.rmin; p.rmax = a.rmax; p.qscale = a.qscale;
   p.attn_out = a.attn_out; p.hits = a.hit_counts;
   const int rows = a.B * a.Q;
   hipLaunchKernelGGL(radar_attn_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, p);

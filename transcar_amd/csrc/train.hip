@@ -1,0 +1,388 @@
+// Backward kernels of the trainable part of the head (SURVEY.md section 8 rows
+// a16 / e / f3): tools/train.py:245-252 freezes the DETR3D decoder, so one
+// training iteration differentiates the radar encoders (HEAD:531-536), the three
+// gated radar fusion layers (HEAD:573-590 and the _2/_3 copies) and the
+// final_cls*/final_reg* MLPs (HEAD:592-600) -- 2,646,316 parameters.
+//
+//   bwd_gemm_kernel<DATA>    dX[M,K]  = dY~[M,N] W[N,K]          (nn.Linear, input grad)
+//   bwd_gemm_kernel<WEIGHT>  dW[N,K] += dY~^T[N,M] X[M,K],  db[N] += colsum dY~
+//        dY~ = dY with the layer's own ReLU mask (its saved output <= 0) and the
+//        row gate of the radar out_proj (rows without a radar hit, HEAD:581)
+//        applied while the tile is staged, so no masked copy is materialised.
+//        f32 MFMA 16x16x4 (exact f32 FMA chain) from LDS tiles; WEIGHT splits the
+//        900-row reduction over the grid and meets in fp32 atomics.
+//   ln_bwd_kernel            LayerNorm(a (+b)) (+ReLU): dz, dgamma +=, dbeta +=
+//   radar_attn_bwd_kernel    the gated attention core: one wavefront per query,
+//        the gate is re-evaluated exactly as in the forward (rowdev.hpp cdist_mm),
+//        softmax statistics are recomputed over the few hit tokens, dK/dV go to
+//        the token rows with atomics.
+//   box_ref_bwd_kernel, sqnorm / adamw kernels (flat bucket, device-side clip).
+#include "kernels.hpp"
+#include "rowdev.hpp"
+
+namespace tc {
+
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+enum { BWD_DATA = 0, BWD_WEIGHT = 1 };
+
+struct BwdGemmK {
+  const float* A; const float* relu; const int* gate; const float* Bm;
+  const float* cmask;          // DATA: zero dX where cmask (the producer's ReLU output) <= 0
+  float* C; float* colsum;
+  int ldA, ldB, ldC, I, J, R, rchunk, accumulate;
+  float alpha;
+};
+
+// C[I,J] (+)= alpha * sum_r A(i,r) B(r,j),  B(r,j) = Bm[r*ldB + j]
+//   DATA:   A(i,r) = dY[i*ldA + r]   (i = row m, r = n)
+//   WEIGHT: A(i,r) = dY[r*ldA + i]   (i = n,     r = row m)
+template <int MODE>
+__global__ __launch_bounds__(256) void bwd_gemm_kernel(BwdGemmK p) {
+  __shared__ float As[16 * 80];
+  __shared__ float Bs[16 * 80];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  const int rbeg = blockIdx.z * p.rchunk, rend = min(p.R, rbeg + p.rchunk);
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float csum = 0.f;
+  const bool do_colsum = MODE == BWD_WEIGHT && p.colsum != nullptr && blockIdx.x == 0;
+  for (int r0 = rbeg; r0 < rend; r0 += 16) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = tid + 256 * e;
+      int i, r;
+      if (MODE == BWD_DATA) { r = idx & 15; i = idx >> 4; }
+      else { i = idx & 63; r = idx >> 6; }
+      const int gi = i0 + i, gr = r0 + r;
+      float v = 0.f;
+      if (gi < p.I && gr < rend) {
+        const size_t off = MODE == BWD_DATA ? (size_t)gi * p.ldA + gr : (size_t)gr * p.ldA + gi;
+        v = p.A[off];
+        if (p.relu != nullptr && p.relu[off] <= 0.f) v = 0.f;
+        if (p.gate != nullptr && p.gate[MODE == BWD_DATA ? gi : gr] <= 0) v = 0.f;
+      }
+      if (MODE == BWD_DATA) As[i * 17 + r] = v; else As[r * 80 + i] = v;
+      // B tile, j fastest (coalesced rows of W / X)
+      const int j = idx & 63, rb = idx >> 6;
+      const int gj = j0 + j, grb = r0 + rb;
+      Bs[rb * 80 + j] = (gj < p.J && grb < rend) ? p.Bm[(size_t)grb * p.ldB + gj] : 0.f;
+    }
+    __syncthreads();
+    if (do_colsum && tid < 64) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) csum += As[r * 80 + tid];
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int k = 4 * kk + (lane >> 4);
+      const int ai = 16 * wave + (lane & 15);
+      const float a = MODE == BWD_DATA ? As[ai * 17 + k] : As[k * 80 + ai];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = MFMA4(a, Bs[k * 80 + 16 * t + (lane & 15)], acc[t]);
+    }
+    __syncthreads();
+  }
+  const bool atomic = MODE == BWD_WEIGHT || gridDim.z > 1;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int col = j0 + 16 * t + (lane & 15);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int row = i0 + 16 * wave + 4 * (lane >> 4) + reg;
+      if (row < p.I && col < p.J) {
+        float v = acc[t][reg] * p.alpha;
+        float* c = p.C + (size_t)row * p.ldC + col;
+        if (p.cmask != nullptr && p.cmask[(size_t)row * p.ldC + col] <= 0.f) v = 0.f;
+        if (atomic) unsafeAtomicAdd(c, v);
+        else if (p.accumulate) *c += v;
+        else *c = v;
+      }
+    }
+  }
+  if (do_colsum && tid < 64 && i0 + tid < p.I) unsafeAtomicAdd(p.colsum + i0 + tid, csum);
+}
+
+int launch_linear_bwd_data(const float* dy, const float* relu_out, const int* row_gate,
+                           const float* w, const float* in_relu_mask, float* dx, int M, int K,
+                           int N, float alpha, int accumulate, hipStream_t s) {
+  TC_REQUIRE(M > 0 && K > 0 && N > 0, "linear_bwd_data: M=%d K=%d N=%d", M, K, N);
+  BwdGemmK p;
+  p.A = dy; p.relu = relu_out; p.gate = row_gate; p.Bm = w; p.cmask = in_relu_mask; p.C = dx;
+  p.colsum = nullptr; p.ldA = N; p.ldB = K; p.ldC = K; p.I = M; p.J = K; p.R = N;
+  p.rchunk = ((N + 15) / 16) * 16; p.accumulate = accumulate; p.alpha = alpha;
+  hipLaunchKernelGGL(bwd_gemm_kernel<BWD_DATA>, dim3((K + 63) / 64, (M + 63) / 64, 1), dim3(256), 0,
+                     s, p);
+  return check_launch("linear_bwd_data");
+}
+
+int launch_linear_bwd_weight(const float* x, const float* dy, const float* relu_out,
+                             const int* row_gate, float* dw, float* db, int M, int K, int N,
+                             float alpha, hipStream_t s) {
+  TC_REQUIRE(M > 0 && K > 0 && N > 0, "linear_bwd_weight: M=%d K=%d N=%d", M, K, N);
+  BwdGemmK p;
+  p.A = dy; p.relu = relu_out; p.gate = row_gate; p.Bm = x; p.cmask = nullptr; p.C = dw;
+  p.colsum = db; p.ldA = N; p.ldB = K; p.ldC = K; p.I = N; p.J = K; p.R = M;
+  p.rchunk = 64; p.accumulate = 1; p.alpha = alpha;
+  TC_REQUIRE(dw != nullptr, "linear_bwd_weight: dw is NULL");
+  hipLaunchKernelGGL(bwd_gemm_kernel<BWD_WEIGHT>,
+                     dim3((K + 63) / 64, (N + 63) / 64, (M + p.rchunk - 1) / p.rchunk), dim3(256),
+                     0, s, p);
+  return check_launch("linear_bwd_weight");
+}
+
+// ---- LayerNorm(a (+b)) (+ReLU) backward, C = 256 ---------------------------
+struct LnBwdK {
+  const float* a; const float* b; const float* gamma; const float* dy; const float* relu_out;
+  float* dz; float* dgamma; float* dbeta; int M;
+};
+
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdK p) {
+  __shared__ float4 sg[4][64];
+  __shared__ float4 sb[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float4 g = ld4(p.gamma + 4 * lane);
+  float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int row = blockIdx.x * 4 + wave; row < p.M; row += gridDim.x * 4) {
+    const size_t o = (size_t)row * 256 + 4 * lane;
+    float4 z = ld4(p.a + o);
+    if (p.b != nullptr) { const float4 t = ld4(p.b + o); z.x += t.x; z.y += t.y; z.z += t.z; z.w += t.w; }
+    // same statistics as the forward (rowdev.hpp ln_row)
+    const float mean = wave_sum(z.x + z.y + z.z + z.w) * (1.0f / 256.0f);
+    const float4 d = make_float4(z.x - mean, z.y - mean, z.z - mean, z.w - mean);
+    const float q = wave_sum(d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / 256.0f) + 1e-5f);
+    const float4 xh = make_float4(d.x * rstd, d.y * rstd, d.z * rstd, d.w * rstd);
+    float4 dy = ld4(p.dy + o);
+    if (p.relu_out != nullptr) {
+      const float4 y = ld4(p.relu_out + o);
+      if (y.x <= 0.f) dy.x = 0.f;
+      if (y.y <= 0.f) dy.y = 0.f;
+      if (y.z <= 0.f) dy.z = 0.f;
+      if (y.w <= 0.f) dy.w = 0.f;
+    }
+    ag.x += dy.x * xh.x; ag.y += dy.y * xh.y; ag.z += dy.z * xh.z; ag.w += dy.w * xh.w;
+    ab.x += dy.x; ab.y += dy.y; ab.z += dy.z; ab.w += dy.w;
+    const float4 dx = make_float4(dy.x * g.x, dy.y * g.y, dy.z * g.z, dy.w * g.w);
+    const float s1 = wave_sum(dx.x + dx.y + dx.z + dx.w) * (1.0f / 256.0f);
+    const float s2 = wave_sum(dx.x * xh.x + dx.y * xh.y + dx.z * xh.z + dx.w * xh.w) * (1.0f / 256.0f);
+    st4(p.dz + o, make_float4(rstd * (dx.x - s1 - xh.x * s2), rstd * (dx.y - s1 - xh.y * s2),
+                              rstd * (dx.z - s1 - xh.z * s2), rstd * (dx.w - s1 - xh.w * s2)));
+  }
+  sg[wave][lane] = ag; sb[wave][lane] = ab;
+  __syncthreads();
+  if (wave == 0) {
+    float4 tg = sg[0][lane], tb = sb[0][lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      tg.x += sg[w][lane].x; tg.y += sg[w][lane].y; tg.z += sg[w][lane].z; tg.w += sg[w][lane].w;
+      tb.x += sb[w][lane].x; tb.y += sb[w][lane].y; tb.z += sb[w][lane].z; tb.w += sb[w][lane].w;
+    }
+    if (p.dgamma != nullptr) {
+      float* dg = p.dgamma + 4 * lane;
+      unsafeAtomicAdd(dg, tg.x); unsafeAtomicAdd(dg + 1, tg.y);
+      unsafeAtomicAdd(dg + 2, tg.z); unsafeAtomicAdd(dg + 3, tg.w);
+    }
+    if (p.dbeta != nullptr) {
+      float* dbp = p.dbeta + 4 * lane;
+      unsafeAtomicAdd(dbp, tb.x); unsafeAtomicAdd(dbp + 1, tb.y);
+      unsafeAtomicAdd(dbp + 2, tb.z); unsafeAtomicAdd(dbp + 3, tb.w);
+    }
+  }
+}
+
+int launch_ln256_bwd(const float* a, const float* b, const float* gamma, const float* dy,
+                     const float* relu_out, float* dz, float* dgamma, float* dbeta, int M,
+                     hipStream_t s) {
+  TC_REQUIRE(M > 0, "layernorm_bwd: M=%d", M);
+  LnBwdK p;
+  p.a = a; p.b = b; p.gamma = gamma; p.dy = dy; p.relu_out = relu_out; p.dz = dz;
+  p.dgamma = dgamma; p.dbeta = dbeta; p.M = M;
+  const int grid = min((M + 3) / 4, 256);
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, s, p);
+  return check_launch("layernorm_bwd");
+}
+
+// ---- gated radar attention core, backward ----------------------------------
+struct RadBwdK {
+  const float* qproj; const float* kv; const float* cxy; const float* box; const float* rxy;
+  const float* attn_out; const float* d_attn;
+  int ldq, ldkv, code, ld_xy, ld_c, B, Q, T, pad_mult;
+  float rmin, rmax, qscale;
+  float* dq; float* dkv;
+};
+
+__device__ __forceinline__ float head_sum(float s) {      // 8 lanes = one 32-channel head
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  s += __shfl_xor(s, 4, 64);
+  return s;
+}
+
+__global__ __launch_bounds__(256) void radar_attn_bwd_kernel(RadBwdK p) {
+  const int lane = threadIdx.x & 63;
+  const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (row >= p.B * p.Q) return;
+  const int b = row / p.Q;
+  const float cx = p.cxy[(size_t)row * p.ld_c + 0], cy = p.cxy[(size_t)row * p.ld_c + 1];
+  const float* bx = p.box + (size_t)row * p.code;
+  float4 q4 = ld4(p.qproj + (size_t)row * p.ldq + 4 * lane);
+  q4.x *= p.qscale; q4.y *= p.qscale; q4.z *= p.qscale; q4.w *= p.qscale;
+  const float* rxy = p.rxy + (size_t)b * p.T * p.ld_xy;
+  const float* kv = p.kv + (size_t)b * p.T * p.ldkv;
+  float* dkv = p.dkv + (size_t)b * p.T * p.ldkv;
+  // gate geometry: identical to rowdev.hpp radar_attn_row (HEAD:553-567)
+  const float len = expf(bx[3]);
+  const float rs = -bx[6], rc = -bx[7];
+  const float ox = __fmul_rn(__fmul_rn(len, 0.25f), rs), oy = __fmul_rn(__fmul_rn(len, 0.25f), rc);
+  const float fx = __fadd_rn(cx, ox), fy = __fadd_rn(cy, oy);
+  const float bxx = __fsub_rn(cx, ox), byy = __fsub_rn(cy, oy);
+  const float rad = fminf(fmaxf(len / 2.0f, p.rmin), p.rmax);
+  const float cn = sqnorm2(cx, cy), fn = sqnorm2(fx, fy), bn = sqnorm2(bxx, byy);
+  const float4 dO = ld4(p.d_attn + (size_t)row * 256 + 4 * lane);
+  const float4 o4 = ld4(p.attn_out + (size_t)row * 256 + 4 * lane);
+  const float D = head_sum(dO.x * o4.x + dO.y * o4.y + dO.z * o4.z + dO.w * o4.w);
+  float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
+  float m = -INFINITY, l = 0.f;
+  // pass 0: softmax statistics over the hit tokens;  pass 1: gradients
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int t0 = 0; t0 < p.T; t0 += 64) {
+      const int t = t0 + lane;
+      bool hit = false;
+      if (t < p.T) {
+        const float* y = rxy + (size_t)t * p.ld_xy;
+        const float y0 = y[0], y1 = y[1];
+        const float yn = sqnorm2(y0, y1);
+        hit = (cdist_mm(cx, cy, cn, y0, y1, yn) < rad) || (cdist_mm(fx, fy, fn, y0, y1, yn) < rad) ||
+              (cdist_mm(bxx, byy, bn, y0, y1, yn) < rad);
+      }
+      unsigned long long mask = __ballot(hit);
+      while (mask) {
+        const int j = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        const int tok = t0 + j;
+        const float mult = (tok == p.T - 1) ? (float)p.pad_mult : 1.0f;
+        const float* kvr = kv + (size_t)tok * p.ldkv + 4 * lane;
+        const float4 k4 = ld4(kvr);
+        const float sc = head_sum(q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w);
+        if (pass == 0) {
+          const float mnew = fmaxf(m, sc);
+          l = l * expf(m - mnew) + mult * expf(sc - mnew);
+          m = mnew;
+        } else {
+          const float4 v4 = ld4(kvr + 256);
+          const float pj = mult * expf(sc - m) / l;
+          const float dp = head_sum(dO.x * v4.x + dO.y * v4.y + dO.z * v4.z + dO.w * v4.w);
+          const float ds = pj * (dp - D);
+          dq.x += ds * k4.x; dq.y += ds * k4.y; dq.z += ds * k4.z; dq.w += ds * k4.w;
+          float* dk = dkv + (size_t)tok * p.ldkv + 4 * lane;
+          unsafeAtomicAdd(dk + 0, ds * q4.x); unsafeAtomicAdd(dk + 1, ds * q4.y);
+          unsafeAtomicAdd(dk + 2, ds * q4.z); unsafeAtomicAdd(dk + 3, ds * q4.w);
+          unsafeAtomicAdd(dk + 256, pj * dO.x); unsafeAtomicAdd(dk + 257, pj * dO.y);
+          unsafeAtomicAdd(dk + 258, pj * dO.z); unsafeAtomicAdd(dk + 259, pj * dO.w);
+        }
+      }
+    }
+  }
+  st4(p.dq + (size_t)row * 256 + 4 * lane,
+      make_float4(dq.x * p.qscale, dq.y * p.qscale, dq.z * p.qscale, dq.w * p.qscale));
+}
+
+int launch_radar_attn_bwd(const RadarAttnArgs& a, float qscale, const float* d_attn, float* dq,
+                          float* dkv, hipStream_t s) {
+  TC_REQUIRE(a.C == 256 && a.H == 8, "radar_attn_bwd: C=%d H=%d (256/8 supported)", a.C, a.H);
+  TC_REQUIRE(a.T > 0 && a.pad_mult >= 1, "radar_attn_bwd: T=%d pad_mult=%d", a.T, a.pad_mult);
+  RadBwdK p;
+  p.qproj = a.qproj; p.kv = a.kv; p.cxy = a.centre_xy; p.box = a.box; p.rxy = a.radar_xy;
+  p.attn_out = a.attn_out; p.d_attn = d_attn;
+  p.ldq = a.ldq; p.ldkv = a.ldkv; p.code = a.code; p.ld_xy = a.ld_xy; p.ld_c = a.ld_c;
+  p.B = a.B; p.Q = a.Q; p.T = a.T; p.pad_mult = a.pad_mult; p.rmin = a.rmin; p.rmax = a.rmax;
+  p.qscale = qscale; p.dq = dq; p.dkv = dkv;
+  const int rows = a.B * a.Q;
+  hipLaunchKernelGGL(radar_attn_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, p);
+  return check_launch("radar_attn_bwd");
+}
+
+// ---- box = reg_out (+ reference): backward into the previous layer's box ----
+// HEAD:661-665: tmp2[0:2] += new_reference_3d[0:2] (= tmp[0:2]), tmp2[4] += tmp[4]
+__global__ void box_ref_bwd_kernel(const float* d_box, int code, float* d_prev, int M) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  const float* d = d_box + (size_t)i * code;
+  float* o = d_prev + (size_t)i * code;
+  o[0] += d[0]; o[1] += d[1]; o[4] += d[4];
+}
+
+int launch_box_ref_bwd(const float* d_box, int code, float* d_prev, int M, hipStream_t s) {
+  TC_REQUIRE(M > 0 && code >= 5, "box_ref_bwd: M=%d code=%d", M, code);
+  hipLaunchKernelGGL(box_ref_bwd_kernel, dim3((M + 255) / 256), dim3(256), 0, s, d_box, code, d_prev, M);
+  return check_launch("box_ref_bwd");
+}
+
+// ---- optimizer on the flat gradient bucket ----------------------------------
+// sum of squares -> out[0] (+=); the clip coefficient stays on the device
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, size_t n, float* out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float v = g[i];
+    acc += v * v;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+int launch_sqnorm(const float* g, size_t n, float* out, hipStream_t s) {
+  TC_REQUIRE(n > 0, "sqnorm: n=0");
+  const int grid = (int)min((n + 255) / 256, (size_t)1024);
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(grid), dim3(256), 0, s, g, n, out);
+  return check_launch("sqnorm");
+}
+
+// torch.optim.AdamW step (decoupled weight decay) with mmcv's grad clip
+// (clip_grad_norm_: coef = max_norm / (norm + 1e-6), applied when < 1) and the
+// 1/world_size of the gradient all-reduce folded in.  sqnorm[0] = sum g^2 of the
+// already averaged gradient when grad_scale == 1, else of the raw sum.
+struct AdamK {
+  float* p; const float* g; float* m; float* v; size_t n;
+  float lr, b1, b2, eps, wd, bc1, bc2, grad_scale, max_norm;
+  const float* sqnorm;
+};
+
+__global__ __launch_bounds__(256) void adamw_kernel(AdamK a) {
+  float coef = a.grad_scale;
+  if (a.sqnorm != nullptr && a.max_norm > 0.f) {
+    const float norm = sqrtf(a.sqnorm[0]) * a.grad_scale;
+    const float c = a.max_norm / (norm + 1e-6f);
+    if (c < 1.0f) coef *= c;
+  }
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
+    const float g = a.g[i] * coef;
+    float pv = a.p[i];
+    pv *= 1.0f - a.lr * a.wd;
+    const float m = a.b1 * a.m[i] + (1.0f - a.b1) * g;
+    const float v = a.b2 * a.v[i] + (1.0f - a.b2) * g * g;
+    a.m[i] = m; a.v[i] = v;
+    const float denom = sqrtf(v) / sqrtf(a.bc2) + a.eps;
+    a.p[i] = pv - (a.lr / a.bc1) * (m / denom);
+  }
+}
+
+int launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1,
+                 float b2, float eps, float wd, int step, float grad_scale, float max_norm,
+                 const float* sqnorm, hipStream_t s) {
+  TC_REQUIRE(n > 0 && step >= 1, "adamw: n=%zu step=%d", n, step);
+  AdamK a;
+  a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.lr = lr; a.b1 = b1; a.b2 = b2; a.eps = eps;
+  a.wd = wd; a.bc1 = 1.0f - powf(b1, (float)step); a.bc2 = 1.0f - powf(b2, (float)step);
+  a.grad_scale = grad_scale; a.max_norm = max_norm; a.sqnorm = sqnorm;
+  const int grid = (int)min((n + 255) / 256, (size_t)2048);
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, s, a);
+  return check_launch("adamw");
+}
+
+}  // namespace tc

@@ -272,11 +272,12 @@ class Detr3DHead(BaseModule):
         return torch.from_numpy(tokens).to(device), pad_mult
 
     def forward_nhwc(self, feats_nhwc, lidar2img, img_hw, tokens, pad_mult,
-                     aux=False):
+                     aux=False, _allow_train=False):
         """The device-side forward: everything already on the GPU.
         feats_nhwc: list of [B*N,H,W,C]; lidar2img [B,N,4,4]; tokens [B,T,36].
         Only enqueues work on the current stream (graph-capturable)."""
-        require_eval(self)
+        if not _allow_train:
+            require_eval(self)
         w = self.head_weights()
         B = lidar2img.shape[0]
         T = tokens.shape[1]
@@ -306,8 +307,11 @@ class Detr3DHead(BaseModule):
                                              dtype=torch.float32, device=dev),
                 radar_hit_counts=torch.empty((3, B, Q), dtype=torch.int32,
                                              device=dev),
+                last_box=torch.empty((B, Q, code), dtype=torch.float32,
+                                     device=dev),
                 sample_pairs=torch.zeros(1, dtype=torch.int64, device=dev))
-            aux_s = L.tc_head_aux(*[t.data_ptr() for t in aux_t.values()])
+            aux_s = L.tc_head_aux(**{k: t.data_ptr()
+                                     for k, t in aux_t.items()})
         L.check(lib.tc_head_forward(
             C.byref(w), C.byref(self._packed_view), C.byref(fv), B,
             lidar2img.data_ptr(),
@@ -335,8 +339,122 @@ class Detr3DHead(BaseModule):
         l2i = ops.lidar2img_tensor(img_metas, dev)
         img_hw = img_metas[0]['img_shape'][0][:2]           # XFMR:403-404
         tokens, pad_mult = self.radar_tokens(img_metas, dev)
+        if self.training:
+            return self.forward_train_nhwc(feats_nhwc, l2i, img_hw, tokens,
+                                           pad_mult)
         return self.forward_nhwc(feats_nhwc, l2i, img_hw, tokens, pad_mult,
                                  aux=aux)
+
+    # ------------------------------------------------------------------
+    # training forward: frozen decoder (fused HIP chains, no graph) + the
+    # trainable radar stack operator by operator under autograd
+    # ------------------------------------------------------------------
+    def forward_train_nhwc(self, feats_nhwc, lidar2img, img_hw, tokens,
+                           pad_mult):
+        """Differentiable forward for one training iteration.
+
+        tools/train.py:245-252 freezes transformer / cls_branches /
+        reg_branches / query_embedding, so gradients are only needed in the
+        radar encoders, the three fusion layers and final_cls*/final_reg*
+        (HEAD:531-729).  The frozen decoder runs through tc_head_forward; its
+        last state, last reference and last box (``aux``) feed the radar stack,
+        which is recomputed here node by node (transcar_amd/autograd_ops.py)
+        so that ``loss.backward()`` reaches every trainable parameter through
+        HIP backward kernels.  Dropout layers act as the identity (the
+        reference trains with p = 0.1, HEAD:129-171; stochastic dropout is not
+        implemented, so training here is the deterministic p = 0 variant)."""
+        from . import autograd_ops as A
+        for grp in (self.transformer, self.cls_branches, self.reg_branches,
+                    self.query_embedding):
+            for p in grp.parameters():
+                if p.requires_grad:
+                    raise L.TransCARHipError(
+                        'the DETR3D decoder has no backward here: freeze '
+                        'transformer / cls_branches / reg_branches / '
+                        'query_embedding as tools/train.py:245-252 does '
+                        '(Detr3DHead.freeze_decoder())')
+        with torch.no_grad():
+            base = self.forward_nhwc(feats_nhwc, lidar2img, img_hw, tokens,
+                                     pad_mult, aux=True, _allow_train=True)
+        aux = base['aux']
+        B, Q, E = aux['inter_states'].shape[1:]
+        qf = aux['inter_states'][-1].clone()                  # HEAD:539
+        ref_last = aux['inter_references'][-1].contiguous()
+        prev_box = aux['last_box']
+        cxy, addref = A.radar_reference_l1(ref_last, self.pc_range)
+
+        # radar encoders, HEAD:531-536 (Linear(3,E) runs as K = 4 with a zero column)
+        rpe, rfe = self.radar_position_encoder, self.radar_feat_encoder
+        T = tokens.shape[1]
+        xyz0 = torch.zeros((B, T, 4), dtype=torch.float32, device=tokens.device)
+        xyz0[..., :3] = tokens[..., :3]
+        w0 = torch.cat((rpe[0].weight, rpe[0].weight.new_zeros(E, 1)), 1)
+        u = A.linear(xyz0, w0, rpe[0].bias)
+        u = A.add_layernorm(u, None, rpe[1].weight, rpe[1].bias, relu=True)
+        u = A.linear(u, rpe[3].weight, rpe[3].bias)
+        pos = A.add_layernorm(u, None, rpe[4].weight, rpe[4].bias, relu=True)
+        f = A.linear(tokens, rfe[0].weight, rfe[0].bias, act=1)
+        f = A.linear(f, rfe[2].weight, rfe[2].bias, act=1)
+        f = A.linear(f, rfe[4].weight, rfe[4].bias, act=1)
+        mem = pos + f
+
+        all_cls, all_box = [], []
+        for r, (sfx, asfx) in enumerate((('', ''), ('_2', '2'), ('_3', '3'))):
+            attn = getattr(self, 'rf_multihead_attn' + asfx)
+            wq, bq = attn.in_proj_weight[:E], attn.in_proj_bias[:E]
+            wkv, bkv = attn.in_proj_weight[E:], attn.in_proj_bias[E:]
+            qp = A.linear(qf, wq, bq)
+            kv = A.linear(mem, wkv, bkv)
+            centre, ld_c = (cxy, 2) if r == 0 else (prev_box, self.code_size)
+            rmin, rmax = RADAR_RADII[r]
+            ao, hits = A.radar_attn_core(qp, kv, centre, ld_c, prev_box, tokens,
+                                         pad_mult, rmin, rmax,
+                                         heads=attn.num_heads)
+            x = A.gated_linear_residual(ao, attn.out_proj.weight,
+                                        attn.out_proj.bias, qf, hits)
+            n2 = getattr(self, 'rf_norm2' + sfx)
+            n3 = getattr(self, 'rf_norm3' + sfx)
+            l1 = getattr(self, 'rf_linear1' + sfx)
+            l2 = getattr(self, 'rf_linear2' + sfx)
+            x = A.add_layernorm(x, None, n2.weight, n2.bias)
+            h = A.linear(x, l1.weight, l1.bias, act=1)
+            ff = A.linear(h, l2.weight, l2.bias)
+            qf = A.add_layernorm(x, ff, n3.weight, n3.bias)
+            fc = getattr(self, 'final_cls' + asfx)
+            fr = getattr(self, 'final_reg' + asfx)
+            c = A.linear(qf, fc[0].weight, fc[0].bias)
+            c = A.add_layernorm(c, None, fc[1].weight, fc[1].bias, relu=True)
+            c = A.linear(c, fc[3].weight, fc[3].bias)
+            c = A.add_layernorm(c, None, fc[4].weight, fc[4].bias, relu=True)
+            c = A.linear(c, fc[6].weight, fc[6].bias)
+            t = A.linear(qf, fr[0].weight, fr[0].bias, act=1)
+            t = A.linear(t, fr[2].weight, fr[2].bias, act=1)
+            t = A.linear(t, fr[4].weight, fr[4].bias)
+            box = A.box_add_ref(t, None, addref) if r == 0 else \
+                A.box_add_ref(t, prev_box, None)
+            all_cls.append(c)
+            all_box.append(box)
+            prev_box = box
+        return {'all_cls_scores': torch.stack(all_cls),
+                'all_bbox_preds': torch.stack(all_box),
+                'enc_cls_scores': None, 'enc_bbox_preds': None}
+
+    def freeze_decoder(self):
+        """tools/train.py:245-252."""
+        for grp in (self.transformer, self.cls_branches, self.reg_branches,
+                    self.query_embedding):
+            for p in grp.parameters():
+                p.requires_grad = False
+        return self
+
+    def trainable_parameters(self):
+        """(name, parameter) of what one iteration produces a gradient for:
+        requires_grad and used by the forward (rf_norm1*, attention_weights2/3,
+        output_proj2/3 are constructed but never used, HEAD:191-195)."""
+        unused = ('rf_norm1', 'attention_weights2', 'attention_weights3',
+                  'output_proj2', 'output_proj3')
+        return [(n, p) for n, p in self.named_parameters()
+                if p.requires_grad and not n.startswith(unused)]
 
     def get_bboxes(self, preds_dicts, img_metas, rescale=False):
         """HEAD:1003-1023."""
