@@ -46,6 +46,9 @@ def parse():
     ap.add_argument('--unfused', action='store_true',
                     help='operator-by-operator launches instead of the fused row chains')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    ap.add_argument('--train', action='store_true',
+                    help='time one DDP training iteration of the fusion head (configs[2]) '
+                         'instead of inference')
     return ap.parse_args()
 
 
@@ -252,6 +255,63 @@ def cpu_baseline(sd, inp, seconds):
                        % (len(times), cores))
 
 
+def train_bench(args, head, inp, dev, rank, world):
+    """BASELINE.json configs[2]: batch-per-GPU 1 DDP training of the trainable
+    (radar) part of the head.  A step = frozen decoder forward + radar stack
+    forward (autograd over HIP kernels) + Hungarian/focal/L1 loss (host PyTorch +
+    scipy, as the reference) + HIP backward + ONE all-reduce of the flat gradient
+    bucket over RCCL + device-side clip + AdamW + weight re-pack."""
+    from transcar_amd.trainer import FusionTrainer
+    cfg = configs.head_cfg()
+    cfg['train_cfg'] = configs.train_cfg_pts
+    thead = T.build_head(cfg)
+    thead.load_state_dict(head.state_dict(), strict=True)
+    thead = thead.to(dev)
+    B = args.batch
+    gts, lbs = [], []
+    for b in range(B):
+        boxes, labels = synth.make_gt(seed=7 + rank * 16 + b, n=24)
+        gt = torch.from_numpy(boxes).clone()
+        gt[:, 2] += gt[:, 5] * 0.5
+        gts.append(gt.to(dev))
+        lbs.append(torch.from_numpy(labels).to(dev))
+    torch.set_grad_enabled(True)
+    tr = FusionTrainer(thead)
+
+    def step():
+        return tr.step_nhwc(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'], inp['pad_mult'], gts, lbs)
+
+    for _ in range(args.warmup):
+        step()
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = step()
+    torch.cuda.synchronize()
+    D.barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, dev if world > 1 else None)
+    line = {
+        'metric': 'training frames/sec: fusion head iteration (frozen DETR3D decoder fwd + radar '
+                  'stack fwd/bwd + loss + grad all-reduce + AdamW), FPN features resident in HBM',
+        'value': args.steps * B * world / elapsed, 'unit': 'frames/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+        'data': 'synthetic',
+        'config': {'workload': 'BASELINE.json configs[2]: %s FPN shapes, 900 queries, 255 radar points, '
+                               '24 GT boxes, batch-per-GPU %d, DDP' % (args.shapes, B),
+                   'trainable_parameters': tr.bucket.numel,
+                   'grad_bucket_bytes': tr.bucket.numel * 4,
+                   'parallelism': 'dp%d, one flat-bucket all-reduce per step (RCCL)' % world,
+                   'final_loss': float(sum(losses.values()))},
+    }
+    if rank == 0:
+        print(json.dumps(line))
+    D.barrier()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.unfused:
@@ -264,6 +324,8 @@ def main():
     torch.set_grad_enabled(False)
     head, sd = build_head(dev)
     inp = make_inputs(head, dev, args.shapes, args.batch, seed=1 + rank)
+    if args.train:
+        return train_bench(args, head, inp, dev, rank, world)
 
     graph = None
     if not args.no_graph:

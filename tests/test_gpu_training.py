@@ -290,3 +290,37 @@ def test_adamw_step_matches_torch(A):
                                       2e-4, 0.9, 0.999, 1e-8, 0.01, step, 0.5, 35.0, sq.data_ptr(), s),
                 'tc_adamw_step')
         assert float((p.cpu() - p_ref.detach()).abs().max()) < 2e-6
+
+
+def test_trainer_step_updates_flat_bucket_and_packed_weights(A, golden_dir):
+    from transcar_amd.trainer import FusionTrainer
+    h = train_head(golden_dir)
+    feats, metas, gt, labels = frame_inputs(golden_dir)
+    tr = FusionTrainer(h, lr=1e-3, weight_decay=0.01, max_norm=35.0)
+    assert tr.bucket.numel == sum(p.numel() for _, p in h.trainable_parameters())
+    p0 = tr.bucket.params.clone()
+    with torch.no_grad():
+        before = h.eval()(feats, metas)['all_cls_scores'].clone()
+    l1 = tr.step(feats, metas, [gt], [labels])
+    g = tr.bucket.grads.clone()
+    # every parameter's .grad still aliases the flat gradient buffer
+    for (n, p), off in zip(h.trainable_parameters(), tr.bucket.offsets):
+        assert p.grad.data_ptr() == tr.bucket.grads.data_ptr() + 4 * off, n
+        assert p.data_ptr() == tr.bucket.params.data_ptr() + 4 * off, n
+    # first AdamW step: p*(1-lr*wd) - lr * g_clipped/(|g_clipped| + eps)
+    norm = float(g.double().norm())
+    coef = min(1.0, 35.0 / (norm + 1e-6))
+    gc = g * coef
+    expect = p0 * (1 - 1e-3 * 0.01) - 1e-3 * gc / (gc.abs() + 1e-8)
+    assert float((tr.bucket.params - expect).abs().max()) < 2e-6
+    # the fused eval forward sees the updated weights and agrees with the train forward
+    with torch.no_grad():
+        after = h.eval()(feats, metas)
+    assert float((after['all_cls_scores'] - before).abs().max()) > 1e-3
+    t = h.train()(feats, metas)
+    assert float((t['all_cls_scores'].detach() - after['all_cls_scores']).abs().max()) < 5e-4
+    # a few more steps on the same frame reduce the loss
+    first = float(sum(l1.values()))
+    for _ in range(5):
+        last = tr.step(feats, metas, [gt], [labels])
+    assert float(sum(last.values())) < first

@@ -186,3 +186,57 @@ def test_oracle_backward_matches_reference(golden_dir):
     assert abs(float(total) - float(g8['total_loss'])) < 1e-4 * float(g8['total_loss'])
     total.backward()
     check_grads_against_g8({k: v.grad for k, v in sd.items() if trainable(k)}, g8, 2e-3, 'oracle')
+
+
+# ---------------------------------------------------------------------------
+# flat gradient bucket + schedule (host logic of transcar_amd/trainer.py)
+# ---------------------------------------------------------------------------
+_BUCKET_WORKER = r'''
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from transcar_amd import dist as D
+from transcar_amd.trainer import FlatBucket
+rank, world = D.init_process_group('gloo')
+torch.manual_seed(0)
+m = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+b = FlatBucket(list(m.named_parameters()))
+assert b.numel == 8 * 16 + 16 + 16 * 4 + 4
+x = torch.full((3, 8), float(rank + 1))
+b.zero_grad()
+m(x).sum().backward()
+local = b.grads.clone()
+assert float(local.abs().sum()) > 0                  # autograd accumulated INTO the flat views
+for p, off in zip(b.items, b.offsets):
+    assert p.grad.data_ptr() == b.grads.data_ptr() + 4 * off
+    assert p.data_ptr() == b.params.data_ptr() + 4 * off
+assert b.all_reduce() == 2
+parts = [torch.zeros_like(local) for _ in range(2)]
+dist.all_gather(parts, local)
+assert torch.allclose(b.grads, parts[0] + parts[1])
+dist.destroy_process_group()
+'''
+
+
+def test_flat_bucket_single_all_reduce_gloo_world2(tmp_path):
+    script = tmp_path / 'b.py'
+    script.write_text(_BUCKET_WORKER % ROOT)
+    port = 33000 + os.getpid() % 2000
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=180)
+        assert p.returncode == 0, out.decode()
+
+
+def test_cosine_schedule_with_linear_warmup():
+    from transcar_amd.trainer import cosine_lr
+    base = 1.5e-5                                               # CFG:208
+    assert abs(cosine_lr(base, 0, 0, 24) - base / 3) < 1e-12    # warmup_ratio 1/3
+    assert abs(cosine_lr(base, 4000, 0, 24) - base) < 1e-12
+    assert abs(cosine_lr(base, 10 ** 6, 24, 24) - base * 1e-3) < 1e-12
+    assert cosine_lr(base, 10 ** 6, 12, 24) == pytest.approx(base * (1e-3 + 0.5 * (1 - 1e-3)))

@@ -256,6 +256,20 @@ class Detr3DHead(BaseModule):
         self._weights = None
         return self.head_weights()
 
+    def repack_weights(self):
+        """Re-run the weight re-layout into the existing packed buffer: the
+        parameters changed IN PLACE (optimizer step on the flat bucket), their
+        addresses did not.  Enqueue-only (a few dozen small kernels)."""
+        if self._weights is None:
+            return self.head_weights()
+        dev = self.query_embedding.weight.device
+        L.check(L.lib().tc_head_pack_weights(
+            C.byref(self._weights), self._packed.data_ptr(),
+            self._packed.numel(), C.byref(self._packed_view),
+            C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+            'tc_head_pack_weights')
+        return self._weights
+
     # ------------------------------------------------------------------
     # forward
     # ------------------------------------------------------------------
