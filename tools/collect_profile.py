@@ -84,6 +84,14 @@ def main():
                     lines.append(ln)
     open(os.path.join(dst, name + '_bench.json'), 'w').write('\n'.join(lines) + '\n')
 
+    tb = os.path.join(src, 'bench_train.json')
+    if os.path.exists(tb):
+        tl = [ln.strip() for ln in open(tb) if ln.strip().startswith('{')]
+        open(os.path.join(dst, name + '_train_bench.json'), 'w').write('\n'.join(tl) + '\n')
+    ts = glob.glob(os.path.join(src, 'prof_train', '*', '*kernel_stats.csv'))
+    if ts:
+        open(os.path.join(dst, name + '_train_kernel_stats.csv'), 'w').write(open(ts[0]).read())
+
     stats = one(os.path.join(src, 'prof', '*', '*kernel_stats.csv'))
     open(os.path.join(dst, name + '_kernel_stats.csv'), 'w').write(open(stats).read())
 

@@ -37,57 +37,94 @@ struct BwdGemmK {
 // C[I,J] (+)= alpha * sum_r A(i,r) B(r,j),  B(r,j) = Bm[r*ldB + j]
 //   DATA:   A(i,r) = dY[i*ldA + r]   (i = row m, r = n)
 //   WEIGHT: A(i,r) = dY[r*ldA + i]   (i = n,     r = row m)
+// Tile 64 x BN, reduction step 32; the next step's operands are fetched into
+// registers while the MFMAs of the current one run (the loop is latency-bound:
+// these GEMMs are 900 x 256 x 256).  4 waves = 4 row groups of 16, NT = BN/16
+// accumulators each.
+constexpr int BG_RK = 32;
+
 template <int MODE>
+__device__ __forceinline__ float bg_load_a(const BwdGemmK& p, int gi, int gr, int rend) {
+  float v = 0.f;
+  if (gi < p.I && gr < rend) {
+    const size_t off = MODE == BWD_DATA ? (size_t)gi * p.ldA + gr : (size_t)gr * p.ldA + gi;
+    v = p.A[off];
+    if (p.relu != nullptr && p.relu[off] <= 0.f) v = 0.f;
+    if (p.gate != nullptr && p.gate[MODE == BWD_DATA ? gi : gr] <= 0) v = 0.f;
+  }
+  return v;
+}
+
+template <int MODE, int BN>
 __global__ __launch_bounds__(256) void bwd_gemm_kernel(BwdGemmK p) {
-  __shared__ float As[16 * 80];
-  __shared__ float Bs[16 * 80];
+  constexpr int NT = BN / 16;
+  constexpr int AE = 64 * BG_RK / 256;      // A elements per thread and step (8)
+  constexpr int BE = BN * BG_RK / 256;      // B elements per thread and step (8 or 4)
+  constexpr int LDA_D = BG_RK + 1;          // DATA:   As[i][r]
+  constexpr int LDA_W = 64 + 16;            // WEIGHT: As[r][i]
+  constexpr int LDB = BN + 16;
+  __shared__ float As[(64 * LDA_D > BG_RK * LDA_W) ? 64 * LDA_D : BG_RK * LDA_W];
+  __shared__ float Bs[BG_RK * LDB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * BN;
   const int rbeg = blockIdx.z * p.rchunk, rend = min(p.R, rbeg + p.rchunk);
-  f32x4 acc[4];
+  f32x4 acc[NT];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   float csum = 0.f;
   const bool do_colsum = MODE == BWD_WEIGHT && p.colsum != nullptr && blockIdx.x == 0;
-  for (int r0 = rbeg; r0 < rend; r0 += 16) {
+  float ra[AE], rb[BE];
+
+  auto fetch = [&](int r0) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < AE; ++e) {
       const int idx = tid + 256 * e;
       int i, r;
-      if (MODE == BWD_DATA) { r = idx & 15; i = idx >> 4; }
+      if (MODE == BWD_DATA) { r = idx & (BG_RK - 1); i = idx / BG_RK; }
       else { i = idx & 63; r = idx >> 6; }
-      const int gi = i0 + i, gr = r0 + r;
-      float v = 0.f;
-      if (gi < p.I && gr < rend) {
-        const size_t off = MODE == BWD_DATA ? (size_t)gi * p.ldA + gr : (size_t)gr * p.ldA + gi;
-        v = p.A[off];
-        if (p.relu != nullptr && p.relu[off] <= 0.f) v = 0.f;
-        if (p.gate != nullptr && p.gate[MODE == BWD_DATA ? gi : gr] <= 0) v = 0.f;
-      }
-      if (MODE == BWD_DATA) As[i * 17 + r] = v; else As[r * 80 + i] = v;
-      // B tile, j fastest (coalesced rows of W / X)
-      const int j = idx & 63, rb = idx >> 6;
-      const int gj = j0 + j, grb = r0 + rb;
-      Bs[rb * 80 + j] = (gj < p.J && grb < rend) ? p.Bm[(size_t)grb * p.ldB + gj] : 0.f;
+      ra[e] = bg_load_a<MODE>(p, i0 + i, r0 + r, rend);
+    }
+#pragma unroll
+    for (int e = 0; e < BE; ++e) {
+      const int idx = tid + 256 * e;
+      const int j = idx % BN, r = idx / BN;
+      const int gj = j0 + j, gr = r0 + r;
+      rb[e] = (gj < p.J && gr < rend) ? p.Bm[(size_t)gr * p.ldB + gj] : 0.f;
+    }
+  };
+
+  fetch(rbeg);
+  for (int r0 = rbeg; r0 < rend; r0 += BG_RK) {
+#pragma unroll
+    for (int e = 0; e < AE; ++e) {
+      const int idx = tid + 256 * e;
+      if (MODE == BWD_DATA) As[(idx / BG_RK) * LDA_D + (idx & (BG_RK - 1))] = ra[e];
+      else As[(idx >> 6) * LDA_W + (idx & 63)] = ra[e];
+    }
+#pragma unroll
+    for (int e = 0; e < BE; ++e) {
+      const int idx = tid + 256 * e;
+      Bs[(idx / BN) * LDB + idx % BN] = rb[e];
     }
     __syncthreads();
+    if (r0 + BG_RK < rend) fetch(r0 + BG_RK);
     if (do_colsum && tid < 64) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) csum += As[r * 80 + tid];
+      for (int r = 0; r < BG_RK; ++r) csum += As[r * LDA_W + tid];
     }
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int kk = 0; kk < BG_RK / 4; ++kk) {
       const int k = 4 * kk + (lane >> 4);
       const int ai = 16 * wave + (lane & 15);
-      const float a = MODE == BWD_DATA ? As[ai * 17 + k] : As[k * 80 + ai];
+      const float a = MODE == BWD_DATA ? As[ai * LDA_D + k] : As[k * LDA_W + ai];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = MFMA4(a, Bs[k * 80 + 16 * t + (lane & 15)], acc[t]);
+      for (int t = 0; t < NT; ++t) acc[t] = MFMA4(a, Bs[k * LDB + 16 * t + (lane & 15)], acc[t]);
     }
     __syncthreads();
   }
   const bool atomic = MODE == BWD_WEIGHT || gridDim.z > 1;
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
+  for (int t = 0; t < NT; ++t) {
     const int col = j0 + 16 * t + (lane & 15);
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
@@ -112,9 +149,12 @@ int launch_linear_bwd_data(const float* dy, const float* relu_out, const int* ro
   BwdGemmK p;
   p.A = dy; p.relu = relu_out; p.gate = row_gate; p.Bm = w; p.cmask = in_relu_mask; p.C = dx;
   p.colsum = nullptr; p.ldA = N; p.ldB = K; p.ldC = K; p.I = M; p.J = K; p.R = N;
-  p.rchunk = ((N + 15) / 16) * 16; p.accumulate = accumulate; p.alpha = alpha;
-  hipLaunchKernelGGL(bwd_gemm_kernel<BWD_DATA>, dim3((K + 63) / 64, (M + 63) / 64, 1), dim3(256), 0,
-                     s, p);
+  p.rchunk = ((N + BG_RK - 1) / BG_RK) * BG_RK; p.accumulate = accumulate; p.alpha = alpha;
+  const int mt = (M + 63) / 64;
+  if (mt * ((K + 63) / 64) >= 200)          // enough 64-wide tiles to fill the chip
+    hipLaunchKernelGGL((bwd_gemm_kernel<BWD_DATA, 64>), dim3((K + 63) / 64, mt, 1), dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL((bwd_gemm_kernel<BWD_DATA, 32>), dim3((K + 31) / 32, mt, 1), dim3(256), 0, s, p);
   return check_launch("linear_bwd_data");
 }
 
@@ -127,7 +167,7 @@ int launch_linear_bwd_weight(const float* x, const float* dy, const float* relu_
   p.colsum = db; p.ldA = N; p.ldB = K; p.ldC = K; p.I = N; p.J = K; p.R = M;
   p.rchunk = 64; p.accumulate = 1; p.alpha = alpha;
   TC_REQUIRE(dw != nullptr, "linear_bwd_weight: dw is NULL");
-  hipLaunchKernelGGL(bwd_gemm_kernel<BWD_WEIGHT>,
+  hipLaunchKernelGGL((bwd_gemm_kernel<BWD_WEIGHT, 64>),
                      dim3((K + 63) / 64, (N + 63) / 64, (M + p.rchunk - 1) / p.rchunk), dim3(256),
                      0, s, p);
   return check_launch("linear_bwd_weight");
@@ -200,7 +240,7 @@ int launch_ln256_bwd(const float* a, const float* b, const float* gamma, const f
   LnBwdK p;
   p.a = a; p.b = b; p.gamma = gamma; p.dy = dy; p.relu_out = relu_out; p.dz = dz;
   p.dgamma = dgamma; p.dbeta = dbeta; p.M = M;
-  const int grid = min((M + 3) / 4, 256);
+  const int grid = min((M + 3) / 4, 64);   // few workgroups: dgamma/dbeta meet in 512 atomics each
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, s, p);
   return check_launch("layernorm_bwd");
 }
