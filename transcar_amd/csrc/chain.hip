@@ -45,6 +45,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "kernels.hpp"
 #include "rowdev.hpp"
 
@@ -256,14 +258,23 @@ __device__ __forceinline__ void aload(ABuf& ab, const float* arow, const float* 
   }
 }
 
-template <int NG>
-__device__ __forceinline__ void wcompute(Acc<NG>& acc, const WBuf& wb, const ABuf& ab) {
+// The 16 weight loads of the NEXT item (1 KiB per wave-instruction) are issued one
+// per group of 4*NG MFMAs of the current item.  Issued as one burst they fill the
+// vector-memory queue, the wave blocks at the queue and its MFMAs wait behind the
+// loads in program order: loads and MFMAs then run back to back (2330 cycles per
+// item at R = 4); interleaved they overlap (1410; tools/chainpipe_probe.hip).
+template <int NG, bool PF>
+__device__ __forceinline__ void wcompute(Acc<NG>& acc, const WBuf& wb, const ABuf& ab, WBuf& nx,
+                                         const float* np) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
+    if (PF) nx.b[i] = ld4(np + i * 256);
+    __builtin_amdgcn_sched_barrier(0);
     MfmaGroups<NG, 0>::run(acc, ab.a[i].x, wb.b[i].x, 0);
     MfmaGroups<NG, 0>::run(acc, ab.a[i].y, wb.b[i].y, 1);
     MfmaGroups<NG, 0>::run(acc, ab.a[i].z, wb.b[i].z, 0);
     MfmaGroups<NG, 0>::run(acc, ab.a[i].w, wb.b[i].w, 1);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -315,15 +326,15 @@ __device__ __forceinline__ void lin_epilogue(const LinSpec& s, int tile, const A
 
 // y[R, N] = epilogue(src[R, K] W^T): called by all CH_NT threads, no internal barrier.
 //
-// A wave's work items (its column tiles x 64-deep k blocks) are double buffered
-// in registers: while item i issues its MFMAs, the 16 weight loads (16 KiB per
-// wave) and 16 LDS reads of item i+1 are in flight.  The tail re-loads the last
-// item (unconditional loads keep hipcc's vmcnt bookkeeping exact);
-// sched_barrier(0) stops hipcc from sinking loads next to their first use.
+// A wave's work items (its column tiles x 64-deep k blocks) alternate between two
+// register buffers: while item i issues its MFMAs, the 16 weight loads (16 KiB per
+// wave) of item i+1 are issued in between them; the last item of a step fetches
+// nothing (no redundant L2 traffic: the stream is bound by the CU's L1/L2 path).
 template <int R>
 __device__ __forceinline__ void linear_step(const LinSpec& s) {
   constexpr int NG = R / 4;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ntiles = (s.N + 63) >> 6;
   const int kpad = (s.K + 63) & ~63;                 // packed tile = 64 * kpad floats
   const int nkb = kpad / KB;
@@ -333,16 +344,22 @@ __device__ __forceinline__ void linear_step(const LinSpec& s) {
   const int arow_i = min(lane, R - 1);
   const float* arow = s.src + arow_i * s.src_ld;
   const float* a2row = s.src2 ? s.src2 + arow_i * s.src2_ld : nullptr;
-  const float* wbase = s.W + 4 * lane;
+  const float* wbase = s.W + 4 * lane + (size_t)wave * 64 * kpad;
+  const size_t tile_stride = (size_t)CH_NW * 64 * kpad;
   Acc<NG> acc;
-  auto wl = [&](WBuf& wb, int i) {
-    i = min(i, nitems - 1);
-    const int tt = i / nkb, kb = i - tt * nkb;
-    wload(wb, wbase + (size_t)(wave + tt * CH_NW) * 64 * kpad + (size_t)kb * (KB / 4) * 256, 16);
-  };
   float bv = 0.0f;
-  auto run = [&](const WBuf& wb, int i) {
-    const int tt = i / nkb, kb = i - tt * nkb;
+  // item i = (tile tt, k block kb), kb fastest; tracked incrementally (no divisions)
+  int tt = 0, kb = 0;
+  const float* wcur = wbase;
+  auto advance = [&](const float*& w, int& t, int& k) {
+    if (++k == nkb) { k = 0; ++t; w = wbase + (size_t)t * tile_stride; }
+    else w += (KB / 4) * 256;
+  };
+  auto run = [&](const WBuf& wb, WBuf& nx, auto pf) {
+    constexpr bool PF = decltype(pf)::value;
+    const float* np = wcur;
+    int nt = tt, nk = kb;
+    if (PF) advance(np, nt, nk);
     ABuf ab;
     if (a2row != nullptr) aload<true>(ab, arow + kb * KB, a2row + kb * KB);
     else aload<false>(ab, arow + kb * KB, nullptr);
@@ -351,22 +368,29 @@ __device__ __forceinline__ void linear_step(const LinSpec& s) {
       const int col = (wave + tt * CH_NW) * 64 + lane;        // bias: in flight under the MFMAs
       bv = (s.bias != nullptr && col < s.N) ? s.bias[col] : 0.0f;
     }
-    wcompute<NG>(acc, wb, ab);
+    wcompute<NG, PF>(acc, wb, ab, nx, np);
     if (kb == nkb - 1) lin_epilogue<NG>(s, wave + tt * CH_NW, acc, lane, bv);
+    wcur = np; tt = nt; kb = nk;
   };
+  using Yes = std::integral_constant<bool, true>;
+  using No = std::integral_constant<bool, false>;
   WBuf w0, w1;
-  wl(w0, 0);
+  wload(w0, wbase, 16);
   __builtin_amdgcn_sched_barrier(0);
+  int i = 0;
 #pragma unroll 1
-  for (int i = 0; i < nitems; i += 2) {
-    wl(w1, i + 1);
+  for (; i + 2 < nitems; i += 2) {
+    run(w0, w1, Yes{});
     __builtin_amdgcn_sched_barrier(0);
-    run(w0, i);
+    run(w1, w0, Yes{});
     __builtin_amdgcn_sched_barrier(0);
-    wl(w0, i + 2);
+  }
+  if (i + 1 < nitems) {
+    run(w0, w1, Yes{});
     __builtin_amdgcn_sched_barrier(0);
-    if (i + 1 < nitems) run(w1, i + 1);
-    __builtin_amdgcn_sched_barrier(0);
+    run(w1, w0, No{});
+  } else {
+    run(w0, w1, No{});
   }
 }
 
@@ -389,7 +413,8 @@ template <int R>
 __global__ __launch_bounds__(CH_NT) void chain_kernel(ChainK k) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   ChainLds<R>& S = *reinterpret_cast<ChainLds<R>*>(smem_raw);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int m0 = blockIdx.x * R;
   const int M = k.M;
   const StepDesc* table = k.program == PROG_DECODER ? PROG_DECODER_T
