@@ -151,6 +151,9 @@ def roofline(head, inp, dev):
             code, attn_o.data_ptr(), hs2.data_ptr(), qe.data_ptr(), inp['l2i'].data_ptr(),
             ref.data_ptr(), pc, float(inp['hw'][0]), float(inp['hw'][1]), hs_out.data_ptr(),
             ref_out.data_ptr(), qk.data_ptr(), vt.data_ptr(), qpad, cur_stream()), 'decoder_layer_tail')
+    if getattr(roofline, 'chain_only', False):        # tools/chain_stamps.py: one launch, no timing
+        run_chain()
+        return None
     chain_ms = time_events(run_chain)
     chain_flop = 2.0 * M * (5 * Cd * Cd + Cd * NL + 2 * Cd * F + 3 * Cd * Cd + Cd * code)
     # -- camera sampling stand-alone (HBM/L2 gather): visibility-aware algorithmic bytes
@@ -207,6 +210,15 @@ def roofline(head, inp, dev):
              others={n: {kk: v[kk] for kk in ('bound', 'achieved', 'peak', 'unit', 'frac', 'ms')}
                      for n, v in kern.items() if n != dom})
     return r
+
+
+def roofline_chain_once(head, inp, dev):
+    """One launch of the decoder row chain exactly as `roofline` times it."""
+    roofline.chain_only = True
+    try:
+        roofline(head, inp, dev)
+    finally:
+        roofline.chain_only = False
 
 
 def cpu_baseline(sd, inp, seconds):

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Per-step cycle counts of the fused row chains (debug build with s_memtime
+stamps):   make -C transcar_amd/csrc STAMPS=1
+           TRANSCAR_HIP_LIB=transcar_amd/lib/libtranscar_hip_stamps.so python tools/chain_stamps.py [decoder|radar]
+Prints, for workgroup 100 and each of its 4 waves, the cycles (100 MHz s_memtime
+ticks x 24 = 2.4 GHz core cycles) each step took and the wait at its barrier."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench                                              # noqa: E402
+from transcar_amd import _lib as L                         # noqa: E402
+
+DEC = ['load attn_o', 'load x', 'load pos', 'out_proj', 'norm0', 'attn_w(24)', 'posenc l0', 'SAMPLE', 'pe.3',
+       'output_proj', 'norm1', 'ffn0', 'ffn1', 'norm2', 'reg.0', 'next QK', 'next V', 'reg.2', 'reg.4', 'refupd']
+RAD = ['q proj', 'RADAR ATTN', 'out_proj', 'norm2', 'linear1', 'linear2', 'norm3', 'cls.0', 'reg.0', 'cls LN1',
+       'reg.2', 'cls.3', 'reg.4', 'cls LN4', 'boxadd', 'cls.6']
+
+
+def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else 'decoder'
+    dev = torch.device('cuda:0')
+    torch.set_grad_enabled(False)
+    head, _ = bench.build_head(dev)
+    inp = bench.make_inputs(head, dev, 'res101', 1, seed=1)
+    lib = L.lib()
+    lib.tc_debug_chain_stamps.restype = C.c_int
+    lib.tc_debug_chain_stamps.argtypes = [C.c_void_p]
+    sub = int(sys.argv[2]) if len(sys.argv) > 2 else -1
+    lib.tc_debug_chain_sub.restype = C.c_int
+    lib.tc_debug_chain_sub.argtypes = [C.c_int, C.c_void_p]
+    lib.tc_debug_chain_sub(sub, None)
+    for _ in range(3):
+        head.forward_nhwc(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'], inp['pad_mult'])
+    if which == 'decoder':
+        # the forward's LAST chain launch is the radar chain; run one decoder tail on top
+        bench.roofline_chain_once(head, inp, dev)
+        names = DEC
+    else:
+        names = RAD * 3
+    torch.cuda.synchronize()
+    buf = np.zeros((4, 64), dtype=np.int64)
+    assert lib.tc_debug_chain_stamps(buf.ctypes.data) == 0
+    t = buf - buf[:, :1]                                   # s_memtime ticks (= core cycles here)
+    if sub >= 0:
+        sb = np.zeros((4, 64), dtype=np.int64)
+        assert lib.tc_debug_chain_sub(0, sb.ctypes.data) == 0
+        print('sub-step stamps of table step %d (%s): 0 dispatch, 1 spec built, 2 first load issued, 3.. after item i' % (sub, names[sub]))
+        for w in range(4):
+            row = sb[w]
+            n = int((row[:20] > 0).sum())
+            print('  wave%d:' % w, ' '.join('%6d' % (row[j] - row[0]) for j in range(n)))
+            print('     item0 [start, A read, setup, mfma+prefetch]:', ' '.join('%6d' % (row[j] - row[0]) for j in range(20, 24)),
+                  ' item1:', ' '.join('%6d' % (row[j] - row[0]) for j in range(25, 29)))
+    print('%-14s %s' % ('step', '   '.join('wave%d work / wait' % w for w in range(4))))
+    n = min(len(names), 31)
+    for i in range(n):
+        cols = []
+        for w in range(4):
+            work = t[w, 1 + 2 * i] - t[w, 2 * i]
+            wait = t[w, 2 + 2 * i] - t[w, 1 + 2 * i]
+            cols.append('%7d /%6d' % (work, wait))
+        print('%-14s %s' % (names[i], '   '.join(cols)))
+    print('total cycles (wave 0): %d = %.1f us at 2.4 GHz' % (t[0, 2 * n], t[0, 2 * n] / 2400.0))
+
+
+if __name__ == '__main__':
+    main()

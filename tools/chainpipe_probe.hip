@@ -109,14 +109,14 @@ __device__ __forceinline__ void compute_il(f32x4& a0, f32x4& a1, const WBuf& w, 
 }
 
 template <int GAP>
-__global__ __launch_bounds__(256) void pipe_il(const float* W, int nsteps, int S, int wrap, float* out) {
+__global__ __launch_bounds__(256) void pipe_il(const float* W, int nsteps, int S, int wrap, float* out, int desync = 0) {
   __shared__ float A[4][516];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < 4 * 516; i += 256) (&A[0][0])[i] = 0.001f * i;
   __syncthreads();
   const float* arow = &A[lane & 3][0];
   f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
-  int item = wave * 7;
+  int item = wave * 7 + desync * blockIdx.x * 13;
   for (int st = 0; st < nsteps; ++st) {
     WBuf w0, w1;
     auto src = [&](int i) { return W + (size_t)((item + (i < S ? i : S - 1)) % wrap) * 4096 + 4 * lane; };
@@ -136,20 +136,20 @@ __global__ __launch_bounds__(256) void pipe_il(const float* W, int nsteps, int S
 }
 
 template <int GAP>
-int run_il(const float* W, float* out, int blocks, int nsteps, int S, int wrap) {
+int run_il(const float* W, float* out, int blocks, int nsteps, int S, int wrap, int desync = 0) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  pipe_il<GAP><<<blocks, 256>>>(W, nsteps, S, wrap, out);
+  pipe_il<GAP><<<blocks, 256>>>(W, nsteps, S, wrap, out, desync);
   CK(hipDeviceSynchronize());
   float best = 1e9;
   for (int it = 0; it < 5; ++it) {
     CK(hipEventRecord(e0));
-    pipe_il<GAP><<<blocks, 256>>>(W, nsteps, S, wrap, out);
+    pipe_il<GAP><<<blocks, 256>>>(W, nsteps, S, wrap, out, desync);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
   }
   const int items = nsteps * S;
-  printf("interleaved gap=%d blocks=%3d steps=%3d x %2d items: %7.1f us, %6.0f ns/item = %5.0f cyc@2.4GHz, %.1f GB/s per CU\n",
-         GAP, blocks, nsteps, S, best * 1e3, best * 1e6 / items, best * 1e6 / items * 2.4,
+  printf("interleaved gap=%d desync=%d blocks=%3d steps=%3d x %2d items: %7.1f us, %6.0f ns/item = %5.0f cyc@2.4GHz, %.1f GB/s per CU\n",
+         GAP, desync, blocks, nsteps, S, best * 1e3, best * 1e6 / items, best * 1e6 / items * 2.4,
          4.0 * 16384.0 * items / (best * 1e-3) / 1e9);
   return 0;
 }
@@ -229,6 +229,7 @@ int main() {
     run_il<1>(W, out, 225, 56 / S, S, wrap);
   }
   run_il<1>(W, out, 1, 1, 56, wrap);
+  for (int S : {4, 8, 56}) run_il<1>(W, out, 225, 56 / S, S, wrap, 1);
   for (int S : {4, 8, 56}) run_sb(W, out, 225, 56 / S, S, wrap);
   run_sb(W, out, 1, 1, 56, wrap);
   run<2>(W, out, cyc, 113, 1, 56, wrap, 1);

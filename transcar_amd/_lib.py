@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libtranscar_hip.so')
+#: TRANSCAR_HIP_LIB selects another build of the same ABI (the STAMPS debug build)
+LIB_PATH = os.environ.get('TRANSCAR_HIP_LIB') or os.path.join(_HERE, 'lib', 'libtranscar_hip.so')
 
 TC_MAX_LEVELS = 4
 TC_MAX_LAYERS = 8

@@ -60,8 +60,19 @@ constexpr int LD5 = 516;   // 512 + 4 floats
 constexpr int LD2 = 260;   // 256 + 4
 constexpr int LDL = 36;
 
+// a step of the table with every pointer / size resolved (built once per workgroup)
+struct StepRes {
+  const float* p0; const float* p1; const float* p2; const float* p3;   // linear: W, bias; LN: g, b, g2, b2
+  float* gd; float* gt;          // global destination (source for K_LOAD) / transposed destination
+  int K, N, gld, gmod;
+  short kind, src, src2, dst, res, act, flags, sync, rep, si;
+  int pad_;
+};
+constexpr int MAX_STEPS = 64;
+
 template <int R>
 struct ChainLds {
+  StepRes sres[MAX_STEPS];
   float a[R][LD5];
   float x[R][LD2];
   float r[R][LD2];
@@ -79,7 +90,8 @@ struct ChainLds {
 // ---- step tables -----------------------------------------------------------
 enum Buf : short { B_NONE = -1, B_A = 0, B_X, B_R, B_T, B_U, B_P, B_L };
 enum Kind : short {
-  K_END = 0, K_LOAD, K_LINEAR, K_LN, K_POSENC, K_SAMPLE, K_REFUPD, K_TOKENS, K_RADAR_ATTN, K_BOXADD
+  K_END = 0, K_LOAD, K_LINEAR, K_LN, K_POSENC, K_SAMPLE, K_REFUPD, K_TOKENS, K_RADAR_ATTN, K_BOXADD,
+  K_NOP   // a step switched off at run time (no next layer): only its barrier remains
 };
 enum NSpecial : short { N_LOGITS = -1, N_CODE = -2, N_CLS = -3 };
 enum Flags : short {
@@ -200,6 +212,7 @@ struct LinSpec {
   float* gdst; int gdst_ld;
   float* gt; int gt_ld, gt_rpb;
   int m0, M;
+  int sub_on;
 };
 
 // One work item = (64-column output tile, 64-deep k block): 16 x 16-byte weight
@@ -209,6 +222,18 @@ struct LinSpec {
 // row group q/4, broadcast to the 16 column blocks by cbsz/abid).
 constexpr int KB = 64;
 struct WBuf { float4 b[16]; };
+
+#ifdef TC_CHAIN_STAMPS
+__device__ long long g_chain_sub[CH_NW][64];
+__device__ int g_sub_step;      // table index of the linear step to dissect
+#define SUB_STAMP(slot)                                                                       \
+  do {                                                                                        \
+    if (blockIdx.x == 100 && (threadIdx.x & 63) == 0 && s.sub_on && (slot) < 64)              \
+      g_chain_sub[threadIdx.x >> 6][(slot)] = __builtin_amdgcn_s_memtime();                   \
+  } while (0)
+#else
+#define SUB_STAMP(slot) do {} while (0)
+#endif
 
 __device__ __forceinline__ void wload(WBuf& wb, const float* w, int nq) {
 #pragma unroll
@@ -240,8 +265,8 @@ struct MfmaGroups<NG, NG> {
 
 // The A operand (this lane's activation row, 64 k of it) is read from LDS into
 // registers BEFORE the MFMA burst: issued just in time, every one of the 16
-// ds_read_b128 exposed its ~120-cycle latency to the matrix pipe (measured:
-// +2000 cycles per item, more than the 128 MFMAs themselves).
+// ds_read_b128 exposed its ~120-cycle latency to the matrix pipe (a rolling window
+// of 4 reads in flight was measured too: 1120 instead of 936 cycles per MFMA phase).
 struct ABuf { float4 a[16]; };
 
 // No per-read guards: a conditional around each ds_read_b128 turned the 16 reads
@@ -284,13 +309,14 @@ __device__ __forceinline__ void lin_epilogue(const LinSpec& s, int tile, const A
   const int col = tile * 64 + lane;
   if (col >= s.N) return;
   const float sc = (col < s.scale_cols) ? s.scale : 1.0f;
+  const float bias = s.bias != nullptr ? bv : 0.0f;
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     float v[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = 4 * g + i;
-      float y = ((acc.v[g][0][i] + acc.v[g][1][i]) + bv) * sc;
+      float y = ((acc.v[g][0][i] + acc.v[g][1][i]) + bias) * sc;
       if (s.act == 1) y = fmaxf(y, 0.0f);
       else if (s.act == 2) y = sigmoidf_(y);
       if (s.gate != nullptr && s.gate[row] == 0) y = 0.0f;
@@ -302,7 +328,7 @@ __device__ __forceinline__ void lin_epilogue(const LinSpec& s, int tile, const A
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = s.m0 + 4 * g + i;
-        if (row < s.M) s.gdst[(size_t)row * s.gdst_ld + col] = v[i];
+        if (row < s.M) stg1(s.gdst + (size_t)row * s.gdst_ld + col, v[i]);
       }
     }
     if (s.gt != nullptr) {
@@ -316,7 +342,7 @@ __device__ __forceinline__ void lin_epilogue(const LinSpec& s, int tile, const A
           const int row = row0 + i;
           if (row < s.M) {
             const int bb = row / s.gt_rpb, q = row - bb * s.gt_rpb;
-            s.gt[((size_t)bb * s.N + col) * s.gt_ld + q] = v[i];
+            stg1(s.gt + ((size_t)bb * s.N + col) * s.gt_ld + q, v[i]);
           }
         }
       }
@@ -328,10 +354,14 @@ __device__ __forceinline__ void lin_epilogue(const LinSpec& s, int tile, const A
 //
 // A wave's work items (its column tiles x 64-deep k blocks) alternate between two
 // register buffers: while item i issues its MFMAs, the 16 weight loads (16 KiB per
-// wave) of item i+1 are issued in between them; the last item of a step fetches
-// nothing (no redundant L2 traffic: the stream is bound by the CU's L1/L2 path).
-template <int R>
-__device__ __forceinline__ void linear_step(const LinSpec& s) {
+// wave) of item i+1 are issued in between them.  Inside a run of consecutive
+// linear / LayerNorm steps the pipeline does not drain at a step boundary: the
+// last item of a step fetches `next_first`, the first item of the wave's next
+// linear step (the weight stream depends on the step table only, not on data),
+// which then arrives in `w0` (`preloaded`).  Returns true when w0 holds that item.
+template <int R, typename SpecFn>
+__device__ __forceinline__ bool linear_step(const LinSpec& s, WBuf& w0, bool preloaded,
+                                            const float* next_first, SpecFn make_spec, int step_idx) {
   constexpr int NG = R / 4;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -340,7 +370,6 @@ __device__ __forceinline__ void linear_step(const LinSpec& s) {
   const int nkb = kpad / KB;
   const int my_tiles = wave < ntiles ? (ntiles - wave + CH_NW - 1) / CH_NW : 0;
   const int nitems = my_tiles * nkb;
-  if (nitems == 0) return;
   const int arow_i = min(lane, R - 1);
   const float* arow = s.src + arow_i * s.src_ld;
   const float* a2row = s.src2 ? s.src2 + arow_i * s.src2_ld : nullptr;
@@ -348,50 +377,84 @@ __device__ __forceinline__ void linear_step(const LinSpec& s) {
   const size_t tile_stride = (size_t)CH_NW * 64 * kpad;
   Acc<NG> acc;
   float bv = 0.0f;
-  // item i = (tile tt, k block kb), kb fastest; tracked incrementally (no divisions)
+#ifdef TC_CHAIN_STAMPS
+  constexpr bool stamp_items = true;
+#else
+  constexpr bool stamp_items = false;
+#endif
+  // item = (tile tt, k block kb), kb fastest; tracked incrementally (no divisions)
   int tt = 0, kb = 0;
   const float* wcur = wbase;
-  auto advance = [&](const float*& w, int& t, int& k) {
-    if (++k == nkb) { k = 0; ++t; w = wbase + (size_t)t * tile_stride; }
-    else w += (KB / 4) * 256;
-  };
-  auto run = [&](const WBuf& wb, WBuf& nx, auto pf) {
+  auto run = [&](const WBuf& wb, WBuf& nx, auto pf, const float* np_last) {
     constexpr bool PF = decltype(pf)::value;
     const float* np = wcur;
     int nt = tt, nk = kb;
-    if (PF) advance(np, nt, nk);
+    if (++nk == nkb) { nk = 0; ++nt; np = wbase + (size_t)nt * tile_stride; }
+    else np += (KB / 4) * 256;
+    const float* nload = np_last != nullptr ? np_last : np;
+    if (stamp_items && tt == 0 && kb < 2) SUB_STAMP(20 + 5 * kb);
+    if (kb == 0) {
+      acc_zero<NG>(acc);
+      // bias: in flight under the MFMAs.  Unconditional load (clamped column, any valid
+      // address when there is no bias): behind a branch hipcc waits vmcnt(0) at the join,
+      // i.e. for the whole weight stream in flight (900 cycles per step, measured)
+      const int col = min((wave + tt * CH_NW) * 64 + lane, s.N - 1);
+      bv = ldg1((s.bias != nullptr ? s.bias : s.W) + col);
+    }
+    if (stamp_items && tt == 0 && kb < 2) SUB_STAMP(22 + 5 * kb);
     ABuf ab;
     if (a2row != nullptr) aload<true>(ab, arow + kb * KB, a2row + kb * KB);
     else aload<false>(ab, arow + kb * KB, nullptr);
-    if (kb == 0) {
-      acc_zero<NG>(acc);
-      const int col = (wave + tt * CH_NW) * 64 + lane;        // bias: in flight under the MFMAs
-      bv = (s.bias != nullptr && col < s.N) ? s.bias[col] : 0.0f;
+    wcompute<NG, PF>(acc, wb, ab, nx, nload);
+    if (stamp_items && tt == 0 && kb < 2) SUB_STAMP(23 + 5 * kb);
+    if (kb == nkb - 1) {
+      // The epilogue REBUILDS its view of the step from the LDS record (behind an opaque
+      // asm on the step / tile index): kept live across the item loop, its ~25 uniform
+      // values (destinations, strides, flags) push the kernel past the SGPR budget and
+      // every step starts with ~1200 cycles of v_readlane / v_writelane spill traffic.
+      int tile = wave + tt * CH_NW;
+      int sidx = step_idx;
+      asm volatile("" : "+s"(tile), "+s"(sidx));
+      const LinSpec e = make_spec(sidx);
+      lin_epilogue<NG>(e, tile, acc, lane, bv);
     }
-    wcompute<NG, PF>(acc, wb, ab, nx, np);
-    if (kb == nkb - 1) lin_epilogue<NG>(s, wave + tt * CH_NW, acc, lane, bv);
     wcur = np; tt = nt; kb = nk;
   };
   using Yes = std::integral_constant<bool, true>;
   using No = std::integral_constant<bool, false>;
-  WBuf w0, w1;
-  wload(w0, wbase, 16);
-  __builtin_amdgcn_sched_barrier(0);
+  WBuf w1;
+  SUB_STAMP(1);
+  if (!preloaded) {
+    wload(w0, wbase, 16);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  SUB_STAMP(2);
   int i = 0;
 #pragma unroll 1
   for (; i + 2 < nitems; i += 2) {
-    run(w0, w1, Yes{});
+    run(w0, w1, Yes{}, nullptr);
     __builtin_amdgcn_sched_barrier(0);
-    run(w1, w0, Yes{});
+    SUB_STAMP(3 + i);
+    run(w1, w0, Yes{}, nullptr);
     __builtin_amdgcn_sched_barrier(0);
+    SUB_STAMP(4 + i);
   }
   if (i + 1 < nitems) {
-    run(w0, w1, Yes{});
+    run(w0, w1, Yes{}, nullptr);
     __builtin_amdgcn_sched_barrier(0);
-    run(w1, w0, No{});
+    SUB_STAMP(3 + i);
+    if (next_first != nullptr) {
+      run(w1, w0, Yes{}, next_first + 4 * lane);
+      SUB_STAMP(4 + i);
+      return true;
+    }
+    run(w1, w0, No{}, nullptr);
+    SUB_STAMP(4 + i);
   } else {
-    run(w0, w1, No{});
+    run(w0, w1, No{}, nullptr);      // odd item count (radar feature encoder): no cross-step fetch
+    SUB_STAMP(3 + i);
   }
+  return false;
 }
 
 template <int R>
@@ -409,6 +472,40 @@ __device__ __forceinline__ float* buf_ptr(ChainLds<R>& S, int id) {
 }
 __device__ __forceinline__ int buf_ld(int id) { return id == B_A ? LD5 : id == B_L ? LDL : LD2; }
 
+#ifdef TC_CHAIN_STAMPS
+// debug build only (make STAMPS=1): s_memtime after every step of workgroup 100
+__device__ long long g_chain_stamps[CH_NW][64];
+#define STEP_STAMP()                                                                          \
+  do {                                                                                        \
+    if (blockIdx.x == 100 && lane == 0 && stamp_i < 64)                                       \
+      g_chain_stamps[wave][stamp_i] = __builtin_amdgcn_s_memtime();                           \
+    ++stamp_i;                                                                                \
+  } while (0)
+#else
+#define STEP_STAMP() do {} while (0)
+#endif
+
+__device__ __forceinline__ int ufirst(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename T>
+__device__ __forceinline__ T* uptr(T* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+
+// a resolved step from LDS into SGPRs (every field is uniform over the workgroup:
+// left in VGPRs they cost the item loop ~40 registers and the weight buffers spill)
+__device__ __forceinline__ StepRes load_step(const StepRes& src) {
+  constexpr int NWORDS = sizeof(StepRes) / 4;
+  static_assert(sizeof(StepRes) % 4 == 0, "StepRes size");
+  union U { StepRes r; int w[NWORDS]; __device__ U() {} } u;
+  const int* p = reinterpret_cast<const int*>(&src);
+#pragma unroll
+  for (int i = 0; i < NWORDS; ++i) u.w[i] = __builtin_amdgcn_readfirstlane(p[i]);
+  return u.r;
+}
+
 template <int R>
 __global__ __launch_bounds__(CH_NT) void chain_kernel(ChainK k) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -421,6 +518,43 @@ __global__ __launch_bounds__(CH_NT) void chain_kernel(ChainK k) {
                           : k.program == PROG_PROLOGUE ? PROG_PROLOGUE_T
                           : k.program == PROG_RADAR_ENC ? PROG_RADAR_ENC_T : PROG_RADAR_LAYER_T;
   const int nrep = k.program == PROG_RADAR ? k.nlayers : 1;
+
+  // ---- resolve the step table once: every later step reads one LDS record instead
+  // of chasing constant memory -> kernel arguments -> weights (1200-1850 cycles of
+  // dependent scalar loads per step, measured)
+  int nsteps = 0;
+  while (table[nsteps].kind != K_END) ++nsteps;
+  const int total = nsteps * nrep;
+  for (int idx = threadIdx.x; idx < total; idx += CH_NT) {
+    const int rep = idx / nsteps, si = idx - rep * nsteps;
+    const int pair0 = k.program == PROG_RADAR ? rep * RADAR_PAIRS : 0;
+    const StepDesc d = table[si];
+    StepRes r;
+    r.p0 = r.p1 = r.p2 = r.p3 = nullptr; r.gd = r.gt = nullptr;
+    r.K = d.K; r.N = d.N; r.gld = 0; r.gmod = 0;
+    r.kind = d.kind; r.src = d.src; r.src2 = d.src2; r.dst = d.dst; r.res = d.res; r.act = d.act;
+    r.flags = d.flags; r.sync = d.sync; r.rep = (short)rep; r.si = (short)si;
+    if ((d.flags & F_SKIP_NONEXT) && !k.has_next) r.kind = K_NOP;
+    if (d.gsel != G_NONE) { r.gd = k.g[d.gsel]; r.gld = k.g_ld[d.gsel]; r.gmod = k.g_mod[d.gsel]; }
+    if (d.gtsel != G_NONE) r.gt = k.g[d.gtsel];
+    if (d.kind == K_LINEAR) {
+      const tc_linear pr = k.pairs[pair0 + d.wp];
+      r.K = d.K == 36 ? k.RI : d.K;
+      r.N = d.N == N_LOGITS ? k.nlogits : d.N == N_CODE ? k.code : d.N == N_CLS ? k.ncls : d.N;
+      const int woff = (d.flags & F_WOFF) ? 512 : 0;
+      r.p0 = pr.w + (size_t)woff * ((r.K + 63) & ~63);   // packed: a 64-row tile = 64 * kpad floats
+      r.p1 = pr.b ? pr.b + woff : nullptr;
+      if (d.gsel == G_CLS) r.gd += (size_t)rep * M * k.ncls;
+    } else if (d.kind == K_LN || d.kind == K_POSENC) {
+      const tc_linear n = k.pairs[pair0 + d.wp];
+      r.p0 = n.w; r.p1 = n.b;
+      if (d.kind == K_POSENC || d.src2 != B_NONE) {
+        const tc_linear n2 = k.pairs[pair0 + d.wp2];
+        r.p2 = n2.w; r.p3 = n2.b;
+      }
+    }
+    S.sres[idx] = r;
+  }
 
   if (k.program == PROG_RADAR) {     // HEAD:539, 543-547, 596-598
     for (int row = wave; row < R; row += CH_NW) {
@@ -436,169 +570,210 @@ __global__ __launch_bounds__(CH_NT) void chain_kernel(ChainK k) {
       S.cen[row][2] = rr[2];          // z stays normalised (HEAD:598 indexes an empty slice)
       for (int j = 0; j < k.code; ++j) S.box[row][j] = k.box_in[(size_t)grow * k.code + j];
     }
-    __syncthreads();
   }
+  __syncthreads();
 
-  for (int rep = 0; rep < nrep; ++rep) {
-    const int pair0 = k.program == PROG_RADAR ? rep * RADAR_PAIRS : 0;
-#pragma unroll 1
-    for (int si = 0;; ++si) {
-      const StepDesc d = table[si];
-      if (d.kind == K_END) break;
-      if ((d.flags & F_SKIP_NONEXT) && !k.has_next) {
-        if (d.sync) __syncthreads();
-        continue;
-      }
-      switch (d.kind) {
-        case K_LOAD: {
-          const float* gsrc = k.g[d.gsel];
-          const int ld = k.g_ld[d.gsel], mod = k.g_mod[d.gsel];
-          float* dst = buf_ptr<R>(S, d.dst);
-          for (int row = wave; row < R; row += CH_NW) {
-            int grow = min(m0 + row, M - 1);
-            if (mod > 0) grow = grow % mod;
-            *reinterpret_cast<float4*>(dst + row * LD2 + 4 * lane) = ld4(gsrc + (size_t)grow * ld + 4 * lane);
-          }
-        } break;
-        case K_TOKENS: {   // radar token tile, zero padded to 64 columns
-          for (int i = threadIdx.x; i < R * 64; i += CH_NT) {
-            const int row = i >> 6, c = i & 63;
-            const int grow = min(m0 + row, M - 1);
-            S.a[row][c] = c < k.RI ? k.tokens[(size_t)grow * k.RI + c] : 0.0f;
-          }
-        } break;
-        case K_LINEAR: {
-          const tc_linear& pr = k.pairs[pair0 + d.wp];
-          LinSpec s;
-          s.K = d.K == 36 ? k.RI : d.K;
-          s.N = d.N == N_LOGITS ? k.nlogits : d.N == N_CODE ? k.code : d.N == N_CLS ? k.ncls : d.N;
-          const int woff = (d.flags & F_WOFF) ? 512 : 0;
-          s.W = pr.w + (size_t)woff * ((s.K + 63) & ~63);   // packed: a 64-row tile = 64 * kpad floats
-          s.bias = pr.b ? pr.b + woff : nullptr;
-          s.src = buf_ptr<R>(S, d.src); s.src_ld = buf_ld(d.src);
-          s.src2 = buf_ptr<R>(S, d.src2); s.src2_ld = buf_ld(d.src2);
-          s.dst = buf_ptr<R>(S, d.dst); s.dst_ld = buf_ld(d.dst);
-          s.res = buf_ptr<R>(S, d.res); s.res_ld = buf_ld(d.res);
-          s.gate = (d.flags & F_GATE) ? &S.gate[0] : nullptr;
-          s.act = d.act;
-          s.scale = (d.flags & F_SCALEQ) ? k.qscale : 1.0f; s.scale_cols = (d.flags & F_SCALEQ) ? 256 : 0;
-          s.gdst = nullptr; s.gdst_ld = 0;
-          if (d.gsel != G_NONE) {
-            s.gdst = k.g[d.gsel]; s.gdst_ld = k.g_ld[d.gsel];
-            if (d.gsel == G_CLS) s.gdst += (size_t)rep * M * k.ncls;
-          }
-          s.gt = d.gtsel != G_NONE ? k.g[d.gtsel] : nullptr; s.gt_ld = k.qpad; s.gt_rpb = k.Q;
-          s.m0 = m0; s.M = M;
-          linear_step<R>(s);
-        } break;
-        case K_LN: {   // dst = [relu] LN(a (+ relu(LN(c; wp2)))) (+ d): wave w owns rows 2w, 2w+1
-          const tc_linear& n = k.pairs[pair0 + d.wp];
-          const float* a = buf_ptr<R>(S, d.src); const int lda = buf_ld(d.src);
-          const float* c = buf_ptr<R>(S, d.src2); const int ldc = buf_ld(d.src2);
-          const float* dd = buf_ptr<R>(S, d.res);
-          float* dst = buf_ptr<R>(S, d.dst);
-          float* gdst = d.gsel != G_NONE ? k.g[d.gsel] : nullptr;
-          for (int row = wave; row < R; row += CH_NW) {
-            float4 v = *reinterpret_cast<const float4*>(a + row * lda + 4 * lane);
-            if (c != nullptr) {
-              const tc_linear& n2 = k.pairs[pair0 + d.wp2];
-              v = add4(v, relu4(ln_row(*reinterpret_cast<const float4*>(c + row * ldc + 4 * lane), n2.w, n2.b, lane)));
-            }
-            v = ln_row(v, n.w, n.b, lane);
-            if (d.flags & F_LN_RELU) v = relu4(v);
-            if (dd != nullptr) v = add4(v, *reinterpret_cast<const float4*>(dd + row * LD2 + 4 * lane));
-            *reinterpret_cast<float4*>(dst + row * LD2 + 4 * lane) = v;
-            if (gdst != nullptr && m0 + row < M) st4(gdst + (size_t)(m0 + row) * 256 + 4 * lane, v);
-          }
-        } break;
-        case K_POSENC: {   // Linear(3,256) + LN + ReLU of inverse_sigmoid(ref) or of raw token xyz
-          const tc_linear& l0 = k.pairs[pair0 + d.wp];
-          const tc_linear& n1 = k.pairs[pair0 + d.wp2];
-          float* dst = buf_ptr<R>(S, d.dst);
-          for (int row = wave; row < R; row += CH_NW) {
-            float p0, p1, p2;
-            if (d.src == B_A) { p0 = S.a[row][0]; p1 = S.a[row][1]; p2 = S.a[row][2]; }
-            else {
-              const int grow = min(m0 + row, M - 1);
-              p0 = inverse_sigmoidf_(k.ref_in[(size_t)grow * 3 + 0]);
-              p1 = inverse_sigmoidf_(k.ref_in[(size_t)grow * 3 + 1]);
-              p2 = inverse_sigmoidf_(k.ref_in[(size_t)grow * 3 + 2]);
-            }
-            *reinterpret_cast<float4*>(dst + row * LD2 + 4 * lane) =
-                posenc_l0_row(p0, p1, p2, l0.w, l0.b, n1.w, n1.b, lane);
-          }
-        } break;
-        case K_SAMPLE: {   // camera sampling of this block's 16 queries (2 per wave)
-          int pairs = 0;
-#pragma unroll 1
-          for (int row = wave; row < R; row += CH_NW) {
-            const int grow = min(m0 + row, M - 1);
-            int nvis = 0;
-            const float4 o = cam_sample_row<4>(k.cam, grow, grow / k.Q, &S.l[row][0], lane, nvis);
-            *reinterpret_cast<float4*>(&S.r[row][4 * lane]) = o;
-            if (m0 + row < M) pairs += nvis;
-          }
-          if (k.pair_counter != nullptr && lane == 0 && pairs > 0)
-            atomicAdd(k.pair_counter, (unsigned long long)pairs);
-        } break;
-        case K_REFUPD: {   // XFMR:195-203, HEAD:287-293
-          if (threadIdx.x < R && m0 + (int)threadIdx.x < M) {
-            const int row = threadIdx.x, grow = m0 + row;
-            const float* t = &S.l[row][0];
-            const float* rr = k.ref_in + (size_t)grow * 3;
-            const float nx = sigmoidf_(t[0] + inverse_sigmoidf_(rr[0]));
-            const float ny = sigmoidf_(t[1] + inverse_sigmoidf_(rr[1]));
-            const float nz = sigmoidf_(t[4] + inverse_sigmoidf_(rr[2]));
-            k.ref_out[(size_t)grow * 3 + 0] = nx;
-            k.ref_out[(size_t)grow * 3 + 1] = ny;
-            k.ref_out[(size_t)grow * 3 + 2] = nz;
-            if (k.box_m != nullptr) {
-              float* o = k.box_m + (size_t)grow * k.code;
-              for (int j = 0; j < k.code; ++j) o[j] = t[j];
-              const float* pc = k.cam.pc;
-              o[0] = nx * (pc[3] - pc[0]) + pc[0];
-              o[1] = ny * (pc[4] - pc[1]) + pc[1];
-              o[4] = nz * (pc[5] - pc[2]) + pc[2];
-            }
-          }
-        } break;
-        case K_RADAR_ATTN: {   // distance-gated attention, 2 queries per wave (HEAD:549-579)
-#pragma unroll 1
-          for (int row = wave; row < R; row += CH_NW) {
-            const int grow = min(m0 + row, M - 1);
-            const int b = grow / k.Q;
-            const float4 q4 = *reinterpret_cast<const float4*>(&S.t[row][4 * lane]);
-            const float* kv = (rep == 0 ? k.g[G_KV0] : rep == 1 ? k.g[G_KV1] : k.g[G_KV2]);
-            int count = 0;
-            const float4 o = radar_attn_row(S.cen[row][0], S.cen[row][1], S.box[row][3], S.box[row][6],
-                                            S.box[row][7], k.rmin[rep], k.rmax[rep], q4,
-                                            k.tokens + (size_t)b * k.T * k.RI, k.RI,
-                                            kv + (size_t)b * k.T * 512, 512, k.T, k.pad_mult, lane, count);
-            *reinterpret_cast<float4*>(&S.u[row][4 * lane]) = o;
-            if (lane == 0) {
-              S.gate[row] = count;
-              if (m0 + row < M) k.hits[(size_t)rep * M + m0 + row] = count;
-            }
-          }
-        } break;
-        case K_BOXADD: {   // box = reg + reference (HEAD:599-600, 664-665, 722-723); next ref (HEAD:615-617)
-          if (threadIdx.x < R) {
-            const int row = threadIdx.x;
-            float bx[12];
-            for (int j = 0; j < k.code; ++j) bx[j] = S.l[row][j];
-            bx[0] += S.cen[row][0]; bx[1] += S.cen[row][1]; bx[4] += S.cen[row][2];
-            for (int j = 0; j < k.code; ++j) S.box[row][j] = bx[j];
-            S.cen[row][0] = bx[0]; S.cen[row][1] = bx[1]; S.cen[row][2] = bx[4];
-            if (m0 + row < M) {
-              float* o = k.all_box + ((size_t)rep * M + m0 + row) * k.code;
-              for (int j = 0; j < k.code; ++j) o[j] = bx[j];
-            }
-          }
-        } break;
-        default: break;
-      }
-      if (d.sync) __syncthreads();
+#ifdef TC_CHAIN_STAMPS
+  int stamp_i = 0;
+  STEP_STAMP();
+#endif
+
+  // dst = [relu] LN(a (+ relu(LN(c; p2,p3)))) (+ d): wave w owns rows w, w+4, ...
+  auto do_ln = [&](const StepRes& r) {
+    const float* a = buf_ptr<R>(S, r.src); const int lda = buf_ld(r.src);
+    const float* c = buf_ptr<R>(S, r.src2); const int ldc = buf_ld(r.src2);
+    const float* dd = buf_ptr<R>(S, r.res);
+    float* dst = buf_ptr<R>(S, r.dst);
+    float* gdst = r.gd;
+    for (int row = wave; row < R; row += CH_NW) {
+      float4 v = *reinterpret_cast<const float4*>(a + row * lda + 4 * lane);
+      if (c != nullptr)
+        v = add4(v, relu4(ln_row(*reinterpret_cast<const float4*>(c + row * ldc + 4 * lane), r.p2, r.p3, lane)));
+      v = ln_row(v, r.p0, r.p1, lane);
+      if (r.flags & F_LN_RELU) v = relu4(v);
+      if (dd != nullptr) v = add4(v, *reinterpret_cast<const float4*>(dd + row * LD2 + 4 * lane));
+      *reinterpret_cast<float4*>(dst + row * LD2 + 4 * lane) = v;
+      if (gdst != nullptr && m0 + row < M) st4(gdst + (size_t)(m0 + row) * 256 + 4 * lane, v);
     }
+  };
+  auto lin_spec = [&](const StepRes& r) {
+    LinSpec s;
+    s.K = ufirst(r.K); s.N = ufirst(r.N);
+    s.W = uptr(r.p0); s.bias = uptr(r.p1);
+    s.src = buf_ptr<R>(S, r.src); s.src_ld = buf_ld(r.src);
+    s.src2 = buf_ptr<R>(S, r.src2); s.src2_ld = buf_ld(r.src2);
+    s.dst = buf_ptr<R>(S, r.dst); s.dst_ld = buf_ld(r.dst);
+    s.res = buf_ptr<R>(S, r.res); s.res_ld = buf_ld(r.res);
+    s.gate = (r.flags & F_GATE) ? &S.gate[0] : nullptr;
+    s.act = r.act;
+    s.scale = (r.flags & F_SCALEQ) ? k.qscale : 1.0f; s.scale_cols = (r.flags & F_SCALEQ) ? 256 : 0;
+    s.gdst = uptr(r.gd); s.gdst_ld = ufirst(r.gld);
+    s.gt = uptr(r.gt); s.gt_ld = k.qpad; s.gt_rpb = k.Q;
+    s.m0 = m0; s.M = M;
+    s.sub_on = 0;
+    return s;
+  };
+  // first weight item of the next linear step (after idx, inside the same run of
+  // linear / LN / skipped steps) in which this wave owns a column tile
+  auto next_linear_first = [&](int idx, int& nidx) -> const float* {
+    for (int j = idx + 1; j < total; ++j) {
+      const int kind = ufirst(S.sres[j].kind);
+      if (kind == K_LN || kind == K_NOP) continue;
+      if (kind != K_LINEAR) break;
+      const int N = ufirst(S.sres[j].N), K = ufirst(S.sres[j].K);
+      if (wave >= ((N + 63) >> 6)) continue;
+      nidx = j;
+      return uptr(S.sres[j].p0) + (size_t)wave * 64 * ((K + 63) & ~63);
+    }
+    nidx = -1;
+    return nullptr;
+  };
+
+  int idx = 0;
+#pragma unroll 1
+  while (idx < total) {
+    const int kind = ufirst(S.sres[idx].kind);
+    if (kind == K_LINEAR || kind == K_LN || kind == K_NOP) {
+      // ---- a run of linear / LayerNorm steps: the weight pipeline stays primed across them
+      WBuf w0;
+      int pre_idx = -1;                      // step whose first item is in flight in w0
+#pragma unroll 1
+      for (;;) {
+        const StepRes r = load_step(S.sres[idx]);
+        const int kd = r.kind;
+        if (kd == K_LINEAR) {
+          LinSpec s = lin_spec(r);
+#ifdef TC_CHAIN_STAMPS
+          s.sub_on = (ufirst(r.si) == g_sub_step && ufirst(r.rep) == 0);
+          SUB_STAMP(0);
+#endif
+          if (wave < ((s.N + 63) >> 6)) {      // else: no column tile here, w0 keeps waiting
+            int nidx = -1;
+            const float* nf = next_linear_first(idx, nidx);
+            const bool have = linear_step<R>(s, w0, pre_idx == idx, nf,
+                                             [&](int j) { return lin_spec(load_step(S.sres[j])); }, idx);
+            pre_idx = have ? nidx : -1;
+          }
+        } else if (kd == K_LN) {
+          do_ln(r);
+        } else if (kd != K_NOP) {
+          break;
+        }
+        STEP_STAMP();
+        if (ufirst(r.sync)) __syncthreads();
+        STEP_STAMP();
+        if (++idx >= total) break;
+      }
+      continue;
+    }
+    const StepRes r = load_step(S.sres[idx]);
+    const int rep = r.rep;
+    switch (kind) {
+      case K_LOAD: {
+        const float* gsrc = uptr(r.gd);
+        const int ld = ufirst(r.gld), mod = ufirst(r.gmod);
+        float* dst = buf_ptr<R>(S, r.dst);
+        for (int row = wave; row < R; row += CH_NW) {
+          int grow = min(m0 + row, M - 1);
+          if (mod > 0) grow = grow % mod;
+          *reinterpret_cast<float4*>(dst + row * LD2 + 4 * lane) = ld4(gsrc + (size_t)grow * ld + 4 * lane);
+        }
+      } break;
+      case K_TOKENS: {   // radar token tile, zero padded to 64 columns
+        for (int i = threadIdx.x; i < R * 64; i += CH_NT) {
+          const int row = i >> 6, c = i & 63;
+          const int grow = min(m0 + row, M - 1);
+          S.a[row][c] = c < k.RI ? k.tokens[(size_t)grow * k.RI + c] : 0.0f;
+        }
+      } break;
+      case K_POSENC: {   // Linear(3,256) + LN + ReLU of inverse_sigmoid(ref) or of raw token xyz
+        float* dst = buf_ptr<R>(S, r.dst);
+        for (int row = wave; row < R; row += CH_NW) {
+          float p0, p1, p2;
+          if (r.src == B_A) { p0 = S.a[row][0]; p1 = S.a[row][1]; p2 = S.a[row][2]; }
+          else {
+            const int grow = min(m0 + row, M - 1);
+            p0 = inverse_sigmoidf_(k.ref_in[(size_t)grow * 3 + 0]);
+            p1 = inverse_sigmoidf_(k.ref_in[(size_t)grow * 3 + 1]);
+            p2 = inverse_sigmoidf_(k.ref_in[(size_t)grow * 3 + 2]);
+          }
+          *reinterpret_cast<float4*>(dst + row * LD2 + 4 * lane) =
+              posenc_l0_row(p0, p1, p2, uptr(r.p0), uptr(r.p1), uptr(r.p2), uptr(r.p3), lane);
+        }
+      } break;
+      case K_SAMPLE: {   // camera sampling of this block's queries
+        int pairs = 0;
+#pragma unroll 1
+        for (int row = wave; row < R; row += CH_NW) {
+          const int grow = min(m0 + row, M - 1);
+          int nvis = 0;
+          const float4 o = cam_sample_row<4>(k.cam, grow, grow / k.Q, &S.l[row][0], lane, nvis);
+          *reinterpret_cast<float4*>(&S.r[row][4 * lane]) = o;
+          if (m0 + row < M) pairs += nvis;
+        }
+        if (k.pair_counter != nullptr && lane == 0 && pairs > 0)
+          atomicAdd(k.pair_counter, (unsigned long long)pairs);
+      } break;
+      case K_REFUPD: {   // XFMR:195-203, HEAD:287-293
+        if (threadIdx.x < R && m0 + (int)threadIdx.x < M) {
+          const int row = threadIdx.x, grow = m0 + row;
+          const float* t = &S.l[row][0];
+          const float* rr = k.ref_in + (size_t)grow * 3;
+          const float nx = sigmoidf_(t[0] + inverse_sigmoidf_(rr[0]));
+          const float ny = sigmoidf_(t[1] + inverse_sigmoidf_(rr[1]));
+          const float nz = sigmoidf_(t[4] + inverse_sigmoidf_(rr[2]));
+          k.ref_out[(size_t)grow * 3 + 0] = nx;
+          k.ref_out[(size_t)grow * 3 + 1] = ny;
+          k.ref_out[(size_t)grow * 3 + 2] = nz;
+          if (k.box_m != nullptr) {
+            float* o = k.box_m + (size_t)grow * k.code;
+            for (int j = 0; j < k.code; ++j) o[j] = t[j];
+            const float* pc = k.cam.pc;
+            o[0] = nx * (pc[3] - pc[0]) + pc[0];
+            o[1] = ny * (pc[4] - pc[1]) + pc[1];
+            o[4] = nz * (pc[5] - pc[2]) + pc[2];
+          }
+        }
+      } break;
+      case K_RADAR_ATTN: {   // distance-gated attention (HEAD:549-579)
+#pragma unroll 1
+        for (int row = wave; row < R; row += CH_NW) {
+          const int grow = min(m0 + row, M - 1);
+          const int b = grow / k.Q;
+          const float4 q4 = *reinterpret_cast<const float4*>(&S.t[row][4 * lane]);
+          const float* kv = (rep == 0 ? k.g[G_KV0] : rep == 1 ? k.g[G_KV1] : k.g[G_KV2]);
+          int count = 0;
+          const float4 o = radar_attn_row(S.cen[row][0], S.cen[row][1], S.box[row][3], S.box[row][6],
+                                          S.box[row][7], k.rmin[rep], k.rmax[rep], q4,
+                                          k.tokens + (size_t)b * k.T * k.RI, k.RI,
+                                          kv + (size_t)b * k.T * 512, 512, k.T, k.pad_mult, lane, count);
+          *reinterpret_cast<float4*>(&S.u[row][4 * lane]) = o;
+          if (lane == 0) {
+            S.gate[row] = count;
+            if (m0 + row < M) k.hits[(size_t)rep * M + m0 + row] = count;
+          }
+        }
+      } break;
+      case K_BOXADD: {   // box = reg + reference (HEAD:599-600, 664-665, 722-723); next ref (HEAD:615-617)
+        if (threadIdx.x < R) {
+          const int row = threadIdx.x;
+          float bx[12];
+          for (int j = 0; j < k.code; ++j) bx[j] = S.l[row][j];
+          bx[0] += S.cen[row][0]; bx[1] += S.cen[row][1]; bx[4] += S.cen[row][2];
+          for (int j = 0; j < k.code; ++j) S.box[row][j] = bx[j];
+          S.cen[row][0] = bx[0]; S.cen[row][1] = bx[1]; S.cen[row][2] = bx[4];
+          if (m0 + row < M) {
+            float* o = k.all_box + ((size_t)rep * M + m0 + row) * k.code;
+            for (int j = 0; j < k.code; ++j) o[j] = bx[j];
+          }
+        }
+      } break;
+      default: break;
+    }
+    STEP_STAMP();
+    if (ufirst(r.sync)) __syncthreads();
+    STEP_STAMP();
+    ++idx;
   }
 }
 
@@ -631,6 +806,16 @@ int launch(const ChainK& k, hipStream_t s, const char* what) {
 }
 
 }  // namespace
+
+#ifdef TC_CHAIN_STAMPS
+extern "C" int tc_debug_chain_stamps(long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_chain_stamps), sizeof(long long) * CH_NW * 64);
+}
+extern "C" int tc_debug_chain_sub(int step, long long* host_out) {
+  if (host_out == nullptr) return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_sub_step), &step, sizeof(int));
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_chain_sub), sizeof(long long) * CH_NW * 64);
+}
+#endif
 
 void fill_camk(const CamSampleArgs& a, CamK& p);   // cam_sample.hip
 

@@ -42,10 +42,22 @@ struct Arena {
 inline size_t arena_slice(size_t count, size_t elt) { return (count * elt + 255) & ~size_t(255); }
 
 // ---- device helpers --------------------------------------------------------
+// Wave64 sum on the DPP data path (quad_perm, row_half_mirror, row_mirror,
+// row_bcast:15/31 -> lane 63): ~6 VALU ops instead of six ds_bpermute round trips
+// through the LDS crossbar (a LayerNorm row needs two of these back to back).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false);
+  return v + __builtin_bit_cast(float, t);
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v = dpp_add<0xB1, 0xF>(v);     // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xF>(v);     // quad_perm [2,3,0,1]
+  v = dpp_add<0x141, 0xF>(v);    // row_half_mirror
+  v = dpp_add<0x140, 0xF>(v);    // row_mirror: every lane of a 16-row holds the row sum
+  v = dpp_add<0x142, 0xA>(v);    // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xC>(v);    // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -63,7 +75,19 @@ __device__ __forceinline__ float inverse_sigmoidf_(float x) {
   return logf(x1 / x2);
 }
 
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// Global-memory accessors with an explicit address space: a pointer that went
+// through LDS or an integer (the chain kernel's resolved step records) is "generic"
+// to the compiler, which then emits flat_load/flat_store -- those tick lgkmcnt as
+// well as vmcnt, so every LDS read afterwards waits for the weight stream.
+#define TC_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ float4 ld4(const float* p) {
+  const f32x4 v = *(const TC_GLOBAL f32x4*)(p);
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void st4(float* p, float4 v) {
+  *(TC_GLOBAL f32x4*)(p) = f32x4{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ float ldg1(const float* p) { return *(const TC_GLOBAL float*)(p); }
+__device__ __forceinline__ void stg1(float* p, float v) { *(TC_GLOBAL float*)(p) = v; }
 
 }  // namespace tc

@@ -16,12 +16,12 @@ __device__ __forceinline__ float4 add4(float4 a, float4 b) {
 
 // LayerNorm over the 256 channels of a row held as one float4 per lane; eps 1e-5.
 __device__ __forceinline__ float4 ln_row(float4 v, const float* g, const float* b, int lane) {
+  const float4 gg = ld4(g + 4 * lane), bb = ld4(b + 4 * lane);   // in flight under the reductions
   float s = wave_sum(v.x + v.y + v.z + v.w);
   const float mean = s * (1.0f / 256.0f);
   float4 d = make_float4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
   float q = wave_sum(d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w);
   const float rstd = 1.0f / sqrtf(q * (1.0f / 256.0f) + 1e-5f);
-  const float4 gg = ld4(g + 4 * lane), bb = ld4(b + 4 * lane);
   return make_float4(d.x * rstd * gg.x + bb.x, d.y * rstd * gg.y + bb.y,
                      d.z * rstd * gg.z + bb.z, d.w * rstd * gg.w + bb.w);
 }
@@ -34,7 +34,7 @@ __device__ __forceinline__ float4 posenc_l0_row(float p0, float p1, float p2, co
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = 4 * lane + i;
-    v[i] = w0[c * 3 + 0] * p0 + w0[c * 3 + 1] * p1 + w0[c * 3 + 2] * p2 + b0[c];
+    v[i] = ldg1(w0 + c * 3 + 0) * p0 + ldg1(w0 + c * 3 + 1) * p1 + ldg1(w0 + c * 3 + 2) * p2 + ldg1(b0 + c);
   }
   return relu4(ln_row(make_float4(v[0], v[1], v[2], v[3]), g, beta, lane));
 }
