@@ -304,45 +304,80 @@ __device__ __forceinline__ void wcompute(Acc<NG>& acc, const WBuf& wb, const ABu
 }
 
 // lane n holds y[4g + i][64*tile + n] in acc.v[g][*][i]
+// Phases instead of a per-row chain of branches: all LDS reads of a kind are issued
+// together and waited for once (per row they serialised: ~4 x 150 cycles per tile).
 template <int NG>
 __device__ __forceinline__ void lin_epilogue(const LinSpec& s, int tile, const Acc<NG>& acc, int lane, float bv) {
   const int col = tile * 64 + lane;
   if (col >= s.N) return;
   const float sc = (col < s.scale_cols) ? s.scale : 1.0f;
   const float bias = s.bias != nullptr ? bv : 0.0f;
+  float y[NG][4];
 #pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    float v[4];
+  for (int g = 0; g < NG; ++g)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = 4 * g + i;
-      float y = ((acc.v[g][0][i] + acc.v[g][1][i]) + bias) * sc;
-      if (s.act == 1) y = fmaxf(y, 0.0f);
-      else if (s.act == 2) y = sigmoidf_(y);
-      if (s.gate != nullptr && s.gate[row] == 0) y = 0.0f;
-      if (s.res != nullptr) y += s.res[row * s.res_ld + col];
-      if (s.dst != nullptr) s.dst[row * s.dst_ld + col] = y;
-      v[i] = y;
-    }
-    if (s.gdst != nullptr) {
+    for (int i = 0; i < 4; ++i) y[g][i] = ((acc.v[g][0][i] + acc.v[g][1][i]) + bias) * sc;
+  if (s.act == 1) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = s.m0 + 4 * g + i;
-        if (row < s.M) stg1(s.gdst + (size_t)row * s.gdst_ld + col, v[i]);
-      }
-    }
-    if (s.gt != nullptr) {
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) y[g][i] = fmaxf(y[g][i], 0.0f);
+  } else if (s.act == 2) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) y[g][i] = sigmoidf_(y[g][i]);
+  }
+  if (s.gate != nullptr) {
+    int gt_[NG][4];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) gt_[g][i] = s.gate[4 * g + i];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) if (gt_[g][i] == 0) y[g][i] = 0.0f;
+  }
+  if (s.res != nullptr) {
+    float rr[NG][4];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rr[g][i] = s.res[(4 * g + i) * s.res_ld + col];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) y[g][i] += rr[g][i];
+  }
+  if (s.dst != nullptr) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s.dst[(4 * g + i) * s.dst_ld + col] = y[g][i];
+  }
+  if (s.gdst != nullptr) {
+    float* gp = s.gdst + (size_t)s.m0 * s.gdst_ld + col;
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (s.m0 + 4 * g + i < s.M) stg1(gp + (size_t)(4 * g + i) * s.gdst_ld, y[g][i]);
+  }
+  if (s.gt != nullptr) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
       const int row0 = s.m0 + 4 * g;
       if (row0 + 3 < s.M && (s.gt_rpb & 3) == 0) {
         const int bb = row0 / s.gt_rpb, q = row0 - bb * s.gt_rpb;
-        st4(s.gt + ((size_t)bb * s.N + col) * s.gt_ld + q, make_float4(v[0], v[1], v[2], v[3]));
+        st4(s.gt + ((size_t)bb * s.N + col) * s.gt_ld + q, make_float4(y[g][0], y[g][1], y[g][2], y[g][3]));
       } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int row = row0 + i;
           if (row < s.M) {
             const int bb = row / s.gt_rpb, q = row - bb * s.gt_rpb;
-            stg1(s.gt + ((size_t)bb * s.N + col) * s.gt_ld + q, v[i]);
+            stg1(s.gt + ((size_t)bb * s.N + col) * s.gt_ld + q, y[g][i]);
           }
         }
       }
