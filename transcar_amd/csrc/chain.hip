@@ -705,15 +705,45 @@ __global__ __launch_bounds__(CH_NT) void chain_kernel(ChainK k) {
     const int rep = r.rep;
     switch (kind) {
       case K_LOAD: {
-        const float* gsrc = uptr(r.gd);
-        const int ld = ufirst(r.gld), mod = ufirst(r.gmod);
-        float* dst = buf_ptr<R>(S, r.dst);
-        for (int row = wave; row < R; row += CH_NW) {
-          int grow = min(m0 + row, M - 1);
-          if (mod > 0) grow = grow % mod;
-          *reinterpret_cast<float4*>(dst + row * LD2 + 4 * lane) = ld4(gsrc + (size_t)grow * ld + 4 * lane);
+        // this and the directly following K_LOAD steps (the decoder starts with three) go
+        // out together: one memory latency instead of three, one barrier
+        constexpr int MAXL = 3, RW = (R + CH_NW - 1) / CH_NW;
+        int n = 1;
+        while (n < MAXL && idx + n < total && ufirst(S.sres[idx + n].kind) == K_LOAD) ++n;
+        float4 v[MAXL][RW];
+        float* dsts[MAXL];
+        int any_sync = 0;
+#pragma unroll
+        for (int j = 0; j < MAXL; ++j) {
+          if (j < n) {
+            const StepRes rj = load_step(S.sres[idx + j]);
+            const float* gsrc = rj.gd;
+            const int ld = rj.gld, mod = rj.gmod;
+            dsts[j] = buf_ptr<R>(S, rj.dst);
+            any_sync |= rj.sync;
+#pragma unroll
+            for (int ri = 0; ri < RW; ++ri) {
+              int grow = min(m0 + wave + ri * CH_NW, M - 1);
+              if (mod > 0) grow = grow % mod;
+              v[j][ri] = ld4(gsrc + (size_t)grow * ld + 4 * lane);
+            }
+          }
         }
-      } break;
+#pragma unroll
+        for (int j = 0; j < MAXL; ++j) {
+          if (j < n) {
+#pragma unroll
+            for (int ri = 0; ri < RW; ++ri) {
+              const int row = wave + ri * CH_NW;
+              if (row < R) *reinterpret_cast<float4*>(dsts[j] + row * LD2 + 4 * lane) = v[j][ri];
+            }
+          }
+        }
+        for (int j = 0; j < n; ++j) { STEP_STAMP(); STEP_STAMP(); }
+        if (any_sync) __syncthreads();
+        idx += n;
+        continue;
+      }
       case K_TOKENS: {   // radar token tile, zero padded to 64 columns
         for (int i = threadIdx.x; i < R * 64; i += CH_NT) {
           const int row = i >> 6, c = i & 63;
