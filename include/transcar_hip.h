@@ -34,7 +34,7 @@ extern "C" {
 #define TC_MAX_LEVELS 4
 #define TC_MAX_LAYERS 8
 #define TC_MAX_RADAR_LAYERS 3
-#define TC_ABI_VERSION 3
+#define TC_ABI_VERSION 4
 
 typedef void* tc_stream_t;
 
@@ -89,6 +89,13 @@ typedef struct {
   tc_pos_encoder radar_position_encoder;
   tc_linear radar_feat0, radar_feat2, radar_feat4;  /* radar_feat_encoder.{0,2,4} */
   tc_radar_layer radar[TC_MAX_RADAR_LAYERS];
+  /* Set by tc_head_pack_weights in the packed view only (leave NULL in the caller's
+   * struct).  Layer 0's self-attention sees nothing but the learned query embedding
+   * (XFMR:119-123, config CFG:65-72: q = k = query + query_pos, v = query), so its
+   * initial reference points and its attention output do not depend on the frame:
+   * they are evaluated once per checkpoint, not once per forward. */
+  const float* l0_init_reference;   /* [Q,3]  sigmoid(reference_points(query_pos))      */
+  const float* l0_attn_out;         /* [Q,C]  softmax(q k^T / sqrt(d)) v of layer 0     */
 } tc_head_weights;
 
 /* multi-view FPN feature maps, channels-last: level l is [B*num_cams, H, W, C] */

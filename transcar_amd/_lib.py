@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('TRANSCAR_HIP_LIB') or os.path.join(_HERE, 'lib', 'lib
 TC_MAX_LEVELS = 4
 TC_MAX_LAYERS = 8
 TC_MAX_RADAR_LAYERS = 3
-TC_ABI_VERSION = 3
+TC_ABI_VERSION = 4
 
 c_fp = C.c_void_p      # device pointers travel as integers
 
@@ -81,7 +81,8 @@ class tc_head_weights(C.Structure):
                 ('radar_position_encoder', tc_pos_encoder),
                 ('radar_feat0', tc_linear), ('radar_feat2', tc_linear),
                 ('radar_feat4', tc_linear),
-                ('radar', tc_radar_layer * TC_MAX_RADAR_LAYERS)]
+                ('radar', tc_radar_layer * TC_MAX_RADAR_LAYERS),
+                ('l0_init_reference', c_fp), ('l0_attn_out', c_fp)]
 
 
 class tc_feats_nhwc(C.Structure):

@@ -187,7 +187,7 @@ struct ChainK {
   float* g[G_COUNT]; int g_ld[G_COUNT]; int g_mod[G_COUNT];   // global tensors by GSel
   float qscale; int qpad;
   // decoder
-  const float* ref_in; float* ref_out; float* box_m;
+  const float* ref_in; int ref_mod; float* ref_out; float* box_m;
   CamK cam; unsigned long long* pair_counter;
   // radar
   const float* tokens; int RI, T, pad_mult;
@@ -757,7 +757,8 @@ __global__ __launch_bounds__(CH_NT) void chain_kernel(ChainK k) {
           float p0, p1, p2;
           if (r.src == B_A) { p0 = S.a[row][0]; p1 = S.a[row][1]; p2 = S.a[row][2]; }
           else {
-            const int grow = min(m0 + row, M - 1);
+            int grow = min(m0 + row, M - 1);
+            if (k.ref_mod > 0) grow = grow % k.ref_mod;
             p0 = inverse_sigmoidf_(k.ref_in[(size_t)grow * 3 + 0]);
             p1 = inverse_sigmoidf_(k.ref_in[(size_t)grow * 3 + 1]);
             p2 = inverse_sigmoidf_(k.ref_in[(size_t)grow * 3 + 2]);
@@ -772,7 +773,8 @@ __global__ __launch_bounds__(CH_NT) void chain_kernel(ChainK k) {
         for (int row = wave; row < R; row += CH_NW) {
           const int grow = min(m0 + row, M - 1);
           int nvis = 0;
-          const float4 o = cam_sample_row<4>(k.cam, grow, grow / k.Q, &S.l[row][0], lane, nvis);
+          const float4 o = cam_sample_row<4>(k.cam, k.ref_mod > 0 ? grow % k.ref_mod : grow, grow / k.Q,
+                                             &S.l[row][0], lane, nvis);
           *reinterpret_cast<float4*>(&S.r[row][4 * lane]) = o;
           if (m0 + row < M) pairs += nvis;
         }
@@ -783,7 +785,7 @@ __global__ __launch_bounds__(CH_NT) void chain_kernel(ChainK k) {
         if (threadIdx.x < R && m0 + (int)threadIdx.x < M) {
           const int row = threadIdx.x, grow = m0 + row;
           const float* t = &S.l[row][0];
-          const float* rr = k.ref_in + (size_t)grow * 3;
+          const float* rr = k.ref_in + (size_t)(k.ref_mod > 0 ? grow % k.ref_mod : grow) * 3;
           const float nx = sigmoidf_(t[0] + inverse_sigmoidf_(rr[0]));
           const float ny = sigmoidf_(t[1] + inverse_sigmoidf_(rr[1]));
           const float nz = sigmoidf_(t[4] + inverse_sigmoidf_(rr[2]));
@@ -914,13 +916,13 @@ int launch_decoder_chain(const DecoderChainArgs& a, hipStream_t s) {
   k.pairs[13] = w.reg.l0; k.pairs[14] = w.reg.l2; k.pairs[15] = w.reg.l4;
   k.has_next = a.next_in_proj != nullptr;
   if (k.has_next) k.pairs[16] = *a.next_in_proj;
-  k.g[G_ATTN_O] = const_cast<float*>(a.attn_o); k.g_ld[G_ATTN_O] = 256;
+  k.g[G_ATTN_O] = const_cast<float*>(a.attn_o); k.g_ld[G_ATTN_O] = 256; k.g_mod[G_ATTN_O] = a.attn_mod;
   k.g[G_XIN] = const_cast<float*>(a.x_in); k.g_ld[G_XIN] = a.x_ld; k.g_mod[G_XIN] = a.x_mod;
   k.g[G_POS] = const_cast<float*>(a.qe); k.g_ld[G_POS] = 512; k.g_mod[G_POS] = a.Q;
   k.g[G_HS] = a.hs; k.g_ld[G_HS] = 256;
   k.g[G_QK] = a.qk; k.g_ld[G_QK] = 512; k.g[G_VT] = a.vt;
   k.qscale = a.qscale; k.qpad = a.qpad;
-  k.ref_in = a.ref_in; k.ref_out = a.ref_out; k.box_m = a.box_m;
+  k.ref_in = a.ref_in; k.ref_mod = a.ref_mod; k.ref_out = a.ref_out; k.box_m = a.box_m;
   fill_camk(a.cam, k.cam);
   k.pair_counter = a.cam.pair_counter;
   return launch(k, s, "chain(decoder)");

@@ -218,16 +218,23 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
     if (rs != s) TC_HIP(hipEventRecord(sd.join, rs));
   }
 
-  PrologueArgs pa;
-  pa.qe = w->query_embedding; pa.Q = Q; pa.M = rows; pa.refpts = w->reference_points;
-  pa.in_proj = w->layers[0].self_attn.in_proj; pa.init_ref = h.init_ref; pa.qk = h.qk; pa.vt = h.vt;
-  pa.qpad = h.qpad; pa.qscale = attn_qscale;
-  TC_TRY(launch_prologue(pa, s));
+  // layer 0 up to its attention output is a constant of the checkpoint (pack time)
+  const bool folded = w->l0_attn_out != nullptr && w->l0_init_reference != nullptr;
+  if (!folded) {
+    PrologueArgs pa;
+    pa.qe = w->query_embedding; pa.Q = Q; pa.M = rows; pa.refpts = w->reference_points;
+    pa.in_proj = w->layers[0].self_attn.in_proj; pa.init_ref = h.init_ref; pa.qk = h.qk; pa.vt = h.vt;
+    pa.qpad = h.qpad; pa.qscale = attn_qscale;
+    TC_TRY(launch_prologue(pa, s));
+  }
   for (int lid = 0; lid < L; ++lid) {
-    const float* ref_in = lid == 0 ? h.init_ref : h.inter_refs + (size_t)(lid - 1) * rows * 3;
-    TC_TRY(launch_self_attn_core(h.qk, h.qk + C, 2 * C, h.vt, h.qpad, h.attn_o, C, B, Q, H, s));
+    const bool l0c = folded && lid == 0;
+    const float* ref_in = l0c ? w->l0_init_reference
+                              : lid == 0 ? h.init_ref : h.inter_refs + (size_t)(lid - 1) * rows * 3;
+    if (!l0c) TC_TRY(launch_self_attn_core(h.qk, h.qk + C, 2 * C, h.vt, h.qpad, h.attn_o, C, B, Q, H, s));
     DecoderChainArgs d;
-    d.attn_o = h.attn_o;
+    d.attn_o = l0c ? w->l0_attn_out : h.attn_o;
+    d.attn_mod = l0c ? Q : 0; d.ref_mod = l0c ? Q : 0;
     if (lid == 0) { d.x_in = w->query_embedding + C; d.x_ld = 2 * C; d.x_mod = Q; }
     else { d.x_in = h.hs + (size_t)(lid - 1) * rows * C; d.x_ld = C; d.x_mod = 0; }
     d.qe = w->query_embedding; d.Q = Q;
@@ -248,8 +255,15 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
   if (aux) {
     if (aux->inter_states)
       TC_HIP(hipMemcpyAsync(aux->inter_states, h.hs, (size_t)L * rows * C * 4, hipMemcpyDeviceToDevice, s));
-    if (aux->init_reference)
-      TC_HIP(hipMemcpyAsync(aux->init_reference, h.init_ref, (size_t)rows * 3 * 4, hipMemcpyDeviceToDevice, s));
+    if (aux->init_reference) {
+      if (folded) {
+        for (int b = 0; b < B; ++b)
+          TC_HIP(hipMemcpyAsync(aux->init_reference + (size_t)b * Q * 3, w->l0_init_reference,
+                                (size_t)Q * 3 * 4, hipMemcpyDeviceToDevice, s));
+      } else {
+        TC_HIP(hipMemcpyAsync(aux->init_reference, h.init_ref, (size_t)rows * 3 * 4, hipMemcpyDeviceToDevice, s));
+      }
+    }
     if (aux->inter_references)
       TC_HIP(hipMemcpyAsync(aux->inter_references, h.inter_refs, (size_t)L * rows * 3 * 4,
                             hipMemcpyDeviceToDevice, s));
@@ -511,6 +525,9 @@ size_t tc_head_packed_bytes(const tc_head_weights* w) {
   const int n = collect_pack_items(w, &view, items);
   size_t total = 0;
   for (int i = 0; i < n; ++i) total += arena_slice(packed_floats(items[i].N, items[i].K), 4);
+  // layer-0 constants + the scratch they are computed from (see tc_head_pack_weights)
+  const size_t Q = w->num_query, C = w->embed_dims, qpad = ((Q + 15) / 16) * 16;
+  total += arena_slice(Q * 3, 4) + arena_slice(Q * C, 4) + arena_slice(Q * 2 * C, 4) + arena_slice(C * qpad, 4);
   return total;
 }
 
@@ -528,6 +545,27 @@ int tc_head_pack_weights(const tc_head_weights* w, void* packed, size_t packed_b
     float* dst = a.take<float>(packed_floats(items[i].N, items[i].K));
     TC_TRY(launch_pack_linear(items[i].src, items[i].N, items[i].K, dst, as_stream(stream)));
     *items[i].slot = dst;
+  }
+  // Layer 0's self-attention input is the learned embedding alone: reference points,
+  // QKV projection and softmax(QK^T)V are constants of the checkpoint.  Evaluate them
+  // here with the forward's own kernels (prologue chain + attention core, one batch).
+  {
+    const int Q = w->num_query, C = w->embed_dims, H = w->num_heads;
+    const int qpad = ((Q + 15) / 16) * 16;
+    float* init_ref = a.take<float>((size_t)Q * 3);
+    float* attn_o = a.take<float>((size_t)Q * C);
+    float* qk = a.take<float>((size_t)Q * 2 * C);
+    float* vt = a.take<float>((size_t)C * qpad);
+    hipStream_t s = as_stream(stream);
+    TC_HIP(hipMemsetAsync(vt, 0, (size_t)C * qpad * 4, s));
+    PrologueArgs pa;
+    pa.qe = w->query_embedding; pa.Q = Q; pa.M = Q; pa.refpts = packed_view->reference_points;
+    pa.in_proj = packed_view->layers[0].self_attn.in_proj; pa.init_ref = init_ref; pa.qk = qk; pa.vt = vt;
+    pa.qpad = qpad; pa.qscale = 1.4426950408889634f / sqrtf((float)(C / H));
+    TC_TRY(launch_prologue(pa, s));
+    TC_TRY(launch_self_attn_core(qk, qk + C, 2 * C, vt, qpad, attn_o, C, 1, Q, H, s));
+    packed_view->l0_init_reference = init_ref;
+    packed_view->l0_attn_out = attn_o;
   }
   return 0;
 }

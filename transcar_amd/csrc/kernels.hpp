@@ -85,6 +85,7 @@ int launch_prologue(const PrologueArgs& a, hipStream_t s);
 
 struct DecoderChainArgs {
   const float* attn_o;                       // [M,256]
+  int attn_mod = 0, ref_mod = 0;             // attn_o / ref_in rows taken modulo this when > 0
   const float* x_in; int x_ld, x_mod;        // layer input rows (row % x_mod when x_mod > 0)
   const float* qe; int Q;
   const float* ref_in; float* ref_out; float* box_m;
