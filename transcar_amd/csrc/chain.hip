@@ -866,7 +866,12 @@ void init_k(ChainK& k) { memset(&k, 0, sizeof(k)); }
 int launch(const ChainK& k, hipStream_t s, const char* what) {
   const char* e = getenv("TRANSCAR_CHAIN_ROWS");
   const int forced = e ? atoi(e) : 0;
-  const int rows = forced ? forced : (k.M <= 1024 ? 4 : k.M <= 2048 ? 8 : 16);
+  // The radar encoders run beside the decoder on a side stream and are not needed
+  // before the radar chain: they take the fewest workgroups (16-row tiles) so that the
+  // decoder's 225 workgroups still find a free CU each (225 + 64 > 256 CUs: the first
+  // decoder layer took 91 us instead of 69 next to a 4-row encoder grid).
+  const int rows = forced ? forced
+                   : k.program == PROG_RADAR_ENC ? 16 : (k.M <= 1024 ? 4 : k.M <= 2048 ? 8 : 16);
   if (rows == 4) return launch_r<4>(k, s, what);
   if (rows == 8) return launch_r<8>(k, s, what);
   return launch_r<16>(k, s, what);
