@@ -407,6 +407,32 @@ def test_box_decode_vs_oracle(T, head):
     assert np.all(s[:-1] >= s[1:])
 
 
+@pytest.mark.parametrize('case', ['ties', 'all_equal', 'random_batch'])
+def test_box_decode_ties_and_batches(T, case):
+    """The radix select stops early when a whole bin is wanted; ties between equal
+    scores (which keep it going through the index digits) must still give exactly
+    max_num results: the top scores, ties resolved to the lower flat index."""
+    from transcar_amd import ops
+    rng = np.random.RandomState(7)
+    B = 3 if case == 'random_batch' else 1
+    cls = rng.standard_normal((B, 900, 10)).astype(np.float32)
+    if case == 'ties':
+        cls = np.round(cls * 2) / 2            # ~15 distinct values, 9000 keys
+    elif case == 'all_equal':
+        cls[:] = 0.25
+    box = rng.standard_normal((B, 900, 10)).astype(np.float32) * 0.3
+    pcr = configs.pts_bbox_head['bbox_coder']['post_center_range']
+    boxes, scores, labels, valid = ops.box_decode_topk(gpu(cls), gpu(box), pcr, 300)
+    sg = 1.0 / (1.0 + np.exp(-cls.astype(np.float64)))
+    for b in range(B):
+        flat = sg[b].reshape(-1)
+        order = np.lexsort((np.arange(flat.size), -flat))[:300]      # score desc, index asc
+        np.testing.assert_allclose(scores[b].cpu().numpy(), flat[order], atol=1e-6, rtol=0)
+        if case != 'random_batch':     # (distinct logits may round to one fp32 sigmoid: order free)
+            np.testing.assert_array_equal(labels[b].cpu().numpy(), order % 10)
+            np.testing.assert_allclose(boxes[b].cpu().numpy()[:, 0], box[b][order // 10, 0], atol=1e-6)
+
+
 def test_missing_gpu_inputs_fail_loudly(T, head):
     feats = [torch.from_numpy(f) for f in synth.make_feats('tiny', seed=1)]
     with pytest.raises(T.TransCARHipError):

@@ -99,7 +99,10 @@ enum Flags : short {
   F_SCALEQ = 2,       // linear: scale the first 256 output columns by qscale
   F_WOFF = 4,         // linear: weights start 512 rows into the pair (V part of a packed in_proj)
   F_LN_RELU = 8,      // ln: relu after the outer LN
-  F_SKIP_NONEXT = 16  // skip the step when there is no next layer
+  F_SKIP_NONEXT = 16, // skip the step when there is no next layer
+  F_WAVE1 = 32,       // linear: column tile t goes to wave (t + 1) % 4 -- a narrow step (one tile)
+                      //   then runs BESIDE the preceding narrow step, which keeps wave 0 busy
+  F_NOT_W0 = 64       // posenc: rows go to waves 1..3 only (wave 0 is in a narrow linear step)
 };
 // global tensors, indices into ChainK::g
 enum GSel : short {
@@ -120,7 +123,7 @@ __constant__ StepDesc PROG_DECODER_T[] = {
     {K_LINEAR, 1, -1, 256, 256, B_T, B_NONE, B_U, B_X, 0, 0, G_NONE, G_NONE, 1},          // x + out_proj(attn)
     {K_LN, 2, -1, 0, 0, B_U, B_NONE, B_X, B_NONE, 0, 0, G_NONE, G_NONE, 1},               // norm0
     {K_LINEAR, 3, -1, 256, N_LOGITS, B_X, B_P, B_L, B_NONE, 0, 0, G_NONE, G_NONE, 0},     // attention_weights
-    {K_POSENC, 5, 6, 0, 0, B_NONE, B_NONE, B_T, B_NONE, 0, 0, G_NONE, G_NONE, 1},         // pe.0-2
+    {K_POSENC, 5, 6, 0, 0, B_NONE, B_NONE, B_T, B_NONE, 0, F_NOT_W0, G_NONE, G_NONE, 1},  // pe.0-2 (waves 1-3)
     {K_SAMPLE, 0, 0, 0, 0, B_L, B_NONE, B_R, B_NONE, 0, 0, G_NONE, G_NONE, 1},            // camera sampling
     {K_LINEAR, 7, -1, 256, 256, B_T, B_NONE, B_A, B_NONE, 0, 0, G_NONE, G_NONE, 0},       // pe.3
     {K_LINEAR, 4, -1, 256, 256, B_R, B_NONE, B_U, B_X, 0, 0, G_NONE, G_NONE, 1},          // x + output_proj
@@ -170,11 +173,12 @@ __constant__ StepDesc PROG_RADAR_LAYER_T[] = {
     {K_LINEAR, 11, -1, 256, 256, B_X, B_NONE, B_R, B_NONE, 1, 0, G_NONE, G_NONE, 1},         // final_reg.0
     {K_LN, 7, -1, 0, 0, B_T, B_NONE, B_T, B_NONE, 0, F_LN_RELU, G_NONE, G_NONE, 0},          // in place
     {K_LINEAR, 12, -1, 256, 256, B_R, B_NONE, B_U, B_NONE, 1, 0, G_NONE, G_NONE, 1},         // final_reg.2
-    {K_LINEAR, 8, -1, 256, 256, B_T, B_NONE, B_P, B_NONE, 0, 0, G_NONE, G_NONE, 0},          // final_cls.3
-    {K_LINEAR, 13, -1, 256, N_CODE, B_U, B_NONE, B_L, B_NONE, 0, 0, G_NONE, G_NONE, 1},      // final_reg.4
-    {K_LN, 9, -1, 0, 0, B_P, B_NONE, B_P, B_NONE, 0, F_LN_RELU, G_NONE, G_NONE, 0},          // in place
+    {K_LINEAR, 8, -1, 256, 256, B_T, B_NONE, B_P, B_NONE, 0, 0, G_NONE, G_NONE, 1},          // final_cls.3
+    {K_LN, 9, -1, 0, 0, B_P, B_NONE, B_P, B_NONE, 0, F_LN_RELU, G_NONE, G_NONE, 1},          // in place
+    // the two 10-column steps side by side: final_reg.4 on wave 0, final_cls.6 on wave 1
+    {K_LINEAR, 13, -1, 256, N_CODE, B_U, B_NONE, B_L, B_NONE, 0, 0, G_NONE, G_NONE, 0},      // final_reg.4
+    {K_LINEAR, 10, -1, 256, N_CLS, B_P, B_NONE, B_NONE, B_NONE, 0, F_WAVE1, G_CLS, G_NONE, 1},   // final_cls.6
     {K_BOXADD, 0, 0, 0, 0, B_L, B_NONE, B_NONE, B_NONE, 0, 0, G_NONE, G_NONE, 1},
-    {K_LINEAR, 10, -1, 256, N_CLS, B_P, B_NONE, B_NONE, B_NONE, 0, 0, G_CLS, G_NONE, 1},     // final_cls.6
     {K_END, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
 
 enum Program : int { PROG_PROLOGUE = 0, PROG_DECODER, PROG_RADAR_ENC, PROG_RADAR };
@@ -212,6 +216,7 @@ struct LinSpec {
   float* gdst; int gdst_ld;
   float* gt; int gt_ld, gt_rpb;
   int m0, M;
+  int woff;                    // wave w owns column tiles ((w - woff) & 3) + 4 i
   int sub_on;
 };
 
@@ -399,7 +404,7 @@ __device__ __forceinline__ bool linear_step(const LinSpec& s, WBuf& w0, bool pre
                                             const float* next_first, SpecFn make_spec, int step_idx) {
   constexpr int NG = R / 4;
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave = (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) - s.woff) & (CH_NW - 1);
   const int ntiles = (s.N + 63) >> 6;
   const int kpad = (s.K + 63) & ~63;                 // packed tile = 64 * kpad floats
   const int nkb = kpad / KB;
@@ -645,6 +650,7 @@ __global__ __launch_bounds__(CH_NT) void chain_kernel(ChainK k) {
     s.gdst = uptr(r.gd); s.gdst_ld = ufirst(r.gld);
     s.gt = uptr(r.gt); s.gt_ld = k.qpad; s.gt_rpb = k.Q;
     s.m0 = m0; s.M = M;
+    s.woff = (r.flags & F_WAVE1) ? 1 : 0;
     s.sub_on = 0;
     return s;
   };
@@ -656,9 +662,10 @@ __global__ __launch_bounds__(CH_NT) void chain_kernel(ChainK k) {
       if (kind == K_LN || kind == K_NOP) continue;
       if (kind != K_LINEAR) break;
       const int N = ufirst(S.sres[j].N), K = ufirst(S.sres[j].K);
-      if (wave >= ((N + 63) >> 6)) continue;
+      const int vw = (wave - ((ufirst(S.sres[j].flags) & F_WAVE1) ? 1 : 0)) & (CH_NW - 1);
+      if (vw >= ((N + 63) >> 6)) continue;
       nidx = j;
-      return uptr(S.sres[j].p0) + (size_t)wave * 64 * ((K + 63) & ~63);
+      return uptr(S.sres[j].p0) + (size_t)vw * 64 * ((K + 63) & ~63);
     }
     nidx = -1;
     return nullptr;
@@ -682,7 +689,7 @@ __global__ __launch_bounds__(CH_NT) void chain_kernel(ChainK k) {
           s.sub_on = (ufirst(r.si) == g_sub_step && ufirst(r.rep) == 0);
           SUB_STAMP(0);
 #endif
-          if (wave < ((s.N + 63) >> 6)) {      // else: no column tile here, w0 keeps waiting
+          if (((wave - s.woff) & (CH_NW - 1)) < ((s.N + 63) >> 6)) {   // else: no column tile here, w0 keeps waiting
             int nidx = -1;
             const float* nf = next_linear_first(idx, nidx);
             const bool have = linear_step<R>(s, w0, pre_idx == idx, nf,
@@ -753,7 +760,8 @@ __global__ __launch_bounds__(CH_NT) void chain_kernel(ChainK k) {
       } break;
       case K_POSENC: {   // Linear(3,256) + LN + ReLU of inverse_sigmoid(ref) or of raw token xyz
         float* dst = buf_ptr<R>(S, r.dst);
-        for (int row = wave; row < R; row += CH_NW) {
+        const bool skip0 = (r.flags & F_NOT_W0) != 0;      // wave 0 is busy with the narrow linear step before
+        for (int row = skip0 ? wave - 1 : wave; row < R && row >= 0; row += skip0 ? CH_NW - 1 : CH_NW) {
           float p0, p1, p2;
           if (r.src == B_A) { p0 = S.a[row][0]; p1 = S.a[row][1]; p2 = S.a[row][2]; }
           else {

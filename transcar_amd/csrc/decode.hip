@@ -83,13 +83,19 @@ __global__ __launch_bounds__(DEC_THREADS) void box_decode_kernel(DecK p) {
           if (cum + c1 < remaining) { cum += c1; bin = b0 - 2;
             if (cum + c2 < remaining) { cum += c2; bin = b0 - 3; } } }
         misc[0] = bin; misc[1] = remaining - cum;
+        // every key of the chosen bin is wanted: the lower digits cannot change the
+        // selection, the remaining passes (normally the four over the index half of
+        // the key, ties between scores being rare) are skipped
+        misc[3] = (remaining - cum == (int)hist[bin]) ? 1u : 0u;
       }
     }
     __syncthreads();
     prefix |= (unsigned long long)misc[0] << sh;
     pmask |= 0xFFull << sh;
     remaining = (int)misc[1];
+    const bool done = misc[3] != 0;
     __syncthreads();
+    if (done) break;
   }
   const unsigned long long thr = prefix;    // exactly K keys are >= thr (keys are unique)
   if (tid == 0) misc[2] = 0;
