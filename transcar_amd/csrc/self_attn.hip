@@ -11,7 +11,7 @@
 //   * scores are computed TRANSPOSED, S^T = K Q^T, so the accumulator of a
 //     tile (lane = query column, registers = 4 keys) is already the B operand
 //     of the second product O^T += V^T P^T: no LDS round trip, no shuffles for
-//     the P matrix; the per-query max needs two xor-shuffles (lanes c, c+16,
+//     the P matrix; the per-query max is two permlane swaps (lanes c, c+16,
 //     c+32, c+48 hold the same query);
 //   * V arrives transposed ([B, C, Qpad], written that way by the in_proj GEMM
 //     epilogue) so a lane's 4 keys of one channel are one 16-byte load;
@@ -27,6 +27,21 @@ namespace tc {
 #define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 constexpr int SA_NW = 8;
+
+// max over the four lanes c, c+16, c+32, c+48 (they hold the same query column) on
+// the VALU: gfx950's v_permlane32_swap / v_permlane16_swap exchange half-waves /
+// odd-even 16-lane rows between two registers, so swap(x, x) followed by one v_max is
+// an xor-32 / xor-16 all-reduce.  (__shfl_xor goes through the LDS crossbar, and two
+// of them sat in the dependency chain S -> max -> exp -> PV of every key tile.)
+__device__ __forceinline__ float max_lanes_16_32(float x) {
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  unsigned xi = __builtin_bit_cast(unsigned, x);
+  u2 r = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);
+  x = fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+  xi = __builtin_bit_cast(unsigned, x);
+  r = __builtin_amdgcn_permlane16_swap(xi, xi, false, false);
+  return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
 
 struct KVFrag { float4 ka, kb, v0, v1; };
 
@@ -108,8 +123,7 @@ __global__ __launch_bounds__(SA_NW * 64) void self_attn_kernel(const float* __re
         if (kk + 3 >= Q) s3 = -INFINITY;
       }
       float mx = fmaxf(fmaxf(s0, s1), fmaxf(s2, s3));
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = max_lanes_16_32(mx);
       const float mnew = fmaxf(m[u], mx);           // finite: key0 + 0 < Q in every tile
       const float alpha = __builtin_amdgcn_exp2f(m[u] - mnew);
       const float p0 = __builtin_amdgcn_exp2f(s0 - mnew), p1 = __builtin_amdgcn_exp2f(s1 - mnew);
