@@ -37,7 +37,7 @@ def label_chain(rows, num_layers=6):
     """chain_kernel launches are told apart by their neighbours in dispatch
     order: the small grid is the radar encoder (side stream); a full-grid
     launch right after self_attn is a decoder layer, one right before the first
-    self_attn of a frame is the prologue, the one after the last decoder layer
+    self_attn of a frame is decoder layer 0, the one after the last decoder layer
     of a frame is the radar chain; back-to-back launches without attention in
     between are bench.py's roofline replay of the decoder layer."""
     for r in rows:
@@ -60,8 +60,10 @@ def label_chain(rows, num_layers=6):
             r['K'] = 'chain_kernel(decoder layer)'
             n_dec += 1
         elif nxt.startswith('self_attn'):
-            r['K'] = 'chain_kernel(prologue)'
-            n_dec = 0
+            # first launch of a frame: decoder layer 0 (its self-attention is folded into the
+            # packed weights; builds before that had a prologue chain here)
+            r['K'] = 'chain_kernel(decoder layer)'
+            n_dec = 1
         elif n_dec == num_layers and 'box_decode' in nxt:
             r['K'] = 'chain_kernel(radar)'
         else:
