@@ -255,57 +255,46 @@ __device__ __forceinline__ void acc_zero(Acc<NG>& a) {
   for (int g = 0; g < NG; ++g) { a.v[g][0] = f32x4{0.f, 0.f, 0.f, 0.f}; a.v[g][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 }
 
-template <int NG, int G>
-struct MfmaGroups {
-  static __device__ __forceinline__ void run(Acc<NG>& acc, float a, float b, int par) {
-    if (par == 0) acc.v[G][0] = MFMA44(a, b, acc.v[G][0], G);
-    else acc.v[G][1] = MFMA44(a, b, acc.v[G][1], G);
-    MfmaGroups<NG, G + 1>::run(acc, a, b, par);
-  }
-};
-template <int NG>
-struct MfmaGroups<NG, NG> {
-  static __device__ __forceinline__ void run(Acc<NG>&, float, float, int) {}
-};
-
-// The A operand (this lane's activation row, 64 k of it) is read from LDS into
-// registers BEFORE the MFMA burst: issued just in time, every one of the 16
-// ds_read_b128 exposed its ~120-cycle latency to the matrix pipe (a rolling window
-// of 4 reads in flight was measured too: 1120 instead of 936 cycles per MFMA phase).
-struct ABuf { float4 a[16]; };
-
-// No per-read guards: a conditional around each ds_read_b128 turned the 16 reads
-// into 16 dependent round trips (1350 cycles per item, measured).  Reading past
-// K is safe: the LDS tile is zero filled up to the next multiple of 64 wherever
-// K is not one, and the packed weights are zero there.
-template <bool ADD2>
-__device__ __forceinline__ void aload(ABuf& ab, const float* arow, const float* a2row) {
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    float4 av = *reinterpret_cast<const float4*>(arow + 4 * i);
-    if (ADD2) av = add4(av, *reinterpret_cast<const float4*>(a2row + 4 * i));
-    ab.a[i] = av;
-  }
-}
-
-// The 16 weight loads of the NEXT item (1 KiB per wave-instruction) are issued one
-// per group of 4*NG MFMAs of the current item.  Issued as one burst they fill the
+// The A operand of one item (R rows x 64 k) is ONE ds_read_b128 per row group: lane
+// 4j + q holds row q, k chunk j (4 consecutive k), and the MFMA's abid selects block j
+// as the 4-lane group that is broadcast to the 16 column blocks (cbsz = 4).  (Earlier
+// builds had every lane < R hold its whole row: 16 reads and 64 VGPRs per item, and the
+// weight buffers spilled to AGPRs.)  No guards on the read: the LDS tile is zero filled
+// up to the next multiple of 64 wherever K is not one, and the packed weights are zero
+// there.  Exact fp32: f32 FMA chains, two k-interleaved accumulators per row group so
+// the pipe is issue- not latency-bound.
+//
+// The 16 weight loads of the NEXT item (1 KiB per wave-instruction) are issued one per
+// group of 4*NG MFMAs of the current item.  Issued as one burst they fill the
 // vector-memory queue, the wave blocks at the queue and its MFMAs wait behind the
 // loads in program order: loads and MFMAs then run back to back (2330 cycles per
 // item at R = 4); interleaved they overlap (1410; tools/chainpipe_probe.hip).
-template <int NG, bool PF>
-__device__ __forceinline__ void wcompute(Acc<NG>& acc, const WBuf& wb, const ABuf& ab, WBuf& nx,
-                                         const float* np) {
+template <int NG, bool PF, int J>
+struct ItemSteps {
+  static __device__ __forceinline__ void run(Acc<NG>& acc, const WBuf& wb, const float4* ar, WBuf& nx,
+                                             const float* np) {
+    if (PF) nx.b[J] = ld4(np + J * 256);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    if (PF) nx.b[i] = ld4(np + i * 256);
+    for (int g = 0; g < NG; ++g) {
+      acc.v[g][0] = MFMA44(ar[g].x, wb.b[J].x, acc.v[g][0], J);
+      acc.v[g][1] = MFMA44(ar[g].y, wb.b[J].y, acc.v[g][1], J);
+      acc.v[g][0] = MFMA44(ar[g].z, wb.b[J].z, acc.v[g][0], J);
+      acc.v[g][1] = MFMA44(ar[g].w, wb.b[J].w, acc.v[g][1], J);
+    }
     __builtin_amdgcn_sched_barrier(0);
-    MfmaGroups<NG, 0>::run(acc, ab.a[i].x, wb.b[i].x, 0);
-    MfmaGroups<NG, 0>::run(acc, ab.a[i].y, wb.b[i].y, 1);
-    MfmaGroups<NG, 0>::run(acc, ab.a[i].z, wb.b[i].z, 0);
-    MfmaGroups<NG, 0>::run(acc, ab.a[i].w, wb.b[i].w, 1);
-    __builtin_amdgcn_sched_barrier(0);
+    ItemSteps<NG, PF, J + 1>::run(acc, wb, ar, nx, np);
   }
+};
+template <int NG, bool PF>
+struct ItemSteps<NG, PF, 16> {
+  static __device__ __forceinline__ void run(Acc<NG>&, const WBuf&, const float4*, WBuf&, const float*) {}
+};
+
+template <int NG, bool PF>
+__device__ __forceinline__ void wcompute(Acc<NG>& acc, const WBuf& wb, const float4* ar, WBuf& nx,
+                                         const float* np) {
+  ItemSteps<NG, PF, 0>::run(acc, wb, ar, nx, np);
 }
 
 // lane n holds y[4g + i][64*tile + n] in acc.v[g][*][i]
@@ -410,9 +399,9 @@ __device__ __forceinline__ bool linear_step(const LinSpec& s, WBuf& w0, bool pre
   const int nkb = kpad / KB;
   const int my_tiles = wave < ntiles ? (ntiles - wave + CH_NW - 1) / CH_NW : 0;
   const int nitems = my_tiles * nkb;
-  const int arow_i = min(lane, R - 1);
-  const float* arow = s.src + arow_i * s.src_ld;
-  const float* a2row = s.src2 ? s.src2 + arow_i * s.src2_ld : nullptr;
+  // lane 4j + q reads row q (of each row group), k chunk j
+  const float* arow = s.src + (lane & 3) * s.src_ld + 4 * (lane >> 2);
+  const float* a2row = s.src2 ? s.src2 + (lane & 3) * s.src2_ld + 4 * (lane >> 2) : nullptr;
   const float* wbase = s.W + 4 * lane + (size_t)wave * 64 * kpad;
   const size_t tile_stride = (size_t)CH_NW * 64 * kpad;
   Acc<NG> acc;
@@ -442,10 +431,14 @@ __device__ __forceinline__ bool linear_step(const LinSpec& s, WBuf& w0, bool pre
       bv = ldg1((s.bias != nullptr ? s.bias : s.W) + col);
     }
     if (stamp_items && tt == 0 && kb < 2) SUB_STAMP(22 + 5 * kb);
-    ABuf ab;
-    if (a2row != nullptr) aload<true>(ab, arow + kb * KB, a2row + kb * KB);
-    else aload<false>(ab, arow + kb * KB, nullptr);
-    wcompute<NG, PF>(acc, wb, ab, nx, nload);
+    float4 ar[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      ar[g] = *reinterpret_cast<const float4*>(arow + 4 * g * s.src_ld + kb * KB);
+      if (a2row != nullptr)
+        ar[g] = add4(ar[g], *reinterpret_cast<const float4*>(a2row + 4 * g * s.src2_ld + kb * KB));
+    }
+    wcompute<NG, PF>(acc, wb, ar, nx, nload);
     if (stamp_items && tt == 0 && kb < 2) SUB_STAMP(23 + 5 * kb);
     if (kb == nkb - 1) {
       // The epilogue REBUILDS its view of the step from the LDS record (behind an opaque
