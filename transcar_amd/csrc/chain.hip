@@ -68,11 +68,23 @@ struct StepRes {
   short kind, src, src2, dst, res, act, flags, sync, rep, si;
   int pad_;
 };
+// what the epilogue of a linear step needs, with the LDS buffers as float offsets from
+// the start of shared memory (-1: none): rebuilt from here in ~150 cycles per tile
+struct EpiRec {
+  float* gd; float* gt;
+  int dst_off, res_off, dst_ld, res_ld;
+  int gld, act, flags, N;
+  int has_bias, woff, pad0, pad1;
+};
+// per wave: the next linear step of the same run in which the wave owns a column tile
+struct PreRec { const float* first; int nidx; int pad; };
 constexpr int MAX_STEPS = 64;
 
 template <int R>
 struct ChainLds {
   StepRes sres[MAX_STEPS];
+  EpiRec epi[MAX_STEPS];
+  PreRec pre[MAX_STEPS][CH_NW];
   float a[R][LD5];
   float x[R][LD2];
   float r[R][LD2];
@@ -529,15 +541,17 @@ __device__ __forceinline__ T* uptr(T* p) {
 
 // a resolved step from LDS into SGPRs (every field is uniform over the workgroup:
 // left in VGPRs they cost the item loop ~40 registers and the weight buffers spill)
-__device__ __forceinline__ StepRes load_step(const StepRes& src) {
-  constexpr int NWORDS = sizeof(StepRes) / 4;
-  static_assert(sizeof(StepRes) % 4 == 0, "StepRes size");
-  union U { StepRes r; int w[NWORDS]; __device__ U() {} } u;
+template <typename T>
+__device__ __forceinline__ T load_uniform(const T& src) {
+  constexpr int NWORDS = sizeof(T) / 4;
+  static_assert(sizeof(T) % 4 == 0, "record size");
+  union U { T r; int w[NWORDS]; __device__ U() {} } u;
   const int* p = reinterpret_cast<const int*>(&src);
 #pragma unroll
   for (int i = 0; i < NWORDS; ++i) u.w[i] = __builtin_amdgcn_readfirstlane(p[i]);
   return u.r;
 }
+__device__ __forceinline__ StepRes load_step(const StepRes& src) { return load_uniform<StepRes>(src); }
 
 template <int R>
 __global__ __launch_bounds__(CH_NT) void chain_kernel(ChainK k) {
@@ -587,6 +601,35 @@ __global__ __launch_bounds__(CH_NT) void chain_kernel(ChainK k) {
       }
     }
     S.sres[idx] = r;
+    EpiRec e;
+    e.gd = r.gd; e.gt = r.gt; e.gld = r.gld; e.act = r.act; e.flags = r.flags; e.N = r.N;
+    e.has_bias = r.p1 != nullptr; e.woff = (r.flags & F_WAVE1) ? 1 : 0; e.pad0 = e.pad1 = 0;
+    const float* base = reinterpret_cast<const float*>(smem_raw);
+    const float* dp = buf_ptr<R>(S, r.dst);
+    const float* rp = buf_ptr<R>(S, r.res);
+    e.dst_off = dp ? (int)(dp - base) : -1; e.dst_ld = buf_ld(r.dst);
+    e.res_off = rp ? (int)(rp - base) : -1; e.res_ld = buf_ld(r.res);
+    S.epi[idx] = e;
+  }
+  __syncthreads();
+  // per (step, wave): the next linear step inside the same run of light steps where the
+  // wave owns a column tile, and that step's first weight item
+  for (int t = threadIdx.x; t < total * CH_NW; t += CH_NT) {
+    const int idx = t / CH_NW, w = t - idx * CH_NW;
+    PreRec pr;
+    pr.first = nullptr; pr.nidx = -1; pr.pad = 0;
+    for (int j = idx + 1; j < total; ++j) {
+      const int kind = S.sres[j].kind;
+      if (kind == K_LN || kind == K_NOP) continue;
+      if (kind != K_LINEAR) break;
+      const int N = S.sres[j].N, K = S.sres[j].K;
+      const int vw = (w - ((S.sres[j].flags & F_WAVE1) ? 1 : 0)) & (CH_NW - 1);
+      if (vw >= ((N + 63) >> 6)) continue;
+      pr.nidx = j;
+      pr.first = S.sres[j].p0 + (size_t)vw * 64 * ((K + 63) & ~63);
+      break;
+    }
+    S.pre[idx][w] = pr;
   }
 
   if (k.program == PROG_RADAR) {     // HEAD:539, 543-547, 596-598
@@ -629,39 +672,40 @@ __global__ __launch_bounds__(CH_NT) void chain_kernel(ChainK k) {
       if (gdst != nullptr && m0 + row < M) st4(gdst + (size_t)(m0 + row) * 256 + 4 * lane, v);
     }
   };
+  // the part of a linear step the item loop needs ...
   auto lin_spec = [&](const StepRes& r) {
     LinSpec s;
-    s.K = ufirst(r.K); s.N = ufirst(r.N);
-    s.W = uptr(r.p0); s.bias = uptr(r.p1);
+    s.K = r.K; s.N = r.N;
+    s.W = r.p0; s.bias = r.p1;
     s.src = buf_ptr<R>(S, r.src); s.src_ld = buf_ld(r.src);
     s.src2 = buf_ptr<R>(S, r.src2); s.src2_ld = buf_ld(r.src2);
-    s.dst = buf_ptr<R>(S, r.dst); s.dst_ld = buf_ld(r.dst);
-    s.res = buf_ptr<R>(S, r.res); s.res_ld = buf_ld(r.res);
-    s.gate = (r.flags & F_GATE) ? &S.gate[0] : nullptr;
-    s.act = r.act;
-    s.scale = (r.flags & F_SCALEQ) ? k.qscale : 1.0f; s.scale_cols = (r.flags & F_SCALEQ) ? 256 : 0;
-    s.gdst = uptr(r.gd); s.gdst_ld = ufirst(r.gld);
-    s.gt = uptr(r.gt); s.gt_ld = k.qpad; s.gt_rpb = k.Q;
+    s.dst = nullptr; s.dst_ld = 0; s.res = nullptr; s.res_ld = 0; s.gate = nullptr;
+    s.act = 0; s.scale = 1.0f; s.scale_cols = 0;
+    s.gdst = nullptr; s.gdst_ld = 0; s.gt = nullptr; s.gt_ld = 0; s.gt_rpb = 1;
     s.m0 = m0; s.M = M;
     s.woff = (r.flags & F_WAVE1) ? 1 : 0;
     s.sub_on = 0;
     return s;
   };
-  // first weight item of the next linear step (after idx, inside the same run of
-  // linear / LN / skipped steps) in which this wave owns a column tile
-  auto next_linear_first = [&](int idx, int& nidx) -> const float* {
-    for (int j = idx + 1; j < total; ++j) {
-      const int kind = ufirst(S.sres[j].kind);
-      if (kind == K_LN || kind == K_NOP) continue;
-      if (kind != K_LINEAR) break;
-      const int N = ufirst(S.sres[j].N), K = ufirst(S.sres[j].K);
-      const int vw = (wave - ((ufirst(S.sres[j].flags) & F_WAVE1) ? 1 : 0)) & (CH_NW - 1);
-      if (vw >= ((N + 63) >> 6)) continue;
-      nidx = j;
-      return uptr(S.sres[j].p0) + (size_t)vw * 64 * ((K + 63) & ~63);
-    }
-    nidx = -1;
-    return nullptr;
+  // ... and the part its epilogue needs, rebuilt per tile from the 64-byte LDS record
+  auto epi_spec = [&](int j) {
+    const EpiRec e = load_uniform<EpiRec>(S.epi[j]);
+    float* base = reinterpret_cast<float*>(smem_raw);
+    LinSpec s;
+    s.K = 0; s.N = e.N; s.W = nullptr;
+    s.bias = e.has_bias ? base : nullptr;           // only tested against nullptr in the epilogue
+    s.src = nullptr; s.src_ld = 0; s.src2 = nullptr; s.src2_ld = 0;
+    s.dst = e.dst_off >= 0 ? base + e.dst_off : nullptr; s.dst_ld = e.dst_ld;
+    s.res = e.res_off >= 0 ? base + e.res_off : nullptr; s.res_ld = e.res_ld;
+    s.gate = (e.flags & F_GATE) ? &S.gate[0] : nullptr;
+    s.act = e.act;
+    s.scale = (e.flags & F_SCALEQ) ? k.qscale : 1.0f; s.scale_cols = (e.flags & F_SCALEQ) ? 256 : 0;
+    s.gdst = e.gd; s.gdst_ld = e.gld;
+    s.gt = e.gt; s.gt_ld = k.qpad; s.gt_rpb = k.Q;
+    s.m0 = m0; s.M = M;
+    s.woff = e.woff;
+    s.sub_on = 0;
+    return s;
   };
 
   int idx = 0;
@@ -683,11 +727,9 @@ __global__ __launch_bounds__(CH_NT) void chain_kernel(ChainK k) {
           SUB_STAMP(0);
 #endif
           if (((wave - s.woff) & (CH_NW - 1)) < ((s.N + 63) >> 6)) {   // else: no column tile here, w0 keeps waiting
-            int nidx = -1;
-            const float* nf = next_linear_first(idx, nidx);
-            const bool have = linear_step<R>(s, w0, pre_idx == idx, nf,
-                                             [&](int j) { return lin_spec(load_step(S.sres[j])); }, idx);
-            pre_idx = have ? nidx : -1;
+            const PreRec pr = load_uniform<PreRec>(S.pre[idx][wave]);
+            const bool have = linear_step<R>(s, w0, pre_idx == idx, pr.first, epi_spec, idx);
+            pre_idx = have ? pr.nidx : -1;
           }
         } else if (kd == K_LN) {
           do_ln(r);
