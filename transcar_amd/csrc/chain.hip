@@ -66,6 +66,7 @@ struct StepRes {
   float* gd; float* gt;          // global destination (source for K_LOAD) / transposed destination
   int K, N, gld, gmod;
   short kind, src, src2, dst, res, act, flags, sync, rep, si;
+  int src_off, src2_off;         // linear: A operand buffers as float offsets into shared memory (-1: none)
   int pad_;
 };
 // what the epilogue of a linear step needs, with the LDS buffers as float offsets from
@@ -600,6 +601,14 @@ __global__ __launch_bounds__(CH_NT) void chain_kernel(ChainK k) {
         r.p2 = n2.w; r.p3 = n2.b;
       }
     }
+    {
+      const float* base0 = reinterpret_cast<const float*>(smem_raw);
+      const float* sp = buf_ptr<R>(S, r.src);
+      const float* sp2 = buf_ptr<R>(S, r.src2);
+      r.src_off = sp ? (int)(sp - base0) : -1;
+      r.src2_off = sp2 ? (int)(sp2 - base0) : -1;
+      r.pad_ = 0;
+    }
     S.sres[idx] = r;
     EpiRec e;
     e.gd = r.gd; e.gt = r.gt; e.gld = r.gld; e.act = r.act; e.flags = r.flags; e.N = r.N;
@@ -677,8 +686,9 @@ __global__ __launch_bounds__(CH_NT) void chain_kernel(ChainK k) {
     LinSpec s;
     s.K = r.K; s.N = r.N;
     s.W = r.p0; s.bias = r.p1;
-    s.src = buf_ptr<R>(S, r.src); s.src_ld = buf_ld(r.src);
-    s.src2 = buf_ptr<R>(S, r.src2); s.src2_ld = buf_ld(r.src2);
+    const float* lbase = reinterpret_cast<const float*>(smem_raw);
+    s.src = lbase + r.src_off; s.src_ld = buf_ld(r.src);
+    s.src2 = r.src2_off >= 0 ? lbase + r.src2_off : nullptr; s.src2_ld = buf_ld(r.src2);
     s.dst = nullptr; s.dst_ld = 0; s.res = nullptr; s.res_ld = 0; s.gate = nullptr;
     s.act = 0; s.scale = 1.0f; s.scale_cols = 0;
     s.gdst = nullptr; s.gdst_ld = 0; s.gt = nullptr; s.gt_ld = 0; s.gt_rpb = 1;
