@@ -573,6 +573,26 @@ __global__ __launch_bounds__(CH_NT) void chain_kernel(ChainK k) {
   int nsteps = 0;
   while (table[nsteps].kind != K_END) ++nsteps;
   const int total = nsteps * nrep;
+  // The leading global-to-LDS loads of a program (a decoder layer starts with three) are
+  // issued before the table is resolved: their latency and the resolution overlap.
+  constexpr int EARLY_MAX = 3, EARLY_RW = (R + CH_NW - 1) / CH_NW;
+  float4 early_v[EARLY_MAX][EARLY_RW];
+  int early_n = 0;
+  while (early_n < EARLY_MAX && early_n < nsteps && table[early_n].kind == K_LOAD) ++early_n;
+#pragma unroll
+  for (int j = 0; j < EARLY_MAX; ++j) {
+    if (j < early_n) {
+      const StepDesc d = table[j];
+      const float* gsrc = k.g[d.gsel];
+      const int ld = k.g_ld[d.gsel], mod = k.g_mod[d.gsel];
+#pragma unroll
+      for (int ri = 0; ri < EARLY_RW; ++ri) {
+        int grow = min(m0 + wave + ri * CH_NW, M - 1);
+        if (mod > 0) grow = grow % mod;
+        early_v[j][ri] = ld4(gsrc + (size_t)grow * ld + 4 * lane);
+      }
+    }
+  }
   for (int idx = threadIdx.x; idx < total; idx += CH_NT) {
     const int rep = idx / nsteps, si = idx - rep * nsteps;
     const int pair0 = k.program == PROG_RADAR ? rep * RADAR_PAIRS : 0;
@@ -619,6 +639,17 @@ __global__ __launch_bounds__(CH_NT) void chain_kernel(ChainK k) {
     e.dst_off = dp ? (int)(dp - base) : -1; e.dst_ld = buf_ld(r.dst);
     e.res_off = rp ? (int)(rp - base) : -1; e.res_ld = buf_ld(r.res);
     S.epi[idx] = e;
+  }
+#pragma unroll
+  for (int j = 0; j < EARLY_MAX; ++j) {
+    if (j < early_n) {
+      float* dst = buf_ptr<R>(S, table[j].dst);
+#pragma unroll
+      for (int ri = 0; ri < EARLY_RW; ++ri) {
+        const int row = wave + ri * CH_NW;
+        if (row < R) *reinterpret_cast<float4*>(dst + row * LD2 + 4 * lane) = early_v[j][ri];
+      }
+    }
   }
   __syncthreads();
   // per (step, wave): the next linear step inside the same run of light steps where the
@@ -718,7 +749,10 @@ __global__ __launch_bounds__(CH_NT) void chain_kernel(ChainK k) {
     return s;
   };
 
-  int idx = 0;
+  int idx = early_n;          // the leading loads are already in LDS
+#ifdef TC_CHAIN_STAMPS
+  for (int j = 0; j < 2 * early_n; ++j) STEP_STAMP();
+#endif
 #pragma unroll 1
   while (idx < total) {
     const int kind = ufirst(S.sres[idx].kind);
