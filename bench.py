@@ -46,6 +46,8 @@ def parse():
     ap.add_argument('--unfused', action='store_true',
                     help='operator-by-operator launches instead of the fused row chains')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    ap.add_argument('--no-batched', action='store_true',
+                    help='skip the 4-frames-per-step side measurement')
     ap.add_argument('--train', action='store_true',
                     help='time one DDP training iteration of the fusion head (configs[2]) '
                          'instead of inference')
@@ -210,6 +212,38 @@ def roofline(head, inp, dev):
              others={n: {kk: v[kk] for kk in ('bound', 'achieved', 'peak', 'unit', 'frac', 'ms')}
                      for n, v in kern.items() if n != dom})
     return r
+
+
+def batched_side_run(head, dev, args, frames=4):
+    """Not the headline: the same path with `frames` frames per step (one hipGraph
+    replay), reported beside the B = 1 value because at B = 1 a workgroup of the
+    row chains is bound by its weight stream; larger row
+    tiles move the same kernels toward the MFMA bound."""
+    inp = make_inputs(head, dev, args.shapes, frames, seed=11)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            one_step(head, inp)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        one_step(head, inp)
+    for _ in range(10):
+        g.replay()
+    torch.cuda.synchronize()
+    n = max(20, args.steps // 4)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        g.replay()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    r = roofline(head, inp, dev)
+    return {'frames_per_step': frames, 'value': frames * n / dt, 'unit': 'frames/s',
+            'ms_per_step': dt / n * 1e3,
+            'roofline_frac': r['frac'], 'roofline_kernel': r['kernel'],
+            'self_attn_frac': r['others']['self_attn_kernel']['frac']}
 
 
 def roofline_chain_once(head, inp, dev):
@@ -397,6 +431,8 @@ def main():
     if rank == 0:
         if world == 1:
             line['roofline'] = roofline(head, inp, dev)
+            if args.batch == 1 and not args.no_batched:
+                line['batched'] = batched_side_run(head, dev, args, frames=4)
             if not args.no_cpu_baseline:
                 line['cpu_baseline'] = cpu_baseline(sd, inp, args.cpu_seconds)
         print(json.dumps(line))
