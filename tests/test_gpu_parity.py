@@ -114,6 +114,8 @@ def test_nchw_to_nhwc_roundtrip(T):
 
 @pytest.mark.parametrize('shapes,smooth,atol', [
     ('tiny', None, 3e-5), ('res101', SMOOTH, 1e-4),
+    # BASELINE.json configs[4]: VoVNet FPN levels (232x400 ... 29x50), 757 MB of maps
+    ('vovnet', SMOOTH, 1e-4),
     # iid-noise maps at stride 8: the fp32 rounding of the projected pixel
     # coordinate (~1e-4 px at |u| ~ 1600) times an O(1)/px feature gradient
     ('res101', None, 1e-3)])
