@@ -48,6 +48,9 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--no-batched', action='store_true',
                     help='skip the 4-frames-per-step side measurement')
+    ap.add_argument('--train-autograd', action='store_true',
+                    help='with --train: the per-operator autograd path instead of the two-call '
+                         'fused forward/backward of the trainable stack')
     ap.add_argument('--train', action='store_true',
                     help='time one DDP training iteration of the fusion head (configs[2]) '
                          'instead of inference')
@@ -304,7 +307,7 @@ def cpu_baseline(sd, inp, seconds):
 def train_bench(args, head, inp, dev, rank, world):
     """BASELINE.json configs[2]: batch-per-GPU 1 DDP training of the trainable
     (radar) part of the head.  A step = frozen decoder forward + radar stack
-    forward (autograd over HIP kernels) + Hungarian/focal/L1 loss (host PyTorch +
+    forward (tc_radar_train_fwd) + Hungarian/focal/L1 loss (host PyTorch +
     scipy, as the reference) + HIP backward + ONE all-reduce of the flat gradient
     bucket over RCCL + device-side clip + AdamW + weight re-pack."""
     from transcar_amd.trainer import FusionTrainer
@@ -325,7 +328,8 @@ def train_bench(args, head, inp, dev, rank, world):
     tr = FusionTrainer(thead)
 
     def step():
-        return tr.step_nhwc(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'], inp['pad_mult'], gts, lbs)
+        fn = tr.step_nhwc if args.train_autograd else tr.step_fused_nhwc
+        return fn(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'], inp['pad_mult'], gts, lbs)
 
     for _ in range(args.warmup):
         step()

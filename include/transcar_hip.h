@@ -346,6 +346,26 @@ int tc_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float 
                   float beta1, float beta2, float eps, float weight_decay, int step,
                   float grad_scale, float max_norm, const float* sq_norm, tc_stream_t stream);
 
+
+/* The trainable stack (radar encoders + three fusion layers + final_cls / final_reg,
+ * HEAD:531-729) as two calls: the forward keeps its activations on a caller-provided
+ * tape (tc_radar_train_tape_bytes), the backward walks it and ADDS the parameter
+ * gradients into `grads`, a tc_head_weights whose pointers are the gradient buffers
+ * of the corresponding parameters (only the radar / final_* / radar encoder entries
+ * are used; zero them first).  Inputs of the stack come from tc_head_forward's aux:
+ *   hs_last [B,Q,C] = inter_states[-1], ref_last [B,Q,3] = inter_references[-1],
+ *   last_box [B,Q,code].  `w` holds the UNPACKED nn.Linear weights.
+ *   d_all_cls / d_all_box: gradients of the loss w.r.t. the two outputs. */
+size_t tc_radar_train_tape_bytes(const tc_head_weights* w, int B, int T);
+int tc_radar_train_fwd(const tc_head_weights* w, const float* hs_last, const float* ref_last,
+                       const float* last_box, const float* radar_tokens, int B, int T, int pad_mult,
+                       float* all_cls_scores, float* all_bbox_preds, void* tape, size_t tape_bytes,
+                       tc_stream_t stream);
+int tc_radar_train_bwd(const tc_head_weights* w, const tc_head_weights* grads, const float* hs_last,
+                       const float* last_box, const float* radar_tokens, int B, int T, int pad_mult,
+                       const float* all_bbox_preds, const float* d_all_cls, const float* d_all_box,
+                       void* tape, size_t tape_bytes, tc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -324,3 +324,36 @@ def test_trainer_step_updates_flat_bucket_and_packed_weights(A, golden_dir):
     for _ in range(5):
         last = tr.step(feats, metas, [gt], [labels])
     assert float(sum(last.values())) < first
+
+
+def test_fused_training_path_gradients_match_reference(A, golden_dir):
+    """tc_radar_train_fwd / _bwd (the trainable stack as two C calls) against fixture G8
+    and against the per-operator autograd path on the same frame."""
+    from transcar_amd import ops
+    from transcar_amd.trainer import FusionTrainer
+    g8 = np.load(os.path.join(golden_dir, 'g8_train_grads.npz'))
+    h = train_head(golden_dir)
+    feats, metas, gt, labels = frame_inputs(golden_dir)
+    nhwc = [ops.to_nhwc(f) for f in feats]
+    l2i = ops.lidar2img_tensor(metas, dev())
+    img_hw = metas[0]['img_shape'][0][:2]
+    tokens, pad_mult = h.radar_tokens(metas, dev())
+    tr = FusionTrainer(h)
+    losses = tr.step_fused_nhwc(nhwc, l2i, img_hw, tokens, pad_mult, [gt], [labels], update=False)
+    for k, v in losses.items():
+        ref = float(g8['loss__' + k.replace('.', '_')])
+        assert abs(float(v) - ref) < 2e-3 * max(1.0, abs(ref)), (k, float(v), ref)
+    grads = {k: (p.grad.clone() if p.grad is not None else None) for k, p in h.named_parameters() if trainable(k)}
+    used = {n for n, _ in h.trainable_parameters()}
+    for k in grads:                       # unused tensors are not in the bucket
+        if k not in used:
+            grads[k] = None
+    assert check_grads_against_g8(grads, g8, 4e-3, 'fused') == 98
+    # same numbers as the autograd path
+    fused = tr.bucket.grads.clone()
+    tr.bucket.zero_grad()
+    outs = h.train()(feats, metas)
+    total = sum(v for k, v in h.loss([gt], [labels], outs).items() if 'loss' in k)
+    total.backward()
+    d = (tr.bucket.grads - fused).abs().max() / fused.abs().max()
+    assert float(d) < 1e-4, float(d)

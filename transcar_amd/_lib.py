@@ -158,6 +158,12 @@ SIGNATURES = {
     'tc_radar_attn_core_bwd': (_i, [_vp, _f, _vp, _vp, _i, _vp, _i, _vp, _i,
                                     _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp,
                                     _vp, _vp, _vp]),
+    'tc_radar_train_tape_bytes': (_sz, [_P(tc_head_weights), _i, _i]),
+    'tc_radar_train_fwd': (_i, [_P(tc_head_weights), _vp, _vp, _vp, _vp, _i, _i,
+                                _i, _vp, _vp, _vp, _sz, _vp]),
+    'tc_radar_train_bwd': (_i, [_P(tc_head_weights), _P(tc_head_weights), _vp,
+                                _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz,
+                                _vp]),
     'tc_sq_norm': (_i, [_vp, _sz, _vp, _vp]),
     'tc_adamw_step': (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _f,
                            _f, _vp, _vp]),

@@ -1,0 +1,321 @@
+// One training iteration of the trainable (radar) part of the head as two C calls:
+// tc_radar_train_fwd keeps every activation the backward needs on a caller-provided
+// tape, tc_radar_train_bwd walks it in reverse and ADDS the parameter gradients into a
+// tc_head_weights-shaped table of gradient pointers (the flat gradient bucket of
+// transcar_amd/trainer.py).  Same kernels as the operator-level entry points
+// (gemm.hip, rowops.hip, radar_attn.hip, train.hip); what goes away is the host side:
+// ~60 forward and ~100 backward autograd nodes, each a Python -> ctypes round trip.
+// Reference: HEAD:531-729 (forward), tools/train.py:245-252 (what is trainable).
+#include <math.h>
+
+#include "kernels.hpp"
+
+namespace tc {
+
+#define TS_TRY(expr)          \
+  do {                        \
+    int _rc = (expr);         \
+    if (_rc != 0) return _rc; \
+  } while (0)
+#define TS_HIP(expr)                                          \
+  do {                                                        \
+    hipError_t _e = (expr);                                   \
+    if (_e != hipSuccess) {                                   \
+      tc::set_error("%s: %s", #expr, hipGetErrorString(_e)); \
+      return (int)_e;                                         \
+    }                                                         \
+  } while (0)
+
+namespace {
+
+struct LayerTape {
+  float *qp, *kv, *ao, *x1, *x2, *h, *ff, *x3, *c0, *c1, *c2, *c3, *t0, *t1, *treg;
+  int* hits;
+};
+struct Tape {
+  float *xyz4, *w0p, *u0, *u1, *u2, *pos, *f0, *f1, *f2, *mem, *cxy, *addref;
+  LayerTape L[TC_MAX_RADAR_LAYERS];
+  // backward scratch
+  float *dbox, *dA, *dB, *dC, *dh, *dqp, *dkv, *dmem, *dqin, *dt64, *dt128, *dw0p;
+};
+
+size_t tape_layout(const tc_head_weights* w, int B, int T, void* base, size_t cap, Tape* out) {
+  const size_t rows = (size_t)B * w->num_query, rt = (size_t)B * T;
+  const size_t C = w->embed_dims, F = w->ffn_dims, code = w->code_size;
+  Arena a(base, cap);
+  Tape t;
+  t.xyz4 = a.take<float>(rt * 4); t.w0p = a.take<float>(C * 4);
+  t.u0 = a.take<float>(rt * C); t.u1 = a.take<float>(rt * C); t.u2 = a.take<float>(rt * C);
+  t.pos = a.take<float>(rt * C);
+  t.f0 = a.take<float>(rt * 64); t.f1 = a.take<float>(rt * 128); t.f2 = a.take<float>(rt * C);
+  t.mem = a.take<float>(rt * C);
+  t.cxy = a.take<float>(rows * 2); t.addref = a.take<float>(rows * 3);
+  for (int r = 0; r < TC_MAX_RADAR_LAYERS; ++r) {
+    LayerTape& l = t.L[r];
+    l.qp = a.take<float>(rows * C); l.kv = a.take<float>(rt * 2 * C); l.ao = a.take<float>(rows * C);
+    l.x1 = a.take<float>(rows * C); l.x2 = a.take<float>(rows * C); l.h = a.take<float>(rows * F);
+    l.ff = a.take<float>(rows * C); l.x3 = a.take<float>(rows * C);
+    l.c0 = a.take<float>(rows * C); l.c1 = a.take<float>(rows * C); l.c2 = a.take<float>(rows * C);
+    l.c3 = a.take<float>(rows * C);
+    l.t0 = a.take<float>(rows * C); l.t1 = a.take<float>(rows * C); l.treg = a.take<float>(rows * code);
+    l.hits = a.take<int>(rows);
+  }
+  t.dbox = a.take<float>(rows * code);
+  t.dA = a.take<float>(rows * C); t.dB = a.take<float>(rows * C); t.dC = a.take<float>(rows * C);
+  t.dh = a.take<float>(rows * F); t.dqp = a.take<float>(rows * C);
+  t.dkv = a.take<float>(rt * 2 * C); t.dmem = a.take<float>(rt * C); t.dqin = a.take<float>(rows * C);
+  t.dt64 = a.take<float>(rt * 64); t.dt128 = a.take<float>(rt * 128); t.dw0p = a.take<float>(C * 4);
+  if (out) *out = t;
+  return a.off;
+}
+
+// dst[r*ld_dst + c] (=|+=) src[r*ld_src + c] for c < cols: pads / unpads the 3-column
+// operands of radar_position_encoder.0 to the 4 columns the MFMA tiles want
+__global__ void copy_cols_kernel(const float* src, int ld_src, float* dst, int ld_dst, int rows,
+                                 int cols, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  const int r = i / cols, c = i - r * cols;
+  const float v = src[(size_t)r * ld_src + c];
+  float* d = dst + (size_t)r * ld_dst + c;
+  if (accumulate) *d += v; else *d = v;
+}
+int copy_cols(const float* src, int ld_src, float* dst, int ld_dst, int rows, int cols,
+              int accumulate, hipStream_t s) {
+  const int n = rows * cols;
+  hipLaunchKernelGGL(copy_cols_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, ld_src, dst, ld_dst,
+                     rows, cols, accumulate);
+  return check_launch("copy_cols");
+}
+
+// dst[i] (+=) src[i]
+__global__ void add_kernel(const float* src, float* dst, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] += src[i];
+}
+int add_into(const float* src, float* dst, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, n);
+  return check_launch("add_into");
+}
+
+int lin(const float* x, const tc_linear& w, int M, int K, int N, int act, float* y, hipStream_t s,
+        const float* res = nullptr, const int* gate = nullptr) {
+  GemmArgs g;
+  g.X = x; g.ldx = K; g.W = w.w; g.ldw = K; g.bias = w.b; g.R = res; g.ldr = N; g.rowgate = gate;
+  g.Y = y; g.ldy = N; g.M = M; g.K = K; g.N = N; g.act = act;
+  return launch_gemm(g, s);
+}
+int lnorm(const float* a, const float* b, const tc_lnorm& n, float* y, int M, int relu, hipStream_t s) {
+  LnArgs l;
+  l.a = a; l.b = b; l.gamma = n.g; l.beta = n.b; l.y = y; l.M = M; l.relu = relu;
+  return launch_ln256(l, s);
+}
+// backward of y = act(x W^T + b): dW += dY~^T x, db += colsum dY~, dx (=|+=) dY~ W
+//   y_relu: this layer's saved ReLU output (mask on dY) or nullptr; x_relu: mask on dx
+int lin_bwd(const float* x, const float* dy, const float* y_relu, const int* gate, const tc_linear& w,
+            const tc_linear& g, const float* x_relu, float* dx, int accumulate, int M, int K, int N,
+            hipStream_t s) {
+  TS_TRY(launch_linear_bwd_weight(x, dy, y_relu, gate, const_cast<float*>(g.w), const_cast<float*>(g.b),
+                                  M, K, N, 1.0f, s));
+  if (dx != nullptr)
+    TS_TRY(launch_linear_bwd_data(dy, y_relu, gate, w.w, x_relu, dx, M, K, N, 1.0f, accumulate, s));
+  return 0;
+}
+int ln_bwd(const float* a, const float* b, const tc_lnorm& n, const tc_lnorm& g, const float* dy,
+           const float* relu_out, float* dz, int M, hipStream_t s) {
+  return launch_ln256_bwd(a, b, n.g, dy, relu_out, dz, const_cast<float*>(g.g), const_cast<float*>(g.b),
+                          M, s);
+}
+
+RadarAttnArgs core_args(const tc_head_weights* w, int r, const Tape& t, const float* box_prev,
+                        const float* tokens, int B, int T, int pad_mult) {
+  const int C = w->embed_dims, code = w->code_size;
+  RadarAttnArgs ra;
+  ra.qproj = t.L[r].qp; ra.ldq = C; ra.kv = t.L[r].kv; ra.ldkv = 2 * C;
+  ra.centre_xy = r == 0 ? t.cxy : box_prev; ra.ld_c = r == 0 ? 2 : code;
+  ra.box = box_prev; ra.code = code; ra.radar_xy = tokens; ra.ld_xy = w->radar_in_dims;
+  ra.B = B; ra.Q = w->num_query; ra.T = T; ra.C = C; ra.H = w->num_heads; ra.pad_mult = pad_mult;
+  ra.rmin = w->radar[r].radius_min; ra.rmax = w->radar[r].radius_max;
+  ra.attn_out = t.L[r].ao; ra.hit_counts = t.L[r].hits;
+  ra.qscale = 1.0f / sqrtf((float)(C / w->num_heads));
+  return ra;
+}
+
+int check(const tc_head_weights* w, int B, int T) {
+  TC_REQUIRE(w != nullptr && w->abi_version == TC_ABI_VERSION, "radar_train: bad weights struct");
+  TC_REQUIRE(w->embed_dims == 256 && w->num_heads == 8 && w->num_radar_layers == TC_MAX_RADAR_LAYERS,
+             "radar_train: embed_dims=%d heads=%d radar layers=%d", w->embed_dims, w->num_heads,
+             w->num_radar_layers);
+  TC_REQUIRE(B >= 1 && T >= 1 && (w->radar_in_dims & 3) == 0, "radar_train: B=%d T=%d", B, T);
+  return 0;
+}
+
+}  // namespace
+}  // namespace tc
+
+using namespace tc;
+
+extern "C" {
+
+size_t tc_radar_train_tape_bytes(const tc_head_weights* w, int B, int T) {
+  if (check(w, B, T) != 0) return 0;
+  return tape_layout(w, B, T, nullptr, ~size_t(0), nullptr);
+}
+
+int tc_radar_train_fwd(const tc_head_weights* w, const float* hs_last, const float* ref_last,
+                       const float* last_box, const float* radar_tokens, int B, int T, int pad_mult,
+                       float* all_cls_scores, float* all_bbox_preds, void* tape, size_t tape_bytes,
+                       tc_stream_t stream) {
+  TS_TRY(check(w, B, T));
+  Tape t;
+  TC_REQUIRE(tape_layout(w, B, T, tape, tape_bytes, &t) <= tape_bytes, "radar_train_fwd: tape too small");
+  hipStream_t s = as_stream(stream);
+  const int Q = w->num_query, C = w->embed_dims, F = w->ffn_dims, code = w->code_size;
+  const int ncls = w->num_classes, RI = w->radar_in_dims;
+  const int rows = B * Q, rt = B * T;
+  // radar encoders, HEAD:531-536 (Linear(3,C) as K = 4 with a zero column)
+  const tc_pos_encoder& pe = w->radar_position_encoder;
+  TS_HIP(hipMemsetAsync(t.xyz4, 0, (size_t)rt * 4 * 4, s));
+  TS_HIP(hipMemsetAsync(t.w0p, 0, (size_t)C * 4 * 4, s));
+  TS_TRY(copy_cols(radar_tokens, RI, t.xyz4, 4, rt, 3, 0, s));
+  TS_TRY(copy_cols(pe.l0.w, 3, t.w0p, 4, C, 3, 0, s));
+  TS_TRY(lin(t.xyz4, tc_linear{t.w0p, pe.l0.b}, rt, 4, C, 0, t.u0, s));
+  TS_TRY(lnorm(t.u0, nullptr, pe.n1, t.u1, rt, 1, s));
+  TS_TRY(lin(t.u1, pe.l3, rt, C, C, 0, t.u2, s));
+  TS_TRY(lnorm(t.u2, nullptr, pe.n4, t.pos, rt, 1, s));
+  TS_TRY(lin(radar_tokens, w->radar_feat0, rt, RI, 64, 1, t.f0, s));
+  TS_TRY(lin(t.f0, w->radar_feat2, rt, 64, 128, 1, t.f1, s));
+  TS_TRY(lin(t.f1, w->radar_feat4, rt, 128, C, 1, t.f2, s));
+  {
+    LnArgs l;      // mem = pos + f2 (plain sum)
+    l.a = t.pos; l.b = t.f2; l.y = t.mem; l.M = rt;
+    TS_TRY(launch_ln256(l, s));
+  }
+  TS_TRY(launch_radar_ref_l1(ref_last, w->pc_range, t.cxy, t.addref, rows, s));
+  const float* qin = hs_last;
+  for (int r = 0; r < TC_MAX_RADAR_LAYERS; ++r) {
+    const tc_radar_layer& rl = w->radar[r];
+    LayerTape& l = t.L[r];
+    float* cls_out = all_cls_scores + (size_t)r * rows * ncls;
+    float* box_out = all_bbox_preds + (size_t)r * rows * code;
+    const float* box_prev = r == 0 ? last_box : all_bbox_preds + (size_t)(r - 1) * rows * code;
+    const tc_linear wq{rl.attn.in_proj.w, rl.attn.in_proj.b};
+    const tc_linear wkv{rl.attn.in_proj.w + (size_t)C * C, rl.attn.in_proj.b + C};
+    TS_TRY(lin(qin, wq, rows, C, C, 0, l.qp, s));
+    TS_TRY(lin(t.mem, wkv, rt, C, 2 * C, 0, l.kv, s));
+    TS_TRY(launch_radar_attn(core_args(w, r, t, box_prev, radar_tokens, B, T, pad_mult), s));
+    TS_TRY(lin(l.ao, rl.attn.out_proj, rows, C, C, 0, l.x1, s, qin, l.hits));
+    TS_TRY(lnorm(l.x1, nullptr, rl.norm2, l.x2, rows, 0, s));
+    TS_TRY(lin(l.x2, rl.linear1, rows, C, F, 1, l.h, s));
+    TS_TRY(lin(l.h, rl.linear2, rows, F, C, 0, l.ff, s));
+    TS_TRY(lnorm(l.x2, l.ff, rl.norm3, l.x3, rows, 0, s));
+    TS_TRY(lin(l.x3, rl.final_cls.l0, rows, C, C, 0, l.c0, s));
+    TS_TRY(lnorm(l.c0, nullptr, rl.final_cls.n1, l.c1, rows, 1, s));
+    TS_TRY(lin(l.c1, rl.final_cls.l3, rows, C, C, 0, l.c2, s));
+    TS_TRY(lnorm(l.c2, nullptr, rl.final_cls.n4, l.c3, rows, 1, s));
+    TS_TRY(lin(l.c3, rl.final_cls.l6, rows, C, ncls, 0, cls_out, s));
+    TS_TRY(lin(l.x3, rl.final_reg.l0, rows, C, C, 1, l.t0, s));
+    TS_TRY(lin(l.t0, rl.final_reg.l2, rows, C, C, 1, l.t1, s));
+    TS_TRY(lin(l.t1, rl.final_reg.l4, rows, C, code, 0, l.treg, s));
+    if (r == 0)
+      TS_TRY(launch_box_add_ref(l.treg, code, t.addref, 3, t.addref + 2, 3, box_out, nullptr, rows, s));
+    else
+      TS_TRY(launch_box_add_ref(l.treg, code, box_prev, code, box_prev + 4, code, box_out, nullptr, rows, s));
+    qin = l.x3;
+  }
+  return 0;
+}
+
+int tc_radar_train_bwd(const tc_head_weights* w, const tc_head_weights* grads, const float* hs_last,
+                       const float* last_box, const float* radar_tokens, int B, int T, int pad_mult,
+                       const float* all_bbox_preds, const float* d_all_cls, const float* d_all_box,
+                       void* tape, size_t tape_bytes, tc_stream_t stream) {
+  TS_TRY(check(w, B, T));
+  TC_REQUIRE(grads != nullptr, "radar_train_bwd: grads is NULL");
+  Tape t;
+  TC_REQUIRE(tape_layout(w, B, T, tape, tape_bytes, &t) <= tape_bytes, "radar_train_bwd: tape too small");
+  hipStream_t s = as_stream(stream);
+  const int Q = w->num_query, C = w->embed_dims, F = w->ffn_dims, code = w->code_size;
+  const int ncls = w->num_classes, RI = w->radar_in_dims;
+  const int rows = B * Q, rt = B * T;
+  TS_HIP(hipMemsetAsync(t.dmem, 0, (size_t)rt * C * 4, s));
+  bool have_dqin = false;                       // gradient w.r.t. this layer's output from the layer above
+  bool have_dbox_next = false;
+  for (int r = TC_MAX_RADAR_LAYERS - 1; r >= 0; --r) {
+    const tc_radar_layer& rl = w->radar[r];
+    const tc_radar_layer& gl = grads->radar[r];
+    LayerTape& l = t.L[r];
+    const float* qin = r == 0 ? hs_last : t.L[r - 1].x3;
+    const float* box_prev = r == 0 ? last_box : all_bbox_preds + (size_t)(r - 1) * rows * code;
+    const float* dcls = d_all_cls + (size_t)r * rows * ncls;
+    // box_r = treg_r (+ prev box {0,1,4}); d box_r = given + what layer r+1 sent down (in t.dbox)
+    if (!have_dbox_next) TS_HIP(hipMemsetAsync(t.dbox, 0, (size_t)rows * code * 4, s));
+    TS_TRY(add_into(d_all_box + (size_t)r * rows * code, t.dbox, (size_t)rows * code, s));
+    // reg branch (Linear ReLU Linear ReLU Linear), dx3 -> dA (=)
+    TS_TRY(lin_bwd(l.t1, t.dbox, nullptr, nullptr, rl.final_reg.l4, gl.final_reg.l4, l.t1, t.dB, 0, rows, C, code, s));
+    TS_TRY(lin_bwd(l.t0, t.dB, nullptr, nullptr, rl.final_reg.l2, gl.final_reg.l2, l.t0, t.dC, 0, rows, C, C, s));
+    TS_TRY(lin_bwd(l.x3, t.dC, nullptr, nullptr, rl.final_reg.l0, gl.final_reg.l0, nullptr, t.dA, 0, rows, C, C, s));
+    // the reference of layer r is box_{r-1}: its {0,1,4} columns receive d box_r (HEAD:615-617, 661-662)
+    if (r > 0) {
+      // t.dbox becomes the incoming gradient of box_{r-1}: keep only columns 0,1,4
+      TS_HIP(hipMemsetAsync(t.dB, 0, (size_t)rows * code * 4, s));
+      TS_TRY(launch_box_ref_bwd(t.dbox, code, t.dB, rows, s));
+      TS_HIP(hipMemcpyAsync(t.dbox, t.dB, (size_t)rows * code * 4, hipMemcpyDeviceToDevice, s));
+      have_dbox_next = true;
+    }
+    // cls branch (Linear LN ReLU Linear LN ReLU Linear), dx3 +=
+    TS_TRY(lin_bwd(l.c3, dcls, nullptr, nullptr, rl.final_cls.l6, gl.final_cls.l6, nullptr, t.dB, 0, rows, C, ncls, s));
+    TS_TRY(ln_bwd(l.c2, nullptr, rl.final_cls.n4, gl.final_cls.n4, t.dB, l.c3, t.dC, rows, s));
+    TS_TRY(lin_bwd(l.c1, t.dC, nullptr, nullptr, rl.final_cls.l3, gl.final_cls.l3, nullptr, t.dB, 0, rows, C, C, s));
+    TS_TRY(ln_bwd(l.c0, nullptr, rl.final_cls.n1, gl.final_cls.n1, t.dB, l.c1, t.dC, rows, s));
+    TS_TRY(lin_bwd(l.x3, t.dC, nullptr, nullptr, rl.final_cls.l0, gl.final_cls.l0, nullptr, t.dA, 1, rows, C, C, s));
+    if (have_dqin) TS_TRY(add_into(t.dqin, t.dA, (size_t)rows * C, s));
+    // x3 = LN3(x2 + ff): dz -> dB (grad of x2 and of ff)
+    TS_TRY(ln_bwd(l.x2, l.ff, rl.norm3, gl.norm3, t.dA, nullptr, t.dB, rows, s));
+    TS_TRY(lin_bwd(l.h, t.dB, nullptr, nullptr, rl.linear2, gl.linear2, l.h, t.dh, 0, rows, F, C, s));
+    TS_TRY(lin_bwd(l.x2, t.dh, nullptr, nullptr, rl.linear1, gl.linear1, nullptr, t.dB, 1, rows, C, F, s));   // dx2 = dz + dh W1
+    // x2 = LN2(x1): dx1 -> dC
+    TS_TRY(ln_bwd(l.x1, nullptr, rl.norm2, gl.norm2, t.dB, nullptr, t.dC, rows, s));
+    // x1 = qin + gate * out_proj(ao): d ao -> dA, d qin = dx1
+    TS_TRY(lin_bwd(l.ao, t.dC, nullptr, l.hits, rl.attn.out_proj, gl.attn.out_proj, nullptr, t.dA, 0, rows, C, C, s));
+    TS_HIP(hipMemsetAsync(t.dkv, 0, (size_t)rt * 2 * C * 4, s));
+    {
+      RadarAttnArgs ra = core_args(w, r, t, box_prev, radar_tokens, B, T, pad_mult);
+      const float qs = ra.qscale;
+      ra.qscale = 1.0f;
+      TS_TRY(launch_radar_attn_bwd(ra, qs, t.dA, t.dqp, t.dkv, s));
+    }
+    const tc_linear wq{rl.attn.in_proj.w, rl.attn.in_proj.b};
+    const tc_linear gq{gl.attn.in_proj.w, gl.attn.in_proj.b};
+    const tc_linear wkv{rl.attn.in_proj.w + (size_t)C * C, rl.attn.in_proj.b + C};
+    const tc_linear gkv{gl.attn.in_proj.w + (size_t)C * C, gl.attn.in_proj.b + C};
+    // d qin = dx1 + dqp Wq  (into dqin for the layer below; nothing below layer 0: the decoder is frozen)
+    if (r > 0) {
+      TS_HIP(hipMemcpyAsync(t.dqin, t.dC, (size_t)rows * C * 4, hipMemcpyDeviceToDevice, s));
+      TS_TRY(lin_bwd(qin, t.dqp, nullptr, nullptr, wq, gq, nullptr, t.dqin, 1, rows, C, C, s));
+      have_dqin = true;
+    } else {
+      TS_TRY(lin_bwd(qin, t.dqp, nullptr, nullptr, wq, gq, nullptr, nullptr, 0, rows, C, C, s));
+    }
+    TS_TRY(lin_bwd(t.mem, t.dkv, nullptr, nullptr, wkv, gkv, nullptr, t.dmem, 1, rt, C, 2 * C, s));
+  }
+  // encoders: mem = relu(LN4(u2)) + relu(feat4(f1)); both summands see dmem
+  const tc_pos_encoder& pe = w->radar_position_encoder;
+  const tc_pos_encoder& gpe = grads->radar_position_encoder;
+  TS_TRY(lin_bwd(t.f1, t.dmem, t.f2, nullptr, w->radar_feat4, grads->radar_feat4, t.f1, t.dt128, 0, rt, 128, C, s));
+  TS_TRY(lin_bwd(t.f0, t.dt128, nullptr, nullptr, w->radar_feat2, grads->radar_feat2, t.f0, t.dt64, 0, rt, 64, 128, s));
+  TS_TRY(lin_bwd(radar_tokens, t.dt64, nullptr, nullptr, w->radar_feat0, grads->radar_feat0, nullptr, nullptr, 0, rt, RI, 64, s));
+  // (rows of the token gradients reuse dqp/dkv-sized scratch: rt <= tape sizes by construction)
+  float* du = t.dkv;                 // [rt, C] scratch (dkv is [rt, 2C])
+  float* du2 = t.dkv + (size_t)rt * C;
+  TS_TRY(ln_bwd(t.u2, nullptr, pe.n4, gpe.n4, t.dmem, t.pos, du, rt, s));
+  TS_TRY(lin_bwd(t.u1, du, nullptr, nullptr, pe.l3, gpe.l3, nullptr, du2, 0, rt, C, C, s));
+  TS_TRY(ln_bwd(t.u0, nullptr, pe.n1, gpe.n1, du2, t.u1, du, rt, s));
+  TS_HIP(hipMemsetAsync(t.dw0p, 0, (size_t)C * 4 * 4, s));
+  TS_TRY(launch_linear_bwd_weight(t.xyz4, du, nullptr, nullptr, t.dw0p, const_cast<float*>(gpe.l0.b), rt, 4, C,
+                                  1.0f, s));
+  TS_TRY(copy_cols(t.dw0p, 4, const_cast<float*>(gpe.l0.w), 3, C, 3, 1, s));
+  return 0;
+}
+
+}  // extern "C"

@@ -73,6 +73,37 @@ def cosine_lr(base_lr, cur_iter, cur_epoch, max_epochs, warmup_iters=4000, warmu
     return regular
 
 
+def _g(t):
+    return None if t is None or t.grad is None else C.c_void_p(t.grad.data_ptr())
+
+
+def grad_table(head):
+    """tc_head_weights whose pointers are the .grad buffers of the trainable stack's
+    parameters (the table tc_radar_train_bwd adds into)."""
+    def lin(m):
+        return L.tc_linear(_g(m.weight), _g(m.bias))
+
+    def ln(m):
+        return L.tc_lnorm(_g(m.weight), _g(m.bias))
+
+    g = L.tc_head_weights()
+    g.abi_version = L.TC_ABI_VERSION
+    rpe, rfe = head.radar_position_encoder, head.radar_feat_encoder
+    g.radar_position_encoder = L.tc_pos_encoder(lin(rpe[0]), ln(rpe[1]), lin(rpe[3]), ln(rpe[4]))
+    g.radar_feat0, g.radar_feat2, g.radar_feat4 = lin(rfe[0]), lin(rfe[2]), lin(rfe[4])
+    for r, (sfx, asfx) in enumerate((('', ''), ('_2', '2'), ('_3', '3'))):
+        rl = g.radar[r]
+        attn = getattr(head, 'rf_multihead_attn' + asfx)
+        rl.attn = L.tc_mha(L.tc_linear(_g(attn.in_proj_weight), _g(attn.in_proj_bias)),
+                           lin(attn.out_proj))
+        rl.norm2, rl.norm3 = ln(getattr(head, 'rf_norm2' + sfx)), ln(getattr(head, 'rf_norm3' + sfx))
+        rl.linear1, rl.linear2 = lin(getattr(head, 'rf_linear1' + sfx)), lin(getattr(head, 'rf_linear2' + sfx))
+        fc, fr = getattr(head, 'final_cls' + asfx), getattr(head, 'final_reg' + asfx)
+        rl.final_cls = L.tc_cls_branch(lin(fc[0]), ln(fc[1]), lin(fc[3]), ln(fc[4]), lin(fc[6]))
+        rl.final_reg = L.tc_reg_branch(lin(fr[0]), lin(fr[2]), lin(fr[4]))
+    return g
+
+
 class FusionTrainer:
     """head: transcar_amd.Detr3DHead on the GPU, built with ``train_cfg``."""
 
@@ -97,9 +128,63 @@ class FusionTrainer:
         total = sum(v for k, v in losses.items() if 'loss' in k)
         self.bucket.zero_grad()
         total.backward()
+        self._optimizer_step(lr)
+        return total.detach()
+
+    # ------------------------------------------------------------------
+    # fast path: the trainable stack as two C calls (tc_radar_train_fwd / _bwd) instead of
+    # ~160 autograd nodes; torch autograd only differentiates the loss itself
+    # ------------------------------------------------------------------
+    def step_fused_nhwc(self, feats_nhwc, lidar2img, img_hw, tokens, pad_mult, gt_bboxes_list,
+                        gt_labels_list, lr=None, update=True):
+        """update=False stops after the backward: the gradients sit in the bucket."""
+        head, lib = self.head, L.lib()
+        head.train()
+        with torch.no_grad():
+            base = head.forward_nhwc(feats_nhwc, lidar2img, img_hw, tokens, pad_mult, aux=True,
+                                     _allow_train=True)
+        aux = base['aux']
+        w = head.head_weights()
+        B, T = lidar2img.shape[0], tokens.shape[1]
+        hs_last = aux['inter_states'][-1].contiguous()
+        ref_last = aux['inter_references'][-1].contiguous()
+        last_box = aux['last_box']
+        key = (B, T)
+        if getattr(self, '_tape_key', None) != key:
+            nbytes = lib.tc_radar_train_tape_bytes(C.byref(w), B, T)
+            if nbytes == 0:
+                raise L.TransCARHipError(lib.tc_last_error().decode())
+            self._tape = torch.empty(nbytes, dtype=torch.uint8, device=tokens.device)
+            self._tape_key = key
+        tape = self._tape
+        Q = head.num_query
+        all_cls = torch.empty((3, B, Q, head.cls_out_channels), dtype=torch.float32, device=tokens.device)
+        all_box = torch.empty((3, B, Q, head.code_size), dtype=torch.float32, device=tokens.device)
+        L.check(lib.tc_radar_train_fwd(
+            C.byref(w), hs_last.data_ptr(), ref_last.data_ptr(), last_box.data_ptr(), tokens.data_ptr(),
+            B, T, int(pad_mult), all_cls.data_ptr(), all_box.data_ptr(), tape.data_ptr(), tape.numel(),
+            self._stream()), 'tc_radar_train_fwd')
+        cls_leaf = all_cls.requires_grad_(True)
+        box_leaf = all_box.requires_grad_(True)
+        outs = {'all_cls_scores': cls_leaf, 'all_bbox_preds': box_leaf,
+                'enc_cls_scores': None, 'enc_bbox_preds': None}
+        losses = head.loss(gt_bboxes_list, gt_labels_list, outs)
+        total = sum(v for k, v in losses.items() if 'loss' in k)
+        total.backward()                                   # d loss / d outputs only
+        self.bucket.zero_grad()
+        g = grad_table(head)
+        L.check(lib.tc_radar_train_bwd(
+            C.byref(w), C.byref(g), hs_last.data_ptr(), last_box.data_ptr(), tokens.data_ptr(), B, T,
+            int(pad_mult), all_box.data_ptr(), cls_leaf.grad.contiguous().data_ptr(),
+            box_leaf.grad.contiguous().data_ptr(), tape.data_ptr(), tape.numel(), self._stream()),
+            'tc_radar_train_bwd')
+        if update:
+            self._optimizer_step(lr)
+        return {k: v.detach() for k, v in losses.items()}
+
+    def _optimizer_step(self, lr=None):
         world = self.bucket.all_reduce()
-        b = self.bucket
-        lib = L.lib()
+        b, lib = self.bucket, L.lib()
         self.iter += 1
         self.sq.zero_()
         L.check(lib.tc_sq_norm(b.grads.data_ptr(), b.numel, self.sq.data_ptr(), self._stream()),
@@ -110,7 +195,6 @@ class FusionTrainer:
             self.weight_decay, self.iter, 1.0 / world, float(self.max_norm or 0.0),
             self.sq.data_ptr(), self._stream()), 'tc_adamw_step')
         self.head.repack_weights()
-        return total.detach()
 
     def step(self, mlvl_feats, img_metas, gt_bboxes_list, gt_labels_list, lr=None):
         """One iteration on this rank's frame(s); returns the loss dict (detached)."""
