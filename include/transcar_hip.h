@@ -366,6 +366,31 @@ int tc_radar_train_bwd(const tc_head_weights* w, const tc_head_weights* grads, c
                        const float* all_bbox_preds, const float* d_all_cls, const float* d_all_box,
                        void* tape, size_t tape_bytes, tc_stream_t stream);
 
+
+/* ---- targets and losses on the device (HEAD:742-917; ASSIGN:106-125; COST:15-26) ----
+ * tc_normalize_bbox: UTIL:4-24 on n ground-truth boxes [n,9] -> [n,10].
+ * tc_match_cost: Hungarian cost for every decoder output in one launch,
+ *   cost[l,b,q,g] = cls_weight * FocalLossCost(cls[l,b,q], label[b,g]) + reg_weight * |box[l,b,q,:10] - gt_norm[b,g]|_1
+ *   (0 for g >= gt_counts[b]); gt_norm [B,Gmax,10], gt_labels [B,Gmax], gt_counts [B] (device).
+ *   The assignment itself stays scipy's linear_sum_assignment on the host, as in the reference.
+ * tc_detr_loss_fwd_bwd: with assigned[l,b,q] = matched gt index or -1: sigmoid focal loss
+ *   (mmdet FocalLoss, background = no target) and L1 loss of the matched box codes
+ *   (code_weights [code] on the device; rows with a non-finite target are skipped), each
+ *   divided by avg_factors[2l] (classification) / avg_factors[2l+1] (boxes), device memory:
+ *   max(mean over ranks of the number of positives, 1) (HEAD:889-902):
+ *   losses[l] = {loss_cls, loss_bbox} (+=: zero first) and the gradients d_all_cls, d_all_box (=). */
+int tc_normalize_bbox(const float* gt_boxes, int n, float* out, tc_stream_t stream);
+int tc_match_cost(const float* all_cls, const float* all_box, int num_outputs, int B, int Q,
+                  int num_classes, int code_size, const float* gt_norm, const int* gt_labels,
+                  const int* gt_counts, int Gmax, float cls_weight, float reg_weight, float alpha,
+                  float gamma, float eps, float* cost, tc_stream_t stream);
+int tc_detr_loss_fwd_bwd(const float* all_cls, const float* all_box, int num_outputs, int B, int Q,
+                         int num_classes, int code_size, const float* gt_norm, const int* gt_labels,
+                         int Gmax, const int* assigned, const float* avg_factors,
+                         const float* code_weights, float alpha, float gamma, float cls_loss_weight,
+                         float bbox_loss_weight, float* losses, float* d_all_cls, float* d_all_box,
+                         tc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

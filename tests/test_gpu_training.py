@@ -357,3 +357,54 @@ def test_fused_training_path_gradients_match_reference(A, golden_dir):
     total.backward()
     d = (tr.bucket.grads - fused).abs().max() / fused.abs().max()
     assert float(d) < 1e-4, float(d)
+
+
+@pytest.mark.parametrize('n_gt', [24, 0])
+def test_device_loss_matches_reference_loss_and_autograd(A, golden_dir, n_gt):
+    """tc_match_cost / tc_detr_loss_fwd_bwd against the reference's loss values (G7), its
+    Hungarian assignment, and torch autograd through Detr3DHead.loss for the gradients."""
+    from transcar_amd.device_loss import detr_loss_device
+    g5 = np.load(os.path.join(golden_dir, 'g5_head_tiny.npz'))
+    g7 = np.load(os.path.join(golden_dir, 'g7_loss.npz' if n_gt else 'g7_loss_empty.npz'))
+    h = train_head(golden_dir)
+    boxes, labels = synth.make_gt(seed=7, n=24)
+    gt = torch.from_numpy(boxes[:n_gt]).clone()
+    gt[:, 2] += gt[:, 5] * 0.5
+    gt, lab = gt.to(dev()), torch.from_numpy(labels[:n_gt]).to(dev())
+    cls = torch.from_numpy(g5['all_cls_scores']).to(dev())
+    box = torch.from_numpy(g5['all_bbox_preds']).to(dev())
+    losses, d_cls, d_box, assigned = detr_loss_device(h, cls, box, [gt], [lab])
+    for k, v in losses.items():
+        ref = float(g7[k.replace('.', '_')])
+        assert abs(float(v) - ref) <= 2e-5 * max(1.0, abs(ref)), (k, float(v), ref)
+    if n_gt:
+        want = g7['gt_inds'] - 1                    # the reference stores gt index + 1, 0 = unmatched
+        assert np.array_equal(assigned[:, 0], want)
+    cl, bl = cls.clone().requires_grad_(True), box.clone().requires_grad_(True)
+    ref_losses = h.loss([gt], [lab], {'all_cls_scores': cl, 'all_bbox_preds': bl})
+    sum(ref_losses.values()).backward()
+    assert rel(d_cls, cl.grad) < 2e-5
+    if n_gt:
+        assert rel(d_box, bl.grad) < 2e-5
+    else:
+        assert float(d_box.abs().max()) == 0.0
+
+
+def test_fused_step_with_device_loss_equals_torch_loss(A, golden_dir):
+    from transcar_amd import ops
+    from transcar_amd.trainer import FusionTrainer
+    h = train_head(golden_dir)
+    feats, metas, gt, labels = frame_inputs(golden_dir)
+    nhwc = [ops.to_nhwc(f) for f in feats]
+    l2i = ops.lidar2img_tensor(metas, dev())
+    img_hw = metas[0]['img_shape'][0][:2]
+    tokens, pad_mult = h.radar_tokens(metas, dev())
+    tr = FusionTrainer(h)
+    tr.device_loss = False
+    l_torch = tr.step_fused_nhwc(nhwc, l2i, img_hw, tokens, pad_mult, [gt], [labels], update=False)
+    g_torch = tr.bucket.grads.clone()
+    tr.device_loss = True
+    l_dev = tr.step_fused_nhwc(nhwc, l2i, img_hw, tokens, pad_mult, [gt], [labels], update=False)
+    for k in l_torch:
+        assert abs(float(l_torch[k]) - float(l_dev[k])) < 1e-5 * max(1.0, abs(float(l_torch[k]))), k
+    assert float((tr.bucket.grads - g_torch).abs().max() / g_torch.abs().max()) < 1e-4

@@ -164,6 +164,11 @@ SIGNATURES = {
     'tc_radar_train_bwd': (_i, [_P(tc_head_weights), _P(tc_head_weights), _vp,
                                 _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz,
                                 _vp]),
+    'tc_normalize_bbox': (_i, [_vp, _i, _vp, _vp]),
+    'tc_match_cost': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _f, _f,
+                           _f, _f, _f, _vp, _vp]),
+    'tc_detr_loss_fwd_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp,
+                                  _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp]),
     'tc_sq_norm': (_i, [_vp, _sz, _vp, _vp]),
     'tc_adamw_step': (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _f,
                            _f, _vp, _vp]),

@@ -1,0 +1,93 @@
+"""Detr3DHead.loss on the device: same numbers as
+``Detr3DHead.loss`` (HEAD:742-1001) + the gradients of the summed loss with
+respect to ``all_cls_scores`` / ``all_bbox_preds``, from three kernel launches
+and ONE device->host copy per iteration (the Hungarian assignment itself stays
+scipy's ``linear_sum_assignment`` on the host, exactly as in the reference)."""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from scipy.optimize import linear_sum_assignment
+
+from . import _lib as L
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def gt_tensors(gt_bboxes_list, device):
+    """mmdet3d LiDARInstance3DBoxes (gravity_center / tensor) or plain [n,9]
+    gravity-centre tensors -> list of [n,9] fp32 tensors (HEAD:963-966)."""
+    out = []
+    for g in gt_bboxes_list:
+        if hasattr(g, 'gravity_center'):
+            g = torch.cat((g.gravity_center, g.tensor[:, 3:]), dim=1)
+        out.append(g.to(device=device, dtype=torch.float32))
+    return out
+
+
+def detr_loss_device(head, all_cls, all_box, gt_bboxes_list, gt_labels_list):
+    """-> (loss dict with the reference's keys, d_all_cls, d_all_box, assigned [Lyr,B,Q] numpy).
+    The gradients are those of sum(losses) (mmdet ``_parse_losses``)."""
+    if head.assigner is None:
+        raise L.TransCARHipError('loss needs train_cfg=dict(assigner=...) at construction')
+    lib = L.lib()
+    dev = all_cls.device
+    Lyr, B, Q, ncls = all_cls.shape
+    code = all_box.shape[-1]
+    all_cls = all_cls.detach().contiguous()
+    all_box = all_box.detach().contiguous()
+    gts = gt_tensors(gt_bboxes_list, dev)
+    counts = [int(g.shape[0]) for g in gts]
+    Gmax = max(max(counts), 1)
+    gt9 = torch.ones((B, Gmax, 9), dtype=torch.float32, device=dev)
+    lab = torch.zeros((B, Gmax), dtype=torch.int32, device=dev)
+    for b, (g, l) in enumerate(zip(gts, gt_labels_list)):
+        if counts[b]:
+            gt9[b, :counts[b]] = g[:, :9]
+            lab[b, :counts[b]] = l.to(device=dev, dtype=torch.int32)
+    cnt = torch.tensor(counts, dtype=torch.int32, device=dev)
+    gtn = torch.empty((B, Gmax, 10), dtype=torch.float32, device=dev)
+    L.check(lib.tc_normalize_bbox(gt9.data_ptr(), B * Gmax, gtn.data_ptr(), _stream()), 'tc_normalize_bbox')
+    a = head.assigner
+    cost = torch.empty((Lyr, B, Q, Gmax), dtype=torch.float32, device=dev)
+    L.check(lib.tc_match_cost(
+        all_cls.data_ptr(), all_box.data_ptr(), Lyr, B, Q, ncls, code, gtn.data_ptr(), lab.data_ptr(),
+        cnt.data_ptr(), Gmax, float(a.cls_cost.weight), float(a.reg_cost.weight),
+        float(getattr(a.cls_cost, 'alpha', 0.25)), float(getattr(a.cls_cost, 'gamma', 2.0)),
+        float(getattr(a.cls_cost, 'eps', 1e-12)), cost.data_ptr(), _stream()), 'tc_match_cost')
+    cost_h = cost.cpu().numpy()                                   # the iteration's one sync
+    assigned = np.full((Lyr, B, Q), -1, dtype=np.int32)
+    num_pos = np.zeros(Lyr, dtype=np.float32)
+    for l in range(Lyr):
+        for b in range(B):
+            if counts[b]:
+                rows, cols = linear_sum_assignment(cost_h[l, b, :, :counts[b]])
+                assigned[l, b, rows] = cols
+                num_pos[l] += len(rows)
+    # normalisers, HEAD:885-902: mean over ranks of the number of positives, at least 1
+    box_avg = torch.from_numpy(num_pos).to(dev)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(box_avg, op=dist.ReduceOp.SUM)
+        box_avg = box_avg / dist.get_world_size()
+    cls_avg = box_avg if head.sync_cls_avg_factor else torch.from_numpy(num_pos).to(dev)
+    avg = torch.stack((cls_avg.clamp(min=1.0), box_avg.clamp(min=1.0)), dim=1).contiguous()   # [Lyr,2]
+    asg = torch.from_numpy(assigned).to(dev)
+    losses = torch.zeros((Lyr, 2), dtype=torch.float32, device=dev)
+    d_cls = torch.empty_like(all_cls)
+    d_box = torch.empty_like(all_box)
+    lc, lb = head.loss_cls_cfg, head.loss_bbox_cfg
+    L.check(lib.tc_detr_loss_fwd_bwd(
+        all_cls.data_ptr(), all_box.data_ptr(), Lyr, B, Q, ncls, code, gtn.data_ptr(), lab.data_ptr(),
+        Gmax, asg.data_ptr(), avg.data_ptr(), head.code_weights.data_ptr(),
+        float(lc.get('alpha', 0.25)), float(lc.get('gamma', 2.0)), float(lc.get('loss_weight', 1.0)),
+        float(lb.get('loss_weight', 1.0)), losses.data_ptr(), d_cls.data_ptr(), d_box.data_ptr(),
+        _stream()), 'tc_detr_loss_fwd_bwd')
+    losses = torch.nan_to_num(losses, nan=0.0)
+    out = {'loss_cls': losses[Lyr - 1, 0], 'loss_bbox': losses[Lyr - 1, 1]}
+    for i in range(Lyr - 1):
+        out['d%d.loss_cls' % i] = losses[i, 0]
+        out['d%d.loss_bbox' % i] = losses[i, 1]
+    return out, d_cls, d_box, assigned

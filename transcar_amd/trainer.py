@@ -108,7 +108,7 @@ class FusionTrainer:
     """head: transcar_amd.Detr3DHead on the GPU, built with ``train_cfg``."""
 
     def __init__(self, head, lr=1.5e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01,
-                 max_norm=35.0):
+                 max_norm=35.0, device_loss=True):
         self.head = head.freeze_decoder()
         self.bucket = FlatBucket(head.trainable_parameters())
         head.refresh_weights()                      # parameter addresses moved into the bucket
@@ -118,6 +118,7 @@ class FusionTrainer:
         self.lr, self.betas, self.eps = lr, betas, eps
         self.weight_decay, self.max_norm = weight_decay, max_norm
         self.iter = 0
+        self.device_loss = device_loss     # step_fused_nhwc: losses + their gradients from HIP kernels
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -164,20 +165,25 @@ class FusionTrainer:
             C.byref(w), hs_last.data_ptr(), ref_last.data_ptr(), last_box.data_ptr(), tokens.data_ptr(),
             B, T, int(pad_mult), all_cls.data_ptr(), all_box.data_ptr(), tape.data_ptr(), tape.numel(),
             self._stream()), 'tc_radar_train_fwd')
-        cls_leaf = all_cls.requires_grad_(True)
-        box_leaf = all_box.requires_grad_(True)
-        outs = {'all_cls_scores': cls_leaf, 'all_bbox_preds': box_leaf,
-                'enc_cls_scores': None, 'enc_bbox_preds': None}
-        losses = head.loss(gt_bboxes_list, gt_labels_list, outs)
-        total = sum(v for k, v in losses.items() if 'loss' in k)
-        total.backward()                                   # d loss / d outputs only
+        if self.device_loss:
+            from .device_loss import detr_loss_device
+            losses, d_cls, d_box, _ = detr_loss_device(head, all_cls, all_box, gt_bboxes_list,
+                                                       gt_labels_list)
+        else:                                              # the reference's PyTorch loss + autograd
+            cls_leaf = all_cls.requires_grad_(True)
+            box_leaf = all_box.requires_grad_(True)
+            outs = {'all_cls_scores': cls_leaf, 'all_bbox_preds': box_leaf,
+                    'enc_cls_scores': None, 'enc_bbox_preds': None}
+            losses = head.loss(gt_bboxes_list, gt_labels_list, outs)
+            total = sum(v for k, v in losses.items() if 'loss' in k)
+            total.backward()                               # d loss / d outputs only
+            d_cls, d_box = cls_leaf.grad.contiguous(), box_leaf.grad.contiguous()
         self.bucket.zero_grad()
         g = grad_table(head)
         L.check(lib.tc_radar_train_bwd(
             C.byref(w), C.byref(g), hs_last.data_ptr(), last_box.data_ptr(), tokens.data_ptr(), B, T,
-            int(pad_mult), all_box.data_ptr(), cls_leaf.grad.contiguous().data_ptr(),
-            box_leaf.grad.contiguous().data_ptr(), tape.data_ptr(), tape.numel(), self._stream()),
-            'tc_radar_train_bwd')
+            int(pad_mult), all_box.data_ptr(), d_cls.data_ptr(), d_box.data_ptr(), tape.data_ptr(),
+            tape.numel(), self._stream()), 'tc_radar_train_bwd')
         if update:
             self._optimizer_step(lr)
         return {k: v.detach() for k, v in losses.items()}
