@@ -257,6 +257,11 @@ size_t tc_head_workspace_bytes(const tc_head_weights* w, int B, int T);
 size_t tc_head_packed_bytes(const tc_head_weights* w);
 int tc_head_pack_weights(const tc_head_weights* w, void* packed, size_t packed_bytes,
                          tc_head_weights* packed_view, tc_stream_t stream);
+/* After an optimizer step under the reference's freeze list (tools/train.py:245-252):
+ * re-pack only the radar encoder / fusion layer / final_* weights into the existing
+ * packed buffer; the frozen decoder's weights and the layer-0 constants stay. */
+int tc_head_repack_trainable(const tc_head_weights* w, tc_head_weights* packed_view,
+                             tc_stream_t stream);
 /* packed_view == NULL selects the operator-by-operator launch sequence (~160
  * launches instead of 16); results agree to fp32 rounding. */
 int tc_head_forward(const tc_head_weights* w, const tc_head_weights* packed_view,

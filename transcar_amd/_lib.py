@@ -137,6 +137,7 @@ SIGNATURES = {
     'tc_head_packed_bytes': (_sz, [_P(tc_head_weights)]),
     'tc_head_pack_weights': (_i, [_P(tc_head_weights), _vp, _sz,
                                   _P(tc_head_weights), _vp]),
+    'tc_head_repack_trainable': (_i, [_P(tc_head_weights), _P(tc_head_weights), _vp]),
     'tc_head_forward': (_i, [_P(tc_head_weights), _P(tc_head_weights),
                              _P(tc_feats_nhwc), _i, _vp,
                              _f, _f, _vp, _i, _i, _vp, _vp, _P(tc_head_aux),

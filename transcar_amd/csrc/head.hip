@@ -570,6 +570,26 @@ int tc_head_pack_weights(const tc_head_weights* w, void* packed, size_t packed_b
   return 0;
 }
 
+int tc_head_repack_trainable(const tc_head_weights* w, tc_head_weights* packed_view,
+                             tc_stream_t stream) {
+  TC_TRY(check_dims(w));
+  TC_REQUIRE(packed_view != nullptr && packed_view->l0_attn_out != nullptr,
+             "repack_trainable: packed_view was not produced by tc_head_pack_weights");
+  // the same item order as tc_head_pack_weights; the decoder's items (frozen under
+  // tools/train.py:245-252) and the layer-0 constants keep their packed contents
+  tc_head_weights scratch = *packed_view;
+  PackItem items[MAX_PACK_ITEMS];
+  const int n = collect_pack_items(w, &scratch, items);
+  const int first = 1 + 10 * w->num_layers;
+  for (int i = first; i < n; ++i) {
+    TC_REQUIRE(items[i].src != nullptr, "repack_trainable: weight %d is null", i);
+    // scratch is a copy of the packed view: its slot still holds the packed destination
+    float* dst = const_cast<float*>(*items[i].slot);
+    TC_TRY(launch_pack_linear(items[i].src, items[i].N, items[i].K, dst, as_stream(stream)));
+  }
+  return 0;
+}
+
 size_t tc_head_workspace_bytes(const tc_head_weights* w, int B, int T) {
   if (check_dims(w) != 0) return 0;
   return head_ws_layout(w, B, T, nullptr, ~size_t(0), nullptr);

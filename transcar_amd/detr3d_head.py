@@ -256,13 +256,21 @@ class Detr3DHead(BaseModule):
         self._weights = None
         return self.head_weights()
 
-    def repack_weights(self):
+    def repack_weights(self, trainable_only=False):
         """Re-run the weight re-layout into the existing packed buffer: the
         parameters changed IN PLACE (optimizer step on the flat bucket), their
-        addresses did not.  Enqueue-only (a few dozen small kernels)."""
+        addresses did not.  Enqueue-only (a few dozen small kernels).
+        trainable_only: just the radar / final_* weights (the decoder is frozen
+        under tools/train.py:245-252)."""
         if self._weights is None:
             return self.head_weights()
         dev = self.query_embedding.weight.device
+        if trainable_only:
+            L.check(L.lib().tc_head_repack_trainable(
+                C.byref(self._weights), C.byref(self._packed_view),
+                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                'tc_head_repack_trainable')
+            return self._weights
         L.check(L.lib().tc_head_pack_weights(
             C.byref(self._weights), self._packed.data_ptr(),
             self._packed.numel(), C.byref(self._packed_view),
