@@ -555,12 +555,12 @@ __device__ __forceinline__ T load_uniform(const T& src) {
 __device__ __forceinline__ StepRes load_step(const StepRes& src) { return load_uniform<StepRes>(src); }
 
 template <int R>
-__global__ __launch_bounds__(CH_NT) void chain_kernel(ChainK k) {
+__device__ __forceinline__ void chain_body(const ChainK& k, const int block) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   ChainLds<R>& S = *reinterpret_cast<ChainLds<R>*>(smem_raw);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int m0 = blockIdx.x * R;
+  const int m0 = block * R;
   const int M = k.M;
   const StepDesc* table = k.program == PROG_DECODER ? PROG_DECODER_T
                           : k.program == PROG_PROLOGUE ? PROG_PROLOGUE_T
@@ -932,6 +932,37 @@ __global__ __launch_bounds__(CH_NT) void chain_kernel(ChainK k) {
 }
 
 template <int R>
+__global__ __launch_bounds__(CH_NT) void chain_kernel(ChainK k) {
+  chain_body<R>(k, blockIdx.x);
+}
+
+// Two programs in one launch: workgroups [0, na) run `ka` on RA-row tiles, the rest
+// `kb` on RB-row tiles.  Decoder layer 0 carries the radar encoders this way: as a
+// branch of the hipGraph on a side stream, the fork and the join each left a ~10 us
+// hole in the replayed frame (profiles: rocprofv3 kernel trace).
+static_assert(2 * sizeof(ChainK) <= 3800, "two ChainK must fit the kernel argument segment");
+template <int RA, int RB>
+__global__ __launch_bounds__(CH_NT) void chain_dual_kernel(ChainK ka, ChainK kb, int na) {
+  if ((int)blockIdx.x < na) chain_body<RA>(ka, blockIdx.x);
+  else chain_body<RB>(kb, (int)blockIdx.x - na);
+}
+
+template <int RA, int RB>
+int launch_dual_r(const ChainK& ka, const ChainK& kb, hipStream_t s, const char* what) {
+  constexpr size_t lds = sizeof(ChainLds<RA>) > sizeof(ChainLds<RB>) ? sizeof(ChainLds<RA>) : sizeof(ChainLds<RB>);
+  static bool done = false;
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_dual_kernel<RA, RB>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("chain: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    done = true;
+  }
+  const int na = (ka.M + RA - 1) / RA, nb = (kb.M + RB - 1) / RB;
+  hipLaunchKernelGGL((chain_dual_kernel<RA, RB>), dim3(na + nb), dim3(CH_NT), lds, s, ka, kb, na);
+  return check_launch(what);
+}
+
+template <int R>
 int launch_r(const ChainK& k, hipStream_t s, const char* what) {
   static bool done = false;
   if (!done) {
@@ -991,9 +1022,8 @@ int launch_prologue(const PrologueArgs& a, hipStream_t s) {
   return launch(k, s, "chain(prologue)");
 }
 
-int launch_decoder_chain(const DecoderChainArgs& a, hipStream_t s) {
+static int make_decoder_k(const DecoderChainArgs& a, ChainK& k) {
   TC_REQUIRE(a.code <= 12 && a.cam.num_cams * a.cam.feats.num_levels <= 32, "decoder_chain: code/logit width");
-  ChainK k;
   init_k(k);
   k.program = PROG_DECODER; k.M = a.M; k.Q = a.Q; k.code = a.code;
   k.nlogits = a.cam.num_cams * a.cam.feats.num_levels;
@@ -1017,13 +1047,19 @@ int launch_decoder_chain(const DecoderChainArgs& a, hipStream_t s) {
   k.ref_in = a.ref_in; k.ref_mod = a.ref_mod; k.ref_out = a.ref_out; k.box_m = a.box_m;
   fill_camk(a.cam, k.cam);
   k.pair_counter = a.cam.pair_counter;
+  return 0;
+}
+
+int launch_decoder_chain(const DecoderChainArgs& a, hipStream_t s) {
+  ChainK k;
+  int rc = make_decoder_k(a, k);
+  if (rc != 0) return rc;
   return launch(k, s, "chain(decoder)");
 }
 
-int launch_radar_encode(const RadarEncodeArgs& a, hipStream_t s) {
+static int make_radar_enc_k(const RadarEncodeArgs& a, ChainK& k) {
   TC_REQUIRE(a.RI <= 64 && (a.RI & 3) == 0, "radar_encode: radar_in_dims=%d", a.RI);
   TC_REQUIRE(a.nlayers == TC_MAX_RADAR_LAYERS, "radar_encode: %d radar layers (3 supported)", a.nlayers);
-  ChainK k;
   init_k(k);
   k.program = PROG_RADAR_ENC; k.M = a.M; k.Q = 1; k.RI = a.RI; k.tokens = a.tokens; k.has_next = 1;
   k.pairs[0] = a.rpe.l0; k.pairs[1] = tc_linear{a.rpe.n1.g, a.rpe.n1.b}; k.pairs[2] = a.rpe.l3;
@@ -1032,7 +1068,29 @@ int launch_radar_encode(const RadarEncodeArgs& a, hipStream_t s) {
     k.pairs[7 + r] = a.kvproj[r];
     k.g[G_KV0 + r] = a.kv[r]; k.g_ld[G_KV0 + r] = 512;
   }
+  return 0;
+}
+
+int launch_radar_encode(const RadarEncodeArgs& a, hipStream_t s) {
+  ChainK k;
+  int rc = make_radar_enc_k(a, k);
+  if (rc != 0) return rc;
   return launch(k, s, "chain(radar_encode)");
+}
+
+// a decoder layer and the radar encoders (16-row tiles) in one launch
+int launch_decoder_chain_with_encoders(const DecoderChainArgs& d, const RadarEncodeArgs& e, hipStream_t s) {
+  ChainK kd, ke;
+  int rc = make_decoder_k(d, kd);
+  if (rc != 0) return rc;
+  rc = make_radar_enc_k(e, ke);
+  if (rc != 0) return rc;
+  const char* env = getenv("TRANSCAR_CHAIN_ROWS");
+  const int forced = env ? atoi(env) : 0;
+  const int rows = forced ? forced : (kd.M <= 1024 ? 4 : kd.M <= 2048 ? 8 : 16);
+  if (rows == 4) return launch_dual_r<4, 16>(kd, ke, s, "chain(decoder + radar_encode)");
+  if (rows == 8) return launch_dual_r<8, 16>(kd, ke, s, "chain(decoder + radar_encode)");
+  return launch_dual_r<16, 16>(kd, ke, s, "chain(decoder + radar_encode)");
 }
 
 int launch_radar_chain(const RadarChainArgs& a, hipStream_t s) {

@@ -157,26 +157,7 @@ static size_t head_ws_layout(const tc_head_weights* w, int B, int T, void* base,
   return a.off;
 }
 
-// ---- fused path: 16 launches per frame (chain.hip) ---------------------------
-struct SideStream {
-  hipStream_t s = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
-  bool ready = false;
-};
-
-static SideStream& side_stream() {
-  static thread_local SideStream sd;
-  if (!sd.ready) {
-    if (hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking) == hipSuccess &&
-        hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) == hipSuccess &&
-        hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) == hipSuccess)
-      sd.ready = true;
-    else
-      (void)hipGetLastError();
-  }
-  return sd;
-}
-
+// ---- fused path: 12 launches per frame (chain.hip) ---------------------------
 static bool use_unfused() {
   const char* e = getenv("TRANSCAR_UNFUSED");   // read per call: tests toggle it
   return e != nullptr && e[0] == '1';
@@ -194,16 +175,10 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
   unsigned long long* pairs = aux ? aux->sample_pairs : nullptr;
   const bool radar = w->num_radar_layers > 0;
 
-  // the radar encoders and K/V projections do not depend on the decoder: they
-  // run on a side stream (a parallel branch when the forward is graph-captured)
-  SideStream& sd = side_stream();
-  hipStream_t rs = (radar && sd.ready) ? sd.s : s;
+  // the radar encoders and K/V projections do not depend on the decoder: they ride in
+  // the launch of decoder layer 0 as 16 extra workgroups (chain_dual_kernel)
+  RadarEncodeArgs re;
   if (radar) {
-    if (rs != s) {
-      TC_HIP(hipEventRecord(sd.fork, s));
-      TC_HIP(hipStreamWaitEvent(rs, sd.fork, 0));
-    }
-    RadarEncodeArgs re;
     re.tokens = radar_tokens; re.RI = w->radar_in_dims; re.M = rt;
     re.rpe = w->radar_position_encoder; re.f0 = w->radar_feat0; re.f2 = w->radar_feat2;
     re.f4 = w->radar_feat4; re.nlayers = w->num_radar_layers;
@@ -214,8 +189,6 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
       re.kv[r] = h.kv3[r];
     }
     re.radar_feat = nullptr;
-    TC_TRY(launch_radar_encode(re, rs));
-    if (rs != s) TC_HIP(hipEventRecord(sd.join, rs));
   }
 
   // layer 0 up to its attention output is a constant of the checkpoint (pack time)
@@ -250,7 +223,8 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
     d.cam.img_h = img_h; d.cam.img_w = img_w; d.cam.out = nullptr; d.cam.vis = nullptr;
     d.cam.pair_counter = pairs;
     d.code = code; d.M = rows;
-    TC_TRY(launch_decoder_chain(d, s));
+    if (radar && lid == 0) TC_TRY(launch_decoder_chain_with_encoders(d, re, s));
+    else TC_TRY(launch_decoder_chain(d, s));
   }
   if (aux) {
     if (aux->inter_states)
@@ -271,7 +245,6 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
       TC_HIP(hipMemcpyAsync(aux->last_box, h.box_m, (size_t)rows * code * 4, hipMemcpyDeviceToDevice, s));
   }
   if (!radar) return 0;
-  if (rs != s) TC_HIP(hipStreamWaitEvent(s, sd.join, 0));
   RadarChainArgs rc;
   rc.qf = h.hs + (size_t)(L - 1) * rows * C;
   rc.ref_last = h.inter_refs + (size_t)(L - 1) * rows * 3;
