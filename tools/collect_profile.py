@@ -42,14 +42,19 @@ def label_chain(rows, num_layers=6):
     between are bench.py's roofline replay of the decoder layer."""
     for r in rows:
         r['K'] = short(r['Kernel_Name'])
+        if r['K'].startswith('chain_dual_kernel'):
+            r['K'] = 'chain_dual_kernel(decoder layer 0 + radar encoders)'
     main_rows = []
     for r in rows:
         if r['K'].startswith('chain_kernel') and int(r['Grid_Size']) < 256 * 128:
             r['K'] = 'chain_kernel(radar encoders)'
-        elif r['K'].startswith('chain_kernel') or r['K'].startswith('self_attn') or 'box_decode' in r['K']:
+        elif r['K'].startswith('chain_') or r['K'].startswith('self_attn') or 'box_decode' in r['K']:
             main_rows.append(r)
     n_dec = 0
     for i, r in enumerate(main_rows):
+        if r['K'].startswith('chain_dual_kernel'):
+            n_dec = 1
+            continue
         if not r['K'].startswith('chain_kernel'):
             if 'box_decode' in r['K']:
                 n_dec = 0
@@ -157,6 +162,25 @@ def main():
         res[nm] = {'fetch_kb': round(fk, 1), 'write_kb': round(wk, 1),
                    'traffic_bytes': int((2 * fk + wk) * 1024)}
     json.dump(res, open(os.path.join(dst, name + '_pmc.json'), 'w'), indent=1)
+    mf = glob.glob(os.path.join(src, 'pmc_mfma', '*', '*counter_collection.csv'))
+    if mf:
+        crow = [r for r in csv.DictReader(open(mf[0])) if r['Counter_Name'] == 'SQ_VALU_MFMA_BUSY_CYCLES']
+        crow.sort(key=lambda r: int(r['Dispatch_Id']))
+        label_chain(crow)
+        acc = defaultdict(lambda: [0.0, 0.0, 0])
+        for r in crow:
+            a = acc[r['K']]
+            a[0] += float(r['Counter_Value']); a[1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3; a[2] += 1
+        out_m = OrderedDict()
+        out_m['_comment'] = ('rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES of `bench.py --no-graph --steps 5`, MI355X. '
+                             'The counter sums matrix-pipe busy cycles over the 1024 SIMDs (8 per v_mfma_f32_4x4x1, 32 per '
+                             '16x16x4 f32); utilisation = busy / (1024 * duration * 2.4 GHz).')
+        for k, (busy, dur, n) in sorted(acc.items()):
+            if k.startswith('chain') or k.startswith('self_attn') or k.startswith('bwd_gemm'):
+                out_m['self_attn_kernel' if k.startswith('self_attn') else k] = {
+                    'mfma_busy_cycles': round(busy / n), 'duration_us': round(dur / n, 1),
+                    'mfma_utilisation': round(busy / (1024 * dur * 1e-6 * 2.4e9), 4)}
+        json.dump(out_m, open(os.path.join(dst, name + '_mfma_busy.json'), 'w'), indent=1)
     print(open(os.path.join(dst, name + '_frame_trace.txt')).read())
     print(json.dumps(res, indent=1))
 

@@ -14,13 +14,14 @@ export TMPDIR=/tmp
 python -m pytest tests -x -q -m gpu > "$OUT/pytest_gpu.log" 2>&1
 echo "pytest rc=$?" >> "$OUT/pytest_gpu.log"
 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
-python bench.py --batch 2 --no-cpu-baseline > "$OUT/bench_b2.json" 2>> "$OUT/bench.err"
-python bench.py --batch 4 --no-cpu-baseline > "$OUT/bench_b4.json" 2>> "$OUT/bench.err"
+python bench.py --batch 2 --no-cpu-baseline --no-batched > "$OUT/bench_b2.json" 2>> "$OUT/bench.err"
+python bench.py --batch 4 --no-cpu-baseline --no-batched > "$OUT/bench_b4.json" 2>> "$OUT/bench.err"
 python bench.py --train --steps 50 --warmup 5 > "$OUT/bench_train.json" 2>> "$OUT/bench.err"
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python3 "$REPO/bench.py" --steps 50 --warmup 5 --no-cpu-baseline > "$OUT/prof.log" 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-graph > "$OUT/pmc_fetch.log" 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-graph > "$OUT/pmc_write.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python3 "$REPO/bench.py" --steps 50 --warmup 5 --no-cpu-baseline --no-batched > "$OUT/prof.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-batched --no-graph > "$OUT/pmc_fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-batched --no-graph > "$OUT/pmc_write.log" 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d "$OUT/pmc_mfma" -- python3 "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-batched --no-graph > "$OUT/pmc_mfma.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_train" -- python3 "$REPO/bench.py" --train --steps 20 --warmup 3 > "$OUT/prof_train.log" 2>&1
 cd "$REPO"
 # keep the merge-back small: stats csv + counter csv only
