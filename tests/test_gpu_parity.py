@@ -332,21 +332,24 @@ def test_head_ragged_and_empty_radar(T, sd, head):
             assert int(outs['aux']['radar_hit_counts'].sum()) == 0
 
 
-def test_head_batch2_equals_two_singles(T, head):
-    """Batch > 1 (not supported by the reference's radar part) = per-sample runs."""
-    fa = synth.make_feats('tiny', seed=1, smooth=SMOOTH)
-    fb = synth.make_feats('tiny', seed=7, smooth=SMOOTH)
-    ra = synth.make_radar_frame(seed=2, n_per_radar=51, centres=g('g5_head_tiny.npz')['radar_centres'])
-    rb = synth.make_radar_frame(seed=3, n_per_radar=20)
+@pytest.mark.parametrize('nb', [2, 3])
+def test_head_batch_equals_singles(T, head, nb):
+    """Batch > 1 (not supported by the reference's radar part) = per-sample runs.
+    nb = 2 runs the row chains on 8-row tiles, nb = 3 on 16-row tiles (B = 1: 4 rows)."""
     l2i = synth.make_lidar2img()
-    oa = head([gpu(f) for f in fa], synth.make_img_metas(1, l2i, radar=ra))
-    ob = head([gpu(f) for f in fb], synth.make_img_metas(1, l2i, radar=rb))
-    both = [gpu(np.concatenate([x, y], 0)) for x, y in zip(fa, fb)]
-    metas = synth.make_img_metas(2, l2i, radar=[ra, rb])
-    o2 = head(both, metas)
+    feats, frames, singles = [], [], []
+    for i in range(nb):
+        f = synth.make_feats('tiny', seed=1 + 6 * i, smooth=SMOOTH)
+        r = synth.make_radar_frame(seed=2, n_per_radar=51, centres=g('g5_head_tiny.npz')['radar_centres']) \
+            if i == 0 else synth.make_radar_frame(seed=2 + i, n_per_radar=20 + 7 * i)
+        feats.append(f)
+        frames.append(r)
+        singles.append(head([gpu(x) for x in f], synth.make_img_metas(1, l2i, radar=r)))
+    both = [gpu(np.concatenate([f[l] for f in feats], 0)) for l in range(4)]
+    ob = head(both, synth.make_img_metas(nb, l2i, radar=frames))
     for k in ('all_cls_scores', 'all_bbox_preds'):
-        assert frac_within(o2[k][:, 0].cpu().numpy(), oa[k][:, 0].cpu().numpy(), 1e-4) > 0.998
-        assert frac_within(o2[k][:, 1].cpu().numpy(), ob[k][:, 0].cpu().numpy(), 1e-4) > 0.998
+        for i in range(nb):
+            assert frac_within(ob[k][:, i].cpu().numpy(), singles[i][k][:, 0].cpu().numpy(), 1e-4) > 0.998, (k, i)
 
 
 def test_module_api_matches_fused_head(T, head):
