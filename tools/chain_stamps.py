@@ -51,6 +51,9 @@ def main():
         sb = np.zeros((4, 64), dtype=np.int64)
         assert lib.tc_debug_chain_sub(0, sb.ctypes.data) == 0
         print('sub-step stamps of table step %d (%s): 0 dispatch, 1 spec built, 2 first load issued, 3.. after item i' % (sub, names[sub]))
+        st = sb[0, 40:47]
+        print('kernel start (cycles since entry): early loads issued %d, resolve done %d, early stores %d, barrier %d, prefetch records %d, ready %d'
+              % tuple(int(x - st[0]) for x in st[1:]))
         for w in range(4):
             row = sb[w]
             n = int((row[:20] > 0).sum())

@@ -203,6 +203,7 @@ struct ChainK {
   tc_linear pairs[MAX_PAIRS];
   float* g[G_COUNT]; int g_ld[G_COUNT]; int g_mod[G_COUNT];   // global tensors by GSel
   float qscale; int qpad;
+  int dbg;                     // TRANSCAR_CHAIN_DBG (timing experiments only: wrong results)
   // decoder
   const float* ref_in; int ref_mod; float* ref_out; float* box_m;
   CamK cam; unsigned long long* pair_counter;
@@ -230,6 +231,7 @@ struct LinSpec {
   float* gt; int gt_ld, gt_rpb;
   int m0, M;
   int woff;                    // wave w owns column tiles ((w - woff) & 3) + 4 i
+  int dbg;
   int sub_on;
 };
 
@@ -461,8 +463,10 @@ __device__ __forceinline__ bool linear_step(const LinSpec& s, WBuf& w0, bool pre
       int tile = wave + tt * CH_NW;
       int sidx = step_idx;
       asm volatile("" : "+s"(tile), "+s"(sidx));
-      const LinSpec e = make_spec(sidx);
-      lin_epilogue<NG>(e, tile, acc, lane, bv);
+      if (!(s.dbg & 1)) {
+        const LinSpec e = make_spec(sidx);
+        lin_epilogue<NG>(e, tile, acc, lane, bv);
+      }
     }
     wcur = np; tt = nt; kb = nk;
   };
@@ -470,6 +474,7 @@ __device__ __forceinline__ bool linear_step(const LinSpec& s, WBuf& w0, bool pre
   using No = std::integral_constant<bool, false>;
   WBuf w1;
   SUB_STAMP(1);
+  if (s.dbg & 32) return false;
   if (!preloaded) {
     wload(w0, wbase, 16);
     __builtin_amdgcn_sched_barrier(0);
@@ -554,7 +559,21 @@ __device__ __forceinline__ T load_uniform(const T& src) {
 }
 __device__ __forceinline__ StepRes load_step(const StepRes& src) { return load_uniform<StepRes>(src); }
 
-template <int R>
+#ifdef TC_CHAIN_STAMPS
+#define START_STAMP(slot)                                                                     \
+  do {                                                                                        \
+    if (blockIdx.x == 100 && threadIdx.x == 0) g_chain_sub[0][(slot)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define START_STAMP(slot) do {} while (0)
+#endif
+
+// PROG is a compile-time parameter: each program's kernel contains only the step kinds it
+// uses.  (One code image for all four programs made the R = 4 kernel spill 9 dwords to a
+// private segment under the combined pressure of the camera-sampling and radar-attention
+// bodies -- and a kernel with a private segment costs ~13 us more PER LAUNCH on this
+// platform: 15.4 us for an immediately returning launch in a replayed graph vs 2.)
+template <int R, int PROG>
 __device__ __forceinline__ void chain_body(const ChainK& k, const int block) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   ChainLds<R>& S = *reinterpret_cast<ChainLds<R>*>(smem_raw);
@@ -562,16 +581,22 @@ __device__ __forceinline__ void chain_body(const ChainK& k, const int block) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int m0 = block * R;
   const int M = k.M;
-  const StepDesc* table = k.program == PROG_DECODER ? PROG_DECODER_T
-                          : k.program == PROG_PROLOGUE ? PROG_PROLOGUE_T
-                          : k.program == PROG_RADAR_ENC ? PROG_RADAR_ENC_T : PROG_RADAR_LAYER_T;
-  const int nrep = k.program == PROG_RADAR ? k.nlayers : 1;
+  const StepDesc* table = PROG == PROG_DECODER ? PROG_DECODER_T
+                          : PROG == PROG_PROLOGUE ? PROG_PROLOGUE_T
+                          : PROG == PROG_RADAR_ENC ? PROG_RADAR_ENC_T : PROG_RADAR_LAYER_T;
+  const int nrep = PROG == PROG_RADAR ? k.nlayers : 1;
+  if (k.dbg & 64) return;
+  START_STAMP(40);
 
   // ---- resolve the step table once: every later step reads one LDS record instead
   // of chasing constant memory -> kernel arguments -> weights (1200-1850 cycles of
   // dependent scalar loads per step, measured)
-  int nsteps = 0;
-  while (table[nsteps].kind != K_END) ++nsteps;
+  // table length: a compile-time constant per program (scanning for K_END cost ~20 dependent
+  // constant-memory round trips, several microseconds at every kernel start)
+  constexpr int nsteps = PROG == PROG_DECODER ? (int)(sizeof(PROG_DECODER_T) / sizeof(StepDesc)) - 1
+                         : PROG == PROG_PROLOGUE ? (int)(sizeof(PROG_PROLOGUE_T) / sizeof(StepDesc)) - 1
+                         : PROG == PROG_RADAR_ENC ? (int)(sizeof(PROG_RADAR_ENC_T) / sizeof(StepDesc)) - 1
+                                                  : (int)(sizeof(PROG_RADAR_LAYER_T) / sizeof(StepDesc)) - 1;
   const int total = nsteps * nrep;
   // The leading global-to-LDS loads of a program (a decoder layer starts with three) are
   // issued before the table is resolved: their latency and the resolution overlap.
@@ -593,9 +618,10 @@ __device__ __forceinline__ void chain_body(const ChainK& k, const int block) {
       }
     }
   }
+  START_STAMP(41);
   for (int idx = threadIdx.x; idx < total; idx += CH_NT) {
     const int rep = idx / nsteps, si = idx - rep * nsteps;
-    const int pair0 = k.program == PROG_RADAR ? rep * RADAR_PAIRS : 0;
+    const int pair0 = PROG == PROG_RADAR ? rep * RADAR_PAIRS : 0;
     const StepDesc d = table[si];
     StepRes r;
     r.p0 = r.p1 = r.p2 = r.p3 = nullptr; r.gd = r.gt = nullptr;
@@ -640,6 +666,7 @@ __device__ __forceinline__ void chain_body(const ChainK& k, const int block) {
     e.res_off = rp ? (int)(rp - base) : -1; e.res_ld = buf_ld(r.res);
     S.epi[idx] = e;
   }
+  START_STAMP(42);
 #pragma unroll
   for (int j = 0; j < EARLY_MAX; ++j) {
     if (j < early_n) {
@@ -651,7 +678,9 @@ __device__ __forceinline__ void chain_body(const ChainK& k, const int block) {
       }
     }
   }
+  START_STAMP(43);
   __syncthreads();
+  START_STAMP(44);
   // per (step, wave): the next linear step inside the same run of light steps where the
   // wave owns a column tile, and that step's first weight item
   for (int t = threadIdx.x; t < total * CH_NW; t += CH_NT) {
@@ -671,8 +700,9 @@ __device__ __forceinline__ void chain_body(const ChainK& k, const int block) {
     }
     S.pre[idx][w] = pr;
   }
+  START_STAMP(45);
 
-  if (k.program == PROG_RADAR) {     // HEAD:539, 543-547, 596-598
+  if (PROG == PROG_RADAR) {     // HEAD:539, 543-547, 596-598
     for (int row = wave; row < R; row += CH_NW) {
       const int grow = min(m0 + row, M - 1);
       *reinterpret_cast<float4*>(&S.x[row][4 * lane]) = ld4(k.g[G_QF] + (size_t)grow * 256 + 4 * lane);
@@ -689,6 +719,7 @@ __device__ __forceinline__ void chain_body(const ChainK& k, const int block) {
   }
   __syncthreads();
 
+  START_STAMP(46);
 #ifdef TC_CHAIN_STAMPS
   int stamp_i = 0;
   STEP_STAMP();
@@ -725,6 +756,7 @@ __device__ __forceinline__ void chain_body(const ChainK& k, const int block) {
     s.gdst = nullptr; s.gdst_ld = 0; s.gt = nullptr; s.gt_ld = 0; s.gt_rpb = 1;
     s.m0 = m0; s.M = M;
     s.woff = (r.flags & F_WAVE1) ? 1 : 0;
+    s.dbg = k.dbg;
     s.sub_on = 0;
     return s;
   };
@@ -745,11 +777,12 @@ __device__ __forceinline__ void chain_body(const ChainK& k, const int block) {
     s.gt = e.gt; s.gt_ld = k.qpad; s.gt_rpb = k.Q;
     s.m0 = m0; s.M = M;
     s.woff = e.woff;
+    s.dbg = 0;
     s.sub_on = 0;
     return s;
   };
 
-  int idx = early_n;          // the leading loads are already in LDS
+  int idx = (k.dbg & 16) ? total : early_n;          // the leading loads are already in LDS
 #ifdef TC_CHAIN_STAMPS
   for (int j = 0; j < 2 * early_n; ++j) STEP_STAMP();
 #endif
@@ -776,12 +809,12 @@ __device__ __forceinline__ void chain_body(const ChainK& k, const int block) {
             pre_idx = have ? pr.nidx : -1;
           }
         } else if (kd == K_LN) {
-          do_ln(r);
+          if (!(k.dbg & 4)) do_ln(r);
         } else if (kd != K_NOP) {
           break;
         }
         STEP_STAMP();
-        if (ufirst(r.sync)) __syncthreads();
+        if (ufirst(r.sync) && !(k.dbg & 2)) __syncthreads();
         STEP_STAMP();
         if (++idx >= total) break;
       }
@@ -790,7 +823,7 @@ __device__ __forceinline__ void chain_body(const ChainK& k, const int block) {
     const StepRes r = load_step(S.sres[idx]);
     const int rep = r.rep;
     switch (kind) {
-      case K_LOAD: {
+      case K_LOAD: { if constexpr (PROG == PROG_DECODER || PROG == PROG_PROLOGUE) {
         // this and the directly following K_LOAD steps (the decoder starts with three) go
         // out together: one memory latency instead of three, one barrier
         constexpr int MAXL = 3, RW = (R + CH_NW - 1) / CH_NW;
@@ -830,14 +863,16 @@ __device__ __forceinline__ void chain_body(const ChainK& k, const int block) {
         idx += n;
         continue;
       }
-      case K_TOKENS: {   // radar token tile, zero padded to 64 columns
+      } break;
+      case K_TOKENS: { if constexpr (PROG == PROG_RADAR_ENC) {   // radar token tile, zero padded to 64 columns
         for (int i = threadIdx.x; i < R * 64; i += CH_NT) {
           const int row = i >> 6, c = i & 63;
           const int grow = min(m0 + row, M - 1);
           S.a[row][c] = c < k.RI ? k.tokens[(size_t)grow * k.RI + c] : 0.0f;
         }
       } break;
-      case K_POSENC: {   // Linear(3,256) + LN + ReLU of inverse_sigmoid(ref) or of raw token xyz
+      } break;
+      case K_POSENC: { if constexpr (PROG == PROG_DECODER || PROG == PROG_RADAR_ENC) {   // Linear(3,256) + LN + ReLU of inverse_sigmoid(ref) or of raw token xyz
         float* dst = buf_ptr<R>(S, r.dst);
         const bool skip0 = (r.flags & F_NOT_W0) != 0;      // wave 0 is busy with the narrow linear step before
         for (int row = skip0 ? wave - 1 : wave; row < R && row >= 0; row += skip0 ? CH_NW - 1 : CH_NW) {
@@ -854,7 +889,9 @@ __device__ __forceinline__ void chain_body(const ChainK& k, const int block) {
               posenc_l0_row(p0, p1, p2, uptr(r.p0), uptr(r.p1), uptr(r.p2), uptr(r.p3), lane);
         }
       } break;
-      case K_SAMPLE: {   // camera sampling of this block's queries
+      } break;
+      case K_SAMPLE: { if constexpr (PROG == PROG_DECODER) {   // camera sampling of this block's queries
+        if (k.dbg & 8) break;
         int pairs = 0;
 #pragma unroll 1
         for (int row = wave; row < R; row += CH_NW) {
@@ -868,7 +905,8 @@ __device__ __forceinline__ void chain_body(const ChainK& k, const int block) {
         if (k.pair_counter != nullptr && lane == 0 && pairs > 0)
           atomicAdd(k.pair_counter, (unsigned long long)pairs);
       } break;
-      case K_REFUPD: {   // XFMR:195-203, HEAD:287-293
+      } break;
+      case K_REFUPD: { if constexpr (PROG == PROG_DECODER) {   // XFMR:195-203, HEAD:287-293
         if (threadIdx.x < R && m0 + (int)threadIdx.x < M) {
           const int row = threadIdx.x, grow = m0 + row;
           const float* t = &S.l[row][0];
@@ -889,7 +927,8 @@ __device__ __forceinline__ void chain_body(const ChainK& k, const int block) {
           }
         }
       } break;
-      case K_RADAR_ATTN: {   // distance-gated attention (HEAD:549-579)
+      } break;
+      case K_RADAR_ATTN: { if constexpr (PROG == PROG_RADAR) {   // distance-gated attention (HEAD:549-579)
 #pragma unroll 1
         for (int row = wave; row < R; row += CH_NW) {
           const int grow = min(m0 + row, M - 1);
@@ -908,7 +947,8 @@ __device__ __forceinline__ void chain_body(const ChainK& k, const int block) {
           }
         }
       } break;
-      case K_BOXADD: {   // box = reg + reference (HEAD:599-600, 664-665, 722-723); next ref (HEAD:615-617)
+      } break;
+      case K_BOXADD: { if constexpr (PROG == PROG_RADAR) {   // box = reg + reference (HEAD:599-600, 664-665, 722-723); next ref (HEAD:615-617)
         if (threadIdx.x < R) {
           const int row = threadIdx.x;
           float bx[12];
@@ -922,6 +962,7 @@ __device__ __forceinline__ void chain_body(const ChainK& k, const int block) {
           }
         }
       } break;
+      } break;
       default: break;
     }
     STEP_STAMP();
@@ -931,20 +972,20 @@ __device__ __forceinline__ void chain_body(const ChainK& k, const int block) {
   }
 }
 
-template <int R>
+template <int R, int PROG>
 __global__ __launch_bounds__(CH_NT) void chain_kernel(ChainK k) {
-  chain_body<R>(k, blockIdx.x);
+  chain_body<R, PROG>(k, blockIdx.x);
 }
 
-// Two programs in one launch: workgroups [0, na) run `ka` on RA-row tiles, the rest
-// `kb` on RB-row tiles.  Decoder layer 0 carries the radar encoders this way: as a
-// branch of the hipGraph on a side stream, the fork and the join each left a ~10 us
-// hole in the replayed frame (profiles: rocprofv3 kernel trace).
+// Two programs in one launch: workgroups [0, na) run the decoder layer `ka` on RA-row
+// tiles, the rest the radar encoders `kb` on RB-row tiles.  Decoder layer 0 carries the
+// encoders this way: as a branch of the hipGraph on a side stream, the fork and the join
+// each left a ~10 us hole in the replayed frame (profiles: rocprofv3 kernel trace).
 static_assert(2 * sizeof(ChainK) <= 3800, "two ChainK must fit the kernel argument segment");
 template <int RA, int RB>
 __global__ __launch_bounds__(CH_NT) void chain_dual_kernel(ChainK ka, ChainK kb, int na) {
-  if ((int)blockIdx.x < na) chain_body<RA>(ka, blockIdx.x);
-  else chain_body<RB>(kb, (int)blockIdx.x - na);
+  if ((int)blockIdx.x < na) chain_body<RA, PROG_DECODER>(ka, blockIdx.x);
+  else chain_body<RB, PROG_RADAR_ENC>(kb, (int)blockIdx.x - na);
 }
 
 template <int RA, int RB>
@@ -962,37 +1003,53 @@ int launch_dual_r(const ChainK& ka, const ChainK& kb, hipStream_t s, const char*
   return check_launch(what);
 }
 
-template <int R>
+template <int R, int PROG>
 int launch_r(const ChainK& k, hipStream_t s, const char* what) {
   static bool done = false;
   if (!done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<R>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<R, PROG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)sizeof(ChainLds<R>));
     if (e != hipSuccess) { set_error("chain: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     done = true;
   }
-  hipLaunchKernelGGL(chain_kernel<R>, dim3((k.M + R - 1) / R), dim3(CH_NT), sizeof(ChainLds<R>), s, k);
+  hipLaunchKernelGGL((chain_kernel<R, PROG>), dim3((k.M + R - 1) / R), dim3(CH_NT), sizeof(ChainLds<R>), s, k);
   return check_launch(what);
 }
 
-void init_k(ChainK& k) { memset(&k, 0, sizeof(k)); }
+void init_k(ChainK& k) {
+  memset(&k, 0, sizeof(k));
+  const char* e = getenv("TRANSCAR_CHAIN_DBG");
+  k.dbg = e ? atoi(e) : 0;
+}
 
 // Row-tile height (measured, bench.py --batch 1/2/4): the smallest tile that still
 // gives about one workgroup per CU wins -- 4 rows for B = 1 (225 workgroups), 8 for
 // B = 2, 16 beyond (each weight register then feeds 4 MFMAs).
-int launch(const ChainK& k, hipStream_t s, const char* what) {
+int tile_rows(int M) {
   const char* e = getenv("TRANSCAR_CHAIN_ROWS");
   const int forced = e ? atoi(e) : 0;
-  // The radar encoders run beside the decoder on a side stream and are not needed
-  // before the radar chain: they take the fewest workgroups (16-row tiles) so that the
-  // decoder's 225 workgroups still find a free CU each (225 + 64 > 256 CUs: the first
-  // decoder layer took 91 us instead of 69 next to a 4-row encoder grid).
-  const int rows = forced ? forced
-                   : k.program == PROG_RADAR_ENC ? 16 : (k.M <= 1024 ? 4 : k.M <= 2048 ? 8 : 16);
-  if (rows == 4) return launch_r<4>(k, s, what);
-  if (rows == 8) return launch_r<8>(k, s, what);
-  return launch_r<16>(k, s, what);
+  return forced ? forced : (M <= 1024 ? 4 : M <= 2048 ? 8 : 16);
+}
+
+template <int PROG>
+int launch_rows(const ChainK& k, hipStream_t s, const char* what) {
+  const int rows = tile_rows(k.M);
+  if (rows == 4) return launch_r<4, PROG>(k, s, what);
+  if (rows == 8) return launch_r<8, PROG>(k, s, what);
+  return launch_r<16, PROG>(k, s, what);
+}
+
+int launch(const ChainK& k, hipStream_t s, const char* what) {
+  switch (k.program) {
+    case PROG_DECODER: return launch_rows<PROG_DECODER>(k, s, what);
+    case PROG_RADAR: return launch_rows<PROG_RADAR>(k, s, what);
+    // the prologue runs once per checkpoint on Q rows (tc_head_pack_weights); stand-alone radar
+    // encoders take the fewest workgroups (16-row tiles): 225 + 64 workgroups of 4-row tiles
+    // did not fit 256 CUs next to a decoder layer
+    case PROG_PROLOGUE: return launch_r<4, PROG_PROLOGUE>(k, s, what);
+    default: return launch_r<16, PROG_RADAR_ENC>(k, s, what);
+  }
 }
 
 }  // namespace
@@ -1085,9 +1142,7 @@ int launch_decoder_chain_with_encoders(const DecoderChainArgs& d, const RadarEnc
   if (rc != 0) return rc;
   rc = make_radar_enc_k(e, ke);
   if (rc != 0) return rc;
-  const char* env = getenv("TRANSCAR_CHAIN_ROWS");
-  const int forced = env ? atoi(env) : 0;
-  const int rows = forced ? forced : (kd.M <= 1024 ? 4 : kd.M <= 2048 ? 8 : 16);
+  const int rows = tile_rows(kd.M);
   if (rows == 4) return launch_dual_r<4, 16>(kd, ke, s, "chain(decoder + radar_encode)");
   if (rows == 8) return launch_dual_r<8, 16>(kd, ke, s, "chain(decoder + radar_encode)");
   return launch_dual_r<16, 16>(kd, ke, s, "chain(decoder + radar_encode)");
