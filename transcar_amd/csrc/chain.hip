@@ -120,7 +120,7 @@ enum Flags : short {
 // global tensors, indices into ChainK::g
 enum GSel : short {
   G_NONE = -1, G_HS = 0, G_QK, G_VT, G_INITREF, G_ATTN_O, G_XIN, G_POS, G_CLS, G_KV0, G_KV1, G_KV2,
-  G_QF, G_COUNT
+  G_QF, G_RFEAT, G_COUNT
 };
 
 struct StepDesc {
@@ -172,6 +172,25 @@ __constant__ StepDesc PROG_RADAR_ENC_T[] = {
     {K_LINEAR, 8, -1, 256, 512, B_X, B_NONE, B_NONE, B_NONE, 0, 0, G_KV1, G_NONE, 0},
     {K_LINEAR, 9, -1, 256, 512, B_X, B_NONE, B_NONE, B_NONE, 0, 0, G_KV2, G_NONE, 0},
     {K_END, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
+// The encoders in two halves, carried by the launches of decoder layers 0 and 1 (16 workgroups of
+// 16-row tiles each): as one program they ran 70 us beside a 58 us decoder layer and set its
+// duration.  Half A: encoders + K/V of radar layer 0, encoded tokens to global; half B: K/V of
+// radar layers 1 and 2.
+__constant__ StepDesc PROG_RADAR_ENC_A_T[] = {
+    {K_TOKENS, 0, 0, 0, 0, B_NONE, B_NONE, B_A, B_NONE, 0, 0, G_NONE, G_NONE, 1},
+    {K_POSENC, 0, 1, 0, 0, B_A, B_NONE, B_T, B_NONE, 0, 0, G_NONE, G_NONE, 0},
+    {K_LINEAR, 4, -1, 36, 64, B_A, B_NONE, B_R, B_NONE, 1, 0, G_NONE, G_NONE, 1},
+    {K_LINEAR, 2, -1, 256, 256, B_T, B_NONE, B_U, B_NONE, 0, 0, G_NONE, G_NONE, 0},
+    {K_LINEAR, 5, -1, 64, 128, B_R, B_NONE, B_X, B_NONE, 1, 0, G_NONE, G_NONE, 1},
+    {K_LINEAR, 6, -1, 128, 256, B_X, B_NONE, B_P, B_NONE, 1, 0, G_NONE, G_NONE, 1},
+    {K_LN, 3, -1, 0, 0, B_U, B_NONE, B_X, B_P, 0, F_LN_RELU, G_RFEAT, G_NONE, 1},
+    {K_LINEAR, 7, -1, 256, 512, B_X, B_NONE, B_NONE, B_NONE, 0, 0, G_KV0, G_NONE, 0},
+    {K_END, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
+__constant__ StepDesc PROG_RADAR_ENC_B_T[] = {
+    {K_LOAD, 0, 0, 0, 0, B_NONE, B_NONE, B_X, B_NONE, 0, 0, G_RFEAT, G_NONE, 1},
+    {K_LINEAR, 8, -1, 256, 512, B_X, B_NONE, B_NONE, B_NONE, 0, 0, G_KV1, G_NONE, 0},
+    {K_LINEAR, 9, -1, 256, 512, B_X, B_NONE, B_NONE, B_NONE, 0, 0, G_KV2, G_NONE, 0},
+    {K_END, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
 // radar layer pairs (+14*r): 0 attn.in_proj 1 attn.out_proj 2 norm2 3 linear1 4 linear2 5 norm3
 //   6 cls.0 7 cls.n1 8 cls.3 9 cls.n4 10 cls.6 11 reg.0 12 reg.2 13 reg.4
 __constant__ StepDesc PROG_RADAR_LAYER_T[] = {
@@ -194,7 +213,7 @@ __constant__ StepDesc PROG_RADAR_LAYER_T[] = {
     {K_BOXADD, 0, 0, 0, 0, B_L, B_NONE, B_NONE, B_NONE, 0, 0, G_NONE, G_NONE, 1},
     {K_END, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
 
-enum Program : int { PROG_PROLOGUE = 0, PROG_DECODER, PROG_RADAR_ENC, PROG_RADAR };
+enum Program : int { PROG_PROLOGUE = 0, PROG_DECODER, PROG_RADAR_ENC, PROG_RADAR, PROG_RADAR_ENC_A, PROG_RADAR_ENC_B };
 constexpr int MAX_PAIRS = 48;
 constexpr int RADAR_PAIRS = 14;
 
@@ -583,7 +602,9 @@ __device__ __forceinline__ void chain_body(const ChainK& k, const int block) {
   const int M = k.M;
   const StepDesc* table = PROG == PROG_DECODER ? PROG_DECODER_T
                           : PROG == PROG_PROLOGUE ? PROG_PROLOGUE_T
-                          : PROG == PROG_RADAR_ENC ? PROG_RADAR_ENC_T : PROG_RADAR_LAYER_T;
+                          : PROG == PROG_RADAR_ENC ? PROG_RADAR_ENC_T
+                          : PROG == PROG_RADAR_ENC_A ? PROG_RADAR_ENC_A_T
+                          : PROG == PROG_RADAR_ENC_B ? PROG_RADAR_ENC_B_T : PROG_RADAR_LAYER_T;
   const int nrep = PROG == PROG_RADAR ? k.nlayers : 1;
   if (k.dbg & 64) return;
   START_STAMP(40);
@@ -596,6 +617,8 @@ __device__ __forceinline__ void chain_body(const ChainK& k, const int block) {
   constexpr int nsteps = PROG == PROG_DECODER ? (int)(sizeof(PROG_DECODER_T) / sizeof(StepDesc)) - 1
                          : PROG == PROG_PROLOGUE ? (int)(sizeof(PROG_PROLOGUE_T) / sizeof(StepDesc)) - 1
                          : PROG == PROG_RADAR_ENC ? (int)(sizeof(PROG_RADAR_ENC_T) / sizeof(StepDesc)) - 1
+                         : PROG == PROG_RADAR_ENC_A ? (int)(sizeof(PROG_RADAR_ENC_A_T) / sizeof(StepDesc)) - 1
+                         : PROG == PROG_RADAR_ENC_B ? (int)(sizeof(PROG_RADAR_ENC_B_T) / sizeof(StepDesc)) - 1
                                                   : (int)(sizeof(PROG_RADAR_LAYER_T) / sizeof(StepDesc)) - 1;
   const int total = nsteps * nrep;
   // The leading global-to-LDS loads of a program (a decoder layer starts with three) are
@@ -823,7 +846,7 @@ __device__ __forceinline__ void chain_body(const ChainK& k, const int block) {
     const StepRes r = load_step(S.sres[idx]);
     const int rep = r.rep;
     switch (kind) {
-      case K_LOAD: { if constexpr (PROG == PROG_DECODER || PROG == PROG_PROLOGUE) {
+      case K_LOAD: { if constexpr (PROG == PROG_DECODER || PROG == PROG_PROLOGUE || PROG == PROG_RADAR_ENC_B) {
         // this and the directly following K_LOAD steps (the decoder starts with three) go
         // out together: one memory latency instead of three, one barrier
         constexpr int MAXL = 3, RW = (R + CH_NW - 1) / CH_NW;
@@ -864,7 +887,7 @@ __device__ __forceinline__ void chain_body(const ChainK& k, const int block) {
         continue;
       }
       } break;
-      case K_TOKENS: { if constexpr (PROG == PROG_RADAR_ENC) {   // radar token tile, zero padded to 64 columns
+      case K_TOKENS: { if constexpr (PROG == PROG_RADAR_ENC || PROG == PROG_RADAR_ENC_A) {   // radar token tile, zero padded to 64 columns
         for (int i = threadIdx.x; i < R * 64; i += CH_NT) {
           const int row = i >> 6, c = i & 63;
           const int grow = min(m0 + row, M - 1);
@@ -872,7 +895,7 @@ __device__ __forceinline__ void chain_body(const ChainK& k, const int block) {
         }
       } break;
       } break;
-      case K_POSENC: { if constexpr (PROG == PROG_DECODER || PROG == PROG_RADAR_ENC) {   // Linear(3,256) + LN + ReLU of inverse_sigmoid(ref) or of raw token xyz
+      case K_POSENC: { if constexpr (PROG == PROG_DECODER || PROG == PROG_RADAR_ENC || PROG == PROG_RADAR_ENC_A) {   // Linear(3,256) + LN + ReLU of inverse_sigmoid(ref) or of raw token xyz
         float* dst = buf_ptr<R>(S, r.dst);
         const bool skip0 = (r.flags & F_NOT_W0) != 0;      // wave 0 is busy with the narrow linear step before
         for (int row = skip0 ? wave - 1 : wave; row < R && row >= 0; row += skip0 ? CH_NW - 1 : CH_NW) {
@@ -982,24 +1005,24 @@ __global__ __launch_bounds__(CH_NT) void chain_kernel(ChainK k) {
 // encoders this way: as a branch of the hipGraph on a side stream, the fork and the join
 // each left a ~10 us hole in the replayed frame (profiles: rocprofv3 kernel trace).
 static_assert(2 * sizeof(ChainK) <= 3800, "two ChainK must fit the kernel argument segment");
-template <int RA, int RB>
+template <int RA, int RB, int PROGB>
 __global__ __launch_bounds__(CH_NT) void chain_dual_kernel(ChainK ka, ChainK kb, int na) {
   if ((int)blockIdx.x < na) chain_body<RA, PROG_DECODER>(ka, blockIdx.x);
-  else chain_body<RB, PROG_RADAR_ENC>(kb, (int)blockIdx.x - na);
+  else chain_body<RB, PROGB>(kb, (int)blockIdx.x - na);
 }
 
-template <int RA, int RB>
+template <int RA, int RB, int PROGB>
 int launch_dual_r(const ChainK& ka, const ChainK& kb, hipStream_t s, const char* what) {
   constexpr size_t lds = sizeof(ChainLds<RA>) > sizeof(ChainLds<RB>) ? sizeof(ChainLds<RA>) : sizeof(ChainLds<RB>);
   static bool done = false;
   if (!done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_dual_kernel<RA, RB>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_dual_kernel<RA, RB, PROGB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("chain: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     done = true;
   }
   const int na = (ka.M + RA - 1) / RA, nb = (kb.M + RB - 1) / RB;
-  hipLaunchKernelGGL((chain_dual_kernel<RA, RB>), dim3(na + nb), dim3(CH_NT), lds, s, ka, kb, na);
+  hipLaunchKernelGGL((chain_dual_kernel<RA, RB, PROGB>), dim3(na + nb), dim3(CH_NT), lds, s, ka, kb, na);
   return check_launch(what);
 }
 
@@ -1114,11 +1137,14 @@ int launch_decoder_chain(const DecoderChainArgs& a, hipStream_t s) {
   return launch(k, s, "chain(decoder)");
 }
 
-static int make_radar_enc_k(const RadarEncodeArgs& a, ChainK& k) {
+static int make_radar_enc_k(const RadarEncodeArgs& a, ChainK& k, int part = 0) {
   TC_REQUIRE(a.RI <= 64 && (a.RI & 3) == 0, "radar_encode: radar_in_dims=%d", a.RI);
   TC_REQUIRE(a.nlayers == TC_MAX_RADAR_LAYERS, "radar_encode: %d radar layers (3 supported)", a.nlayers);
   init_k(k);
-  k.program = PROG_RADAR_ENC; k.M = a.M; k.Q = 1; k.RI = a.RI; k.tokens = a.tokens; k.has_next = 1;
+  k.program = part == 1 ? PROG_RADAR_ENC_A : part == 2 ? PROG_RADAR_ENC_B : PROG_RADAR_ENC;
+  k.M = a.M; k.Q = 1; k.RI = a.RI; k.tokens = a.tokens; k.has_next = 1;
+  TC_REQUIRE(part == 0 || a.radar_feat != nullptr, "radar_encode: split programs need the radar_feat buffer");
+  k.g[G_RFEAT] = a.radar_feat; k.g_ld[G_RFEAT] = 256;
   k.pairs[0] = a.rpe.l0; k.pairs[1] = tc_linear{a.rpe.n1.g, a.rpe.n1.b}; k.pairs[2] = a.rpe.l3;
   k.pairs[3] = tc_linear{a.rpe.n4.g, a.rpe.n4.b}; k.pairs[4] = a.f0; k.pairs[5] = a.f2; k.pairs[6] = a.f4;
   for (int r = 0; r < TC_MAX_RADAR_LAYERS; ++r) {
@@ -1135,17 +1161,25 @@ int launch_radar_encode(const RadarEncodeArgs& a, hipStream_t s) {
   return launch(k, s, "chain(radar_encode)");
 }
 
-// a decoder layer and the radar encoders (16-row tiles) in one launch
-int launch_decoder_chain_with_encoders(const DecoderChainArgs& d, const RadarEncodeArgs& e, hipStream_t s) {
+// a decoder layer and (a part of) the radar encoders on 16-row tiles in one launch;
+// part 0: the whole encoder program, 1 / 2: its halves (PROG_RADAR_ENC_A / _B)
+int launch_decoder_chain_with_encoders(const DecoderChainArgs& d, const RadarEncodeArgs& e, int part,
+                                       hipStream_t s) {
   ChainK kd, ke;
   int rc = make_decoder_k(d, kd);
   if (rc != 0) return rc;
-  rc = make_radar_enc_k(e, ke);
+  rc = make_radar_enc_k(e, ke, part);
   if (rc != 0) return rc;
   const int rows = tile_rows(kd.M);
-  if (rows == 4) return launch_dual_r<4, 16>(kd, ke, s, "chain(decoder + radar_encode)");
-  if (rows == 8) return launch_dual_r<8, 16>(kd, ke, s, "chain(decoder + radar_encode)");
-  return launch_dual_r<16, 16>(kd, ke, s, "chain(decoder + radar_encode)");
+  const char* what = "chain(decoder + radar_encode)";
+#define TC_DUAL(RA)                                                                   \
+  (part == 1 ? launch_dual_r<RA, 16, PROG_RADAR_ENC_A>(kd, ke, s, what)               \
+   : part == 2 ? launch_dual_r<RA, 16, PROG_RADAR_ENC_B>(kd, ke, s, what)             \
+               : launch_dual_r<RA, 16, PROG_RADAR_ENC>(kd, ke, s, what))
+  if (rows == 4) return TC_DUAL(4);
+  if (rows == 8) return TC_DUAL(8);
+  return TC_DUAL(16);
+#undef TC_DUAL
 }
 
 int launch_radar_chain(const RadarChainArgs& a, hipStream_t s) {

@@ -188,7 +188,7 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
                                m.in_proj.b ? m.in_proj.b + C : nullptr};
       re.kv[r] = h.kv3[r];
     }
-    re.radar_feat = nullptr;
+    re.radar_feat = h.radar_feat;
   }
 
   // layer 0 up to its attention output is a constant of the checkpoint (pack time)
@@ -223,7 +223,10 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
     d.cam.img_h = img_h; d.cam.img_w = img_w; d.cam.out = nullptr; d.cam.vis = nullptr;
     d.cam.pair_counter = pairs;
     d.code = code; d.M = rows;
-    if (radar && lid == 0) TC_TRY(launch_decoder_chain_with_encoders(d, re, s));
+    // the radar encoders ride in the launches of layers 0 and 1, half each (all in layer 0
+    // when there is only one layer)
+    if (radar && lid == 0) TC_TRY(launch_decoder_chain_with_encoders(d, re, L > 1 ? 1 : 0, s));
+    else if (radar && lid == 1) TC_TRY(launch_decoder_chain_with_encoders(d, re, 2, s));
     else TC_TRY(launch_decoder_chain(d, s));
   }
   if (aux) {

@@ -106,7 +106,8 @@ struct RadarEncodeArgs {
 };
 int launch_radar_encode(const RadarEncodeArgs& a, hipStream_t s);
 // a decoder layer and the radar encoders as ONE launch (no side stream / graph branch)
-int launch_decoder_chain_with_encoders(const DecoderChainArgs& d, const RadarEncodeArgs& e, hipStream_t s);
+int launch_decoder_chain_with_encoders(const DecoderChainArgs& d, const RadarEncodeArgs& e, int part,
+                                       hipStream_t s);
 
 struct RadarChainArgs {
   const float* qf; const float* ref_last; const float* box_m;
