@@ -43,7 +43,7 @@ def label_chain(rows, num_layers=6):
     for r in rows:
         r['K'] = short(r['Kernel_Name'])
         if r['K'].startswith('chain_dual_kernel'):
-            r['K'] = 'chain_dual_kernel(decoder layer 0 + radar encoders)'
+            r['K'] = 'chain_dual_kernel(decoder layer + radar encoder half)'
     main_rows = []
     for r in rows:
         if r['K'].startswith('chain_kernel') and int(r['Grid_Size']) < 256 * 128:
@@ -52,8 +52,9 @@ def label_chain(rows, num_layers=6):
             main_rows.append(r)
     n_dec = 0
     for i, r in enumerate(main_rows):
-        if r['K'].startswith('chain_dual_kernel'):
-            n_dec = 1
+        if r['K'].startswith('chain_dual_kernel'):      # decoder layers 0 and 1 carry the radar encoders
+            prev = main_rows[i - 1]['K'] if i else ''
+            n_dec = n_dec + 1 if prev.startswith('self_attn') else 1
             continue
         if not r['K'].startswith('chain_kernel'):
             if 'box_decode' in r['K']:
