@@ -208,6 +208,52 @@ int run_sb(const float* W, float* out, int blocks, int nsteps, int S, int wrap) 
   return 0;
 }
 
+// interleaved, THREE buffers: item i computes while the loads of item i+2 are issued
+__global__ __launch_bounds__(256) void pipe_il3(const float* W, int nsteps, int S, int wrap, float* out) {
+  __shared__ float A[4][516];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 4 * 516; i += 256) (&A[0][0])[i] = 0.001f * i;
+  __syncthreads();
+  const float* arow = &A[lane & 3][0];
+  f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+  int item = wave * 7;
+  for (int st = 0; st < nsteps; ++st) {
+    WBuf w0, w1, w2;
+    auto src = [&](int i) { return W + (size_t)((item + (i < S ? i : S - 1)) % wrap) * 4096 + 4 * lane; };
+    wload(w0, src(0));
+    wload(w1, src(1));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+    for (int i = 0; i < S; i += 3) {
+      compute_il<1>(a0, a1, w0, w2, src(i + 2), arow + (i & 7) * 64);
+      __builtin_amdgcn_sched_barrier(0);
+      compute_il<1>(a0, a1, w1, w0, src(i + 3), arow + ((i + 1) & 7) * 64);
+      __builtin_amdgcn_sched_barrier(0);
+      compute_il<1>(a0, a1, w2, w1, src(i + 4), arow + ((i + 2) & 7) * 64);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    item += S;
+    __syncthreads();
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = a0[0] + a0[1] + a1[0] + a1[3];
+}
+int run_il3(const float* W, float* out, int blocks, int nsteps, int S, int wrap) {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  pipe_il3<<<blocks, 256>>>(W, nsteps, S, wrap, out);
+  CK(hipDeviceSynchronize());
+  float best = 1e9;
+  for (int it = 0; it < 5; ++it) {
+    CK(hipEventRecord(e0));
+    pipe_il3<<<blocks, 256>>>(W, nsteps, S, wrap, out);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+  }
+  const int items = nsteps * S;
+  printf("interleaved 3 buffers blocks=%3d steps=%3d x %2d items: %7.1f us, %6.0f ns/item = %5.0f cyc@2.4GHz\n",
+         blocks, nsteps, S, best * 1e3, best * 1e6 / items, best * 1e6 / items * 2.4);
+  return 0;
+}
+
 int main() {
   const int wrap = 200;   // 200 items x 16 KiB = 3.2 MB, one decoder layer's weights
   float *W, *out; long long* cyc;
@@ -229,6 +275,9 @@ int main() {
     run_il<1>(W, out, 225, 56 / S, S, wrap);
   }
   run_il<1>(W, out, 1, 1, 56, wrap);
+  run_il3(W, out, 225, 1, 57, wrap);
+  run_il3(W, out, 225, 7, 9, wrap);
+  run_il3(W, out, 225, 19, 3, wrap);
   for (int S : {4, 8, 56}) run_il<1>(W, out, 225, 56 / S, S, wrap, 1);
   for (int S : {4, 8, 56}) run_sb(W, out, 225, 56 / S, S, wrap);
   run_sb(W, out, 1, 1, 56, wrap);

@@ -546,8 +546,9 @@ class Detr3DHead(BaseModule):
     def loss(self, gt_bboxes_list, gt_labels_list, preds_dicts, gt_bboxes_ignore=None):
         """HEAD:919-1001.  gt boxes: objects with ``gravity_center`` / ``tensor``
         (mmdet3d LiDARInstance3DBoxes) or plain [n,9] gravity-centre tensors.
-        Forward value of the losses; the backward kernels of the radar stack
-        are the next row of the scope table."""
+        PyTorch ops exactly as in the reference (autograd differentiates them);
+        ``transcar_amd/device_loss.py`` computes the same values and their
+        gradients with three HIP launches and is what ``FusionTrainer`` uses."""
         assert gt_bboxes_ignore is None
         if self.assigner is None:
             raise L.TransCARHipError('loss() needs train_cfg=dict(assigner=...) at construction')

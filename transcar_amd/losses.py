@@ -3,8 +3,10 @@ CFG:95-114).  In the reference these are mmdet's ``FocalLoss`` /
 ``L1Loss`` / ``FocalLossCost`` (un-vendored third party) and the plugin's own
 ``BBox3DL1Cost`` (match_cost.py:15-26): small elementwise reductions over
 [900,10] tensors that run in PyTorch in the reference as well, followed by a
-host-side Hungarian match -- host/PyTorch by design (SURVEY.md section 8, row
-a16), not a kernel target.
+host-side Hungarian match.  This module keeps
+the reference's formulation for ``Detr3DHead.loss`` (drop-in semantics, torch
+autograd); the device-side equivalent with closed-form gradients is
+``transcar_amd/device_loss.py`` over ``csrc/loss.hip`` (row f4).
 """
 import torch
 import torch.distributed as dist
