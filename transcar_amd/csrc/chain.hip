@@ -60,7 +60,7 @@ constexpr int LD5 = 516;   // 512 + 4 floats
 constexpr int LD2 = 260;   // 256 + 4
 constexpr int LDL = 36;
 
-// a step of the table with every pointer / size resolved (built once per workgroup)
+// a step of the table with every pointer / size resolved (built once per launch, on the host)
 struct StepRes {
   const float* p0; const float* p1; const float* p2; const float* p3;   // linear: W, bias; LN: g, b, g2, b2
   float* gd; float* gt;          // global destination (source for K_LOAD) / transposed destination
@@ -79,13 +79,22 @@ struct EpiRec {
 };
 // per wave: the next linear step of the same run in which the wave owns a column tile
 struct PreRec { const float* first; int nidx; int pad; };
-constexpr int MAX_STEPS = 64;
+// One step, resolved ON THE HOST at launch time and handed over in the kernel-argument
+// segment; the workgroup copies the records to LDS with one round of parallel vector loads
+// and reads a step from there (ds_read + v_readfirstlane into SGPRs).  Measured
+// alternatives: resolved by the workgroup itself (table in constant memory -> kernel
+// arguments -> LDS records) every launch began with ~9400 cycles of dependent loads, 4 us
+// of a 56 us decoder layer; read per step with scalar loads straight from the
+// kernel-argument segment, every step paid 400-800 cycles of scalar-cache misses (+6 us).
+struct StepAll { StepRes r; EpiRec e; PreRec p[CH_NW]; };
+static_assert(sizeof(StepAll) % 16 == 0, "records are copied 16 bytes at a time");
+template <int N> struct Recs { StepAll s[N]; };
+
+constexpr int MAX_RECS = 48;     // 16 radar steps x 3 layers
 
 template <int R>
 struct ChainLds {
-  StepRes sres[MAX_STEPS];
-  EpiRec epi[MAX_STEPS];
-  PreRec pre[MAX_STEPS][CH_NW];
+  StepAll recs[MAX_RECS];
   float a[R][LD5];
   float x[R][LD2];
   float r[R][LD2];
@@ -129,7 +138,7 @@ struct StepDesc {
 //   kind      wp wp2   K    N        src   src2    dst    res  act flags gsel gtsel sync
 // decoder layer pairs: 0 in_proj 1 out_proj 2 norm0 3 attw 4 output_proj 5 pe.l0 6 pe.n1 7 pe.l3
 //   8 pe.n4 9 norm1 10 ffn0 11 ffn1 12 norm2 13 reg.l0 14 reg.l2 15 reg.l4 ; 16 next in_proj
-__constant__ StepDesc PROG_DECODER_T[] = {
+constexpr StepDesc PROG_DECODER_T[] = {
     {K_LOAD, 0, 0, 0, 0, B_NONE, B_NONE, B_T, B_NONE, 0, 0, G_ATTN_O, G_NONE, 0},
     {K_LOAD, 0, 0, 0, 0, B_NONE, B_NONE, B_X, B_NONE, 0, 0, G_XIN, G_NONE, 0},
     {K_LOAD, 0, 0, 0, 0, B_NONE, B_NONE, B_P, B_NONE, 0, 0, G_POS, G_NONE, 1},
@@ -152,7 +161,7 @@ __constant__ StepDesc PROG_DECODER_T[] = {
     {K_REFUPD, 0, 0, 0, 0, B_L, B_NONE, B_NONE, B_NONE, 0, 0, G_NONE, G_NONE, 0},
     {K_END, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
 // prologue pairs: 0 reference_points 16 layer-0 in_proj
-__constant__ StepDesc PROG_PROLOGUE_T[] = {
+constexpr StepDesc PROG_PROLOGUE_T[] = {
     {K_LOAD, 0, 0, 0, 0, B_NONE, B_NONE, B_P, B_NONE, 0, 0, G_POS, G_NONE, 0},
     {K_LOAD, 0, 0, 0, 0, B_NONE, B_NONE, B_X, B_NONE, 0, 0, G_XIN, G_NONE, 1},
     {K_LINEAR, 0, -1, 256, 3, B_P, B_NONE, B_NONE, B_NONE, 2, 0, G_INITREF, G_NONE, 0},
@@ -160,7 +169,7 @@ __constant__ StepDesc PROG_PROLOGUE_T[] = {
     {K_LINEAR, 16, -1, 256, 256, B_X, B_NONE, B_NONE, B_NONE, 0, F_WOFF, G_NONE, G_VT, 0},
     {K_END, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
 // radar encoder pairs: 0 rpe.l0 1 rpe.n1 2 rpe.l3 3 rpe.n4 4 f0 5 f2 6 f4 7..9 kv proj of layer 0..2
-__constant__ StepDesc PROG_RADAR_ENC_T[] = {
+constexpr StepDesc PROG_RADAR_ENC_T[] = {
     {K_TOKENS, 0, 0, 0, 0, B_NONE, B_NONE, B_A, B_NONE, 0, 0, G_NONE, G_NONE, 1},
     {K_POSENC, 0, 1, 0, 0, B_A, B_NONE, B_T, B_NONE, 0, 0, G_NONE, G_NONE, 0},            // raw xyz from the tile
     {K_LINEAR, 4, -1, 36, 64, B_A, B_NONE, B_R, B_NONE, 1, 0, G_NONE, G_NONE, 1},         // feat.0 (K = RI)
@@ -176,7 +185,7 @@ __constant__ StepDesc PROG_RADAR_ENC_T[] = {
 // 16-row tiles each): as one program they ran 70 us beside a 58 us decoder layer and set its
 // duration.  Half A: encoders + K/V of radar layer 0, encoded tokens to global; half B: K/V of
 // radar layers 1 and 2.
-__constant__ StepDesc PROG_RADAR_ENC_A_T[] = {
+constexpr StepDesc PROG_RADAR_ENC_A_T[] = {
     {K_TOKENS, 0, 0, 0, 0, B_NONE, B_NONE, B_A, B_NONE, 0, 0, G_NONE, G_NONE, 1},
     {K_POSENC, 0, 1, 0, 0, B_A, B_NONE, B_T, B_NONE, 0, 0, G_NONE, G_NONE, 0},
     {K_LINEAR, 4, -1, 36, 64, B_A, B_NONE, B_R, B_NONE, 1, 0, G_NONE, G_NONE, 1},
@@ -186,14 +195,14 @@ __constant__ StepDesc PROG_RADAR_ENC_A_T[] = {
     {K_LN, 3, -1, 0, 0, B_U, B_NONE, B_X, B_P, 0, F_LN_RELU, G_RFEAT, G_NONE, 1},
     {K_LINEAR, 7, -1, 256, 512, B_X, B_NONE, B_NONE, B_NONE, 0, 0, G_KV0, G_NONE, 0},
     {K_END, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
-__constant__ StepDesc PROG_RADAR_ENC_B_T[] = {
+constexpr StepDesc PROG_RADAR_ENC_B_T[] = {
     {K_LOAD, 0, 0, 0, 0, B_NONE, B_NONE, B_X, B_NONE, 0, 0, G_RFEAT, G_NONE, 1},
     {K_LINEAR, 8, -1, 256, 512, B_X, B_NONE, B_NONE, B_NONE, 0, 0, G_KV1, G_NONE, 0},
     {K_LINEAR, 9, -1, 256, 512, B_X, B_NONE, B_NONE, B_NONE, 0, 0, G_KV2, G_NONE, 0},
     {K_END, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
 // radar layer pairs (+14*r): 0 attn.in_proj 1 attn.out_proj 2 norm2 3 linear1 4 linear2 5 norm3
 //   6 cls.0 7 cls.n1 8 cls.3 9 cls.n4 10 cls.6 11 reg.0 12 reg.2 13 reg.4
-__constant__ StepDesc PROG_RADAR_LAYER_T[] = {
+constexpr StepDesc PROG_RADAR_LAYER_T[] = {
     {K_LINEAR, 0, -1, 256, 256, B_X, B_NONE, B_T, B_NONE, 0, F_SCALEQ, G_NONE, G_NONE, 1},   // q projection
     {K_RADAR_ATTN, 0, 0, 0, 0, B_T, B_NONE, B_U, B_NONE, 0, 0, G_NONE, G_NONE, 1},
     {K_LINEAR, 1, -1, 256, 256, B_U, B_NONE, B_R, B_X, 0, F_GATE, G_NONE, G_NONE, 1},        // x + gate*out_proj
@@ -217,9 +226,10 @@ enum Program : int { PROG_PROLOGUE = 0, PROG_DECODER, PROG_RADAR_ENC, PROG_RADAR
 constexpr int MAX_PAIRS = 48;
 constexpr int RADAR_PAIRS = 14;
 
-struct ChainK {
+// what the device reads ...
+struct ChainDev {
   int program, M, Q, code, ncls, nlogits, has_next, nlayers;
-  tc_linear pairs[MAX_PAIRS];
+  int total, early_n;          // resolved steps; leading K_LOAD steps (issued before anything else)
   float* g[G_COUNT]; int g_ld[G_COUNT]; int g_mod[G_COUNT];   // global tensors by GSel
   float qscale; int qpad;
   int dbg;                     // TRANSCAR_CHAIN_DBG (timing experiments only: wrong results)
@@ -232,6 +242,27 @@ struct ChainK {
   float rmin[TC_MAX_RADAR_LAYERS], rmax[TC_MAX_RADAR_LAYERS];
   float* all_box; int* hits;
 };
+// ... plus what only the host-side resolver needs
+struct ChainK : ChainDev {
+  tc_linear pairs[MAX_PAIRS];
+};
+
+constexpr int table_steps(int prog) {
+  return (prog == PROG_DECODER ? (int)(sizeof(PROG_DECODER_T) / sizeof(StepDesc))
+          : prog == PROG_PROLOGUE ? (int)(sizeof(PROG_PROLOGUE_T) / sizeof(StepDesc))
+          : prog == PROG_RADAR_ENC ? (int)(sizeof(PROG_RADAR_ENC_T) / sizeof(StepDesc))
+          : prog == PROG_RADAR_ENC_A ? (int)(sizeof(PROG_RADAR_ENC_A_T) / sizeof(StepDesc))
+          : prog == PROG_RADAR_ENC_B ? (int)(sizeof(PROG_RADAR_ENC_B_T) / sizeof(StepDesc))
+                                     : (int)(sizeof(PROG_RADAR_LAYER_T) / sizeof(StepDesc))) - 1;
+}
+constexpr int rec_cap(int prog) { return table_steps(prog) * (prog == PROG_RADAR ? TC_MAX_RADAR_LAYERS : 1); }
+inline const StepDesc* prog_table(int prog) {
+  return prog == PROG_DECODER ? PROG_DECODER_T
+         : prog == PROG_PROLOGUE ? PROG_PROLOGUE_T
+         : prog == PROG_RADAR_ENC ? PROG_RADAR_ENC_T
+         : prog == PROG_RADAR_ENC_A ? PROG_RADAR_ENC_A_T
+         : prog == PROG_RADAR_ENC_B ? PROG_RADAR_ENC_B_T : PROG_RADAR_LAYER_T;
+}
 
 __device__ __forceinline__ float comp4(const float4& v, int i) {
   return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w;
@@ -576,7 +607,6 @@ __device__ __forceinline__ T load_uniform(const T& src) {
   for (int i = 0; i < NWORDS; ++i) u.w[i] = __builtin_amdgcn_readfirstlane(p[i]);
   return u.r;
 }
-__device__ __forceinline__ StepRes load_step(const StepRes& src) { return load_uniform<StepRes>(src); }
 
 #ifdef TC_CHAIN_STAMPS
 #define START_STAMP(slot)                                                                     \
@@ -593,137 +623,65 @@ __device__ __forceinline__ StepRes load_step(const StepRes& src) { return load_u
 // bodies -- and a kernel with a private segment costs ~13 us more PER LAUNCH on this
 // platform: 15.4 us for an immediately returning launch in a replayed graph vs 2.)
 template <int R, int PROG>
-__device__ __forceinline__ void chain_body(const ChainK& k, const int block) {
+__device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __restrict__ recs, const int block) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   ChainLds<R>& S = *reinterpret_cast<ChainLds<R>*>(smem_raw);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int m0 = block * R;
+  // The records, kernel-argument segment -> registers (-> LDS below): issued before anything
+  // depends on a kernel argument -- the first touch of the segment costs ~2600 cycles, and
+  // this way the copy and the scalar loads of the arguments share that one latency.
+  constexpr int REC16 = rec_cap(PROG) * (int)(sizeof(StepAll) / 16);
+  constexpr int REC_TRIPS = (REC16 + CH_NT - 1) / CH_NT;
+  int4 rec_v[REC_TRIPS];
+#pragma unroll
+  for (int t = 0; t < REC_TRIPS; ++t) {
+    const int i = threadIdx.x + t * CH_NT;
+    if (i < REC16) rec_v[t] = reinterpret_cast<const int4*>(recs)[i];
+  }
   const int M = k.M;
-  const StepDesc* table = PROG == PROG_DECODER ? PROG_DECODER_T
-                          : PROG == PROG_PROLOGUE ? PROG_PROLOGUE_T
-                          : PROG == PROG_RADAR_ENC ? PROG_RADAR_ENC_T
-                          : PROG == PROG_RADAR_ENC_A ? PROG_RADAR_ENC_A_T
-                          : PROG == PROG_RADAR_ENC_B ? PROG_RADAR_ENC_B_T : PROG_RADAR_LAYER_T;
-  const int nrep = PROG == PROG_RADAR ? k.nlayers : 1;
   if (k.dbg & 64) return;
   START_STAMP(40);
-
-  // ---- resolve the step table once: every later step reads one LDS record instead
-  // of chasing constant memory -> kernel arguments -> weights (1200-1850 cycles of
-  // dependent scalar loads per step, measured)
-  // table length: a compile-time constant per program (scanning for K_END cost ~20 dependent
-  // constant-memory round trips, several microseconds at every kernel start)
-  constexpr int nsteps = PROG == PROG_DECODER ? (int)(sizeof(PROG_DECODER_T) / sizeof(StepDesc)) - 1
-                         : PROG == PROG_PROLOGUE ? (int)(sizeof(PROG_PROLOGUE_T) / sizeof(StepDesc)) - 1
-                         : PROG == PROG_RADAR_ENC ? (int)(sizeof(PROG_RADAR_ENC_T) / sizeof(StepDesc)) - 1
-                         : PROG == PROG_RADAR_ENC_A ? (int)(sizeof(PROG_RADAR_ENC_A_T) / sizeof(StepDesc)) - 1
-                         : PROG == PROG_RADAR_ENC_B ? (int)(sizeof(PROG_RADAR_ENC_B_T) / sizeof(StepDesc)) - 1
-                                                  : (int)(sizeof(PROG_RADAR_LAYER_T) / sizeof(StepDesc)) - 1;
-  const int total = nsteps * nrep;
-  // The leading global-to-LDS loads of a program (a decoder layer starts with three) are
-  // issued before the table is resolved: their latency and the resolution overlap.
+  const int total = k.total;
+  // The leading global-to-LDS loads of a program (a decoder layer starts with three) go out
+  // together: one memory latency, one barrier.
   constexpr int EARLY_MAX = 3, EARLY_RW = (R + CH_NW - 1) / CH_NW;
-  float4 early_v[EARLY_MAX][EARLY_RW];
-  int early_n = 0;
-  while (early_n < EARLY_MAX && early_n < nsteps && table[early_n].kind == K_LOAD) ++early_n;
+  const int early_n = k.early_n;
+  {
+    float4 early_v[EARLY_MAX][EARLY_RW];
 #pragma unroll
-  for (int j = 0; j < EARLY_MAX; ++j) {
-    if (j < early_n) {
-      const StepDesc d = table[j];
-      const float* gsrc = k.g[d.gsel];
-      const int ld = k.g_ld[d.gsel], mod = k.g_mod[d.gsel];
+    for (int j = 0; j < EARLY_MAX; ++j) {
+      if (j < early_n) {
+        const float* gsrc = recs[j].r.gd;
+        const int ld = recs[j].r.gld, mod = recs[j].r.gmod;
 #pragma unroll
-      for (int ri = 0; ri < EARLY_RW; ++ri) {
-        int grow = min(m0 + wave + ri * CH_NW, M - 1);
-        if (mod > 0) grow = grow % mod;
-        early_v[j][ri] = ld4(gsrc + (size_t)grow * ld + 4 * lane);
+        for (int ri = 0; ri < EARLY_RW; ++ri) {
+          int grow = min(m0 + wave + ri * CH_NW, M - 1);
+          if (mod > 0) grow = grow % mod;
+          early_v[j][ri] = ld4(gsrc + (size_t)grow * ld + 4 * lane);
+        }
+      }
+    }
+    START_STAMP(41);
+#pragma unroll
+    for (int j = 0; j < EARLY_MAX; ++j) {
+      if (j < early_n) {
+        float* dst = reinterpret_cast<float*>(smem_raw) + recs[j].e.dst_off;
+#pragma unroll
+        for (int ri = 0; ri < EARLY_RW; ++ri) {
+          const int row = wave + ri * CH_NW;
+          if (row < R) *reinterpret_cast<float4*>(dst + row * LD2 + 4 * lane) = early_v[j][ri];
+        }
       }
     }
   }
-  START_STAMP(41);
-  for (int idx = threadIdx.x; idx < total; idx += CH_NT) {
-    const int rep = idx / nsteps, si = idx - rep * nsteps;
-    const int pair0 = PROG == PROG_RADAR ? rep * RADAR_PAIRS : 0;
-    const StepDesc d = table[si];
-    StepRes r;
-    r.p0 = r.p1 = r.p2 = r.p3 = nullptr; r.gd = r.gt = nullptr;
-    r.K = d.K; r.N = d.N; r.gld = 0; r.gmod = 0;
-    r.kind = d.kind; r.src = d.src; r.src2 = d.src2; r.dst = d.dst; r.res = d.res; r.act = d.act;
-    r.flags = d.flags; r.sync = d.sync; r.rep = (short)rep; r.si = (short)si;
-    if ((d.flags & F_SKIP_NONEXT) && !k.has_next) r.kind = K_NOP;
-    if (d.gsel != G_NONE) { r.gd = k.g[d.gsel]; r.gld = k.g_ld[d.gsel]; r.gmod = k.g_mod[d.gsel]; }
-    if (d.gtsel != G_NONE) r.gt = k.g[d.gtsel];
-    if (d.kind == K_LINEAR) {
-      const tc_linear pr = k.pairs[pair0 + d.wp];
-      r.K = d.K == 36 ? k.RI : d.K;
-      r.N = d.N == N_LOGITS ? k.nlogits : d.N == N_CODE ? k.code : d.N == N_CLS ? k.ncls : d.N;
-      const int woff = (d.flags & F_WOFF) ? 512 : 0;
-      r.p0 = pr.w + (size_t)woff * ((r.K + 63) & ~63);   // packed: a 64-row tile = 64 * kpad floats
-      r.p1 = pr.b ? pr.b + woff : nullptr;
-      if (d.gsel == G_CLS) r.gd += (size_t)rep * M * k.ncls;
-    } else if (d.kind == K_LN || d.kind == K_POSENC) {
-      const tc_linear n = k.pairs[pair0 + d.wp];
-      r.p0 = n.w; r.p1 = n.b;
-      if (d.kind == K_POSENC || d.src2 != B_NONE) {
-        const tc_linear n2 = k.pairs[pair0 + d.wp2];
-        r.p2 = n2.w; r.p3 = n2.b;
-      }
-    }
-    {
-      const float* base0 = reinterpret_cast<const float*>(smem_raw);
-      const float* sp = buf_ptr<R>(S, r.src);
-      const float* sp2 = buf_ptr<R>(S, r.src2);
-      r.src_off = sp ? (int)(sp - base0) : -1;
-      r.src2_off = sp2 ? (int)(sp2 - base0) : -1;
-      r.pad_ = 0;
-    }
-    S.sres[idx] = r;
-    EpiRec e;
-    e.gd = r.gd; e.gt = r.gt; e.gld = r.gld; e.act = r.act; e.flags = r.flags; e.N = r.N;
-    e.has_bias = r.p1 != nullptr; e.woff = (r.flags & F_WAVE1) ? 1 : 0; e.pad0 = e.pad1 = 0;
-    const float* base = reinterpret_cast<const float*>(smem_raw);
-    const float* dp = buf_ptr<R>(S, r.dst);
-    const float* rp = buf_ptr<R>(S, r.res);
-    e.dst_off = dp ? (int)(dp - base) : -1; e.dst_ld = buf_ld(r.dst);
-    e.res_off = rp ? (int)(rp - base) : -1; e.res_ld = buf_ld(r.res);
-    S.epi[idx] = e;
-  }
-  START_STAMP(42);
 #pragma unroll
-  for (int j = 0; j < EARLY_MAX; ++j) {
-    if (j < early_n) {
-      float* dst = buf_ptr<R>(S, table[j].dst);
-#pragma unroll
-      for (int ri = 0; ri < EARLY_RW; ++ri) {
-        const int row = wave + ri * CH_NW;
-        if (row < R) *reinterpret_cast<float4*>(dst + row * LD2 + 4 * lane) = early_v[j][ri];
-      }
-    }
+  for (int t = 0; t < REC_TRIPS; ++t) {
+    const int i = threadIdx.x + t * CH_NT;
+    if (i < REC16) reinterpret_cast<int4*>(&S.recs[0])[i] = rec_v[t];
   }
   START_STAMP(43);
-  __syncthreads();
-  START_STAMP(44);
-  // per (step, wave): the next linear step inside the same run of light steps where the
-  // wave owns a column tile, and that step's first weight item
-  for (int t = threadIdx.x; t < total * CH_NW; t += CH_NT) {
-    const int idx = t / CH_NW, w = t - idx * CH_NW;
-    PreRec pr;
-    pr.first = nullptr; pr.nidx = -1; pr.pad = 0;
-    for (int j = idx + 1; j < total; ++j) {
-      const int kind = S.sres[j].kind;
-      if (kind == K_LN || kind == K_NOP) continue;
-      if (kind != K_LINEAR) break;
-      const int N = S.sres[j].N, K = S.sres[j].K;
-      const int vw = (w - ((S.sres[j].flags & F_WAVE1) ? 1 : 0)) & (CH_NW - 1);
-      if (vw >= ((N + 63) >> 6)) continue;
-      pr.nidx = j;
-      pr.first = S.sres[j].p0 + (size_t)vw * 64 * ((K + 63) & ~63);
-      break;
-    }
-    S.pre[idx][w] = pr;
-  }
-  START_STAMP(45);
 
   if (PROG == PROG_RADAR) {     // HEAD:539, 543-547, 596-598
     for (int row = wave; row < R; row += CH_NW) {
@@ -785,7 +743,7 @@ __device__ __forceinline__ void chain_body(const ChainK& k, const int block) {
   };
   // ... and the part its epilogue needs, rebuilt per tile from the 64-byte LDS record
   auto epi_spec = [&](int j) {
-    const EpiRec e = load_uniform<EpiRec>(S.epi[j]);
+    const EpiRec e = load_uniform<EpiRec>(S.recs[j].e);
     float* base = reinterpret_cast<float*>(smem_raw);
     LinSpec s;
     s.K = 0; s.N = e.N; s.W = nullptr;
@@ -811,23 +769,23 @@ __device__ __forceinline__ void chain_body(const ChainK& k, const int block) {
 #endif
 #pragma unroll 1
   while (idx < total) {
-    const int kind = ufirst(S.sres[idx].kind);
+    const int kind = ufirst(S.recs[idx].r.kind);
     if (kind == K_LINEAR || kind == K_LN || kind == K_NOP) {
       // ---- a run of linear / LayerNorm steps: the weight pipeline stays primed across them
       WBuf w0;
       int pre_idx = -1;                      // step whose first item is in flight in w0
 #pragma unroll 1
       for (;;) {
-        const StepRes r = load_step(S.sres[idx]);
+        const StepRes r = load_uniform<StepRes>(S.recs[idx].r);
         const int kd = r.kind;
         if (kd == K_LINEAR) {
           LinSpec s = lin_spec(r);
 #ifdef TC_CHAIN_STAMPS
-          s.sub_on = (ufirst(r.si) == g_sub_step && ufirst(r.rep) == 0);
+          s.sub_on = (r.si == g_sub_step && r.rep == 0);
           SUB_STAMP(0);
 #endif
           if (((wave - s.woff) & (CH_NW - 1)) < ((s.N + 63) >> 6)) {   // else: no column tile here, w0 keeps waiting
-            const PreRec pr = load_uniform<PreRec>(S.pre[idx][wave]);
+            const PreRec pr = load_uniform<PreRec>(S.recs[idx].p[wave]);
             const bool have = linear_step<R>(s, w0, pre_idx == idx, pr.first, epi_spec, idx);
             pre_idx = have ? pr.nidx : -1;
           }
@@ -837,13 +795,13 @@ __device__ __forceinline__ void chain_body(const ChainK& k, const int block) {
           break;
         }
         STEP_STAMP();
-        if (ufirst(r.sync) && !(k.dbg & 2)) __syncthreads();
+        if (r.sync && !(k.dbg & 2)) __syncthreads();
         STEP_STAMP();
         if (++idx >= total) break;
       }
       continue;
     }
-    const StepRes r = load_step(S.sres[idx]);
+    const StepRes r = load_uniform<StepRes>(S.recs[idx].r);
     const int rep = r.rep;
     switch (kind) {
       case K_LOAD: { if constexpr (PROG == PROG_DECODER || PROG == PROG_PROLOGUE || PROG == PROG_RADAR_ENC_B) {
@@ -851,14 +809,14 @@ __device__ __forceinline__ void chain_body(const ChainK& k, const int block) {
         // out together: one memory latency instead of three, one barrier
         constexpr int MAXL = 3, RW = (R + CH_NW - 1) / CH_NW;
         int n = 1;
-        while (n < MAXL && idx + n < total && ufirst(S.sres[idx + n].kind) == K_LOAD) ++n;
+        while (n < MAXL && idx + n < total && ufirst(S.recs[idx + n].r.kind) == K_LOAD) ++n;
         float4 v[MAXL][RW];
         float* dsts[MAXL];
         int any_sync = 0;
 #pragma unroll
         for (int j = 0; j < MAXL; ++j) {
           if (j < n) {
-            const StepRes rj = load_step(S.sres[idx + j]);
+            const StepRes rj = load_uniform<StepRes>(S.recs[idx + j].r);
             const float* gsrc = rj.gd;
             const int ld = rj.gld, mod = rj.gmod;
             dsts[j] = buf_ptr<R>(S, rj.dst);
@@ -989,30 +947,112 @@ __device__ __forceinline__ void chain_body(const ChainK& k, const int block) {
       default: break;
     }
     STEP_STAMP();
-    if (ufirst(r.sync)) __syncthreads();
+    if (r.sync) __syncthreads();
     STEP_STAMP();
     ++idx;
   }
 }
 
 template <int R, int PROG>
-__global__ __launch_bounds__(CH_NT) void chain_kernel(ChainK k) {
-  chain_body<R, PROG>(k, blockIdx.x);
+__global__ __launch_bounds__(CH_NT) void chain_kernel(ChainDev k, Recs<rec_cap(PROG)> recs) {
+  chain_body<R, PROG>(k, recs.s, blockIdx.x);
 }
 
 // Two programs in one launch: workgroups [0, na) run the decoder layer `ka` on RA-row
 // tiles, the rest the radar encoders `kb` on RB-row tiles.  Decoder layer 0 carries the
 // encoders this way: as a branch of the hipGraph on a side stream, the fork and the join
 // each left a ~10 us hole in the replayed frame (profiles: rocprofv3 kernel trace).
-static_assert(2 * sizeof(ChainK) <= 3800, "two ChainK must fit the kernel argument segment");
 template <int RA, int RB, int PROGB>
-__global__ __launch_bounds__(CH_NT) void chain_dual_kernel(ChainK ka, ChainK kb, int na) {
-  if ((int)blockIdx.x < na) chain_body<RA, PROG_DECODER>(ka, blockIdx.x);
-  else chain_body<RB, PROGB>(kb, (int)blockIdx.x - na);
+__global__ __launch_bounds__(CH_NT) void chain_dual_kernel(ChainDev ka, ChainDev kb, int na,
+                                                           Recs<rec_cap(PROG_DECODER)> ra,
+                                                           Recs<rec_cap(PROGB)> rb) {
+  if ((int)blockIdx.x < na) chain_body<RA, PROG_DECODER>(ka, ra.s, blockIdx.x);
+  else chain_body<RB, PROGB>(kb, rb.s, (int)blockIdx.x - na);
+}
+
+// ---- host side: the step table of a program -> resolved records --------------------------
+template <int R>
+int lds_off(int id) {     // float offset of an LDS buffer from the start of shared memory
+  switch (id) {
+    case B_A: return (int)(offsetof(ChainLds<R>, a) / 4);
+    case B_X: return (int)(offsetof(ChainLds<R>, x) / 4);
+    case B_R: return (int)(offsetof(ChainLds<R>, r) / 4);
+    case B_T: return (int)(offsetof(ChainLds<R>, t) / 4);
+    case B_U: return (int)(offsetof(ChainLds<R>, u) / 4);
+    case B_P: return (int)(offsetof(ChainLds<R>, p) / 4);
+    case B_L: return (int)(offsetof(ChainLds<R>, l) / 4);
+    default: return -1;
+  }
+}
+inline int buf_ld_h(int id) { return id == B_A ? LD5 : id == B_L ? LDL : LD2; }
+
+template <int R, int PROG>
+void resolve_program(ChainK& k, StepAll* out) {
+  const StepDesc* table = prog_table(PROG);
+  constexpr int nsteps = table_steps(PROG);
+  const int nrep = PROG == PROG_RADAR ? k.nlayers : 1;
+  const int total = nsteps * nrep;
+  memset(out, 0, sizeof(StepAll) * rec_cap(PROG));
+  for (int idx = 0; idx < total; ++idx) {
+    const int rep = idx / nsteps, si = idx - rep * nsteps;
+    const int pair0 = PROG == PROG_RADAR ? rep * RADAR_PAIRS : 0;
+    const StepDesc d = table[si];
+    StepRes& r = out[idx].r;
+    r.K = d.K; r.N = d.N;
+    r.kind = d.kind; r.src = d.src; r.src2 = d.src2; r.dst = d.dst; r.res = d.res; r.act = d.act;
+    r.flags = d.flags; r.sync = d.sync; r.rep = (short)rep; r.si = (short)si;
+    if ((d.flags & F_SKIP_NONEXT) && !k.has_next) r.kind = K_NOP;
+    if (d.gsel != G_NONE) { r.gd = k.g[d.gsel]; r.gld = k.g_ld[d.gsel]; r.gmod = k.g_mod[d.gsel]; }
+    if (d.gtsel != G_NONE) r.gt = k.g[d.gtsel];
+    if (d.kind == K_LINEAR) {
+      const tc_linear pr = k.pairs[pair0 + d.wp];
+      r.K = d.K == 36 ? k.RI : d.K;
+      r.N = d.N == N_LOGITS ? k.nlogits : d.N == N_CODE ? k.code : d.N == N_CLS ? k.ncls : d.N;
+      const int woff = (d.flags & F_WOFF) ? 512 : 0;
+      r.p0 = pr.w + (size_t)woff * ((r.K + 63) & ~63);   // packed: a 64-row tile = 64 * kpad floats
+      r.p1 = pr.b ? pr.b + woff : nullptr;
+      if (d.gsel == G_CLS) r.gd += (size_t)rep * k.M * k.ncls;
+    } else if (d.kind == K_LN || d.kind == K_POSENC) {
+      const tc_linear n = k.pairs[pair0 + d.wp];
+      r.p0 = n.w; r.p1 = n.b;
+      if (d.kind == K_POSENC || d.src2 != B_NONE) {
+        const tc_linear n2 = k.pairs[pair0 + d.wp2];
+        r.p2 = n2.w; r.p3 = n2.b;
+      }
+    }
+    r.src_off = lds_off<R>(r.src); r.src2_off = lds_off<R>(r.src2);
+    EpiRec& e = out[idx].e;
+    e.gd = r.gd; e.gt = r.gt; e.gld = r.gld; e.act = r.act; e.flags = r.flags; e.N = r.N;
+    e.has_bias = r.p1 != nullptr; e.woff = (r.flags & F_WAVE1) ? 1 : 0;
+    e.dst_off = lds_off<R>(r.dst); e.dst_ld = buf_ld_h(r.dst);
+    e.res_off = lds_off<R>(r.res); e.res_ld = buf_ld_h(r.res);
+  }
+  // per (step, wave): the next linear step inside the same run of light steps where the
+  // wave owns a column tile, and that step's first weight item
+  for (int idx = 0; idx < total; ++idx) {
+    for (int w = 0; w < CH_NW; ++w) {
+      PreRec& pr = out[idx].p[w];
+      pr.first = nullptr; pr.nidx = -1;
+      for (int j = idx + 1; j < total; ++j) {
+        const StepRes& n = out[j].r;
+        if (n.kind == K_LN || n.kind == K_NOP) continue;
+        if (n.kind != K_LINEAR) break;
+        const int vw = (w - ((n.flags & F_WAVE1) ? 1 : 0)) & (CH_NW - 1);
+        if (vw >= ((n.N + 63) >> 6)) continue;
+        pr.nidx = j;
+        pr.first = n.p0 + (size_t)vw * 64 * ((n.K + 63) & ~63);
+        break;
+      }
+    }
+  }
+  k.total = total;
+  int early = 0;
+  while (early < 3 && early < total && out[early].r.kind == K_LOAD) ++early;
+  k.early_n = early;
 }
 
 template <int RA, int RB, int PROGB>
-int launch_dual_r(const ChainK& ka, const ChainK& kb, hipStream_t s, const char* what) {
+int launch_dual_r(const ChainK& ka_, const ChainK& kb_, hipStream_t s, const char* what) {
   constexpr size_t lds = sizeof(ChainLds<RA>) > sizeof(ChainLds<RB>) ? sizeof(ChainLds<RA>) : sizeof(ChainLds<RB>);
   static bool done = false;
   if (!done) {
@@ -1021,13 +1061,19 @@ int launch_dual_r(const ChainK& ka, const ChainK& kb, hipStream_t s, const char*
     if (e != hipSuccess) { set_error("chain: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     done = true;
   }
+  ChainK ka = ka_, kb = kb_;
+  Recs<rec_cap(PROG_DECODER)> ra;
+  Recs<rec_cap(PROGB)> rb;
+  resolve_program<RA, PROG_DECODER>(ka, ra.s);
+  resolve_program<RB, PROGB>(kb, rb.s);
   const int na = (ka.M + RA - 1) / RA, nb = (kb.M + RB - 1) / RB;
-  hipLaunchKernelGGL((chain_dual_kernel<RA, RB, PROGB>), dim3(na + nb), dim3(CH_NT), lds, s, ka, kb, na);
+  hipLaunchKernelGGL((chain_dual_kernel<RA, RB, PROGB>), dim3(na + nb), dim3(CH_NT), lds, s,
+                     static_cast<const ChainDev&>(ka), static_cast<const ChainDev&>(kb), na, ra, rb);
   return check_launch(what);
 }
 
 template <int R, int PROG>
-int launch_r(const ChainK& k, hipStream_t s, const char* what) {
+int launch_r(const ChainK& k_, hipStream_t s, const char* what) {
   static bool done = false;
   if (!done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<R, PROG>),
@@ -1036,7 +1082,11 @@ int launch_r(const ChainK& k, hipStream_t s, const char* what) {
     if (e != hipSuccess) { set_error("chain: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     done = true;
   }
-  hipLaunchKernelGGL((chain_kernel<R, PROG>), dim3((k.M + R - 1) / R), dim3(CH_NT), sizeof(ChainLds<R>), s, k);
+  ChainK k = k_;
+  Recs<rec_cap(PROG)> recs;
+  resolve_program<R, PROG>(k, recs.s);
+  hipLaunchKernelGGL((chain_kernel<R, PROG>), dim3((k.M + R - 1) / R), dim3(CH_NT), sizeof(ChainLds<R>), s,
+                     static_cast<const ChainDev&>(k), recs);
   return check_launch(what);
 }
 
