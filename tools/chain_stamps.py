@@ -60,6 +60,30 @@ def main():
             print('  wave%d:' % w, ' '.join('%6d' % (row[j] - row[0]) for j in range(n)))
             print('     item0 [start, A read, setup, mfma+prefetch]:', ' '.join('%6d' % (row[j] - row[0]) for j in range(20, 24)),
                   ' item1:', ' '.join('%6d' % (row[j] - row[0]) for j in range(25, 29)))
+    if which == 'decoder':
+        wg = np.zeros((1024, 2), dtype=np.int64)
+        lib.tc_debug_wg_spans.restype = C.c_int
+        lib.tc_debug_wg_spans.argtypes = [C.c_void_p]
+        assert lib.tc_debug_wg_spans(wg.ctypes.data) == 0
+        nb = min(int((wg[:, 1] > 0).sum()), (900 + 3) // 4)      # stale entries beyond: earlier dual launches
+        w = wg[:nb]
+        t0 = w[:, 0].min()
+        start, end, span = w[:, 0] - t0, w[:, 1] - t0, w[:, 1] - w[:, 0]
+        print('workgroups: %d; entry skew min/median/max %d/%d/%d; span min/median/max %d/%d/%d; last exit %d'
+              % (nb, start.min(), np.median(start), start.max(), span.min(), np.median(span), span.max(), end.max()))
+        print('  span deciles:', ' '.join('%d' % x for x in np.percentile(span, [0, 10, 20, 30, 40, 50, 60, 70, 80, 90, 100])))
+        print('  entry deciles:', ' '.join('%d' % x for x in np.percentile(start, [0, 10, 50, 90, 100])))
+        print('  block 100: span %d; step stamps cover %d..%d after its entry' % (span[100], buf[0, 0] - w[100, 0], buf[0, :].max() - w[100, 0]))
+        order = np.argsort(-end)[:8]
+        print('  last to finish (block: entry, span):', ', '.join('%d: %d, %d' % (b, start[b], span[b]) for b in order))
+        cb = np.zeros((4, 8), dtype=np.int64)
+        lib.tc_debug_cam_stamps.restype = C.c_int
+        lib.tc_debug_cam_stamps.argtypes = [C.c_void_p]
+        assert lib.tc_debug_cam_stamps(cb.ctypes.data) == 0
+        print('camera sampling (cycles relative to the entry of cam_sample_row): step entry, projected + ballot, '
+              'taps issued (last visible camera), accumulated, row done, rows done, pair counter added')
+        for w in range(4):
+            print('  wave%d:' % w, ' '.join('%6d' % (cb[w, j] - cb[w, 0]) for j in (5, 1, 2, 3, 4, 6, 7)))
     print('%-14s %s' % ('step', '   '.join('wave%d work / wait' % w for w in range(4))))
     n = min(len(names), 31)
     for i in range(n):

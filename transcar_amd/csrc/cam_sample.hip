@@ -47,6 +47,9 @@ void fill_camk(const CamSampleArgs& a, CamK& p) {
 int launch_cam_sample(const CamSampleArgs& a, hipStream_t s) {
   TC_REQUIRE(a.C == 256, "cam_sample: C=%d (256 supported)", a.C);
   TC_REQUIRE(a.feats.num_levels == 4, "cam_sample: num_levels=%d (4 supported)", a.feats.num_levels);
+  for (int l = 0; l < a.feats.num_levels; ++l)      // pixel indices are 32-bit in the kernels
+    TC_REQUIRE((long long)a.B * a.num_cams * a.feats.H[l] * a.feats.W[l] < (1ll << 31),
+               "cam_sample: level %d has too many pixels for one call", l);
   CamK p;
   fill_camk(a, p);
   const int rows = a.B * a.Q;

@@ -48,6 +48,14 @@
 #include <type_traits>
 
 #include "kernels.hpp"
+#ifdef TC_CHAIN_STAMPS
+__device__ long long g_cam_stamps[4][8];      // camera sampling of workgroup 100, per wave
+#define CAM_STAMP(slot)                                                                        \
+  do {                                                                                         \
+    if (blockIdx.x == 100 && (threadIdx.x & 63) == 0)                                          \
+      g_cam_stamps[(threadIdx.x >> 6) & 3][(slot)] = __builtin_amdgcn_s_memtime();             \
+  } while (0)
+#endif
 #include "rowdev.hpp"
 
 namespace tc {
@@ -90,12 +98,18 @@ struct StepAll { StepRes r; EpiRec e; PreRec p[CH_NW]; };
 static_assert(sizeof(StepAll) % 16 == 0, "records are copied 16 bytes at a time");
 template <int N> struct Recs { StepAll s[N]; };
 
-constexpr int MAX_RECS = 48;     // 16 radar steps x 3 layers
+// Camera-sampling taps of a decoder layer at R = 4, fetched at kernel start by LDS-DMA
+// (global_load_lds_dwordx4: 64 lanes x 16 B = one tap's 256 channels per instruction) for
+// up to TAP_CAMS visible cameras per query: 16 taps x 1 KiB per camera.  The region starts at
+// buffer `a` (idle until the position encoder's second linear, after the sampling step)
+// and extends past the struct.
+constexpr int TAP_CAMS = 2;
+constexpr int TAP_CAM_BYTES = 16 * 1024;
+constexpr int TAP_ROWS = 4;
 
-template <int R>
+template <int R, int NREC>
 struct ChainLds {
-  StepAll recs[MAX_RECS];
-  float a[R][LD5];
+  StepAll recs[NREC];
   float x[R][LD2];
   float r[R][LD2];
   float t[R][LD2];
@@ -105,7 +119,29 @@ struct ChainLds {
   float box[R][12];
   float cen[R][4];
   int gate[R];
+  float2 proj[R][8];          // decoder, R = 4: camera projections of the rows (kernel start)
+  unsigned vmask[R];
+  int pad_[R];
+  float a[R][LD5];            // last: the tap region overlays it
 };
+
+// One tap (this lane's 16 bytes of it) global -> LDS without a destination register.  Inline
+// asm on purpose: the compiler's own builtin makes every later LDS access wait for the
+// transfer; as asm it is fire-and-forget, and because vector-memory operations return in
+// order it has landed once any load issued after it has been consumed (the sampling step
+// waits vmcnt(0) anyway).
+__device__ __forceinline__ void lds_dma16(const float* g, unsigned lds_byte_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+               :: "v"(g), "s"(lds_byte_addr) : "memory", "m0");
+}
+// same with a uniform base address (SGPR pair) and a per-lane byte offset
+__device__ __forceinline__ void lds_dma16_s(const float* sbase, unsigned voff, unsigned lds_byte_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+               :: "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory", "m0");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+  return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
+}
 
 #define MFMA44(a, b, c, grp) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 4, (grp), 0)
 
@@ -558,8 +594,8 @@ __device__ __forceinline__ bool linear_step(const LinSpec& s, WBuf& w0, bool pre
   return false;
 }
 
-template <int R>
-__device__ __forceinline__ float* buf_ptr(ChainLds<R>& S, int id) {
+template <int R, int NREC>
+__device__ __forceinline__ float* buf_ptr(ChainLds<R, NREC>& S, int id) {
   switch (id) {
     case B_A: return &S.a[0][0];
     case B_X: return &S.x[0][0];
@@ -613,19 +649,26 @@ __device__ __forceinline__ T load_uniform(const T& src) {
   do {                                                                                        \
     if (blockIdx.x == 100 && threadIdx.x == 0) g_chain_sub[0][(slot)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
+// entry / exit time of every workgroup (wave 0): dispatch skew and the slowest workgroups
+__device__ long long g_wg_span[1024][2];
+#define WG_STAMP(which)                                                                       \
+  do {                                                                                        \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_wg_span[blockIdx.x][(which)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
 #else
 #define START_STAMP(slot) do {} while (0)
+#define WG_STAMP(which) do {} while (0)
 #endif
 
 // PROG is a compile-time parameter: each program's kernel contains only the step kinds it
 // uses.  (One code image for all four programs made the R = 4 kernel spill 9 dwords to a
 // private segment under the combined pressure of the camera-sampling and radar-attention
-// bodies -- and a kernel with a private segment costs ~13 us more PER LAUNCH on this
-// platform: 15.4 us for an immediately returning launch in a replayed graph vs 2.)
+// bodies; the specialised kernels are smaller and were 3.5 % faster per frame.)
 template <int R, int PROG>
 __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __restrict__ recs, const int block) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  ChainLds<R>& S = *reinterpret_cast<ChainLds<R>*>(smem_raw);
+  using Lds = ChainLds<R, rec_cap(PROG)>;
+  Lds& S = *reinterpret_cast<Lds*>(smem_raw);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int m0 = block * R;
@@ -637,12 +680,13 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
   int4 rec_v[REC_TRIPS];
 #pragma unroll
   for (int t = 0; t < REC_TRIPS; ++t) {
-    const int i = threadIdx.x + t * CH_NT;
-    if (i < REC16) rec_v[t] = reinterpret_cast<const int4*>(recs)[i];
+    const int i = min((int)threadIdx.x + t * CH_NT, REC16 - 1);   // unconditional: stays in registers
+    rec_v[t] = reinterpret_cast<const int4*>(recs)[i];
   }
   const int M = k.M;
   if (k.dbg & 64) return;
   START_STAMP(40);
+  WG_STAMP(0);
   const int total = k.total;
   // The leading global-to-LDS loads of a program (a decoder layer starts with three) go out
   // together: one memory latency, one barrier.
@@ -708,10 +752,10 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
 
   // dst = [relu] LN(a (+ relu(LN(c; p2,p3)))) (+ d): wave w owns rows w, w+4, ...
   auto do_ln = [&](const StepRes& r) {
-    const float* a = buf_ptr<R>(S, r.src); const int lda = buf_ld(r.src);
-    const float* c = buf_ptr<R>(S, r.src2); const int ldc = buf_ld(r.src2);
-    const float* dd = buf_ptr<R>(S, r.res);
-    float* dst = buf_ptr<R>(S, r.dst);
+    const float* a = buf_ptr(S, r.src); const int lda = buf_ld(r.src);
+    const float* c = buf_ptr(S, r.src2); const int ldc = buf_ld(r.src2);
+    const float* dd = buf_ptr(S, r.res);
+    float* dst = buf_ptr(S, r.dst);
     float* gdst = r.gd;
     for (int row = wave; row < R; row += CH_NW) {
       float4 v = *reinterpret_cast<const float4*>(a + row * lda + 4 * lane);
@@ -819,7 +863,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
             const StepRes rj = load_uniform<StepRes>(S.recs[idx + j].r);
             const float* gsrc = rj.gd;
             const int ld = rj.gld, mod = rj.gmod;
-            dsts[j] = buf_ptr<R>(S, rj.dst);
+            dsts[j] = buf_ptr(S, rj.dst);
             any_sync |= rj.sync;
 #pragma unroll
             for (int ri = 0; ri < RW; ++ri) {
@@ -854,9 +898,52 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
       } break;
       } break;
       case K_POSENC: { if constexpr (PROG == PROG_DECODER || PROG == PROG_RADAR_ENC || PROG == PROG_RADAR_ENC_A) {   // Linear(3,256) + LN + ReLU of inverse_sigmoid(ref) or of raw token xyz
-        float* dst = buf_ptr<R>(S, r.dst);
+        float* dst = buf_ptr(S, r.dst);
         const bool skip0 = (r.flags & F_NOT_W0) != 0;      // wave 0 is busy with the narrow linear step before
-        for (int row = skip0 ? wave - 1 : wave; row < R && row >= 0; row += skip0 ? CH_NW - 1 : CH_NW) {
+        int row_first = skip0 ? wave - 1 : wave, row_step = skip0 ? CH_NW - 1 : CH_NW;
+        if constexpr (PROG == PROG_DECODER && R == TAP_ROWS) {
+          // Wave 1 starts the camera taps of all rows towards LDS instead (and waits for them: it
+          // has the time, wave 0 is in the logit step for ~7000 cycles); waves 2, 3 take two rows
+          // each.  Issued by a wave with a weight stream in flight the transfers would stall it:
+          // vector-memory operations return in order.
+          if (skip0) {
+            row_first = wave - 2; row_step = 2;
+            if (wave == 1 && !(k.dbg & 8)) {
+              // lane 8 r + c: row r on camera c, all rows in one pass
+              float u, v;
+              const int prow = (lane >> 3) & (R - 1), pgrow = min(m0 + prow, M - 1);
+              const bool vis = cam_project_lane(k.cam, k.ref_mod > 0 ? pgrow % k.ref_mod : pgrow, pgrow / k.Q,
+                                                min(lane & 7, k.cam.num_cams - 1),
+                                                lane < 8 * R && (lane & 7) < k.cam.num_cams, u, v);
+              const unsigned long long vis_all = __ballot(vis);
+              if (lane < 8 * R) S.proj[prow][lane & 7] = make_float2(u, v);
+              if (lane < R) S.vmask[lane] = (unsigned)(vis_all >> (8 * lane)) & 0xffu;
+#pragma unroll 1
+              for (int row = 0; row < R; ++row) {
+                const int b = min(m0 + row, M - 1) / k.Q;
+                unsigned mask = (unsigned)(vis_all >> (8 * row)) & 0xffu;
+                unsigned dma_dst = lds_addr_of(&S.a[0][0]) + (unsigned)row * TAP_CAMS * TAP_CAM_BYTES;
+#pragma unroll 1
+                for (int c = 0; c < TAP_CAMS && mask; ++c) {
+                  const int cam = __ffs((int)mask) - 1;
+                  mask &= mask - 1;
+                  float w_lane;
+                  int pix_lane;
+                  cam_tap_lane<4>(k.cam, b, cam, lane_f(u, 8 * row + cam), lane_f(v, 8 * row + cam), lane, w_lane, pix_lane);
+#pragma unroll
+                  for (int j = 0; j < 16; ++j) {
+                    const int pix = __builtin_amdgcn_readlane(pix_lane, j);
+                    lds_dma16_s(k.cam.data[j >> 2] + ((size_t)(unsigned)pix << 8), 16u * lane, dma_dst);
+                    dma_dst += 1024;
+                  }
+                }
+              }
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            if (wave == 1) row_first = -1;
+          }
+        }
+        for (int row = row_first; row < R && row >= 0; row += row_step) {
           float p0, p1, p2;
           if (r.src == B_A) { p0 = S.a[row][0]; p1 = S.a[row][1]; p2 = S.a[row][2]; }
           else {
@@ -874,17 +961,38 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
       case K_SAMPLE: { if constexpr (PROG == PROG_DECODER) {   // camera sampling of this block's queries
         if (k.dbg & 8) break;
         int pairs = 0;
+        CAM_STAMP(5);
 #pragma unroll 1
         for (int row = wave; row < R; row += CH_NW) {
           const int grow = min(m0 + row, M - 1);
           int nvis = 0;
-          const float4 o = cam_sample_row<4>(k.cam, k.ref_mod > 0 ? grow % k.ref_mod : grow, grow / k.Q,
-                                             &S.l[row][0], lane, nvis);
+          float4 o;
+          if constexpr (R == TAP_ROWS) {
+            // projections and taps were started at kernel entry
+            CAM_STAMP(0);
+            const float2 uv = S.proj[row][lane & 7];
+            const unsigned long long vm = S.vmask[row];
+            nvis = __popcll(vm);
+            const float* taps = &S.a[0][0] + (size_t)row * TAP_CAMS * (TAP_CAM_BYTES / 4) + 4 * lane;
+            CAM_STAMP(1);
+            o = cam_sample_core<4>(k.cam, grow / k.Q, &S.l[row][0], lane, vm, uv.x, uv.y,
+                                   [&](int c, int l, int t, const float* ptr) {
+                                     if (c < TAP_CAMS)
+                                       return *reinterpret_cast<const float4*>(taps + (size_t)((c * 4 + l) * 4 + t) * 256);
+                                     return ld4(ptr);
+                                   });
+            CAM_STAMP(4);
+          } else {
+            o = cam_sample_row<4>(k.cam, k.ref_mod > 0 ? grow % k.ref_mod : grow, grow / k.Q,
+                                  &S.l[row][0], lane, nvis);
+          }
           *reinterpret_cast<float4*>(&S.r[row][4 * lane]) = o;
           if (m0 + row < M) pairs += nvis;
         }
+        CAM_STAMP(6);
         if (k.pair_counter != nullptr && lane == 0 && pairs > 0)
           atomicAdd(k.pair_counter, (unsigned long long)pairs);
+        CAM_STAMP(7);
       } break;
       } break;
       case K_REFUPD: { if constexpr (PROG == PROG_DECODER) {   // XFMR:195-203, HEAD:287-293
@@ -951,6 +1059,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
     STEP_STAMP();
     ++idx;
   }
+  WG_STAMP(1);
 }
 
 template <int R, int PROG>
@@ -971,18 +1080,25 @@ __global__ __launch_bounds__(CH_NT) void chain_dual_kernel(ChainDev ka, ChainDev
 }
 
 // ---- host side: the step table of a program -> resolved records --------------------------
-template <int R>
+template <int R, int PROG>
 int lds_off(int id) {     // float offset of an LDS buffer from the start of shared memory
+  using Lds = ChainLds<R, rec_cap(PROG)>;
   switch (id) {
-    case B_A: return (int)(offsetof(ChainLds<R>, a) / 4);
-    case B_X: return (int)(offsetof(ChainLds<R>, x) / 4);
-    case B_R: return (int)(offsetof(ChainLds<R>, r) / 4);
-    case B_T: return (int)(offsetof(ChainLds<R>, t) / 4);
-    case B_U: return (int)(offsetof(ChainLds<R>, u) / 4);
-    case B_P: return (int)(offsetof(ChainLds<R>, p) / 4);
-    case B_L: return (int)(offsetof(ChainLds<R>, l) / 4);
+    case B_A: return (int)(offsetof(Lds, a) / 4);
+    case B_X: return (int)(offsetof(Lds, x) / 4);
+    case B_R: return (int)(offsetof(Lds, r) / 4);
+    case B_T: return (int)(offsetof(Lds, t) / 4);
+    case B_U: return (int)(offsetof(Lds, u) / 4);
+    case B_P: return (int)(offsetof(Lds, p) / 4);
+    case B_L: return (int)(offsetof(Lds, l) / 4);
     default: return -1;
   }
+}
+template <int R, int PROG>
+constexpr size_t chain_lds_bytes() {
+  using Lds = ChainLds<R, rec_cap(PROG)>;
+  return (PROG == PROG_DECODER && R == TAP_ROWS) ? offsetof(Lds, a) + (size_t)TAP_ROWS * TAP_CAMS * TAP_CAM_BYTES
+                                                 : sizeof(Lds);
 }
 inline int buf_ld_h(int id) { return id == B_A ? LD5 : id == B_L ? LDL : LD2; }
 
@@ -1020,12 +1136,12 @@ void resolve_program(ChainK& k, StepAll* out) {
         r.p2 = n2.w; r.p3 = n2.b;
       }
     }
-    r.src_off = lds_off<R>(r.src); r.src2_off = lds_off<R>(r.src2);
+    r.src_off = lds_off<R, PROG>(r.src); r.src2_off = lds_off<R, PROG>(r.src2);
     EpiRec& e = out[idx].e;
     e.gd = r.gd; e.gt = r.gt; e.gld = r.gld; e.act = r.act; e.flags = r.flags; e.N = r.N;
     e.has_bias = r.p1 != nullptr; e.woff = (r.flags & F_WAVE1) ? 1 : 0;
-    e.dst_off = lds_off<R>(r.dst); e.dst_ld = buf_ld_h(r.dst);
-    e.res_off = lds_off<R>(r.res); e.res_ld = buf_ld_h(r.res);
+    e.dst_off = lds_off<R, PROG>(r.dst); e.dst_ld = buf_ld_h(r.dst);
+    e.res_off = lds_off<R, PROG>(r.res); e.res_ld = buf_ld_h(r.res);
   }
   // per (step, wave): the next linear step inside the same run of light steps where the
   // wave owns a column tile, and that step's first weight item
@@ -1053,7 +1169,7 @@ void resolve_program(ChainK& k, StepAll* out) {
 
 template <int RA, int RB, int PROGB>
 int launch_dual_r(const ChainK& ka_, const ChainK& kb_, hipStream_t s, const char* what) {
-  constexpr size_t lds = sizeof(ChainLds<RA>) > sizeof(ChainLds<RB>) ? sizeof(ChainLds<RA>) : sizeof(ChainLds<RB>);
+  constexpr size_t lds = chain_lds_bytes<RA, PROG_DECODER>() > chain_lds_bytes<RB, PROGB>() ? chain_lds_bytes<RA, PROG_DECODER>() : chain_lds_bytes<RB, PROGB>();
   static bool done = false;
   if (!done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_dual_kernel<RA, RB, PROGB>),
@@ -1078,14 +1194,15 @@ int launch_r(const ChainK& k_, hipStream_t s, const char* what) {
   if (!done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<R, PROG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)sizeof(ChainLds<R>));
+                                       (int)chain_lds_bytes<R, PROG>());
     if (e != hipSuccess) { set_error("chain: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     done = true;
   }
   ChainK k = k_;
   Recs<rec_cap(PROG)> recs;
   resolve_program<R, PROG>(k, recs.s);
-  hipLaunchKernelGGL((chain_kernel<R, PROG>), dim3((k.M + R - 1) / R), dim3(CH_NT), sizeof(ChainLds<R>), s,
+  constexpr size_t lds = chain_lds_bytes<R, PROG>();
+  hipLaunchKernelGGL((chain_kernel<R, PROG>), dim3((k.M + R - 1) / R), dim3(CH_NT), lds, s,
                      static_cast<const ChainDev&>(k), recs);
   return check_launch(what);
 }
@@ -1131,6 +1248,12 @@ int launch(const ChainK& k, hipStream_t s, const char* what) {
 extern "C" int tc_debug_chain_stamps(long long* host_out) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_chain_stamps), sizeof(long long) * CH_NW * 64);
 }
+extern "C" int tc_debug_wg_spans(long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wg_span), sizeof(long long) * 1024 * 2);
+}
+extern "C" int tc_debug_cam_stamps(long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_cam_stamps), sizeof(long long) * 4 * 8);
+}
 extern "C" int tc_debug_chain_sub(int step, long long* host_out) {
   if (host_out == nullptr) return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_sub_step), &step, sizeof(int));
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_chain_sub), sizeof(long long) * CH_NW * 64);
@@ -1154,6 +1277,10 @@ int launch_prologue(const PrologueArgs& a, hipStream_t s) {
 
 static int make_decoder_k(const DecoderChainArgs& a, ChainK& k) {
   TC_REQUIRE(a.code <= 12 && a.cam.num_cams * a.cam.feats.num_levels <= 32, "decoder_chain: code/logit width");
+  TC_REQUIRE(a.cam.num_cams <= 8, "decoder_chain: num_cams=%d (<= 8)", a.cam.num_cams);
+  for (int l = 0; l < a.cam.feats.num_levels; ++l)      // pixel indices are 32-bit in the kernel
+    TC_REQUIRE((long long)a.cam.B * a.cam.num_cams * a.cam.feats.H[l] * a.cam.feats.W[l] < (1ll << 31),
+               "decoder_chain: level %d has too many pixels for one call", l);
   init_k(k);
   k.program = PROG_DECODER; k.M = a.M; k.Q = a.Q; k.code = a.code;
   k.nlogits = a.cam.num_cams * a.cam.feats.num_levels;

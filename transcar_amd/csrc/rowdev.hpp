@@ -39,6 +39,9 @@ __device__ __forceinline__ float4 posenc_l0_row(float p0, float p1, float p2, co
   return relu4(ln_row(make_float4(v[0], v[1], v[2], v[3]), g, beta, lane));
 }
 
+#ifndef CAM_STAMP
+#define CAM_STAMP(slot) do {} while (0)      // s_memtime stamps in the STAMPS=1 build of chain.hip
+#endif
 // ---- camera sampling of one query (XFMR:365-373, 381-422) -------------------
 struct CamK {
   const float* data[TC_MAX_LEVELS];
@@ -49,59 +52,96 @@ struct CamK {
   float* out; unsigned char* vis; unsigned long long* pair_counter;
 };
 
-// lg: the query's num_cams*L attention logits (any address space).
-template <int L>
-__device__ __forceinline__ float4 cam_sample_row(const CamK& p, int row, int b, const float* lg,
-                                                 int lane, int& nvis) {
+// Reference point `row` of sample b projected onto camera `cam` (XFMR:389-409), any
+// (row, camera) per lane: u, v in [-1, 1] grid_sample coordinates; true if visible.
+__device__ __forceinline__ bool cam_project_lane(const CamK& p, int row, int b, int cam, bool active,
+                                                 float& u, float& v) {
   const int N = p.num_cams;
   // XFMR:389-391
   const float rx = p.ref[(size_t)row * 3 + 0] * (p.pc[3] - p.pc[0]) + p.pc[0];
   const float ry = p.ref[(size_t)row * 3 + 1] * (p.pc[4] - p.pc[1]) + p.pc[1];
   const float rz = p.ref[(size_t)row * 3 + 2] * (p.pc[5] - p.pc[2]) + p.pc[2];
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  nvis = 0;
-  for (int cam = 0; cam < N; ++cam) {
-    const float* m = p.l2i + ((size_t)b * N + cam) * 16;
-    // XFMR:398-409
-    const float cx = m[0] * rx + m[1] * ry + m[2] * rz + m[3];
-    const float cy = m[4] * rx + m[5] * ry + m[6] * rz + m[7];
-    const float cz = m[8] * rx + m[9] * ry + m[10] * rz + m[11];
-    const float eps = 1e-5f;
-    const float zc = fmaxf(cz, eps);
-    float u = (cx / zc) / p.img_w;
-    float v = (cy / zc) / p.img_h;
-    u = (u - 0.5f) * 2.0f;
-    v = (v - 0.5f) * 2.0f;
-    const bool visible = (cz > eps) && (u > -1.0f) && (u < 1.0f) && (v > -1.0f) && (v < 1.0f);
-    if (p.vis != nullptr && lane == 0) p.vis[(size_t)row * N + cam] = visible ? 1 : 0;
-    if (!visible) continue;
-    ++nvis;
+  const float* m = p.l2i + ((size_t)b * N + cam) * 16;
+  // XFMR:398-409
+  const float cx = m[0] * rx + m[1] * ry + m[2] * rz + m[3];
+  const float cy = m[4] * rx + m[5] * ry + m[6] * rz + m[7];
+  const float cz = m[8] * rx + m[9] * ry + m[10] * rz + m[11];
+  const float eps = 1e-5f;
+  const float zc = fmaxf(cz, eps);
+  u = (cx / zc) / p.img_w;
+  v = (cy / zc) / p.img_h;
+  u = (u - 0.5f) * 2.0f;
+  v = (v - 0.5f) * 2.0f;
+  const bool visible = active && (cz > eps) && (u > -1.0f) && (u < 1.0f) && (v > -1.0f) && (v < 1.0f);
+  if (p.vis != nullptr && active) p.vis[(size_t)row * N + cam] = visible ? 1 : 0;
+  return visible;
+}
+// Lane c < num_cams projects reference point `row` onto camera c; returns the mask of visible
+// cameras.  The N matrix reads are one memory round trip (as a loop over the cameras each
+// iteration's reads waited behind the previous camera's visibility branch).
+__device__ __forceinline__ unsigned long long cam_project(const CamK& p, int row, int b, int lane,
+                                                          float& u, float& v) {
+  return __ballot(cam_project_lane(p, row, b, min(lane, p.num_cams - 1), lane < p.num_cams, u, v));
+}
 
+// Bilinear tap geometry, one tap per lane: lane j < 4 L owns tap t = j & 3 (nw, ne, sw, se)
+// of level l = j >> 2 around (u_, v_) on camera `cam` -- its weight (zero outside the map:
+// F.grid_sample, bilinear, zeros padding, align_corners=False) and the index of its
+// (clamped) pixel in the level's [B * num_cams, H, W] grid.  (With every lane computing all
+// 4 L taps the sampling step was instruction bound: ~700 VALU instructions per camera.)
+template <int L>
+__device__ __forceinline__ void cam_tap_lane(const CamK& p, int b, int cam, float u_, float v_, int lane,
+                                             float& wgt, int& pix) {
+  const int l = min(lane >> 2, L - 1);
+  int H = p.H[0], W = p.W[0];
+#pragma unroll
+  for (int i = 1; i < L; ++i)
+    if (l == i) { H = p.H[i]; W = p.W[i]; }
+  const float ix = ((u_ + 1.0f) * (float)W - 1.0f) * 0.5f;
+  const float iy = ((v_ + 1.0f) * (float)H - 1.0f) * 0.5f;
+  const float xw = floorf(ix), yn = floorf(iy);
+  const float w_ = ix - xw, e_ = 1.0f - w_, n_ = iy - yn, s_ = 1.0f - n_;
+  const int xs = lane & 1, ys = (lane >> 1) & 1;
+  const int x = (int)xw + xs, y = (int)yn + ys;
+  const bool valid = (x >= 0) && (x < W) && (y >= 0) && (y < H);
+  wgt = valid ? (ys ? n_ : s_) * (xs ? w_ : e_) : 0.0f;
+  const int xc = min(max(x, 0), W - 1), yc = min(max(y, 0), H - 1);
+  pix = ((b * p.num_cams + cam) * H + yc) * W + xc;
+}
+// this lane's 4 channels of pixel `pix` (uniform) of level l
+__device__ __forceinline__ const float* cam_tap_ptr(const CamK& p, int l, int pix, int lane) {
+  return p.data[l] + ((size_t)(unsigned)pix << 8) + 4 * lane;
+}
+__device__ __forceinline__ float lane_f(float v, int j) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
+}
+
+// Weighted sum over the visible cameras (XFMR:365-373).  u, v: lane c holds camera c's
+// coordinates; lg: the query's num_cams*L attention logits (any address space);
+// fetch(c, l, t, ptr): this lane's 4 channels of tap t of level l of the c-th visible camera.
+template <int L, typename Fetch>
+__device__ __forceinline__ float4 cam_sample_core(const CamK& p, int b, const float* lg, int lane,
+                                                  unsigned long long vmask, float u, float v, Fetch fetch) {
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  int c = 0;
+  while (vmask) {
+    const int cam = __ffsll((long long)vmask) - 1;
+    vmask &= vmask - 1;
+    const float u_ = lane_f(u, cam), v_ = lane_f(v, cam);
     float4 tap[L][4];
     float wgt[L][4];
+    float w_lane;
+    int pix_lane;
+    cam_tap_lane<L>(p, b, cam, u_, v_, lane, w_lane, pix_lane);
 #pragma unroll
     for (int l = 0; l < L; ++l) {
-      const int H = p.H[l], W = p.W[l];
-      // F.grid_sample, bilinear, zeros padding, align_corners=False
-      const float ix = ((u + 1.0f) * (float)W - 1.0f) * 0.5f;
-      const float iy = ((v + 1.0f) * (float)H - 1.0f) * 0.5f;
-      const float xw = floorf(ix), yn = floorf(iy);
-      const float w_ = ix - xw, e_ = 1.0f - w_, n_ = iy - yn, s_ = 1.0f - n_;
-      const int x0 = (int)xw, y0 = (int)yn, x1 = x0 + 1, y1 = y0 + 1;
-      const bool vx0 = (x0 >= 0) && (x0 < W), vx1 = (x1 >= 0) && (x1 < W);
-      const bool vy0 = (y0 >= 0) && (y0 < H), vy1 = (y1 >= 0) && (y1 < H);
-      wgt[l][0] = (vx0 && vy0) ? s_ * e_ : 0.0f;   // nw
-      wgt[l][1] = (vx1 && vy0) ? s_ * w_ : 0.0f;   // ne
-      wgt[l][2] = (vx0 && vy1) ? n_ * e_ : 0.0f;   // sw
-      wgt[l][3] = (vx1 && vy1) ? n_ * w_ : 0.0f;   // se
-      const int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x1, 0), W - 1);
-      const int yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y1, 0), H - 1);
-      const float* base = p.data[l] + ((size_t)(b * N + cam) * H * W) * 256 + 4 * lane;
-      tap[l][0] = ld4(base + ((size_t)yc0 * W + xc0) * 256);
-      tap[l][1] = ld4(base + ((size_t)yc0 * W + xc1) * 256);
-      tap[l][2] = ld4(base + ((size_t)yc1 * W + xc0) * 256);
-      tap[l][3] = ld4(base + ((size_t)yc1 * W + xc1) * 256);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        wgt[l][t] = lane_f(w_lane, 4 * l + t);
+        tap[l][t] = fetch(c, l, t, cam_tap_ptr(p, l, __builtin_amdgcn_readlane(pix_lane, 4 * l + t), lane));
+      }
     }
+    CAM_STAMP(2);
     float4 camacc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int l = 0; l < L; ++l) {
@@ -119,7 +159,23 @@ __device__ __forceinline__ float4 cam_sample_row(const CamK& p, int row, int b, 
       camacc.x += s.x * a; camacc.y += s.y * a; camacc.z += s.z * a; camacc.w += s.w * a;
     }
     acc.x += camacc.x; acc.y += camacc.y; acc.z += camacc.z; acc.w += camacc.w;
+    CAM_STAMP(3);
+    ++c;
   }
+  return acc;
+}
+
+template <int L>
+__device__ __forceinline__ float4 cam_sample_row(const CamK& p, int row, int b, const float* lg,
+                                                 int lane, int& nvis) {
+  CAM_STAMP(0);
+  float u, v;
+  const unsigned long long vmask = cam_project(p, row, b, lane, u, v);
+  nvis = __popcll(vmask);
+  CAM_STAMP(1);
+  const float4 acc = cam_sample_core<L>(p, b, lg, lane, vmask, u, v,
+                                        [](int, int, int, const float* ptr) { return ld4(ptr); });
+  CAM_STAMP(4);
   return acc;
 }
 
