@@ -27,7 +27,8 @@ def main():
     dev = torch.device('cuda:0')
     torch.set_grad_enabled(False)
     head, _ = bench.build_head(dev)
-    inp = bench.make_inputs(head, dev, 'res101', 1, seed=1)
+    batch = int(os.environ.get('STAMPS_BATCH', '1'))        # 4: the 16-row tiles
+    inp = bench.make_inputs(head, dev, 'res101', batch, seed=1)
     lib = L.lib()
     lib.tc_debug_chain_stamps.restype = C.c_int
     lib.tc_debug_chain_stamps.argtypes = [C.c_void_p]
@@ -65,7 +66,7 @@ def main():
         lib.tc_debug_wg_spans.restype = C.c_int
         lib.tc_debug_wg_spans.argtypes = [C.c_void_p]
         assert lib.tc_debug_wg_spans(wg.ctypes.data) == 0
-        nb = min(int((wg[:, 1] > 0).sum()), (900 + 3) // 4)      # stale entries beyond: earlier dual launches
+        nb = min(int((wg[:, 1] > 0).sum()), 1024)      # stale entries beyond: earlier dual launches
         w = wg[:nb]
         t0 = w[:, 0].min()
         start, end, span = w[:, 0] - t0, w[:, 1] - t0, w[:, 1] - w[:, 0]
