@@ -396,6 +396,32 @@ def test_fused_chains_match_operator_path(T, head):
     assert int(fused['aux']['sample_pairs']) == int(plain['aux']['sample_pairs'])
 
 
+def test_fused_sampling_with_many_visible_cameras(T, head):
+    """Queries seen by 3 and by 6 cameras at once (cameras duplicated): at one frame per
+    step the fused decoder chain prefetches the taps of the first two visible cameras into
+    LDS and reads the others directly; the operator path samples every camera directly."""
+    _, frame = _radar_inputs('res101')
+    feats = [gpu(f) for f in synth.make_feats('res101', seed=3, smooth=SMOOTH)]
+    for dup in ((0, 0, 0, 3, 3, 3), (2, 2, 2, 2, 2, 2)):
+        metas = synth.make_img_metas(1, radar=frame)
+        l2i = metas[0]['lidar2img']
+        metas[0]['lidar2img'] = [np.array(l2i[i], copy=True) for i in dup]
+        fused = head(feats, metas, aux=True)
+        os.environ['TRANSCAR_UNFUSED'] = '1'
+        try:
+            plain = head(feats, metas, aux=True)
+        finally:
+            os.environ.pop('TRANSCAR_UNFUSED')
+        pairs = int(fused['aux']['sample_pairs'])
+        assert pairs == int(plain['aux']['sample_pairs'])
+        assert pairs % 3 == 0 and pairs > 0            # every visible query is seen by 3 (or 6) cameras
+        # layer 0: identical inputs on both paths
+        np.testing.assert_allclose(fused['aux']['inter_states'][0].cpu().numpy(),
+                                   plain['aux']['inter_states'][0].cpu().numpy(), atol=2e-4)
+        np.testing.assert_allclose(fused['aux']['inter_references'].cpu().numpy(),
+                                   plain['aux']['inter_references'].cpu().numpy(), atol=1e-4)
+
+
 def test_box_decode_vs_oracle(T, head):
     gold = g('g5_head_res101.npz')
     outs = {'all_cls_scores': gpu(gold['all_cls_scores']),
