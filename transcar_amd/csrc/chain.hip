@@ -732,14 +732,20 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
       const int grow = min(m0 + row, M - 1);
       *reinterpret_cast<float4*>(&S.x[row][4 * lane]) = ld4(k.g[G_QF] + (size_t)grow * 256 + 4 * lane);
     }
-    if (threadIdx.x < R) {
-      const int row = threadIdx.x, grow = min(m0 + row, M - 1);
-      const float* rr = k.ref_last + (size_t)grow * 3;
-      const float* pc = k.cam.pc;
-      S.cen[row][0] = __fadd_rn(__fmul_rn(rr[0], pc[3] - pc[0]), pc[0]);
-      S.cen[row][1] = __fadd_rn(__fmul_rn(rr[1], pc[4] - pc[1]), pc[1]);
-      S.cen[row][2] = rr[2];          // z stays normalised (HEAD:598 indexes an empty slice)
-      for (int j = 0; j < k.code; ++j) S.box[row][j] = k.box_in[(size_t)grow * k.code + j];
+    {
+      // one (row, column) per thread: columns 0..code-1 the previous box, 12..14 the gate centre
+      const int row = threadIdx.x >> 4, j = threadIdx.x & 15;
+      if (row < R) {
+        const int grow = min(m0 + row, M - 1);
+        if (j < k.code) S.box[row][j] = k.box_in[(size_t)grow * k.code + j];
+        if (j >= 12 && j < 15) {
+          const int c = j - 12;
+          const float r = k.ref_last[(size_t)grow * 3 + c];
+          const float* pc = k.cam.pc;
+          // z stays normalised (HEAD:598 indexes an empty slice)
+          S.cen[row][c] = c < 2 ? __fadd_rn(__fmul_rn(r, pc[3 + c] - pc[c]), pc[c]) : r;
+        }
+      }
     }
   }
   __syncthreads();
@@ -996,24 +1002,20 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
       } break;
       } break;
       case K_REFUPD: { if constexpr (PROG == PROG_DECODER) {   // XFMR:195-203, HEAD:287-293
-        if (threadIdx.x < R && m0 + (int)threadIdx.x < M) {
-          const int row = threadIdx.x, grow = m0 + row;
-          const float* t = &S.l[row][0];
-          const float* rr = k.ref_in + (size_t)(k.ref_mod > 0 ? grow % k.ref_mod : grow) * 3;
-          const float nx = sigmoidf_(t[0] + inverse_sigmoidf_(rr[0]));
-          const float ny = sigmoidf_(t[1] + inverse_sigmoidf_(rr[1]));
-          const float nz = sigmoidf_(t[4] + inverse_sigmoidf_(rr[2]));
-          k.ref_out[(size_t)grow * 3 + 0] = nx;
-          k.ref_out[(size_t)grow * 3 + 1] = ny;
-          k.ref_out[(size_t)grow * 3 + 2] = nz;
-          if (k.box_m != nullptr) {
-            float* o = k.box_m + (size_t)grow * k.code;
-            for (int j = 0; j < k.code; ++j) o[j] = t[j];
+        // one (row, box column) per thread: as a per-row loop on R threads this took ~2900 cycles
+        const int row = threadIdx.x >> 4, j = threadIdx.x & 15;
+        if (row < R && m0 + row < M && j < k.code) {
+          const int grow = m0 + row;
+          float val = S.l[row][j];
+          const int c = j == 0 ? 0 : j == 1 ? 1 : j == 4 ? 2 : -1;      // box columns cx, cy, cz <- reference x, y, z
+          if (c >= 0) {
+            const float rr = k.ref_in[(size_t)(k.ref_mod > 0 ? grow % k.ref_mod : grow) * 3 + c];
+            const float n = sigmoidf_(val + inverse_sigmoidf_(rr));
+            k.ref_out[(size_t)grow * 3 + c] = n;
             const float* pc = k.cam.pc;
-            o[0] = nx * (pc[3] - pc[0]) + pc[0];
-            o[1] = ny * (pc[4] - pc[1]) + pc[1];
-            o[4] = nz * (pc[5] - pc[2]) + pc[2];
+            val = n * (pc[3 + c] - pc[c]) + pc[c];
           }
+          if (k.box_m != nullptr) k.box_m[(size_t)grow * k.code + j] = val;
         }
       } break;
       } break;
@@ -1038,17 +1040,13 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
       } break;
       } break;
       case K_BOXADD: { if constexpr (PROG == PROG_RADAR) {   // box = reg + reference (HEAD:599-600, 664-665, 722-723); next ref (HEAD:615-617)
-        if (threadIdx.x < R) {
-          const int row = threadIdx.x;
-          float bx[12];
-          for (int j = 0; j < k.code; ++j) bx[j] = S.l[row][j];
-          bx[0] += S.cen[row][0]; bx[1] += S.cen[row][1]; bx[4] += S.cen[row][2];
-          for (int j = 0; j < k.code; ++j) S.box[row][j] = bx[j];
-          S.cen[row][0] = bx[0]; S.cen[row][1] = bx[1]; S.cen[row][2] = bx[4];
-          if (m0 + row < M) {
-            float* o = k.all_box + ((size_t)rep * M + m0 + row) * k.code;
-            for (int j = 0; j < k.code; ++j) o[j] = bx[j];
-          }
+        const int row = threadIdx.x >> 4, j = threadIdx.x & 15;     // one (row, box column) per thread
+        if (row < R && j < k.code) {
+          const int c = j == 0 ? 0 : j == 1 ? 1 : j == 4 ? 2 : -1;
+          float bx = S.l[row][j];
+          if (c >= 0) { bx += S.cen[row][c]; S.cen[row][c] = bx; }   // only this thread touches cen[row][c]
+          S.box[row][j] = bx;
+          if (m0 + row < M) k.all_box[((size_t)rep * M + m0 + row) * k.code + j] = bx;
         }
       } break;
       } break;
