@@ -317,6 +317,45 @@ def test_head_end_to_end(T, sd, head, tag):
     assert 0 < int(aux['sample_pairs']) <= 6 * 900 * 6
 
 
+@pytest.mark.parametrize('nq', [777, 130])
+def test_head_other_query_counts(T, nq):
+    """num_query that is no multiple of the row tiles (4), the attention query tiles (32) or
+    the key tiles: the tails of every kernel, against the CPU oracle."""
+    sd_np = synth.make_state_dict(seed=5, num_query=nq)
+    sd_t = O.to_torch_sd(sd_np)
+    h = T.build_head(configs.head_cfg(num_query=nq))
+    h.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
+    h = h.to(dev()).eval()
+    _, frame = _radar_inputs('tiny')
+    feats_np = synth.make_feats('tiny', seed=2, smooth=SMOOTH)
+    l2i = synth.make_lidar2img()
+    outs = h([gpu(f) for f in feats_np], synth.make_img_metas(1, l2i, radar=frame), aux=True)
+    aux = outs['aux']
+    want, dbg = O.head_forward(sd_t, [torch.from_numpy(f) for f in feats_np],
+                               torch.from_numpy(l2i).float()[None], HW,
+                               O.build_radar_features(frame), PCR, return_debug=True)
+    assert outs['all_cls_scores'].shape == (3, 1, nq, 10)
+    np.testing.assert_allclose(aux['inter_references'].cpu().numpy(), dbg['inter_refs'].numpy(),
+                               atol=5e-5, rtol=0)
+    np.testing.assert_allclose(aux['inter_states'].cpu().numpy(), dbg['hs'].numpy(), atol=E2E_TOL, rtol=0)
+    want_hits = np.stack([x.numpy() for x in dbg['hit_counts']])
+    _e2e_check(outs, want['all_cls_scores'][:, 0].numpy(), want['all_bbox_preds'][:, 0].numpy(),
+               want_hits, aux)
+    # two frames per step: a sample boundary inside a row tile and inside a transposed-V store
+    feats2 = [gpu(np.concatenate([f, f], 0)) for f in feats_np]
+    metas2 = synth.make_img_metas(2, l2i, radar=frame)
+    outs2 = h(feats2, metas2)
+    for k_ in ('all_cls_scores', 'all_bbox_preds'):
+        a_ = outs2[k_].cpu().numpy()
+        np.testing.assert_array_equal(a_[:, 0], a_[:, 1])
+        np.testing.assert_allclose(a_[:, 0], outs[k_][:, 0].cpu().numpy(), atol=2e-4, rtol=0)   # 8- vs 4-row tiles
+    # decode: top-k of nq * 10 scores
+    boxes, scores, labels = h.get_bboxes(outs, synth.make_img_metas(1))[0]
+    assert boxes.shape[0] == scores.shape[0] == labels.shape[0] <= 300
+    s_ = scores.cpu().numpy()
+    assert np.all(s_[:-1] >= s_[1:])
+
+
 def test_head_ragged_and_empty_radar(T, sd, head):
     gold = g('g4_radar_ragged.npz')
     feats_np = synth.make_feats('tiny', seed=1, smooth=SMOOTH)

@@ -114,7 +114,6 @@ static int check_dims(const tc_head_weights* w) {
              "num_radar_layers=%d", w->num_radar_layers);
   TC_REQUIRE(w->num_levels == 4, "num_levels=%d (4 supported)", w->num_levels);
   TC_REQUIRE((w->ffn_dims & 31) == 0 && (w->radar_in_dims & 3) == 0, "ffn_dims/radar_in_dims alignment");
-  TC_REQUIRE((w->num_query & 3) == 0, "num_query=%d must be a multiple of 4", w->num_query);
   return 0;
 }
 
