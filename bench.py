@@ -433,8 +433,8 @@ def main():
                    'parallelism': 'dp%d (frames sharded, no data-path collective)' % world},
     }
     if rank == 0:
+        line['roofline'] = roofline(head, inp, dev)      # rank 0's GPU; the other ranks wait at the barrier
         if world == 1:
-            line['roofline'] = roofline(head, inp, dev)
             if args.batch == 1 and not args.no_batched:
                 line['batched'] = batched_side_run(head, dev, args, frames=4)
             if not args.no_cpu_baseline:

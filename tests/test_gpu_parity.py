@@ -317,6 +317,26 @@ def test_head_end_to_end(T, sd, head, tag):
     assert 0 < int(aux['sample_pairs']) <= 6 * 900 * 6
 
 
+def test_head_end_to_end_vovnet_shapes(T, sd, head):
+    """BASELINE.json configs[4]: the VoVNet FPN levels (232x400 ... 29x50; 757 MB of maps),
+    whole head against the CPU oracle."""
+    _, frame = _radar_inputs('res101')
+    feats_np = synth.make_feats('vovnet', seed=4, smooth=SMOOTH)
+    l2i = synth.make_lidar2img()
+    outs = head([gpu(f) for f in feats_np], synth.make_img_metas(1, l2i, radar=frame), aux=True)
+    aux = outs['aux']
+    want, dbg = O.head_forward(sd, [torch.from_numpy(f) for f in feats_np],
+                               torch.from_numpy(l2i).float()[None], HW,
+                               O.build_radar_features(frame), PCR, return_debug=True)
+    del feats_np
+    np.testing.assert_allclose(aux['inter_references'].cpu().numpy(), dbg['inter_refs'].numpy(),
+                               atol=5e-5, rtol=0)
+    np.testing.assert_allclose(aux['inter_states'].cpu().numpy(), dbg['hs'].numpy(), atol=E2E_TOL, rtol=0)
+    want_hits = np.stack([x.numpy() for x in dbg['hit_counts']])
+    _e2e_check(outs, want['all_cls_scores'][:, 0].numpy(), want['all_bbox_preds'][:, 0].numpy(),
+               want_hits, aux)
+
+
 @pytest.mark.parametrize('nq', [777, 130])
 def test_head_other_query_counts(T, nq):
     """num_query that is no multiple of the row tiles (4), the attention query tiles (32) or
