@@ -42,6 +42,9 @@ def parse():
     ap.add_argument('--shapes', default='res101', choices=['res101', 'vovnet', 'tiny'])
     ap.add_argument('--batch', type=int, default=1, help='frames per step and GPU')
     ap.add_argument('--no-graph', action='store_true', help='eager launches (no hipGraph)')
+    ap.add_argument('--lanes', type=int, default=3,
+                    help='frames in flight per GPU: one hipGraph + HIP stream each '
+                         '(transcar_amd/pipeline.py); 1 = strictly one frame at a time')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--unfused', action='store_true',
                     help='operator-by-operator launches instead of the fused row chains')
@@ -219,32 +222,26 @@ def roofline(head, inp, dev):
 
 def batched_side_run(head, dev, args, frames=4):
     """Not the headline: the same path with `frames` frames per step (one hipGraph
-    replay), reported beside the B = 1 value because at B = 1 a workgroup of the
+    replay per step, two steps in flight), reported beside the B = 1 value because at B = 1 a workgroup of the
     row chains is bound by its weight stream; larger row
     tiles move the same kernels toward the MFMA bound."""
+    from transcar_amd.pipeline import FramePipeline
     inp = make_inputs(head, dev, args.shapes, frames, seed=11)
-    s = torch.cuda.Stream()
-    s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):
-        for _ in range(3):
-            one_step(head, inp)
-    torch.cuda.current_stream().wait_stream(s)
-    torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        one_step(head, inp)
+    nl = 1 if args.no_graph else min(2, max(1, args.lanes))
+    pipe = FramePipeline(head, [inp] + [make_inputs(head, dev, args.shapes, frames, seed=13)
+                                        for _ in range(nl - 1)])
     for _ in range(10):
-        g.replay()
+        pipe.launch()
     torch.cuda.synchronize()
     n = max(20, args.steps // 4)
     t0 = time.perf_counter()
     for _ in range(n):
-        g.replay()
+        pipe.launch()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     r = roofline(head, inp, dev)
-    return {'frames_per_step': frames, 'value': frames * n / dt, 'unit': 'frames/s',
-            'ms_per_step': dt / n * 1e3,
+    return {'frames_per_step': frames, 'frames_in_flight': frames * pipe.lanes,
+            'value': frames * n / dt, 'unit': 'frames/s', 'ms_per_step': dt / n * 1e3,
             'roofline_frac': r['frac'], 'roofline_kernel': r['kernel'],
             'self_attn_frac': r['others']['self_attn_kernel']['frac']}
 
@@ -377,24 +374,18 @@ def main():
     if args.train:
         return train_bench(args, head, inp, dev, rank, world)
 
-    graph = None
+    pipe = None
     if not args.no_graph:
-        # the ~150 kernel launches of a frame are captured once into a hipGraph
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            for _ in range(3):
-                one_step(head, inp)
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            static_out = one_step(head, inp)
+        # a frame (13 kernel launches + decode) is captured once into a hipGraph per lane;
+        # lane i works on its own synthetic frame
+        from transcar_amd.pipeline import FramePipeline
+        lanes = [inp] + [make_inputs(head, dev, args.shapes, args.batch, seed=101 + rank + 7 * i)
+                         for i in range(1, max(1, args.lanes))]
+        pipe = FramePipeline(head, lanes)
 
     def step():
-        if graph is not None:
-            graph.replay()
-            return static_out
+        if pipe is not None:
+            return pipe.launch()[1]
         return one_step(head, inp)
 
     for _ in range(args.warmup):
@@ -429,10 +420,21 @@ def main():
                                'points, %d frame(s)/step/GPU, 1xMI355X inference'
                                % (configs.LEVEL_SHAPES[args.shapes], args.batch),
                    'shapes': args.shapes, 'frames_per_step_per_gpu': args.batch,
-                   'launch': 'eager' if graph is None else 'hipGraph replay',
+                   'launch': 'eager' if pipe is None else 'hipGraph replay',
+                   'frames_in_flight': 1 if pipe is None else pipe.lanes,
                    'parallelism': 'dp%d (frames sharded, no data-path collective)' % world},
     }
     if rank == 0:
+        if pipe is not None and pipe.lanes > 1:
+            # one frame at a time on one lane: the latency of a frame with nothing else in flight
+            pipe.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                pipe.launch(0)
+            pipe.synchronize()
+            dt1 = time.perf_counter() - t1
+            line['single_lane'] = {'frames_in_flight': 1, 'value': args.steps * args.batch / dt1,
+                                   'unit': 'frames/s', 'ms_per_frame': dt1 / args.steps * 1e3 / args.batch}
         line['roofline'] = roofline(head, inp, dev)      # rank 0's GPU; the other ranks wait at the barrier
         if world == 1:
             if args.batch == 1 and not args.no_batched:

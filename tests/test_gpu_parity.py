@@ -481,6 +481,37 @@ def test_fused_sampling_with_many_visible_cameras(T, head):
                                    plain['aux']['inter_references'].cpu().numpy(), atol=1e-4)
 
 
+def test_frames_in_flight_equal_sequential(T, head):
+    """transcar_amd.pipeline.FramePipeline: three frames in flight on three HIP streams (one
+    hipGraph, one workspace each) give bit for bit what one frame at a time gives."""
+    import bench
+    from transcar_amd.pipeline import FramePipeline
+    lanes = [bench.make_inputs(head, dev(), 'tiny', 1, seed=11 + i) for i in range(3)]
+    want = []
+    for inp in lanes:
+        outs, dec = bench.one_step(head, inp)
+        want.append([outs['all_cls_scores'].clone(), outs['all_bbox_preds'].clone()] + [d.clone() for d in dec])
+    torch.cuda.synchronize()
+    pipe = FramePipeline(head, lanes)
+    assert pipe.lanes == 3
+    for rnd in range(4):                                   # 12 launches, round robin, no waits in between
+        for _ in range(3):
+            pipe.launch()
+    pipe.synchronize()
+    for i in range(3):
+        outs, dec = pipe.outputs[i]
+        got = [outs['all_cls_scores'], outs['all_bbox_preds']] + list(dec)
+        for a_, b_ in zip(got, want[i]):
+            assert torch.equal(a_, b_)
+    # new data in a lane's static inputs -> new result from the same graph
+    lanes[0]['tokens'].copy_(lanes[1]['tokens'])
+    for f0, f1 in zip(lanes[0]['nhwc'], lanes[1]['nhwc']):
+        f0.copy_(f1)
+    lane, (outs, dec) = pipe.launch(0)
+    pipe.wait(lane)
+    assert torch.equal(outs['all_bbox_preds'], want[1][1])
+
+
 def test_box_decode_vs_oracle(T, head):
     gold = g('g5_head_res101.npz')
     outs = {'all_cls_scores': gpu(gold['all_cls_scores']),

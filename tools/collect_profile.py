@@ -76,6 +76,19 @@ def label_chain(rows, num_layers=6):
             r['K'] = 'chain_kernel(decoder layer)'      # roofline replay
 
 
+def prog_label(kernel_name):
+    """Label from the template arguments (chain_kernel<rows, program>): works in any launch order."""
+    import re
+    m = re.search(r'chain_dual_kernel<(\d+), (\d+), (\d+)>', kernel_name)
+    if m:
+        return 'chain_dual_kernel(decoder layer + radar encoder half %s)' % ('A' if m.group(3) == '4' else 'B')
+    m = re.search(r'chain_kernel<(\d+), (\d+)>', kernel_name)
+    if m:
+        return 'chain_kernel(%s)' % {'0': 'prologue', '1': 'decoder layer', '2': 'radar encoders',
+                                     '3': 'radar'}.get(m.group(2), 'program ' + m.group(2))
+    return short(kernel_name)
+
+
 def main():
     tag, name = sys.argv[1], sys.argv[2]
     src = os.path.join(ROOT, 'gpurun_out', tag)
@@ -132,6 +145,39 @@ def main():
     for (k, g), v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
         out.append('%-46s %10s  n=%-6d avg %8.1f us  total %10.1f us' % (k[:46], g, len(v), sum(v) / len(v), sum(v)))
     open(os.path.join(dst, name + '_frame_trace.txt'), 'w').write('\n'.join(out) + '\n')
+
+    # the default command: several frames in flight (transcar_amd/pipeline.py)
+    lt = glob.glob(os.path.join(src, 'prof_lanes', '*', '*kernel_trace.csv'))
+    ls = glob.glob(os.path.join(src, 'prof_lanes', '*', '*kernel_stats.csv'))
+    if lt and ls:
+        open(os.path.join(dst, name + '_lanes_kernel_stats.csv'), 'w').write(open(ls[0]).read())
+        lrows = list(csv.DictReader(open(lt[0])))
+        for r in lrows:
+            if 'Grid_Size' not in r:
+                r['Grid_Size'] = str(int(r['Grid_Size_X']) * int(r['Grid_Size_Y']) * int(r['Grid_Size_Z']))
+        for r in lrows:
+            r['K'] = prog_label(r['Kernel_Name'])
+        lrows.sort(key=lambda r: int(r['Start_Timestamp']))
+        dec = [i for i, r in enumerate(lrows) if 'box_decode' in r['Kernel_Name']]
+        lo = ['# `bench.py` (default: 3 frames in flight, one hipGraph + HIP stream each) from rocprofv3',
+              '# --kernel-trace on MI355X: the kernels of ~3 consecutive frames in start order; us',
+              '# %-44s %8s %10s %10s' % ('kernel', 'stream', 'start', 'dur')]
+        if len(dec) >= 8:
+            a, b = dec[-5] + 1, dec[-2] + 1
+            t0 = int(lrows[a]['Start_Timestamp'])
+            for r in lrows[a:b]:
+                st, en = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+                lo.append('%-46s %8s %10.1f %10.1f' % (r['K'][:46], r.get('Stream_Id', r.get('Queue_Id', '?')), (st - t0) / 1e3, (en - st) / 1e3))
+            span = (max(int(r['End_Timestamp']) for r in lrows[a:b]) - t0) / 1e3
+            lo.append('# %d box decodes (= frames) completed in this window of %.1f us' % (3, span))
+        agg2 = defaultdict(list)
+        for r in lrows:
+            agg2[(r['K'], r['Grid_Size'])].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+        lo.append('')
+        lo.append('# average duration per (kernel, grid size) with frames in flight (kernels of different frames share the CUs)')
+        for (k, g), v in sorted(agg2.items(), key=lambda kv: -sum(kv[1]))[:8]:
+            lo.append('%-46s %10s  n=%-6d avg %8.1f us' % (k[:46], g, len(v), sum(v) / len(v)))
+        open(os.path.join(dst, name + '_lanes_trace.txt'), 'w').write('\n'.join(lo) + '\n')
 
     # PMC: KB per launch per (kernel, grid)
     pmc = {}

@@ -18,7 +18,10 @@ python bench.py --batch 2 --no-cpu-baseline --no-batched > "$OUT/bench_b2.json" 
 python bench.py --batch 4 --no-cpu-baseline --no-batched > "$OUT/bench_b4.json" 2>> "$OUT/bench.err"
 python bench.py --train --steps 50 --warmup 5 > "$OUT/bench_train.json" 2>> "$OUT/bench.err"
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python3 "$REPO/bench.py" --steps 50 --warmup 5 --no-cpu-baseline --no-batched > "$OUT/prof.log" 2>&1
+# per-kernel durations: one frame at a time (with frames in flight the kernels of different frames share the GPU)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python3 "$REPO/bench.py" --lanes 1 --steps 50 --warmup 5 --no-cpu-baseline --no-batched > "$OUT/prof.log" 2>&1
+# the default command (3 frames in flight): trace of the overlap
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_lanes" -- python3 "$REPO/bench.py" --steps 50 --warmup 5 --no-cpu-baseline --no-batched > "$OUT/prof_lanes.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-batched --no-graph > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-batched --no-graph > "$OUT/pmc_write.log" 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d "$OUT/pmc_mfma" -- python3 "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-batched --no-graph > "$OUT/pmc_mfma.log" 2>&1

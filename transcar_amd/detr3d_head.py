@@ -294,10 +294,13 @@ class Detr3DHead(BaseModule):
         return torch.from_numpy(tokens).to(device), pad_mult
 
     def forward_nhwc(self, feats_nhwc, lidar2img, img_hw, tokens, pad_mult,
-                     aux=False, _allow_train=False):
+                     aux=False, _allow_train=False, lane=0):
         """The device-side forward: everything already on the GPU.
         feats_nhwc: list of [B*N,H,W,C]; lidar2img [B,N,4,4]; tokens [B,T,36].
-        Only enqueues work on the current stream (graph-capturable)."""
+        Only enqueues work on the current stream (graph-capturable).
+        lane: forwards that may be in flight at the same time (on different
+        streams, transcar_amd/pipeline.py) need different lanes -- each lane
+        owns a workspace; the weights are shared."""
         if not _allow_train:
             require_eval(self)
         w = self.head_weights()
@@ -305,7 +308,7 @@ class Detr3DHead(BaseModule):
         T = tokens.shape[1]
         dev = lidar2img.device
         lib = L.lib()
-        key = (B, T, str(dev))
+        key = (B, T, str(dev), int(lane))
         if key not in self._workspace:
             nbytes = lib.tc_head_workspace_bytes(C.byref(w), B, T)
             if nbytes == 0:
