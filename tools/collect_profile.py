@@ -162,8 +162,8 @@ def main():
         lo = ['# `bench.py` (default: 3 frames in flight, one hipGraph + HIP stream each) from rocprofv3',
               '# --kernel-trace on MI355X: the kernels of ~3 consecutive frames in start order; us',
               '# %-44s %8s %10s %10s' % ('kernel', 'stream', 'start', 'dur')]
-        if len(dec) >= 8:
-            a, b = dec[-5] + 1, dec[-2] + 1
+        if len(dec) >= 40:
+            a, b = dec[30] + 1, dec[33] + 1          # inside the timed region (the tail of the run is single-lane)
             t0 = int(lrows[a]['Start_Timestamp'])
             for r in lrows[a:b]:
                 st, en = int(r['Start_Timestamp']), int(r['End_Timestamp'])
