@@ -98,15 +98,6 @@ struct StepAll { StepRes r; EpiRec e; PreRec p[CH_NW]; };
 static_assert(sizeof(StepAll) % 16 == 0, "records are copied 16 bytes at a time");
 template <int N> struct Recs { StepAll s[N]; };
 
-// Camera-sampling taps of a decoder layer at R = 4, fetched at kernel start by LDS-DMA
-// (global_load_lds_dwordx4: 64 lanes x 16 B = one tap's 256 channels per instruction) for
-// up to TAP_CAMS visible cameras per query: 16 taps x 1 KiB per camera.  The region starts at
-// buffer `a` (idle until the position encoder's second linear, after the sampling step)
-// and extends past the struct.
-constexpr int TAP_CAMS = 2;
-constexpr int TAP_CAM_BYTES = 16 * 1024;
-constexpr int TAP_ROWS = 4;
-
 template <int R, int NREC>
 struct ChainLds {
   StepAll recs[NREC];
@@ -119,29 +110,8 @@ struct ChainLds {
   float box[R][12];
   float cen[R][4];
   int gate[R];
-  float2 proj[R][8];          // decoder, R = 4: camera projections of the rows (kernel start)
-  unsigned vmask[R];
-  int pad_[R];
-  float a[R][LD5];            // last: the tap region overlays it
+  float a[R][LD5];
 };
-
-// One tap (this lane's 16 bytes of it) global -> LDS without a destination register.  Inline
-// asm on purpose: the compiler's own builtin makes every later LDS access wait for the
-// transfer; as asm it is fire-and-forget, and because vector-memory operations return in
-// order it has landed once any load issued after it has been consumed (the sampling step
-// waits vmcnt(0) anyway).
-__device__ __forceinline__ void lds_dma16(const float* g, unsigned lds_byte_addr) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-               :: "v"(g), "s"(lds_byte_addr) : "memory", "m0");
-}
-// same with a uniform base address (SGPR pair) and a per-lane byte offset
-__device__ __forceinline__ void lds_dma16_s(const float* sbase, unsigned voff, unsigned lds_byte_addr) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-               :: "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory", "m0");
-}
-__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
-  return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
-}
 
 #define MFMA44(a, b, c, grp) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 4, (grp), 0)
 
@@ -906,49 +876,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
       case K_POSENC: { if constexpr (PROG == PROG_DECODER || PROG == PROG_RADAR_ENC || PROG == PROG_RADAR_ENC_A) {   // Linear(3,256) + LN + ReLU of inverse_sigmoid(ref) or of raw token xyz
         float* dst = buf_ptr(S, r.dst);
         const bool skip0 = (r.flags & F_NOT_W0) != 0;      // wave 0 is busy with the narrow linear step before
-        int row_first = skip0 ? wave - 1 : wave, row_step = skip0 ? CH_NW - 1 : CH_NW;
-        if constexpr (PROG == PROG_DECODER && R == TAP_ROWS) {
-          // Wave 1 starts the camera taps of all rows towards LDS instead (and waits for them: it
-          // has the time, wave 0 is in the logit step for ~7000 cycles); waves 2, 3 take two rows
-          // each.  Issued by a wave with a weight stream in flight the transfers would stall it:
-          // vector-memory operations return in order.
-          if (skip0) {
-            row_first = wave - 2; row_step = 2;
-            if (wave == 1 && !(k.dbg & 8)) {
-              // lane 8 r + c: row r on camera c, all rows in one pass
-              float u, v;
-              const int prow = (lane >> 3) & (R - 1), pgrow = min(m0 + prow, M - 1);
-              const bool vis = cam_project_lane(k.cam, k.ref_mod > 0 ? pgrow % k.ref_mod : pgrow, pgrow / k.Q,
-                                                min(lane & 7, k.cam.num_cams - 1),
-                                                lane < 8 * R && (lane & 7) < k.cam.num_cams, u, v);
-              const unsigned long long vis_all = __ballot(vis);
-              if (lane < 8 * R) S.proj[prow][lane & 7] = make_float2(u, v);
-              if (lane < R) S.vmask[lane] = (unsigned)(vis_all >> (8 * lane)) & 0xffu;
-#pragma unroll 1
-              for (int row = 0; row < R; ++row) {
-                const int b = min(m0 + row, M - 1) / k.Q;
-                unsigned mask = (unsigned)(vis_all >> (8 * row)) & 0xffu;
-                unsigned dma_dst = lds_addr_of(&S.a[0][0]) + (unsigned)row * TAP_CAMS * TAP_CAM_BYTES;
-#pragma unroll 1
-                for (int c = 0; c < TAP_CAMS && mask; ++c) {
-                  const int cam = __ffs((int)mask) - 1;
-                  mask &= mask - 1;
-                  float w_lane;
-                  int pix_lane;
-                  cam_tap_lane<4>(k.cam, b, cam, lane_f(u, 8 * row + cam), lane_f(v, 8 * row + cam), lane, w_lane, pix_lane);
-#pragma unroll
-                  for (int j = 0; j < 16; ++j) {
-                    const int pix = __builtin_amdgcn_readlane(pix_lane, j);
-                    lds_dma16_s(k.cam.data[j >> 2] + ((size_t)(unsigned)pix << 8), 16u * lane, dma_dst);
-                    dma_dst += 1024;
-                  }
-                }
-              }
-              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            if (wave == 1) row_first = -1;
-          }
-        }
+        const int row_first = skip0 ? wave - 1 : wave, row_step = skip0 ? CH_NW - 1 : CH_NW;
         for (int row = row_first; row < R && row >= 0; row += row_step) {
           float p0, p1, p2;
           if (r.src == B_A) { p0 = S.a[row][0]; p1 = S.a[row][1]; p2 = S.a[row][2]; }
@@ -972,26 +900,8 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
         for (int row = wave; row < R; row += CH_NW) {
           const int grow = min(m0 + row, M - 1);
           int nvis = 0;
-          float4 o;
-          if constexpr (R == TAP_ROWS) {
-            // projections and taps were started at kernel entry
-            CAM_STAMP(0);
-            const float2 uv = S.proj[row][lane & 7];
-            const unsigned long long vm = S.vmask[row];
-            nvis = __popcll(vm);
-            const float* taps = &S.a[0][0] + (size_t)row * TAP_CAMS * (TAP_CAM_BYTES / 4) + 4 * lane;
-            CAM_STAMP(1);
-            o = cam_sample_core<4>(k.cam, grow / k.Q, &S.l[row][0], lane, vm, uv.x, uv.y,
-                                   [&](int c, int l, int t, const float* ptr) {
-                                     if (c < TAP_CAMS)
-                                       return *reinterpret_cast<const float4*>(taps + (size_t)((c * 4 + l) * 4 + t) * 256);
-                                     return ld4(ptr);
-                                   });
-            CAM_STAMP(4);
-          } else {
-            o = cam_sample_row<4>(k.cam, k.ref_mod > 0 ? grow % k.ref_mod : grow, grow / k.Q,
-                                  &S.l[row][0], lane, nvis);
-          }
+          const float4 o = cam_sample_row<4>(k.cam, k.ref_mod > 0 ? grow % k.ref_mod : grow, grow / k.Q,
+                                             &S.l[row][0], lane, nvis);
           *reinterpret_cast<float4*>(&S.r[row][4 * lane]) = o;
           if (m0 + row < M) pairs += nvis;
         }
@@ -1061,7 +971,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
 }
 
 template <int R, int PROG>
-__global__ __launch_bounds__(CH_NT) void chain_kernel(ChainDev k, Recs<rec_cap(PROG)> recs) {
+__global__ __launch_bounds__(CH_NT, R <= 8 ? 2 : 1) void chain_kernel(ChainDev k, Recs<rec_cap(PROG)> recs) {
   chain_body<R, PROG>(k, recs.s, blockIdx.x);
 }
 
@@ -1070,7 +980,7 @@ __global__ __launch_bounds__(CH_NT) void chain_kernel(ChainDev k, Recs<rec_cap(P
 // encoders this way: as a branch of the hipGraph on a side stream, the fork and the join
 // each left a ~10 us hole in the replayed frame (profiles: rocprofv3 kernel trace).
 template <int RA, int RB, int PROGB>
-__global__ __launch_bounds__(CH_NT) void chain_dual_kernel(ChainDev ka, ChainDev kb, int na,
+__global__ __launch_bounds__(CH_NT, RA <= 8 ? 2 : 1) void chain_dual_kernel(ChainDev ka, ChainDev kb, int na,
                                                            Recs<rec_cap(PROG_DECODER)> ra,
                                                            Recs<rec_cap(PROGB)> rb) {
   if ((int)blockIdx.x < na) chain_body<RA, PROG_DECODER>(ka, ra.s, blockIdx.x);
@@ -1093,11 +1003,7 @@ int lds_off(int id) {     // float offset of an LDS buffer from the start of sha
   }
 }
 template <int R, int PROG>
-constexpr size_t chain_lds_bytes() {
-  using Lds = ChainLds<R, rec_cap(PROG)>;
-  return (PROG == PROG_DECODER && R == TAP_ROWS) ? offsetof(Lds, a) + (size_t)TAP_ROWS * TAP_CAMS * TAP_CAM_BYTES
-                                                 : sizeof(Lds);
-}
+constexpr size_t chain_lds_bytes() { return sizeof(ChainLds<R, rec_cap(PROG)>); }
 inline int buf_ld_h(int id) { return id == B_A ? LD5 : id == B_L ? LDL : LD2; }
 
 template <int R, int PROG>
@@ -1336,7 +1242,7 @@ int launch_radar_encode(const RadarEncodeArgs& a, hipStream_t s) {
   return launch(k, s, "chain(radar_encode)");
 }
 
-// a decoder layer and (a part of) the radar encoders on 16-row tiles in one launch;
+// a decoder layer and (a part of) the radar encoders in one launch;
 // part 0: the whole encoder program, 1 / 2: its halves (PROG_RADAR_ENC_A / _B)
 int launch_decoder_chain_with_encoders(const DecoderChainArgs& d, const RadarEncodeArgs& e, int part,
                                        hipStream_t s) {
@@ -1347,13 +1253,16 @@ int launch_decoder_chain_with_encoders(const DecoderChainArgs& d, const RadarEnc
   if (rc != 0) return rc;
   const int rows = tile_rows(kd.M);
   const char* what = "chain(decoder + radar_encode)";
-#define TC_DUAL(RA)                                                                   \
-  (part == 1 ? launch_dual_r<RA, 16, PROG_RADAR_ENC_A>(kd, ke, s, what)               \
-   : part == 2 ? launch_dual_r<RA, 16, PROG_RADAR_ENC_B>(kd, ke, s, what)             \
-               : launch_dual_r<RA, 16, PROG_RADAR_ENC>(kd, ke, s, what))
-  if (rows == 4) return TC_DUAL(4);
-  if (rows == 8) return TC_DUAL(8);
-  return TC_DUAL(16);
+#define TC_DUAL(RA, RB)                                                               \
+  (part == 1 ? launch_dual_r<RA, RB, PROG_RADAR_ENC_A>(kd, ke, s, what)               \
+   : part == 2 ? launch_dual_r<RA, RB, PROG_RADAR_ENC_B>(kd, ke, s, what)             \
+               : launch_dual_r<RA, RB, PROG_RADAR_ENC>(kd, ke, s, what))
+  // 4-row decoder tiles run two workgroups per CU (256 VGPRs): the encoder rows then use 4-row
+  // tiles too -- a 16-row body in the same kernel would spill ~100 registers at that budget,
+  // and 225 + T/4 workgroups fit the chip at two per CU
+  if (rows == 4) return TC_DUAL(4, 4);
+  if (rows == 8) return TC_DUAL(8, 8);
+  return TC_DUAL(16, 16);
 #undef TC_DUAL
 }
 
