@@ -456,9 +456,8 @@ def test_fused_chains_match_operator_path(T, head):
 
 
 def test_fused_sampling_with_many_visible_cameras(T, head):
-    """Queries seen by 3 and by 6 cameras at once (cameras duplicated): at one frame per
-    step the fused decoder chain prefetches the taps of the first two visible cameras into
-    LDS and reads the others directly; the operator path samples every camera directly."""
+    """Queries seen by 3 and by 6 cameras at once (cameras duplicated): the loop over the
+    visible cameras of the fused decoder chain against the operator path."""
     _, frame = _radar_inputs('res101')
     feats = [gpu(f) for f in synth.make_feats('res101', seed=3, smooth=SMOOTH)]
     for dup in ((0, 0, 0, 3, 3, 3), (2, 2, 2, 2, 2, 2)):
