@@ -112,7 +112,7 @@ def time_events(fn, iters=50, warm=3):
     torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, capture_error_mode='thread_local'):
         for _ in range(iters):
             fn()
     g.replay()

@@ -56,7 +56,8 @@ class FramePipeline:
                         self._step(i)
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=s):
+                # thread_local: a RCCL watchdog thread of torch.distributed must not break the capture
+                with torch.cuda.graph(g, stream=s, capture_error_mode='thread_local'):
                     out = self._step(i)
                 self.graphs.append(g)
                 self.outputs.append(out)
