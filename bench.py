@@ -214,6 +214,16 @@ def roofline(head, inp, dev):
             traffic, src = pmc[dom]['traffic_bytes'], 'profiles/r1_pmc.json'
     except Exception:
         pass
+    # algorithmic flop of the whole path per frame: 6 decoder chains (the last without the next
+    # layer's QKV), 5 attention cores (layer 0's is a constant of the checkpoint), radar encoders
+    # (T tokens) and 3 radar fusion layers
+    T_tok = int(inp['tokens'].shape[1])
+    nly = head.head_weights().num_layers
+    path_flop = (nly * chain_flop - 2.0 * M * 3 * Cd * Cd
+                 + (nly - 1) * attn_flop
+                 + 2.0 * B * T_tok * (3 * Cd + Cd * Cd + 36 * 64 + 64 * 128 + 128 * Cd + 3 * Cd * 2 * Cd)
+                 + 3 * 2.0 * M * (6 * Cd * Cd + 2 * Cd * F + 2 * Cd * code)) / B
+    r.update(path_flop_per_frame=path_flop)
     r.update(kernel=dom, traffic=traffic, traffic_source=src,
              others={n: {kk: v[kk] for kk in ('bound', 'achieved', 'peak', 'unit', 'frac', 'ms')}
                      for n, v in kern.items() if n != dom})
@@ -436,6 +446,10 @@ def main():
             line['single_lane'] = {'frames_in_flight': 1, 'value': args.steps * args.batch / dt1,
                                    'unit': 'frames/s', 'ms_per_frame': dt1 / args.steps * 1e3 / args.batch}
         line['roofline'] = roofline(head, inp, dev)      # rank 0's GPU; the other ranks wait at the barrier
+        # every kernel of the path together, at the measured whole-job rate
+        pf = line['roofline']['path_flop_per_frame']
+        line['roofline']['path_achieved_tflops'] = pf * line['value'] / world / 1e12
+        line['roofline']['path_frac'] = line['roofline']['path_achieved_tflops'] / line['roofline']['peak']
         if world == 1:
             if args.batch == 1 and not args.no_batched:
                 line['batched'] = batched_side_run(head, dev, args, frames=4)
