@@ -34,7 +34,7 @@ extern "C" {
 #define TC_MAX_LEVELS 4
 #define TC_MAX_LAYERS 8
 #define TC_MAX_RADAR_LAYERS 3
-#define TC_ABI_VERSION 4
+#define TC_ABI_VERSION 5
 
 typedef void* tc_stream_t;
 
@@ -360,16 +360,26 @@ int tc_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float 
  * are used; zero them first).  Inputs of the stack come from tc_head_forward's aux:
  *   hs_last [B,Q,C] = inter_states[-1], ref_last [B,Q,3] = inter_references[-1],
  *   last_box [B,Q,code].  `w` holds the UNPACKED nn.Linear weights.
- *   d_all_cls / d_all_box: gradients of the loss w.r.t. the two outputs. */
+ *   d_all_cls / d_all_box: gradients of the loss w.r.t. the two outputs.
+ * dropout_p > 0: the four dropout sites of each fusion layer as in train mode of the
+ *   reference (HEAD:129-171, 581-585: attention probabilities, rf_dropout2, rf_dropout,
+ *   rf_dropout3; p = 0.1 there).  Masks are counter-based -- a function of (dropout_seed,
+ *   site, element index), regenerated by the backward: pass the SAME p and seed to both,
+ *   a fresh seed per iteration.  tc_dropout_mask writes the multipliers (0 or 1/(1-p)) of
+ *   elements 0..n-1 of site 4*layer + {0 probabilities [(row*8+head)*num_radar_tokens_ref + token],
+ *   1 rf_dropout2, 2 rf_dropout, 3 rf_dropout3 [row*cols + col]}. */
 size_t tc_radar_train_tape_bytes(const tc_head_weights* w, int B, int T);
 int tc_radar_train_fwd(const tc_head_weights* w, const float* hs_last, const float* ref_last,
                        const float* last_box, const float* radar_tokens, int B, int T, int pad_mult,
                        float* all_cls_scores, float* all_bbox_preds, void* tape, size_t tape_bytes,
-                       tc_stream_t stream);
+                       float dropout_p, unsigned long long dropout_seed, tc_stream_t stream);
 int tc_radar_train_bwd(const tc_head_weights* w, const tc_head_weights* grads, const float* hs_last,
                        const float* last_box, const float* radar_tokens, int B, int T, int pad_mult,
                        const float* all_bbox_preds, const float* d_all_cls, const float* d_all_box,
-                       void* tape, size_t tape_bytes, tc_stream_t stream);
+                       void* tape, size_t tape_bytes, float dropout_p, unsigned long long dropout_seed,
+                       tc_stream_t stream);
+int tc_dropout_mask(float dropout_p, unsigned long long seed, int site, size_t n, float* out,
+                    tc_stream_t stream);
 
 
 /* ---- targets and losses on the device (HEAD:742-917; ASSIGN:106-125; COST:15-26) ----

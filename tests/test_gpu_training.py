@@ -296,7 +296,7 @@ def test_trainer_step_updates_flat_bucket_and_packed_weights(A, golden_dir):
     from transcar_amd.trainer import FusionTrainer
     h = train_head(golden_dir)
     feats, metas, gt, labels = frame_inputs(golden_dir)
-    tr = FusionTrainer(h, lr=1e-3, weight_decay=0.01, max_norm=35.0)
+    tr = FusionTrainer(h, lr=1e-3, weight_decay=0.01, max_norm=35.0, dropout=0.0)
     assert tr.bucket.numel == sum(p.numel() for _, p in h.trainable_parameters())
     p0 = tr.bucket.params.clone()
     with torch.no_grad():
@@ -338,7 +338,7 @@ def test_fused_training_path_gradients_match_reference(A, golden_dir):
     l2i = ops.lidar2img_tensor(metas, dev())
     img_hw = metas[0]['img_shape'][0][:2]
     tokens, pad_mult = h.radar_tokens(metas, dev())
-    tr = FusionTrainer(h)
+    tr = FusionTrainer(h, dropout=0.0)
     losses = tr.step_fused_nhwc(nhwc, l2i, img_hw, tokens, pad_mult, [gt], [labels], update=False)
     for k, v in losses.items():
         ref = float(g8['loss__' + k.replace('.', '_')])
@@ -399,7 +399,7 @@ def test_fused_step_with_device_loss_equals_torch_loss(A, golden_dir):
     l2i = ops.lidar2img_tensor(metas, dev())
     img_hw = metas[0]['img_shape'][0][:2]
     tokens, pad_mult = h.radar_tokens(metas, dev())
-    tr = FusionTrainer(h)
+    tr = FusionTrainer(h, dropout=0.0)
     tr.device_loss = False
     l_torch = tr.step_fused_nhwc(nhwc, l2i, img_hw, tokens, pad_mult, [gt], [labels], update=False)
     g_torch = tr.bucket.grads.clone()
@@ -408,3 +408,79 @@ def test_fused_step_with_device_loss_equals_torch_loss(A, golden_dir):
     for k in l_torch:
         assert abs(float(l_torch[k]) - float(l_dev[k])) < 1e-5 * max(1.0, abs(float(l_torch[k]))), k
     assert float((tr.bucket.grads - g_torch).abs().max() / g_torch.abs().max()) < 1e-4
+
+
+def test_fused_training_with_dropout_matches_reference_formula(A, golden_dir):
+    """The four dropout sites of every fusion layer (HEAD:129-171, 581-585; p = 0.1) in
+    tc_radar_train_fwd / _bwd.  The masks are counter-based, so the check is: with the SAME masks
+    (read back through tc_dropout_mask) the reference formula -- the oracle in train mode with given
+    masks, torch autograd -- gives the same outputs, losses and gradients."""
+    import ctypes as C
+    from transcar_amd import _lib as L
+    from transcar_amd import ops
+    from transcar_amd.trainer import FusionTrainer
+    p = 0.1
+    h = train_head(golden_dir)
+    feats, metas, gt, labels = frame_inputs(golden_dir)
+    nhwc = [ops.to_nhwc(f) for f in feats]
+    l2i = ops.lidar2img_tensor(metas, dev())
+    img_hw = metas[0]['img_shape'][0][:2]
+    tokens, pad_mult = h.radar_tokens(metas, dev())
+    tr = FusionTrainer(h, dropout=p, seed=5)
+    tr.iter = 3
+    losses = tr.step_fused_nhwc(nhwc, l2i, img_hw, tokens, pad_mult, [gt], [labels], update=False)
+    seed = tr.last_dropout_seed
+    hip_grads = {n: q.grad.detach().cpu().clone() for n, q in h.trainable_parameters()}
+    # a different seed gives different masks and a different loss; the same seed the same
+    l_same = tr.step_fused_nhwc(nhwc, l2i, img_hw, tokens, pad_mult, [gt], [labels], update=False)
+    assert tr.last_dropout_seed == seed and all(float(l_same[k]) == float(losses[k]) for k in losses)
+    tr.iter = 4
+    l_other = tr.step_fused_nhwc(nhwc, l2i, img_hw, tokens, pad_mult, [gt], [labels], update=False)
+    assert tr.last_dropout_seed != seed
+    assert any(abs(float(l_other[k]) - float(losses[k])) > 1e-6 for k in losses)
+
+    # ---- the masks
+    lib = L.lib()
+    Q, Cd, Fd, H, TR = h.num_query, 256, 512, 8, 1500
+
+    def mask(site, n):
+        out = torch.empty(n, dtype=torch.float32, device=dev())
+        L.check(lib.tc_dropout_mask(p, seed, site, n, out.data_ptr(),
+                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'tc_dropout_mask')
+        return out.cpu()
+    drop = []
+    for r in range(3):
+        pm = mask(4 * r + 0, Q * H * TR).view(Q, H, TR).permute(1, 0, 2).contiguous()
+        drop.append(dict(probs=pm, d2=mask(4 * r + 1, Q * Cd).view(Q, Cd),
+                         ffn=mask(4 * r + 2, Q * Fd).view(Q, Fd), d3=mask(4 * r + 3, Q * Cd).view(Q, Cd)))
+    m = drop[0]['ffn']
+    assert set(np.unique(m.numpy()).tolist()) == {0.0, np.float32(1.0 / (1.0 - p))}
+    keep = float((m > 0).float().mean())
+    assert abs(keep - (1 - p)) < 4e-3, keep                     # 460 800 Bernoulli draws
+    assert not torch.equal(drop[0]['d2'], drop[1]['d2']) and not torch.equal(drop[0]['d2'], drop[0]['d3'])
+
+    # ---- the reference formula with these masks (CPU, autograd)
+    g_feats, g_l2i, frame, boxes, lab = g8_inputs(golden_dir)
+    sd = O.to_torch_sd(synth.make_state_dict(3))
+    for k, v in sd.items():
+        if trainable(k):
+            v.requires_grad_(True)
+    outs = O.head_forward(sd, [torch.from_numpy(f) for f in g_feats], torch.from_numpy(g_l2i).float()[None],
+                          configs.IMG_SHAPE[:2], O.build_radar_features(frame), configs.point_cloud_range,
+                          drop=drop)
+    res, _ = O.loss(outs, torch.from_numpy(boxes), torch.from_numpy(lab), sd['code_weights'])
+    for k, v in losses.items():
+        ref = float(res[k])
+        assert abs(float(v) - ref) < 2e-3 * max(1.0, abs(ref)), (k, float(v), ref)
+    sum(res.values()).backward()
+    worst = 0.0
+    for n, g in hip_grads.items():
+        ref = sd[n].grad
+        d = float((g.double() - ref.double()).norm() / max(float(ref.double().norm()), 1e-12))
+        worst = max(worst, d)
+        assert d < 5e-3, (n, d)
+    # and they are NOT the no-dropout gradients
+    g8 = np.load(os.path.join(golden_dir, 'g8_train_grads.npz'))
+    k0 = 'rf_linear2.weight'
+    assert abs(float(hip_grads[k0].double().norm()) - float(g8[k0.replace('.', '__') + '__stats'][2])) > \
+        1e-3 * float(g8[k0.replace('.', '__') + '__stats'][2])

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('TRANSCAR_HIP_LIB') or os.path.join(_HERE, 'lib', 'lib
 TC_MAX_LEVELS = 4
 TC_MAX_LAYERS = 8
 TC_MAX_RADAR_LAYERS = 3
-TC_ABI_VERSION = 4
+TC_ABI_VERSION = 5
 
 c_fp = C.c_void_p      # device pointers travel as integers
 
@@ -161,10 +161,11 @@ SIGNATURES = {
                                     _vp, _vp, _vp]),
     'tc_radar_train_tape_bytes': (_sz, [_P(tc_head_weights), _i, _i]),
     'tc_radar_train_fwd': (_i, [_P(tc_head_weights), _vp, _vp, _vp, _vp, _i, _i,
-                                _i, _vp, _vp, _vp, _sz, _vp]),
+                                _i, _vp, _vp, _vp, _sz, _f, C.c_ulonglong, _vp]),
     'tc_radar_train_bwd': (_i, [_P(tc_head_weights), _P(tc_head_weights), _vp,
                                 _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz,
-                                _vp]),
+                                _f, C.c_ulonglong, _vp]),
+    'tc_dropout_mask': (_i, [_f, C.c_ulonglong, _i, _sz, _vp, _vp]),
     'tc_normalize_bbox': (_i, [_vp, _i, _vp, _vp]),
     'tc_match_cost': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _f, _f,
                            _f, _f, _f, _vp, _vp]),

@@ -90,4 +90,33 @@ __device__ __forceinline__ void st4(float* p, float4 v) {
 __device__ __forceinline__ float ldg1(const float* p) { return *(const TC_GLOBAL float*)(p); }
 __device__ __forceinline__ void stg1(float* p, float v) { *(TC_GLOBAL float*)(p) = v; }
 
+
+// ---- dropout (training): counter-based Bernoulli masks ----------------------
+// keep(seed, site, idx) = splitmix64(seed, site, idx) >> 32 >= thr, thr = round(p * 2^32): the
+// forward and the backward regenerate the same mask from (seed, site, element index) -- no mask
+// tensor is stored.  site = 4 * radar layer + {0: attention probabilities, 1: rf_dropout2,
+// 2: rf_dropout (FFN), 3: rf_dropout3}  (HEAD:129-171).
+struct DropK {
+  unsigned long long seed;
+  unsigned thr;                // 0: dropout off
+  float scale;                 // 1 / (1 - p)
+  unsigned site;
+  unsigned tokens_ref;         // stride of the probability index (1500 reference tokens)
+};
+__host__ __device__ __forceinline__ bool drop_keep(unsigned long long seed, unsigned site, unsigned idx,
+                                                   unsigned thr) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (((((unsigned long long)site) << 32) | idx) + 1ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (unsigned)(z >> 32) >= thr;
+}
+inline DropK make_drop(float p, unsigned long long seed, unsigned site, unsigned tokens_ref) {
+  DropK d;
+  d.seed = seed; d.site = site; d.tokens_ref = tokens_ref;
+  d.thr = p > 0.0f ? (unsigned)((double)p * 4294967296.0 + 0.5) : 0u;
+  d.scale = p > 0.0f ? 1.0f / (1.0f - p) : 1.0f;
+  return d;
+}
+
 }  // namespace tc

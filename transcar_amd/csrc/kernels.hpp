@@ -137,8 +137,11 @@ struct RadarAttnArgs {
   float* attn_out;                     // [B*Q, C] (zero rows where no hit)
   int* hit_counts;                     // [B*Q]
   float qscale = 1.0f;                 // applied to qproj on load (1 when pre-scaled)
+  DropK drop = DropK{0, 0, 1.0f, 0, 1500};   // training: dropout on the attention probabilities (thr 0 = off)
 };
 int launch_radar_attn(const RadarAttnArgs& a, hipStream_t s);
+int launch_dropout(const float* x, const float* res, const int* gate, int rows, int cols, const DropK& d,
+                   float* out, hipStream_t s);
 
 // ---- train.hip: backward of the trainable (radar) part + optimizer ----------
 int launch_linear_bwd_data(const float* dy, const float* relu_out, const int* row_gate,

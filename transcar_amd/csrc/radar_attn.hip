@@ -29,8 +29,10 @@ struct RadK {
   int ldq, ldkv, code, ld_xy, ld_c, B, Q, T, pad_mult;
   float rmin, rmax, qscale;
   float* attn_out; int* hits;
+  DropK drop;
 };
 
+template <bool DROP>
 __global__ __launch_bounds__(256) void radar_attn_kernel(RadK p) {
   const int lane = threadIdx.x & 63;
   const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -41,10 +43,10 @@ __global__ __launch_bounds__(256) void radar_attn_kernel(RadK p) {
   float4 q4 = ld4(p.qproj + (size_t)row * p.ldq + 4 * lane);
   q4.x *= p.qscale; q4.y *= p.qscale; q4.z *= p.qscale; q4.w *= p.qscale;
   int count = 0;
-  const float4 o = radar_attn_row(cx, cy, bx[3], bx[6], bx[7], p.rmin, p.rmax, q4,
-                                  p.rxy + (size_t)b * p.T * p.ld_xy, p.ld_xy,
-                                  p.kv + (size_t)b * p.T * p.ldkv, p.ldkv, p.T, p.pad_mult, lane,
-                                  count);
+  const float4 o = radar_attn_row<DROP>(cx, cy, bx[3], bx[6], bx[7], p.rmin, p.rmax, q4,
+                                        p.rxy + (size_t)b * p.T * p.ld_xy, p.ld_xy,
+                                        p.kv + (size_t)b * p.T * p.ldkv, p.ldkv, p.T, p.pad_mult, lane,
+                                        count, p.drop, row);
   st4(p.attn_out + (size_t)row * 256 + 4 * lane, o);
   if (lane == 0) p.hits[row] = count;
 }
@@ -56,9 +58,12 @@ int launch_radar_attn(const RadarAttnArgs& a, hipStream_t s) {
   p.qproj = a.qproj; p.kv = a.kv; p.cxy = a.centre_xy; p.box = a.box; p.rxy = a.radar_xy;
   p.ldq = a.ldq; p.ldkv = a.ldkv; p.code = a.code; p.ld_xy = a.ld_xy; p.ld_c = a.ld_c;
   p.B = a.B; p.Q = a.Q; p.T = a.T; p.pad_mult = a.pad_mult; p.rmin = a.rmin; p.rmax = a.rmax; p.qscale = a.qscale;
-  p.attn_out = a.attn_out; p.hits = a.hit_counts;
+  p.attn_out = a.attn_out; p.hits = a.hit_counts; p.drop = a.drop;
   const int rows = a.B * a.Q;
-  hipLaunchKernelGGL(radar_attn_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, p);
+  if (a.drop.thr != 0)
+    hipLaunchKernelGGL(radar_attn_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL(radar_attn_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, s, p);
   return check_launch("radar_attn");
 }
 

@@ -196,10 +196,15 @@ __device__ __forceinline__ float sqnorm2(float a, float b) {
 // q4: this lane's 4 channels of the projected, scaled query;
 // rxy: xy of token t at rxy[t*ld_xy + {0,1}]; kv: token t at kv[t*ldkv]: K | V (256 each).
 // Returns the attention output (zero if no hit); count = gated tokens (with multiplicity).
+// DROP (training forward): dropout on the attention probabilities (nn.MultiheadAttention
+// dropout = 0.1, HEAD:129): the softmax denominator counts every hit token, the weighted sum only
+// the kept ones, scaled by 1 / (1 - p); mask index ((row * 8 + head) * tokens_ref + token).
+template <bool DROP = false>
 __device__ __forceinline__ float4 radar_attn_row(float cx, float cy, float b3, float b6, float b7,
                                                  float rmin, float rmax, float4 q4,
                                                  const float* rxy, int ld_xy, const float* kv,
-                                                 int ldkv, int T, int pad_mult, int lane, int& count) {
+                                                 int ldkv, int T, int pad_mult, int lane, int& count,
+                                                 DropK drop = DropK(), int row = 0) {
   // gate geometry, HEAD:553-567
   const float len = expf(b3);
   const float rs = -b6, rc = -b7;
@@ -239,8 +244,12 @@ __device__ __forceinline__ float4 radar_attn_row(float cx, float cy, float b3, f
       const float alpha = expf(m - mnew);
       const float pw = (float)mult * expf(s - mnew);
       l = l * alpha + pw;
-      acc.x = acc.x * alpha + pw * v4.x; acc.y = acc.y * alpha + pw * v4.y;
-      acc.z = acc.z * alpha + pw * v4.z; acc.w = acc.w * alpha + pw * v4.w;
+      float pv = pw;
+      if (DROP)
+        pv = drop_keep(drop.seed, drop.site, ((unsigned)row * 8u + (unsigned)(lane >> 3)) * drop.tokens_ref + (unsigned)tok,
+                       drop.thr) ? pw * drop.scale : 0.0f;
+      acc.x = acc.x * alpha + pv * v4.x; acc.y = acc.y * alpha + pv * v4.y;
+      acc.z = acc.z * alpha + pv * v4.z; acc.w = acc.w * alpha + pv * v4.w;
       m = mnew;
     }
   }

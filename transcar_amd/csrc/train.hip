@@ -252,6 +252,7 @@ struct RadBwdK {
   int ldq, ldkv, code, ld_xy, ld_c, B, Q, T, pad_mult;
   float rmin, rmax, qscale;
   float* dq; float* dkv;
+  DropK drop;                  // dropout on the attention probabilities (thr 0 = off)
 };
 
 __device__ __forceinline__ float head_sum(float s) {      // 8 lanes = one 32-channel head
@@ -314,14 +315,21 @@ __global__ __launch_bounds__(256) void radar_attn_bwd_kernel(RadBwdK p) {
         } else {
           const float4 v4 = ld4(kvr + 256);
           const float pj = mult * expf(sc - m) / l;
-          const float dp = head_sum(dO.x * v4.x + dO.y * v4.y + dO.z * v4.z + dO.w * v4.w);
+          // O = sum_j keep_j p_j v_j: dP_j = keep_j (dO . v_j), dV_j = keep_j p_j dO; D = dO . O as without
+          float keep = 1.0f;
+          if (p.drop.thr != 0)
+            keep = drop_keep(p.drop.seed, p.drop.site,
+                             ((unsigned)row * 8u + (unsigned)(lane >> 3)) * p.drop.tokens_ref + (unsigned)tok,
+                             p.drop.thr) ? p.drop.scale : 0.0f;
+          const float dp = keep * head_sum(dO.x * v4.x + dO.y * v4.y + dO.z * v4.z + dO.w * v4.w);
           const float ds = pj * (dp - D);
+          const float pk = pj * keep;
           dq.x += ds * k4.x; dq.y += ds * k4.y; dq.z += ds * k4.z; dq.w += ds * k4.w;
           float* dk = dkv + (size_t)tok * p.ldkv + 4 * lane;
           unsafeAtomicAdd(dk + 0, ds * q4.x); unsafeAtomicAdd(dk + 1, ds * q4.y);
           unsafeAtomicAdd(dk + 2, ds * q4.z); unsafeAtomicAdd(dk + 3, ds * q4.w);
-          unsafeAtomicAdd(dk + 256, pj * dO.x); unsafeAtomicAdd(dk + 257, pj * dO.y);
-          unsafeAtomicAdd(dk + 258, pj * dO.z); unsafeAtomicAdd(dk + 259, pj * dO.w);
+          unsafeAtomicAdd(dk + 256, pk * dO.x); unsafeAtomicAdd(dk + 257, pk * dO.y);
+          unsafeAtomicAdd(dk + 258, pk * dO.z); unsafeAtomicAdd(dk + 259, pk * dO.w);
         }
       }
     }
@@ -339,10 +347,30 @@ int launch_radar_attn_bwd(const RadarAttnArgs& a, float qscale, const float* d_a
   p.attn_out = a.attn_out; p.d_attn = d_attn;
   p.ldq = a.ldq; p.ldkv = a.ldkv; p.code = a.code; p.ld_xy = a.ld_xy; p.ld_c = a.ld_c;
   p.B = a.B; p.Q = a.Q; p.T = a.T; p.pad_mult = a.pad_mult; p.rmin = a.rmin; p.rmax = a.rmax;
-  p.qscale = qscale; p.dq = dq; p.dkv = dkv;
+  p.qscale = qscale; p.dq = dq; p.dkv = dkv; p.drop = a.drop;
   const int rows = a.B * a.Q;
   hipLaunchKernelGGL(radar_attn_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, p);
   return check_launch("radar_attn_bwd");
+}
+
+// ---- elementwise dropout: out = (res) + [gate] * keep * x / (1 - p) -----------
+// forward of rf_dropout / rf_dropout2 / rf_dropout3 (HEAD:581-585) and, applied to the
+// gradient with the same (seed, site), their backward.  Element index row * cols + col.
+__global__ void dropout_kernel(const float* x, const float* res, const int* gate, int rows, int cols,
+                               DropK d, float* out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)rows * cols) return;
+  float v = drop_keep(d.seed, d.site, (unsigned)i, d.thr) ? x[i] * d.scale : 0.0f;
+  if (gate != nullptr && gate[i / cols] <= 0) v = 0.0f;
+  out[i] = res != nullptr ? res[i] + v : v;
+}
+int launch_dropout(const float* x, const float* res, const int* gate, int rows, int cols, const DropK& d,
+                   float* out, hipStream_t s) {
+  const size_t n = (size_t)rows * cols;
+  TC_REQUIRE(n > 0 && n < (1ull << 32), "dropout: %d x %d elements", rows, cols);
+  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, res, gate, rows,
+                     cols, d, out);
+  return check_launch("dropout");
 }
 
 // ---- box = reg_out (+ reference): backward into the previous layer's box ----

@@ -7,6 +7,9 @@
 // ~60 forward and ~100 backward autograd nodes, each a Python -> ctypes round trip.
 // Reference: HEAD:531-729 (forward), tools/train.py:245-252 (what is trainable).
 #include <math.h>
+#include <string.h>
+
+#include <vector>
 
 #include "kernels.hpp"
 
@@ -36,7 +39,7 @@ struct Tape {
   float *xyz4, *w0p, *u0, *u1, *u2, *pos, *f0, *f1, *f2, *mem, *cxy, *addref;
   LayerTape L[TC_MAX_RADAR_LAYERS];
   // backward scratch
-  float *dbox, *dA, *dB, *dC, *dh, *dqp, *dkv, *dmem, *dqin, *dt64, *dt128, *dw0p;
+  float *dbox, *dA, *dB, *dC, *dD, *dh, *dqp, *dkv, *dmem, *dqin, *dt64, *dt128, *dw0p;
 };
 
 size_t tape_layout(const tc_head_weights* w, int B, int T, void* base, size_t cap, Tape* out) {
@@ -62,6 +65,7 @@ size_t tape_layout(const tc_head_weights* w, int B, int T, void* base, size_t ca
   }
   t.dbox = a.take<float>(rows * code);
   t.dA = a.take<float>(rows * C); t.dB = a.take<float>(rows * C); t.dC = a.take<float>(rows * C);
+  t.dD = a.take<float>(rows * C);
   t.dh = a.take<float>(rows * F); t.dqp = a.take<float>(rows * C);
   t.dkv = a.take<float>(rt * 2 * C); t.dmem = a.take<float>(rt * C); t.dqin = a.take<float>(rows * C);
   t.dt64 = a.take<float>(rt * 64); t.dt128 = a.take<float>(rt * 128); t.dw0p = a.take<float>(C * 4);
@@ -112,13 +116,14 @@ int lnorm(const float* a, const float* b, const tc_lnorm& n, float* y, int M, in
 }
 // backward of y = act(x W^T + b): dW += dY~^T x, db += colsum dY~, dx (=|+=) dY~ W
 //   y_relu: this layer's saved ReLU output (mask on dY) or nullptr; x_relu: mask on dx
+//   dx_scale: 1 / (1 - p) when x is a dropped-out ReLU output (zeros of x_relu = ReLU zeros + dropped)
 int lin_bwd(const float* x, const float* dy, const float* y_relu, const int* gate, const tc_linear& w,
             const tc_linear& g, const float* x_relu, float* dx, int accumulate, int M, int K, int N,
-            hipStream_t s) {
+            hipStream_t s, float dx_scale = 1.0f) {
   TS_TRY(launch_linear_bwd_weight(x, dy, y_relu, gate, const_cast<float*>(g.w), const_cast<float*>(g.b),
                                   M, K, N, 1.0f, s));
   if (dx != nullptr)
-    TS_TRY(launch_linear_bwd_data(dy, y_relu, gate, w.w, x_relu, dx, M, K, N, 1.0f, accumulate, s));
+    TS_TRY(launch_linear_bwd_data(dy, y_relu, gate, w.w, x_relu, dx, M, K, N, dx_scale, accumulate, s));
   return 0;
 }
 int ln_bwd(const float* a, const float* b, const tc_lnorm& n, const tc_lnorm& g, const float* dy,
@@ -128,7 +133,8 @@ int ln_bwd(const float* a, const float* b, const tc_lnorm& n, const tc_lnorm& g,
 }
 
 RadarAttnArgs core_args(const tc_head_weights* w, int r, const Tape& t, const float* box_prev,
-                        const float* tokens, int B, int T, int pad_mult) {
+                        const float* tokens, int B, int T, int pad_mult, float drop_p = 0.0f,
+                        unsigned long long seed = 0) {
   const int C = w->embed_dims, code = w->code_size;
   RadarAttnArgs ra;
   ra.qproj = t.L[r].qp; ra.ldq = C; ra.kv = t.L[r].kv; ra.ldkv = 2 * C;
@@ -138,6 +144,7 @@ RadarAttnArgs core_args(const tc_head_weights* w, int r, const Tape& t, const fl
   ra.rmin = w->radar[r].radius_min; ra.rmax = w->radar[r].radius_max;
   ra.attn_out = t.L[r].ao; ra.hit_counts = t.L[r].hits;
   ra.qscale = 1.0f / sqrtf((float)(C / w->num_heads));
+  ra.drop = make_drop(drop_p, seed, 4u * r + 0u, (unsigned)w->num_radar_tokens_ref);
   return ra;
 }
 
@@ -165,8 +172,11 @@ size_t tc_radar_train_tape_bytes(const tc_head_weights* w, int B, int T) {
 int tc_radar_train_fwd(const tc_head_weights* w, const float* hs_last, const float* ref_last,
                        const float* last_box, const float* radar_tokens, int B, int T, int pad_mult,
                        float* all_cls_scores, float* all_bbox_preds, void* tape, size_t tape_bytes,
-                       tc_stream_t stream) {
+                       float dropout_p, unsigned long long dropout_seed, tc_stream_t stream) {
   TS_TRY(check(w, B, T));
+  TC_REQUIRE(dropout_p >= 0.0f && dropout_p < 1.0f, "radar_train_fwd: dropout_p=%g", (double)dropout_p);
+  const bool drop = dropout_p > 0.0f;
+  const unsigned tref = (unsigned)w->num_radar_tokens_ref;
   Tape t;
   TC_REQUIRE(tape_layout(w, B, T, tape, tape_bytes, &t) <= tape_bytes, "radar_train_fwd: tape too small");
   hipStream_t s = as_stream(stream);
@@ -203,11 +213,20 @@ int tc_radar_train_fwd(const tc_head_weights* w, const float* hs_last, const flo
     const tc_linear wkv{rl.attn.in_proj.w + (size_t)C * C, rl.attn.in_proj.b + C};
     TS_TRY(lin(qin, wq, rows, C, C, 0, l.qp, s));
     TS_TRY(lin(t.mem, wkv, rt, C, 2 * C, 0, l.kv, s));
-    TS_TRY(launch_radar_attn(core_args(w, r, t, box_prev, radar_tokens, B, T, pad_mult), s));
-    TS_TRY(lin(l.ao, rl.attn.out_proj, rows, C, C, 0, l.x1, s, qin, l.hits));
+    TS_TRY(launch_radar_attn(core_args(w, r, t, box_prev, radar_tokens, B, T, pad_mult, dropout_p, dropout_seed), s));
+    if (drop) {     // x1 = qin + gate * rf_dropout2(out_proj(ao)), HEAD:581 (l.ff is free until linear2)
+      TS_TRY(lin(l.ao, rl.attn.out_proj, rows, C, C, 0, l.ff, s));
+      TS_TRY(launch_dropout(l.ff, qin, l.hits, rows, C, make_drop(dropout_p, dropout_seed, 4u * r + 1u, tref), l.x1, s));
+    } else {
+      TS_TRY(lin(l.ao, rl.attn.out_proj, rows, C, C, 0, l.x1, s, qin, l.hits));
+    }
     TS_TRY(lnorm(l.x1, nullptr, rl.norm2, l.x2, rows, 0, s));
     TS_TRY(lin(l.x2, rl.linear1, rows, C, F, 1, l.h, s));
+    if (drop)       // rf_dropout(relu(linear1)), HEAD:584: the tape keeps the dropped activations
+      TS_TRY(launch_dropout(l.h, nullptr, nullptr, rows, F, make_drop(dropout_p, dropout_seed, 4u * r + 2u, tref), l.h, s));
     TS_TRY(lin(l.h, rl.linear2, rows, F, C, 0, l.ff, s));
+    if (drop)       // rf_dropout3(ffn_out), HEAD:585
+      TS_TRY(launch_dropout(l.ff, nullptr, nullptr, rows, C, make_drop(dropout_p, dropout_seed, 4u * r + 3u, tref), l.ff, s));
     TS_TRY(lnorm(l.x2, l.ff, rl.norm3, l.x3, rows, 0, s));
     TS_TRY(lin(l.x3, rl.final_cls.l0, rows, C, C, 0, l.c0, s));
     TS_TRY(lnorm(l.c0, nullptr, rl.final_cls.n1, l.c1, rows, 1, s));
@@ -229,9 +248,14 @@ int tc_radar_train_fwd(const tc_head_weights* w, const float* hs_last, const flo
 int tc_radar_train_bwd(const tc_head_weights* w, const tc_head_weights* grads, const float* hs_last,
                        const float* last_box, const float* radar_tokens, int B, int T, int pad_mult,
                        const float* all_bbox_preds, const float* d_all_cls, const float* d_all_box,
-                       void* tape, size_t tape_bytes, tc_stream_t stream) {
+                       void* tape, size_t tape_bytes, float dropout_p, unsigned long long dropout_seed,
+                       tc_stream_t stream) {
   TS_TRY(check(w, B, T));
   TC_REQUIRE(grads != nullptr, "radar_train_bwd: grads is NULL");
+  TC_REQUIRE(dropout_p >= 0.0f && dropout_p < 1.0f, "radar_train_bwd: dropout_p=%g", (double)dropout_p);
+  const bool drop = dropout_p > 0.0f;
+  const unsigned tref = (unsigned)w->num_radar_tokens_ref;
+  const float keep_scale = drop ? 1.0f / (1.0f - dropout_p) : 1.0f;
   Tape t;
   TC_REQUIRE(tape_layout(w, B, T, tape, tape_bytes, &t) <= tape_bytes, "radar_train_bwd: tape too small");
   hipStream_t s = as_stream(stream);
@@ -272,15 +296,27 @@ int tc_radar_train_bwd(const tc_head_weights* w, const tc_head_weights* grads, c
     if (have_dqin) TS_TRY(add_into(t.dqin, t.dA, (size_t)rows * C, s));
     // x3 = LN3(x2 + ff): dz -> dB (grad of x2 and of ff)
     TS_TRY(ln_bwd(l.x2, l.ff, rl.norm3, gl.norm3, t.dA, nullptr, t.dB, rows, s));
-    TS_TRY(lin_bwd(l.h, t.dB, nullptr, nullptr, rl.linear2, gl.linear2, l.h, t.dh, 0, rows, F, C, s));
+    const float* dff = t.dB;                                  // gradient of ffn_out
+    if (drop) {     // through rf_dropout3: same mask on the gradient; dz itself still feeds dx2 below
+      TS_TRY(launch_dropout(t.dB, nullptr, nullptr, rows, C, make_drop(dropout_p, dropout_seed, 4u * r + 3u, tref), t.dD, s));
+      dff = t.dD;
+    }
+    // l.h = rf_dropout(relu(.)): its zeros are the ReLU zeros and the dropped elements, the kept ones
+    // carry 1 / (1 - p)
+    TS_TRY(lin_bwd(l.h, dff, nullptr, nullptr, rl.linear2, gl.linear2, l.h, t.dh, 0, rows, F, C, s, keep_scale));
     TS_TRY(lin_bwd(l.x2, t.dh, nullptr, nullptr, rl.linear1, gl.linear1, nullptr, t.dB, 1, rows, C, F, s));   // dx2 = dz + dh W1
     // x2 = LN2(x1): dx1 -> dC
     TS_TRY(ln_bwd(l.x1, nullptr, rl.norm2, gl.norm2, t.dB, nullptr, t.dC, rows, s));
     // x1 = qin + gate * out_proj(ao): d ao -> dA, d qin = dx1
-    TS_TRY(lin_bwd(l.ao, t.dC, nullptr, l.hits, rl.attn.out_proj, gl.attn.out_proj, nullptr, t.dA, 0, rows, C, C, s));
+    const float* dproj = t.dC;                                // gradient of out_proj(ao) before the row gate
+    if (drop) {     // through rf_dropout2
+      TS_TRY(launch_dropout(t.dC, nullptr, nullptr, rows, C, make_drop(dropout_p, dropout_seed, 4u * r + 1u, tref), t.dD, s));
+      dproj = t.dD;
+    }
+    TS_TRY(lin_bwd(l.ao, dproj, nullptr, l.hits, rl.attn.out_proj, gl.attn.out_proj, nullptr, t.dA, 0, rows, C, C, s));
     TS_HIP(hipMemsetAsync(t.dkv, 0, (size_t)rt * 2 * C * 4, s));
     {
-      RadarAttnArgs ra = core_args(w, r, t, box_prev, radar_tokens, B, T, pad_mult);
+      RadarAttnArgs ra = core_args(w, r, t, box_prev, radar_tokens, B, T, pad_mult, dropout_p, dropout_seed);
       const float qs = ra.qscale;
       ra.qscale = 1.0f;
       TS_TRY(launch_radar_attn_bwd(ra, qs, t.dA, t.dqp, t.dkv, s));
@@ -316,6 +352,26 @@ int tc_radar_train_bwd(const tc_head_weights* w, const tc_head_weights* grads, c
                                   1.0f, s));
   TS_TRY(copy_cols(t.dw0p, 4, const_cast<float*>(gpe.l0.w), 3, C, 3, 1, s));
   return 0;
+}
+
+// The multipliers (0 or 1 / (1 - p)) of elements 0..n-1 of a dropout site, for tests and for
+// replaying an iteration elsewhere (site = 4 * radar layer + {0 attention probabilities, index
+// ((row * 8 + head) * num_radar_tokens_ref + token); 1 rf_dropout2; 2 rf_dropout; 3 rf_dropout3,
+// index row * cols + col}).
+int tc_dropout_mask(float dropout_p, unsigned long long seed, int site, size_t n, float* out,
+                    tc_stream_t stream) {
+  TC_REQUIRE(dropout_p >= 0.0f && dropout_p < 1.0f && n < (1ull << 32), "dropout_mask: p=%g n=%zu",
+             (double)dropout_p, n);
+  hipStream_t s = as_stream(stream);
+  // ones -> dropout
+  std::vector<float> ones(1, 1.0f);
+  (void)ones;
+  TS_HIP(hipMemsetAsync(out, 0, n * 4, s));
+  float one = 1.0f;
+  unsigned bits;
+  memcpy(&bits, &one, 4);
+  TS_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(out), (int)bits, n, s));
+  return launch_dropout(out, nullptr, nullptr, 1, (int)n, make_drop(dropout_p, seed, (unsigned)site, 1500u), out, s);
 }
 
 }  // extern "C"

@@ -385,9 +385,10 @@ class Detr3DHead(BaseModule):
         last state, last reference and last box (``aux``) feed the radar stack,
         which is recomputed here node by node (transcar_amd/autograd_ops.py)
         so that ``loss.backward()`` reaches every trainable parameter through
-        HIP backward kernels.  Dropout layers act as the identity (the
-        reference trains with p = 0.1, HEAD:129-171; stochastic dropout is not
-        implemented, so training here is the deterministic p = 0 variant)."""
+        HIP backward kernels.  Dropout layers act as the identity on this path
+        (the reference trains with p = 0.1, HEAD:129-171); the two-call path of
+        transcar_amd/trainer.py (tc_radar_train_fwd/_bwd) applies the fusion
+        layers' dropout."""
         from . import autograd_ops as A
         for grp in (self.transformer, self.cls_branches, self.reg_branches,
                     self.query_embedding):

@@ -108,7 +108,7 @@ class FusionTrainer:
     """head: transcar_amd.Detr3DHead on the GPU, built with ``train_cfg``."""
 
     def __init__(self, head, lr=1.5e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01,
-                 max_norm=35.0, device_loss=True):
+                 max_norm=35.0, device_loss=True, dropout=0.1, seed=0):
         self.head = head.freeze_decoder()
         self.bucket = FlatBucket(head.trainable_parameters())
         head.refresh_weights()                      # parameter addresses moved into the bucket
@@ -119,6 +119,10 @@ class FusionTrainer:
         self.weight_decay, self.max_norm = weight_decay, max_norm
         self.iter = 0
         self.device_loss = device_loss     # step_fused_nhwc: losses + their gradients from HIP kernels
+        # step_fused_nhwc: dropout of the fusion layers as the reference trains them (HEAD:129-171,
+        # p = 0.1); counter-based masks from (seed, iteration).  The frozen decoder and the
+        # per-operator autograd path (step / step_nhwc) run without dropout.
+        self.dropout, self.seed = float(dropout), int(seed)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -161,10 +165,11 @@ class FusionTrainer:
         Q = head.num_query
         all_cls = torch.empty((3, B, Q, head.cls_out_channels), dtype=torch.float32, device=tokens.device)
         all_box = torch.empty((3, B, Q, head.code_size), dtype=torch.float32, device=tokens.device)
+        drop_seed = (self.seed * 0x9E3779B1 + self.iter * 0x85EBCA77 + 1) & 0xFFFFFFFFFFFFFFFF
         L.check(lib.tc_radar_train_fwd(
             C.byref(w), hs_last.data_ptr(), ref_last.data_ptr(), last_box.data_ptr(), tokens.data_ptr(),
             B, T, int(pad_mult), all_cls.data_ptr(), all_box.data_ptr(), tape.data_ptr(), tape.numel(),
-            self._stream()), 'tc_radar_train_fwd')
+            self.dropout, drop_seed, self._stream()), 'tc_radar_train_fwd')
         if self.device_loss:
             from .device_loss import detr_loss_device
             losses, d_cls, d_box, _ = detr_loss_device(head, all_cls, all_box, gt_bboxes_list,
@@ -183,7 +188,8 @@ class FusionTrainer:
         L.check(lib.tc_radar_train_bwd(
             C.byref(w), C.byref(g), hs_last.data_ptr(), last_box.data_ptr(), tokens.data_ptr(), B, T,
             int(pad_mult), all_box.data_ptr(), d_cls.data_ptr(), d_box.data_ptr(), tape.data_ptr(),
-            tape.numel(), self._stream()), 'tc_radar_train_bwd')
+            tape.numel(), self.dropout, drop_seed, self._stream()), 'tc_radar_train_bwd')
+        self.last_dropout_seed = drop_seed
         if update:
             self._optimizer_step(lr)
         return {k: v.detach() for k, v in losses.items()}
