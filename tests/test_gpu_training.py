@@ -433,11 +433,12 @@ def test_fused_training_with_dropout_matches_reference_formula(A, golden_dir):
     hip_grads = {n: q.grad.detach().cpu().clone() for n, q in h.trainable_parameters()}
     # a different seed gives different masks and a different loss; the same seed the same
     l_same = tr.step_fused_nhwc(nhwc, l2i, img_hw, tokens, pad_mult, [gt], [labels], update=False)
-    assert tr.last_dropout_seed == seed and all(float(l_same[k]) == float(losses[k]) for k in losses)
+    assert tr.last_dropout_seed == seed                      # (the loss sums use atomics: equal up to rounding)
+    assert all(abs(float(l_same[k]) - float(losses[k])) <= 1e-5 * max(1.0, abs(float(losses[k]))) for k in losses)
     tr.iter = 4
     l_other = tr.step_fused_nhwc(nhwc, l2i, img_hw, tokens, pad_mult, [gt], [labels], update=False)
     assert tr.last_dropout_seed != seed
-    assert any(abs(float(l_other[k]) - float(losses[k])) > 1e-6 for k in losses)
+    assert any(abs(float(l_other[k]) - float(losses[k])) > 1e-4 * max(1.0, abs(float(losses[k]))) for k in losses)
 
     # ---- the masks
     lib = L.lib()

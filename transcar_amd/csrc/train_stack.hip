@@ -9,8 +9,6 @@
 #include <math.h>
 #include <string.h>
 
-#include <vector>
-
 #include "kernels.hpp"
 
 namespace tc {
@@ -363,11 +361,7 @@ int tc_dropout_mask(float dropout_p, unsigned long long seed, int site, size_t n
   TC_REQUIRE(dropout_p >= 0.0f && dropout_p < 1.0f && n < (1ull << 32), "dropout_mask: p=%g n=%zu",
              (double)dropout_p, n);
   hipStream_t s = as_stream(stream);
-  // ones -> dropout
-  std::vector<float> ones(1, 1.0f);
-  (void)ones;
-  TS_HIP(hipMemsetAsync(out, 0, n * 4, s));
-  float one = 1.0f;
+  const float one = 1.0f;          // dropout of a tensor of ones
   unsigned bits;
   memcpy(&bits, &one, 4);
   TS_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(out), (int)bits, n, s));
