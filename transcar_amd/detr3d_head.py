@@ -294,16 +294,26 @@ class Detr3DHead(BaseModule):
         return torch.from_numpy(tokens).to(device), pad_mult
 
     def forward_nhwc(self, feats_nhwc, lidar2img, img_hw, tokens, pad_mult,
-                     aux=False, _allow_train=False, lane=0):
+                     aux=False, _allow_train=False, lane=0, decoder_only=False):
         """The device-side forward: everything already on the GPU.
         feats_nhwc: list of [B*N,H,W,C]; lidar2img [B,N,4,4]; tokens [B,T,36].
         Only enqueues work on the current stream (graph-capturable).
         lane: forwards that may be in flight at the same time (on different
         streams, transcar_amd/pipeline.py) need different lanes -- each lane
-        owns a workspace; the weights are shared."""
+        owns a workspace; the weights are shared.
+        decoder_only: stop after the DETR3D decoder (aux carries its states);
+        the training iteration recomputes the radar stack itself."""
         if not _allow_train:
             require_eval(self)
         w = self.head_weights()
+        packed = self._packed_view
+        if decoder_only:
+            def _no_radar(src):
+                dst = L.tc_head_weights()
+                C.memmove(C.byref(dst), C.byref(src), C.sizeof(src))
+                dst.num_radar_layers = 0
+                return dst
+            w, packed = _no_radar(w), _no_radar(packed)
         B = lidar2img.shape[0]
         T = tokens.shape[1]
         dev = lidar2img.device
@@ -338,7 +348,7 @@ class Detr3DHead(BaseModule):
             aux_s = L.tc_head_aux(**{k: t.data_ptr()
                                      for k, t in aux_t.items()})
         L.check(lib.tc_head_forward(
-            C.byref(w), C.byref(self._packed_view), C.byref(fv), B,
+            C.byref(w), C.byref(packed), C.byref(fv), B,
             lidar2img.data_ptr(),
             float(img_hw[0]), float(img_hw[1]), tokens.data_ptr(), T,
             int(pad_mult), cls.data_ptr(), box.data_ptr(),

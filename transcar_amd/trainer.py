@@ -147,7 +147,7 @@ class FusionTrainer:
         head.train()
         with torch.no_grad():
             base = head.forward_nhwc(feats_nhwc, lidar2img, img_hw, tokens, pad_mult, aux=True,
-                                     _allow_train=True)
+                                     _allow_train=True, decoder_only=True)
         aux = base['aux']
         w = head.head_weights()
         B, T = lidar2img.shape[0], tokens.shape[1]
