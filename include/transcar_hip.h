@@ -333,13 +333,21 @@ int tc_radar_attn_core_fwd(const float* qproj, float q_scale, const float* kv,
                            const float* centre_xy, int ld_c, const float* box, int code_size,
                            const float* radar_xy, int ld_xy, int B, int Q, int T, int C,
                            int num_heads, int pad_mult, float radius_min, float radius_max,
-                           float* attn_out, int* hit_counts, tc_stream_t stream);
+                           float* attn_out, int* hit_counts, float dropout_p,
+                           unsigned long long dropout_seed, int dropout_site, tc_stream_t stream);
 int tc_radar_attn_core_bwd(const float* qproj, float q_scale, const float* kv,
                            const float* centre_xy, int ld_c, const float* box, int code_size,
                            const float* radar_xy, int ld_xy, int B, int Q, int T, int C,
                            int num_heads, int pad_mult, float radius_min, float radius_max,
                            const float* attn_out, const float* d_attn, float* dq, float* dkv,
+                           float dropout_p, unsigned long long dropout_seed, int dropout_site,
                            tc_stream_t stream);
+/* out[i] = keep(seed, site, i) ? x[i] / (1 - p) : 0 (nn.Dropout in train mode with the counter-based
+ * masks described at tc_radar_train_fwd; in place allowed; applied to a gradient with the same
+ * (seed, site) it is the backward).  dropout_p / seed / site of the attention core: the mask on the
+ * attention probabilities (nn.MultiheadAttention(dropout=0.1), HEAD:129); p = 0 turns it off. */
+int tc_dropout(const float* x, int rows, int cols, float dropout_p, unsigned long long seed, int site,
+               float* out, tc_stream_t stream);
 
 /* Optimizer on the flat fp32 bucket of the trainable parameters (one RCCL
  * all-reduce): out[0] += sum g^2;  torch.optim.AdamW step with

@@ -224,7 +224,9 @@ def train_head(golden_dir):
     cfg['train_cfg'] = configs.train_cfg_pts
     h = T.build_head(cfg)
     h.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(3).items()})
-    return h.to(dev()).freeze_decoder()
+    # deterministic training forward for the comparisons with the (dropout-free) fixtures; the
+    # dropout tests set their own p
+    return h.to(dev()).freeze_decoder().set_dropout(0.0)
 
 
 def frame_inputs(golden_dir):
@@ -410,7 +412,8 @@ def test_fused_step_with_device_loss_equals_torch_loss(A, golden_dir):
     assert float((tr.bucket.grads - g_torch).abs().max() / g_torch.abs().max()) < 1e-4
 
 
-def test_fused_training_with_dropout_matches_reference_formula(A, golden_dir):
+@pytest.mark.parametrize('path', ['fused', 'autograd'])
+def test_fused_training_with_dropout_matches_reference_formula(A, golden_dir, path):
     """The four dropout sites of every fusion layer (HEAD:129-171, 581-585; p = 0.1) in
     tc_radar_train_fwd / _bwd.  The masks are counter-based, so the check is: with the SAME masks
     (read back through tc_dropout_mask) the reference formula -- the oracle in train mode with given
@@ -427,18 +430,33 @@ def test_fused_training_with_dropout_matches_reference_formula(A, golden_dir):
     img_hw = metas[0]['img_shape'][0][:2]
     tokens, pad_mult = h.radar_tokens(metas, dev())
     tr = FusionTrainer(h, dropout=p, seed=5)
-    tr.iter = 3
-    losses = tr.step_fused_nhwc(nhwc, l2i, img_hw, tokens, pad_mult, [gt], [labels], update=False)
-    seed = tr.last_dropout_seed
-    hip_grads = {n: q.grad.detach().cpu().clone() for n, q in h.trainable_parameters()}
-    # a different seed gives different masks and a different loss; the same seed the same
-    l_same = tr.step_fused_nhwc(nhwc, l2i, img_hw, tokens, pad_mult, [gt], [labels], update=False)
-    assert tr.last_dropout_seed == seed                      # (the loss sums use atomics: equal up to rounding)
-    assert all(abs(float(l_same[k]) - float(losses[k])) <= 1e-5 * max(1.0, abs(float(losses[k]))) for k in losses)
-    tr.iter = 4
-    l_other = tr.step_fused_nhwc(nhwc, l2i, img_hw, tokens, pad_mult, [gt], [labels], update=False)
-    assert tr.last_dropout_seed != seed
-    assert any(abs(float(l_other[k]) - float(losses[k])) > 1e-4 * max(1.0, abs(float(losses[k]))) for k in losses)
+    if path == 'fused':          # tc_radar_train_fwd / _bwd
+        tr.iter = 3
+        losses = tr.step_fused_nhwc(nhwc, l2i, img_hw, tokens, pad_mult, [gt], [labels], update=False)
+        seed = tr.last_dropout_seed
+        hip_grads = {n: q.grad.detach().cpu().clone() for n, q in h.trainable_parameters()}
+        # a different seed gives different masks and a different loss; the same seed the same
+        l_same = tr.step_fused_nhwc(nhwc, l2i, img_hw, tokens, pad_mult, [gt], [labels], update=False)
+        assert tr.last_dropout_seed == seed                      # (the loss sums use atomics: equal up to rounding)
+        assert all(abs(float(l_same[k]) - float(losses[k])) <= 1e-5 * max(1.0, abs(float(losses[k]))) for k in losses)
+        tr.iter = 4
+        l_other = tr.step_fused_nhwc(nhwc, l2i, img_hw, tokens, pad_mult, [gt], [labels], update=False)
+        assert tr.last_dropout_seed != seed
+        assert any(abs(float(l_other[k]) - float(losses[k])) > 1e-4 * max(1.0, abs(float(losses[k]))) for k in losses)
+    else:                        # the module API: head.train()(feats, metas) -> loss -> backward
+        h.set_dropout(p)
+        h.dropout_seed = 11
+        tr.bucket.zero_grad()
+        outs = h.train()(feats, metas)
+        seed = h.last_dropout_seed
+        losses = h.loss([gt], [labels], outs)
+        sum(v for k, v in losses.items() if 'loss' in k).backward()
+        losses = {k: v.detach() for k, v in losses.items()}
+        hip_grads = {n: q.grad.detach().cpu().clone() for n, q in h.trainable_parameters()}
+        with torch.no_grad():
+            again = h(feats, metas)                               # next forward: next masks
+        assert h.last_dropout_seed != seed
+        assert float((again['all_cls_scores'] - outs['all_cls_scores']).abs().max()) > 1e-4
 
     # ---- the masks
     lib = L.lib()

@@ -155,10 +155,11 @@ SIGNATURES = {
     'tc_box_add_ref_bwd': (_i, [_vp, _i, _vp, _i, _vp]),
     'tc_radar_attn_core_fwd': (_i, [_vp, _f, _vp, _vp, _i, _vp, _i, _vp, _i,
                                     _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp,
-                                    _vp]),
+                                    _f, C.c_ulonglong, _i, _vp]),
+    'tc_dropout': (_i, [_vp, _i, _i, _f, C.c_ulonglong, _i, _vp, _vp]),
     'tc_radar_attn_core_bwd': (_i, [_vp, _f, _vp, _vp, _i, _vp, _i, _vp, _i,
                                     _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp,
-                                    _vp, _vp, _vp]),
+                                    _vp, _vp, _f, C.c_ulonglong, _i, _vp]),
     'tc_radar_train_tape_bytes': (_sz, [_P(tc_head_weights), _i, _i]),
     'tc_radar_train_fwd': (_i, [_P(tc_head_weights), _vp, _vp, _vp, _vp, _i, _i,
                                 _i, _vp, _vp, _vp, _sz, _f, C.c_ulonglong, _vp]),

@@ -133,7 +133,8 @@ class _RadarAttnCore(Function):
     reference's masks are boolean).  Returns (attn_out [B,Q,C], hits [B,Q])."""
 
     @staticmethod
-    def forward(ctx, qproj, kv, centre, ld_c, box, tokens, pad_mult, rmin, rmax, heads):
+    def forward(ctx, qproj, kv, centre, ld_c, box, tokens, pad_mult, rmin, rmax, heads,
+                drop=(0.0, 0, 0)):
         for n, t in (('qproj', qproj), ('kv', kv), ('centre', centre), ('box', box),
                      ('tokens', tokens)):
             _chk(t, n)
@@ -146,9 +147,11 @@ class _RadarAttnCore(Function):
                 int(pad_mult), float(rmin), float(rmax))
         L.check(L.lib().tc_radar_attn_core_fwd(
             _p(qproj), scale, _p(kv), _p(centre), meta[1], _p(box), meta[2], _p(tokens), meta[3],
-            B, Q, T, Cd, meta[8], meta[9], meta[10], meta[11], _p(out), _p(hits), _stream()),
+            B, Q, T, Cd, meta[8], meta[9], meta[10], meta[11], _p(out), _p(hits),
+            float(drop[0]), int(drop[1]), int(drop[2]), _stream()),
             'tc_radar_attn_core_fwd')
         ctx.meta = meta
+        ctx.drop = (float(drop[0]), int(drop[1]), int(drop[2]))
         ctx.save_for_backward(qproj, kv, centre, box, tokens, out)
         ctx.mark_non_differentiable(hits)
         return out, hits
@@ -164,8 +167,32 @@ class _RadarAttnCore(Function):
         L.check(L.lib().tc_radar_attn_core_bwd(
             _p(qproj), scale, _p(kv), _p(centre), ld_c, _p(box), code, _p(tokens), ld_xy,
             B, Q, T, Cd, heads, pad_mult, rmin, rmax, _p(out), _p(d_out), _p(dq), _p(dkv),
-            _stream()), 'tc_radar_attn_core_bwd')
-        return dq, dkv, None, None, None, None, None, None, None, None
+            ctx.drop[0], ctx.drop[1], ctx.drop[2], _stream()), 'tc_radar_attn_core_bwd')
+        return dq, dkv, None, None, None, None, None, None, None, None, None
+
+
+class _Dropout(Function):
+    """nn.Dropout in train mode with the library's counter-based mask of (seed, site):
+    y = keep * x / (1 - p); the backward applies the same mask to the gradient."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed, site):
+        _chk(x, 'x')
+        cols = x.shape[-1]
+        out = torch.empty_like(x)
+        ctx.args = (x.numel() // cols, cols, float(p), int(seed), int(site))
+        L.check(L.lib().tc_dropout(_p(x), ctx.args[0], cols, ctx.args[2], ctx.args[3], ctx.args[4],
+                                   _p(out), _stream()), 'tc_dropout')
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        rows, cols, p, seed, site = ctx.args
+        L.check(L.lib().tc_dropout(_p(dy), rows, cols, p, seed, site, _p(dx), _stream()), 'tc_dropout')
+        return dx, None, None, None
 
 
 class _BoxAddRef(Function):
@@ -217,8 +244,14 @@ def add_layernorm(a, b, gamma, beta, relu=False):
     return _AddLayerNorm.apply(a, b, gamma, beta, relu)
 
 
-def radar_attn_core(qproj, kv, centre, ld_c, box, tokens, pad_mult, rmin, rmax, heads=8):
-    return _RadarAttnCore.apply(qproj, kv, centre, ld_c, box, tokens, pad_mult, rmin, rmax, heads)
+def dropout(x, p, seed, site):
+    """Identity when p == 0."""
+    return x if p <= 0.0 else _Dropout.apply(x, p, seed, site)
+
+
+def radar_attn_core(qproj, kv, centre, ld_c, box, tokens, pad_mult, rmin, rmax, heads=8,
+                    drop=(0.0, 0, 0)):
+    return _RadarAttnCore.apply(qproj, kv, centre, ld_c, box, tokens, pad_mult, rmin, rmax, heads, drop)
 
 
 def box_add_ref(reg_out, prev_box=None, add_ref=None):

@@ -769,11 +769,14 @@ int tc_radar_attn_core_fwd(const float* qproj, float q_scale, const float* kv,
                            const float* centre_xy, int ld_c, const float* box, int code_size,
                            const float* radar_xy, int ld_xy, int B, int Q, int T, int C,
                            int num_heads, int pad_mult, float radius_min, float radius_max,
-                           float* attn_out, int* hit_counts, tc_stream_t stream) {
+                           float* attn_out, int* hit_counts, float dropout_p,
+                           unsigned long long dropout_seed, int dropout_site, tc_stream_t stream) {
   TC_REQUIRE(attn_out != nullptr && hit_counts != nullptr, "radar_attn_core: NULL output");
+  TC_REQUIRE(dropout_p >= 0.0f && dropout_p < 1.0f, "radar_attn_core: dropout_p=%g", (double)dropout_p);
   RadarAttnArgs r = radar_core_args(qproj, q_scale, kv, centre_xy, ld_c, box, code_size, radar_xy,
                                     ld_xy, B, Q, T, C, num_heads, pad_mult, radius_min, radius_max);
   r.attn_out = attn_out; r.hit_counts = hit_counts;
+  r.drop = make_drop(dropout_p, dropout_seed, (unsigned)dropout_site, 1500u);
   return launch_radar_attn(r, as_stream(stream));
 }
 
@@ -782,11 +785,21 @@ int tc_radar_attn_core_bwd(const float* qproj, float q_scale, const float* kv,
                            const float* radar_xy, int ld_xy, int B, int Q, int T, int C,
                            int num_heads, int pad_mult, float radius_min, float radius_max,
                            const float* attn_out, const float* d_attn, float* dq, float* dkv,
+                           float dropout_p, unsigned long long dropout_seed, int dropout_site,
                            tc_stream_t stream) {
+  TC_REQUIRE(dropout_p >= 0.0f && dropout_p < 1.0f, "radar_attn_core_bwd: dropout_p=%g", (double)dropout_p);
   RadarAttnArgs r = radar_core_args(qproj, 1.0f, kv, centre_xy, ld_c, box, code_size, radar_xy,
                                     ld_xy, B, Q, T, C, num_heads, pad_mult, radius_min, radius_max);
   r.attn_out = const_cast<float*>(attn_out);
+  r.drop = make_drop(dropout_p, dropout_seed, (unsigned)dropout_site, 1500u);
   return launch_radar_attn_bwd(r, q_scale, d_attn, dq, dkv, as_stream(stream));
+}
+
+int tc_dropout(const float* x, int rows, int cols, float dropout_p, unsigned long long seed, int site,
+               float* out, tc_stream_t stream) {
+  TC_REQUIRE(dropout_p >= 0.0f && dropout_p < 1.0f, "dropout: p=%g", (double)dropout_p);
+  return launch_dropout(x, nullptr, nullptr, rows, cols, make_drop(dropout_p, seed, (unsigned)site, 1500u), out,
+                        as_stream(stream));
 }
 
 int tc_sq_norm(const float* g, size_t n, float* out, tc_stream_t stream) {

@@ -124,6 +124,10 @@ class Detr3DHead(BaseModule):
             setattr(self, 'rf_linear2' + sfx, nn.Linear(F, E))
             for n in (1, 2, 3):
                 setattr(self, 'rf_norm%d%s' % (n, sfx), nn.LayerNorm(E))
+            # HEAD:132, 138-140 (rf_dropout1* is constructed but never used there either)
+            setattr(self, 'rf_dropout' + sfx, nn.Dropout(0.1))
+            for n in (1, 2, 3):
+                setattr(self, 'rf_dropout%d%s' % (n, sfx), nn.Dropout(0.1))
         self.radar_position_encoder = nn.Sequential(
             nn.Linear(3, E), nn.LayerNorm(E), nn.ReLU(inplace=True),
             nn.Linear(E, E), nn.LayerNorm(E), nn.ReLU(inplace=True))
@@ -395,10 +399,12 @@ class Detr3DHead(BaseModule):
         last state, last reference and last box (``aux``) feed the radar stack,
         which is recomputed here node by node (transcar_amd/autograd_ops.py)
         so that ``loss.backward()`` reaches every trainable parameter through
-        HIP backward kernels.  Dropout layers act as the identity on this path
-        (the reference trains with p = 0.1, HEAD:129-171); the two-call path of
-        transcar_amd/trainer.py (tc_radar_train_fwd/_bwd) applies the fusion
-        layers' dropout."""
+        HIP backward kernels.  The dropout layers of the fusion layers
+        (rf_multihead_attn*.dropout, rf_dropout*, rf_dropout2*, rf_dropout3*;
+        p = 0.1 in the reference, HEAD:129-171) are active with counter-based
+        masks of (``self.dropout_seed``, number of training forwards so far);
+        set their ``p`` to 0 (``set_dropout(0.0)``) for the deterministic
+        variant.  The frozen decoder runs without dropout."""
         from . import autograd_ops as A
         for grp in (self.transformer, self.cls_branches, self.reg_branches,
                     self.query_embedding):
@@ -434,9 +440,17 @@ class Detr3DHead(BaseModule):
         f = A.linear(f, rfe[4].weight, rfe[4].bias, act=1)
         mem = pos + f
 
+        self._train_forwards = getattr(self, '_train_forwards', 0) + 1
+        seed = (int(getattr(self, 'dropout_seed', 0)) * 0x9E3779B1
+                + self._train_forwards * 0x85EBCA77 + 1) & 0xFFFFFFFFFFFFFFFF
+        self.last_dropout_seed = seed
         all_cls, all_box = [], []
         for r, (sfx, asfx) in enumerate((('', ''), ('_2', '2'), ('_3', '3'))):
             attn = getattr(self, 'rf_multihead_attn' + asfx)
+            p_attn = float(attn.dropout)
+            p_ffn = float(getattr(self, 'rf_dropout' + sfx).p)
+            p2 = float(getattr(self, 'rf_dropout2' + sfx).p)
+            p3 = float(getattr(self, 'rf_dropout3' + sfx).p)
             wq, bq = attn.in_proj_weight[:E], attn.in_proj_bias[:E]
             wkv, bkv = attn.in_proj_weight[E:], attn.in_proj_bias[E:]
             qp = A.linear(qf, wq, bq)
@@ -445,16 +459,22 @@ class Detr3DHead(BaseModule):
             rmin, rmax = RADAR_RADII[r]
             ao, hits = A.radar_attn_core(qp, kv, centre, ld_c, prev_box, tokens,
                                          pad_mult, rmin, rmax,
-                                         heads=attn.num_heads)
-            x = A.gated_linear_residual(ao, attn.out_proj.weight,
-                                        attn.out_proj.bias, qf, hits)
+                                         heads=attn.num_heads,
+                                         drop=(p_attn, seed, 4 * r + 0))
+            if p2 > 0.0:            # qf + gate * rf_dropout2(out_proj(ao)), HEAD:581
+                y = A.dropout(A.linear(ao, attn.out_proj.weight, attn.out_proj.bias),
+                              p2, seed, 4 * r + 1)
+                x = qf + y * (hits > 0).unsqueeze(-1).to(y.dtype)
+            else:
+                x = A.gated_linear_residual(ao, attn.out_proj.weight,
+                                            attn.out_proj.bias, qf, hits)
             n2 = getattr(self, 'rf_norm2' + sfx)
             n3 = getattr(self, 'rf_norm3' + sfx)
             l1 = getattr(self, 'rf_linear1' + sfx)
             l2 = getattr(self, 'rf_linear2' + sfx)
             x = A.add_layernorm(x, None, n2.weight, n2.bias)
-            h = A.linear(x, l1.weight, l1.bias, act=1)
-            ff = A.linear(h, l2.weight, l2.bias)
+            h = A.dropout(A.linear(x, l1.weight, l1.bias, act=1), p_ffn, seed, 4 * r + 2)
+            ff = A.dropout(A.linear(h, l2.weight, l2.bias), p3, seed, 4 * r + 3)
             qf = A.add_layernorm(x, ff, n3.weight, n3.bias)
             fc = getattr(self, 'final_cls' + asfx)
             fr = getattr(self, 'final_reg' + asfx)
@@ -474,6 +494,15 @@ class Detr3DHead(BaseModule):
         return {'all_cls_scores': torch.stack(all_cls),
                 'all_bbox_preds': torch.stack(all_box),
                 'enc_cls_scores': None, 'enc_bbox_preds': None}
+
+    def set_dropout(self, p):
+        """p of every dropout site of the radar fusion layers (HEAD:129-171 build
+        them with 0.1): 0.0 = the deterministic training forward."""
+        for asfx, sfx in (('', ''), ('2', '_2'), ('3', '_3')):
+            getattr(self, 'rf_multihead_attn' + asfx).dropout = float(p)
+            for name in ('rf_dropout', 'rf_dropout1', 'rf_dropout2', 'rf_dropout3'):
+                getattr(self, name + sfx).p = float(p)
+        return self
 
     def freeze_decoder(self):
         """tools/train.py:245-252."""
