@@ -549,32 +549,27 @@ __device__ __forceinline__ bool linear_step(const LinSpec& s, WBuf& w0, bool pre
     __builtin_amdgcn_sched_barrier(0);
   }
   SUB_STAMP(2);
+  // Two copies of the item body only (w0 -> w1, w1 -> w0): every item prefetches -- the next
+  // item of the step, the first item of the wave's next linear step (`next_first`), or, when
+  // there is neither, a harmless re-read (16 KiB at the end of a run of steps).
+  const float* fallback = wbase;
   int i = 0;
 #pragma unroll 1
-  for (; i + 2 < nitems; i += 2) {
+  for (; i + 1 < nitems; i += 2) {
     run(w0, w1, Yes{}, nullptr);
     __builtin_amdgcn_sched_barrier(0);
     SUB_STAMP(3 + i);
-    run(w1, w0, Yes{}, nullptr);
+    const bool last = i + 2 >= nitems;
+    run(w1, w0, Yes{}, last ? (next_first != nullptr ? next_first + 4 * lane : fallback) : nullptr);
     __builtin_amdgcn_sched_barrier(0);
     SUB_STAMP(4 + i);
   }
-  if (i + 1 < nitems) {
-    run(w0, w1, Yes{}, nullptr);
-    __builtin_amdgcn_sched_barrier(0);
+  if (i < nitems) {                  // odd item count (radar feature encoder): no cross-step fetch
+    run(w0, w1, Yes{}, fallback);
     SUB_STAMP(3 + i);
-    if (next_first != nullptr) {
-      run(w1, w0, Yes{}, next_first + 4 * lane);
-      SUB_STAMP(4 + i);
-      return true;
-    }
-    run(w1, w0, No{}, nullptr);
-    SUB_STAMP(4 + i);
-  } else {
-    run(w0, w1, No{}, nullptr);      // odd item count (radar feature encoder): no cross-step fetch
-    SUB_STAMP(3 + i);
+    return false;
   }
-  return false;
+  return next_first != nullptr;
 }
 
 template <int R, int NREC>
