@@ -531,19 +531,6 @@ __device__ __forceinline__ bool linear_step(const LinSpec& s, WBuf& w0, bool pre
   WBuf w1;
   SUB_STAMP(1);
   if (s.dbg & 32) return false;
-  if constexpr (R == 16) {
-    // 16-row tiles: one weight buffer.  An item then has 256 MFMAs (2048 cycles) to its 16 KiB
-    // of loads, the second buffer bought nothing for one frame at a time, and without it the
-    // kernel needs 220 instead of 396 VGPRs -- room for the attention workgroups of other
-    // frames in flight on the same CU (4 frames per step, 3 steps in flight: 3930 -> 4200 frames/s).
-    for (int it = 0; it < nitems; ++it) {
-      wload(w0, wcur, 16);
-      __builtin_amdgcn_sched_barrier(0);
-      run(w0, w1, No{}, nullptr);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    return false;
-  }
   if (!preloaded) {
     wload(w0, wbase, 16);
     __builtin_amdgcn_sched_barrier(0);
