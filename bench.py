@@ -45,6 +45,8 @@ def parse():
     ap.add_argument('--lanes', type=int, default=3,
                     help='frames in flight per GPU: one hipGraph + HIP stream each '
                          '(transcar_amd/pipeline.py); 1 = strictly one frame at a time')
+    ap.add_argument('--tile-rows', type=int, default=0, choices=[0, 4, 8, 16],
+                    help='row-tile height of the fused chains in the frame pipeline (0 = automatic)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--unfused', action='store_true',
                     help='operator-by-operator launches instead of the fused row chains')
@@ -391,7 +393,7 @@ def main():
         from transcar_amd.pipeline import FramePipeline
         lanes = [inp] + [make_inputs(head, dev, args.shapes, args.batch, seed=101 + rank + 7 * i)
                          for i in range(1, max(1, args.lanes))]
-        pipe = FramePipeline(head, lanes)
+        pipe = FramePipeline(head, lanes, tile_rows=args.tile_rows or None)
 
     def step():
         if pipe is not None:
@@ -432,6 +434,7 @@ def main():
                    'shapes': args.shapes, 'frames_per_step_per_gpu': args.batch,
                    'launch': 'eager' if pipe is None else 'hipGraph replay',
                    'frames_in_flight': 1 if pipe is None else pipe.lanes,
+                   'chain_tile_rows': args.tile_rows or 'auto',
                    'parallelism': 'dp%d (frames sharded, no data-path collective)' % world},
     }
     if rank == 0:

@@ -389,6 +389,13 @@ int tc_radar_train_bwd(const tc_head_weights* w, const tc_head_weights* grads, c
 int tc_dropout_mask(float dropout_p, unsigned long long seed, int site, size_t n, float* out,
                     tc_stream_t stream);
 
+/* Tuning: row-tile height of the fused row chains (4, 8 or 16 rows per workgroup; 0 = automatic:
+ * 4 up to 1024 rows per launch, 8 up to 2048, 16 beyond).  Process-wide, read when a forward is
+ * enqueued or captured.  With frames in flight (several streams) 8-row tiles at one frame per
+ * launch trade latency for throughput (MI355X: 1530 instead of 1910 frames/s one frame at a time,
+ * 3320 instead of 3150 with three in flight). */
+int tc_set_chain_tile_rows(int rows);
+
 
 /* ---- targets and losses on the device (HEAD:742-917; ASSIGN:106-125; COST:15-26) ----
  * tc_normalize_bbox: UTIL:4-24 on n ground-truth boxes [n,9] -> [n,10].

@@ -509,6 +509,13 @@ def test_frames_in_flight_equal_sequential(T, head):
     lane, (outs, dec) = pipe.launch(0)
     pipe.wait(lane)
     assert torch.equal(outs['all_bbox_preds'], want[1][1])
+    # 8-row tiles in this pipeline's graphs only (tc_set_chain_tile_rows): same results up to rounding
+    pipe8 = FramePipeline(head, lanes[1:], tile_rows=8)
+    lane, (outs8, _) = pipe8.launch(0)
+    pipe8.wait(lane)
+    np.testing.assert_allclose(outs8['all_bbox_preds'].cpu().numpy(), want[1][1].cpu().numpy(), atol=2e-4, rtol=0)
+    outs4, _ = bench.one_step(head, lanes[1])                 # the library is back on automatic
+    assert torch.equal(outs4['all_bbox_preds'], want[1][1])
 
 
 def test_box_decode_vs_oracle(T, head):

@@ -167,6 +167,7 @@ SIGNATURES = {
                                 _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz,
                                 _f, C.c_ulonglong, _vp]),
     'tc_dropout_mask': (_i, [_f, C.c_ulonglong, _i, _sz, _vp, _vp]),
+    'tc_set_chain_tile_rows': (_i, [_i]),
     'tc_normalize_bbox': (_i, [_vp, _i, _vp, _vp]),
     'tc_match_cost': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _f, _f,
                            _f, _f, _f, _vp, _vp]),

@@ -1115,9 +1115,10 @@ void init_k(ChainK& k) {
 // Row-tile height (measured, bench.py --batch 1/2/4): the smallest tile that still
 // gives about one workgroup per CU wins -- 4 rows for B = 1 (225 workgroups), 8 for
 // B = 2, 16 beyond (each weight register then feeds 4 MFMAs).
+static int g_tile_rows = 0;      // tc_set_chain_tile_rows (0: automatic)
 int tile_rows(int M) {
   const char* e = getenv("TRANSCAR_CHAIN_ROWS");
-  const int forced = e ? atoi(e) : 0;
+  const int forced = g_tile_rows ? g_tile_rows : e ? atoi(e) : 0;
   return forced ? forced : (M <= 1024 ? 4 : M <= 2048 ? 8 : 16);
 }
 
@@ -1142,6 +1143,17 @@ int launch(const ChainK& k, hipStream_t s, const char* what) {
 }
 
 }  // namespace
+
+void g_tile_rows_set(int rows) { g_tile_rows = rows; }
+
+extern "C" int tc_set_chain_tile_rows(int rows) {
+  if (rows != 0 && rows != 4 && rows != 8 && rows != 16) {
+    tc::set_error("tc_set_chain_tile_rows: rows=%d (0 = automatic, 4, 8 or 16)", rows);
+    return 1;
+  }
+  tc::g_tile_rows_set(rows);
+  return 0;
+}
 
 #ifdef TC_CHAIN_STAMPS
 extern "C" int tc_debug_chain_stamps(long long* host_out) {

@@ -27,7 +27,7 @@ class FramePipeline:
     ``launch``.
     """
 
-    def __init__(self, head, static_inputs, decode=True):
+    def __init__(self, head, static_inputs, decode=True, tile_rows=None):
         if not static_inputs:
             raise ValueError('at least one lane')
         self.head, self.decode = head, decode
@@ -35,7 +35,17 @@ class FramePipeline:
         self.streams = [torch.cuda.Stream() for _ in self.inputs]
         self.graphs, self.outputs = [], []
         self._next = 0
-        self._capture()
+        # tile_rows (4 | 8 | 16): row-tile height of the fused chains in THIS pipeline's graphs
+        # (tc_set_chain_tile_rows; None = the library's choice).  8 at one frame per lane buys
+        # throughput with >= 3 lanes and costs latency.
+        from . import _lib as L
+        if tile_rows:
+            L.check(L.lib().tc_set_chain_tile_rows(int(tile_rows)), 'tc_set_chain_tile_rows')
+        try:
+            self._capture()
+        finally:
+            if tile_rows:
+                L.lib().tc_set_chain_tile_rows(0)
 
     def _step(self, i):
         inp = self.inputs[i]
