@@ -117,6 +117,14 @@ def test_workspace_query_runs_without_gpu():
     assert b'embed_dims' in T.lib().tc_last_error()
 
 
+def test_tuning_knob_validates_without_gpu():
+    lib = T.lib()
+    assert lib.tc_set_chain_tile_rows(8) == 0 and lib.tc_set_chain_tile_rows(0) == 0
+    assert lib.tc_set_chain_tile_rows(5) != 0
+    assert b'tile_rows' in lib.tc_last_error()
+    assert lib.tc_set_chain_tile_rows(0) == 0
+
+
 _WORKER = r'''
 import os, sys
 sys.path.insert(0, %r)
