@@ -390,7 +390,7 @@ int tc_dropout_mask(float dropout_p, unsigned long long seed, int site, size_t n
                     tc_stream_t stream);
 
 /* Tuning: row-tile height of the fused row chains (4, 8 or 16 rows per workgroup; 0 = automatic:
- * 4 up to 1024 rows per launch, 8 up to 2048, 16 beyond).  Process-wide, read when a forward is
+ * 4 up to 1024 rows per launch, 8 beyond).  Process-wide, read when a forward is
  * enqueued or captured.  With frames in flight (several streams) 8-row tiles at one frame per
  * launch trade latency for throughput (MI355X: 1530 instead of 1910 frames/s one frame at a time,
  * 3320 instead of 3150 with three in flight). */

@@ -1112,14 +1112,16 @@ void init_k(ChainK& k) {
   k.dbg = e ? atoi(e) : 0;
 }
 
-// Row-tile height (measured, bench.py --batch 1/2/4): the smallest tile that still
-// gives about one workgroup per CU wins -- 4 rows for B = 1 (225 workgroups), 8 for
-// B = 2, 16 beyond (each weight register then feeds 4 MFMAs).
+// Row-tile height (measured, bench.py --batch 1/2/3/4/8): 4 rows while that gives about one
+// workgroup per CU (B = 1: 225 workgroups), 8 beyond.  Both run two workgroups per CU.  16-row
+// tiles (each weight register feeds 4 MFMAs, but 304 VGPRs and 120 KB of LDS: one workgroup per
+// CU) were the choice for B >= 3 until the item loop shrank; now they lose to 8 rows everywhere
+// (B = 4, one step at a time: 3410 vs 3770 frames/s) and remain selectable (tc_set_chain_tile_rows).
 static int g_tile_rows = 0;      // tc_set_chain_tile_rows (0: automatic)
 int tile_rows(int M) {
   const char* e = getenv("TRANSCAR_CHAIN_ROWS");
   const int forced = g_tile_rows ? g_tile_rows : e ? atoi(e) : 0;
-  return forced ? forced : (M <= 1024 ? 4 : M <= 2048 ? 8 : 16);
+  return forced ? forced : (M <= 1024 ? 4 : 8);
 }
 
 template <int PROG>
