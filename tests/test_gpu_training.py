@@ -361,6 +361,39 @@ def test_fused_training_path_gradients_match_reference(A, golden_dir):
     assert float(d) < 1e-4, float(d)
 
 
+def test_fused_training_batch_of_two_matches_autograd_path(A, golden_dir):
+    """Two different frames per iteration (the reference hard-codes one in its radar part): the
+    two-call stack + device loss against the per-operator autograd path + PyTorch loss."""
+    from transcar_amd import ops
+    from transcar_amd.trainer import FusionTrainer
+    h = train_head(golden_dir)
+    feats, metas, gt, labels = frame_inputs(golden_dir)
+    feats2_np = synth.make_feats('tiny', seed=9, smooth=(4, 6))
+    feats_b = [torch.cat([f, torch.from_numpy(g_).to(dev())], 0) for f, g_ in zip(feats, feats2_np)]
+    g5 = np.load(os.path.join(golden_dir, 'g5_head_tiny.npz'))
+    frame2 = synth.make_radar_frame(seed=5, n_per_radar=33, centres=g5['radar_centres'])
+    metas_b = synth.make_img_metas(2, synth.make_lidar2img(), radar=[metas[0]['radar'], frame2])
+    boxes2, labels2 = synth.make_gt(seed=8, n=11)
+    gt2 = torch.from_numpy(boxes2).clone()
+    gt2[:, 2] += gt2[:, 5] * 0.5
+    gts, lbs = [gt, gt2.to(dev())], [labels, torch.from_numpy(labels2).to(dev())]
+    nhwc = [ops.to_nhwc(f) for f in feats_b]
+    l2i = ops.lidar2img_tensor(metas_b, dev())
+    img_hw = metas_b[0]['img_shape'][0][:2]
+    tokens, pad_mult = h.radar_tokens(metas_b, dev())
+    tr = FusionTrainer(h, dropout=0.0)
+    l_fused = tr.step_fused_nhwc(nhwc, l2i, img_hw, tokens, pad_mult, gts, lbs, update=False)
+    fused = tr.bucket.grads.clone()
+    tr.bucket.zero_grad()
+    outs = h.train()(feats_b, metas_b)
+    l_auto = h.loss(gts, lbs, outs)
+    sum(v for k, v in l_auto.items() if 'loss' in k).backward()
+    for k in l_auto:
+        assert abs(float(l_auto[k]) - float(l_fused[k])) < 1e-4 * max(1.0, abs(float(l_auto[k]))), k
+    d = (tr.bucket.grads - fused).abs().max() / fused.abs().max()
+    assert float(d) < 2e-4, float(d)
+
+
 @pytest.mark.parametrize('n_gt', [24, 0])
 def test_device_loss_matches_reference_loss_and_autograd(A, golden_dir, n_gt):
     """tc_match_cost / tc_detr_loss_fwd_bwd against the reference's loss values (G7), its
