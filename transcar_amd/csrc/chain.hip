@@ -270,10 +270,6 @@ inline const StepDesc* prog_table(int prog) {
          : prog == PROG_RADAR_ENC_B ? PROG_RADAR_ENC_B_T : PROG_RADAR_LAYER_T;
 }
 
-__device__ __forceinline__ float comp4(const float4& v, int i) {
-  return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w;
-}
-
 // runtime view of a linear step
 struct LinSpec {
   const float* W; const float* bias; int K, N;
@@ -527,7 +523,6 @@ __device__ __forceinline__ bool linear_step(const LinSpec& s, WBuf& w0, bool pre
     wcur = np; tt = nt; kb = nk;
   };
   using Yes = std::integral_constant<bool, true>;
-  using No = std::integral_constant<bool, false>;
   WBuf w1;
   SUB_STAMP(1);
   if (s.dbg & 32) return false;
