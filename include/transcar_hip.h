@@ -34,7 +34,7 @@ extern "C" {
 #define TC_MAX_LEVELS 4
 #define TC_MAX_LAYERS 8
 #define TC_MAX_RADAR_LAYERS 3
-#define TC_ABI_VERSION 5
+#define TC_ABI_VERSION 6
 
 typedef void* tc_stream_t;
 
@@ -117,6 +117,27 @@ typedef struct {
   unsigned long long* sample_pairs; /* [1]: += number of visible (query,cam) pairs sampled */
 } tc_head_aux;
 
+/* per-call options of tc_head_forward (NULL = all defaults = the reference's eval forward) */
+typedef struct {
+  int chain_tile_rows;      /* rows of a workgroup's tile in the fused row chains: 0 = automatic
+                               (4 up to 1024 rows per launch, 8 beyond), 4, 8 or 16 */
+  int unfused;              /* 1: operator-by-operator launch sequence (~160 launches), the
+                               in-tree cross-check of the fused chains */
+  int last_level_cls_only;  /* 1 (inference opt-in): final_cls / final_cls2 are not evaluated --
+                               get_bboxes decodes level 3 only (HEAD:1003-1023) and levels 1-2
+                               feed only their BOX to the next gate; all_cls_scores[0:2] are
+                               left untouched.  0 keeps the reference's [3,B,Q,10] output */
+  int reserved0;
+  /* train-mode statistics of the FROZEN decoder: tools/train.py:245-252 only clears
+   * requires_grad, so the dropout (p = 0.1, CFG:68-80, XFMR:378) of the decoder layers stays
+   * active during training.  0 = eval (off).  Masks are counter-based (common.hpp drop_keep):
+   * site = 16 + 8 * layer + {0 attention probabilities, 1 self-attention output, 2 cross-
+   * attention output, 3 FFN hidden, 4 FFN output}. */
+  float decoder_dropout_p;
+  float reserved1;
+  unsigned long long dropout_seed;
+} tc_head_options;
+
 /* ---- library ---- */
 int tc_abi_version(void);
 const char* tc_last_error(void);
@@ -127,6 +148,10 @@ int tc_device_count(void);
 /* FPN handoff (DET:62-66 hands the head NCHW [B,N,C,H,W]): NCHW -> NHWC. */
 int tc_nchw_to_nhwc(const float* src, float* dst, int n_img, int C, int H, int W,
                     tc_stream_t stream);
+/* The same for all FPN levels of a frame in ONE launch.  src / dst / H / W are HOST
+ * arrays of num_levels (<= TC_MAX_LEVELS) entries; level l is [n_img, C, H[l], W[l]]. */
+int tc_nchw_to_nhwc_levels(const float* const* src, float* const* dst, int num_levels,
+                           int n_img, int C, const int* H, const int* W, tc_stream_t stream);
 
 /* ---- operators, one per reference call site ---- */
 
@@ -198,7 +223,8 @@ int tc_decoder_layer_tail_fwd(const tc_decoder_layer* layer, const tc_linear* ne
                               const float* query_embedding, const float* lidar2img,
                               const float* ref_in, const float* pc_range /*host[6]*/,
                               float img_h, float img_w, float* hs, float* ref_out,
-                              float* qk, float* vt, int qpad, tc_stream_t stream);
+                              float* qk, float* vt, int qpad,
+                              int tile_rows /* 0 automatic, 4, 8, 16 */, tc_stream_t stream);
 
 /* The attention core of the above on already projected operands (the kernel
  * the roofline is quoted on): out = softmax(q k^T) v per (batch, head).
@@ -229,6 +255,27 @@ int tc_radar_gated_xattn_fwd(const tc_mha* w, const float* query, const float* c
                              float radius_min, float radius_max,
                              float* out, int* hit_counts,
                              void* workspace, size_t workspace_bytes, tc_stream_t stream);
+
+/* The radar part of Detr3DHead.forward on its own (HEAD:531-729), from given decoder
+ * outputs: radar encoders + K/V projections, then fusion layers [first_layer,
+ * first_layer + num_layers) -- the same fused chain kernels tc_head_forward runs.
+ *   hs_last   [B,Q,C]    query_feat entering layer `first_layer` (HEAD:539: hs[-1] for layer 0)
+ *   ref_last  [B,Q,3]    normalised reference points of the last decoder layer; read only
+ *                        when first_layer == 0 (gate centre of layer 1, HEAD:543-547, z quirk
+ *                        of HEAD:596-598); may be NULL otherwise
+ *   prev_box  [B,Q,code] box whose length / sin / cos shape the gate: the decoder's last `tmp`
+ *                        (HEAD:287-293) for first_layer == 0, else the previous fusion layer's
+ *                        all_bbox_preds slice, which is also the gate centre (HEAD:615-617)
+ *   all_cls_scores / all_bbox_preds [R,B,Q,*]: slices first_layer.. are written
+ *   hit_counts [R,B,Q] (may be NULL): slices first_layer.. are written
+ *   workspace: tc_head_workspace_bytes(packed_view, B, T) bytes.
+ * Used by the per-layer teacher-forced parity tests (tests/test_gpu_teacher_forced.py). */
+int tc_radar_fusion_fwd(const tc_head_weights* packed_view, const float* hs_last,
+                        const float* ref_last, const float* prev_box, const float* radar_tokens,
+                        int B, int T, int pad_mult, int first_layer, int num_layers,
+                        float* all_cls_scores, float* all_bbox_preds, int* hit_counts,
+                        const tc_head_options* options, void* workspace, size_t workspace_bytes,
+                        tc_stream_t stream);
 
 /* NMSFreeCoder.decode_single + get_bboxes z-shift (CODER:39-90, UTIL:26-52,
  * HEAD:1018): sigmoid, top-`max_num` of Q*num_classes scores, gather,
@@ -270,6 +317,7 @@ int tc_head_forward(const tc_head_weights* w, const tc_head_weights* packed_view
                     const float* radar_tokens, int T, int pad_mult,
                     float* all_cls_scores, float* all_bbox_preds,
                     const tc_head_aux* aux /*may be NULL*/,
+                    const tc_head_options* options /*may be NULL*/,
                     void* workspace, size_t workspace_bytes, tc_stream_t stream);
 
 
@@ -389,12 +437,9 @@ int tc_radar_train_bwd(const tc_head_weights* w, const tc_head_weights* grads, c
 int tc_dropout_mask(float dropout_p, unsigned long long seed, int site, size_t n, float* out,
                     tc_stream_t stream);
 
-/* Tuning: row-tile height of the fused row chains (4, 8 or 16 rows per workgroup; 0 = automatic:
- * 4 up to 1024 rows per launch, 8 beyond).  Process-wide, read when a forward is
- * enqueued or captured.  With frames in flight (several streams) 8-row tiles at one frame per
- * launch trade latency for throughput (MI355X: 1530 instead of 1910 frames/s one frame at a time,
- * 3320 instead of 3150 with three in flight). */
-int tc_set_chain_tile_rows(int rows);
+/* (ABI 5's process-global tc_set_chain_tile_rows is gone: the tile height is per call --
+ * tc_head_options.chain_tile_rows, tc_decoder_layer_tail_fwd's tile_rows.  With frames in flight
+ * 8-row tiles at one frame per launch trade latency for throughput.) */
 
 
 /* ---- targets and losses on the device (HEAD:742-917; ASSIGN:106-125; COST:15-26) ----

@@ -1,0 +1,68 @@
+"""`bench.py --gpus N` must really start N ranks (round-1 VERDICT: the flag was parsed and
+ignored).  CPU dry run: the launcher parent spawns N fresh children, they rendezvous over gloo,
+the rank census all-reduce sees N ranks, rank 0 prints ONE JSON line with n_gpus = N.  The same
+for the training mode (one all-reduce of the real 10 MB flat gradient bucket per step) and under
+the driver's own launcher (torch.distributed.run).  Reference: tools/dist_train.sh:7-9."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAST = ['--dry-run', '--steps', '3', '--warmup', '1', '--min-window-s', '0.02', '--warmup-s', '0']
+
+
+def _run(cmd, env=None):
+    e = {k: v for k, v in os.environ.items()
+         if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    e.update(env or {})
+    r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout            # exactly one JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize('mode', [[], ['--train']])
+def test_gpus_flag_spawns_that_many_ranks(mode):
+    line = _run([sys.executable, 'bench.py', '--gpus', '2'] + FAST + mode)
+    assert line['n_gpus'] == 2 and line['rccl_ranks'] == 2
+    assert line['config']['launcher'] == 'bench.py'
+    assert line['steps'] == 3 and line['warmup'] == 1
+    assert line['bucket_all_reduce_ok'] is True
+    if mode:
+        assert line['config']['grad_bucket_bytes'] > 9_000_000     # 2.5 M trainable fp32 values
+
+
+def test_single_process_default():
+    line = _run([sys.executable, 'bench.py'] + FAST)
+    assert line['n_gpus'] == 1 and line['rccl_ranks'] == 1
+    assert line['config']['launcher'] == 'single process'
+
+
+def test_under_torch_distributed_run():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    line = _run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                 '--master-addr', '127.0.0.1', '--master-port', str(port), 'bench.py', '--gpus', '2']
+                + FAST)
+    assert line['n_gpus'] == 2 and line['rccl_ranks'] == 2
+    assert line['config']['launcher'] == 'torch.distributed.run'
+
+
+def test_a_dead_rank_fails_the_launch():
+    """a child that exits non-zero takes the launch down instead of hanging the others"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('on a GPU box the ranks would run the real bench')
+    e = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       cwd=ROOT, env=e, capture_output=True, text=True, timeout=300)
+    # no GPU in this container and no --dry-run: every rank asserts
+    assert r.returncode != 0
+    assert 'needs MI355X' in r.stderr

@@ -1,0 +1,245 @@
+"""Whole-head parity ON THE BENCH WORKLOAD by per-layer teacher forcing (-m gpu).
+
+The end-to-end rigs of test_gpu_parity.py are conditioned (smooth feature fields, last layer of
+every box-regression MLP scaled by 0.1) because the decoder's reference-point -> sampling ->
+reference-point loop amplifies fp32 rounding by ~4x per layer on iid-noise maps: after six layers
+no two fp32 implementations agree.  Here the loop is cut instead of tamed:
+on the UN-conditioned inputs (``make_feats('res101', smooth=None)`` = the maps bench.py times,
+``reg_out_scale=1.0`` = full xavier-scale refinements) every HIP layer is fed the ORACLE's state of
+the layer before -- query features and reference points -- and must reproduce the oracle's output of
+that one layer.  The kernels are the ones the timed path runs: tc_sdpa_fwd (attention core),
+tc_decoder_layer_tail_fwd (the fused decoder row chain incl. camera sampling, FFN, box refinement
+and the next layer's QKV projection) and tc_radar_fusion_fwd (radar encoders + the fused radar
+chain), each fusion layer teacher-forced from the oracle's previous box / features as well.
+
+Reference lines: XFMR:178-214 (decoder loop + refinement), XFMR:346-378 (cross attention),
+HEAD:538-729 (three fusion layers).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import transcar_oracle as O
+from transcar_amd import configs, radar as R, synth
+
+pytestmark = pytest.mark.gpu
+
+PCR = configs.point_cloud_range
+HW = configs.IMG_SHAPE[:2]
+LAYER_TOL = 1e-4          # one layer on identical inputs, O(1) activations (LayerNorm outputs)
+REF_TOL = 2e-6            # refined reference points (sigmoid outputs in [0, 1])
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def gpu(x):
+    return torch.as_tensor(x).float().contiguous().to(dev())
+
+
+@pytest.fixture(autouse=True)
+def _no_grad():
+    with torch.no_grad():
+        yield
+
+
+@pytest.fixture(scope='module')
+def rig():
+    """Un-conditioned bench inputs + the oracle's trace of every layer."""
+    import transcar_amd as T
+    sd_np = synth.make_state_dict(seed=3, reg_out_scale=1.0)
+    sd = O.to_torch_sd(sd_np)
+    head = T.build_head(configs.head_cfg())
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
+    head = head.to(dev()).eval()
+    head.head_weights()
+    feats_np = synth.make_feats('res101', seed=1, smooth=None)        # iid N(0,1): bench.py:make_inputs
+    feats = [torch.from_numpy(f) for f in feats_np]
+    l2i = torch.from_numpy(synth.make_lidar2img()).float()[None]
+    hs, init_ref, inter_refs, _ = O.transformer(sd, feats, PCR, l2i, HW)   # hs [L,Q,1,C]
+    nhwc = [head_ops().to_nhwc(gpu(f)) for f in feats_np]
+    return dict(T=T, sd=sd, head=head, feats=feats, nhwc=nhwc, l2i=l2i, hs=hs, init_ref=init_ref,
+                inter_refs=inter_refs)
+
+
+def head_ops():
+    from transcar_amd import ops
+    return ops
+
+
+def _qkv_from_oracle_state(sd, lid, x, pos):
+    """q (pre-scaled for the 2^x softmax), k, v^T of decoder layer `lid` from the oracle's layer
+    input, computed on the host in fp64 and rounded once: the attention core's operands without
+    any HIP arithmetic in front of it."""
+    name = 'transformer.decoder.layers.%d.attentions.0.attn' % lid
+    W, b = sd[name + '.in_proj_weight'].double(), sd[name + '.in_proj_bias'].double()
+    C = 256
+    qk_in = (x + pos).double()
+    q = F.linear(qk_in, W[:C], b[:C]) * (1.4426950408889634 / np.sqrt(32.0))
+    k = F.linear(qk_in, W[C:2 * C], b[C:2 * C])
+    v = F.linear(x.double(), W[2 * C:], b[2 * C:])
+    Q = x.shape[1]
+    qpad = ((Q + 15) // 16) * 16
+    vt = torch.zeros((x.shape[0], C, qpad), dtype=torch.float64)
+    vt[:, :, :Q] = v.permute(0, 2, 1)
+    return q.float(), k.float(), vt.float()
+
+
+def test_decoder_layers_teacher_forced_on_bench_inputs(rig):
+    """HIP layer l (attention core + fused row chain) on the oracle's layer-(l-1) state and
+    reference points vs the oracle's layer-l output, l = 0..5, iid-noise ResNet-101 maps, full-scale
+    refinement MLPs.  Also: the refined reference points and the next layer's projected q / k / v^T
+    the chain hands to the following attention core."""
+    ops = head_ops()
+    sd, head = rig['sd'], rig['head']
+    qe = sd['query_embedding.weight']
+    pos = qe[:, :256][None]                                   # [1,Q,C]
+    l2i = gpu(rig['l2i'])
+    pv = head._packed_view
+    L = 6
+    worst = []
+    for lid in range(L):
+        x_prev = qe[:, 256:][None] if lid == 0 else rig['hs'][lid - 1].permute(1, 0, 2)   # [1,Q,C]
+        ref_prev = rig['init_ref'] if lid == 0 else rig['inter_refs'][lid - 1]
+        q, k, vt = _qkv_from_oracle_state(sd, lid, x_prev, pos)
+        attn_o = ops.sdpa(gpu(q), gpu(k), gpu(vt))
+        # attention core alone vs the oracle's softmax(QK^T)V (before out_proj)
+        name = 'transformer.decoder.layers.%d.attentions.0.attn' % lid
+        qk_in = (x_prev + pos).permute(1, 0, 2)
+        want_full = O.multihead_attention(sd, name, qk_in, qk_in, x_prev.permute(1, 0, 2))   # incl. out_proj
+        nxt = pv.layers[lid + 1].self_attn.in_proj if lid + 1 < L else None
+        hs, ref_out, qk_next, vt_next = ops.decoder_layer_tail(
+            pv.layers[lid], nxt, rig['nhwc'], attn_o, gpu(x_prev), gpu(qe), l2i, gpu(ref_prev), PCR, HW)
+        want_hs = rig['hs'][lid].permute(1, 0, 2)             # [1,Q,C]
+        want_ref = rig['inter_refs'][lid]
+        d_hs = (hs.cpu() - want_hs).abs()
+        d_ref = (ref_out.cpu() - want_ref).abs()
+        worst.append((lid, float(d_hs.max()), float(d_ref.max())))
+        # a query whose projected point sits within fp32 rounding of an image border / depth
+        # threshold may flip its visibility mask (a discontinuity of the reference, XFMR:399-409):
+        # allow <= 2 such rows per layer, everything else must hold the tolerance
+        bad = (d_hs.amax(-1) > LAYER_TOL)[0]
+        assert int(bad.sum()) <= 2, 'layer %d: %d rows off by more than %g (max %.3g)' % (
+            lid, int(bad.sum()), LAYER_TOL, float(d_hs.max()))
+        ok = ~bad
+        assert float(d_ref[0][ok].max()) <= REF_TOL, (lid, float(d_ref[0][ok].max()))
+        del want_full
+        if nxt is not None:
+            # the chain's projection of ITS hs for the next attention core, against the host
+            # projection of the oracle's hs
+            q2, k2, vt2 = _qkv_from_oracle_state(sd, lid + 1, want_hs, pos)
+            got_q, got_k = qk_next[..., :256].cpu(), qk_next[..., 256:].cpu()
+            assert float((got_q - q2).abs()[0][ok].max()) <= 2e-4
+            assert float((got_k - k2).abs()[0][ok].max()) <= 2e-4
+            Q = want_hs.shape[1]
+            assert float((vt_next.cpu()[0, :, :Q].T - vt2[0, :, :Q].T).abs()[ok].max()) <= 2e-4
+    print('teacher-forced decoder layers (layer, max|d hs|, max|d ref|):', worst)
+
+
+def test_attention_core_teacher_forced(rig):
+    """tc_sdpa_fwd + out_proj residual on the oracle's layer-3 input vs torch MHA semantics."""
+    ops = head_ops()
+    sd = rig['sd']
+    qe = sd['query_embedding.weight']
+    pos = qe[:, :256][None]
+    x_prev = rig['hs'][2].permute(1, 0, 2)
+    q, k, vt = _qkv_from_oracle_state(sd, 3, x_prev, pos)
+    attn_o = ops.sdpa(gpu(q), gpu(k), gpu(vt)).cpu()
+    name = 'transformer.decoder.layers.3.attentions.0.attn'
+    got = F.linear(attn_o, sd[name + '.out_proj.weight'], sd[name + '.out_proj.bias'])
+    qk_in = (x_prev + pos).permute(1, 0, 2)
+    want = O.multihead_attention(sd, name, qk_in, qk_in, x_prev.permute(1, 0, 2)).permute(1, 0, 2)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), atol=3e-5, rtol=0)
+
+
+def _hit_aware(got, want, got_hits, want_hits, tol, what):
+    """compare rows whose gate decision agrees; bound the number of disagreeing rows"""
+    agree = (got_hits == want_hits)
+    assert int((~agree).sum()) <= 2, '%s: gate decisions differ on %d queries' % (what, int((~agree).sum()))
+    d = np.abs(got - want)[agree]
+    assert d.max() <= tol, '%s: max|d| = %.3g' % (what, d.max())
+    return agree
+
+
+def test_radar_layers_teacher_forced_on_bench_inputs(rig):
+    """The fused radar chain, ONE fusion layer at a time: layer r is fed the oracle's query
+    features and box of layer r-1 (hs[5] / the decoder's last box for r = 0) and must reproduce the
+    oracle's class scores, boxes and hit counts of layer r; then all three layers in one launch from
+    the oracle's hs[5] (the launch tc_head_forward makes)."""
+    ops = head_ops()
+    sd, head = rig['sd'], rig['head']
+    # radar frame with 80 % of the returns near the boxes the oracle's decoder predicts (bench.py)
+    refs = rig['inter_refs'][-1][0].double().numpy()
+    centres = np.round(np.stack([refs[:, 0] * (PCR[3] - PCR[0]) + PCR[0],
+                                 refs[:, 1] * (PCR[4] - PCR[1]) + PCR[1]], 1), 2)
+    frame = synth.make_radar_frame(seed=2, centres=centres)
+    f36 = O.build_radar_features(frame)
+    # the oracle's own trace of the radar part, layer by layer (HEAD:538-729)
+    want, dbg = O.head_forward(sd, rig['feats'], rig['l2i'], HW, f36, PCR, return_debug=True)
+    want_cls = want['all_cls_scores'][:, 0].numpy()
+    want_box = want['all_bbox_preds'][:, 0].numpy()
+    want_hits = np.stack([h.numpy() for h in dbg['hit_counts']])
+    assert want_hits.astype(bool).sum() > 300, 'the rig must exercise the gated attention'
+    tok_np, pad_mult = R.pack_tokens([R.build_radar_features(frame)])
+    tokens = gpu(tok_np)
+    hs5 = gpu(dbg['hs'][-1])                                  # [1,Q,C]
+    ref5 = gpu(dbg['inter_refs'][-1])
+    tmp = gpu(dbg['tmp'])                                     # the decoder's last box, metres
+    # -- all three layers in one launch (what tc_head_forward does), from the oracle's decoder state
+    cls, box, hits = ops.radar_fusion(head, hs5, ref5, tmp, tokens, pad_mult, 0, 3)
+    agree0 = _hit_aware(box[0, 0].cpu().numpy(), want_box[0], hits[0, 0].cpu().numpy(), want_hits[0],
+                        LAYER_TOL, 'fusion layer 1 box')
+    _hit_aware(cls[0, 0].cpu().numpy(), want_cls[0], hits[0, 0].cpu().numpy(), want_hits[0],
+               LAYER_TOL, 'fusion layer 1 cls')
+    # -- one layer at a time, teacher-forced.  Layer r's query features are not an output of the
+    # head; recompute them with the oracle's layer function from its own previous state.
+    qf = dbg['hs'][-1].permute(1, 0, 2)                       # [Q,1,C]
+    radar_feat = dbg['radar_feat']
+    tokens_full, _ = O.radar_tokens_from_features(f36)
+    prev_box = dbg['tmp']
+    for r, (sa, sf, rmin, rmax) in enumerate((('', '', 1.0, 2.0), ('2', '_2', 1.0, 2.0), ('3', '_3', 0.5, 1.0))):
+        if r == 0:
+            ref = dbg['inter_refs'][-1]
+            cxy = torch.stack([ref[..., 0] * (PCR[3] - PCR[0]) + PCR[0],
+                               ref[..., 1] * (PCR[4] - PCR[1]) + PCR[1]], -1)
+        else:
+            cxy = prev_box[..., :2]
+        mask = O.circle_mask(cxy, prev_box[..., 3], prev_box[..., 6], prev_box[..., 7],
+                             tokens_full[:, :, :2], rmin, rmax)
+        cls_r, box_r, hits_r = ops.radar_fusion(head, gpu(qf.permute(1, 0, 2)),
+                                                ref5 if r == 0 else None, gpu(prev_box), tokens,
+                                                pad_mult, r, 1)
+        agree = _hit_aware(box_r[r, 0].cpu().numpy(), want_box[r], hits_r[r, 0].cpu().numpy(),
+                           want_hits[r], LAYER_TOL, 'fusion layer %d box (teacher-forced)' % (r + 1))
+        _hit_aware(cls_r[r, 0].cpu().numpy(), want_cls[r], hits_r[r, 0].cpu().numpy(), want_hits[r],
+                   LAYER_TOL, 'fusion layer %d cls (teacher-forced)' % (r + 1))
+        assert torch.isnan(cls_r[(r + 1) % 3]).all()          # only the requested layer was written
+        qf, _ = O.radar_layer(sd, sa, sf, qf, radar_feat, mask)
+        prev_box = want['all_bbox_preds'][r]
+    del agree0, agree
+
+
+def test_last_level_cls_only_option(rig):
+    """tc_head_options.last_level_cls_only (inference opt-in): boxes of all levels and the class
+    scores of the decoded level are bit-identical to the default; the two skipped class slices are
+    left untouched."""
+    from transcar_amd.detr3d_head import head_options
+    ops = head_ops()
+    head = rig['head']
+    frame = synth.make_radar_frame(seed=2)
+    tok_np, pad_mult = R.pack_tokens([R.build_radar_features(frame)])
+    tokens = gpu(tok_np)
+    l2i = gpu(rig['l2i'])
+    full = head.forward_nhwc(rig['nhwc'], l2i, HW, tokens, pad_mult)
+    torch.cuda.synchronize()
+    fast = head.forward_nhwc(rig['nhwc'], l2i, HW, tokens, pad_mult,
+                             options=head_options(last_level_cls_only=True))
+    assert torch.equal(full['all_bbox_preds'], fast['all_bbox_preds'])
+    assert torch.equal(full['all_cls_scores'][2], fast['all_cls_scores'][2])
+    a = head.get_bboxes(full, synth.make_img_metas(1))[0]
+    b = head.get_bboxes(fast, synth.make_img_metas(1))[0]
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    del ops

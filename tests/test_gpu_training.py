@@ -464,15 +464,16 @@ def test_fused_training_with_dropout_matches_reference_formula(A, golden_dir, pa
     tokens, pad_mult = h.radar_tokens(metas, dev())
     tr = FusionTrainer(h, dropout=p, seed=5)
     if path == 'fused':          # tc_radar_train_fwd / _bwd
-        tr.iter = 3
+        h._train_forwards = 3
         losses = tr.step_fused_nhwc(nhwc, l2i, img_hw, tokens, pad_mult, [gt], [labels], update=False)
         seed = tr.last_dropout_seed
         hip_grads = {n: q.grad.detach().cpu().clone() for n, q in h.trainable_parameters()}
         # a different seed gives different masks and a different loss; the same seed the same
+        h._train_forwards = 3                                    # rewind the forward counter: same masks
         l_same = tr.step_fused_nhwc(nhwc, l2i, img_hw, tokens, pad_mult, [gt], [labels], update=False)
         assert tr.last_dropout_seed == seed                      # (the loss sums use atomics: equal up to rounding)
         assert all(abs(float(l_same[k]) - float(losses[k])) <= 1e-5 * max(1.0, abs(float(losses[k]))) for k in losses)
-        tr.iter = 4
+        # the next forward (e.g. a gradient-accumulation step: no optimizer step in between) draws new masks
         l_other = tr.step_fused_nhwc(nhwc, l2i, img_hw, tokens, pad_mult, [gt], [labels], update=False)
         assert tr.last_dropout_seed != seed
         assert any(abs(float(l_other[k]) - float(losses[k])) > 1e-4 * max(1.0, abs(float(losses[k]))) for k in losses)

@@ -118,11 +118,27 @@ def test_workspace_query_runs_without_gpu():
 
 
 def test_tuning_knob_validates_without_gpu():
+    """tc_head_options.chain_tile_rows is validated before anything is launched (no GPU needed:
+    the call fails on the argument check), and the host-side env knob is validated at import."""
     lib = T.lib()
-    assert lib.tc_set_chain_tile_rows(8) == 0 and lib.tc_set_chain_tile_rows(0) == 0
-    assert lib.tc_set_chain_tile_rows(5) != 0
-    assert b'tile_rows' in lib.tc_last_error()
-    assert lib.tc_set_chain_tile_rows(0) == 0
+    w = _lib.tc_head_weights()
+    w.abi_version = _lib.TC_ABI_VERSION
+    w.num_query, w.embed_dims, w.num_heads, w.ffn_dims = 900, 256, 8, 512
+    w.num_layers, w.num_cams, w.num_levels = 6, 6, 4
+    w.num_classes, w.code_size, w.radar_in_dims, w.num_radar_layers = 10, 10, 36, 0
+    fv = _lib.tc_feats_nhwc()
+    fv.num_levels = 4
+    from transcar_amd.detr3d_head import head_options
+    opt = head_options(tile_rows=8)
+    assert opt.chain_tile_rows == 8
+    opt.chain_tile_rows = 5
+    rc = lib.tc_head_forward(ctypes.byref(w), None, ctypes.byref(fv), 1, None, 928.0, 1600.0, None, 0, 0,
+                             None, None, None, ctypes.byref(opt), None, 0, None)
+    assert rc != 0 and b'chain_tile_rows' in lib.tc_last_error()
+    import subprocess
+    r = subprocess.run([sys.executable, '-c', 'import transcar_amd'], cwd=ROOT,
+                       env=dict(os.environ, TRANSCAR_CHAIN_ROWS='5'), capture_output=True, text=True)
+    assert r.returncode != 0 and 'TRANSCAR_CHAIN_ROWS' in r.stderr
 
 
 _WORKER = r'''

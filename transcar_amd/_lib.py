@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('TRANSCAR_HIP_LIB') or os.path.join(_HERE, 'lib', 'lib
 TC_MAX_LEVELS = 4
 TC_MAX_LAYERS = 8
 TC_MAX_RADAR_LAYERS = 3
-TC_ABI_VERSION = 5
+TC_ABI_VERSION = 6
 
 c_fp = C.c_void_p      # device pointers travel as integers
 
@@ -98,6 +98,13 @@ class tc_head_aux(C.Structure):
                 ('last_box', c_fp), ('sample_pairs', c_fp)]
 
 
+class tc_head_options(C.Structure):
+    _fields_ = [('chain_tile_rows', C.c_int), ('unfused', C.c_int),
+                ('last_level_cls_only', C.c_int), ('reserved0', C.c_int),
+                ('decoder_dropout_p', C.c_float), ('reserved1', C.c_float),
+                ('dropout_seed', C.c_ulonglong)]
+
+
 _P = C.POINTER
 _i, _f, _sz, _vp = C.c_int, C.c_float, C.c_size_t, C.c_void_p
 
@@ -107,6 +114,7 @@ SIGNATURES = {
     'tc_last_error': (C.c_char_p, []),
     'tc_device_count': (_i, []),
     'tc_nchw_to_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'tc_nchw_to_nhwc_levels': (_i, [_P(_vp), _P(_vp), _i, _i, _i, _P(_i), _P(_i), _vp]),
     'tc_linear_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'tc_add_layernorm_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'tc_refine_reference_fwd': (_i, [_vp, _i, _vp, _vp, _i, _vp]),
@@ -124,12 +132,14 @@ SIGNATURES = {
     'tc_decoder_layer_tail_fwd': (_i, [_P(tc_decoder_layer), _P(tc_linear),
                                        _P(tc_feats_nhwc), _i, _i, _i, _i, _vp,
                                        _vp, _vp, _vp, _vp, _P(_f), _f, _f, _vp,
-                                       _vp, _vp, _vp, _i, _vp]),
+                                       _vp, _vp, _vp, _i, _i, _vp]),
     'tc_sdpa_fwd': (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     'tc_radar_xattn_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'tc_radar_gated_xattn_fwd': (_i, [_P(tc_mha), _vp, _vp, _vp, _i, _vp, _vp,
                                       _i, _i, _i, _i, _i, _i, _f, _f, _vp,
                                       _vp, _vp, _sz, _vp]),
+    'tc_radar_fusion_fwd': (_i, [_P(tc_head_weights), _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i,
+                                 _vp, _vp, _vp, _P(tc_head_options), _vp, _sz, _vp]),
     'tc_box_decode_workspace_bytes': (_sz, [_i, _i, _i]),
     'tc_box_decode_topk': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _P(_f), _vp,
                                 _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -141,7 +151,7 @@ SIGNATURES = {
     'tc_head_forward': (_i, [_P(tc_head_weights), _P(tc_head_weights),
                              _P(tc_feats_nhwc), _i, _vp,
                              _f, _f, _vp, _i, _i, _vp, _vp, _P(tc_head_aux),
-                             _vp, _sz, _vp]),
+                             _P(tc_head_options), _vp, _sz, _vp]),
     # training (backward of the trainable radar stack + optimizer)
     'tc_linear_gated_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'tc_linear_bwd_data': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f,
@@ -167,7 +177,6 @@ SIGNATURES = {
                                 _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz,
                                 _f, C.c_ulonglong, _vp]),
     'tc_dropout_mask': (_i, [_f, C.c_ulonglong, _i, _sz, _vp, _vp]),
-    'tc_set_chain_tile_rows': (_i, [_i]),
     'tc_normalize_bbox': (_i, [_vp, _i, _vp, _vp]),
     'tc_match_cost': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _f, _f,
                            _f, _f, _f, _vp, _vp]),

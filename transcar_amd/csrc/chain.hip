@@ -113,6 +113,14 @@ struct ChainLds {
   float a[R][LD5];
 };
 
+// timing experiments (skip epilogues / barriers / LayerNorm / sampling) exist in the STAMPS
+// build only; the production library has no such switch
+#ifdef TC_CHAIN_STAMPS
+#define CHAIN_DBG(v) (v)
+#else
+#define CHAIN_DBG(v) 0
+#endif
+
 #define MFMA44(a, b, c, grp) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 4, (grp), 0)
 
 // ---- step tables -----------------------------------------------------------
@@ -238,13 +246,16 @@ struct ChainDev {
   int total, early_n;          // resolved steps; leading K_LOAD steps (issued before anything else)
   float* g[G_COUNT]; int g_ld[G_COUNT]; int g_mod[G_COUNT];   // global tensors by GSel
   float qscale; int qpad;
-  int dbg;                     // TRANSCAR_CHAIN_DBG (timing experiments only: wrong results)
+  int dbg;                     // STAMPS build only: TRANSCAR_CHAIN_DBG (timing experiments, wrong results)
+  int tile_rows;               // requested row-tile height (0: automatic); host side only
+  int last_cls_only;           // radar program: class MLPs of the last layer only; host side only
   // decoder
   const float* ref_in; int ref_mod; float* ref_out; float* box_m;
   CamK cam; unsigned long long* pair_counter;
   // radar
   const float* tokens; int RI, T, pad_mult;
   const float* ref_last; const float* box_in;
+  int cen_from_box;            // the first layer run is not fusion layer 1: gate centre = previous box
   float rmin[TC_MAX_RADAR_LAYERS], rmax[TC_MAX_RADAR_LAYERS];
   float* all_box; int* hits;
 };
@@ -515,7 +526,7 @@ __device__ __forceinline__ bool linear_step(const LinSpec& s, WBuf& w0, bool pre
       int tile = wave + tt * CH_NW;
       int sidx = step_idx;
       asm volatile("" : "+s"(tile), "+s"(sidx));
-      if (!(s.dbg & 1)) {
+      if (!(CHAIN_DBG(s.dbg) & 1)) {
         const LinSpec e = make_spec(sidx);
         lin_epilogue<NG>(e, tile, acc, lane, bv);
       }
@@ -525,7 +536,7 @@ __device__ __forceinline__ bool linear_step(const LinSpec& s, WBuf& w0, bool pre
   using Yes = std::integral_constant<bool, true>;
   WBuf w1;
   SUB_STAMP(1);
-  if (s.dbg & 32) return false;
+  if (CHAIN_DBG(s.dbg) & 32) return false;
   if (!preloaded) {
     wload(w0, wbase, 16);
     __builtin_amdgcn_sched_barrier(0);
@@ -644,7 +655,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
     rec_v[t] = reinterpret_cast<const int4*>(recs)[i];
   }
   const int M = k.M;
-  if (k.dbg & 64) return;
+  if (CHAIN_DBG(k.dbg) & 64) return;
   START_STAMP(40);
   WG_STAMP(0);
   const int total = k.total;
@@ -700,10 +711,14 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
         if (j < k.code) S.box[row][j] = k.box_in[(size_t)grow * k.code + j];
         if (j >= 12 && j < 15) {
           const int c = j - 12;
-          const float r = k.ref_last[(size_t)grow * 3 + c];
-          const float* pc = k.cam.pc;
-          // z stays normalised (HEAD:598 indexes an empty slice)
-          S.cen[row][c] = c < 2 ? __fadd_rn(__fmul_rn(r, pc[3 + c] - pc[c]), pc[c]) : r;
+          if (k.cen_from_box) {      // HEAD:615-617 / 671-673: xy = box[0:2], z = box[4]
+            S.cen[row][c] = k.box_in[(size_t)grow * k.code + (c == 2 ? 4 : c)];
+          } else {
+            const float r = k.ref_last[(size_t)grow * 3 + c];
+            const float* pc = k.cam.pc;
+            // z stays normalised (HEAD:598 indexes an empty slice)
+            S.cen[row][c] = c < 2 ? __fadd_rn(__fmul_rn(r, pc[3 + c] - pc[c]), pc[c]) : r;
+          }
         }
       }
     }
@@ -773,7 +788,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
     return s;
   };
 
-  int idx = (k.dbg & 16) ? total : early_n;          // the leading loads are already in LDS
+  int idx = (CHAIN_DBG(k.dbg) & 16) ? total : early_n;          // the leading loads are already in LDS
 #ifdef TC_CHAIN_STAMPS
   for (int j = 0; j < 2 * early_n; ++j) STEP_STAMP();
 #endif
@@ -800,12 +815,12 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
             pre_idx = have ? pr.nidx : -1;
           }
         } else if (kd == K_LN) {
-          if (!(k.dbg & 4)) do_ln(r);
+          if (!(CHAIN_DBG(k.dbg) & 4)) do_ln(r);
         } else if (kd != K_NOP) {
           break;
         }
         STEP_STAMP();
-        if (r.sync && !(k.dbg & 2)) __syncthreads();
+        if (r.sync && !(CHAIN_DBG(k.dbg) & 2)) __syncthreads();
         STEP_STAMP();
         if (++idx >= total) break;
       }
@@ -883,7 +898,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
       } break;
       } break;
       case K_SAMPLE: { if constexpr (PROG == PROG_DECODER) {   // camera sampling of this block's queries
-        if (k.dbg & 8) break;
+        if (CHAIN_DBG(k.dbg) & 8) break;
         int pairs = 0;
         CAM_STAMP(5);
 #pragma unroll 1
@@ -1012,6 +1027,12 @@ void resolve_program(ChainK& k, StepAll* out) {
     r.kind = d.kind; r.src = d.src; r.src2 = d.src2; r.dst = d.dst; r.res = d.res; r.act = d.act;
     r.flags = d.flags; r.sync = d.sync; r.rep = (short)rep; r.si = (short)si;
     if ((d.flags & F_SKIP_NONEXT) && !k.has_next) r.kind = K_NOP;
+    // inference opt-in (tc_head_options.last_level_cls_only): get_bboxes decodes the last level
+    // only and levels 1-2 hand only their BOX to the next gate (HEAD:615-617, 1003-1023), so the
+    // class MLPs (pairs 6..10: final_cls.0 / n1 / .3 / n4 / .6) of the earlier layers are dropped
+    if (PROG == PROG_RADAR && k.last_cls_only && rep + 1 < nrep && d.wp >= 6 && d.wp <= 10 &&
+        (d.kind == K_LINEAR || d.kind == K_LN))
+      r.kind = K_NOP;
     if (d.gsel != G_NONE) { r.gd = k.g[d.gsel]; r.gld = k.g_ld[d.gsel]; r.gmod = k.g_mod[d.gsel]; }
     if (d.gtsel != G_NONE) r.gt = k.g[d.gtsel];
     if (d.kind == K_LINEAR) {
@@ -1064,12 +1085,12 @@ void resolve_program(ChainK& k, StepAll* out) {
 template <int RA, int RB, int PROGB>
 int launch_dual_r(const ChainK& ka_, const ChainK& kb_, hipStream_t s, const char* what) {
   constexpr size_t lds = chain_lds_bytes<RA, PROG_DECODER>() > chain_lds_bytes<RB, PROGB>() ? chain_lds_bytes<RA, PROG_DECODER>() : chain_lds_bytes<RB, PROGB>();
-  static bool done = false;
-  if (!done) {
+  static DeviceOnce once;
+  if (once.need()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_dual_kernel<RA, RB, PROGB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("chain: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    done = true;
+    once.done();
   }
   ChainK ka = ka_, kb = kb_;
   Recs<rec_cap(PROG_DECODER)> ra;
@@ -1084,13 +1105,13 @@ int launch_dual_r(const ChainK& ka_, const ChainK& kb_, hipStream_t s, const cha
 
 template <int R, int PROG>
 int launch_r(const ChainK& k_, hipStream_t s, const char* what) {
-  static bool done = false;
-  if (!done) {
+  static DeviceOnce once;
+  if (once.need()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<R, PROG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)chain_lds_bytes<R, PROG>());
     if (e != hipSuccess) { set_error("chain: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    done = true;
+    once.done();
   }
   ChainK k = k_;
   Recs<rec_cap(PROG)> recs;
@@ -1103,8 +1124,10 @@ int launch_r(const ChainK& k_, hipStream_t s, const char* what) {
 
 void init_k(ChainK& k) {
   memset(&k, 0, sizeof(k));
-  const char* e = getenv("TRANSCAR_CHAIN_DBG");
-  k.dbg = e ? atoi(e) : 0;
+#ifdef TC_CHAIN_STAMPS
+  static const int dbg = [] { const char* e = getenv("TRANSCAR_CHAIN_DBG"); return e ? atoi(e) : 0; }();
+  k.dbg = dbg;
+#endif
 }
 
 // Row-tile height (measured, bench.py --batch 1/2/3/4/8): 4 rows while that gives about one
@@ -1112,16 +1135,13 @@ void init_k(ChainK& k) {
 // tiles (each weight register feeds 4 MFMAs, but 304 VGPRs and 120 KB of LDS: one workgroup per
 // CU) were the choice for B >= 3 until the item loop shrank; now they lose to 8 rows everywhere
 // (B = 4, one step at a time: 3410 vs 3770 frames/s) and remain selectable (tc_set_chain_tile_rows).
-static int g_tile_rows = 0;      // tc_set_chain_tile_rows (0: automatic)
-int tile_rows(int M) {
-  const char* e = getenv("TRANSCAR_CHAIN_ROWS");
-  const int forced = g_tile_rows ? g_tile_rows : e ? atoi(e) : 0;
-  return forced ? forced : (M <= 1024 ? 4 : 8);
-}
+// The height is a per-call argument (tc_head_options.chain_tile_rows / tile_rows of
+// tc_decoder_layer_tail_fwd): no process-global state.
+int tile_rows(const ChainK& k) { return k.tile_rows ? k.tile_rows : (k.M <= 1024 ? 4 : 8); }
 
 template <int PROG>
 int launch_rows(const ChainK& k, hipStream_t s, const char* what) {
-  const int rows = tile_rows(k.M);
+  const int rows = tile_rows(k);
   if (rows == 4) return launch_r<4, PROG>(k, s, what);
   if (rows == 8) return launch_r<8, PROG>(k, s, what);
   return launch_r<16, PROG>(k, s, what);
@@ -1140,17 +1160,6 @@ int launch(const ChainK& k, hipStream_t s, const char* what) {
 }
 
 }  // namespace
-
-void g_tile_rows_set(int rows) { g_tile_rows = rows; }
-
-extern "C" int tc_set_chain_tile_rows(int rows) {
-  if (rows != 0 && rows != 4 && rows != 8 && rows != 16) {
-    tc::set_error("tc_set_chain_tile_rows: rows=%d (0 = automatic, 4, 8 or 16)", rows);
-    return 1;
-  }
-  tc::g_tile_rows_set(rows);
-  return 0;
-}
 
 #ifdef TC_CHAIN_STAMPS
 extern "C" int tc_debug_chain_stamps(long long* host_out) {
@@ -1212,6 +1221,9 @@ static int make_decoder_k(const DecoderChainArgs& a, ChainK& k) {
   k.ref_in = a.ref_in; k.ref_mod = a.ref_mod; k.ref_out = a.ref_out; k.box_m = a.box_m;
   fill_camk(a.cam, k.cam);
   k.pair_counter = a.cam.pair_counter;
+  TC_REQUIRE(a.tile_rows == 0 || a.tile_rows == 4 || a.tile_rows == 8 || a.tile_rows == 16,
+             "decoder_chain: tile_rows=%d (0 = automatic, 4, 8 or 16)", a.tile_rows);
+  k.tile_rows = a.tile_rows;
   return 0;
 }
 
@@ -1255,7 +1267,7 @@ int launch_decoder_chain_with_encoders(const DecoderChainArgs& d, const RadarEnc
   if (rc != 0) return rc;
   rc = make_radar_enc_k(e, ke, part);
   if (rc != 0) return rc;
-  const int rows = tile_rows(kd.M);
+  const int rows = tile_rows(kd);
   const char* what = "chain(decoder + radar_encode)";
 #define TC_DUAL(RA, RB)                                                               \
   (part == 1 ? launch_dual_r<RA, RB, PROG_RADAR_ENC_A>(kd, ke, s, what)               \
@@ -1292,9 +1304,13 @@ int launch_radar_chain(const RadarChainArgs& a, hipStream_t s) {
   k.g[G_CLS] = a.all_cls; k.g_ld[G_CLS] = a.ncls;
   k.qscale = a.qscale;
   k.tokens = a.tokens; k.RI = a.RI; k.T = a.T; k.pad_mult = a.pad_mult;
-  k.ref_last = a.ref_last; k.box_in = a.box_m;
+  k.ref_last = a.ref_last; k.box_in = a.box_m; k.cen_from_box = a.cen_from_box;
+  TC_REQUIRE(a.cen_from_box || a.ref_last != nullptr, "radar_chain: ref_last is null");
   for (int i = 0; i < 6; ++i) k.cam.pc[i] = a.pc[i];
   k.all_box = a.all_box; k.hits = a.hits;
+  TC_REQUIRE(a.tile_rows == 0 || a.tile_rows == 4 || a.tile_rows == 8 || a.tile_rows == 16,
+             "radar_chain: tile_rows=%d (0 = automatic, 4, 8 or 16)", a.tile_rows);
+  k.tile_rows = a.tile_rows; k.last_cls_only = a.last_cls_only;
   return launch(k, s, "chain(radar)");
 }
 

@@ -24,6 +24,18 @@ int check_launch(const char* what);   // hipGetLastError -> message; returns cod
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// "done once per DEVICE" (hipFuncSetAttribute is per device: a second GPU used by the same
+// process needs its own call).  Racing first calls both set the attribute -- harmless.
+struct DeviceOnce {
+  unsigned long long mask[4] = {0, 0, 0, 0};     // up to 256 devices
+  int dev = 0;
+  bool need() {
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 256) { dev = -1; return true; }
+    return ((__atomic_load_n(&mask[dev >> 6], __ATOMIC_ACQUIRE) >> (dev & 63)) & 1ull) == 0;
+  }
+  void done() { if (dev >= 0) __atomic_fetch_or(&mask[dev >> 6], 1ull << (dev & 63), __ATOMIC_RELEASE); }
+};
+
 // bump allocator over the caller's workspace (256-byte aligned slices)
 struct Arena {
   char* base;
@@ -85,6 +97,14 @@ __device__ __forceinline__ float4 ld4(const float* p) {
   return make_float4(v[0], v[1], v[2], v[3]);
 }
 __device__ __forceinline__ void st4(float* p, float4 v) {
+  *(TC_GLOBAL f32x4*)(p) = f32x4{v.x, v.y, v.z, v.w};
+}
+// read-once / write-once streams (the hand-off transposes): non-temporal hint
+__device__ __forceinline__ float4 ldg4_stream(const float* p) {
+  const f32x4 v = __builtin_nontemporal_load((const TC_GLOBAL f32x4*)(p));
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void stg4_stream(float* p, float4 v) {
   *(TC_GLOBAL f32x4*)(p) = f32x4{v.x, v.y, v.z, v.w};
 }
 __device__ __forceinline__ float ldg1(const float* p) { return *(const TC_GLOBAL float*)(p); }

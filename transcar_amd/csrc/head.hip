@@ -157,16 +157,11 @@ static size_t head_ws_layout(const tc_head_weights* w, int B, int T, void* base,
 }
 
 // ---- fused path: 12 launches per frame (chain.hip) ---------------------------
-static bool use_unfused() {
-  const char* e = getenv("TRANSCAR_UNFUSED");   // read per call: tests toggle it
-  return e != nullptr && e[0] == '1';
-}
-
 static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* feats, int B,
                               const float* lidar2img, float img_h, float img_w,
                               const float* radar_tokens, int T, int pad_mult, float* all_cls_scores,
-                              float* all_bbox_preds, const tc_head_aux* aux, const HeadWs& h,
-                              hipStream_t s) {
+                              float* all_bbox_preds, const tc_head_aux* aux, const tc_head_options& opt,
+                              const HeadWs& h, hipStream_t s) {
   const int Q = w->num_query, C = w->embed_dims, L = w->num_layers, H = w->num_heads;
   const int code = w->code_size, ncls = w->num_classes;
   const int rows = B * Q, rt = B * T;
@@ -221,7 +216,7 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
     for (int i = 0; i < 6; ++i) d.cam.pc[i] = w->pc_range[i];
     d.cam.img_h = img_h; d.cam.img_w = img_w; d.cam.out = nullptr; d.cam.vis = nullptr;
     d.cam.pair_counter = pairs;
-    d.code = code; d.M = rows;
+    d.code = code; d.M = rows; d.tile_rows = opt.chain_tile_rows;
     // the radar encoders ride in the launches of layers 0 and 1, half each (all in layer 0
     // when there is only one layer)
     if (radar && lid == 0) TC_TRY(launch_decoder_chain_with_encoders(d, re, L > 1 ? 1 : 0, s));
@@ -256,6 +251,7 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
   rc.ncls = ncls; rc.M = rows; rc.qscale = 1.0f / sqrtf((float)(C / H));
   for (int i = 0; i < 6; ++i) rc.pc[i] = w->pc_range[i];
   rc.all_cls = all_cls_scores; rc.all_box = all_bbox_preds; rc.hits = h.hits;
+  rc.tile_rows = opt.chain_tile_rows; rc.last_cls_only = opt.last_level_cls_only;
   TC_TRY(launch_radar_chain(rc, s));
   if (aux && aux->radar_hit_counts)
     TC_HIP(hipMemcpyAsync(aux->radar_hit_counts, h.hits, (size_t)w->num_radar_layers * rows * 4,
@@ -327,6 +323,12 @@ int tc_device_count(void) {
 
 int tc_nchw_to_nhwc(const float* src, float* dst, int n_img, int C, int H, int W, tc_stream_t stream) {
   return launch_nchw_to_nhwc(src, dst, n_img, C, H, W, as_stream(stream));
+}
+
+int tc_nchw_to_nhwc_levels(const float* const* src, float* const* dst, int num_levels, int n_img, int C,
+                           const int* H, const int* W, tc_stream_t stream) {
+  TC_REQUIRE(src != nullptr && dst != nullptr && H != nullptr && W != nullptr, "nchw_to_nhwc_levels: null argument");
+  return launch_nchw_to_nhwc_levels(src, dst, num_levels, n_img, C, H, W, as_stream(stream));
 }
 
 int tc_linear_fwd(const float* x, const float* x2, const float* w, const float* b, const float* res,
@@ -421,7 +423,7 @@ int tc_decoder_layer_tail_fwd(const tc_decoder_layer* layer, const tc_linear* ne
                               const float* query_embedding, const float* lidar2img,
                               const float* ref_in, const float* pc_range, float img_h,
                               float img_w, float* hs, float* ref_out, float* qk, float* vt,
-                              int qpad, tc_stream_t stream) {
+                              int qpad, int tile_rows, tc_stream_t stream) {
   TC_REQUIRE(layer != nullptr && feats != nullptr, "decoder_layer_tail: null argument");
   const int C = 256;
   DecoderChainArgs d;
@@ -435,7 +437,7 @@ int tc_decoder_layer_tail_fwd(const tc_decoder_layer* layer, const tc_linear* ne
   for (int i = 0; i < 6; ++i) d.cam.pc[i] = pc_range[i];
   d.cam.img_h = img_h; d.cam.img_w = img_w; d.cam.out = nullptr; d.cam.vis = nullptr;
   d.cam.pair_counter = nullptr;
-  d.code = code_size; d.M = B * Q;
+  d.code = code_size; d.M = B * Q; d.tile_rows = tile_rows;
   return launch_decoder_chain(d, as_stream(stream));
 }
 
@@ -478,6 +480,59 @@ int tc_radar_gated_xattn_fwd(const tc_mha* w, const float* query, const float* c
   r.rmin = radius_min; r.rmax = radius_max; r.attn_out = rattn; r.hit_counts = hits;
   TC_TRY(launch_radar_attn(r, s));
   return linear(rattn, C, w->out_proj, rows, C, C, 0, out, C, s, nullptr, query, C, hits);
+}
+
+int tc_radar_fusion_fwd(const tc_head_weights* packed_view, const float* hs_last, const float* ref_last,
+                        const float* prev_box, const float* radar_tokens, int B, int T, int pad_mult,
+                        int first_layer, int num_layers, float* all_cls_scores, float* all_bbox_preds,
+                        int* hit_counts, const tc_head_options* options, void* workspace,
+                        size_t workspace_bytes, tc_stream_t stream) {
+  const tc_head_weights* w = packed_view;
+  TC_TRY(check_dims(w));
+  TC_REQUIRE(w->l0_attn_out != nullptr, "radar_fusion: packed_view was not produced by tc_head_pack_weights");
+  TC_REQUIRE(first_layer >= 0 && num_layers >= 1 && first_layer + num_layers <= w->num_radar_layers,
+             "radar_fusion: layers [%d, %d) of %d", first_layer, first_layer + num_layers, w->num_radar_layers);
+  TC_REQUIRE(hs_last && prev_box && radar_tokens && all_cls_scores && all_bbox_preds && (first_layer > 0 || ref_last),
+             "radar_fusion: null argument");
+  TC_REQUIRE(B >= 1 && T >= 1 && pad_mult >= 1, "radar_fusion: B=%d T=%d pad_mult=%d", B, T, pad_mult);
+  tc_head_options opt;
+  memset(&opt, 0, sizeof(opt));
+  if (options != nullptr) opt = *options;
+  HeadWs h;
+  const size_t need = head_ws_layout(w, B, T, workspace, workspace_bytes, &h);
+  TC_REQUIRE(need <= workspace_bytes, "workspace too small: need %zu, have %zu", need, workspace_bytes);
+  hipStream_t s = as_stream(stream);
+  const int Q = w->num_query, C = w->embed_dims, H = w->num_heads, rows = B * Q, rt = B * T;
+  const int code = w->code_size, ncls = w->num_classes;
+  // encoders + K/V projections of all layers (stand-alone encoder program)
+  RadarEncodeArgs re;
+  re.tokens = radar_tokens; re.RI = w->radar_in_dims; re.M = rt;
+  re.rpe = w->radar_position_encoder; re.f0 = w->radar_feat0; re.f2 = w->radar_feat2;
+  re.f4 = w->radar_feat4; re.nlayers = w->num_radar_layers;
+  for (int r = 0; r < TC_MAX_RADAR_LAYERS; ++r) {
+    const tc_mha& m = w->radar[r].attn;
+    re.kvproj[r] = tc_linear{m.in_proj.w ? m.in_proj.w + (size_t)C * C : nullptr,
+                             m.in_proj.b ? m.in_proj.b + C : nullptr};
+    re.kv[r] = h.kv3[r];
+  }
+  re.radar_feat = h.radar_feat;
+  TC_TRY(launch_radar_encode(re, s));
+  RadarChainArgs rc;
+  rc.qf = hs_last; rc.ref_last = ref_last; rc.box_m = prev_box; rc.tokens = radar_tokens;
+  rc.RI = w->radar_in_dims;
+  for (int r = 0; r < num_layers; ++r) { rc.kv[r] = h.kv3[first_layer + r]; rc.w[r] = w->radar[first_layer + r]; }
+  rc.nlayers = num_layers; rc.Q = Q; rc.T = T; rc.pad_mult = pad_mult; rc.code = code; rc.ncls = ncls;
+  rc.M = rows; rc.qscale = 1.0f / sqrtf((float)(C / H));
+  for (int i = 0; i < 6; ++i) rc.pc[i] = w->pc_range[i];
+  rc.all_cls = all_cls_scores + (size_t)first_layer * rows * ncls;
+  rc.all_box = all_bbox_preds + (size_t)first_layer * rows * code;
+  rc.hits = h.hits; rc.tile_rows = opt.chain_tile_rows; rc.last_cls_only = opt.last_level_cls_only;
+  rc.cen_from_box = first_layer > 0;
+  TC_TRY(launch_radar_chain(rc, s));
+  if (hit_counts != nullptr)
+    TC_HIP(hipMemcpyAsync(hit_counts + (size_t)first_layer * rows, h.hits, (size_t)num_layers * rows * 4,
+                          hipMemcpyDeviceToDevice, s));
+  return 0;
 }
 
 size_t tc_box_decode_workspace_bytes(int B, int Q, int num_classes) {
@@ -574,8 +629,17 @@ int tc_head_forward(const tc_head_weights* w, const tc_head_weights* packed_view
                     const tc_feats_nhwc* feats, int B, const float* lidar2img, float img_h,
                     float img_w, const float* radar_tokens, int T, int pad_mult,
                     float* all_cls_scores, float* all_bbox_preds, const tc_head_aux* aux,
-                    void* workspace, size_t workspace_bytes, tc_stream_t stream) {
+                    const tc_head_options* options, void* workspace, size_t workspace_bytes,
+                    tc_stream_t stream) {
   TC_TRY(check_dims(w));
+  tc_head_options opt;
+  memset(&opt, 0, sizeof(opt));
+  if (options != nullptr) opt = *options;
+  TC_REQUIRE(opt.chain_tile_rows == 0 || opt.chain_tile_rows == 4 || opt.chain_tile_rows == 8 ||
+                 opt.chain_tile_rows == 16,
+             "options.chain_tile_rows=%d (0 = automatic, 4, 8 or 16)", opt.chain_tile_rows);
+  TC_REQUIRE(opt.decoder_dropout_p >= 0.0f && opt.decoder_dropout_p < 1.0f, "options.decoder_dropout_p=%g",
+             (double)opt.decoder_dropout_p);
   TC_REQUIRE(feats != nullptr && feats->num_levels == w->num_levels, "feats: num_levels mismatch");
   TC_REQUIRE(B >= 1, "B=%d", B);
   TC_REQUIRE(w->num_radar_layers == 0 || (radar_tokens != nullptr && T >= 1 && pad_mult >= 1),
@@ -589,11 +653,13 @@ int tc_head_forward(const tc_head_weights* w, const tc_head_weights* packed_view
   const int rows = B * Q, rt = B * T;
   const float* pc = w->pc_range;
   unsigned long long* pairs = aux ? aux->sample_pairs : nullptr;
-  if (packed_view != nullptr && !use_unfused())
+  if (packed_view != nullptr && !opt.unfused)
     return head_forward_fused(packed_view, feats, B, lidar2img, img_h, img_w, radar_tokens, T, pad_mult,
-                              all_cls_scores, all_bbox_preds, aux, h, s);
+                              all_cls_scores, all_bbox_preds, aux, opt, h, s);
+  TC_REQUIRE(opt.decoder_dropout_p == 0.0f && !opt.last_level_cls_only,
+             "the operator-by-operator path implements the default options only");
 
-  // ---- operator-by-operator path (TRANSCAR_UNFUSED=1): the first build, kept
+  // ---- operator-by-operator path (options.unfused): the first build, kept
   // as an in-tree cross-check of the fused chains.  XFMR:119-123
   TC_TRY(launch_split_embed(w->query_embedding, Q, C, B, h.pos, h.x, s));
   TC_TRY(launch_init_ref(w->query_embedding, Q, C, w->reference_points.w, w->reference_points.b,

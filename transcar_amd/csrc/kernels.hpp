@@ -95,6 +95,7 @@ struct DecoderChainArgs {
   float* hs; float* qk; float* vt; int qpad;
   CamSampleArgs cam;                         // feats, lidar2img, pc, img size (ref/logits/out unused)
   int code, M;
+  int tile_rows = 0;                         // 0: automatic (4 up to 1024 rows, 8 beyond), 4, 8, 16
 };
 int launch_decoder_chain(const DecoderChainArgs& a, hipStream_t s);
 
@@ -117,6 +118,9 @@ struct RadarChainArgs {
   int nlayers, Q, T, pad_mult, code, ncls, M;
   float qscale; float pc[6];
   float* all_cls; float* all_box; int* hits;
+  int tile_rows = 0;
+  int last_cls_only = 0;                     // skip final_cls of all but the last layer (inference opt-in)
+  int cen_from_box = 0;                      // w[0] is not fusion layer 1: gate centre from box_m (HEAD:615-617)
 };
 int launch_radar_chain(const RadarChainArgs& a, hipStream_t s);
 
@@ -167,6 +171,8 @@ int launch_pack_linear(const float* W, int N, int K, float* P, hipStream_t s);
 
 // ---- transpose.hip ---------------------------------------------------------
 int launch_nchw_to_nhwc(const float* src, float* dst, int n_img, int C, int H, int W, hipStream_t s);
+int launch_nchw_to_nhwc_levels(const float* const* src, float* const* dst, int num_levels, int n_img,
+                               int C, const int* H, const int* W, hipStream_t s);
 
 // ---- decode.hip ------------------------------------------------------------
 int launch_box_decode(const float* cls, const float* box, int B, int Q, int ncls, int code,

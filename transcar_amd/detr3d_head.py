@@ -35,6 +35,33 @@ from .registry import (BBOX_ASSIGNERS, HEADS, build_bbox_coder,
 RADAR_RADII = ((1.0, 2.0), (1.0, 2.0), (0.5, 1.0))     # HEAD:567, 635, 693
 
 
+def _env_tile_rows():
+    """TRANSCAR_CHAIN_ROWS (host-side tuning knob, read once at import, validated)."""
+    import os
+    v = os.environ.get('TRANSCAR_CHAIN_ROWS', '0')
+    if v not in ('0', '4', '8', '16'):
+        raise ValueError('TRANSCAR_CHAIN_ROWS=%r (0 = automatic, 4, 8 or 16)' % v)
+    return int(v)
+
+
+DEFAULT_TILE_ROWS = _env_tile_rows()
+
+
+def head_options(tile_rows=None, unfused=None, last_level_cls_only=False,
+                 decoder_dropout_p=0.0, dropout_seed=0):
+    """tc_head_options for one forward.  unfused=None: the TRANSCAR_UNFUSED=1
+    environment switch of the operator-by-operator cross-check path (a host-side
+    knob: the library itself reads no environment)."""
+    import os
+    o = L.tc_head_options()
+    o.chain_tile_rows = int(tile_rows) if tile_rows else DEFAULT_TILE_ROWS
+    o.unfused = int(os.environ.get('TRANSCAR_UNFUSED', '0') == '1') if unfused is None else int(bool(unfused))
+    o.last_level_cls_only = int(bool(last_level_cls_only))
+    o.decoder_dropout_p = float(decoder_dropout_p)
+    o.dropout_seed = int(dropout_seed) & 0xFFFFFFFFFFFFFFFF
+    return o
+
+
 def _cls_branch(embed, ncls):
     return nn.Sequential(
         nn.Linear(embed, embed), nn.LayerNorm(embed), nn.ReLU(inplace=True),
@@ -142,6 +169,10 @@ class Detr3DHead(BaseModule):
         self.output_proj3 = nn.Linear(E, E)
         self._weights = None
         self._workspace = {}
+        self._packed = None
+        #: bumped whenever a device buffer a captured hipGraph may point at (packed weights,
+        #: lane workspaces) is re-allocated: FramePipeline refuses to replay a stale capture
+        self.buffers_generation = 0
 
     def _init_layers(self):
         """HEAD:198-238."""
@@ -173,6 +204,8 @@ class Detr3DHead(BaseModule):
     def _apply(self, fn, *a, **k):
         self._weights = None            # pointers move on .to()/.cuda()
         self._workspace = {}
+        self._packed = None
+        self.buffers_generation += 1
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
@@ -244,7 +277,12 @@ class Detr3DHead(BaseModule):
         if nbytes == 0:
             raise L.TransCARHipError(lib.tc_last_error().decode())
         dev = self.query_embedding.weight.device
-        self._packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        # Re-pack IN PLACE when the buffer fits (load_state_dict / refresh_weights / a
+        # FusionTrainer moving the parameters into its flat bucket): captured hipGraphs hold
+        # raw pointers into it.  A new allocation bumps buffers_generation instead.
+        if self._packed is None or self._packed.numel() != nbytes or self._packed.device != dev:
+            self._packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self.buffers_generation += 1
         self._packed_view = L.tc_head_weights()
         L.check(lib.tc_head_pack_weights(
             C.byref(w), self._packed.data_ptr(), nbytes,
@@ -298,7 +336,8 @@ class Detr3DHead(BaseModule):
         return torch.from_numpy(tokens).to(device), pad_mult
 
     def forward_nhwc(self, feats_nhwc, lidar2img, img_hw, tokens, pad_mult,
-                     aux=False, _allow_train=False, lane=0, decoder_only=False):
+                     aux=False, _allow_train=False, lane=0, decoder_only=False,
+                     options=None):
         """The device-side forward: everything already on the GPU.
         feats_nhwc: list of [B*N,H,W,C]; lidar2img [B,N,4,4]; tokens [B,T,36].
         Only enqueues work on the current stream (graph-capturable).
@@ -306,7 +345,8 @@ class Detr3DHead(BaseModule):
         streams, transcar_amd/pipeline.py) need different lanes -- each lane
         owns a workspace; the weights are shared.
         decoder_only: stop after the DETR3D decoder (aux carries its states);
-        the training iteration recomputes the radar stack itself."""
+        the training iteration recomputes the radar stack itself.
+        options: tc_head_options (``head_options(...)``); None = defaults."""
         if not _allow_train:
             require_eval(self)
         w = self.head_weights()
@@ -329,6 +369,8 @@ class Detr3DHead(BaseModule):
                 raise L.TransCARHipError(lib.tc_last_error().decode())
             self._workspace[key] = torch.empty(nbytes, dtype=torch.uint8,
                                                device=dev)
+        if options is None:
+            options = head_options()
         ws = self._workspace[key]
         Q, ncls, code = self.num_query, self.cls_out_channels, self.code_size
         cls = torch.empty((3, B, Q, ncls), dtype=torch.float32, device=dev)
@@ -357,7 +399,7 @@ class Detr3DHead(BaseModule):
             float(img_hw[0]), float(img_hw[1]), tokens.data_ptr(), T,
             int(pad_mult), cls.data_ptr(), box.data_ptr(),
             C.byref(aux_s) if aux_s is not None else None,
-            ws.data_ptr(), ws.numel(),
+            C.byref(options), ws.data_ptr(), ws.numel(),
             C.c_void_p(torch.cuda.current_stream().cuda_stream)),
             'tc_head_forward')
         outs = {'all_cls_scores': cls, 'all_bbox_preds': box,
@@ -374,7 +416,7 @@ class Detr3DHead(BaseModule):
             raise L.TransCARHipError(
                 'Detr3DHead.forward needs the feature maps on the MI355X '
                 '(got %s); transcar_amd has no CPU path' % dev)
-        feats_nhwc = [ops.to_nhwc(f) for f in mlvl_feats]
+        feats_nhwc = ops.to_nhwc_levels(mlvl_feats)       # one launch; channels_last levels zero-copy
         l2i = ops.lidar2img_tensor(img_metas, dev)
         img_hw = img_metas[0]['img_shape'][0][:2]           # XFMR:403-404
         tokens, pad_mult = self.radar_tokens(img_metas, dev)
@@ -440,10 +482,7 @@ class Detr3DHead(BaseModule):
         f = A.linear(f, rfe[4].weight, rfe[4].bias, act=1)
         mem = pos + f
 
-        self._train_forwards = getattr(self, '_train_forwards', 0) + 1
-        seed = (int(getattr(self, 'dropout_seed', 0)) * 0x9E3779B1
-                + self._train_forwards * 0x85EBCA77 + 1) & 0xFFFFFFFFFFFFFFFF
-        self.last_dropout_seed = seed
+        seed = self.next_dropout_seed()
         all_cls, all_box = [], []
         for r, (sfx, asfx) in enumerate((('', ''), ('_2', '2'), ('_3', '3'))):
             attn = getattr(self, 'rf_multihead_attn' + asfx)
@@ -494,6 +533,21 @@ class Detr3DHead(BaseModule):
         return {'all_cls_scores': torch.stack(all_cls),
                 'all_bbox_preds': torch.stack(all_box),
                 'enc_cls_scores': None, 'enc_bbox_preds': None}
+
+    def next_dropout_seed(self):
+        """Seed of the counter-based dropout masks of ONE training forward: a function of
+        (``self.dropout_seed``, this process's rank, the number of training forwards so far).
+        Both training paths (``forward_train_nhwc`` and ``FusionTrainer.step_fused_nhwc``) draw
+        from this one counter, so they are seed-compatible; ranks draw different masks as the
+        reference's per-process RNG streams do; gradient-accumulation steps (no optimizer step
+        in between) get fresh masks."""
+        import torch.distributed as dist
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        self._train_forwards = getattr(self, '_train_forwards', 0) + 1
+        seed = (int(getattr(self, 'dropout_seed', 0)) * 0x9E3779B1 + rank * 0xC2B2AE3D27D4EB4F
+                + self._train_forwards * 0x85EBCA77 + 1) & 0xFFFFFFFFFFFFFFFF
+        self.last_dropout_seed = seed
+        return seed
 
     def set_dropout(self, p):
         """p of every dropout site of the radar fusion layers (HEAD:129-171 build

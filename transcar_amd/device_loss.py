@@ -85,6 +85,13 @@ def detr_loss_device(head, all_cls, all_box, gt_bboxes_list, gt_labels_list):
         float(lc.get('alpha', 0.25)), float(lc.get('gamma', 2.0)), float(lc.get('loss_weight', 1.0)),
         float(lb.get('loss_weight', 1.0)), losses.data_ptr(), d_cls.data_ptr(), d_box.data_ptr(),
         _stream()), 'tc_detr_loss_fwd_bwd')
+    # HEAD:915-916 zeroes a non-finite loss (torch.nan_to_num); its gradient must not reach the flat
+    # bucket / the Adam moments either: a layer whose loss is not finite contributes nothing
+    fin = torch.isfinite(losses)
+    d_cls = torch.where(fin[:, 0].view(Lyr, 1, 1, 1), torch.nan_to_num(d_cls, nan=0.0, posinf=0.0, neginf=0.0),
+                        torch.zeros_like(d_cls))
+    d_box = torch.where(fin[:, 1].view(Lyr, 1, 1, 1), torch.nan_to_num(d_box, nan=0.0, posinf=0.0, neginf=0.0),
+                        torch.zeros_like(d_box))
     losses = torch.nan_to_num(losses, nan=0.0)
     out = {'loss_cls': losses[Lyr - 1, 0], 'loss_bbox': losses[Lyr - 1, 1]}
     for i in range(Lyr - 1):

@@ -64,6 +64,42 @@ def to_nhwc(feat, out=None):
     return out
 
 
+def to_nhwc_levels(feats, out=None):
+    """All FPN levels of a frame, NCHW -> NHWC, in ONE launch
+    (tc_nchw_to_nhwc_levels).  feats: list of [B,N,C,H,W] / [BN,C,H,W] fp32;
+    out: optional list of preallocated [BN,H,W,C] tensors (a lane's static
+    inputs).  Levels that are already channels-last in memory are taken
+    zero-copy and left out of the launch."""
+    res, todo = [], []
+    for l, f in enumerate(feats):
+        if f.dim() == 5:
+            f = f.reshape(-1, *f.shape[2:])
+        if f.is_contiguous(memory_format=torch.channels_last) and not f.is_contiguous() \
+                and out is None:
+            res.append(f.permute(0, 2, 3, 1))
+            continue
+        _chk(f, 'feats[%d]' % l)
+        n, c, h, w = f.shape
+        o = out[l] if out is not None else torch.empty((n, h, w, c), dtype=torch.float32,
+                                                       device=f.device)
+        if out is not None and (tuple(o.shape) != (n, h, w, c) or not o.is_contiguous()):
+            raise L.TransCARHipError('out[%d] must be a contiguous [%d,%d,%d,%d] tensor' % (l, n, h, w, c))
+        res.append(o)
+        todo.append((f, o))
+    if todo:
+        k = len(todo)
+        if len({(f.shape[0], f.shape[1]) for f, _ in todo}) != 1:
+            raise L.TransCARHipError('all levels must have the same image count and channels')
+        src = (C.c_void_p * k)(*[f.data_ptr() for f, _ in todo])
+        dst = (C.c_void_p * k)(*[o.data_ptr() for _, o in todo])
+        hs = (C.c_int * k)(*[f.shape[2] for f, _ in todo])
+        ws = (C.c_int * k)(*[f.shape[3] for f, _ in todo])
+        L.check(L.lib().tc_nchw_to_nhwc_levels(src, dst, k, todo[0][0].shape[0],
+                                               todo[0][0].shape[1], hs, ws, _stream()),
+                'tc_nchw_to_nhwc_levels')
+    return res
+
+
 def feats_view(feats_nhwc):
     """list of [B*N,H,W,C] -> tc_feats_nhwc."""
     fv = L.tc_feats_nhwc()
@@ -162,6 +198,71 @@ def self_attn(mha, x, pos, num_heads=8):
                                      Q, Cdim, num_heads, _p(ws), nbytes,
                                      _stream()), 'tc_self_attn_fwd')
     return out
+
+
+def sdpa(q, k, vt, num_heads=8):
+    """The self-attention core on projected operands (tc_sdpa_fwd):
+    q, k [B,Q,C] token-major (q pre-scaled by log2(e)/sqrt(head_dim)),
+    vt [B,C,qpad] = V transposed, qpad = round_up(Q,16) -> [B,Q,C]."""
+    B, Q, Cdim = q.shape
+    qk = torch.cat((q, k), -1).contiguous()                 # the layout the chains produce
+    _chk(qk, 'qk'); _chk(vt, 'vt')
+    out = torch.empty((B, Q, Cdim), dtype=torch.float32, device=q.device)
+    L.check(L.lib().tc_sdpa_fwd(qk.data_ptr(), qk.data_ptr() + 4 * Cdim, 2 * Cdim, _p(vt),
+                                vt.shape[-1], _p(out), Cdim, B, Q, num_heads, _stream()),
+            'tc_sdpa_fwd')
+    return out
+
+
+def decoder_layer_tail(packed_layer, packed_next_in_proj, feats_nhwc, attn_o, x_in,
+                       query_embedding, lidar2img, ref_in, pc_range, img_hw, code_size=10,
+                       num_cams=6, tile_rows=0):
+    """One decoder layer after its attention core as the fused row chain
+    (tc_decoder_layer_tail_fwd).  packed_*: members of the head's packed view
+    (``head._packed_view.layers[l]``, ``.layers[l + 1].self_attn.in_proj`` or
+    None).  Returns (hs [B,Q,C], ref_out [B,Q,3], qk [B,Q,2C], vt [B,C,qpad])."""
+    for n, t in (('attn_o', attn_o), ('x_in', x_in), ('ref_in', ref_in), ('lidar2img', lidar2img)):
+        _chk(t, n)
+    B, Q, Cdim = x_in.shape
+    qpad = ((Q + 15) // 16) * 16
+    dev = x_in.device
+    hs = torch.empty((B, Q, Cdim), dtype=torch.float32, device=dev)
+    ref_out = torch.empty((B, Q, 3), dtype=torch.float32, device=dev)
+    qk = torch.zeros((B, Q, 2 * Cdim), dtype=torch.float32, device=dev)
+    vt = torch.zeros((B, Cdim, qpad), dtype=torch.float32, device=dev)
+    fv = feats_view(feats_nhwc)
+    L.check(L.lib().tc_decoder_layer_tail_fwd(
+        C.byref(packed_layer), C.byref(packed_next_in_proj) if packed_next_in_proj is not None else None,
+        C.byref(fv), B, Q, num_cams, code_size, _p(attn_o), _p(x_in), _p(query_embedding),
+        _p(lidar2img), _p(ref_in), L.f6(pc_range), float(img_hw[0]), float(img_hw[1]), _p(hs),
+        _p(ref_out), _p(qk), _p(vt), qpad, int(tile_rows), _stream()), 'tc_decoder_layer_tail_fwd')
+    return hs, ref_out, qk, vt
+
+
+def radar_fusion(head, hs_last, ref_last, prev_box, tokens, pad_mult, first_layer=0,
+                 num_layers=3, options=None):
+    """The radar part of the head from given decoder outputs (tc_radar_fusion_fwd):
+    encoders + fusion layers [first_layer, first_layer + num_layers).  Returns
+    (all_cls [3,B,Q,ncls], all_box [3,B,Q,code], hits [3,B,Q]); only the slices of
+    the layers that ran are written (the rest is NaN / -1)."""
+    head.head_weights()
+    pv = head._packed_view
+    B, Q = hs_last.shape[:2]
+    T = tokens.shape[1]
+    dev = hs_last.device
+    for n, t in (('hs_last', hs_last), ('prev_box', prev_box), ('tokens', tokens)):
+        _chk(t, n)
+    nbytes = L.lib().tc_head_workspace_bytes(C.byref(pv), B, T)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    cls = torch.full((3, B, Q, head.cls_out_channels), float('nan'), dtype=torch.float32, device=dev)
+    box = torch.full((3, B, Q, head.code_size), float('nan'), dtype=torch.float32, device=dev)
+    hits = torch.full((3, B, Q), -1, dtype=torch.int32, device=dev)
+    L.check(L.lib().tc_radar_fusion_fwd(
+        C.byref(pv), _p(hs_last), _p(ref_last), _p(prev_box), _p(tokens), B, T, int(pad_mult),
+        int(first_layer), int(num_layers), _p(cls), _p(box), _p(hits),
+        C.byref(options) if options is not None else None, _p(ws), nbytes, _stream()),
+        'tc_radar_fusion_fwd')
+    return cls, box, hits
 
 
 def radar_gated_xattn(mha, query, centre_xy, box, radar_feat, radar_xy,

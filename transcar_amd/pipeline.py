@@ -6,51 +6,60 @@ The reference's test loop (tools/test.py -> mmdet ``single_gpu_test`` /
 this decoder is a dependent chain of 13 kernels, each of which fills 225 of the
 256 CUs with one workgroup per CU and ends in a tail.  Consecutive frames are
 independent, so a second (third) frame on its own stream runs in the CUs,
-tails and launch gaps the first leaves idle: measured on MI355X 1880 -> 2290
-(2 lanes) -> 2390 (3 lanes) frames/s at one frame per step; the latency of a
-single frame rises accordingly (0.53 -> 0.87 -> 1.26 ms).
+tails and launch gaps the first leaves idle; the latency of a single frame
+rises accordingly.
 
-Each lane owns a captured graph (head forward + box decode), a stream, static
-input tensors the producer (FPN, radar pipeline) writes into, and its own head
-workspace (``Detr3DHead.forward_nhwc(lane=i)``); the weights are shared.
+Each lane owns a captured graph (optional NCHW -> NHWC hand-off + head forward
++ box decode), a stream, static input tensors the producer (FPN, radar
+pipeline) writes into, and its own head workspace
+(``Detr3DHead.forward_nhwc(lane=i)``); the weights are shared.
+
+Ordering contract (the producer works on the CURRENT stream):
+  * ``launch(i)`` makes lane i's stream wait for everything enqueued so far on
+    the current stream, so inputs written there (FPN kernels, H2D copies) are
+    complete before the replay reads them;
+  * after the replay the lane records an event; ``producer_wait(i)`` /
+    ``write_inputs(i, ...)`` make the current stream wait for it before a
+    lane's static inputs (or outputs) are touched again.
 """
 import torch
 
 from . import ops
+from ._lib import TransCARHipError
 
 
 class FramePipeline:
     """``lanes`` frames in flight.
 
     static_inputs: list (one per lane) of dict(nhwc=[...], l2i, hw, tokens,
-    pad_mult) -- the tensors a lane's graph reads; fill them in place before
-    ``launch``.
+    pad_mult[, nchw=[...]]) -- the tensors a lane's graph reads.  With
+    ``nchw`` (list of [B,N,C,H,W] / [BN,C,H,W] maps, what the reference's FPN
+    hands over, DET:62-66) the graph starts with the one-launch transposition
+    of all levels into ``nhwc``.
+    tile_rows (4 | 8 | 16): row-tile height of the fused chains in THIS
+    pipeline's graphs (tc_head_options.chain_tile_rows; None = automatic).
+    8 at one frame per lane buys throughput with >= 3 lanes and costs latency.
     """
 
-    def __init__(self, head, static_inputs, decode=True, tile_rows=None):
+    def __init__(self, head, static_inputs, decode=True, tile_rows=None, options=None):
         if not static_inputs:
             raise ValueError('at least one lane')
+        from .detr3d_head import head_options
         self.head, self.decode = head, decode
         self.inputs = list(static_inputs)
         self.streams = [torch.cuda.Stream() for _ in self.inputs]
+        self.done = [torch.cuda.Event() for _ in self.inputs]
+        self.options = options if options is not None else head_options(tile_rows=tile_rows)
         self.graphs, self.outputs = [], []
         self._next = 0
-        # tile_rows (4 | 8 | 16): row-tile height of the fused chains in THIS pipeline's graphs
-        # (tc_set_chain_tile_rows; None = the library's choice).  8 at one frame per lane buys
-        # throughput with >= 3 lanes and costs latency.
-        from . import _lib as L
-        if tile_rows:
-            L.check(L.lib().tc_set_chain_tile_rows(int(tile_rows)), 'tc_set_chain_tile_rows')
-        try:
-            self._capture()
-        finally:
-            if tile_rows:
-                L.lib().tc_set_chain_tile_rows(0)
+        self._capture()
 
     def _step(self, i):
         inp = self.inputs[i]
+        if inp.get('nchw') is not None:
+            ops.to_nhwc_levels(inp['nchw'], out=inp['nhwc'])
         outs = self.head.forward_nhwc(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'],
-                                      inp['pad_mult'], lane=i)
+                                      inp['pad_mult'], lane=i, options=self.options)
         if not self.decode:
             return outs, None
         dec = ops.box_decode_topk(outs['all_cls_scores'][-1], outs['all_bbox_preds'][-1],
@@ -58,6 +67,7 @@ class FramePipeline:
         return outs, dec
 
     def _capture(self):
+        self.graphs, self.outputs = [], []
         with torch.no_grad():
             for i, s in enumerate(self.streams):
                 s.wait_stream(torch.cuda.current_stream())
@@ -72,6 +82,14 @@ class FramePipeline:
                 self.graphs.append(g)
                 self.outputs.append(out)
         torch.cuda.synchronize()
+        # the graphs hold raw pointers into the head's packed weights and lane workspaces
+        self._generation = self.head.buffers_generation
+
+    def recapture(self):
+        """Capture the lanes again (after the head re-allocated its packed weights or
+        workspaces: ``.to()``, a checkpoint of another size)."""
+        self.synchronize()
+        self._capture()
 
     @property
     def lanes(self):
@@ -81,11 +99,50 @@ class FramePipeline:
         """Enqueue one frame on the next lane (round robin) and return
         (lane, (outs, decoded)): the lane's static output tensors, valid once
         ``wait(lane)`` returns and until the lane is launched again."""
+        if self.head.buffers_generation != self._generation:
+            raise TransCARHipError(
+                'FramePipeline: the head re-allocated device buffers (packed weights / workspaces) '
+                'after these graphs were captured; call recapture()')
         i = self._next if lane is None else lane
         self._next = (i + 1) % self.lanes
-        with torch.cuda.stream(self.streams[i]):
+        s = self.streams[i]
+        s.wait_stream(torch.cuda.current_stream())     # the producer's writes come first
+        with torch.cuda.stream(s):
             self.graphs[i].replay()
+            self.done[i].record(s)
         return i, self.outputs[i]
+
+    def producer_wait(self, lane):
+        """The current stream waits until lane's last replay has finished: after this, work
+        enqueued on the current stream may overwrite the lane's static inputs."""
+        torch.cuda.current_stream().wait_event(self.done[lane])
+
+    def write_inputs(self, lane, nhwc=None, nchw=None, l2i=None, tokens=None, pad_mult=None):
+        """Refill a lane's static inputs in place from the current stream (device tensors or
+        pinned host tensors: ``copy_`` is asynchronous), ordered after the lane's previous
+        replay.  tokens must have the captured shape and pad_mult (radar.pack_tokens(T=...))."""
+        inp = self.inputs[lane]
+        self.producer_wait(lane)
+        for key, new in (('nhwc', nhwc), ('nchw', nchw)):
+            if new is None:
+                continue
+            if inp.get(key) is None or len(new) != len(inp[key]):
+                raise TransCARHipError('lane %d has no static %r inputs of %d levels' % (lane, key, len(new)))
+            for dst, src in zip(inp[key], new):
+                if tuple(dst.shape) != tuple(src.shape):
+                    raise TransCARHipError('%s level shape %s != captured %s' % (key, tuple(src.shape),
+                                                                                 tuple(dst.shape)))
+                dst.copy_(src, non_blocking=True)
+        if l2i is not None:
+            inp['l2i'].copy_(l2i, non_blocking=True)
+        if tokens is not None:
+            if tuple(tokens.shape) != tuple(inp['tokens'].shape) or \
+                    (pad_mult is not None and int(pad_mult) != int(inp['pad_mult'])):
+                raise TransCARHipError(
+                    'tokens %s / pad_mult %s differ from the captured %s / %d: pack every frame with '
+                    'radar.pack_tokens(T=%d)' % (tuple(tokens.shape), pad_mult, tuple(inp['tokens'].shape),
+                                                 inp['pad_mult'], inp['tokens'].shape[1]))
+            inp['tokens'].copy_(tokens, non_blocking=True)
 
     def wait(self, lane):
         self.streams[lane].synchronize()

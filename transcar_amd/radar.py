@@ -80,8 +80,12 @@ def build_radar_features(radar, point_range=POINT_RANGE):
     return allp[keep]
 
 
-def pack_tokens(feature_list, granule=64):
+def pack_tokens(feature_list, granule=64, T=None):
     """Batch of [n_i,36] arrays -> (tokens [B,T,36] float32, pad_mult).
+
+    T: fixed token count (a frame pipeline's static ``tokens`` tensor has one
+    shape for every frame: T and pad_mult are baked into its captured graph);
+    None picks the smallest multiple of ``granule`` that holds the frame.
 
     The reference always attends over 1500 tokens, the unused ones filled
     with 500.0 (HEAD:526-530).  Identical pad tokens have identical keys and
@@ -89,7 +93,11 @@ def pack_tokens(feature_list, granule=64):
     materialised and the last one carries the multiplicity of the missing
     1500 - T pad tokens (see tc_radar_gated_xattn_fwd)."""
     n_max = max(min(f.shape[0], NUM_RADAR_TOKENS) for f in feature_list)
-    T = min(NUM_RADAR_TOKENS, ((n_max + 1 + granule - 1) // granule) * granule)
+    if T is None:
+        T = min(NUM_RADAR_TOKENS, ((n_max + 1 + granule - 1) // granule) * granule)
+    elif not (1 <= T <= NUM_RADAR_TOKENS) or (n_max + 1 > T and T < NUM_RADAR_TOKENS):
+        raise ValueError('T=%d cannot hold %d radar points + one pad token (max %d)'
+                         % (T, n_max, NUM_RADAR_TOKENS))
     tokens = np.full((len(feature_list), T, NUM_FEATURES), PAD_VALUE,
                      dtype=np.float32)
     for b, f in enumerate(feature_list):

@@ -123,6 +123,7 @@ class FusionTrainer:
         # p = 0.1); counter-based masks from (seed, iteration).  The frozen decoder and the
         # per-operator autograd path (step / step_nhwc) run without dropout.
         self.dropout, self.seed = float(dropout), int(seed)
+        head.dropout_seed = int(seed)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -165,7 +166,7 @@ class FusionTrainer:
         Q = head.num_query
         all_cls = torch.empty((3, B, Q, head.cls_out_channels), dtype=torch.float32, device=tokens.device)
         all_box = torch.empty((3, B, Q, head.code_size), dtype=torch.float32, device=tokens.device)
-        drop_seed = (self.seed * 0x9E3779B1 + self.iter * 0x85EBCA77 + 1) & 0xFFFFFFFFFFFFFFFF
+        drop_seed = head.next_dropout_seed()       # (seed, rank, forward counter): shared with forward_train_nhwc
         L.check(lib.tc_radar_train_fwd(
             C.byref(w), hs_last.data_ptr(), ref_last.data_ptr(), last_box.data_ptr(), tokens.data_ptr(),
             B, T, int(pad_mult), all_cls.data_ptr(), all_box.data_ptr(), tape.data_ptr(), tape.numel(),
