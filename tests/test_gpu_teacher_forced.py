@@ -27,8 +27,16 @@ pytestmark = pytest.mark.gpu
 
 PCR = configs.point_cloud_range
 HW = configs.IMG_SHAPE[:2]
-LAYER_TOL = 1e-4          # one layer on identical inputs, O(1) activations (LayerNorm outputs)
-REF_TOL = 2e-6            # refined reference points (sigmoid outputs in [0, 1])
+# One layer on identical inputs; activations are LayerNorm outputs, |x| up to ~5.  On these
+# un-conditioned inputs the fp32 REFERENCE formula itself deviates from its fp64 evaluation by up to
+# 1.6e-4 per layer (max over 900 x 256 values; mean 4e-6 -- measured, and re-measured by the test):
+# iid-noise maps turn the fp32 rounding of a projected pixel coordinate (1e-4 px at |u| ~ 1600)
+# into an O(1e-4) change of the sampled feature.  So the test measures both implementations against
+# the fp64 evaluation ("truth") and asserts that HIP is as close to it as the fp32 oracle is.
+LAYER_MAX_TOL = 3e-4      # max |hip - fp64| (the fp32 oracle reaches 1.6e-4)
+LAYER_MEAN_TOL = 1e-5     # mean |hip - fp64| (the fp32 oracle: 4e-6)
+LAYER_TOL = 1e-4          # radar layers (no sampling: plain linear algebra on O(1) values)
+REF_TOL = 5e-6            # refined reference points (sigmoid outputs in [0, 1])
 
 
 def dev():
@@ -60,8 +68,8 @@ def rig():
     l2i = torch.from_numpy(synth.make_lidar2img()).float()[None]
     hs, init_ref, inter_refs, _ = O.transformer(sd, feats, PCR, l2i, HW)   # hs [L,Q,1,C]
     nhwc = [head_ops().to_nhwc(gpu(f)) for f in feats_np]
-    return dict(T=T, sd=sd, head=head, feats=feats, nhwc=nhwc, l2i=l2i, hs=hs, init_ref=init_ref,
-                inter_refs=inter_refs)
+    return dict(T=T, sd=sd, sd64={k: v.double() for k, v in sd.items()}, head=head, feats=feats,
+                nhwc=nhwc, l2i=l2i, hs=hs, init_ref=init_ref, inter_refs=inter_refs)
 
 
 def head_ops():
@@ -89,53 +97,65 @@ def _qkv_from_oracle_state(sd, lid, x, pos):
 
 def test_decoder_layers_teacher_forced_on_bench_inputs(rig):
     """HIP layer l (attention core + fused row chain) on the oracle's layer-(l-1) state and
-    reference points vs the oracle's layer-l output, l = 0..5, iid-noise ResNet-101 maps, full-scale
-    refinement MLPs.  Also: the refined reference points and the next layer's projected q / k / v^T
-    the chain hands to the following attention core."""
+    reference points, l = 0..5, iid-noise ResNet-101 maps, full-scale refinement MLPs -- measured
+    against the fp64 evaluation of the reference formula on the same inputs, next to the fp32
+    oracle's own deviation from it.  Also: the refined reference points and the next layer's
+    projected q / k / v^T the chain hands to the following attention core."""
     ops = head_ops()
-    sd, head = rig['sd'], rig['head']
+    sd, sd64, head = rig['sd'], rig['sd64'], rig['head']
     qe = sd['query_embedding.weight']
     pos = qe[:, :256][None]                                   # [1,Q,C]
     l2i = gpu(rig['l2i'])
     pv = head._packed_view
+    feats64 = [f.double() for f in rig['feats']]
     L = 6
-    worst = []
+    report = []
     for lid in range(L):
         x_prev = qe[:, 256:][None] if lid == 0 else rig['hs'][lid - 1].permute(1, 0, 2)   # [1,Q,C]
         ref_prev = rig['init_ref'] if lid == 0 else rig['inter_refs'][lid - 1]
         q, k, vt = _qkv_from_oracle_state(sd, lid, x_prev, pos)
         attn_o = ops.sdpa(gpu(q), gpu(k), gpu(vt))
-        # attention core alone vs the oracle's softmax(QK^T)V (before out_proj)
-        name = 'transformer.decoder.layers.%d.attentions.0.attn' % lid
-        qk_in = (x_prev + pos).permute(1, 0, 2)
-        want_full = O.multihead_attention(sd, name, qk_in, qk_in, x_prev.permute(1, 0, 2))   # incl. out_proj
         nxt = pv.layers[lid + 1].self_attn.in_proj if lid + 1 < L else None
         hs, ref_out, qk_next, vt_next = ops.decoder_layer_tail(
             pv.layers[lid], nxt, rig['nhwc'], attn_o, gpu(x_prev), gpu(qe), l2i, gpu(ref_prev), PCR, HW)
-        want_hs = rig['hs'][lid].permute(1, 0, 2)             # [1,Q,C]
-        want_ref = rig['inter_refs'][lid]
-        d_hs = (hs.cpu() - want_hs).abs()
-        d_ref = (ref_out.cpu() - want_ref).abs()
-        worst.append((lid, float(d_hs.max()), float(d_ref.max())))
+        # the same layer: fp32 oracle (from the rig's trace) and fp64 evaluation of the same formula
+        p = 'transformer.decoder.layers.%d.' % lid
+        truth = O.decoder_layer(sd64, p, x_prev.permute(1, 0, 2).double(), pos.permute(1, 0, 2).double(),
+                                feats64, ref_prev.double(), PCR, rig['l2i'].double(), HW).permute(1, 0, 2)
+        tmp64 = O.reg_branch(sd64, 'reg_branches.%d' % lid, truth)
+        new_ref = torch.zeros_like(ref_prev.double())
+        new_ref[..., :2] = tmp64[..., :2] + O.inverse_sigmoid(ref_prev.double()[..., :2])
+        new_ref[..., 2:3] = tmp64[..., 4:5] + O.inverse_sigmoid(ref_prev.double()[..., 2:3])
+        truth_ref = new_ref.sigmoid()
+        oracle32 = rig['hs'][lid].permute(1, 0, 2)            # [1,Q,C]
+        e_hip = (hs.cpu().double() - truth).abs()
+        e_o32 = (oracle32.double() - truth).abs()
+        e_ref_hip = (ref_out.cpu().double() - truth_ref).abs()
+        e_ref_o32 = (rig['inter_refs'][lid].double() - truth_ref).abs()
+        report.append('layer %d: max|hs - fp64| hip %.2e / fp32 oracle %.2e; mean %.2e / %.2e; '
+                      'max|ref - fp64| %.1e / %.1e' % (lid, e_hip.max(), e_o32.max(), e_hip.mean(),
+                                                       e_o32.mean(), e_ref_hip.max(), e_ref_o32.max()))
         # a query whose projected point sits within fp32 rounding of an image border / depth
         # threshold may flip its visibility mask (a discontinuity of the reference, XFMR:399-409):
         # allow <= 2 such rows per layer, everything else must hold the tolerance
-        bad = (d_hs.amax(-1) > LAYER_TOL)[0]
-        assert int(bad.sum()) <= 2, 'layer %d: %d rows off by more than %g (max %.3g)' % (
-            lid, int(bad.sum()), LAYER_TOL, float(d_hs.max()))
+        bad = (e_hip.amax(-1) > LAYER_MAX_TOL)[0]
+        assert int(bad.sum()) <= 2, report[-1]
         ok = ~bad
-        assert float(d_ref[0][ok].max()) <= REF_TOL, (lid, float(d_ref[0][ok].max()))
-        del want_full
+        assert float(e_hip[0][ok].mean()) <= LAYER_MEAN_TOL, report[-1]
+        # as close to the fp64 truth as the fp32 reference formula is (same order of magnitude)
+        assert float(e_hip[0][ok].mean()) <= 2.0 * float(e_o32.mean()) + 1e-6, report[-1]
+        assert float(e_hip[0][ok].max()) <= 2.0 * float(e_o32.max()) + 5e-5, report[-1]
+        assert float(e_ref_hip[0][ok].max()) <= REF_TOL, report[-1]
         if nxt is not None:
             # the chain's projection of ITS hs for the next attention core, against the host
-            # projection of the oracle's hs
-            q2, k2, vt2 = _qkv_from_oracle_state(sd, lid + 1, want_hs, pos)
+            # (fp64, rounded once) projection of the SAME hs
+            q2, k2, vt2 = _qkv_from_oracle_state(sd, lid + 1, hs.cpu(), pos)
             got_q, got_k = qk_next[..., :256].cpu(), qk_next[..., 256:].cpu()
-            assert float((got_q - q2).abs()[0][ok].max()) <= 2e-4
-            assert float((got_k - k2).abs()[0][ok].max()) <= 2e-4
-            Q = want_hs.shape[1]
-            assert float((vt_next.cpu()[0, :, :Q].T - vt2[0, :, :Q].T).abs()[ok].max()) <= 2e-4
-    print('teacher-forced decoder layers (layer, max|d hs|, max|d ref|):', worst)
+            assert float((got_q - q2).abs().max()) <= 2e-5, lid
+            assert float((got_k - k2).abs().max()) <= 2e-5, lid
+            Q = hs.shape[1]
+            assert float((vt_next.cpu()[0, :, :Q] - vt2[0, :, :Q]).abs().max()) <= 2e-5, lid
+    print('\n'.join(['teacher-forced decoder layers on the bench workload:'] + report))
 
 
 def test_attention_core_teacher_forced(rig):

@@ -478,7 +478,7 @@ def test_fused_training_with_dropout_matches_reference_formula(A, golden_dir, pa
         assert tr.last_dropout_seed != seed
         assert any(abs(float(l_other[k]) - float(losses[k])) > 1e-4 * max(1.0, abs(float(losses[k]))) for k in losses)
     else:                        # the module API: head.train()(feats, metas) -> loss -> backward
-        h.set_dropout(p)
+        h.set_dropout(p, decoder=False)          # this test: the fusion layers' sites only
         h.dropout_seed = 11
         tr.bucket.zero_grad()
         outs = h.train()(feats, metas)
@@ -537,3 +537,81 @@ def test_fused_training_with_dropout_matches_reference_formula(A, golden_dir, pa
     k0 = 'rf_linear2.weight'
     assert abs(float(hip_grads[k0].double().norm()) - float(g8[k0.replace('.', '__') + '__stats'][2])) > \
         1e-3 * float(g8[k0.replace('.', '__') + '__stats'][2])
+
+
+def test_decoder_train_mode_dropout_matches_reference_formula(A, golden_dir):
+    """tools/train.py:245-252 freezes the decoder's parameters but leaves it in train mode, so
+    the five dropout sites of every decoder layer (CFG:68-80: the mmcv attention wrapper's
+    probability and output dropout, the FFN's two; XFMR:378: Detr3DCrossAtten.dropout; p = 0.1)
+    act on configs[2].  tc_head_options.decoder_dropout_p switches them on in the HIP decoder
+    (attention core + row chains, layer 0 no longer folded into the checkpoint constants).  The
+    masks are counter-based, so the check is: with the SAME masks (read back through
+    tc_dropout_mask) the reference formula -- the oracle's decoder with given masks -- gives the
+    same decoder states and reference points."""
+    import ctypes as C
+    from transcar_amd import _lib as L
+    from transcar_amd import ops
+    from transcar_amd.detr3d_head import head_options
+    p, seed = 0.1, 0x5EED1234ABCD
+    h = train_head(golden_dir)
+    assert h.decoder_dropout_p() == 0.0                       # train_head: set_dropout(0.0)
+    h.set_decoder_dropout(p)
+    assert h.decoder_dropout_p() == p
+    feats, metas, _, _ = frame_inputs(golden_dir)
+    nhwc = ops.to_nhwc_levels(feats)
+    l2i = ops.lidar2img_tensor(metas, dev())
+    img_hw = metas[0]['img_shape'][0][:2]
+    tokens, pad_mult = h.radar_tokens(metas, dev())
+    with torch.no_grad():
+        ev = h.eval().forward_nhwc(nhwc, l2i, img_hw, tokens, pad_mult, aux=True)
+        h.train()
+        tr_ = h.forward_nhwc(nhwc, l2i, img_hw, tokens, pad_mult, aux=True, _allow_train=True,
+                             options=head_options(decoder_dropout_p=p, dropout_seed=seed))
+        tr2 = h.forward_nhwc(nhwc, l2i, img_hw, tokens, pad_mult, aux=True, _allow_train=True,
+                             options=head_options(decoder_dropout_p=p, dropout_seed=seed))
+        tr3 = h.forward_nhwc(nhwc, l2i, img_hw, tokens, pad_mult, aux=True, _allow_train=True,
+                             options=head_options(decoder_dropout_p=p, dropout_seed=seed + 1))
+        off = h.forward_nhwc(nhwc, l2i, img_hw, tokens, pad_mult, aux=True, _allow_train=True,
+                             options=head_options(decoder_dropout_p=0.0, dropout_seed=seed))
+    hs = tr_['aux']['inter_states']
+    assert torch.equal(hs, tr2['aux']['inter_states'])               # same seed, same masks
+    assert float((hs - tr3['aux']['inter_states']).abs().max()) > 1e-2   # another seed
+    assert float((hs - ev['aux']['inter_states']).abs().max()) > 1e-2    # not the eval forward
+    assert torch.equal(off['aux']['inter_states'], ev['aux']['inter_states'])   # p = 0: the eval kernels
+
+    # ---- the masks, site = 16 + 8 * layer + {0 probs, 1 self-attn out, 2 cross-attn out, 3 FFN hidden, 4 FFN out}
+    lib = L.lib()
+    Q, Cd, Fd, H = h.num_query, 256, 512, 8
+
+    def mask(site, n):
+        out = torch.empty(n, dtype=torch.float32, device=dev())
+        L.check(lib.tc_dropout_mask(p, seed, site, n, out.data_ptr(),
+                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'tc_dropout_mask')
+        return out.cpu()
+    dec_drop = []
+    for l in range(6):
+        s0 = 16 + 8 * l
+        dec_drop.append(dict(
+            probs=mask(s0 + 0, H * Q * Q).view(H, Q, Q),              # [B*heads, Q, Q], B = 1
+            sa=mask(s0 + 1, Q * Cd).view(Q, 1, Cd), ca=mask(s0 + 2, Q * Cd).view(Q, 1, Cd),
+            ffn_h=mask(s0 + 3, Q * Fd).view(Q, 1, Fd), ffn_o=mask(s0 + 4, Q * Cd).view(Q, 1, Cd)))
+    keep = float((dec_drop[2]['probs'] > 0).float().mean())
+    assert abs(keep - (1 - p)) < 1e-3, keep                      # 6.5 M Bernoulli draws
+    g_feats, g_l2i, frame, _, _ = g8_inputs(golden_dir)
+    sd = O.to_torch_sd(synth.make_state_dict(3))
+    with torch.no_grad():
+        want_hs, init_ref, want_refs, _ = O.transformer(
+            sd, [torch.from_numpy(f) for f in g_feats], configs.point_cloud_range,
+            torch.from_numpy(g_l2i).float()[None], configs.IMG_SHAPE[:2], dec_drop=dec_drop)
+    np.testing.assert_allclose(tr_['aux']['init_reference'].cpu().numpy(), init_ref.numpy(), atol=1e-6, rtol=0)
+    # layer by layer; the loop gain of the refinement makes late layers looser (DESIGN.md section 3)
+    got_hs = hs.cpu().numpy()[:, 0]
+    got_refs = tr_['aux']['inter_references'].cpu().numpy()
+    np.testing.assert_allclose(got_hs[0], want_hs[0][:, 0].numpy(), atol=2e-4, rtol=0)
+    np.testing.assert_allclose(got_refs[0], want_refs[0].numpy(), atol=2e-5, rtol=0)
+    np.testing.assert_allclose(got_refs, want_refs.numpy(), atol=2e-4, rtol=0)
+    np.testing.assert_allclose(got_hs, want_hs[:, :, 0].numpy(), atol=2e-3, rtol=0)
+    # the training iteration uses it: FusionTrainer draws decoder masks from the iteration's seed
+    from transcar_amd.trainer import FusionTrainer
+    t = FusionTrainer(h, dropout=p, seed=3)
+    assert t.decoder_dropout == p

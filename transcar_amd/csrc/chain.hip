@@ -83,7 +83,9 @@ struct EpiRec {
   float* gd; float* gt;
   int dst_off, res_off, dst_ld, res_ld;
   int gld, act, flags, N;
-  int has_bias, woff, pad0, pad1;
+  int has_bias, woff;
+  int drop_site;               // train-mode decoder dropout on this step's output: site + 1 (0: none)
+  int pad1;
 };
 // per wave: the next linear step of the same run in which the wave owns a column tile
 struct PreRec { const float* first; int nidx; int pad; };
@@ -246,6 +248,7 @@ struct ChainDev {
   int total, early_n;          // resolved steps; leading K_LOAD steps (issued before anything else)
   float* g[G_COUNT]; int g_ld[G_COUNT]; int g_mod[G_COUNT];   // global tensors by GSel
   float qscale; int qpad;
+  DropK drop;                  // decoder program, DROP instantiation only (thr 0: off)
   int dbg;                     // STAMPS build only: TRANSCAR_CHAIN_DBG (timing experiments, wrong results)
   int tile_rows;               // requested row-tile height (0: automatic); host side only
   int last_cls_only;           // radar program: class MLPs of the last layer only; host side only
@@ -296,6 +299,8 @@ struct LinSpec {
   int woff;                    // wave w owns column tiles ((w - woff) & 3) + 4 i
   int dbg;
   int sub_on;
+  int drop_site;               // DROP instantiations: site + 1 of this step's output dropout (0: none)
+  unsigned long long drop_seed; unsigned drop_thr; float drop_scale;
 };
 
 // One work item = (64-column output tile, 64-deep k block): 16 x 16-byte weight
@@ -378,7 +383,7 @@ __device__ __forceinline__ void wcompute(Acc<NG>& acc, const WBuf& wb, const flo
 // lane n holds y[4g + i][64*tile + n] in acc.v[g][*][i]
 // Phases instead of a per-row chain of branches: all LDS reads of a kind are issued
 // together and waited for once (per row they serialised: ~4 x 150 cycles per tile).
-template <int NG>
+template <int NG, bool DROP>
 __device__ __forceinline__ void lin_epilogue(const LinSpec& s, int tile, const Acc<NG>& acc, int lane, float bv) {
   const int col = tile * 64 + lane;
   if (col >= s.N) return;
@@ -410,6 +415,18 @@ __device__ __forceinline__ void lin_epilogue(const LinSpec& s, int tile, const A
     for (int g = 0; g < NG; ++g)
 #pragma unroll
       for (int i = 0; i < 4; ++i) if (gt_[g][i] == 0) y[g][i] = 0.0f;
+  }
+  if (DROP) {
+    // nn.Dropout on this step's output (before the residual): element index row * N + col
+    if (s.drop_site != 0) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const unsigned idx = (unsigned)(s.m0 + 4 * g + i) * (unsigned)s.N + (unsigned)col;
+          y[g][i] = drop_keep(s.drop_seed, (unsigned)(s.drop_site - 1), idx, s.drop_thr) ? y[g][i] * s.drop_scale : 0.0f;
+        }
+    }
   }
   if (s.res != nullptr) {
     float rr[NG][4];
@@ -466,7 +483,7 @@ __device__ __forceinline__ void lin_epilogue(const LinSpec& s, int tile, const A
 // last item of a step fetches `next_first`, the first item of the wave's next
 // linear step (the weight stream depends on the step table only, not on data),
 // which then arrives in `w0` (`preloaded`).  Returns true when w0 holds that item.
-template <int R, typename SpecFn>
+template <int R, bool DROP, typename SpecFn>
 __device__ __forceinline__ bool linear_step(const LinSpec& s, WBuf& w0, bool preloaded,
                                             const float* next_first, SpecFn make_spec, int step_idx) {
   constexpr int NG = R / 4;
@@ -528,7 +545,7 @@ __device__ __forceinline__ bool linear_step(const LinSpec& s, WBuf& w0, bool pre
       asm volatile("" : "+s"(tile), "+s"(sidx));
       if (!(CHAIN_DBG(s.dbg) & 1)) {
         const LinSpec e = make_spec(sidx);
-        lin_epilogue<NG>(e, tile, acc, lane, bv);
+        lin_epilogue<NG, DROP>(e, tile, acc, lane, bv);
       }
     }
     wcur = np; tt = nt; kb = nk;
@@ -635,7 +652,7 @@ __device__ long long g_wg_span[1024][2];
 // uses.  (One code image for all four programs made the R = 4 kernel spill 9 dwords to a
 // private segment under the combined pressure of the camera-sampling and radar-attention
 // bodies; the specialised kernels are smaller and were 3.5 % faster per frame.)
-template <int R, int PROG>
+template <int R, int PROG, bool DROP = false>
 __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __restrict__ recs, const int block) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   using Lds = ChainLds<R, rec_cap(PROG)>;
@@ -764,6 +781,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
     s.woff = (r.flags & F_WAVE1) ? 1 : 0;
     s.dbg = k.dbg;
     s.sub_on = 0;
+    s.drop_site = 0; s.drop_seed = 0; s.drop_thr = 0; s.drop_scale = 1.0f;
     return s;
   };
   // ... and the part its epilogue needs, rebuilt per tile from the 64-byte LDS record
@@ -785,6 +803,10 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
     s.woff = e.woff;
     s.dbg = 0;
     s.sub_on = 0;
+    s.drop_site = 0; s.drop_seed = 0; s.drop_thr = 0; s.drop_scale = 1.0f;
+    if (DROP) {
+      s.drop_site = e.drop_site; s.drop_seed = k.drop.seed; s.drop_thr = k.drop.thr; s.drop_scale = k.drop.scale;
+    }
     return s;
   };
 
@@ -811,7 +833,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
 #endif
           if (((wave - s.woff) & (CH_NW - 1)) < ((s.N + 63) >> 6)) {   // else: no column tile here, w0 keeps waiting
             const PreRec pr = load_uniform<PreRec>(S.recs[idx].p[wave]);
-            const bool have = linear_step<R>(s, w0, pre_idx == idx, pr.first, epi_spec, idx);
+            const bool have = linear_step<R, DROP>(s, w0, pre_idx == idx, pr.first, epi_spec, idx);
             pre_idx = have ? pr.nidx : -1;
           }
         } else if (kd == K_LN) {
@@ -975,9 +997,9 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
   WG_STAMP(1);
 }
 
-template <int R, int PROG>
+template <int R, int PROG, bool DROP = false>
 __global__ __launch_bounds__(CH_NT, R <= 8 ? 2 : 1) void chain_kernel(ChainDev k, Recs<rec_cap(PROG)> recs) {
-  chain_body<R, PROG>(k, recs.s, blockIdx.x);
+  chain_body<R, PROG, DROP>(k, recs.s, blockIdx.x);
 }
 
 // Two programs in one launch: workgroups [0, na) run the decoder layer `ka` on RA-row
@@ -1055,6 +1077,12 @@ void resolve_program(ChainK& k, StepAll* out) {
     EpiRec& e = out[idx].e;
     e.gd = r.gd; e.gt = r.gt; e.gld = r.gld; e.act = r.act; e.flags = r.flags; e.N = r.N;
     e.has_bias = r.p1 != nullptr; e.woff = (r.flags & F_WAVE1) ? 1 : 0;
+    e.drop_site = 0;
+    if (PROG == PROG_DECODER && k.drop.thr != 0 && d.kind == K_LINEAR) {
+      // mmcv MultiheadAttention's output dropout, Detr3DCrossAtten.dropout (XFMR:378), the FFN's two
+      const int off = d.wp == 1 ? 1 : d.wp == 4 ? 2 : d.wp == 10 ? 3 : d.wp == 11 ? 4 : 0;
+      if (off) e.drop_site = (int)k.drop.site + off + 1;
+    }
     e.dst_off = lds_off<R, PROG>(r.dst); e.dst_ld = buf_ld_h(r.dst);
     e.res_off = lds_off<R, PROG>(r.res); e.res_ld = buf_ld_h(r.res);
   }
@@ -1103,11 +1131,11 @@ int launch_dual_r(const ChainK& ka_, const ChainK& kb_, hipStream_t s, const cha
   return check_launch(what);
 }
 
-template <int R, int PROG>
+template <int R, int PROG, bool DROP = false>
 int launch_r(const ChainK& k_, hipStream_t s, const char* what) {
   static DeviceOnce once;
   if (once.need()) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<R, PROG>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<R, PROG, DROP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)chain_lds_bytes<R, PROG>());
     if (e != hipSuccess) { set_error("chain: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
@@ -1117,7 +1145,7 @@ int launch_r(const ChainK& k_, hipStream_t s, const char* what) {
   Recs<rec_cap(PROG)> recs;
   resolve_program<R, PROG>(k, recs.s);
   constexpr size_t lds = chain_lds_bytes<R, PROG>();
-  hipLaunchKernelGGL((chain_kernel<R, PROG>), dim3((k.M + R - 1) / R), dim3(CH_NT), lds, s,
+  hipLaunchKernelGGL((chain_kernel<R, PROG, DROP>), dim3((k.M + R - 1) / R), dim3(CH_NT), lds, s,
                      static_cast<const ChainDev&>(k), recs);
   return check_launch(what);
 }
@@ -1149,7 +1177,13 @@ int launch_rows(const ChainK& k, hipStream_t s, const char* what) {
 
 int launch(const ChainK& k, hipStream_t s, const char* what) {
   switch (k.program) {
-    case PROG_DECODER: return launch_rows<PROG_DECODER>(k, s, what);
+    case PROG_DECODER:
+      if (k.drop.thr != 0) {            // train-mode dropout: its own instantiations, 4- and 8-row tiles
+        TC_REQUIRE((unsigned long long)k.M * 512ull < (1ull << 32), "decoder_chain: dropout index space");
+        return tile_rows(k) == 4 ? launch_r<4, PROG_DECODER, true>(k, s, what)
+                                 : launch_r<8, PROG_DECODER, true>(k, s, what);
+      }
+      return launch_rows<PROG_DECODER>(k, s, what);
     case PROG_RADAR: return launch_rows<PROG_RADAR>(k, s, what);
     // the prologue runs once per checkpoint on Q rows (tc_head_pack_weights); stand-alone radar
     // encoders take the fewest workgroups (16-row tiles): 225 + 64 workgroups of 4-row tiles
@@ -1224,6 +1258,7 @@ static int make_decoder_k(const DecoderChainArgs& a, ChainK& k) {
   TC_REQUIRE(a.tile_rows == 0 || a.tile_rows == 4 || a.tile_rows == 8 || a.tile_rows == 16,
              "decoder_chain: tile_rows=%d (0 = automatic, 4, 8 or 16)", a.tile_rows);
   k.tile_rows = a.tile_rows;
+  k.drop = a.drop;
   return 0;
 }
 
@@ -1267,6 +1302,7 @@ int launch_decoder_chain_with_encoders(const DecoderChainArgs& d, const RadarEnc
   if (rc != 0) return rc;
   rc = make_radar_enc_k(e, ke, part);
   if (rc != 0) return rc;
+  TC_REQUIRE(kd.drop.thr == 0, "decoder dropout: launch the encoders on their own (launch_radar_encode)");
   const int rows = tile_rows(kd);
   const char* what = "chain(decoder + radar_encode)";
 #define TC_DUAL(RA, RB)                                                               \

@@ -185,8 +185,13 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
     re.radar_feat = h.radar_feat;
   }
 
-  // layer 0 up to its attention output is a constant of the checkpoint (pack time)
-  const bool folded = w->l0_attn_out != nullptr && w->l0_init_reference != nullptr;
+  // train-mode statistics of the frozen decoder: five dropout sites per layer (sites 16 + 8 l + 0..4)
+  const bool ddrop = opt.decoder_dropout_p > 0.0f;
+  TC_REQUIRE(!ddrop || (unsigned long long)B * H * Q * Q < (1ull << 32), "decoder dropout: B*H*Q*Q exceeds 32 bits");
+  if (radar && ddrop) TC_TRY(launch_radar_encode(re, s));     // no ride in the decoder launches then
+  // layer 0 up to its attention output is a constant of the checkpoint (pack time) -- in eval
+  // mode: with dropout on the attention probabilities it is not
+  const bool folded = !ddrop && w->l0_attn_out != nullptr && w->l0_init_reference != nullptr;
   if (!folded) {
     PrologueArgs pa;
     pa.qe = w->query_embedding; pa.Q = Q; pa.M = rows; pa.refpts = w->reference_points;
@@ -198,8 +203,10 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
     const bool l0c = folded && lid == 0;
     const float* ref_in = l0c ? w->l0_init_reference
                               : lid == 0 ? h.init_ref : h.inter_refs + (size_t)(lid - 1) * rows * 3;
-    if (!l0c) TC_TRY(launch_self_attn_core(h.qk, h.qk + C, 2 * C, h.vt, h.qpad, h.attn_o, C, B, Q, H, s));
     DecoderChainArgs d;
+    if (ddrop) d.drop = make_drop(opt.decoder_dropout_p, opt.dropout_seed, 16u + 8u * (unsigned)lid, 0u);
+    if (!l0c) TC_TRY(launch_self_attn_core(h.qk, h.qk + C, 2 * C, h.vt, h.qpad, h.attn_o, C, B, Q, H, s,
+                                           ddrop ? &d.drop : nullptr));
     d.attn_o = l0c ? w->l0_attn_out : h.attn_o;
     d.attn_mod = l0c ? Q : 0; d.ref_mod = l0c ? Q : 0;
     if (lid == 0) { d.x_in = w->query_embedding + C; d.x_ld = 2 * C; d.x_mod = Q; }
@@ -219,8 +226,8 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
     d.code = code; d.M = rows; d.tile_rows = opt.chain_tile_rows;
     // the radar encoders ride in the launches of layers 0 and 1, half each (all in layer 0
     // when there is only one layer)
-    if (radar && lid == 0) TC_TRY(launch_decoder_chain_with_encoders(d, re, L > 1 ? 1 : 0, s));
-    else if (radar && lid == 1) TC_TRY(launch_decoder_chain_with_encoders(d, re, 2, s));
+    if (radar && !ddrop && lid == 0) TC_TRY(launch_decoder_chain_with_encoders(d, re, L > 1 ? 1 : 0, s));
+    else if (radar && !ddrop && lid == 1) TC_TRY(launch_decoder_chain_with_encoders(d, re, 2, s));
     else TC_TRY(launch_decoder_chain(d, s));
   }
   if (aux) {

@@ -96,6 +96,10 @@ struct DecoderChainArgs {
   CamSampleArgs cam;                         // feats, lidar2img, pc, img size (ref/logits/out unused)
   int code, M;
   int tile_rows = 0;                         // 0: automatic (4 up to 1024 rows, 8 beyond), 4, 8, 16
+  // train-mode statistics of the frozen decoder (thr 0 = eval): drop.site is the site of THIS
+  // layer's attention probabilities (16 + 8 * layer); the chain's four sites are drop.site + 1
+  // (self-attention output), + 2 (cross-attention output, XFMR:378), + 3 (FFN hidden), + 4 (FFN output)
+  DropK drop = DropK{0, 0, 1.0f, 0, 0};
 };
 int launch_decoder_chain(const DecoderChainArgs& a, hipStream_t s);
 
@@ -126,8 +130,10 @@ int launch_radar_chain(const RadarChainArgs& a, hipStream_t s);
 
 // ---- self_attn.hip ---------------------------------------------------------
 // q,k: [B*Q, ld] token-major with head h at column h*32; vt: [B, C, ldt] (V transposed)
+// drop (may be null / thr 0 = eval): dropout on the attention probabilities, index ((b*H+h)*Q+i)*Q+j
 int launch_self_attn_core(const float* q, const float* k, int ld, const float* vt, int ldt,
-                          float* out, int ldo, int B, int Q, int H, hipStream_t s);
+                          float* out, int ldo, int B, int Q, int H, hipStream_t s,
+                          const DropK* drop = nullptr);
 
 // ---- radar_attn.hip --------------------------------------------------------
 struct RadarAttnArgs {

@@ -59,12 +59,18 @@ __device__ __forceinline__ KVFrag load_kv(const float* __restrict__ k, const flo
 // QT = 16-query sub-tiles per workgroup: the K/V fragments of a key tile are loaded
 // once and used for QT score / PV products (K/V re-reads from L2 are the kernel's
 // main memory traffic: 57 query tiles x 8 heads x 230 KB at QT = 1).
-template <int QT>
+//
+// DROP (training statistics of the frozen decoder, tools/train.py:245-252 leaves its dropouts
+// on): nn.MultiheadAttention's dropout on the attention probabilities -- the normalised
+// probability of (batch b, head h, query i, key j) is multiplied by 0 or 1/(1-p), mask
+// drop_keep(seed, site, ((b*H + h)*Q + i)*Q + j): only the PV product sees the mask, the
+// normaliser l does not.  A separate instantiation: the eval kernel is unchanged.
+template <int QT, bool DROP>
 __global__ __launch_bounds__(SA_NW * 64) void self_attn_kernel(const float* __restrict__ q,
                                                                const float* __restrict__ k, int ld,
                                                                const float* __restrict__ vt, int ldt,
                                                                float* __restrict__ out, int ldo,
-                                                               int Q, int C) {
+                                                               int Q, int C, DropK drop) {
   __shared__ float sm_m[SA_NW][QT][16];
   __shared__ float sm_l[SA_NW][QT][64];
   __shared__ float4 sm_o[SA_NW][QT][2][64];
@@ -131,11 +137,20 @@ __global__ __launch_bounds__(SA_NW * 64) void self_attn_kernel(const float* __re
       lpart[u] = lpart[u] * alpha + ((p0 + p1) + (p2 + p3));
       m[u] = mnew;
       o0[u] *= alpha; o1[u] *= alpha;
+      float d0 = p0, d1 = p1, d2 = p2, d3 = p3;
+      if (DROP) {
+        const unsigned qi = (unsigned)min(q0 + 16 * u + r, Q - 1);
+        const unsigned base = (((unsigned)b * gridDim.y + h) * Q + qi) * Q + kk;
+        d0 = drop_keep(drop.seed, drop.site, base + 0, drop.thr) ? p0 * drop.scale : 0.0f;
+        d1 = drop_keep(drop.seed, drop.site, base + 1, drop.thr) ? p1 * drop.scale : 0.0f;
+        d2 = drop_keep(drop.seed, drop.site, base + 2, drop.thr) ? p2 * drop.scale : 0.0f;
+        d3 = drop_keep(drop.seed, drop.site, base + 3, drop.thr) ? p3 * drop.scale : 0.0f;
+      }
       // O^T[d][q] += V^T[d][key] P^T[key][q]
-      o0[u] = MFMA4(v0.x, p0, o0[u]); o1[u] = MFMA4(v1.x, p0, o1[u]);
-      o0[u] = MFMA4(v0.y, p1, o0[u]); o1[u] = MFMA4(v1.y, p1, o1[u]);
-      o0[u] = MFMA4(v0.z, p2, o0[u]); o1[u] = MFMA4(v1.z, p2, o1[u]);
-      o0[u] = MFMA4(v0.w, p3, o0[u]); o1[u] = MFMA4(v1.w, p3, o1[u]);
+      o0[u] = MFMA4(v0.x, d0, o0[u]); o1[u] = MFMA4(v1.x, d0, o1[u]);
+      o0[u] = MFMA4(v0.y, d1, o0[u]); o1[u] = MFMA4(v1.y, d1, o1[u]);
+      o0[u] = MFMA4(v0.z, d2, o0[u]); o1[u] = MFMA4(v1.z, d2, o1[u]);
+      o0[u] = MFMA4(v0.w, d3, o0[u]); o1[u] = MFMA4(v1.w, d3, o1[u]);
     }
     cur = nxt;
   }
@@ -171,12 +186,19 @@ __global__ __launch_bounds__(SA_NW * 64) void self_attn_kernel(const float* __re
 }
 
 int launch_self_attn_core(const float* q, const float* k, int ld, const float* vt, int ldt,
-                          float* out, int ldo, int B, int Q, int H, hipStream_t s) {
+                          float* out, int ldo, int B, int Q, int H, hipStream_t s, const DropK* drop) {
   TC_REQUIRE(Q > 0 && B > 0 && H > 0, "self_attn: empty problem");
   TC_REQUIRE((ldt & 3) == 0 && ldt >= ((Q + 15) / 16) * 16, "self_attn: ldt=%d too small for Q=%d", ldt, Q);
   constexpr int QT = 2;
   dim3 grid((Q + 16 * QT - 1) / (16 * QT), H, B);
-  hipLaunchKernelGGL(self_attn_kernel<QT>, grid, dim3(SA_NW * 64), 0, s, q, k, ld, vt, ldt, out, ldo, Q, H * 32);
+  if (drop != nullptr && drop->thr != 0) {
+    TC_REQUIRE((unsigned long long)B * H * Q * Q < (1ull << 32), "self_attn: dropout index space (B*H*Q*Q) exceeds 32 bits");
+    hipLaunchKernelGGL((self_attn_kernel<QT, true>), grid, dim3(SA_NW * 64), 0, s, q, k, ld, vt, ldt, out, ldo, Q,
+                       H * 32, *drop);
+  } else {
+    hipLaunchKernelGGL((self_attn_kernel<QT, false>), grid, dim3(SA_NW * 64), 0, s, q, k, ld, vt, ldt, out, ldo, Q,
+                       H * 32, DropK{0, 0, 1.0f, 0, 0});
+  }
   return check_launch("self_attn");
 }
 

@@ -444,9 +444,12 @@ class Detr3DHead(BaseModule):
         HIP backward kernels.  The dropout layers of the fusion layers
         (rf_multihead_attn*.dropout, rf_dropout*, rf_dropout2*, rf_dropout3*;
         p = 0.1 in the reference, HEAD:129-171) are active with counter-based
-        masks of (``self.dropout_seed``, number of training forwards so far);
-        set their ``p`` to 0 (``set_dropout(0.0)``) for the deterministic
-        variant.  The frozen decoder runs without dropout."""
+        masks of (``self.dropout_seed``, rank, number of training forwards so
+        far); set their ``p`` to 0 (``set_dropout(0.0)``) for the deterministic
+        variant.  The frozen decoder runs in train mode too, as in the
+        reference (tools/train.py:245-252 only clears requires_grad): the five
+        dropout sites of every decoder layer (``decoder_dropout_p``) draw their
+        masks from the same seed."""
         from . import autograd_ops as A
         for grp in (self.transformer, self.cls_branches, self.reg_branches,
                     self.query_embedding):
@@ -457,9 +460,11 @@ class Detr3DHead(BaseModule):
                         'transformer / cls_branches / reg_branches / '
                         'query_embedding as tools/train.py:245-252 does '
                         '(Detr3DHead.freeze_decoder())')
+        seed = self.next_dropout_seed()
         with torch.no_grad():
             base = self.forward_nhwc(feats_nhwc, lidar2img, img_hw, tokens,
-                                     pad_mult, aux=True, _allow_train=True)
+                                     pad_mult, aux=True, _allow_train=True,
+                                     options=self.train_options(seed))
         aux = base['aux']
         B, Q, E = aux['inter_states'].shape[1:]
         qf = aux['inter_states'][-1].clone()                  # HEAD:539
@@ -482,7 +487,6 @@ class Detr3DHead(BaseModule):
         f = A.linear(f, rfe[4].weight, rfe[4].bias, act=1)
         mem = pos + f
 
-        seed = self.next_dropout_seed()
         all_cls, all_box = [], []
         for r, (sfx, asfx) in enumerate((('', ''), ('_2', '2'), ('_3', '3'))):
             attn = getattr(self, 'rf_multihead_attn' + asfx)
@@ -549,14 +553,55 @@ class Detr3DHead(BaseModule):
         self.last_dropout_seed = seed
         return seed
 
-    def set_dropout(self, p):
+    def set_dropout(self, p, decoder=True):
         """p of every dropout site of the radar fusion layers (HEAD:129-171 build
-        them with 0.1): 0.0 = the deterministic training forward."""
+        them with 0.1) and, with ``decoder``, of the frozen decoder layers
+        (CFG:68-80, XFMR:378): 0.0 = the deterministic training forward."""
         for asfx, sfx in (('', ''), ('2', '_2'), ('3', '_3')):
             getattr(self, 'rf_multihead_attn' + asfx).dropout = float(p)
             for name in ('rf_dropout', 'rf_dropout1', 'rf_dropout2', 'rf_dropout3'):
                 getattr(self, name + sfx).p = float(p)
+        if decoder:
+            self.set_decoder_dropout(p)
         return self
+
+    def _decoder_dropout_modules(self):
+        for ly in self.transformer.decoder.layers:
+            sa, ca, ffn = ly.attentions[0], ly.attentions[1], ly.ffns[0]
+            yield sa, ca, ffn
+
+    def set_decoder_dropout(self, p):
+        """p of the five dropout sites of every decoder layer."""
+        for sa, ca, ffn in self._decoder_dropout_modules():
+            sa.attn.dropout = float(p)
+            if isinstance(sa.dropout_layer, nn.Dropout):
+                sa.dropout_layer.p = float(p)
+            elif p > 0:
+                sa.dropout_layer = nn.Dropout(float(p))
+            ca.dropout.p = float(p)
+            ffn.layers[0][2].p = float(p)
+            ffn.layers[2].p = float(p)
+        return self
+
+    def decoder_dropout_p(self):
+        """The dropout probability of the decoder layers in train mode -- one value: the
+        HIP path implements the reference configs, where the mmcv wrapper's attention /
+        output dropout, the FFN's two dropouts (CFG:68-80) and Detr3DCrossAtten.dropout
+        (XFMR:243, 378) are all 0.1."""
+        ps = set()
+        for sa, ca, ffn in self._decoder_dropout_modules():
+            if float(sa.proj_drop.p) != 0.0:
+                raise NotImplementedError('MultiheadAttention.proj_drop > 0')
+            ps.update((float(sa.attn.dropout), float(getattr(sa.dropout_layer, 'p', 0.0)),
+                       float(ca.dropout.p), float(ffn.layers[0][2].p), float(ffn.layers[2].p)))
+        if len(ps) != 1:
+            raise NotImplementedError('decoder dropout sites with different p: %r' % sorted(ps))
+        return ps.pop()
+
+    def train_options(self, seed):
+        """tc_head_options of the frozen decoder's forward inside a training iteration."""
+        return head_options(decoder_dropout_p=self.decoder_dropout_p() if self.training else 0.0,
+                            dropout_seed=seed)
 
     def freeze_decoder(self):
         """tools/train.py:245-252."""

@@ -108,7 +108,7 @@ class FusionTrainer:
     """head: transcar_amd.Detr3DHead on the GPU, built with ``train_cfg``."""
 
     def __init__(self, head, lr=1.5e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01,
-                 max_norm=35.0, device_loss=True, dropout=0.1, seed=0):
+                 max_norm=35.0, device_loss=True, dropout=0.1, seed=0, decoder_dropout=None):
         self.head = head.freeze_decoder()
         self.bucket = FlatBucket(head.trainable_parameters())
         head.refresh_weights()                      # parameter addresses moved into the bucket
@@ -124,6 +124,11 @@ class FusionTrainer:
         # per-operator autograd path (step / step_nhwc) run without dropout.
         self.dropout, self.seed = float(dropout), int(seed)
         head.dropout_seed = int(seed)
+        # the frozen decoder's own dropouts (the reference leaves them active, tools/train.py:245-252):
+        # None = as the modules are configured (0.1) when the fusion layers train with dropout, else off
+        if decoder_dropout is None:
+            decoder_dropout = head.decoder_dropout_p() if self.dropout > 0 else 0.0
+        self.decoder_dropout = float(decoder_dropout)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -146,9 +151,13 @@ class FusionTrainer:
         """update=False stops after the backward: the gradients sit in the bucket."""
         head, lib = self.head, L.lib()
         head.train()
+        from .detr3d_head import head_options
+        drop_seed = head.next_dropout_seed()       # (seed, rank, forward counter): shared with forward_train_nhwc
         with torch.no_grad():
             base = head.forward_nhwc(feats_nhwc, lidar2img, img_hw, tokens, pad_mult, aux=True,
-                                     _allow_train=True, decoder_only=True)
+                                     _allow_train=True, decoder_only=True,
+                                     options=head_options(decoder_dropout_p=self.decoder_dropout,
+                                                          dropout_seed=drop_seed))
         aux = base['aux']
         w = head.head_weights()
         B, T = lidar2img.shape[0], tokens.shape[1]
@@ -166,7 +175,6 @@ class FusionTrainer:
         Q = head.num_query
         all_cls = torch.empty((3, B, Q, head.cls_out_channels), dtype=torch.float32, device=tokens.device)
         all_box = torch.empty((3, B, Q, head.code_size), dtype=torch.float32, device=tokens.device)
-        drop_seed = head.next_dropout_seed()       # (seed, rank, forward counter): shared with forward_train_nhwc
         L.check(lib.tc_radar_train_fwd(
             C.byref(w), hs_last.data_ptr(), ref_last.data_ptr(), last_box.data_ptr(), tokens.data_ptr(),
             B, T, int(pad_mult), all_cls.data_ptr(), all_box.data_ptr(), tape.data_ptr(), tape.numel(),
