@@ -62,6 +62,10 @@ def parse(argv=None):
     ap.add_argument('--lanes', type=int, default=3,
                     help='frames in flight per GPU: one hipGraph + HIP stream each '
                          '(transcar_amd/pipeline.py); 1 = strictly one frame at a time')
+    ap.add_argument('--pair', type=int, default=1,
+                    help='frames per launch: the pipeline hands the head P consecutive frames (one per '
+                         'step, the per-frame API is unchanged) as ONE launch sequence -- 8-row tiles, '
+                         'every streamed weight fragment feeds both frames.  1 = one frame per launch')
     ap.add_argument('--tile-rows', type=int, default=0, choices=[0, 4, 8, 16],
                     help='row-tile height of the fused chains in the frame pipeline (0 = automatic)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -260,6 +264,26 @@ def roofline(head, inp, dev):
                                 vt_in.data_ptr(), qpad, ao.data_ptr(), Cd, B, Q, H, cur_stream()), 'sdpa')
     attn_ms = time_events(run_attn)
     attn_flop = 4.0 * Q * Q * 32 * H * B
+    # -- fused radar chain (three fusion layers in one launch) on this frame's decoder outputs
+    from transcar_amd.detr3d_head import head_options
+    hs5 = o['aux']['inter_states'][-1].contiguous()
+    ref5 = o['aux']['inter_references'][-1].contiguous()
+    lbox = o['aux']['last_box'].contiguous()
+    T_tok = int(inp['tokens'].shape[1])
+    rws = torch.empty(lib.tc_head_workspace_bytes(C.byref(pv), B, T_tok), dtype=torch.uint8, device=dev)
+    rcls = torch.empty((3, B, Q, head.cls_out_channels), device=dev)
+    rbox = torch.empty((3, B, Q, code), device=dev)
+    ropt = head_options()
+
+    def run_radar():
+        L.check(lib.tc_radar_fusion_fwd(
+            C.byref(pv), hs5.data_ptr(), ref5.data_ptr(), lbox.data_ptr(), inp['tokens'].data_ptr(), B, T_tok,
+            int(inp['pad_mult']), 0, 3, rcls.data_ptr(), rbox.data_ptr(), None, C.byref(ropt),
+            rws.data_ptr(), rws.numel(), cur_stream()), 'radar_fusion')
+    run_radar()                           # encoders + K/V once ...
+    ropt.reuse_radar_kv = 1               # ... then the chain alone
+    radar_ms = time_events(run_radar)
+    radar_flop = 3 * 2.0 * M * (6 * Cd * Cd + 2 * Cd * F + 2 * Cd * code)
     kern = {
         'chain_kernel(decoder layer)': dict(
             bound='mfma', achieved=chain_flop / chain_ms / 1e9, peak=F32_MFMA_PEAK_TFLOPS,
@@ -267,6 +291,9 @@ def roofline(head, inp, dev):
         'self_attn_kernel': dict(
             bound='mfma', achieved=attn_flop / attn_ms / 1e9, peak=F32_MFMA_PEAK_TFLOPS,
             unit='TFLOP/s', ms=attn_ms, per_frame=6, alg_flop=attn_flop),
+        'chain_kernel(radar fusion)': dict(
+            bound='mfma', achieved=radar_flop / radar_ms / 1e9, peak=F32_MFMA_PEAK_TFLOPS,
+            unit='TFLOP/s', ms=radar_ms, per_frame=1, alg_flop=radar_flop),
         'cam_sample_kernel': dict(
             bound='hbm', achieved=cam_bytes / cam_ms / 1e6, peak=HBM_PEAK_GBS, unit='GB/s',
             ms=cam_ms, per_frame=0, alg_bytes=cam_bytes, visible_pairs=pairs,
@@ -279,16 +306,18 @@ def roofline(head, inp, dev):
     # HBM-side traffic per launch comes from the committed PMC passes (rocprofv3 cannot
     # run inside this process); null when no profile of this kernel is committed
     traffic, src = None, None
+    pmc = {}
     try:
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r1_pmc.json')))
-        if dom in pmc and B == 1:
-            traffic, src = pmc[dom]['traffic_bytes'], 'profiles/r1_pmc.json'
+        # {kernel: {"<frames per launch>": {"traffic_bytes": ...}}}, written by tools/collect_profile.py
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r2_pmc.json')))
+        ent = pmc.get(dom, {}).get(str(B))
+        if ent:
+            traffic, src = ent['traffic_bytes'], 'profiles/r2_pmc.json'
     except Exception:
         pass
     # algorithmic flop of the whole path per frame: 6 decoder chains (the last without the next
     # layer's QKV), 5 attention cores (layer 0's is a constant of the checkpoint), radar encoders
     # (T tokens) and 3 radar fusion layers
-    T_tok = int(inp['tokens'].shape[1])
     nly = head.head_weights().num_layers
     path_flop = (nly * chain_flop - 2.0 * M * 3 * Cd * Cd
                  + (nly - 1) * attn_flop
@@ -296,7 +325,8 @@ def roofline(head, inp, dev):
                  + 3 * 2.0 * M * (6 * Cd * Cd + 2 * Cd * F + 2 * Cd * code)) / B
     r.update(path_flop_per_frame=path_flop)
     r.update(kernel=dom, traffic=traffic, traffic_source=src,
-             others={n: {kk: v[kk] for kk in ('bound', 'achieved', 'peak', 'unit', 'frac', 'ms')}
+             others={n: dict({kk: v[kk] for kk in ('bound', 'achieved', 'peak', 'unit', 'frac', 'ms', 'per_frame')},
+                             traffic=(pmc.get(n, {}).get(str(B)) or {}).get('traffic_bytes'))
                      for n, v in kern.items() if n != dom})
     return r
 
@@ -317,7 +347,7 @@ def _replay_rate(launch, sync, n, min_s=0.3):
 
 
 def single_lane(pipe, args):
-    """One frame at a time on lane 0.  `ms_per_frame_synced`: the host waits for every frame
+    """One frame at a time on lane 0 (of a one-frame-per-launch pipeline).  `ms_per_frame_synced`: the host waits for every frame
     before it launches the next, as the reference's benchmark loop does
     (tools/analysis_tools/benchmark.py:64-91) = the latency of a frame incl. the replay launch;
     `ms_per_frame`: back-to-back replays on the one stream (no host wait in between)."""
@@ -342,8 +372,9 @@ def handoff_side_run(head, dev, args):
     (tc_nchw_to_nhwc_levels, one launch).  A channels_last FPN skips this (zero-copy)."""
     from transcar_amd.pipeline import FramePipeline
     lanes = []
+    fpl = args.batch * max(1, args.pair)
     for i in range(max(1, args.lanes)):
-        inp = make_inputs(head, dev, args.shapes, args.batch, seed=201 + 7 * i)
+        inp = make_inputs(head, dev, args.shapes, fpl, seed=201 + 7 * i)
         inp['nchw'] = [torch.from_numpy(f).to(dev) for f in inp['feats_np']]
         lanes.append(inp)
     pipe = FramePipeline(head, lanes, tile_rows=args.tile_rows or None)
@@ -357,8 +388,8 @@ def handoff_side_run(head, dev, args):
     def tr():
         ops.to_nhwc_levels(lanes[0]['nchw'], out=lanes[0]['nhwc'])
     tr_ms = time_events(tr)
-    return {'frames_in_flight': pipe.lanes, 'value': args.batch / t, 'unit': 'frames/s',
-            'ms_per_frame': t * 1e3 / args.batch, 'single_lane_ms_per_frame': t1 * 1e3 / args.batch,
+    return {'frames_in_flight': pipe.lanes * fpl, 'frames_per_launch': fpl, 'value': fpl / t, 'unit': 'frames/s',
+            'ms_per_frame': t * 1e3 / fpl, 'single_lane_ms_per_frame': t1 * 1e3 / fpl,
             'transpose': {'bound': 'hbm', 'ms': tr_ms, 'bytes': nbytes,
                           'achieved': nbytes / tr_ms / 1e6, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                           'frac': nbytes / tr_ms / 1e6 / HBM_PEAK_GBS}}
@@ -383,17 +414,17 @@ def producer_side_run(pipe, args):
                           nhwc=spare if with_feats else None)
         pipe.launch(i)
     n = max(20, args.steps)
+    fpl = pipe.frames_per_launch            # a replay = fpl frames; their inputs are written together
     for _ in range(2 * lanes):
         step(True)
-    t_small = _replay_rate(lambda: step(False), torch.cuda.synchronize, n)
-    t_all = _replay_rate(lambda: step(True), torch.cuda.synchronize, n)
+    t_small = _replay_rate(lambda: step(False), torch.cuda.synchronize, n) / fpl
+    t_all = _replay_rate(lambda: step(True), torch.cuda.synchronize, n) / fpl
     # restore lane 0's own frame (spare was a copy of it: nothing changed)
-    return {'frames_in_flight': lanes,
-            'tokens_l2i_h2d': {'value': args.batch / t_small, 'unit': 'frames/s',
-                               'ms_per_frame': t_small * 1e3 / args.batch},
+    return {'frames_in_flight': lanes * fpl,
+            'tokens_l2i_h2d': {'value': 1.0 / t_small, 'unit': 'frames/s', 'ms_per_frame': t_small * 1e3},
             'tokens_l2i_h2d_plus_feature_copy': {
-                'value': args.batch / t_all, 'unit': 'frames/s', 'ms_per_frame': t_all * 1e3 / args.batch,
-                'feature_bytes': sum(int(f.numel()) * 4 for f in spare)}}
+                'value': 1.0 / t_all, 'unit': 'frames/s', 'ms_per_frame': t_all * 1e3,
+                'feature_bytes_per_frame': sum(int(f.numel()) * 4 for f in spare) // fpl}}
 
 
 def batched_side_run(head, dev, args, frames=4):
@@ -687,22 +718,33 @@ def main(argv=None):
     if args.train:
         return train_bench(args, head, inp, dev, rank, world)
 
-    pipe = None
+    pipe, pair = None, 1
     if not args.no_graph:
-        # a frame (13 kernel launches + decode) is captured once into a hipGraph per lane;
-        # lane i works on its own synthetic frame
+        # a frame (13 kernel launches + decode) is captured once into a hipGraph per lane; lane i
+        # works on its own synthetic frame(s).  --pair P: a lane holds P frame slots; the bench
+        # submits ONE frame per step and the lane is replayed when its slots are filled
         from transcar_amd.pipeline import FramePipeline
-        lanes = [inp] + [make_inputs(head, dev, args.shapes, args.batch, seed=101 + rank + 7 * i)
-                         for i in range(1, max(1, args.lanes))]
+        pair = max(1, args.pair)
+        fpl = args.batch * pair
+        first = inp if pair == 1 else make_inputs(head, dev, args.shapes, fpl, seed=1 + rank)
+        lanes = [first] + [make_inputs(head, dev, args.shapes, fpl, seed=101 + rank + 7 * i)
+                           for i in range(1, max(1, args.lanes))]
         pipe = FramePipeline(head, lanes, tile_rows=args.tile_rows or None)
 
     def step():
-        if pipe is not None:
+        if pipe is None:
+            return one_step(head, inp)
+        if pair == 1:
             return pipe.launch()[1]
-        return one_step(head, inp)
+        return pipe.submit()
+
+    def sync():
+        if pipe is not None and pair > 1:
+            pipe.flush()                     # a window ends with every submitted frame launched
+        torch.cuda.synchronize()
 
     census = rank_census(dev, world)
-    med, win = timed_windows(step, torch.cuda.synchronize, args, dev, world)
+    med, win = timed_windows(step, sync, args, dev, world)
     frames = args.steps * args.batch * world
     line = {
         'metric': 'nuScenes frames/sec (6-cam+radar, 900 queries): fusion decoder '
@@ -728,7 +770,8 @@ def main(argv=None):
                                % (configs.LEVEL_SHAPES[args.shapes], args.batch, world),
                    'shapes': args.shapes, 'frames_per_step_per_gpu': args.batch,
                    'launch': 'eager' if pipe is None else 'hipGraph replay',
-                   'frames_in_flight': 1 if pipe is None else pipe.lanes,
+                   'frames_per_launch': 1 if pipe is None else pipe.frames_per_launch,
+                   'frames_in_flight': 1 if pipe is None else pipe.lanes * pipe.frames_per_launch,
                    'chain_tile_rows': args.tile_rows or 'auto',
                    'launcher': launcher_name(),
                    'parallelism': 'dp%d (frames sharded, no data-path collective)' % world},
@@ -737,9 +780,13 @@ def main(argv=None):
         if pipe is not None:
             # one frame at a time, host sync per frame: the reference's own method
             # (tools/analysis_tools/benchmark.py:64-91) -- the latency of a frame
-            line['single_lane'] = single_lane(pipe, args)
+            from transcar_amd.pipeline import FramePipeline
+            pipe1 = pipe if pipe.frames_per_launch == args.batch else FramePipeline(head, [inp])
+            line['single_lane'] = single_lane(pipe1, args)
             line['latency_ms_per_frame'] = line['single_lane']['ms_per_frame_synced']
-        line['roofline'] = roofline(head, inp, dev)      # rank 0's GPU; the other ranks wait at the barrier
+        # the dominant kernel as the timed region launches it (frames_per_launch frames per launch)
+        line['roofline'] = roofline(head, pipe.inputs[0] if pipe is not None else inp, dev)
+        line['roofline']['frames_per_launch'] = 1 if pipe is None else pipe.frames_per_launch
         # every kernel of the path together, at the measured whole-job rate
         pf = line['roofline']['path_flop_per_frame']
         line['roofline']['path_achieved_tflops'] = pf * line['value'] / world / 1e12

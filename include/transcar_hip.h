@@ -127,7 +127,9 @@ typedef struct {
                                get_bboxes decodes level 3 only (HEAD:1003-1023) and levels 1-2
                                feed only their BOX to the next gate; all_cls_scores[0:2] are
                                left untouched.  0 keeps the reference's [3,B,Q,10] output */
-  int reserved0;
+  int reuse_radar_kv;       /* tc_radar_fusion_fwd only: 1 = skip the radar encoders, the K/V
+                               projections of the previous call in the same workspace are reused
+                               (timing the fusion chain on its own) */
   /* train-mode statistics of the FROZEN decoder: tools/train.py:245-252 only clears
    * requires_grad, so the dropout (p = 0.1, CFG:68-80, XFMR:378) of the decoder layers stays
    * active during training.  0 = eval (off).  Masks are counter-based (common.hpp drop_keep):

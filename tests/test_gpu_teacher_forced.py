@@ -36,7 +36,7 @@ HW = configs.IMG_SHAPE[:2]
 LAYER_MAX_TOL = 3e-4      # max |hip - fp64| (the fp32 oracle reaches 1.6e-4)
 LAYER_MEAN_TOL = 1e-5     # mean |hip - fp64| (the fp32 oracle: 4e-6)
 LAYER_TOL = 1e-4          # radar layers (no sampling: plain linear algebra on O(1) values)
-REF_TOL = 5e-6            # refined reference points (sigmoid outputs in [0, 1])
+REF_TOL = 3e-5            # refined reference points (sigmoid of a full-xavier-scale MLP output; the fp32 oracle: 1.2e-5)
 
 
 def dev():
@@ -145,7 +145,7 @@ def test_decoder_layers_teacher_forced_on_bench_inputs(rig):
         # as close to the fp64 truth as the fp32 reference formula is (same order of magnitude)
         assert float(e_hip[0][ok].mean()) <= 2.0 * float(e_o32.mean()) + 1e-6, report[-1]
         assert float(e_hip[0][ok].max()) <= 2.0 * float(e_o32.max()) + 5e-5, report[-1]
-        assert float(e_ref_hip[0][ok].max()) <= REF_TOL, report[-1]
+        assert float(e_ref_hip[0][ok].max()) <= min(REF_TOL, 2.0 * float(e_ref_o32.max()) + 1e-6), report[-1]
         if nxt is not None:
             # the chain's projection of ITS hs for the next attention core, against the host
             # (fp64, rounded once) projection of the SAME hs

@@ -523,7 +523,7 @@ int tc_radar_fusion_fwd(const tc_head_weights* packed_view, const float* hs_last
     re.kv[r] = h.kv3[r];
   }
   re.radar_feat = h.radar_feat;
-  TC_TRY(launch_radar_encode(re, s));
+  if (!opt.reuse_radar_kv) TC_TRY(launch_radar_encode(re, s));
   RadarChainArgs rc;
   rc.qf = hs_last; rc.ref_last = ref_last; rc.box_m = prev_box; rc.tokens = radar_tokens;
   rc.RI = w->radar_in_dims;

@@ -240,7 +240,7 @@ def decoder_layer_tail(packed_layer, packed_next_in_proj, feats_nhwc, attn_o, x_
 
 
 def radar_fusion(head, hs_last, ref_last, prev_box, tokens, pad_mult, first_layer=0,
-                 num_layers=3, options=None):
+                 num_layers=3, options=None, ws=None):
     """The radar part of the head from given decoder outputs (tc_radar_fusion_fwd):
     encoders + fusion layers [first_layer, first_layer + num_layers).  Returns
     (all_cls [3,B,Q,ncls], all_box [3,B,Q,code], hits [3,B,Q]); only the slices of
@@ -253,7 +253,8 @@ def radar_fusion(head, hs_last, ref_last, prev_box, tokens, pad_mult, first_laye
     for n, t in (('hs_last', hs_last), ('prev_box', prev_box), ('tokens', tokens)):
         _chk(t, n)
     nbytes = L.lib().tc_head_workspace_bytes(C.byref(pv), B, T)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    if ws is None:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     cls = torch.full((3, B, Q, head.cls_out_channels), float('nan'), dtype=torch.float32, device=dev)
     box = torch.full((3, B, Q, head.code_size), float('nan'), dtype=torch.float32, device=dev)
     hits = torch.full((3, B, Q), -1, dtype=torch.int32, device=dev)

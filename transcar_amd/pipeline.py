@@ -14,6 +14,15 @@ Each lane owns a captured graph (optional NCHW -> NHWC hand-off + head forward
 pipeline) writes into, and its own head workspace
 (``Detr3DHead.forward_nhwc(lane=i)``); the weights are shared.
 
+Frames per launch: with ``frames_per_launch = P > 1`` a lane's graph processes P
+frames in ONE launch sequence (its static inputs are batch-P tensors, frame j of
+the lane is slot j).  The caller still hands over one frame at a time
+(``submit``); the lane is replayed when its P slots are filled.  Two frames
+share every weight fragment the row chains stream (8-row tiles: each weight
+register feeds two MFMAs), which at one frame per launch is what binds them
+(DESIGN.md section 5): 2 frames per launch x 3 lanes give ~1.35x the frames/s
+of 1 x 3 at twice the latency.
+
 Ordering contract (the producer works on the CURRENT stream):
   * ``launch(i)`` makes lane i's stream wait for everything enqueued so far on
     the current stream, so inputs written there (FPN kernels, H2D copies) are
@@ -47,6 +56,12 @@ class FramePipeline:
         from .detr3d_head import head_options
         self.head, self.decode = head, decode
         self.inputs = list(static_inputs)
+        #: frames per launch = the batch size of the lanes' static inputs
+        self.frames_per_launch = int(self.inputs[0]['l2i'].shape[0])
+        if any(int(i['l2i'].shape[0]) != self.frames_per_launch for i in self.inputs):
+            raise ValueError('all lanes must have the same number of frame slots')
+        self._filled = [0] * len(self.inputs)
+        self._fill_lane = 0
         self.streams = [torch.cuda.Stream() for _ in self.inputs]
         self.done = [torch.cuda.Event() for _ in self.inputs]
         self.options = options if options is not None else head_options(tile_rows=tile_rows)
@@ -112,37 +127,81 @@ class FramePipeline:
             self.done[i].record(s)
         return i, self.outputs[i]
 
+    def submit(self, write=None):
+        """Hand over ONE frame: it takes the next free slot (lane, slot) of the lane being filled;
+        ``write(pipe, lane, slot)`` (optional) refills that slot's static inputs (e.g.
+        ``pipe.write_inputs(lane, slot=slot, ...)``); when the lane's ``frames_per_launch`` slots
+        are filled the lane is replayed and the next lane starts filling.  Returns
+        (lane, slot, launched)."""
+        lane, slot = self._fill_lane, self._filled[self._fill_lane]
+        if write is not None:
+            write(self, lane, slot)
+        self._filled[lane] = slot + 1
+        launched = False
+        if self._filled[lane] == self.frames_per_launch:
+            self.launch(lane)
+            self._filled[lane] = 0
+            self._fill_lane = (lane + 1) % self.lanes
+            launched = True
+        return lane, slot, launched
+
+    def flush(self):
+        """Replay a partly filled lane (its unfilled slots hold stale frames whose results the
+        caller ignores).  Returns the number of valid slots launched (0: nothing pending)."""
+        lane = self._fill_lane
+        n = self._filled[lane]
+        if n:
+            self.launch(lane)
+            self._filled[lane] = 0
+            self._fill_lane = (lane + 1) % self.lanes
+        return n
+
     def producer_wait(self, lane):
         """The current stream waits until lane's last replay has finished: after this, work
         enqueued on the current stream may overwrite the lane's static inputs."""
         torch.cuda.current_stream().wait_event(self.done[lane])
 
-    def write_inputs(self, lane, nhwc=None, nchw=None, l2i=None, tokens=None, pad_mult=None):
+    def write_inputs(self, lane, nhwc=None, nchw=None, l2i=None, tokens=None, pad_mult=None, slot=None):
         """Refill a lane's static inputs in place from the current stream (device tensors or
         pinned host tensors: ``copy_`` is asynchronous), ordered after the lane's previous
-        replay.  tokens must have the captured shape and pad_mult (radar.pack_tokens(T=...))."""
+        replay.  tokens must have the captured shape and pad_mult (radar.pack_tokens(T=...)).
+        slot=None: the whole lane (tensors of the captured batch size); slot=j: ONE frame
+        (batch-1 tensors) into frame slot j of a ``frames_per_launch > 1`` lane."""
         inp = self.inputs[lane]
+        P = self.frames_per_launch
+        if slot is not None and not 0 <= slot < P:
+            raise TransCARHipError('slot %r of %d' % (slot, P))
         self.producer_wait(lane)
+
+        def view(dst):          # the part of a static tensor one frame slot owns (dim 0 = P or P * num_cams)
+            if slot is None:
+                return dst
+            n = dst.shape[0] // P
+            return dst[slot * n:(slot + 1) * n]
         for key, new in (('nhwc', nhwc), ('nchw', nchw)):
             if new is None:
                 continue
             if inp.get(key) is None or len(new) != len(inp[key]):
                 raise TransCARHipError('lane %d has no static %r inputs of %d levels' % (lane, key, len(new)))
             for dst, src in zip(inp[key], new):
+                dst = view(dst.reshape(-1, *dst.shape[-3:]))
+                src = src.reshape(-1, *src.shape[-3:])
                 if tuple(dst.shape) != tuple(src.shape):
                     raise TransCARHipError('%s level shape %s != captured %s' % (key, tuple(src.shape),
                                                                                  tuple(dst.shape)))
                 dst.copy_(src, non_blocking=True)
         if l2i is not None:
-            inp['l2i'].copy_(l2i, non_blocking=True)
+            view(inp['l2i']).copy_(l2i.reshape(-1, *inp['l2i'].shape[1:]), non_blocking=True)
         if tokens is not None:
-            if tuple(tokens.shape) != tuple(inp['tokens'].shape) or \
+            dst = view(inp['tokens'])
+            tokens = tokens.reshape(-1, *tokens.shape[-2:])
+            if tuple(tokens.shape) != tuple(dst.shape) or \
                     (pad_mult is not None and int(pad_mult) != int(inp['pad_mult'])):
                 raise TransCARHipError(
                     'tokens %s / pad_mult %s differ from the captured %s / %d: pack every frame with '
-                    'radar.pack_tokens(T=%d)' % (tuple(tokens.shape), pad_mult, tuple(inp['tokens'].shape),
+                    'radar.pack_tokens(T=%d)' % (tuple(tokens.shape), pad_mult, tuple(dst.shape),
                                                  inp['pad_mult'], inp['tokens'].shape[1]))
-            inp['tokens'].copy_(tokens, non_blocking=True)
+            dst.copy_(tokens, non_blocking=True)
 
     def wait(self, lane):
         self.streams[lane].synchronize()
