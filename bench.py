@@ -62,10 +62,11 @@ def parse(argv=None):
     ap.add_argument('--lanes', type=int, default=3,
                     help='frames in flight per GPU: one hipGraph + HIP stream each '
                          '(transcar_amd/pipeline.py); 1 = strictly one frame at a time')
-    ap.add_argument('--pair', type=int, default=1,
+    ap.add_argument('--pair', type=int, default=2,
                     help='frames per launch: the pipeline hands the head P consecutive frames (one per '
                          'step, the per-frame API is unchanged) as ONE launch sequence -- 8-row tiles, '
-                         'every streamed weight fragment feeds both frames.  1 = one frame per launch')
+                         'every streamed weight fragment feeds both frames.  1 = one frame per launch '
+                         '(the like-for-like latency figure `latency_ms_per_frame` is always measured that way)')
     ap.add_argument('--tile-rows', type=int, default=0, choices=[0, 4, 8, 16],
                     help='row-tile height of the fused chains in the frame pipeline (0 = automatic)')
     ap.add_argument('--no-cpu-baseline', action='store_true')

@@ -207,9 +207,9 @@ def freeze_like_train_py(head):
             p.requires_grad = False
 
 
-def g8_train_grads(ref):
+def g8_train_grads(ref, tag='tiny'):
     """One training iteration's gradients from the reference: Detr3DHead.forward (tiny
-    shapes, radar near the G5 centres) -> loss() -> sum of the six losses (mmdet
+    shapes -- or, tag 'res101', the ResNet-101 FPN shapes of BASELINE.json configs[2] -- radar near the G5 centres) -> loss() -> sum of the six losses (mmdet
     `_parse_losses`) -> backward, dropout off (eval mode), frozen groups as in
     tools/train.py:245-252.  Stored per trainable parameter: [sum, sum|.|, l2] in
     float64 and the first 16 entries."""
@@ -218,15 +218,15 @@ def g8_train_grads(ref):
     head.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     head.eval()
     freeze_like_train_py(head)
-    g5 = np.load(os.path.join(HERE, 'g5_head_tiny.npz'))
-    feats = synth.make_feats('tiny', seed=1, smooth=SMOOTH)
+    g5 = np.load(os.path.join(HERE, 'g5_head_%s.npz' % tag))
+    feats = synth.make_feats(tag, seed=1, smooth=SMOOTH)
     l2i = synth.make_lidar2img()
     frame = synth.make_radar_frame(seed=2, n_per_radar=51, centres=g5['radar_centres'])
     boxes, labels = synth.make_gt(seed=7, n=24)
     with torch.enable_grad():
         outs, cap, _ = run_head(head, feats, l2i, frame)
         d = np.abs(outs['all_cls_scores'].detach().numpy() - g5['all_cls_scores']).max()
-        assert d < 5e-4, d                      # same frame as fixture G5 (tiny)
+        assert d < 5e-4, d                      # same frame as fixture G5
         losses = head.loss([RH.GtBoxes(torch.from_numpy(boxes))], [torch.from_numpy(labels)], outs)
         total = sum(v for k, v in losses.items() if 'loss' in k)
         total.backward()
@@ -247,7 +247,7 @@ def g8_train_grads(ref):
         out[key + '__stats'] = np.array([g.sum(), g.abs().sum(), g.norm()], np.float64)
         out[key + '__head'] = g[:16].float().numpy()
         names.append(k)
-    save('g8_train_grads.npz', **out)
+    save('g8_train_grads.npz' if tag == 'tiny' else 'g8_train_grads_%s.npz' % tag, **out)
     print('g8: total loss', float(total), len(names), 'parameters with gradients,',
           sum(p.numel() for p in head.parameters() if p.requires_grad), 'trainable scalars')
 
@@ -262,6 +262,7 @@ def main():
     g4_radar_empty(head)
     g7_loss(ref)
     g8_train_grads(ref)
+    g8_train_grads(ref, 'res101')
 
 
 if __name__ == '__main__':

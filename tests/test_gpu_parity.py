@@ -112,6 +112,70 @@ def test_nchw_to_nhwc_roundtrip(T):
     assert yc.data_ptr() == xc.data_ptr() and torch.equal(yc.cpu(), y.cpu())
 
 
+def test_nchw_to_nhwc_levels_one_launch(T):
+    """All levels of a frame in one launch (tc_nchw_to_nhwc_levels): the 16-byte path (H*W % 4 == 0),
+    the scalar path (29x50, 15x25), channel counts that are not multiples of 64 / 4, ragged tiles."""
+    rng = np.random.RandomState(8)
+    for C_, shapes in ((256, [(116, 200), (58, 100), (29, 50), (15, 25)]), (40, [(8, 12), (5, 7)]),
+                       (7, [(4, 8), (3, 3)])):
+        xs = [torch.from_numpy(rng.standard_normal((2, 3, C_, h, w)).astype(np.float32)) for h, w in shapes]
+        ys = T.ops.to_nhwc_levels([gpu(x) for x in xs])
+        for x, y in zip(xs, ys):
+            assert torch.equal(y.cpu(), x.reshape(-1, *x.shape[2:]).permute(0, 2, 3, 1).contiguous())
+    # into preallocated outputs (a pipeline lane's static inputs)
+    outs = [torch.zeros_like(y) for y in ys]
+    got = T.ops.to_nhwc_levels([gpu(x) for x in xs], out=outs)
+    assert all(g_.data_ptr() == o_.data_ptr() and torch.equal(g_, y) for g_, o_, y in zip(got, outs, ys))
+
+
+class _StockFPN(torch.nn.Module):
+    """A plain torch.nn FPN with the reference's settings (CFG:43-50: start_level=1,
+    add_extra_convs='on_output', num_outs=4, relu_before_extra_convs): laterals on C3..C5,
+    3x3 output convs, one stride-2 extra conv on the last output."""
+
+    def __init__(self, in_channels=(64, 128, 256), out_channels=256):
+        super().__init__()
+        nn = torch.nn
+        self.lat = nn.ModuleList([nn.Conv2d(c, out_channels, 1) for c in in_channels])
+        self.out = nn.ModuleList([nn.Conv2d(out_channels, out_channels, 3, padding=1) for _ in in_channels])
+        self.extra = nn.Conv2d(out_channels, out_channels, 3, stride=2, padding=1)
+
+    def forward(self, xs):
+        lat = [l(x) for l, x in zip(self.lat, xs)]
+        for i in range(len(lat) - 1, 0, -1):
+            lat[i - 1] = lat[i - 1] + torch.nn.functional.interpolate(lat[i], size=lat[i - 1].shape[2:], mode='nearest')
+        outs = [o(x) for o, x in zip(self.out, lat)]
+        outs.append(self.extra(torch.relu(outs[-1])))
+        return outs
+
+
+def test_channels_last_fpn_feeds_the_head_zero_copy(T, head):
+    """a stock torch.nn FPN run in ``channels_last`` (MIOpen NHWC convolutions) hands
+    the head its maps without any transposition -- ops.to_nhwc_levels returns views of the very
+    same storage -- and the head's output equals, bit for bit, the reference hand-off (NCHW maps,
+    DET:62-66) of the same values through tc_nchw_to_nhwc_levels."""
+    torch.manual_seed(0)
+    fpn = _StockFPN().to(dev()).eval().to(memory_format=torch.channels_last)
+    N = 6
+    sizes = [(32, 48), (16, 24), (8, 12)]                      # C3..C5 of a small image
+    xs = [torch.randn(N, c, h, w, device=dev()).contiguous(memory_format=torch.channels_last)
+          for c, (h, w) in zip((64, 128, 256), sizes)]
+    feats_cl = fpn(xs)                                           # 4 levels [N,256,H,W]
+    assert all(f.is_contiguous(memory_format=torch.channels_last) and not f.is_contiguous() for f in feats_cl), \
+        'the FPN did not stay in channels_last'
+    nhwc = T.ops.to_nhwc_levels([f[None] for f in feats_cl])
+    for f, v in zip(feats_cl, nhwc):
+        assert v.data_ptr() == f.data_ptr() and v.shape == (N, f.shape[2], f.shape[3], 256)   # zero copy
+    frame = synth.make_radar_frame(seed=5, n_per_radar=20)
+    metas = synth.make_img_metas(1, radar=frame)
+    out_cl = head([f[None] for f in feats_cl], metas)
+    feats_nchw = [f.contiguous()[None] for f in feats_cl]        # what the reference's FPN returns
+    assert all(f.is_contiguous() for f in feats_nchw)
+    out_nchw = head(feats_nchw, metas)
+    for k in ('all_cls_scores', 'all_bbox_preds'):
+        assert torch.equal(out_cl[k], out_nchw[k]), k
+
+
 @pytest.mark.parametrize('shapes,smooth,atol', [
     ('tiny', None, 3e-5), ('res101', SMOOTH, 1e-4),
     # BASELINE.json configs[4]: VoVNet FPN levels (232x400 ... 29x50), 757 MB of maps
@@ -532,6 +596,47 @@ def test_frames_in_flight_equal_sequential(T, head):
     np.testing.assert_allclose(outs8['all_bbox_preds'].cpu().numpy(), want[1][1].cpu().numpy(), atol=2e-4, rtol=0)
     outs4, _ = bench.one_step(head, lanes[1])                 # per-call option: nothing process-wide changed
     assert torch.equal(outs4['all_bbox_preds'], want[1][1])
+
+
+def test_pipeline_pairs_frames_per_launch(T, head):
+    """frames_per_launch = 2: the caller still submits one frame at a time (per-slot input writes);
+    a lane is replayed when both of its slots are filled, flush() launches a half-filled lane.
+    Every frame's result equals its one-frame-per-launch result up to the rounding of 8- vs 4-row
+    tiles (same tolerance as test_head_batch_equals_singles)."""
+    import bench
+    from transcar_amd.pipeline import FramePipeline
+    nframes = 7
+    frames = [bench.make_inputs(head, dev(), 'tiny', 1, seed=51 + i) for i in range(nframes)]
+    want = []
+    for f in frames:
+        outs, dec = bench.one_step(head, f)
+        want.append((outs['all_bbox_preds'].clone(), outs['all_cls_scores'].clone()))
+    lanes = [bench.make_inputs(head, dev(), 'tiny', 2, seed=71 + i) for i in range(2)]
+    pipe = FramePipeline(head, lanes)
+    assert pipe.frames_per_launch == 2 and pipe.lanes == 2
+    got, where = {}, {}
+    launches = 0
+    for i, f in enumerate(frames):
+        def write(p_, lane, slot, f=f):
+            p_.write_inputs(lane, slot=slot, nhwc=f['nhwc'], l2i=f['l2i'], tokens=f['tokens'],
+                            pad_mult=f['pad_mult'])
+        lane, slot, launched = pipe.submit(write)
+        where[i] = (lane, slot)
+        launches += int(launched)
+        if launched or i == nframes - 1:
+            if not launched:
+                assert pipe.flush() == 1 and pipe.flush() == 0          # the odd last frame
+                launches += 1
+            outs, _ = pipe.outputs[lane]
+            with torch.cuda.stream(pipe.streams[lane]):
+                for j in [k for k, (l_, _) in where.items() if l_ == lane and k not in got]:
+                    s_ = where[j][1]
+                    got[j] = (outs['all_bbox_preds'][:, s_].clone(), outs['all_cls_scores'][:, s_].clone())
+    pipe.synchronize()
+    assert launches == 4 and len(got) == nframes
+    for i in range(nframes):
+        for a_, b_ in zip(got[i], want[i]):
+            assert frac_within(a_.cpu().numpy(), b_[:, 0].cpu().numpy(), 1e-4) > 0.998, i
 
 
 def test_pipeline_producer_rewrites_lane_inputs(T, head):

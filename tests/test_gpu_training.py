@@ -17,7 +17,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import transcar_oracle as O
-from test_training import check_grads_against_g8, g8_inputs, trainable
+from test_training import check_grads_against_g8, g8_inputs, g8_name, trainable
 from transcar_amd import configs, synth
 
 pytestmark = pytest.mark.gpu
@@ -229,8 +229,8 @@ def train_head(golden_dir):
     return h.to(dev()).freeze_decoder().set_dropout(0.0)
 
 
-def frame_inputs(golden_dir):
-    feats, l2i, frame, boxes, labels = g8_inputs(golden_dir)
+def frame_inputs(golden_dir, tag='tiny'):
+    feats, l2i, frame, boxes, labels = g8_inputs(golden_dir, tag)
     metas = synth.make_img_metas(1, l2i)
     metas[0]['radar'] = frame
     gt = torch.from_numpy(boxes).clone()
@@ -249,10 +249,13 @@ def test_train_forward_equals_eval_forward(A, golden_dir):
     assert float((t['all_bbox_preds'] - e['all_bbox_preds']).abs().max()) < 2e-4
 
 
-def test_training_iteration_gradients_match_reference(A, golden_dir):
-    g8 = np.load(os.path.join(golden_dir, 'g8_train_grads.npz'))
+@pytest.mark.parametrize('tag', ['tiny', 'res101'])
+def test_training_iteration_gradients_match_reference(A, golden_dir, tag):
+    """tag res101: BASELINE.json configs[2] at its full FPN shapes (every training test
+    ran at tiny shapes only)."""
+    g8 = np.load(os.path.join(golden_dir, g8_name(tag)))
     h = train_head(golden_dir).train()
-    feats, metas, gt, labels = frame_inputs(golden_dir)
+    feats, metas, gt, labels = frame_inputs(golden_dir, tag)
     outs = h(feats, metas)
     assert float((outs['all_cls_scores'].detach().cpu() - torch.from_numpy(g8['all_cls_scores'])).abs().max()) < 1e-3
     losses = h.loss([gt], [labels], outs)
@@ -328,14 +331,15 @@ def test_trainer_step_updates_flat_bucket_and_packed_weights(A, golden_dir):
     assert float(sum(last.values())) < first
 
 
-def test_fused_training_path_gradients_match_reference(A, golden_dir):
+@pytest.mark.parametrize('tag', ['tiny', 'res101'])
+def test_fused_training_path_gradients_match_reference(A, golden_dir, tag):
     """tc_radar_train_fwd / _bwd (the trainable stack as two C calls) against fixture G8
-    and against the per-operator autograd path on the same frame."""
+    (tiny and ResNet-101 FPN shapes) and against the per-operator autograd path on the same frame."""
     from transcar_amd import ops
     from transcar_amd.trainer import FusionTrainer
-    g8 = np.load(os.path.join(golden_dir, 'g8_train_grads.npz'))
+    g8 = np.load(os.path.join(golden_dir, g8_name(tag)))
     h = train_head(golden_dir)
-    feats, metas, gt, labels = frame_inputs(golden_dir)
+    feats, metas, gt, labels = frame_inputs(golden_dir, tag)
     nhwc = [ops.to_nhwc(f) for f in feats]
     l2i = ops.lidar2img_tensor(metas, dev())
     img_hw = metas[0]['img_shape'][0][:2]

@@ -137,9 +137,14 @@ def trainable(name):
     return not name.startswith(FROZEN)
 
 
-def g8_inputs(golden_dir):
-    g5 = np.load(os.path.join(golden_dir, 'g5_head_tiny.npz'))
-    feats = synth.make_feats('tiny', seed=1, smooth=(4, 6))
+def g8_name(tag='tiny'):
+    return 'g8_train_grads.npz' if tag == 'tiny' else 'g8_train_grads_%s.npz' % tag
+
+
+def g8_inputs(golden_dir, tag='tiny'):
+    """tag: 'tiny' FPN shapes, or 'res101' = the ResNet-101 shapes of BASELINE.json configs[2]"""
+    g5 = np.load(os.path.join(golden_dir, 'g5_head_%s.npz' % tag))
+    feats = synth.make_feats(tag, seed=1, smooth=(4, 6))
     l2i = synth.make_lidar2img()
     frame = synth.make_radar_frame(seed=2, n_per_radar=51, centres=g5['radar_centres'])
     boxes, labels = synth.make_gt(seed=7, n=24)
@@ -169,9 +174,10 @@ def check_grads_against_g8(grads, g8, rtol, what):
     return checked
 
 
-def test_oracle_backward_matches_reference(golden_dir):
-    g8 = np.load(os.path.join(golden_dir, 'g8_train_grads.npz'))
-    feats, l2i, frame, boxes, labels = g8_inputs(golden_dir)
+@pytest.mark.parametrize('tag', ['tiny', 'res101'])
+def test_oracle_backward_matches_reference(golden_dir, tag):
+    g8 = np.load(os.path.join(golden_dir, g8_name(tag)))
+    feats, l2i, frame, boxes, labels = g8_inputs(golden_dir, tag)
     sd = O.to_torch_sd(synth.make_state_dict(3))
     for k, v in sd.items():
         if trainable(k):
