@@ -155,6 +155,25 @@ int tc_nchw_to_nhwc(const float* src, float* dst, int n_img, int C, int H, int W
 int tc_nchw_to_nhwc_levels(const float* const* src, float* const* dst, int num_levels,
                            int n_img, int C, const int* H, const int* W, tc_stream_t stream);
 
+/* ---- radar ingest on the device (HEAD:301-536; numpy on the main thread in the reference) ----
+ * Raw devkit rows of ONE sample -> the [T,36] float32 token matrix tc_head_forward reads.
+ *   raw        device [N,18] float64, point-major: the 18 fields of RadarPointCloud (x y z dyn_prop
+ *              id rcs vx vy vx_comp vy_comp is_quality_valid ambig_state x_rms y_rms invalid_state
+ *              pdh0 vx_rms vy_rms), the radars concatenated in the reference's channel order
+ *              (RADAR_FRONT, _FRONT_LEFT, _FRONT_RIGHT, _BACK_LEFT, _BACK_RIGHT, HEAD:310-451)
+ *   times      device [N] float64 sweep time lags (from_file_multisweep's second result)
+ *   chan_start HOST [num_chan+1]: rows chan_start[c] .. chan_start[c+1] belong to radar c
+ *   radar_rot  HOST [num_chan,9] row-major rotation radar -> ego of each radar's calibrated sensor
+ *   lidar_rot  HOST [9] rotation lidar -> ego (applied transposed, HEAD:317-327)
+ *   point_range HOST [6] (HEAD:304: -51.2 -51.2 -5 51.2 51.2 3), strict inequalities
+ *   tokens     device [T,36]: kept points in order, then rows of 500.0 (HEAD:523-530)
+ *   count      device [1] (may be NULL): number of kept points; > T-1 means the frame does not fit
+ *              T tokens (rows beyond T are dropped; the reference keeps 1500)
+ * With tokens [T,36] the head is called with pad_mult = 1500 - T + 1. */
+int tc_radar_build_tokens(const double* raw, const double* times, const int* chan_start, int num_chan,
+                          const double* radar_rot, const double* lidar_rot, const float* point_range,
+                          float* tokens, int T, int* count, tc_stream_t stream);
+
 /* ---- operators, one per reference call site ---- */
 
 /* nn.Linear (+ optional fused pieces).  y[M,N] = act((x (+x2)) W^T + b) (+res)

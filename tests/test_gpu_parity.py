@@ -304,6 +304,63 @@ def test_radar_xattn_teacher_forced(T, sd, head):
     assert int(rows.numel()) == int(gold['Lq'][0])
 
 
+@pytest.mark.parametrize('case', ['g5', 'ragged', 'empty', 'out_of_range', 'overflow'])
+def test_radar_ingest_on_device(T, case):
+    """tc_radar_build_tokens: raw devkit rows -> [T,36] tokens in one launch, against
+    (i) the rows the REFERENCE built from the same raw frame (fixtures G5 / G4: HEAD:301-521 run
+    unmodified by tests/golden/make_golden.py) and (ii) the host builder transcar_amd/radar.py.
+    Columns without arithmetic (coordinates, ids, states, one-hots, time offsets) must be bit
+    equal; the six rotated-velocity columns are float64 products rounded to float32 once on either
+    side: at most 1 ulp(float32) apart."""
+    from transcar_amd import radar as R
+    gold_rows = None
+    if case == 'g5':
+        gold, frame = _radar_inputs('tiny')
+        gold_rows = gold['radar_tokens']
+    elif case == 'ragged':
+        frame = synth.make_radar_frame(seed=5, n_per_radar=[7, 0, 3, 0, 12])
+        gold_rows = g('g4_radar_ragged.npz')['radar_tokens']
+    elif case == 'empty':
+        frame = synth.make_radar_frame(seed=5, n_per_radar=[0, 0, 0, 0, 0])
+    elif case == 'out_of_range':
+        frame = synth.make_radar_frame(seed=9, n_per_radar=[40, 13, 0, 64, 70])
+        rng = np.random.RandomState(3)
+        for chan in R.RADAR_CHANNELS:                       # push a third of the points outside HEAD:304's box
+            p = frame['points'][chan]
+            if p.shape[1]:
+                out = rng.rand(p.shape[1]) < 0.33
+                p[rng.randint(0, 3), out] = 77.7
+        frame['points'][R.RADAR_CHANNELS[0]][0, 0] = 51.2    # exactly on the bound: strict inequality drops it
+    else:
+        frame = synth.make_radar_frame(seed=4, n_per_radar=[90, 80, 70, 60, 50])    # 350 points > T - 1
+    Tn = 256
+    want_rows = R.build_radar_features(frame)
+    tokens, count, pad_mult = T.ops.radar_build_tokens(frame, Tn, dev())
+    assert pad_mult == 1500 - Tn + 1 and tokens.shape == (1, Tn, 36)
+    n = int(count.item())
+    assert n == want_rows.shape[0]
+    got = tokens[0].cpu().numpy()
+    k = min(n, Tn)
+    want = np.full((Tn, 36), 500.0, np.float32)
+    want[:k] = want_rows[:k].astype(np.float32)
+    exact = [c for c in range(36) if c not in (9, 10, 11, 12, 13, 14)]
+    np.testing.assert_array_equal(got[:, exact], want[:, exact])
+    vel = [9, 10, 11, 12, 13, 14]
+    ulp = np.spacing(np.abs(want[:, vel]).astype(np.float32))
+    assert np.all(np.abs(got[:, vel] - want[:, vel]) <= ulp)
+    if gold_rows is not None:                               # the reference's own rows
+        assert gold_rows.shape[0] == n
+        np.testing.assert_array_equal(got[:n, exact], gold_rows[:, exact].astype(np.float32))
+        assert np.all(np.abs(got[:n, vel] - gold_rows[:, vel]) <= np.spacing(np.abs(gold_rows[:, vel]).astype(np.float32)))
+    if case == 'overflow':
+        assert n > Tn - 1                                   # the caller sees that the frame did not fit
+    elif case != 'empty':
+        # and the head consumes them: same result as the host-built tokens
+        tok_np, pm = R.pack_tokens([want_rows], T=Tn)
+        assert pm == pad_mult
+        np.testing.assert_array_equal(got[:, exact], tok_np[0][:, exact])
+
+
 def test_radar_pad_token_multiplicity(T, head):
     """A query parked on the pad location (500,500) must see all pad tokens:
     folding them into one token with multiplicity equals materialising them."""

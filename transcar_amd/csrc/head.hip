@@ -338,6 +338,13 @@ int tc_nchw_to_nhwc_levels(const float* const* src, float* const* dst, int num_l
   return launch_nchw_to_nhwc_levels(src, dst, num_levels, n_img, C, H, W, as_stream(stream));
 }
 
+int tc_radar_build_tokens(const double* raw, const double* times, const int* chan_start, int num_chan,
+                          const double* radar_rot, const double* lidar_rot, const float* point_range,
+                          float* tokens, int T, int* count, tc_stream_t stream) {
+  return launch_radar_ingest(raw, times, chan_start, num_chan, radar_rot, lidar_rot, point_range, tokens, T,
+                             count, as_stream(stream));
+}
+
 int tc_linear_fwd(const float* x, const float* x2, const float* w, const float* b, const float* res,
                   float* y, int M, int K, int N, int act, tc_stream_t stream) {
   tc_linear lw{w, b};

@@ -180,6 +180,11 @@ int launch_nchw_to_nhwc(const float* src, float* dst, int n_img, int C, int H, i
 int launch_nchw_to_nhwc_levels(const float* const* src, float* const* dst, int num_levels, int n_img,
                                int C, const int* H, const int* W, hipStream_t s);
 
+// ---- radar_ingest.hip ------------------------------------------------------
+int launch_radar_ingest(const double* raw, const double* times, const int* chan_start_host, int num_chan,
+                        const double* radar_rot_host, const double* lidar_rot_host,
+                        const float* point_range_host, float* tokens, int T, int* count, hipStream_t s);
+
 // ---- decode.hip ------------------------------------------------------------
 int launch_box_decode(const float* cls, const float* box, int B, int Q, int ncls, int code,
                       int max_num, const float* pcr6_host, float* boxes, float* scores, int* labels,

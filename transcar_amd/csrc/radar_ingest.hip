@@ -1,0 +1,133 @@
+// Radar ingest on the device: the reference builds the 36-feature rows
+// in numpy on the main thread inside Detr3DHead.forward (HEAD:301-536).  Here the raw devkit rows
+// of a sample (18 float64 fields per point, five radars concatenated in RADAR_CHANNELS order) are
+// uploaded as they are and ONE workgroup turns them into the [T, 36] float32 token matrix the
+// fusion chains read: velocity rotation radar -> ego -> lidar frame (HEAD:317-327), time offsets
+// relative to each radar's newest sweep (HEAD:453-455), one-hot state columns (HEAD:499-510),
+// the point-range filter (HEAD:304, 512-521) as an order-preserving compaction, float32
+// conversion and the 500.0 padding (HEAD:523-530).  All arithmetic in float64 like the reference,
+// rounded to float32 once.  With a fixed T this makes the radar input of a frame pipeline lane a
+// pure device-side refill (pad_mult = 1500 - T + 1 does not depend on the frame).
+#include "kernels.hpp"
+
+namespace tc {
+
+namespace {
+
+constexpr int RI_RAW = 18, RI_OUT = 36, MAX_CHAN = 8, NT = 256;
+
+struct IngestK {
+  const double* raw;        // [N, 18] point-major
+  const double* times;      // [N]
+  int chan_start[MAX_CHAN + 1];
+  int num_chan, N, T;
+  double rot_radar[MAX_CHAN][9];   // radar -> ego, row-major
+  double rot_ref[9];               // lidar -> ego (applied transposed)
+  double lo[3], hi[3];
+  float* tokens;            // [T, 36]
+  int* count;               // [1]
+};
+
+__device__ __forceinline__ unsigned long long ord(double x) {   // order-preserving map double -> u64
+  const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double unord(unsigned long long u) {
+  const unsigned long long b = (u >> 63) ? (u & 0x7fffffffffffffffull) : ~u;
+  return __longlong_as_double((long long)b);
+}
+
+__global__ __launch_bounds__(NT) void radar_ingest_kernel(IngestK k) {
+  __shared__ unsigned long long tmax[MAX_CHAN];
+  __shared__ int wave_cnt[NT / 64];
+  __shared__ int base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < MAX_CHAN) tmax[tid] = 0ull;                       // ord(x) > 0 for every double
+  if (tid == 0) base = 0;
+  __syncthreads();
+  // newest sweep time of every radar (HEAD:453-455: times - max(times))
+  for (int c = 0; c < k.num_chan; ++c) {
+    unsigned long long m = 0ull;
+    for (int i = k.chan_start[c] + tid; i < k.chan_start[c + 1]; i += NT) m = max(m, ord(k.times[i]));
+    if (m) atomicMax(&tmax[c], m);
+  }
+  __syncthreads();
+  for (int i0 = 0; i0 < k.N; i0 += NT) {
+    const int i = i0 + tid;
+    bool keep = false;
+    const double* r = k.raw + (size_t)min(i, k.N - 1) * RI_RAW;
+    if (i < k.N)
+      keep = r[0] > k.lo[0] && r[1] > k.lo[1] && r[2] > k.lo[2] && r[0] < k.hi[0] && r[1] < k.hi[1] && r[2] < k.hi[2];
+    const unsigned long long bal = __ballot(keep);
+    if (lane == 0) wave_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+    off += __popcll(bal & ((1ull << lane) - 1ull));
+    if (keep && off < k.T) {
+      int c = 0;
+      while (c + 1 < k.num_chan && i >= k.chan_start[c + 1]) ++c;
+      const double* R = k.rot_radar[c];
+      const double t = k.times[i] - unord(tmax[c]);
+      float* o = k.tokens + (size_t)off * RI_OUT;
+      // x y z id rcs is_quality_valid invalid_state (HEAD:499)
+      o[0] = (float)r[0]; o[1] = (float)r[1]; o[2] = (float)r[2]; o[3] = (float)r[4]; o[4] = (float)r[5];
+      o[5] = (float)r[10]; o[6] = (float)r[14];
+      o[7] = (float)t; o[8] = (float)t;
+      double vxy[2][2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {            // s = 0: compensated velocity (fields 8, 9); 1: raw (6, 7)
+        const double vx = r[s == 0 ? 8 : 6], vy = r[s == 0 ? 9 : 7];
+        double e[3];                            // radar -> ego, z component of the input is 0
+#pragma unroll
+        for (int a = 0; a < 3; ++a) e[a] = fma(R[3 * a + 2], 0.0, fma(R[3 * a + 1], vy, R[3 * a + 0] * vx));
+#pragma unroll
+        for (int a = 0; a < 2; ++a)             // ego -> lidar: rot_ref^T
+          vxy[s][a] = fma(k.rot_ref[6 + a], e[2], fma(k.rot_ref[3 + a], e[1], k.rot_ref[a] * e[0]));
+      }
+      o[9] = (float)(vxy[0][0] * t); o[10] = (float)(vxy[0][1] * t);
+      o[11] = (float)vxy[0][0]; o[12] = (float)vxy[0][1];
+      o[13] = (float)vxy[1][0]; o[14] = (float)vxy[1][1];
+      const int dyn = (int)r[3], amb = (int)r[11], pdh = (int)r[15];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[15 + j] = j == dyn ? 1.0f : 0.0f;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) o[23 + j] = j == amb ? 1.0f : 0.0f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[28 + j] = j == pdh ? 1.0f : 0.0f;
+    }
+    __syncthreads();
+    if (tid == 0) { int s = base; for (int w = 0; w < NT / 64; ++w) s += wave_cnt[w]; base = s; }
+    __syncthreads();
+  }
+  // pad tokens (HEAD:526-530)
+  const int filled = min(base, k.T);
+  for (int j = filled * RI_OUT + tid; j < k.T * RI_OUT; j += NT) k.tokens[j] = 500.0f;
+  if (tid == 0 && k.count != nullptr) k.count[0] = base;
+}
+
+}  // namespace
+
+int launch_radar_ingest(const double* raw, const double* times, const int* chan_start_host, int num_chan,
+                        const double* radar_rot_host, const double* lidar_rot_host,
+                        const float* point_range_host, float* tokens, int T, int* count, hipStream_t s) {
+  TC_REQUIRE(num_chan >= 1 && num_chan <= MAX_CHAN, "radar_ingest: num_chan=%d (1..%d)", num_chan, MAX_CHAN);
+  TC_REQUIRE(tokens != nullptr && T >= 1 && chan_start_host != nullptr && radar_rot_host != nullptr &&
+                 lidar_rot_host != nullptr && point_range_host != nullptr, "radar_ingest: null argument");
+  IngestK k;
+  k.raw = raw; k.times = times; k.num_chan = num_chan; k.T = T; k.tokens = tokens; k.count = count;
+  for (int c = 0; c <= MAX_CHAN; ++c) k.chan_start[c] = chan_start_host[c <= num_chan ? c : num_chan];
+  TC_REQUIRE(k.chan_start[0] == 0, "radar_ingest: chan_start[0] must be 0");
+  for (int c = 0; c < num_chan; ++c)
+    TC_REQUIRE(k.chan_start[c + 1] >= k.chan_start[c], "radar_ingest: chan_start must ascend");
+  k.N = k.chan_start[num_chan];
+  TC_REQUIRE(k.N == 0 || (raw != nullptr && times != nullptr), "radar_ingest: null points");
+  for (int c = 0; c < MAX_CHAN; ++c)
+    for (int j = 0; j < 9; ++j) k.rot_radar[c][j] = c < num_chan ? radar_rot_host[c * 9 + j] : 0.0;
+  for (int j = 0; j < 9; ++j) k.rot_ref[j] = lidar_rot_host[j];
+  for (int j = 0; j < 3; ++j) { k.lo[j] = (double)point_range_host[j]; k.hi[j] = (double)point_range_host[3 + j]; }
+  hipLaunchKernelGGL(radar_ingest_kernel, dim3(1), dim3(NT), 0, s, k);
+  return check_launch("radar_ingest");
+}
+
+}  // namespace tc

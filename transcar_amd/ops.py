@@ -287,6 +287,48 @@ def radar_gated_xattn(mha, query, centre_xy, box, radar_feat, radar_xy,
     return out, hits
 
 
+def radar_raw_arrays(frame):
+    """Raw radar of one sample (transcar_amd/radar.py layout) -> what tc_radar_build_tokens
+    takes: (raw [N,18] float64, times [N] float64, chan_start [6], radar_rot [5,9], lidar_rot [9]),
+    all numpy / host.  The only arithmetic here is the quaternion -> rotation matrix conversion."""
+    from . import radar as R
+    raws, times, start = [], [], [0]
+    for chan in R.RADAR_CHANNELS:
+        p = np.asarray(frame['points'][chan], dtype=np.float64)          # [18,n]
+        t = np.asarray(frame['times'][chan], dtype=np.float64).reshape(-1)
+        raws.append(p.T)
+        times.append(t)
+        start.append(start[-1] + p.shape[1])
+    raw = np.ascontiguousarray(np.concatenate(raws, 0)) if start[-1] else np.zeros((0, 18))
+    rr = np.stack([R.quaternion_rotation_matrix(frame['radar_rot'][c]).reshape(9) for c in R.RADAR_CHANNELS])
+    lr = R.quaternion_rotation_matrix(frame['lidar_rot']).reshape(9)
+    return raw, np.concatenate(times) if start[-1] else np.zeros(0), np.asarray(start, np.int32), rr, lr
+
+
+def radar_build_tokens(frame, T, device, out=None, point_range=None):
+    """Radar ingest of one sample on the device (tc_radar_build_tokens, HEAD:301-536): the raw
+    rows go up as they are (H2D of N x 19 float64), one launch writes the [T,36] token matrix.
+    Returns (tokens [1,T,36] -- ``out`` when given, e.g. a pipeline lane's static tensor --,
+    count: int32 device tensor with the number of points kept by the range filter,
+    pad_mult = 1500 - T + 1)."""
+    from . import radar as R
+    raw, times, start, rr, lr = radar_raw_arrays(frame)
+    n = int(start[-1])
+    raw_d = torch.from_numpy(raw).to(device, non_blocking=True) if n else None
+    times_d = torch.from_numpy(times).to(device, non_blocking=True) if n else None
+    if out is None:
+        out = torch.empty((1, T, R.NUM_FEATURES), dtype=torch.float32, device=device)
+    if tuple(out.shape[-2:]) != (T, R.NUM_FEATURES) or out.numel() != T * R.NUM_FEATURES or not out.is_contiguous():
+        raise L.TransCARHipError('out must be a contiguous [1,%d,%d] tensor' % (T, R.NUM_FEATURES))
+    count = torch.zeros(1, dtype=torch.int32, device=device)
+    pr = (C.c_float * 6)(*[float(v) for v in (point_range or R.POINT_RANGE)])
+    L.check(L.lib().tc_radar_build_tokens(
+        _p(raw_d), _p(times_d), start.ctypes.data_as(C.POINTER(C.c_int)), len(R.RADAR_CHANNELS),
+        rr.ctypes.data_as(C.POINTER(C.c_double)), lr.ctypes.data_as(C.POINTER(C.c_double)), pr,
+        _p(out), int(T), _p(count), _stream()), 'tc_radar_build_tokens')
+    return out, count, R.NUM_RADAR_TOKENS - T + 1
+
+
 def box_decode_topk(cls_scores, bbox_preds, post_center_range, max_num=300):
     """NMSFreeCoder.decode_single + z-shift (CODER:39-90, HEAD:1018) for a
     batch: fixed-size outputs + a validity mask."""
