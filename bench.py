@@ -70,6 +70,9 @@ def parse(argv=None):
     ap.add_argument('--tile-rows', type=int, default=0, choices=[0, 4, 8, 16],
                     help='row-tile height of the fused chains in the frame pipeline (0 = automatic)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true',
+                    help='skip the per-kernel timing replays (the PMC passes of tools/profile_round.sh: '
+                         'only the launches of real frames are to be counted)')
     ap.add_argument('--unfused', action='store_true',
                     help='operator-by-operator launches instead of the fused row chains')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
@@ -785,13 +788,14 @@ def main(argv=None):
             pipe1 = pipe if pipe.frames_per_launch == args.batch else FramePipeline(head, [inp])
             line['single_lane'] = single_lane(pipe1, args)
             line['latency_ms_per_frame'] = line['single_lane']['ms_per_frame_synced']
-        # the dominant kernel as the timed region launches it (frames_per_launch frames per launch)
-        line['roofline'] = roofline(head, pipe.inputs[0] if pipe is not None else inp, dev)
-        line['roofline']['frames_per_launch'] = 1 if pipe is None else pipe.frames_per_launch
-        # every kernel of the path together, at the measured whole-job rate
-        pf = line['roofline']['path_flop_per_frame']
-        line['roofline']['path_achieved_tflops'] = pf * line['value'] / world / 1e12
-        line['roofline']['path_frac'] = line['roofline']['path_achieved_tflops'] / line['roofline']['peak']
+        if not args.no_roofline:
+            # the dominant kernel as the timed region launches it (frames_per_launch frames per launch)
+            line['roofline'] = roofline(head, pipe.inputs[0] if pipe is not None else inp, dev)
+            line['roofline']['frames_per_launch'] = 1 if pipe is None else pipe.frames_per_launch
+            # every kernel of the path together, at the measured whole-job rate
+            pf = line['roofline']['path_flop_per_frame']
+            line['roofline']['path_achieved_tflops'] = pf * line['value'] / world / 1e12
+            line['roofline']['path_frac'] = line['roofline']['path_achieved_tflops'] / line['roofline']['peak']
         if world == 1:
             if pipe is not None:
                 line['with_input_delivery'] = producer_side_run(pipe, args)

@@ -165,13 +165,14 @@ int tc_nchw_to_nhwc_levels(const float* const* src, float* const* dst, int num_l
  *   chan_start HOST [num_chan+1]: rows chan_start[c] .. chan_start[c+1] belong to radar c
  *   radar_rot  HOST [num_chan,9] row-major rotation radar -> ego of each radar's calibrated sensor
  *   lidar_rot  HOST [9] rotation lidar -> ego (applied transposed, HEAD:317-327)
- *   point_range HOST [6] (HEAD:304: -51.2 -51.2 -5 51.2 51.2 3), strict inequalities
+ *   point_range HOST [6] float64 (HEAD:304: -51.2 -51.2 -5 51.2 51.2 3), strict inequalities in
+ *              float64 as in the reference (a point at exactly 51.2 is dropped)
  *   tokens     device [T,36]: kept points in order, then rows of 500.0 (HEAD:523-530)
  *   count      device [1] (may be NULL): number of kept points; > T-1 means the frame does not fit
  *              T tokens (rows beyond T are dropped; the reference keeps 1500)
  * With tokens [T,36] the head is called with pad_mult = 1500 - T + 1. */
 int tc_radar_build_tokens(const double* raw, const double* times, const int* chan_start, int num_chan,
-                          const double* radar_rot, const double* lidar_rot, const float* point_range,
+                          const double* radar_rot, const double* lidar_rot, const double* point_range,
                           float* tokens, int T, int* count, tc_stream_t stream);
 
 /* ---- operators, one per reference call site ---- */

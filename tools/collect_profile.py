@@ -82,10 +82,12 @@ def prog_label(kernel_name):
     m = re.search(r'chain_dual_kernel<(\d+), (\d+), (\d+)>', kernel_name)
     if m:
         return 'chain_dual_kernel(decoder layer + radar encoder half %s)' % ('A' if m.group(3) == '4' else 'B')
-    m = re.search(r'chain_kernel<(\d+), (\d+)>', kernel_name)
+    m = re.search(r'chain_kernel<(\d+), (\d+)(?:, (\w+))?>', kernel_name)
     if m:
         return 'chain_kernel(%s)' % {'0': 'prologue', '1': 'decoder layer', '2': 'radar encoders',
-                                     '3': 'radar'}.get(m.group(2), 'program ' + m.group(2))
+                                     '3': 'radar fusion'}.get(m.group(2), 'program ' + m.group(2))
+    if 'self_attn_kernel' in kernel_name:
+        return 'self_attn_kernel'
     return short(kernel_name)
 
 
@@ -96,7 +98,7 @@ def main():
     os.makedirs(dst, exist_ok=True)
 
     lines = []
-    for f in ('bench.json', 'bench_b2.json', 'bench_b4.json'):
+    for f in ('bench.json', 'bench_pair1.json', 'bench_pair4.json', 'bench_b2.json', 'bench_b4.json'):
         p = os.path.join(src, f)
         if os.path.exists(p):
             for ln in open(p):
@@ -123,9 +125,10 @@ def main():
         if 'Grid_Size' not in r:
             r['Grid_Size'] = str(int(r['Grid_Size_X']) * int(r['Grid_Size_Y']) * int(r['Grid_Size_Z']))
     rows.sort(key=lambda r: int(r['Dispatch_Id']))
-    label_chain(rows)
+    for r in rows:
+        r['K'] = prog_label(r['Kernel_Name'])
     dec = [i for i, r in enumerate(rows) if 'box_decode' in r['Kernel_Name']]
-    out = ['# one frame of `bench.py` (hipGraph replay) from rocprofv3 --kernel-trace on MI355X; us',
+    out = ['# one replay of `bench.py --lanes 1` (hipGraph; default: 2 frames per launch sequence) from rocprofv3 --kernel-trace on MI355X; us',
            '# %-44s %10s %10s %10s' % ('kernel', 'grid', 'start', 'dur')]
     if len(dec) >= 2:
         a, b = dec[-2] + 1, dec[-1] + 1
@@ -179,55 +182,53 @@ def main():
             lo.append('%-46s %10s  n=%-6d avg %8.1f us' % (k[:46], g, len(v), sum(v) / len(v)))
         open(os.path.join(dst, name + '_lanes_trace.txt'), 'w').write('\n'.join(lo) + '\n')
 
-    # PMC: KB per launch per (kernel, grid)
-    pmc = {}
-    for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
-        d = 'pmc_fetch' if ctr == 'FETCH_SIZE' else 'pmc_write'
-        try:
-            f = one(os.path.join(src, d, '*', '*counter_collection.csv'))
-        except SystemExit:
-            continue
-        acc = defaultdict(list)
-        crow = [r for r in csv.DictReader(open(f)) if r['Counter_Name'] == ctr]
-        crow.sort(key=lambda r: int(r['Dispatch_Id']))
-        label_chain(crow)
-        for r in crow:
-            acc[r['K']].append(float(r['Counter_Value']))
-        for k, v in acc.items():
-            pmc.setdefault(k, {})[ctr] = sum(v) / len(v)
-    # name the launches the bench quotes; decoder chain = the chain_kernel grid launched 6x / frame
+    # PMC passes (one counter per run, kernel-trace only; `bench.py --no-graph --no-roofline --batch B`:
+    # B = 2 is the launch shape of the default bench command, 2 frames per launch), per launch and
+    # kernel; kernels are told apart by their template arguments (prog_label)
     res = OrderedDict()
-    res['_comment'] = ('rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, kernel-trace only) of '
-                       '`bench.py --no-graph --steps 5`, MI355X. KB per launch as reported; traffic_bytes = '
-                       '(2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE tallies 64 B per 128-B request, '
-                       'MI355X_MICROARCH.md, HBM section).')
-    for k, v in sorted(pmc.items()):
-        nm = 'self_attn_kernel' if k.startswith('self_attn_kernel') else k
-        if nm.startswith('at::') or nm.startswith('__amd'):
-            continue
-        fk, wk = v.get('FETCH_SIZE', 0.0), v.get('WRITE_SIZE', 0.0)
-        res[nm] = {'fetch_kb': round(fk, 1), 'write_kb': round(wk, 1),
-                   'traffic_bytes': int((2 * fk + wk) * 1024)}
+    res['_comment'] = ('rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of '
+                       '`bench.py --no-graph --no-roofline --batch B --steps 5`, MI355X; second key = B, the frames '
+                       'per launch.  KB per launch as reported; traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 '
+                       '(gfx950: FETCH_SIZE tallies 64 B per 128-B request, MI355X_MICROARCH.md, HBM section).')
+    out_m = OrderedDict()
+    out_m['_comment'] = ('rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES of the same command; second key = '
+                         'frames per launch.  The counter sums matrix-pipe busy cycles over the 1024 SIMDs (8 per '
+                         'v_mfma_f32_4x4x1, 32 per 16x16x4 f32); utilisation = busy / (1024 * duration * 2.4 GHz).')
+    for B in ('1', '2'):
+        per = defaultdict(dict)
+        for ctr in ('FETCH_SIZE', 'WRITE_SIZE', 'SQ_VALU_MFMA_BUSY_CYCLES'):
+            fs = glob.glob(os.path.join(src, 'pmc_%s_b%s' % (ctr, B), '*', '*counter_collection.csv'))
+            if not fs:
+                continue
+            acc = defaultdict(lambda: [0.0, 0.0, 0])
+            for r in csv.DictReader(open(fs[0])):
+                if r['Counter_Name'] != ctr:
+                    continue
+                a = acc[prog_label(r['Kernel_Name'])]
+                a[0] += float(r['Counter_Value'])
+                a[1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+                a[2] += 1
+            for k, (v, dur, n) in acc.items():
+                per[k][ctr] = (v / n, dur / n, n)
+        for k, v in sorted(per.items()):
+            if not (k.startswith('chain') or k.startswith('self_attn') or 'box_decode' in k or 'nchw' in k):
+                continue
+            if 'FETCH_SIZE' in v or 'WRITE_SIZE' in v:
+                fk, wk = v.get('FETCH_SIZE', (0.0,))[0], v.get('WRITE_SIZE', (0.0,))[0]
+                res.setdefault(k, OrderedDict())[B] = {
+                    'fetch_kb': round(fk, 1), 'write_kb': round(wk, 1), 'traffic_bytes': int((2 * fk + wk) * 1024),
+                    'launches': v.get('FETCH_SIZE', v.get('WRITE_SIZE'))[2]}
+            if 'SQ_VALU_MFMA_BUSY_CYCLES' in v:
+                busy, dur, n = v['SQ_VALU_MFMA_BUSY_CYCLES']
+                out_m.setdefault(k, OrderedDict())[B] = {
+                    'mfma_busy_cycles': round(busy), 'duration_us': round(dur, 1),
+                    'mfma_utilisation': round(busy / (1024 * dur * 1e-6 * 2.4e9), 4), 'launches': n}
     json.dump(res, open(os.path.join(dst, name + '_pmc.json'), 'w'), indent=1)
-    mf = glob.glob(os.path.join(src, 'pmc_mfma', '*', '*counter_collection.csv'))
-    if mf:
-        crow = [r for r in csv.DictReader(open(mf[0])) if r['Counter_Name'] == 'SQ_VALU_MFMA_BUSY_CYCLES']
-        crow.sort(key=lambda r: int(r['Dispatch_Id']))
-        label_chain(crow)
-        acc = defaultdict(lambda: [0.0, 0.0, 0])
-        for r in crow:
-            a = acc[r['K']]
-            a[0] += float(r['Counter_Value']); a[1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3; a[2] += 1
-        out_m = OrderedDict()
-        out_m['_comment'] = ('rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES of `bench.py --no-graph --steps 5`, MI355X. '
-                             'The counter sums matrix-pipe busy cycles over the 1024 SIMDs (8 per v_mfma_f32_4x4x1, 32 per '
-                             '16x16x4 f32); utilisation = busy / (1024 * duration * 2.4 GHz).')
-        for k, (busy, dur, n) in sorted(acc.items()):
-            if k.startswith('chain') or k.startswith('self_attn') or k.startswith('bwd_gemm'):
-                out_m['self_attn_kernel' if k.startswith('self_attn') else k] = {
-                    'mfma_busy_cycles': round(busy / n), 'duration_us': round(dur / n, 1),
-                    'mfma_utilisation': round(busy / (1024 * dur * 1e-6 * 2.4e9), 4)}
-        json.dump(out_m, open(os.path.join(dst, name + '_mfma_busy.json'), 'w'), indent=1)
+    json.dump(out_m, open(os.path.join(dst, name + '_mfma_busy.json'), 'w'), indent=1)
+    # one launch sequence of one frame at a time (--pair 1 --lanes 1): the latency anatomy
+    p1 = glob.glob(os.path.join(src, 'prof_pair1', '*', '*kernel_stats.csv'))
+    if p1:
+        open(os.path.join(dst, name + '_pair1_kernel_stats.csv'), 'w').write(open(p1[0]).read())
     print(open(os.path.join(dst, name + '_frame_trace.txt')).read())
     print(json.dumps(res, indent=1))
 

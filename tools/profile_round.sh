@@ -1,34 +1,38 @@
 #!/bin/bash
 # Round profile on an MI355X box (run through gpurun from the repo root):
-#   gpurun --timeout 1500 -- 'bash tools/profile_round.sh r1'
-# Writes under gpurun_out/<tag>/ : GPU test log, bench JSON line, rocprofv3
-# kernel stats + trace of the same bench command, and the two PMC passes
-# (FETCH_SIZE / WRITE_SIZE, separate runs, kernel-trace only).  Copy what is to
-# be judged into profiles/ with tools/collect_profile.py.
+#   gpurun --timeout 2400 -- 'bash tools/profile_round.sh r2'
+# Writes under gpurun_out/<tag>/ : GPU test log, bench JSON lines, rocprofv3 kernel stats + traces
+# of the same bench command, and the PMC passes (FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES:
+# separate runs, kernel-trace only).  Copy what is to be judged into profiles/ with
+# tools/collect_profile.py <tag> <name>.
 set -u
-TAG=${1:-r1}
+TAG=${1:-r2}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 python -m pytest tests -x -q -m gpu > "$OUT/pytest_gpu.log" 2>&1
 echo "pytest rc=$?" >> "$OUT/pytest_gpu.log"
-python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
-python bench.py --batch 2 --no-cpu-baseline --no-batched > "$OUT/bench_b2.json" 2>> "$OUT/bench.err"
-python bench.py --batch 4 --no-cpu-baseline --no-batched > "$OUT/bench_b4.json" 2>> "$OUT/bench.err"
+python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"                                   # default: 2 frames per launch x 3 lanes
+python bench.py --pair 1 --no-cpu-baseline --no-batched > "$OUT/bench_pair1.json" 2>> "$OUT/bench.err"
+python bench.py --pair 4 --lanes 2 --no-cpu-baseline --no-batched --no-handoff > "$OUT/bench_pair4.json" 2>> "$OUT/bench.err"
 python bench.py --train --steps 50 --warmup 5 > "$OUT/bench_train.json" 2>> "$OUT/bench.err"
 cd /tmp
-# per-kernel durations: one frame at a time (with frames in flight the kernels of different frames share the GPU)
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python3 "$REPO/bench.py" --lanes 1 --steps 50 --warmup 5 --no-cpu-baseline --no-batched > "$OUT/prof.log" 2>&1
-# the default command (3 frames in flight): trace of the overlap
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_lanes" -- python3 "$REPO/bench.py" --steps 50 --warmup 5 --no-cpu-baseline --no-batched > "$OUT/prof_lanes.log" 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-batched --no-graph > "$OUT/pmc_fetch.log" 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-batched --no-graph > "$OUT/pmc_write.log" 2>&1
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d "$OUT/pmc_mfma" -- python3 "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-batched --no-graph > "$OUT/pmc_mfma.log" 2>&1
+Q="--no-cpu-baseline --no-batched --no-handoff"
+# per-kernel durations, one launch sequence at a time (with frames in flight the kernels of different lanes share the GPU)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python3 "$REPO/bench.py" --lanes 1 --steps 50 --warmup 5 $Q > "$OUT/prof.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_pair1" -- python3 "$REPO/bench.py" --lanes 1 --pair 1 --steps 50 --warmup 5 $Q > "$OUT/prof_pair1.log" 2>&1
+# the default command (3 lanes): trace of the overlap
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_lanes" -- python3 "$REPO/bench.py" --steps 50 --warmup 5 $Q > "$OUT/prof_lanes.log" 2>&1
+for B in 2 1; do
+  for C in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
+    rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_${C}_b$B" -- python3 "$REPO/bench.py" --batch $B --steps 5 --warmup 2 $Q --no-graph --no-roofline > "$OUT/pmc_${C}_b$B.log" 2>&1
+  done
+done
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_train" -- python3 "$REPO/bench.py" --train --steps 20 --warmup 3 > "$OUT/prof_train.log" 2>&1
 cd "$REPO"
 # keep the merge-back small: stats csv + counter csv only
 find "$OUT" -name '*.db' -delete 2>/dev/null
 find "$OUT" -name '*kernel_trace.csv' -size +20M -delete 2>/dev/null
-ls -R "$OUT" | head -50
+ls -R "$OUT" | head -60
 tail -3 "$OUT/pytest_gpu.log"; cat "$OUT/bench.json"

@@ -115,8 +115,8 @@ SIGNATURES = {
     'tc_device_count': (_i, []),
     'tc_nchw_to_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'tc_nchw_to_nhwc_levels': (_i, [_P(_vp), _P(_vp), _i, _i, _i, _P(_i), _P(_i), _vp]),
-    'tc_radar_build_tokens': (_i, [_vp, _vp, _P(_i), _i, _P(C.c_double), _P(C.c_double), _P(_f),
-                                   _vp, _i, _vp, _vp]),
+    'tc_radar_build_tokens': (_i, [_vp, _vp, _P(_i), _i, _P(C.c_double), _P(C.c_double),
+                                   _P(C.c_double), _vp, _i, _vp, _vp]),
     'tc_linear_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'tc_add_layernorm_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'tc_refine_reference_fwd': (_i, [_vp, _i, _vp, _vp, _i, _vp]),

@@ -339,7 +339,7 @@ int tc_nchw_to_nhwc_levels(const float* const* src, float* const* dst, int num_l
 }
 
 int tc_radar_build_tokens(const double* raw, const double* times, const int* chan_start, int num_chan,
-                          const double* radar_rot, const double* lidar_rot, const float* point_range,
+                          const double* radar_rot, const double* lidar_rot, const double* point_range,
                           float* tokens, int T, int* count, tc_stream_t stream) {
   return launch_radar_ingest(raw, times, chan_start, num_chan, radar_rot, lidar_rot, point_range, tokens, T,
                              count, as_stream(stream));

@@ -183,7 +183,7 @@ int launch_nchw_to_nhwc_levels(const float* const* src, float* const* dst, int n
 // ---- radar_ingest.hip ------------------------------------------------------
 int launch_radar_ingest(const double* raw, const double* times, const int* chan_start_host, int num_chan,
                         const double* radar_rot_host, const double* lidar_rot_host,
-                        const float* point_range_host, float* tokens, int T, int* count, hipStream_t s);
+                        const double* point_range_host, float* tokens, int T, int* count, hipStream_t s);
 
 // ---- decode.hip ------------------------------------------------------------
 int launch_box_decode(const float* cls, const float* box, int B, int Q, int ncls, int code,

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(NT) void radar_ingest_kernel(IngestK k) {
 
 int launch_radar_ingest(const double* raw, const double* times, const int* chan_start_host, int num_chan,
                         const double* radar_rot_host, const double* lidar_rot_host,
-                        const float* point_range_host, float* tokens, int T, int* count, hipStream_t s) {
+                        const double* point_range_host, float* tokens, int T, int* count, hipStream_t s) {
   TC_REQUIRE(num_chan >= 1 && num_chan <= MAX_CHAN, "radar_ingest: num_chan=%d (1..%d)", num_chan, MAX_CHAN);
   TC_REQUIRE(tokens != nullptr && T >= 1 && chan_start_host != nullptr && radar_rot_host != nullptr &&
                  lidar_rot_host != nullptr && point_range_host != nullptr, "radar_ingest: null argument");
@@ -125,7 +125,7 @@ int launch_radar_ingest(const double* raw, const double* times, const int* chan_
   for (int c = 0; c < MAX_CHAN; ++c)
     for (int j = 0; j < 9; ++j) k.rot_radar[c][j] = c < num_chan ? radar_rot_host[c * 9 + j] : 0.0;
   for (int j = 0; j < 9; ++j) k.rot_ref[j] = lidar_rot_host[j];
-  for (int j = 0; j < 3; ++j) { k.lo[j] = (double)point_range_host[j]; k.hi[j] = (double)point_range_host[3 + j]; }
+  for (int j = 0; j < 3; ++j) { k.lo[j] = point_range_host[j]; k.hi[j] = point_range_host[3 + j]; }
   hipLaunchKernelGGL(radar_ingest_kernel, dim3(1), dim3(NT), 0, s, k);
   return check_launch("radar_ingest");
 }

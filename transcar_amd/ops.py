@@ -321,7 +321,7 @@ def radar_build_tokens(frame, T, device, out=None, point_range=None):
     if tuple(out.shape[-2:]) != (T, R.NUM_FEATURES) or out.numel() != T * R.NUM_FEATURES or not out.is_contiguous():
         raise L.TransCARHipError('out must be a contiguous [1,%d,%d] tensor' % (T, R.NUM_FEATURES))
     count = torch.zeros(1, dtype=torch.int32, device=device)
-    pr = (C.c_float * 6)(*[float(v) for v in (point_range or R.POINT_RANGE)])
+    pr = (C.c_double * 6)(*[float(v) for v in (point_range or R.POINT_RANGE)])
     L.check(L.lib().tc_radar_build_tokens(
         _p(raw_d), _p(times_d), start.ctypes.data_as(C.POINTER(C.c_int)), len(R.RADAR_CHANNELS),
         rr.ctypes.data_as(C.POINTER(C.c_double)), lr.ctypes.data_as(C.POINTER(C.c_double)), pr,
