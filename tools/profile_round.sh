@@ -31,8 +31,13 @@ for B in 2 1; do
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_train" -- python3 "$REPO/bench.py" --train --steps 20 --warmup 3 > "$OUT/prof_train.log" 2>&1
 cd "$REPO"
-# keep the merge-back small: stats csv + counter csv only
-find "$OUT" -name '*.db' -delete 2>/dev/null
-find "$OUT" -name '*kernel_trace.csv' -size +20M -delete 2>/dev/null
-ls -R "$OUT" | head -60
+# keep the merge-back small (gpurun copies back at most 64 MiB): stats / trace / counter csv only
+find "$OUT" -type f ! -name '*kernel_stats.csv' ! -name '*kernel_trace.csv' ! -name '*counter_collection.csv' \
+     ! -name '*.json' ! -name '*.log' ! -name '*.err' -delete 2>/dev/null
+find "$OUT" -name '*kernel_trace.csv' -size +12M -delete 2>/dev/null
+# the counter csv of a PMC pass carries every dispatch of the process: keep the kernels of the path
+for f in $(find "$OUT" -name '*counter_collection.csv'); do
+  (head -1 "$f"; grep -E 'chain_|self_attn|box_decode|nchw_to_nhwc|radar_' "$f") > "$f.tmp" && mv "$f.tmp" "$f"
+done
+du -sh "$OUT"; du -s "$OUT"/* | sort -n | tail -12
 tail -3 "$OUT/pytest_gpu.log"; cat "$OUT/bench.json"
