@@ -18,7 +18,7 @@ python bench.py --pair 1 --no-cpu-baseline --no-batched > "$OUT/bench_pair1.json
 python bench.py --pair 4 --lanes 2 --no-cpu-baseline --no-batched --no-handoff > "$OUT/bench_pair4.json" 2>> "$OUT/bench.err"
 python bench.py --train --steps 50 --warmup 5 > "$OUT/bench_train.json" 2>> "$OUT/bench.err"
 cd /tmp
-Q="--no-cpu-baseline --no-batched --no-handoff"
+Q="--no-cpu-baseline --no-batched --no-handoff --min-window-s 0.05 --warmup-s 0.05"   # short windows: small traces
 # per-kernel durations, one launch sequence at a time (with frames in flight the kernels of different lanes share the GPU)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python3 "$REPO/bench.py" --lanes 1 --steps 50 --warmup 5 $Q > "$OUT/prof.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_pair1" -- python3 "$REPO/bench.py" --lanes 1 --pair 1 --steps 50 --warmup 5 $Q > "$OUT/prof_pair1.log" 2>&1
