@@ -70,6 +70,9 @@ def parse(argv=None):
     ap.add_argument('--tile-rows', type=int, default=0, choices=[0, 4, 8, 16],
                     help='row-tile height of the fused chains in the frame pipeline (0 = automatic)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--main-only', action='store_true',
+                    help='only the main timed loop: no single-lane, roofline, delivery, hand-off, batched or CPU '
+                         'side measurements (kernel traces of tools/profile_round.sh)')
     ap.add_argument('--no-roofline', action='store_true',
                     help='skip the per-kernel timing replays (the PMC passes of tools/profile_round.sh: '
                          'only the launches of real frames are to be counted)')
@@ -698,6 +701,8 @@ def dry_run(args):
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse(argv)
+    if args.main_only:
+        args.no_roofline = args.no_handoff = args.no_batched = args.no_cpu_baseline = True
     env_world = os.environ.get('WORLD_SIZE')
     if env_world is None and args.gpus > 1:
         return spawn_ranks(args, argv)          # launcher parent: no torch, no GPU
@@ -781,7 +786,7 @@ def main(argv=None):
                    'parallelism': 'dp%d (frames sharded, no data-path collective)' % world},
     }
     if rank == 0:
-        if pipe is not None:
+        if pipe is not None and not args.main_only:
             # one frame at a time, host sync per frame: the reference's own method
             # (tools/analysis_tools/benchmark.py:64-91) -- the latency of a frame
             from transcar_amd.pipeline import FramePipeline
@@ -797,7 +802,7 @@ def main(argv=None):
             line['roofline']['path_achieved_tflops'] = pf * line['value'] / world / 1e12
             line['roofline']['path_frac'] = line['roofline']['path_achieved_tflops'] / line['roofline']['peak']
         if world == 1:
-            if pipe is not None:
+            if pipe is not None and not args.main_only:
                 line['with_input_delivery'] = producer_side_run(pipe, args)
             if not args.no_handoff and not args.no_graph:
                 line['with_handoff'] = handoff_side_run(head, dev, args)

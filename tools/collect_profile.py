@@ -12,6 +12,7 @@ into the committed summaries under profiles/:
 """
 import csv
 import glob
+import re
 import json
 import os
 import sys
@@ -81,11 +82,13 @@ def prog_label(kernel_name):
     import re
     m = re.search(r'chain_dual_kernel<(\d+), (\d+), (\d+)>', kernel_name)
     if m:
-        return 'chain_dual_kernel(decoder layer + radar encoder half %s)' % ('A' if m.group(3) == '4' else 'B')
+        return 'chain_dual_kernel(decoder layer + radar encoder half %s, %s-row tiles)' % (
+            'A' if m.group(3) == '4' else 'B', m.group(1))
     m = re.search(r'chain_kernel<(\d+), (\d+)(?:, (\w+))?>', kernel_name)
     if m:
-        return 'chain_kernel(%s)' % {'0': 'prologue', '1': 'decoder layer', '2': 'radar encoders',
-                                     '3': 'radar fusion'}.get(m.group(2), 'program ' + m.group(2))
+        return 'chain_kernel(%s, %s-row tiles)' % ({'0': 'prologue', '1': 'decoder layer', '2': 'radar encoders',
+                                                    '3': 'radar fusion'}.get(m.group(2), 'program ' + m.group(2)),
+                                                   m.group(1))
     if 'self_attn_kernel' in kernel_name:
         return 'self_attn_kernel'
     return short(kernel_name)
@@ -204,7 +207,7 @@ def main():
             for r in csv.DictReader(open(fs[0])):
                 if r['Counter_Name'] != ctr:
                     continue
-                a = acc[prog_label(r['Kernel_Name'])]
+                a = acc[re.sub(r', \d+-row tiles', '', prog_label(r['Kernel_Name']))]
                 a[0] += float(r['Counter_Value'])
                 a[1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
                 a[2] += 1
