@@ -100,20 +100,22 @@ struct StepAll { StepRes r; EpiRec e; PreRec p[CH_NW]; };
 static_assert(sizeof(StepAll) % 16 == 0, "records are copied 16 bytes at a time");
 template <int N> struct Recs { StepAll s[N]; };
 
+// Activations of the R rows: FOUR [R][256 + 4] units (round 1 had seven: 120 KB at R = 16, one
+// workgroup per CU).  Unit 0 (B_X) is the residual stream; units 1-3 are temporaries placed by the
+// step tables below from the programs' liveness; the 512-wide FFN hidden tile (B_A, row stride
+// 512 + 4) spans units 1 and 2.  query_pos is not held at all: the LayerNorm in front of the two
+// linears that need x + query_pos writes that sum next to x (F_LN_XP).  R = 16: 66.6 KB + records
+// = 76 KB -- two workgroups per CU.
 template <int R, int NREC>
 struct ChainLds {
   StepAll recs[NREC];
-  float x[R][LD2];
-  float r[R][LD2];
-  float t[R][LD2];
-  float u[R][LD2];
-  float p[R][LD2];
+  float unit[4][R][LD2];
   float l[R][LDL];
   float box[R][12];
   float cen[R][4];
   int gate[R];
-  float a[R][LD5];
 };
+static_assert(LD5 * 1 <= 2 * LD2, "the 512-wide tile must fit two units");
 
 // timing experiments (skip epilogues / barriers / LayerNorm / sampling) exist in the STAMPS
 // build only; the production library has no such switch
@@ -126,7 +128,7 @@ struct ChainLds {
 #define MFMA44(a, b, c, grp) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 4, (grp), 0)
 
 // ---- step tables -----------------------------------------------------------
-enum Buf : short { B_NONE = -1, B_A = 0, B_X, B_R, B_T, B_U, B_P, B_L };
+enum Buf : short { B_NONE = -1, B_A = 0 /* units 1+2, row stride LD5 */, B_X /* unit 0 */, B_U1, B_U2, B_U3, B_L };
 enum Kind : short {
   K_END = 0, K_LOAD, K_LINEAR, K_LN, K_POSENC, K_SAMPLE, K_REFUPD, K_TOKENS, K_RADAR_ATTN, K_BOXADD,
   K_NOP   // a step switched off at run time (no next layer): only its barrier remains
@@ -140,7 +142,8 @@ enum Flags : short {
   F_SKIP_NONEXT = 16, // skip the step when there is no next layer
   F_WAVE1 = 32,       // linear: column tile t goes to wave (t + 1) % 4 -- a narrow step (one tile)
                       //   then runs BESIDE the preceding narrow step, which keeps wave 0 busy
-  F_NOT_W0 = 64       // posenc: rows go to waves 1..3 only (wave 0 is in a narrow linear step)
+  F_NOT_W0 = 64,      // posenc: rows go to waves 1..3 only (wave 0 is in a narrow linear step)
+  F_LN_XP = 128       // ln: also write (result + query_pos row) into the buffer named by `res`
 };
 // global tensors, indices into ChainK::g
 enum GSel : short {
@@ -155,47 +158,48 @@ struct StepDesc {
 // decoder layer pairs: 0 in_proj 1 out_proj 2 norm0 3 attw 4 output_proj 5 pe.l0 6 pe.n1 7 pe.l3
 //   8 pe.n4 9 norm1 10 ffn0 11 ffn1 12 norm2 13 reg.l0 14 reg.l2 15 reg.l4 ; 16 next in_proj
 constexpr StepDesc PROG_DECODER_T[] = {
-    {K_LOAD, 0, 0, 0, 0, B_NONE, B_NONE, B_T, B_NONE, 0, 0, G_ATTN_O, G_NONE, 0},
-    {K_LOAD, 0, 0, 0, 0, B_NONE, B_NONE, B_X, B_NONE, 0, 0, G_XIN, G_NONE, 0},
-    {K_LOAD, 0, 0, 0, 0, B_NONE, B_NONE, B_P, B_NONE, 0, 0, G_POS, G_NONE, 1},
-    {K_LINEAR, 1, -1, 256, 256, B_T, B_NONE, B_U, B_X, 0, 0, G_NONE, G_NONE, 1},          // x + out_proj(attn)
-    {K_LN, 2, -1, 0, 0, B_U, B_NONE, B_X, B_NONE, 0, 0, G_NONE, G_NONE, 1},               // norm0
-    {K_LINEAR, 3, -1, 256, N_LOGITS, B_X, B_P, B_L, B_NONE, 0, 0, G_NONE, G_NONE, 0},     // attention_weights
-    {K_POSENC, 5, 6, 0, 0, B_NONE, B_NONE, B_T, B_NONE, 0, F_NOT_W0, G_NONE, G_NONE, 1},  // pe.0-2 (waves 1-3)
-    {K_SAMPLE, 0, 0, 0, 0, B_L, B_NONE, B_R, B_NONE, 0, 0, G_NONE, G_NONE, 1},            // camera sampling
-    {K_LINEAR, 7, -1, 256, 256, B_T, B_NONE, B_A, B_NONE, 0, 0, G_NONE, G_NONE, 0},       // pe.3
-    {K_LINEAR, 4, -1, 256, 256, B_R, B_NONE, B_U, B_X, 0, 0, G_NONE, G_NONE, 1},          // x + output_proj
-    {K_LN, 9, 8, 0, 0, B_U, B_A, B_X, B_NONE, 0, 0, G_NONE, G_NONE, 1},                   // norm1(u + relu(LN(a)))
+    {K_LOAD, 0, 0, 0, 0, B_NONE, B_NONE, B_U1, B_NONE, 0, 0, G_ATTN_O, G_NONE, 0},
+    {K_LOAD, 0, 0, 0, 0, B_NONE, B_NONE, B_X, B_NONE, 0, 0, G_XIN, G_NONE, 1},
+    {K_LINEAR, 1, -1, 256, 256, B_U1, B_NONE, B_U2, B_X, 0, 0, G_NONE, G_NONE, 1},        // x + out_proj(attn)
+    {K_LN, 2, -1, 0, 0, B_U2, B_NONE, B_X, B_U1, 0, F_LN_XP, G_NONE, G_NONE, 1},          // norm0; x + pos -> U1
+    {K_LINEAR, 3, -1, 256, N_LOGITS, B_U1, B_NONE, B_L, B_NONE, 0, 0, G_NONE, G_NONE, 0}, // attention_weights(x + pos)
+    {K_POSENC, 5, 6, 0, 0, B_NONE, B_NONE, B_U2, B_NONE, 0, F_NOT_W0, G_NONE, G_NONE, 1}, // pe.0-2 (waves 1-3)
+    {K_SAMPLE, 0, 0, 0, 0, B_L, B_NONE, B_U3, B_NONE, 0, 0, G_NONE, G_NONE, 1},           // camera sampling
+    {K_LINEAR, 7, -1, 256, 256, B_U2, B_NONE, B_U1, B_NONE, 0, 0, G_NONE, G_NONE, 1},     // pe.3 (barrier: U2 is re-used next)
+    {K_LINEAR, 4, -1, 256, 256, B_U3, B_NONE, B_U2, B_X, 0, 0, G_NONE, G_NONE, 1},        // x + output_proj
+    {K_LN, 9, 8, 0, 0, B_U2, B_U1, B_X, B_NONE, 0, 0, G_NONE, G_NONE, 1},                 // norm1(U2 + relu(LN(U1)))
     {K_LINEAR, 10, -1, 256, 512, B_X, B_NONE, B_A, B_NONE, 1, 0, G_NONE, G_NONE, 1},      // ffn0
-    {K_LINEAR, 11, -1, 512, 256, B_A, B_NONE, B_U, B_X, 0, 0, G_NONE, G_NONE, 1},         // x + ffn1
-    {K_LN, 12, -1, 0, 0, B_U, B_NONE, B_X, B_NONE, 0, 0, G_HS, G_NONE, 1},                // norm2 -> hs
-    {K_LINEAR, 13, -1, 256, 256, B_X, B_NONE, B_T, B_NONE, 1, 0, G_NONE, G_NONE, 0},      // reg.0
-    {K_LINEAR, 16, -1, 256, 512, B_X, B_P, B_NONE, B_NONE, 0, F_SCALEQ | F_SKIP_NONEXT, G_QK, G_NONE, 0},
+    {K_LINEAR, 11, -1, 512, 256, B_A, B_NONE, B_U3, B_X, 0, 0, G_NONE, G_NONE, 1},        // x + ffn1
+    {K_LN, 12, -1, 0, 0, B_U3, B_NONE, B_X, B_U1, 0, F_LN_XP, G_HS, G_NONE, 1},           // norm2 -> hs; x + pos -> U1
+    {K_LINEAR, 13, -1, 256, 256, B_X, B_NONE, B_U2, B_NONE, 1, 0, G_NONE, G_NONE, 0},     // reg.0
+    {K_LINEAR, 16, -1, 256, 512, B_U1, B_NONE, B_NONE, B_NONE, 0, F_SCALEQ | F_SKIP_NONEXT, G_QK, G_NONE, 0},
     {K_LINEAR, 16, -1, 256, 256, B_X, B_NONE, B_NONE, B_NONE, 0, F_WOFF | F_SKIP_NONEXT, G_NONE, G_VT, 1},
-    {K_LINEAR, 14, -1, 256, 256, B_T, B_NONE, B_U, B_NONE, 1, 0, G_NONE, G_NONE, 1},      // reg.2
-    {K_LINEAR, 15, -1, 256, N_CODE, B_U, B_NONE, B_L, B_NONE, 0, 0, G_NONE, G_NONE, 1},   // reg.4
+    {K_LINEAR, 14, -1, 256, 256, B_U2, B_NONE, B_U3, B_NONE, 1, 0, G_NONE, G_NONE, 1},    // reg.2
+    {K_LINEAR, 15, -1, 256, N_CODE, B_U3, B_NONE, B_L, B_NONE, 0, 0, G_NONE, G_NONE, 1},  // reg.4
     {K_REFUPD, 0, 0, 0, 0, B_L, B_NONE, B_NONE, B_NONE, 0, 0, G_NONE, G_NONE, 0},
     {K_END, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
 // prologue pairs: 0 reference_points 16 layer-0 in_proj
 constexpr StepDesc PROG_PROLOGUE_T[] = {
-    {K_LOAD, 0, 0, 0, 0, B_NONE, B_NONE, B_P, B_NONE, 0, 0, G_POS, G_NONE, 0},
+    {K_LOAD, 0, 0, 0, 0, B_NONE, B_NONE, B_U1, B_NONE, 0, 0, G_POS, G_NONE, 0},
     {K_LOAD, 0, 0, 0, 0, B_NONE, B_NONE, B_X, B_NONE, 0, 0, G_XIN, G_NONE, 1},
-    {K_LINEAR, 0, -1, 256, 3, B_P, B_NONE, B_NONE, B_NONE, 2, 0, G_INITREF, G_NONE, 0},
-    {K_LINEAR, 16, -1, 256, 512, B_X, B_P, B_NONE, B_NONE, 0, F_SCALEQ, G_QK, G_NONE, 0},
+    {K_LINEAR, 0, -1, 256, 3, B_U1, B_NONE, B_NONE, B_NONE, 2, 0, G_INITREF, G_NONE, 0},
+    {K_LINEAR, 16, -1, 256, 512, B_X, B_U1, B_NONE, B_NONE, 0, F_SCALEQ, G_QK, G_NONE, 0},
     {K_LINEAR, 16, -1, 256, 256, B_X, B_NONE, B_NONE, B_NONE, 0, F_WOFF, G_NONE, G_VT, 0},
     {K_END, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
 // radar encoder pairs: 0 rpe.l0 1 rpe.n1 2 rpe.l3 3 rpe.n4 4 f0 5 f2 6 f4 7..9 kv proj of layer 0..2
+// units: the token tile (64 columns) lives in B_A (units 1-2) until feat.0 and the position
+// encoder's first layer have read it; the encoded tokens end in U2
 constexpr StepDesc PROG_RADAR_ENC_T[] = {
     {K_TOKENS, 0, 0, 0, 0, B_NONE, B_NONE, B_A, B_NONE, 0, 0, G_NONE, G_NONE, 1},
-    {K_POSENC, 0, 1, 0, 0, B_A, B_NONE, B_T, B_NONE, 0, 0, G_NONE, G_NONE, 0},            // raw xyz from the tile
-    {K_LINEAR, 4, -1, 36, 64, B_A, B_NONE, B_R, B_NONE, 1, 0, G_NONE, G_NONE, 1},         // feat.0 (K = RI)
-    {K_LINEAR, 2, -1, 256, 256, B_T, B_NONE, B_U, B_NONE, 0, 0, G_NONE, G_NONE, 0},       // rpe.3
-    {K_LINEAR, 5, -1, 64, 128, B_R, B_NONE, B_X, B_NONE, 1, 0, G_NONE, G_NONE, 1},        // feat.2
-    {K_LINEAR, 6, -1, 128, 256, B_X, B_NONE, B_P, B_NONE, 1, 0, G_NONE, G_NONE, 1},       // feat.4
-    {K_LN, 3, -1, 0, 0, B_U, B_NONE, B_X, B_P, 0, F_LN_RELU, G_NONE, G_NONE, 1},          // relu(LN(u)) + p
-    {K_LINEAR, 7, -1, 256, 512, B_X, B_NONE, B_NONE, B_NONE, 0, 0, G_KV0, G_NONE, 0},
-    {K_LINEAR, 8, -1, 256, 512, B_X, B_NONE, B_NONE, B_NONE, 0, 0, G_KV1, G_NONE, 0},
-    {K_LINEAR, 9, -1, 256, 512, B_X, B_NONE, B_NONE, B_NONE, 0, 0, G_KV2, G_NONE, 0},
+    {K_POSENC, 0, 1, 0, 0, B_A, B_NONE, B_U3, B_NONE, 0, 0, G_NONE, G_NONE, 0},           // raw xyz from the tile
+    {K_LINEAR, 4, -1, 36, 64, B_A, B_NONE, B_X, B_NONE, 1, 0, G_NONE, G_NONE, 1},         // feat.0 (K = RI)
+    {K_LINEAR, 2, -1, 256, 256, B_U3, B_NONE, B_U1, B_NONE, 0, 0, G_NONE, G_NONE, 0},     // rpe.3
+    {K_LINEAR, 5, -1, 64, 128, B_X, B_NONE, B_U2, B_NONE, 1, 0, G_NONE, G_NONE, 1},       // feat.2
+    {K_LINEAR, 6, -1, 128, 256, B_U2, B_NONE, B_X, B_NONE, 1, 0, G_NONE, G_NONE, 1},      // feat.4
+    {K_LN, 3, -1, 0, 0, B_U1, B_NONE, B_U2, B_X, 0, F_LN_RELU, G_NONE, G_NONE, 1},        // relu(LN(U1)) + feat
+    {K_LINEAR, 7, -1, 256, 512, B_U2, B_NONE, B_NONE, B_NONE, 0, 0, G_KV0, G_NONE, 0},
+    {K_LINEAR, 8, -1, 256, 512, B_U2, B_NONE, B_NONE, B_NONE, 0, 0, G_KV1, G_NONE, 0},
+    {K_LINEAR, 9, -1, 256, 512, B_U2, B_NONE, B_NONE, B_NONE, 0, 0, G_KV2, G_NONE, 0},
     {K_END, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
 // The encoders in two halves, carried by the launches of decoder layers 0 and 1 (16 workgroups of
 // 16-row tiles each): as one program they ran 70 us beside a 58 us decoder layer and set its
@@ -203,13 +207,13 @@ constexpr StepDesc PROG_RADAR_ENC_T[] = {
 // radar layers 1 and 2.
 constexpr StepDesc PROG_RADAR_ENC_A_T[] = {
     {K_TOKENS, 0, 0, 0, 0, B_NONE, B_NONE, B_A, B_NONE, 0, 0, G_NONE, G_NONE, 1},
-    {K_POSENC, 0, 1, 0, 0, B_A, B_NONE, B_T, B_NONE, 0, 0, G_NONE, G_NONE, 0},
-    {K_LINEAR, 4, -1, 36, 64, B_A, B_NONE, B_R, B_NONE, 1, 0, G_NONE, G_NONE, 1},
-    {K_LINEAR, 2, -1, 256, 256, B_T, B_NONE, B_U, B_NONE, 0, 0, G_NONE, G_NONE, 0},
-    {K_LINEAR, 5, -1, 64, 128, B_R, B_NONE, B_X, B_NONE, 1, 0, G_NONE, G_NONE, 1},
-    {K_LINEAR, 6, -1, 128, 256, B_X, B_NONE, B_P, B_NONE, 1, 0, G_NONE, G_NONE, 1},
-    {K_LN, 3, -1, 0, 0, B_U, B_NONE, B_X, B_P, 0, F_LN_RELU, G_RFEAT, G_NONE, 1},
-    {K_LINEAR, 7, -1, 256, 512, B_X, B_NONE, B_NONE, B_NONE, 0, 0, G_KV0, G_NONE, 0},
+    {K_POSENC, 0, 1, 0, 0, B_A, B_NONE, B_U3, B_NONE, 0, 0, G_NONE, G_NONE, 0},
+    {K_LINEAR, 4, -1, 36, 64, B_A, B_NONE, B_X, B_NONE, 1, 0, G_NONE, G_NONE, 1},
+    {K_LINEAR, 2, -1, 256, 256, B_U3, B_NONE, B_U1, B_NONE, 0, 0, G_NONE, G_NONE, 0},
+    {K_LINEAR, 5, -1, 64, 128, B_X, B_NONE, B_U2, B_NONE, 1, 0, G_NONE, G_NONE, 1},
+    {K_LINEAR, 6, -1, 128, 256, B_U2, B_NONE, B_X, B_NONE, 1, 0, G_NONE, G_NONE, 1},
+    {K_LN, 3, -1, 0, 0, B_U1, B_NONE, B_U2, B_X, 0, F_LN_RELU, G_RFEAT, G_NONE, 1},
+    {K_LINEAR, 7, -1, 256, 512, B_U2, B_NONE, B_NONE, B_NONE, 0, 0, G_KV0, G_NONE, 0},
     {K_END, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
 constexpr StepDesc PROG_RADAR_ENC_B_T[] = {
     {K_LOAD, 0, 0, 0, 0, B_NONE, B_NONE, B_X, B_NONE, 0, 0, G_RFEAT, G_NONE, 1},
@@ -219,22 +223,22 @@ constexpr StepDesc PROG_RADAR_ENC_B_T[] = {
 // radar layer pairs (+14*r): 0 attn.in_proj 1 attn.out_proj 2 norm2 3 linear1 4 linear2 5 norm3
 //   6 cls.0 7 cls.n1 8 cls.3 9 cls.n4 10 cls.6 11 reg.0 12 reg.2 13 reg.4
 constexpr StepDesc PROG_RADAR_LAYER_T[] = {
-    {K_LINEAR, 0, -1, 256, 256, B_X, B_NONE, B_T, B_NONE, 0, F_SCALEQ, G_NONE, G_NONE, 1},   // q projection
-    {K_RADAR_ATTN, 0, 0, 0, 0, B_T, B_NONE, B_U, B_NONE, 0, 0, G_NONE, G_NONE, 1},
-    {K_LINEAR, 1, -1, 256, 256, B_U, B_NONE, B_R, B_X, 0, F_GATE, G_NONE, G_NONE, 1},        // x + gate*out_proj
-    {K_LN, 2, -1, 0, 0, B_R, B_NONE, B_X, B_NONE, 0, 0, G_NONE, G_NONE, 1},                  // rf_norm2
+    {K_LINEAR, 0, -1, 256, 256, B_X, B_NONE, B_U1, B_NONE, 0, F_SCALEQ, G_NONE, G_NONE, 1},  // q projection
+    {K_RADAR_ATTN, 0, 0, 0, 0, B_U1, B_NONE, B_U2, B_NONE, 0, 0, G_NONE, G_NONE, 1},
+    {K_LINEAR, 1, -1, 256, 256, B_U2, B_NONE, B_U3, B_X, 0, F_GATE, G_NONE, G_NONE, 1},      // x + gate*out_proj
+    {K_LN, 2, -1, 0, 0, B_U3, B_NONE, B_X, B_NONE, 0, 0, G_NONE, G_NONE, 1},                 // rf_norm2
     {K_LINEAR, 3, -1, 256, 512, B_X, B_NONE, B_A, B_NONE, 1, 0, G_NONE, G_NONE, 1},
-    {K_LINEAR, 4, -1, 512, 256, B_A, B_NONE, B_U, B_X, 0, 0, G_NONE, G_NONE, 1},
-    {K_LN, 5, -1, 0, 0, B_U, B_NONE, B_X, B_NONE, 0, 0, G_NONE, G_NONE, 1},                  // rf_norm3
-    {K_LINEAR, 6, -1, 256, 256, B_X, B_NONE, B_T, B_NONE, 0, 0, G_NONE, G_NONE, 0},          // final_cls.0
-    {K_LINEAR, 11, -1, 256, 256, B_X, B_NONE, B_R, B_NONE, 1, 0, G_NONE, G_NONE, 1},         // final_reg.0
-    {K_LN, 7, -1, 0, 0, B_T, B_NONE, B_T, B_NONE, 0, F_LN_RELU, G_NONE, G_NONE, 0},          // in place
-    {K_LINEAR, 12, -1, 256, 256, B_R, B_NONE, B_U, B_NONE, 1, 0, G_NONE, G_NONE, 1},         // final_reg.2
-    {K_LINEAR, 8, -1, 256, 256, B_T, B_NONE, B_P, B_NONE, 0, 0, G_NONE, G_NONE, 1},          // final_cls.3
-    {K_LN, 9, -1, 0, 0, B_P, B_NONE, B_P, B_NONE, 0, F_LN_RELU, G_NONE, G_NONE, 1},          // in place
+    {K_LINEAR, 4, -1, 512, 256, B_A, B_NONE, B_U3, B_X, 0, 0, G_NONE, G_NONE, 1},
+    {K_LN, 5, -1, 0, 0, B_U3, B_NONE, B_X, B_NONE, 0, 0, G_NONE, G_NONE, 1},                 // rf_norm3
+    {K_LINEAR, 6, -1, 256, 256, B_X, B_NONE, B_U1, B_NONE, 0, 0, G_NONE, G_NONE, 0},         // final_cls.0
+    {K_LINEAR, 11, -1, 256, 256, B_X, B_NONE, B_U2, B_NONE, 1, 0, G_NONE, G_NONE, 1},        // final_reg.0
+    {K_LN, 7, -1, 0, 0, B_U1, B_NONE, B_U1, B_NONE, 0, F_LN_RELU, G_NONE, G_NONE, 0},        // in place
+    {K_LINEAR, 12, -1, 256, 256, B_U2, B_NONE, B_U3, B_NONE, 1, 0, G_NONE, G_NONE, 1},       // final_reg.2
+    {K_LINEAR, 8, -1, 256, 256, B_U1, B_NONE, B_U2, B_NONE, 0, 0, G_NONE, G_NONE, 1},        // final_cls.3
+    {K_LN, 9, -1, 0, 0, B_U2, B_NONE, B_U2, B_NONE, 0, F_LN_RELU, G_NONE, G_NONE, 1},        // in place
     // the two 10-column steps side by side: final_reg.4 on wave 0, final_cls.6 on wave 1
-    {K_LINEAR, 13, -1, 256, N_CODE, B_U, B_NONE, B_L, B_NONE, 0, 0, G_NONE, G_NONE, 0},      // final_reg.4
-    {K_LINEAR, 10, -1, 256, N_CLS, B_P, B_NONE, B_NONE, B_NONE, 0, F_WAVE1, G_CLS, G_NONE, 1},   // final_cls.6
+    {K_LINEAR, 13, -1, 256, N_CODE, B_U3, B_NONE, B_L, B_NONE, 0, 0, G_NONE, G_NONE, 0},     // final_reg.4
+    {K_LINEAR, 10, -1, 256, N_CLS, B_U2, B_NONE, B_NONE, B_NONE, 0, F_WAVE1, G_CLS, G_NONE, 1},  // final_cls.6
     {K_BOXADD, 0, 0, 0, 0, B_L, B_NONE, B_NONE, B_NONE, 0, 0, G_NONE, G_NONE, 1},
     {K_END, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
 
@@ -585,12 +589,11 @@ __device__ __forceinline__ bool linear_step(const LinSpec& s, WBuf& w0, bool pre
 template <int R, int NREC>
 __device__ __forceinline__ float* buf_ptr(ChainLds<R, NREC>& S, int id) {
   switch (id) {
-    case B_A: return &S.a[0][0];
-    case B_X: return &S.x[0][0];
-    case B_R: return &S.r[0][0];
-    case B_T: return &S.t[0][0];
-    case B_U: return &S.u[0][0];
-    case B_P: return &S.p[0][0];
+    case B_A: return &S.unit[1][0][0];
+    case B_X: return &S.unit[0][0][0];
+    case B_U1: return &S.unit[1][0][0];
+    case B_U2: return &S.unit[2][0][0];
+    case B_U3: return &S.unit[3][0][0];
     case B_L: return &S.l[0][0];
     default: return nullptr;
   }
@@ -718,7 +721,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
   if (PROG == PROG_RADAR) {     // HEAD:539, 543-547, 596-598
     for (int row = wave; row < R; row += CH_NW) {
       const int grow = min(m0 + row, M - 1);
-      *reinterpret_cast<float4*>(&S.x[row][4 * lane]) = ld4(k.g[G_QF] + (size_t)grow * 256 + 4 * lane);
+      *reinterpret_cast<float4*>(&S.unit[0][row][4 * lane]) = ld4(k.g[G_QF] + (size_t)grow * 256 + 4 * lane);
     }
     {
       // one (row, column) per thread: columns 0..code-1 the previous box, 12..14 the gate centre
@@ -752,10 +755,18 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
   auto do_ln = [&](const StepRes& r) {
     const float* a = buf_ptr(S, r.src); const int lda = buf_ld(r.src);
     const float* c = buf_ptr(S, r.src2); const int ldc = buf_ld(r.src2);
-    const float* dd = buf_ptr(S, r.res);
+    const bool xp = (r.flags & F_LN_XP) != 0;          // `res` names an OUTPUT then: result + query_pos
+    const float* dd = xp ? nullptr : buf_ptr(S, r.res);
+    float* dst2 = xp ? buf_ptr(S, r.res) : nullptr;
     float* dst = buf_ptr(S, r.dst);
     float* gdst = r.gd;
     for (int row = wave; row < R; row += CH_NW) {
+      float4 pos4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (xp) {                                        // in flight under the reductions
+        int prow = min(m0 + row, M - 1);
+        if (k.g_mod[G_POS] > 0) prow = prow % k.g_mod[G_POS];
+        pos4 = ld4(k.g[G_POS] + (size_t)prow * k.g_ld[G_POS] + 4 * lane);
+      }
       float4 v = *reinterpret_cast<const float4*>(a + row * lda + 4 * lane);
       if (c != nullptr)
         v = add4(v, relu4(ln_row(*reinterpret_cast<const float4*>(c + row * ldc + 4 * lane), r.p2, r.p3, lane)));
@@ -763,6 +774,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
       if (r.flags & F_LN_RELU) v = relu4(v);
       if (dd != nullptr) v = add4(v, *reinterpret_cast<const float4*>(dd + row * LD2 + 4 * lane));
       *reinterpret_cast<float4*>(dst + row * LD2 + 4 * lane) = v;
+      if (xp) *reinterpret_cast<float4*>(dst2 + row * LD2 + 4 * lane) = add4(v, pos4);
       if (gdst != nullptr && m0 + row < M) st4(gdst + (size_t)(m0 + row) * 256 + 4 * lane, v);
     }
   };
@@ -896,7 +908,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
         for (int i = threadIdx.x; i < R * 64; i += CH_NT) {
           const int row = i >> 6, c = i & 63;
           const int grow = min(m0 + row, M - 1);
-          S.a[row][c] = c < k.RI ? k.tokens[(size_t)grow * k.RI + c] : 0.0f;
+          (&S.unit[1][0][0])[row * LD5 + c] = c < k.RI ? k.tokens[(size_t)grow * k.RI + c] : 0.0f;
         }
       } break;
       } break;
@@ -906,7 +918,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
         const int row_first = skip0 ? wave - 1 : wave, row_step = skip0 ? CH_NW - 1 : CH_NW;
         for (int row = row_first; row < R && row >= 0; row += row_step) {
           float p0, p1, p2;
-          if (r.src == B_A) { p0 = S.a[row][0]; p1 = S.a[row][1]; p2 = S.a[row][2]; }
+          if (r.src == B_A) { const float* tk = &S.unit[1][0][0] + row * LD5; p0 = tk[0]; p1 = tk[1]; p2 = tk[2]; }
           else {
             int grow = min(m0 + row, M - 1);
             if (k.ref_mod > 0) grow = grow % k.ref_mod;
@@ -929,7 +941,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
           int nvis = 0;
           const float4 o = cam_sample_row<4>(k.cam, k.ref_mod > 0 ? grow % k.ref_mod : grow, grow / k.Q,
                                              &S.l[row][0], lane, nvis);
-          *reinterpret_cast<float4*>(&S.r[row][4 * lane]) = o;
+          *reinterpret_cast<float4*>(buf_ptr(S, r.dst) + row * LD2 + 4 * lane) = o;
           if (m0 + row < M) pairs += nvis;
         }
         CAM_STAMP(6);
@@ -961,14 +973,14 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
         for (int row = wave; row < R; row += CH_NW) {
           const int grow = min(m0 + row, M - 1);
           const int b = grow / k.Q;
-          const float4 q4 = *reinterpret_cast<const float4*>(&S.t[row][4 * lane]);
+          const float4 q4 = *reinterpret_cast<const float4*>(buf_ptr(S, r.src) + row * LD2 + 4 * lane);
           const float* kv = (rep == 0 ? k.g[G_KV0] : rep == 1 ? k.g[G_KV1] : k.g[G_KV2]);
           int count = 0;
           const float4 o = radar_attn_row(S.cen[row][0], S.cen[row][1], S.box[row][3], S.box[row][6],
                                           S.box[row][7], k.rmin[rep], k.rmax[rep], q4,
                                           k.tokens + (size_t)b * k.T * k.RI, k.RI,
                                           kv + (size_t)b * k.T * 512, 512, k.T, k.pad_mult, lane, count);
-          *reinterpret_cast<float4*>(&S.u[row][4 * lane]) = o;
+          *reinterpret_cast<float4*>(buf_ptr(S, r.dst) + row * LD2 + 4 * lane) = o;
           if (lane == 0) {
             S.gate[row] = count;
             if (m0 + row < M) k.hits[(size_t)rep * M + m0 + row] = count;
@@ -1018,13 +1030,13 @@ __global__ __launch_bounds__(CH_NT, RA <= 8 ? 2 : 1) void chain_dual_kernel(Chai
 template <int R, int PROG>
 int lds_off(int id) {     // float offset of an LDS buffer from the start of shared memory
   using Lds = ChainLds<R, rec_cap(PROG)>;
+  const int unit0 = (int)(offsetof(Lds, unit) / 4), ustride = R * LD2;
   switch (id) {
-    case B_A: return (int)(offsetof(Lds, a) / 4);
-    case B_X: return (int)(offsetof(Lds, x) / 4);
-    case B_R: return (int)(offsetof(Lds, r) / 4);
-    case B_T: return (int)(offsetof(Lds, t) / 4);
-    case B_U: return (int)(offsetof(Lds, u) / 4);
-    case B_P: return (int)(offsetof(Lds, p) / 4);
+    case B_A: return unit0 + ustride;
+    case B_X: return unit0;
+    case B_U1: return unit0 + ustride;
+    case B_U2: return unit0 + 2 * ustride;
+    case B_U3: return unit0 + 3 * ustride;
     case B_L: return (int)(offsetof(Lds, l) / 4);
     default: return -1;
   }
