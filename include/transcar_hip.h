@@ -120,7 +120,7 @@ typedef struct {
 /* per-call options of tc_head_forward (NULL = all defaults = the reference's eval forward) */
 typedef struct {
   int chain_tile_rows;      /* rows of a workgroup's tile in the fused row chains: 0 = automatic
-                               (4 up to 1024 rows per launch, 8 beyond), 4, 8 or 16 */
+                               (4 up to 1024 rows per launch, 8 up to 2048, 16 beyond), 4, 8 or 16 */
   int unfused;              /* 1: operator-by-operator launch sequence (~160 launches), the
                                in-tree cross-check of the fused chains */
   int last_level_cls_only;  /* 1 (inference opt-in): final_cls / final_cls2 are not evaluated --

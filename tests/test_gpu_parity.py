@@ -651,6 +651,12 @@ def test_frames_in_flight_equal_sequential(T, head):
     lane, (outs8, _) = pipe8.launch(0)
     pipe8.wait(lane)
     np.testing.assert_allclose(outs8['all_bbox_preds'].cpu().numpy(), want[1][1].cpu().numpy(), atol=2e-4, rtol=0)
+    # 16-row tiles (one weight buffer refilled in place, two workgroups per CU)
+    pipe16 = FramePipeline(head, lanes[1:], tile_rows=16)
+    lane, (outs16, _) = pipe16.launch(0)
+    pipe16.wait(lane)
+    np.testing.assert_allclose(outs16['all_bbox_preds'].cpu().numpy(), want[1][1].cpu().numpy(), atol=2e-4, rtol=0)
+    np.testing.assert_allclose(outs16['all_cls_scores'].cpu().numpy(), want[1][0].cpu().numpy(), atol=2e-4, rtol=0)
     outs4, _ = bench.one_step(head, lanes[1])                 # per-call option: nothing process-wide changed
     assert torch.equal(outs4['all_bbox_preds'], want[1][1])
 

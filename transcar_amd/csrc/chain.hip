@@ -372,16 +372,39 @@ struct ItemSteps {
     __builtin_amdgcn_sched_barrier(0);
     ItemSteps<NG, PF, J + 1>::run(acc, wb, ar, nx, np);
   }
+  // ONE buffer, refilled in place: fragment J of the NEXT item is loaded into the registers of
+  // fragment J as soon as its 4 * NG MFMAs have been issued (the matrix pipe reads its operands at
+  // issue; the load writes them hundreds of cycles later).  The 16-row tiles use this: 256 MFMAs
+  // per 16 KiB item leave every fragment a whole item time (~2300 cycles) to arrive, and without
+  // the second buffer the kernel fits 256 registers -- two workgroups per CU.
+  static __device__ __forceinline__ void run_inplace(Acc<NG>& acc, WBuf& wb, const float4* ar, const float* np) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      acc.v[g][0] = MFMA44(ar[g].x, wb.b[J].x, acc.v[g][0], J);
+      acc.v[g][1] = MFMA44(ar[g].y, wb.b[J].y, acc.v[g][1], J);
+      acc.v[g][0] = MFMA44(ar[g].z, wb.b[J].z, acc.v[g][0], J);
+      acc.v[g][1] = MFMA44(ar[g].w, wb.b[J].w, acc.v[g][1], J);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    wb.b[J] = ld4(np + J * 256);
+    __builtin_amdgcn_sched_barrier(0);
+    ItemSteps<NG, PF, J + 1>::run_inplace(acc, wb, ar, np);
+  }
 };
 template <int NG, bool PF>
 struct ItemSteps<NG, PF, 16> {
   static __device__ __forceinline__ void run(Acc<NG>&, const WBuf&, const float4*, WBuf&, const float*) {}
+  static __device__ __forceinline__ void run_inplace(Acc<NG>&, WBuf&, const float4*, const float*) {}
 };
 
 template <int NG, bool PF>
 __device__ __forceinline__ void wcompute(Acc<NG>& acc, const WBuf& wb, const float4* ar, WBuf& nx,
                                          const float* np) {
   ItemSteps<NG, PF, 0>::run(acc, wb, ar, nx, np);
+}
+template <int NG>
+__device__ __forceinline__ void wcompute_inplace(Acc<NG>& acc, WBuf& wb, const float4* ar, const float* np) {
+  ItemSteps<NG, true, 0>::run_inplace(acc, wb, ar, np);
 }
 
 // lane n holds y[4g + i][64*tile + n] in acc.v[g][*][i]
@@ -513,6 +536,7 @@ __device__ __forceinline__ bool linear_step(const LinSpec& s, WBuf& w0, bool pre
   // item = (tile tt, k block kb), kb fastest; tracked incrementally (no divisions)
   int tt = 0, kb = 0;
   const float* wcur = wbase;
+  constexpr bool INPLACE = (R == 16);      // one weight buffer, refilled in place (see ItemSteps::run_inplace)
   auto run = [&](const WBuf& wb, WBuf& nx, auto pf, const float* np_last) {
     constexpr bool PF = decltype(pf)::value;
     const float* np = wcur;
@@ -537,7 +561,8 @@ __device__ __forceinline__ bool linear_step(const LinSpec& s, WBuf& w0, bool pre
       if (a2row != nullptr)
         ar[g] = add4(ar[g], *reinterpret_cast<const float4*>(a2row + 4 * g * s.src2_ld + kb * KB));
     }
-    wcompute<NG, PF>(acc, wb, ar, nx, nload);
+    if constexpr (INPLACE) wcompute_inplace<NG>(acc, nx, ar, nload);      // wb and nx are the same buffer
+    else wcompute<NG, PF>(acc, wb, ar, nx, nload);
     if (stamp_items && tt == 0 && kb < 2) SUB_STAMP(23 + 5 * kb);
     if (kb == nkb - 1) {
       // The epilogue REBUILDS its view of the step from the LDS record (behind an opaque
@@ -555,7 +580,6 @@ __device__ __forceinline__ bool linear_step(const LinSpec& s, WBuf& w0, bool pre
     wcur = np; tt = nt; kb = nk;
   };
   using Yes = std::integral_constant<bool, true>;
-  WBuf w1;
   SUB_STAMP(1);
   if (CHAIN_DBG(s.dbg) & 32) return false;
   if (!preloaded) {
@@ -563,6 +587,17 @@ __device__ __forceinline__ bool linear_step(const LinSpec& s, WBuf& w0, bool pre
     __builtin_amdgcn_sched_barrier(0);
   }
   SUB_STAMP(2);
+  if constexpr (INPLACE) {
+    const float* fb = wbase;
+#pragma unroll 1
+    for (int it = 0; it < nitems; ++it) {
+      const bool last = it + 1 >= nitems;
+      run(w0, w0, Yes{}, last ? (next_first != nullptr ? next_first + 4 * lane : fb) : nullptr);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    return next_first != nullptr;
+  }
+  WBuf w1;
   // Two copies of the item body only (w0 -> w1, w1 -> w0): every item prefetches -- the next
   // item of the step, the first item of the wave's next linear step (`next_first`), or, when
   // there is neither, a harmless re-read (16 KiB at the end of a run of steps).
@@ -1010,7 +1045,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
 }
 
 template <int R, int PROG, bool DROP = false>
-__global__ __launch_bounds__(CH_NT, R <= 8 ? 2 : 1) void chain_kernel(ChainDev k, Recs<rec_cap(PROG)> recs) {
+__global__ __launch_bounds__(CH_NT, 2) void chain_kernel(ChainDev k, Recs<rec_cap(PROG)> recs) {
   chain_body<R, PROG, DROP>(k, recs.s, blockIdx.x);
 }
 
@@ -1019,7 +1054,7 @@ __global__ __launch_bounds__(CH_NT, R <= 8 ? 2 : 1) void chain_kernel(ChainDev k
 // encoders this way: as a branch of the hipGraph on a side stream, the fork and the join
 // each left a ~10 us hole in the replayed frame (profiles: rocprofv3 kernel trace).
 template <int RA, int RB, int PROGB>
-__global__ __launch_bounds__(CH_NT, RA <= 8 ? 2 : 1) void chain_dual_kernel(ChainDev ka, ChainDev kb, int na,
+__global__ __launch_bounds__(CH_NT, 2) void chain_dual_kernel(ChainDev ka, ChainDev kb, int na,
                                                            Recs<rec_cap(PROG_DECODER)> ra,
                                                            Recs<rec_cap(PROGB)> rb) {
   if ((int)blockIdx.x < na) chain_body<RA, PROG_DECODER>(ka, ra.s, blockIdx.x);
@@ -1170,14 +1205,14 @@ void init_k(ChainK& k) {
 #endif
 }
 
-// Row-tile height (measured, bench.py --batch 1/2/3/4/8): 4 rows while that gives about one
-// workgroup per CU (B = 1: 225 workgroups), 8 beyond.  Both run two workgroups per CU.  16-row
-// tiles (each weight register feeds 4 MFMAs, but 304 VGPRs and 120 KB of LDS: one workgroup per
-// CU) were the choice for B >= 3 until the item loop shrank; now they lose to 8 rows everywhere
-// (B = 4, one step at a time: 3410 vs 3770 frames/s) and remain selectable (tc_set_chain_tile_rows).
+// Row-tile height (measured, bench.py --pair 1/2/4/8): 4 rows while that gives about one
+// workgroup per CU (one frame: 225 workgroups), 8 rows up to two frames per launch, 16 beyond.
+// All three run two workgroups per CU: the 16-row tiles since round 2 (four LDS units = 76 KB,
+// one weight buffer refilled in place = 239 VGPRs; before: 120 KB / 304 VGPRs, one per CU, and
+// they lost to 8 rows everywhere).  4 frames per launch x 3 lanes: 4214 (8 rows) -> 4597 frames/s.
 // The height is a per-call argument (tc_head_options.chain_tile_rows / tile_rows of
 // tc_decoder_layer_tail_fwd): no process-global state.
-int tile_rows(const ChainK& k) { return k.tile_rows ? k.tile_rows : (k.M <= 1024 ? 4 : 8); }
+int tile_rows(const ChainK& k) { return k.tile_rows ? k.tile_rows : (k.M <= 1024 ? 4 : k.M <= 2048 ? 8 : 16); }
 
 template <int PROG>
 int launch_rows(const ChainK& k, hipStream_t s, const char* what) {

@@ -95,7 +95,7 @@ struct DecoderChainArgs {
   float* hs; float* qk; float* vt; int qpad;
   CamSampleArgs cam;                         // feats, lidar2img, pc, img size (ref/logits/out unused)
   int code, M;
-  int tile_rows = 0;                         // 0: automatic (4 up to 1024 rows, 8 beyond), 4, 8, 16
+  int tile_rows = 0;                         // 0: automatic (4 up to 1024 rows, 8 up to 2048, 16 beyond), 4, 8, 16
   // train-mode statistics of the frozen decoder (thr 0 = eval): drop.site is the site of THIS
   // layer's attention probabilities (16 + 8 * layer); the chain's four sites are drop.site + 1
   // (self-attention output), + 2 (cross-attention output, XFMR:378), + 3 (FFN hidden), + 4 (FFN output)
