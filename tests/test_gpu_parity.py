@@ -738,6 +738,24 @@ def test_pipeline_producer_rewrites_lane_inputs(T, head):
     for fidx in range(nframes):
         for a_, b_ in zip(got[fidx], want[fidx]):
             assert torch.equal(a_, b_), 'frame %d' % fidx
+    # the same with the H2D copies inside the lanes' graphs: the producer only touches pinned host memory
+    spipe = FramePipeline(head, lanes, host_staging=True)
+    got2 = [None] * nframes
+    for fidx in range(nframes):
+        lane = fidx % nl
+        spipe.host_wait(lane)
+        h = spipe.host_inputs(lane)
+        h['tokens'].copy_(host[fidx]['tokens'])
+        h['l2i'].copy_(host[fidx]['l2i'])
+        spipe.write_inputs(lane, nhwc=host[fidx]['nhwc'])
+        _, (outs, dec) = spipe.launch(lane)
+        with torch.cuda.stream(spipe.streams[lane]):
+            got2[fidx] = (outs['all_bbox_preds'].clone(), outs['all_cls_scores'].clone(), dec[0].clone())
+    spipe.synchronize()
+    torch.cuda.synchronize()
+    for fidx in range(nframes):
+        for a_, b_ in zip(got2[fidx], want[fidx]):
+            assert torch.equal(a_, b_), 'staged frame %d' % fidx
     # a frame packed to another token count is refused, not silently mis-read
     tok_np, pm = R.pack_tokens([frames[0]['radar_feats'][0]], T=320)
     with pytest.raises(T.TransCARHipError):
