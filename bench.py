@@ -70,6 +70,9 @@ def parse(argv=None):
     ap.add_argument('--tile-rows', type=int, default=0, choices=[0, 4, 8, 16],
                     help='row-tile height of the fused chains in the frame pipeline (0 = automatic)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--last-cls-only', action='store_true',
+                    help='inference opt-in tc_head_options.last_level_cls_only: final_cls / final_cls2 are not '
+                         'evaluated (get_bboxes decodes level 3 only); NOT the reference output contract')
     ap.add_argument('--main-only', action='store_true',
                     help='only the main timed loop: no single-lane, roofline, delivery, hand-off, batched or CPU '
                          'side measurements (kernel traces of tools/profile_round.sh)')
@@ -763,7 +766,9 @@ def main(argv=None):
         first = inp if pair == 1 else make_inputs(head, dev, args.shapes, fpl, seed=1 + rank)
         lanes = [first] + [make_inputs(head, dev, args.shapes, fpl, seed=101 + rank + 7 * i)
                            for i in range(1, max(1, args.lanes))]
-        pipe = FramePipeline(head, lanes, tile_rows=args.tile_rows or None)
+        from transcar_amd.detr3d_head import head_options
+        pipe = FramePipeline(head, lanes, options=head_options(tile_rows=args.tile_rows or None,
+                                                              last_level_cls_only=args.last_cls_only))
 
     def step():
         if pipe is None:
@@ -807,6 +812,7 @@ def main(argv=None):
                    'frames_per_launch': 1 if pipe is None else pipe.frames_per_launch,
                    'frames_in_flight': 1 if pipe is None else pipe.lanes * pipe.frames_per_launch,
                    'chain_tile_rows': args.tile_rows or 'auto',
+                   'last_level_cls_only': bool(args.last_cls_only),
                    'launcher': launcher_name(),
                    'parallelism': 'dp%d (frames sharded, no data-path collective)' % world},
     }
