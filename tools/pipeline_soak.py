@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Soak test of transcar_amd.pipeline.FramePipeline: thousands of overlapping launches on static
-inputs must keep giving bit-identical outputs per lane (a lane sharing a buffer with another would not)."""
+inputs must keep giving bit-identical outputs per lane (a lane sharing a buffer with another would not;
+neither would a weight fragment overwritten before its MFMAs have read it -- the 16-row tiles refill
+their one weight buffer in place).
+    python tools/pipeline_soak.py [launches] [frames per launch: 1 (4-row tiles) | 2 (8) | 4 (16)]"""
 import os
 import sys
 
@@ -14,10 +17,11 @@ from transcar_amd.pipeline import FramePipeline            # noqa: E402
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+    fpl = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     dev = torch.device('cuda:0')
     torch.set_grad_enabled(False)
     head, _ = bench.build_head(dev)
-    lanes = [bench.make_inputs(head, dev, 'res101', 1, seed=1 + i) for i in range(3)]
+    lanes = [bench.make_inputs(head, dev, 'res101', fpl, seed=1 + i) for i in range(3)]
     pipe = FramePipeline(head, lanes)
     for _ in range(3):
         pipe.launch()
@@ -36,7 +40,7 @@ def main():
         outs, dec = pipe.outputs[i]
         got = [outs['all_cls_scores'], outs['all_bbox_preds'], dec[0], dec[1]]
         bad += sum(0 if torch.equal(a, b) else 1 for a, b in zip(got, ref[i]))
-    print('launches %d, mismatching tensors %d' % (n, bad))
+    print('launches %d of %d frame(s), mismatching tensors %d' % (n, fpl, bad))
     return 1 if bad else 0
 
 
