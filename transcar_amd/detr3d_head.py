@@ -170,6 +170,9 @@ class Detr3DHead(BaseModule):
         self._weights = None
         self._workspace = {}
         self._packed = None
+        #: the trainable (radar) weights changed in place since they were last re-packed
+        #: (an optimizer step): the next forward / pipeline replay that reads them re-packs first
+        self._packed_dirty = False
         #: bumped whenever a device buffer a captured hipGraph may point at (packed weights,
         #: lane workspaces) is re-allocated: FramePipeline refuses to replay a stale capture
         self.buffers_generation = 0
@@ -290,13 +293,35 @@ class Detr3DHead(BaseModule):
             C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
             'tc_head_pack_weights')
         self._weights = w
+        self._packed_dirty = False
         return w
 
     def refresh_weights(self):
         """Re-read the parameter pointers and re-pack the weights; call after
-        the parameters were changed in place (e.g. an optimizer step)."""
+        the parameters were changed in place (e.g. an optimizer step) or moved
+        (a flat optimizer bucket): captured graphs also hold the un-packed
+        pointers (biases, LayerNorm affine), so moved parameters bump
+        buffers_generation and a FramePipeline refuses to replay until recapture()."""
+        old = bytes(self._weights) if self._weights is not None else None
         self._weights = None
-        return self.head_weights()
+        w = self.head_weights()
+        if old is not None and bytes(w) != old:
+            self.buffers_generation += 1
+        return w
+
+    def mark_trainable_dirty(self):
+        """The trainable parameters were updated in place (optimizer step on the flat bucket).
+        Re-packing them for the fused inference chains is deferred to the next consumer: a
+        training iteration never reads the packed radar weights (the frozen decoder's are
+        constant, the trainable stack runs on the checkpoint layout), so the 34-launch re-pack
+        per iteration was wasted work there."""
+        self._packed_dirty = True
+
+    def sync_packed_weights(self):
+        """Re-pack the trainable weights now if an optimizer step left them stale (enqueue-only)."""
+        if self._packed_dirty and self._weights is not None:
+            self.repack_weights(trainable_only=True)
+        self._packed_dirty = False
 
     def repack_weights(self, trainable_only=False):
         """Re-run the weight re-layout into the existing packed buffer: the
@@ -350,6 +375,8 @@ class Detr3DHead(BaseModule):
         if not _allow_train:
             require_eval(self)
         w = self.head_weights()
+        if not decoder_only:
+            self.sync_packed_weights()
         packed = self._packed_view
         if decoder_only:
             def _no_radar(src):

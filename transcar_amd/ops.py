@@ -246,6 +246,7 @@ def radar_fusion(head, hs_last, ref_last, prev_box, tokens, pad_mult, first_laye
     (all_cls [3,B,Q,ncls], all_box [3,B,Q,code], hits [3,B,Q]); only the slices of
     the layers that ran are written (the rest is NaN / -1)."""
     head.head_weights()
+    head.sync_packed_weights()
     pv = head._packed_view
     B, Q = hs_last.shape[:2]
     T = tokens.shape[1]

@@ -133,6 +133,7 @@ class FramePipeline:
             raise TransCARHipError(
                 'FramePipeline: the head re-allocated device buffers (packed weights / workspaces) '
                 'after these graphs were captured; call recapture()')
+        self.head.sync_packed_weights()                # an optimizer step since the last replay (current stream)
         i = self._next if lane is None else lane
         self._next = (i + 1) % self.lanes
         s = self.streams[i]

@@ -215,7 +215,7 @@ class FusionTrainer:
             float(self.lr if lr is None else lr), self.betas[0], self.betas[1], self.eps,
             self.weight_decay, self.iter, 1.0 / world, float(self.max_norm or 0.0),
             self.sq.data_ptr(), self._stream()), 'tc_adamw_step')
-        self.head.repack_weights(trainable_only=True)
+        self.head.mark_trainable_dirty()      # re-packed lazily by the next inference forward / replay
 
     def step(self, mlvl_feats, img_metas, gt_bboxes_list, gt_labels_list, lr=None):
         """One iteration on this rank's frame(s); returns the loss dict (detached)."""
