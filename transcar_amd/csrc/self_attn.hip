@@ -27,6 +27,7 @@ namespace tc {
 #define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 constexpr int SA_NW = 8;
+constexpr float SA_TAU = 8.0f;       // re-centre when a score exceeds the running reference by 2^8
 
 // max over the four lanes c, c+16, c+32, c+48 (they hold the same query column) on
 // the VALU: gfx950's v_permlane32_swap / v_permlane16_swap exchange half-waves /
@@ -45,15 +46,82 @@ __device__ __forceinline__ float max_lanes_16_32(float x) {
 
 struct KVFrag { float4 ka, kb, v0, v1; };
 
-__device__ __forceinline__ KVFrag load_kv(const float* __restrict__ k, const float* vbase, int ld,
-                                          int ldt, size_t brow, int h, int key0, int r, int g, int Q) {
+// per-lane pointers of a wave's current key tile: K rows (lane r = key, 8 channels of group g) and
+// the two V^T channel rows (r, r + 16; 4 keys of group g); advanced by whole strides, no index math
+struct KVPtr { const float* k; const float* v0; const float* v1; };
+
+__device__ __forceinline__ KVFrag load_kv(const KVPtr& p) {
   KVFrag f;
-  const int krow = min(key0 + r, Q - 1);
-  const float* kp = k + (brow + krow) * ld + h * 32 + 8 * g;
-  f.ka = ld4(kp); f.kb = ld4(kp + 4);
-  f.v0 = ld4(vbase + key0 + 4 * g);
-  f.v1 = ld4(vbase + (size_t)16 * ldt + key0 + 4 * g);
+  f.ka = ld4(p.k); f.kb = ld4(p.k + 4);
+  f.v0 = ld4(p.v0); f.v1 = ld4(p.v1);
   return f;
+}
+
+// "does any of the four scores exceed tau (> 0)?" on the integer unit: for non-NaN floats x > tau is the
+// signed comparison of the bit patterns (negative floats are negative integers), and v_max3_i32 needs no
+// canonicalising v_max per MFMA-produced operand as an fmaxf chain does.  (NOT inline asm: hipcc's hazard
+// recogniser does not see inside it and the MFMA -> VALU read needs its wait states.)
+__device__ __forceinline__ bool any_above(float a, float b, float c, float d, float tau) {
+  const int m = max(max(max(__builtin_bit_cast(int, a), __builtin_bit_cast(int, b)), __builtin_bit_cast(int, c)),
+                    __builtin_bit_cast(int, d));
+  return m > __builtin_bit_cast(int, tau);
+}
+
+// Running softmax state of one 16-query sub-tile: O^T (2 x 16 channels x 16 queries), the partial
+// normaliser and the NEGATED running reference as the four equal entries of an MFMA C operand.
+struct SAState { f32x4 o0, o1, negm; float l; };
+
+// One 16-key tile against one 16-query sub-tile.
+//
+// Lazy re-centring: on gfx950 every VALU instruction costs the f32 MFMA pipe its issue cycles (the
+// f32 matrix instructions run on the same FMA lanes: tools/issue_probe.hip), so the softmax
+// bookkeeping is kept off the common path.  The scores leave the MFMA chain already relative to the
+// running reference (-negm is the chain's C operand), and as long as none exceeds it by more than
+// SA_TAU (p <= 2^SA_TAU: harmless in fp32) a tile costs max + compare + 4 exp + 3 add.  Only a tile
+// that does (always the wave's first) pays for the cross-lane max, alpha and the rescale of O.
+// softmax is shift invariant: the result is the running-max formulation's up to rounding.
+// nvalid < 16 (the ragged last tile): keys >= nvalid are masked.
+template <bool DROP>
+__device__ __forceinline__ void sa_tile(const KVFrag& f, const float4& qa, const float4& qb, SAState& st,
+                                        bool first, int nvalid, int g, const DropK& drop, unsigned drop_base) {
+  f32x4 s = MFMA4(f.ka.x, qa.x, st.negm);
+  s = MFMA4(f.ka.y, qa.y, s); s = MFMA4(f.ka.z, qa.z, s); s = MFMA4(f.ka.w, qa.w, s);
+  s = MFMA4(f.kb.x, qb.x, s); s = MFMA4(f.kb.y, qb.y, s);
+  s = MFMA4(f.kb.z, qb.z, s); s = MFMA4(f.kb.w, qb.w, s);
+  // s[i] = log2(e) * S^T[key0 + 4g + i][query r] + negm
+  float s0 = s[0], s1 = s[1], s2 = s[2], s3 = s[3];
+  float4 v0 = f.v0, v1 = f.v1;
+  if (nvalid < 16) {                                   // wave-uniform
+    const int kk = 4 * g;
+    if (kk + 0 >= nvalid) { s0 = -INFINITY; v0.x = 0.f; v1.x = 0.f; }
+    if (kk + 1 >= nvalid) { s1 = -INFINITY; v0.y = 0.f; v1.y = 0.f; }
+    if (kk + 2 >= nvalid) { s2 = -INFINITY; v0.z = 0.f; v1.z = 0.f; }
+    if (kk + 3 >= nvalid) { s3 = -INFINITY; v0.w = 0.f; v1.w = 0.f; }
+  }
+  if (first || __builtin_amdgcn_ballot_w64(any_above(s0, s1, s2, s3, SA_TAU)) != 0) {
+    const float mx = max_lanes_16_32(fmaxf(fmaxf(s0, s1), fmaxf(s2, s3)));   // finite: key 0 of every tile is valid
+    const float delta = first ? mx : fmaxf(mx, 0.0f);
+    const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);   // first tile: l = O = 0
+    s0 -= delta; s1 -= delta; s2 -= delta; s3 -= delta;
+    st.l *= alpha;
+    st.o0 *= alpha; st.o1 *= alpha;
+    st.negm -= delta;
+  }
+  const float p0 = __builtin_amdgcn_exp2f(s0), p1 = __builtin_amdgcn_exp2f(s1);
+  const float p2 = __builtin_amdgcn_exp2f(s2), p3 = __builtin_amdgcn_exp2f(s3);
+  st.l += (p0 + p1) + (p2 + p3);
+  float d0 = p0, d1 = p1, d2 = p2, d3 = p3;
+  if (DROP) {
+    d0 = drop_keep(drop.seed, drop.site, drop_base + 0, drop.thr) ? p0 * drop.scale : 0.0f;
+    d1 = drop_keep(drop.seed, drop.site, drop_base + 1, drop.thr) ? p1 * drop.scale : 0.0f;
+    d2 = drop_keep(drop.seed, drop.site, drop_base + 2, drop.thr) ? p2 * drop.scale : 0.0f;
+    d3 = drop_keep(drop.seed, drop.site, drop_base + 3, drop.thr) ? p3 * drop.scale : 0.0f;
+  }
+  // O^T[d][q] += V^T[d][key] P^T[key][q]
+  st.o0 = MFMA4(v0.x, d0, st.o0); st.o1 = MFMA4(v1.x, d0, st.o1);
+  st.o0 = MFMA4(v0.y, d1, st.o0); st.o1 = MFMA4(v1.y, d1, st.o1);
+  st.o0 = MFMA4(v0.z, d2, st.o0); st.o1 = MFMA4(v1.z, d2, st.o1);
+  st.o0 = MFMA4(v0.w, d3, st.o0); st.o1 = MFMA4(v1.w, d3, st.o1);
 }
 
 // QT = 16-query sub-tiles per workgroup: the K/V fragments of a key tile are loaded
@@ -74,93 +142,70 @@ __global__ __launch_bounds__(SA_NW * 64) void self_attn_kernel(const float* __re
   __shared__ float sm_m[SA_NW][QT][16];
   __shared__ float sm_l[SA_NW][QT][64];
   __shared__ float4 sm_o[SA_NW][QT][2][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, g = lane >> 4;
   const int q0 = blockIdx.x * 16 * QT, h = blockIdx.y, b = blockIdx.z;
   const size_t brow = (size_t)b * Q;
 
   float4 qa[QT], qb[QT];
+  SAState st[QT];
+  unsigned dbase[QT];
 #pragma unroll
   for (int u = 0; u < QT; ++u) {
     const int qrow = min(q0 + 16 * u + r, Q - 1);
     const float* qp = q + (brow + qrow) * ld + h * 32 + 8 * g;
     qa[u] = ld4(qp); qb[u] = ld4(qp + 4);
+    st[u].o0 = f32x4{0.f, 0.f, 0.f, 0.f}; st[u].o1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    st[u].negm = f32x4{0.f, 0.f, 0.f, 0.f}; st[u].l = 0.0f;
+    dbase[u] = DROP ? (((unsigned)b * gridDim.y + h) * Q + (unsigned)qrow) * Q + 4 * g : 0u;
   }
-  const float* vbase = vt + ((size_t)b * C + h * 32 + r) * ldt;
-
-  f32x4 o0[QT], o1[QT];
-  float m[QT], lpart[QT];
+  // the wave's key tiles: wave, wave + NW, ... among the nfull whole tiles (two fragment buffers,
+  // each loaded one tile ahead), then the ragged tile if it is this wave's turn
+  const int nfull = Q >> 4;
+  const int n = wave < nfull ? (nfull - wave + SA_NW - 1) / SA_NW : 0;
+  const size_t kstep = (size_t)SA_NW * 16 * ld;
+  KVPtr p;
+  p.k = k + (brow + wave * 16 + r) * ld + h * 32 + 8 * g;
+  p.v0 = vt + ((size_t)b * C + h * 32 + r) * ldt + wave * 16 + 4 * g;
+  p.v1 = p.v0 + (size_t)16 * ldt;
+  auto advance = [&]() { p.k += kstep; p.v0 += SA_NW * 16; p.v1 += SA_NW * 16; };
+  auto tile = [&](const KVFrag& f, int i, int nvalid) {
 #pragma unroll
-  for (int u = 0; u < QT; ++u) {
-    o0[u] = f32x4{0.f, 0.f, 0.f, 0.f}; o1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    m[u] = -INFINITY; lpart[u] = 0.0f;
+    for (int u = 0; u < QT; ++u)
+      sa_tile<DROP>(f, qa[u], qb[u], st[u], i == 0, nvalid, g, drop, dbase[u] + (unsigned)(wave + i * SA_NW) * 16u);
+  };
+  KVFrag fa, fb;
+  if (n > 0) fa = load_kv(p);
+  int i = 0;
+  for (; i + 2 <= n; i += 2) {
+    advance();
+    fb = load_kv(p);                       // i + 1 < n
+    __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of this tile's MFMAs
+    tile(fa, i, 16);
+    advance();
+    if (i + 2 < n) fa = load_kv(p);
+    __builtin_amdgcn_sched_barrier(0);
+    tile(fb, i + 1, 16);
   }
-  const int ntiles = (Q + 15) / 16;
-  int t = wave;
-  KVFrag cur;
-  if (t < ntiles) cur = load_kv(k, vbase, ld, ldt, brow, h, t * 16, r, g, Q);
-  for (; t < ntiles; t += SA_NW) {
-    const int key0 = t * 16;
-    KVFrag nxt = cur;
-    if (t + SA_NW < ntiles) nxt = load_kv(k, vbase, ld, ldt, brow, h, (t + SA_NW) * 16, r, g, Q);
-    __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this tile's MFMAs
-    float4 v0 = cur.v0, v1 = cur.v1;
-    const bool ragged = key0 + 16 > Q;   // wave-uniform
-    const int kk = key0 + 4 * g;
-    if (ragged) {
-      if (kk + 0 >= Q) { v0.x = 0.f; v1.x = 0.f; }
-      if (kk + 1 >= Q) { v0.y = 0.f; v1.y = 0.f; }
-      if (kk + 2 >= Q) { v0.z = 0.f; v1.z = 0.f; }
-      if (kk + 3 >= Q) { v0.w = 0.f; v1.w = 0.f; }
-    }
-#pragma unroll
-    for (int u = 0; u < QT; ++u) {
-      f32x4 s = {0.f, 0.f, 0.f, 0.f};
-      s = MFMA4(cur.ka.x, qa[u].x, s); s = MFMA4(cur.ka.y, qa[u].y, s);
-      s = MFMA4(cur.ka.z, qa[u].z, s); s = MFMA4(cur.ka.w, qa[u].w, s);
-      s = MFMA4(cur.kb.x, qb[u].x, s); s = MFMA4(cur.kb.y, qb[u].y, s);
-      s = MFMA4(cur.kb.z, qb[u].z, s); s = MFMA4(cur.kb.w, qb[u].w, s);
-      // s[i] = log2(e) * S^T[key0 + 4g + i][q0 + 16u + r]
-      float s0 = s[0], s1 = s[1], s2 = s[2], s3 = s[3];
-      if (ragged) {
-        if (kk + 0 >= Q) s0 = -INFINITY;
-        if (kk + 1 >= Q) s1 = -INFINITY;
-        if (kk + 2 >= Q) s2 = -INFINITY;
-        if (kk + 3 >= Q) s3 = -INFINITY;
-      }
-      float mx = fmaxf(fmaxf(s0, s1), fmaxf(s2, s3));
-      mx = max_lanes_16_32(mx);
-      const float mnew = fmaxf(m[u], mx);           // finite: key0 + 0 < Q in every tile
-      const float alpha = __builtin_amdgcn_exp2f(m[u] - mnew);
-      const float p0 = __builtin_amdgcn_exp2f(s0 - mnew), p1 = __builtin_amdgcn_exp2f(s1 - mnew);
-      const float p2 = __builtin_amdgcn_exp2f(s2 - mnew), p3 = __builtin_amdgcn_exp2f(s3 - mnew);
-      lpart[u] = lpart[u] * alpha + ((p0 + p1) + (p2 + p3));
-      m[u] = mnew;
-      o0[u] *= alpha; o1[u] *= alpha;
-      float d0 = p0, d1 = p1, d2 = p2, d3 = p3;
-      if (DROP) {
-        const unsigned qi = (unsigned)min(q0 + 16 * u + r, Q - 1);
-        const unsigned base = (((unsigned)b * gridDim.y + h) * Q + qi) * Q + kk;
-        d0 = drop_keep(drop.seed, drop.site, base + 0, drop.thr) ? p0 * drop.scale : 0.0f;
-        d1 = drop_keep(drop.seed, drop.site, base + 1, drop.thr) ? p1 * drop.scale : 0.0f;
-        d2 = drop_keep(drop.seed, drop.site, base + 2, drop.thr) ? p2 * drop.scale : 0.0f;
-        d3 = drop_keep(drop.seed, drop.site, base + 3, drop.thr) ? p3 * drop.scale : 0.0f;
-      }
-      // O^T[d][q] += V^T[d][key] P^T[key][q]
-      o0[u] = MFMA4(v0.x, d0, o0[u]); o1[u] = MFMA4(v1.x, d0, o1[u]);
-      o0[u] = MFMA4(v0.y, d1, o0[u]); o1[u] = MFMA4(v1.y, d1, o1[u]);
-      o0[u] = MFMA4(v0.z, d2, o0[u]); o1[u] = MFMA4(v1.z, d2, o1[u]);
-      o0[u] = MFMA4(v0.w, d3, o0[u]); o1[u] = MFMA4(v1.w, d3, o1[u]);
-    }
-    cur = nxt;
+  if (i < n) { tile(fa, i, 16); ++i; }
+  const int rag = Q & 15;
+  if (rag != 0 && wave == (nfull % SA_NW)) {           // i == n: this wave's next tile is the ragged one
+    KVPtr pr;
+    pr.k = k + (brow + min(nfull * 16 + r, Q - 1)) * ld + h * 32 + 8 * g;
+    pr.v0 = vt + ((size_t)b * C + h * 32 + r) * ldt + nfull * 16 + 4 * g;    // ldt >= 16 * (nfull + 1)
+    pr.v1 = pr.v0 + (size_t)16 * ldt;
+    const KVFrag fr = load_kv(pr);
+    tile(fr, i, rag);
+    ++i;
   }
+  const bool idle = i == 0;                             // a wave without a tile: weight 0 in the merge
   // merge the key slices
 #pragma unroll
   for (int u = 0; u < QT; ++u) {
-    if (g == 0) sm_m[wave][u][r] = m[u];
-    sm_l[wave][u][lane] = lpart[u];
-    sm_o[wave][u][0][lane] = make_float4(o0[u][0], o0[u][1], o0[u][2], o0[u][3]);
-    sm_o[wave][u][1][lane] = make_float4(o1[u][0], o1[u][1], o1[u][2], o1[u][3]);
+    if (g == 0) sm_m[wave][u][r] = idle ? -INFINITY : -st[u].negm[0];
+    sm_l[wave][u][lane] = st[u].l;
+    sm_o[wave][u][0][lane] = make_float4(st[u].o0[0], st[u].o0[1], st[u].o0[2], st[u].o0[3]);
+    sm_o[wave][u][1][lane] = make_float4(st[u].o1[0], st[u].o1[1], st[u].o1[2], st[u].o1[3]);
   }
   __syncthreads();
   // wave w finalises (sub-tile w/2, channel half w&1)
