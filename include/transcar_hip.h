@@ -34,7 +34,7 @@ extern "C" {
 #define TC_MAX_LEVELS 4
 #define TC_MAX_LAYERS 8
 #define TC_MAX_RADAR_LAYERS 3
-#define TC_ABI_VERSION 6
+#define TC_ABI_VERSION 7
 
 typedef void* tc_stream_t;
 
@@ -62,6 +62,10 @@ typedef struct {
   tc_linear ffn1;                   /* ffns.0.layers.1   [C,F]                */
   tc_lnorm norm2;
   tc_reg_branch reg;                /* reg_branches.{lid}                     */
+  /* Set by tc_head_pack_weights in the packed view only (0 in the caller's struct): every packed
+   * linear weight has a second copy, laid out for the 16-row tiles' 16x16x4 MFMA, this many FLOATS
+   * behind the first (the same distance for all weights of a packed buffer). */
+  size_t packed16_delta;
 } tc_decoder_layer;
 
 /* one radar fusion layer (HEAD:538-611 / :613-668 / :670-729) */
@@ -74,6 +78,7 @@ typedef struct {
   tc_cls_branch final_cls;          /* final_cls{,2,3}                        */
   tc_reg_branch final_reg;          /* final_reg{,2,3}                        */
   float radius_min, radius_max;     /* clamp: (1,2),(1,2),(0.5,1)  HEAD:567,635,693 */
+  size_t packed16_delta;            /* packed view only, as in tc_decoder_layer */
 } tc_radar_layer;
 
 /* All parameters Detr3DHead.forward reads (HEAD:43-238), in eval mode. */
@@ -96,6 +101,7 @@ typedef struct {
    * they are evaluated once per checkpoint, not once per forward. */
   const float* l0_init_reference;   /* [Q,3]  sigmoid(reference_points(query_pos))      */
   const float* l0_attn_out;         /* [Q,C]  softmax(q k^T / sqrt(d)) v of layer 0     */
+  size_t packed16_delta;            /* packed view only, as in tc_decoder_layer         */
 } tc_head_weights;
 
 /* multi-view FPN feature maps, channels-last: level l is [B*num_cams, H, W, C] */

@@ -651,12 +651,15 @@ def test_frames_in_flight_equal_sequential(T, head):
     lane, (outs8, _) = pipe8.launch(0)
     pipe8.wait(lane)
     np.testing.assert_allclose(outs8['all_bbox_preds'].cpu().numpy(), want[1][1].cpu().numpy(), atol=2e-4, rtol=0)
-    # 16-row tiles (one weight buffer refilled in place, two workgroups per CU)
+    # 16-row tiles (one weight buffer refilled in place, two workgroups per CU; v_mfma_f32_16x16x4 on the
+    # P16 weight copy: another summation order over k than the 4x4x1 tiles', so rounding-level differences
+    # go through the rig's loop gain, DESIGN.md section 3 -- measured 3e-4 on 1-3 of 27 000 values; against the
+    # oracle the 16-row tiles hold the same per-layer tolerances as the others, test_gpu_teacher_forced.py)
     pipe16 = FramePipeline(head, lanes[1:], tile_rows=16)
     lane, (outs16, _) = pipe16.launch(0)
     pipe16.wait(lane)
-    np.testing.assert_allclose(outs16['all_bbox_preds'].cpu().numpy(), want[1][1].cpu().numpy(), atol=2e-4, rtol=0)
-    np.testing.assert_allclose(outs16['all_cls_scores'].cpu().numpy(), want[1][0].cpu().numpy(), atol=2e-4, rtol=0)
+    np.testing.assert_allclose(outs16['all_bbox_preds'].cpu().numpy(), want[1][1].cpu().numpy(), atol=5e-4, rtol=0)
+    np.testing.assert_allclose(outs16['all_cls_scores'].cpu().numpy(), want[1][0].cpu().numpy(), atol=5e-4, rtol=0)
     outs4, _ = bench.one_step(head, lanes[1])                 # per-call option: nothing process-wide changed
     assert torch.equal(outs4['all_bbox_preds'], want[1][1])
 

@@ -95,8 +95,11 @@ def _qkv_from_oracle_state(sd, lid, x, pos):
     return q.float(), k.float(), vt.float()
 
 
-def test_decoder_layers_teacher_forced_on_bench_inputs(rig):
-    """HIP layer l (attention core + fused row chain) on the oracle's layer-(l-1) state and
+@pytest.mark.parametrize('tile_rows', [0, 8, 16])
+def test_decoder_layers_teacher_forced_on_bench_inputs(rig, tile_rows):
+    """Every tile height of the row chain (0 = the automatic choice, 4-row tiles at one frame; 8; 16 =
+    the v_mfma_f32_16x16x4 path on the second weight copy):
+    HIP layer l (attention core + fused row chain) on the oracle's layer-(l-1) state and
     reference points, l = 0..5, iid-noise ResNet-101 maps, full-scale refinement MLPs -- measured
     against the fp64 evaluation of the reference formula on the same inputs, next to the fp32
     oracle's own deviation from it.  Also: the refined reference points and the next layer's
@@ -117,7 +120,8 @@ def test_decoder_layers_teacher_forced_on_bench_inputs(rig):
         attn_o = ops.sdpa(gpu(q), gpu(k), gpu(vt))
         nxt = pv.layers[lid + 1].self_attn.in_proj if lid + 1 < L else None
         hs, ref_out, qk_next, vt_next = ops.decoder_layer_tail(
-            pv.layers[lid], nxt, rig['nhwc'], attn_o, gpu(x_prev), gpu(qe), l2i, gpu(ref_prev), PCR, HW)
+            pv.layers[lid], nxt, rig['nhwc'], attn_o, gpu(x_prev), gpu(qe), l2i, gpu(ref_prev), PCR, HW,
+            tile_rows=tile_rows)
         # the same layer: fp32 oracle (from the rig's trace) and fp64 evaluation of the same formula
         p = 'transformer.decoder.layers.%d.' % lid
         truth = O.decoder_layer(sd64, p, x_prev.permute(1, 0, 2).double(), pos.permute(1, 0, 2).double(),
@@ -183,8 +187,9 @@ def _hit_aware(got, want, got_hits, want_hits, tol, what):
     return agree
 
 
-def test_radar_layers_teacher_forced_on_bench_inputs(rig):
-    """The fused radar chain, ONE fusion layer at a time: layer r is fed the oracle's query
+@pytest.mark.parametrize('tile_rows', [0, 16])
+def test_radar_layers_teacher_forced_on_bench_inputs(rig, tile_rows):
+    """(4-row tiles and the 16-row tiles' 16x16x4 path.)  The fused radar chain, ONE fusion layer at a time: layer r is fed the oracle's query
     features and box of layer r-1 (hs[5] / the decoder's last box for r = 0) and must reproduce the
     oracle's class scores, boxes and hit counts of layer r; then all three layers in one launch from
     the oracle's hs[5] (the launch tc_head_forward makes)."""
@@ -208,7 +213,9 @@ def test_radar_layers_teacher_forced_on_bench_inputs(rig):
     ref5 = gpu(dbg['inter_refs'][-1])
     tmp = gpu(dbg['tmp'])                                     # the decoder's last box, metres
     # -- all three layers in one launch (what tc_head_forward does), from the oracle's decoder state
-    cls, box, hits = ops.radar_fusion(head, hs5, ref5, tmp, tokens, pad_mult, 0, 3)
+    from transcar_amd.detr3d_head import head_options
+    opt = head_options(tile_rows=tile_rows or None)
+    cls, box, hits = ops.radar_fusion(head, hs5, ref5, tmp, tokens, pad_mult, 0, 3, options=opt)
     agree0 = _hit_aware(box[0, 0].cpu().numpy(), want_box[0], hits[0, 0].cpu().numpy(), want_hits[0],
                         LAYER_TOL, 'fusion layer 1 box')
     _hit_aware(cls[0, 0].cpu().numpy(), want_cls[0], hits[0, 0].cpu().numpy(), want_hits[0],
@@ -230,7 +237,7 @@ def test_radar_layers_teacher_forced_on_bench_inputs(rig):
                              tokens_full[:, :, :2], rmin, rmax)
         cls_r, box_r, hits_r = ops.radar_fusion(head, gpu(qf.permute(1, 0, 2)),
                                                 ref5 if r == 0 else None, gpu(prev_box), tokens,
-                                                pad_mult, r, 1)
+                                                pad_mult, r, 1, options=opt)
         agree = _hit_aware(box_r[r, 0].cpu().numpy(), want_box[r], hits_r[r, 0].cpu().numpy(),
                            want_hits[r], LAYER_TOL, 'fusion layer %d box (teacher-forced)' % (r + 1))
         _hit_aware(cls_r[r, 0].cpu().numpy(), want_cls[r], hits_r[r, 0].cpu().numpy(), want_hits[r],

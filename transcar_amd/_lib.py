@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('TRANSCAR_HIP_LIB') or os.path.join(_HERE, 'lib', 'lib
 TC_MAX_LEVELS = 4
 TC_MAX_LAYERS = 8
 TC_MAX_RADAR_LAYERS = 3
-TC_ABI_VERSION = 6
+TC_ABI_VERSION = 7
 
 c_fp = C.c_void_p      # device pointers travel as integers
 
@@ -55,14 +55,14 @@ class tc_decoder_layer(C.Structure):
                 ('attention_weights', tc_linear), ('output_proj', tc_linear),
                 ('position_encoder', tc_pos_encoder), ('norm1', tc_lnorm),
                 ('ffn0', tc_linear), ('ffn1', tc_linear), ('norm2', tc_lnorm),
-                ('reg', tc_reg_branch)]
+                ('reg', tc_reg_branch), ('packed16_delta', C.c_size_t)]
 
 
 class tc_radar_layer(C.Structure):
     _fields_ = [('attn', tc_mha), ('norm2', tc_lnorm), ('linear1', tc_linear),
                 ('linear2', tc_linear), ('norm3', tc_lnorm),
                 ('final_cls', tc_cls_branch), ('final_reg', tc_reg_branch),
-                ('radius_min', C.c_float), ('radius_max', C.c_float)]
+                ('radius_min', C.c_float), ('radius_max', C.c_float), ('packed16_delta', C.c_size_t)]
 
 
 class tc_head_weights(C.Structure):
@@ -82,7 +82,7 @@ class tc_head_weights(C.Structure):
                 ('radar_feat0', tc_linear), ('radar_feat2', tc_linear),
                 ('radar_feat4', tc_linear),
                 ('radar', tc_radar_layer * TC_MAX_RADAR_LAYERS),
-                ('l0_init_reference', c_fp), ('l0_attn_out', c_fp)]
+                ('l0_init_reference', c_fp), ('l0_attn_out', c_fp), ('packed16_delta', C.c_size_t)]
 
 
 class tc_feats_nhwc(C.Structure):

@@ -269,6 +269,7 @@ struct ChainDev {
 // ... plus what only the host-side resolver needs
 struct ChainK : ChainDev {
   tc_linear pairs[MAX_PAIRS];
+  size_t w16_delta = 0;        // packed16_delta of the packed view: 16-row tiles read their own weight copy
 };
 
 constexpr int table_steps(int prog) {
@@ -501,6 +502,217 @@ __device__ __forceinline__ void lin_epilogue(const LinSpec& s, int tile, const A
   }
 }
 
+// ---- 16-row tiles: v_mfma_f32_16x16x4 on the P16 copy of the weights (pack.hip) --------------------
+// A single wave issues a v_mfma_f32_4x4x1 every 12.3 cycles, not 8 (tools/issue_probe.hip; 9.5 with
+// four waves per SIMD), a 16x16x4 every 34 of its 32: with all 16 rows of an MFMA in use the larger
+// instruction is 1.2-1.45x the matrix rate.  Per item (64 columns x 64 k) still 16 weight loads of
+// 1 KiB per wave, refilled in place; 64 MFMAs (4 column sub-tiles x 16 k groups of 4) instead of 256;
+// the A operand of a 16-wide k group is one ds_read_b128 (lane 16g + c: row c, k 16 kg + 4g .. + 3).
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+struct Acc16 { f32x4 v[4]; };     // v[j][i] = y[4g + i][64 tile + 16j + c] at lane 16g + c
+
+__device__ __forceinline__ float f4_at(const float4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+
+template <int J>
+struct ItemSteps16 {
+  // np: wave-uniform address of the next item, lo: the lane's float offset (scalar base + 32-bit
+  // vector offset: the address arithmetic of the 16 loads stays on the scalar unit)
+  static __device__ __forceinline__ void run(Acc16& acc, WBuf& wb, const float4* ar, const float* np, unsigned lo) {
+    const float a = f4_at(ar[J >> 2], J & 3);
+    acc.v[0] = MFMA16(a, wb.b[J].x, acc.v[0]);
+    acc.v[1] = MFMA16(a, wb.b[J].y, acc.v[1]);
+    acc.v[2] = MFMA16(a, wb.b[J].z, acc.v[2]);
+    acc.v[3] = MFMA16(a, wb.b[J].w, acc.v[3]);
+    __builtin_amdgcn_sched_barrier(0);
+    wb.b[J] = ld4(np + (size_t)(lo + J * 256u));   // fragment J of the next item, into fragment J's registers
+    __builtin_amdgcn_sched_barrier(0);
+    ItemSteps16<J + 1>::run(acc, wb, ar, np, lo);
+  }
+};
+template <>
+struct ItemSteps16<16> {
+  static __device__ __forceinline__ void run(Acc16&, WBuf&, const float4*, const float*, unsigned) {}
+};
+
+// lin_epilogue for the 16x16 accumulator layout: lane 16g + c holds rows 4g .. 4g + 3 of the columns
+// 64 tile + 16j + c, j = 0..3 (bv[j]: their biases)
+template <bool DROP>
+__device__ __forceinline__ void lin_epilogue16(const LinSpec& s, int tile, const Acc16& acc, int lane, const float* bv) {
+  const int c = lane & 15, g = lane >> 4;
+  const int col0 = tile * 64 + c;
+  if (col0 >= s.N) return;                       // columns 16j + c only grow with j
+  float y[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = col0 + 16 * j;
+    const float sc = (col < s.scale_cols) ? s.scale : 1.0f;
+    const float bias = s.bias != nullptr ? bv[j] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[j][i] = (acc.v[j][i] + bias) * sc;
+  }
+  if (s.act == 1) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) y[j][i] = fmaxf(y[j][i], 0.0f);
+  } else if (s.act == 2) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) y[j][i] = sigmoidf_(y[j][i]);
+  }
+  if (s.gate != nullptr) {
+    int gt_[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gt_[i] = s.gate[4 * g + i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) if (gt_[i] == 0) y[j][i] = 0.0f;
+  }
+  if (DROP) {
+    if (s.drop_site != 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const unsigned idx = (unsigned)(s.m0 + 4 * g + i) * (unsigned)s.N + (unsigned)(col0 + 16 * j);
+          y[j][i] = drop_keep(s.drop_seed, (unsigned)(s.drop_site - 1), idx, s.drop_thr) ? y[j][i] * s.drop_scale : 0.0f;
+        }
+    }
+  }
+  if (s.res != nullptr) {
+    float rr[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        rr[j][i] = col0 + 16 * j < s.N ? s.res[(4 * g + i) * s.res_ld + col0 + 16 * j] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) y[j][i] += rr[j][i];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = col0 + 16 * j;
+    if (col >= s.N) break;
+    if (s.dst != nullptr) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s.dst[(4 * g + i) * s.dst_ld + col] = y[j][i];
+    }
+    if (s.gdst != nullptr) {
+      float* gp = s.gdst + (size_t)s.m0 * s.gdst_ld + col;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (s.m0 + 4 * g + i < s.M) stg1(gp + (size_t)(4 * g + i) * s.gdst_ld, y[j][i]);
+    }
+    if (s.gt != nullptr) {
+      const int row0 = s.m0 + 4 * g;
+      if (row0 + 3 < s.M && (s.gt_rpb & 3) == 0) {
+        const int bb = row0 / s.gt_rpb, q = row0 - bb * s.gt_rpb;
+        st4(s.gt + ((size_t)bb * s.N + col) * s.gt_ld + q, make_float4(y[j][0], y[j][1], y[j][2], y[j][3]));
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = row0 + i;
+          if (row < s.M) {
+            const int bb = row / s.gt_rpb, q = row - bb * s.gt_rpb;
+            stg1(s.gt + ((size_t)bb * s.N + col) * s.gt_ld + q, y[j][i]);
+          }
+        }
+      }
+    }
+  }
+  // Global stores read their data registers late and gfx9 tracks that with vmcnt, which retires in
+  // order: hipcc, seeing stores that MAY have been issued (this epilogue sits in the item loop), put
+  // s_waitcnt vmcnt(1) / vmcnt(0) in front of the first operand reads of EVERY item -- i.e. every item
+  // waited for the weight loads issued at the end of the previous one (~600 cycles of 2600).  An
+  // explicit drain here, in the two steps of a layer that store, tells it nothing is pending there.
+  if (s.gdst != nullptr || s.gt != nullptr) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+}
+
+// linear_step for R = 16 (same contract: w0 may arrive preloaded with the step's first item, the last
+// item fetches `next_first`): one weight buffer refilled in place.
+template <bool DROP, bool SRC2, typename SpecFn>
+__device__ __forceinline__ bool linear_step16(const LinSpec& s, WBuf& w0, bool preloaded, const float* next_first,
+                                              SpecFn make_spec, int step_idx) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) - s.woff) & (CH_NW - 1);
+  const int ntiles = (s.N + 63) >> 6;
+  const int kpad = (s.K + 63) & ~63;
+  const int nkb = kpad / KB;
+  const int my_tiles = wave < ntiles ? (ntiles - wave + CH_NW - 1) / CH_NW : 0;
+  const int nitems = my_tiles * nkb;
+  // lane 16g + c reads row c, the 4 consecutive k of group g in every 16-wide k group
+  const float* arow = s.src + (lane & 15) * s.src_ld + 4 * (lane >> 4);
+  const float* a2row = SRC2 && s.src2 ? s.src2 + (lane & 15) * s.src2_ld + 4 * (lane >> 4) : nullptr;
+  const float* wbase = s.W + (size_t)wave * 64 * kpad;       // wave-uniform; the lane adds lo
+  const unsigned lo = 4u * lane;
+  const size_t tile_stride = (size_t)CH_NW * 64 * kpad;
+  Acc16 acc;
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+#ifdef TC_CHAIN_STAMPS
+  constexpr bool stamp_items = true;
+#else
+  constexpr bool stamp_items = false;
+#endif
+  SUB_STAMP(1);
+  if (CHAIN_DBG(s.dbg) & 32) return false;
+  if (!preloaded) {
+    wload(w0, wbase + lo, 16);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  SUB_STAMP(2);
+  // Nothing but this step's first weight item may be in flight when the item loop starts: a global
+  // store of an earlier step (LayerNorm -> hs, ...) still reading its data registers is enough for
+  // hipcc to put s_waitcnt vmcnt(1) / vmcnt(0) in front of the operand reads of EVERY item (vmcnt
+  // retires in order: each item then waited for the weight loads issued at the end of the one before).
+  __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
+  int tt = 0, kb = 0;
+  const float* wcur = wbase;
+#pragma unroll 1
+  for (int it = 0; it < nitems; ++it) {
+    const float* np = wcur;
+    int nt = tt, nk = kb;
+    if (++nk == nkb) { nk = 0; ++nt; np = wbase + (size_t)nt * tile_stride; }
+    else np += (KB / 4) * 256;
+    const bool last = it + 1 >= nitems;
+    const float* nload = last ? (next_first != nullptr ? next_first : wbase) : np;
+    if (stamp_items && tt == 0 && kb < 2) SUB_STAMP(20 + 5 * kb);
+    if (kb == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc.v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // biases in flight under the MFMAs; unconditional loads (see linear_step)
+      const float* bsrc = s.bias != nullptr ? s.bias : s.W;
+      const int col0 = (wave + tt * CH_NW) * 64 + (lane & 15);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[j] = ldg1(bsrc + min(col0 + 16 * j, s.N - 1));
+    }
+    if (stamp_items && tt == 0 && kb < 2) SUB_STAMP(22 + 5 * kb);
+    float4 ar[4];
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+      ar[kg] = *reinterpret_cast<const float4*>(arow + kb * KB + 16 * kg);
+      if (SRC2 && a2row != nullptr) ar[kg] = add4(ar[kg], *reinterpret_cast<const float4*>(a2row + kb * KB + 16 * kg));
+    }
+    ItemSteps16<0>::run(acc, w0, ar, nload, lo);
+    if (stamp_items && tt == 0 && kb < 2) SUB_STAMP(23 + 5 * kb);
+    if (kb == nkb - 1) {
+      int tile = wave + tt * CH_NW;
+      int sidx = step_idx;
+      asm volatile("" : "+s"(tile), "+s"(sidx));         // see linear_step: the epilogue rebuilds its view
+      if (!(CHAIN_DBG(s.dbg) & 1)) {
+        const LinSpec e = make_spec(sidx);
+        lin_epilogue16<DROP>(e, tile, acc, lane, bv);
+      }
+    }
+    wcur = np; tt = nt; kb = nk;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  return next_first != nullptr;
+}
+
 // y[R, N] = epilogue(src[R, K] W^T): called by all CH_NT threads, no internal barrier.
 //
 // A wave's work items (its column tiles x 64-deep k blocks) alternate between two
@@ -510,9 +722,13 @@ __device__ __forceinline__ void lin_epilogue(const LinSpec& s, int tile, const A
 // last item of a step fetches `next_first`, the first item of the wave's next
 // linear step (the weight stream depends on the step table only, not on data),
 // which then arrives in `w0` (`preloaded`).  Returns true when w0 holds that item.
-template <int R, bool DROP, typename SpecFn>
+// SRC2: the A operand is src + src2 (the prologue's x + query_pos only: a run-time test of the pointer
+// put branches between the operand reads of every item, and hipcc waits vmcnt(0) at their joins, i.e.
+// for the item's whole weight fetch)
+template <int R, bool DROP, bool SRC2, typename SpecFn>
 __device__ __forceinline__ bool linear_step(const LinSpec& s, WBuf& w0, bool preloaded,
                                             const float* next_first, SpecFn make_spec, int step_idx) {
+  if constexpr (R == 16) return linear_step16<DROP, SRC2>(s, w0, preloaded, next_first, make_spec, step_idx);
   constexpr int NG = R / 4;
   const int lane = threadIdx.x & 63;
   const int wave = (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) - s.woff) & (CH_NW - 1);
@@ -523,7 +739,7 @@ __device__ __forceinline__ bool linear_step(const LinSpec& s, WBuf& w0, bool pre
   const int nitems = my_tiles * nkb;
   // lane 4j + q reads row q (of each row group), k chunk j
   const float* arow = s.src + (lane & 3) * s.src_ld + 4 * (lane >> 2);
-  const float* a2row = s.src2 ? s.src2 + (lane & 3) * s.src2_ld + 4 * (lane >> 2) : nullptr;
+  const float* a2row = SRC2 && s.src2 ? s.src2 + (lane & 3) * s.src2_ld + 4 * (lane >> 2) : nullptr;
   const float* wbase = s.W + 4 * lane + (size_t)wave * 64 * kpad;
   const size_t tile_stride = (size_t)CH_NW * 64 * kpad;
   Acc<NG> acc;
@@ -558,7 +774,7 @@ __device__ __forceinline__ bool linear_step(const LinSpec& s, WBuf& w0, bool pre
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       ar[g] = *reinterpret_cast<const float4*>(arow + 4 * g * s.src_ld + kb * KB);
-      if (a2row != nullptr)
+      if (SRC2 && a2row != nullptr)
         ar[g] = add4(ar[g], *reinterpret_cast<const float4*>(a2row + 4 * g * s.src2_ld + kb * KB));
     }
     if constexpr (INPLACE) wcompute_inplace<NG>(acc, nx, ar, nload);      // wb and nx are the same buffer
@@ -880,7 +1096,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
 #endif
           if (((wave - s.woff) & (CH_NW - 1)) < ((s.N + 63) >> 6)) {   // else: no column tile here, w0 keeps waiting
             const PreRec pr = load_uniform<PreRec>(S.recs[idx].p[wave]);
-            const bool have = linear_step<R, DROP>(s, w0, pre_idx == idx, pr.first, epi_spec, idx);
+            const bool have = linear_step<R, DROP, PROG == PROG_PROLOGUE>(s, w0, pre_idx == idx, pr.first, epi_spec, idx);
             pre_idx = have ? pr.nidx : -1;
           }
         } else if (kd == K_LN) {
@@ -1110,6 +1326,7 @@ void resolve_program(ChainK& k, StepAll* out) {
       r.N = d.N == N_LOGITS ? k.nlogits : d.N == N_CODE ? k.code : d.N == N_CLS ? k.ncls : d.N;
       const int woff = (d.flags & F_WOFF) ? 512 : 0;
       r.p0 = pr.w + (size_t)woff * ((r.K + 63) & ~63);   // packed: a 64-row tile = 64 * kpad floats
+      if (R == 16) r.p0 += k.w16_delta;                   // the 16x16x4 copy (pack.hip); launch_r checks delta != 0
       r.p1 = pr.b ? pr.b + woff : nullptr;
       if (d.gsel == G_CLS) r.gd += (size_t)rep * k.M * k.ncls;
     } else if (d.kind == K_LN || d.kind == K_POSENC) {
@@ -1168,6 +1385,8 @@ int launch_dual_r(const ChainK& ka_, const ChainK& kb_, hipStream_t s, const cha
     once.done();
   }
   ChainK ka = ka_, kb = kb_;
+  TC_REQUIRE((RA != 16 || ka.w16_delta != 0) && (RB != 16 || kb.w16_delta != 0),
+             "%s: 16-row tiles need weights from a tc_head_pack_weights view (packed16_delta is 0)", what);
   Recs<rec_cap(PROG_DECODER)> ra;
   Recs<rec_cap(PROGB)> rb;
   resolve_program<RA, PROG_DECODER>(ka, ra.s);
@@ -1189,6 +1408,8 @@ int launch_r(const ChainK& k_, hipStream_t s, const char* what) {
     once.done();
   }
   ChainK k = k_;
+  TC_REQUIRE(R != 16 || k.w16_delta != 0,
+             "%s: 16-row tiles need weights from a tc_head_pack_weights view (packed16_delta is 0)", what);
   Recs<rec_cap(PROG)> recs;
   resolve_program<R, PROG>(k, recs.s);
   constexpr size_t lds = chain_lds_bytes<R, PROG>();
@@ -1263,7 +1484,7 @@ void fill_camk(const CamSampleArgs& a, CamK& p);   // cam_sample.hip
 int launch_prologue(const PrologueArgs& a, hipStream_t s) {
   ChainK k;
   init_k(k);
-  k.program = PROG_PROLOGUE; k.M = a.M; k.Q = a.Q; k.has_next = 1;
+  k.program = PROG_PROLOGUE; k.M = a.M; k.Q = a.Q; k.has_next = 1; k.w16_delta = a.w16_delta;
   k.pairs[0] = a.refpts; k.pairs[16] = a.in_proj;
   k.g[G_POS] = const_cast<float*>(a.qe); k.g_ld[G_POS] = 512; k.g_mod[G_POS] = a.Q;
   k.g[G_XIN] = const_cast<float*>(a.qe) + 256; k.g_ld[G_XIN] = 512; k.g_mod[G_XIN] = a.Q;
@@ -1293,6 +1514,7 @@ static int make_decoder_k(const DecoderChainArgs& a, ChainK& k) {
   k.pairs[13] = w.reg.l0; k.pairs[14] = w.reg.l2; k.pairs[15] = w.reg.l4;
   k.has_next = a.next_in_proj != nullptr;
   if (k.has_next) k.pairs[16] = *a.next_in_proj;
+  k.w16_delta = w.packed16_delta;
   k.g[G_ATTN_O] = const_cast<float*>(a.attn_o); k.g_ld[G_ATTN_O] = 256; k.g_mod[G_ATTN_O] = a.attn_mod;
   k.g[G_XIN] = const_cast<float*>(a.x_in); k.g_ld[G_XIN] = a.x_ld; k.g_mod[G_XIN] = a.x_mod;
   k.g[G_POS] = const_cast<float*>(a.qe); k.g_ld[G_POS] = 512; k.g_mod[G_POS] = a.Q;
@@ -1322,6 +1544,7 @@ static int make_radar_enc_k(const RadarEncodeArgs& a, ChainK& k, int part = 0) {
   init_k(k);
   k.program = part == 1 ? PROG_RADAR_ENC_A : part == 2 ? PROG_RADAR_ENC_B : PROG_RADAR_ENC;
   k.M = a.M; k.Q = 1; k.RI = a.RI; k.tokens = a.tokens; k.has_next = 1;
+  k.w16_delta = a.w16_delta;
   TC_REQUIRE(part == 0 || a.radar_feat != nullptr, "radar_encode: split programs need the radar_feat buffer");
   k.g[G_RFEAT] = a.radar_feat; k.g_ld[G_RFEAT] = 256;
   k.pairs[0] = a.rpe.l0; k.pairs[1] = tc_linear{a.rpe.n1.g, a.rpe.n1.b}; k.pairs[2] = a.rpe.l3;
@@ -1371,6 +1594,7 @@ int launch_radar_chain(const RadarChainArgs& a, hipStream_t s) {
   ChainK k;
   init_k(k);
   k.program = PROG_RADAR; k.M = a.M; k.Q = a.Q; k.code = a.code; k.ncls = a.ncls; k.nlayers = a.nlayers;
+  k.w16_delta = a.w[0].packed16_delta;
   k.has_next = 1;
   for (int r = 0; r < a.nlayers; ++r) {
     const tc_radar_layer& w = a.w[r];

@@ -183,6 +183,7 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
       re.kv[r] = h.kv3[r];
     }
     re.radar_feat = h.radar_feat;
+    re.w16_delta = w->packed16_delta;
   }
 
   // train-mode statistics of the frozen decoder: five dropout sites per layer (sites 16 + 8 l + 0..4)
@@ -196,7 +197,7 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
     PrologueArgs pa;
     pa.qe = w->query_embedding; pa.Q = Q; pa.M = rows; pa.refpts = w->reference_points;
     pa.in_proj = w->layers[0].self_attn.in_proj; pa.init_ref = h.init_ref; pa.qk = h.qk; pa.vt = h.vt;
-    pa.qpad = h.qpad; pa.qscale = attn_qscale;
+    pa.qpad = h.qpad; pa.qscale = attn_qscale; pa.w16_delta = w->packed16_delta;
     TC_TRY(launch_prologue(pa, s));
   }
   for (int lid = 0; lid < L; ++lid) {
@@ -530,6 +531,7 @@ int tc_radar_fusion_fwd(const tc_head_weights* packed_view, const float* hs_last
     re.kv[r] = h.kv3[r];
   }
   re.radar_feat = h.radar_feat;
+  re.w16_delta = w->packed16_delta;
   if (!opt.reuse_radar_kv) TC_TRY(launch_radar_encode(re, s));
   RadarChainArgs rc;
   rc.qf = hs_last; rc.ref_last = ref_last; rc.box_m = prev_box; rc.tokens = radar_tokens;
@@ -568,7 +570,7 @@ size_t tc_head_packed_bytes(const tc_head_weights* w) {
   PackItem items[MAX_PACK_ITEMS];
   const int n = collect_pack_items(w, &view, items);
   size_t total = 0;
-  for (int i = 0; i < n; ++i) total += arena_slice(packed_floats(items[i].N, items[i].K), 4);
+  for (int i = 0; i < n; ++i) total += 2 * arena_slice(packed_floats(items[i].N, items[i].K), 4);   // + the 16x16x4 copies
   // layer-0 constants + the scratch they are computed from (see tc_head_pack_weights)
   const size_t Q = w->num_query, C = w->embed_dims, qpad = ((Q + 15) / 16) * 16;
   total += arena_slice(Q * 3, 4) + arena_slice(Q * C, 4) + arena_slice(Q * 2 * C, 4) + arena_slice(C * qpad, 4);
@@ -584,12 +586,22 @@ int tc_head_pack_weights(const tc_head_weights* w, void* packed, size_t packed_b
   PackItem items[MAX_PACK_ITEMS];
   const int n = collect_pack_items(w, packed_view, items);
   Arena a(packed, packed_bytes);
+  // region A: every weight in the 4x4x1 layout; region B: the same weights, same order and slice
+  // sizes, in the 16x16x4 layout -- one distance (packed16_delta floats) from any address of a
+  // weight (or of a row block of it) to its counterpart
+  size_t region_a = 0;
+  for (int i = 0; i < n; ++i) region_a += arena_slice(packed_floats(items[i].N, items[i].K), 4);
+  const size_t delta = region_a / sizeof(float);
   for (int i = 0; i < n; ++i) {
     TC_REQUIRE(items[i].src != nullptr, "pack_weights: weight %d is null", i);
     float* dst = a.take<float>(packed_floats(items[i].N, items[i].K));
-    TC_TRY(launch_pack_linear(items[i].src, items[i].N, items[i].K, dst, as_stream(stream)));
+    TC_TRY(launch_pack_linear(items[i].src, items[i].N, items[i].K, dst, dst + delta, as_stream(stream)));
     *items[i].slot = dst;
   }
+  for (int i = 0; i < n; ++i) a.take<float>(packed_floats(items[i].N, items[i].K));     // region B
+  packed_view->packed16_delta = delta;
+  for (int l = 0; l < TC_MAX_LAYERS; ++l) packed_view->layers[l].packed16_delta = delta;
+  for (int l = 0; l < TC_MAX_RADAR_LAYERS; ++l) packed_view->radar[l].packed16_delta = delta;
   // Layer 0's self-attention input is the learned embedding alone: reference points,
   // QKV projection and softmax(QK^T)V are constants of the checkpoint.  Evaluate them
   // here with the forward's own kernels (prologue chain + attention core, one batch).
@@ -606,6 +618,7 @@ int tc_head_pack_weights(const tc_head_weights* w, void* packed, size_t packed_b
     pa.qe = w->query_embedding; pa.Q = Q; pa.M = Q; pa.refpts = packed_view->reference_points;
     pa.in_proj = packed_view->layers[0].self_attn.in_proj; pa.init_ref = init_ref; pa.qk = qk; pa.vt = vt;
     pa.qpad = qpad; pa.qscale = 1.4426950408889634f / sqrtf((float)(C / H));
+    pa.w16_delta = delta;
     TC_TRY(launch_prologue(pa, s));
     TC_TRY(launch_self_attn_core(qk, qk + C, 2 * C, vt, qpad, attn_o, C, 1, Q, H, s));
     packed_view->l0_init_reference = init_ref;
@@ -629,7 +642,8 @@ int tc_head_repack_trainable(const tc_head_weights* w, tc_head_weights* packed_v
     TC_REQUIRE(items[i].src != nullptr, "repack_trainable: weight %d is null", i);
     // scratch is a copy of the packed view: its slot still holds the packed destination
     float* dst = const_cast<float*>(*items[i].slot);
-    TC_TRY(launch_pack_linear(items[i].src, items[i].N, items[i].K, dst, as_stream(stream)));
+    TC_TRY(launch_pack_linear(items[i].src, items[i].N, items[i].K, dst, dst + packed_view->packed16_delta,
+                              as_stream(stream)));
   }
   return 0;
 }

@@ -80,6 +80,7 @@ struct PrologueArgs {
   const float* qe; int Q, M;                 // query_embedding [Q,512]; M = B*Q rows
   tc_linear refpts, in_proj;                 // transformer.reference_points, layer-0 in_proj
   float* init_ref; float* qk; float* vt; int qpad; float qscale;
+  size_t w16_delta = 0;                      // packed view's packed16_delta (16-row tiles read W + delta)
 };
 int launch_prologue(const PrologueArgs& a, hipStream_t s);
 
@@ -108,6 +109,7 @@ struct RadarEncodeArgs {
   tc_pos_encoder rpe; tc_linear f0, f2, f4;
   int nlayers; tc_linear kvproj[TC_MAX_RADAR_LAYERS]; float* kv[TC_MAX_RADAR_LAYERS];
   float* radar_feat;                         // optional [M,256]
+  size_t w16_delta = 0;
 };
 int launch_radar_encode(const RadarEncodeArgs& a, hipStream_t s);
 // a decoder layer and the radar encoders as ONE launch (no side stream / graph branch)
@@ -173,7 +175,8 @@ int launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float l
 
 // ---- pack.hip: one-time weight re-layout for the fused chains ---------------
 size_t packed_floats(int N, int K);
-int launch_pack_linear(const float* W, int N, int K, float* P, hipStream_t s);
+// P16 (may be null): the copy for the 16-row tiles' 16x16x4 MFMA (pack.hip)
+int launch_pack_linear(const float* W, int N, int K, float* P, float* P16, hipStream_t s);
 
 // ---- transpose.hip ---------------------------------------------------------
 int launch_nchw_to_nhwc(const float* src, float* dst, int n_img, int C, int H, int W, hipStream_t s);

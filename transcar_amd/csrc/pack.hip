@@ -9,12 +9,21 @@
 // tile still spans 64 * Kpad floats, so row offsets (multiples of 64) keep their
 // meaning.  N and K are zero padded to multiples of 64 (no guards in the loop).
 // Done once per checkpoint load (tc_head_pack_weights), not per frame.
+//
+// The 16-row tiles compute with v_mfma_f32_16x16x4 (one instruction = 16 rows x 16 columns x 4 k: a
+// single wave issues the 4x4x1 at 12.3 cycles instead of 8, tools/issue_probe.hip).  Its B operand is
+// one k per 16-lane group, so those tiles read a second copy with the same tile / item structure,
+//     P16[t][k/64][kg][i][lane 16g + c][j] = W[64t + 16j + c][64 (k/64) + 16 kg + 4g + i]
+// (kg = 16-wide k group of the item, i = MFMA of the group, j = 16-column sub-tile): again 1 KiB
+// contiguous per wave-instruction, one float4 = the B operands of the four sub-tiles' MFMAs, and the
+// A operand of a k group is one ds_read_b128 per lane (row c... 4 consecutive k at 16 kg + 4g).
 #include "kernels.hpp"
 
 namespace tc {
 
 __global__ __launch_bounds__(256) void pack_linear_kernel(const float* __restrict__ W, int N, int K,
-                                                          float* __restrict__ P, int ntile, int nkq) {
+                                                          float* __restrict__ P, float* __restrict__ P16,
+                                                          int ntile, int nkq) {
   const size_t total = (size_t)ntile * nkq * 256;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int j = i & 3;
@@ -24,6 +33,12 @@ __global__ __launch_bounds__(256) void pack_linear_kernel(const float* __restric
     const int t = tk / nkq;
     const int n = 64 * t + lane, k = 4 * kq + j;
     P[i] = (n < N && k < K) ? W[(size_t)n * K + k] : 0.0f;
+    if (P16 != nullptr) {
+      const int g = lane >> 4, c = lane & 15;
+      const int n16 = 64 * t + 16 * j + c;
+      const int k16 = 64 * (kq >> 4) + 16 * ((kq & 15) >> 2) + 4 * g + (kq & 3);
+      P16[i] = (n16 < N && k16 < K) ? W[(size_t)n16 * K + k16] : 0.0f;
+    }
   }
 }
 
@@ -31,12 +46,12 @@ size_t packed_floats(int N, int K) {
   return (size_t)((N + 63) / 64) * 64 * ((K + 63) / 64) * 64;
 }
 
-int launch_pack_linear(const float* W, int N, int K, float* P, hipStream_t s) {
+int launch_pack_linear(const float* W, int N, int K, float* P, float* P16, hipStream_t s) {
   TC_REQUIRE(W != nullptr && P != nullptr && N > 0 && K > 0, "pack_linear: bad arguments");
   const int ntile = (N + 63) / 64, nkq = ((K + 63) / 64) * 16;
   const size_t total = (size_t)ntile * nkq * 256;
   const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
-  hipLaunchKernelGGL(pack_linear_kernel, dim3(blocks), dim3(256), 0, s, W, N, K, P, ntile, nkq);
+  hipLaunchKernelGGL(pack_linear_kernel, dim3(blocks), dim3(256), 0, s, W, N, K, P, P16, ntile, nkq);
   return check_launch("pack_linear");
 }
 
