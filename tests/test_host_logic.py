@@ -99,7 +99,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert lib.tc_abi_version() == _lib.TC_ABI_VERSION
     # struct layouts: sizes the C side and the ctypes mirror must agree on are
     # checked through the workspace query (a wrong layout gives a wrong answer)
-    assert ctypes.sizeof(_lib.tc_decoder_layer) == 8 * (4 + 2 + 2 + 2 + 8 + 2 + 2 + 2 + 2 + 6)
+    assert ctypes.sizeof(_lib.tc_decoder_layer) == 8 * (4 + 2 + 2 + 2 + 8 + 2 + 2 + 2 + 2 + 6 + 1)    # + packed16_delta
 
 
 def test_workspace_query_runs_without_gpu():
