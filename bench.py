@@ -62,11 +62,12 @@ def parse(argv=None):
     ap.add_argument('--lanes', type=int, default=3,
                     help='frames in flight per GPU: one hipGraph + HIP stream each '
                          '(transcar_amd/pipeline.py); 1 = strictly one frame at a time')
-    ap.add_argument('--pair', type=int, default=2,
+    ap.add_argument('--pair', type=int, default=4,
                     help='frames per launch: the pipeline hands the head P consecutive frames (one per '
-                         'step, the per-frame API is unchanged) as ONE launch sequence -- 8-row tiles, '
-                         'every streamed weight fragment feeds both frames.  1 = one frame per launch '
-                         '(the like-for-like latency figure `latency_ms_per_frame` is always measured that way)')
+                         'step, the per-frame API is unchanged) as ONE launch sequence -- P = 4: 16-row tiles '
+                         'on the 16x16x4 MFMA, every streamed weight fragment feeds four frames; 2: 8-row tiles; '
+                         '1 = one frame per launch.  The other settings are measured beside the headline '
+                         '(`frames_per_launch_sweep`), the like-for-like latency `latency_ms_per_frame` always at 1')
     ap.add_argument('--tile-rows', type=int, default=0, choices=[0, 4, 8, 16],
                     help='row-tile height of the fused chains in the frame pipeline (0 = automatic)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -83,7 +84,7 @@ def parse(argv=None):
                     help='operator-by-operator launches instead of the fused row chains')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-batched', action='store_true',
-                    help='skip the 4-frames-per-step side measurement')
+                    help='skip the frames-per-launch sweep (side measurement)')
     ap.add_argument('--no-handoff', action='store_true',
                     help='skip the side measurement with the NCHW -> NHWC hand-off inside the frame')
     ap.add_argument('--train-autograd', action='store_true',
@@ -462,26 +463,41 @@ def producer_side_run(pipe, args):
                 'feature_bytes_per_frame': sum(int(f.numel()) * 4 for f in spare) // fpl}}
 
 
-def batched_side_run(head, dev, args, frames=4):
-    """Not the headline: the same path with `frames` frames per step (one hipGraph
-    replay per step, two steps in flight), reported beside the B = 1 value because at B = 1 a workgroup of the
-    row chains is bound by its weight stream; larger row
-    tiles move the same kernels toward the MFMA bound."""
+def sweep_side_run(head, dev, args, skip):
+    """Not the headline: the same pipeline at the other frames-per-launch settings (same lanes,
+    the caller submits one frame per step everywhere), so that one bench line shows what pairing
+    buys: 1 = one frame per launch (4-row tiles, a workgroup bound by its weight stream, DESIGN.md
+    section 5), 2 = 8-row tiles, 4 = 16-row tiles on the 16x16x4 MFMA.  Decoder-chain time and
+    fraction of the f32 MFMA peak of each setting ride along."""
     from transcar_amd.pipeline import FramePipeline
-    inp = make_inputs(head, dev, args.shapes, frames, seed=11)
-    nl = 1 if args.no_graph else min(2, max(1, args.lanes))
-    pipe = FramePipeline(head, [inp] + [make_inputs(head, dev, args.shapes, frames, seed=13)
-                                        for _ in range(nl - 1)])
-    for _ in range(10):
-        pipe.launch()
-    torch.cuda.synchronize()
-    n = max(20, args.steps // 4)
-    t = _replay_rate(pipe.launch, pipe.synchronize, n)
-    r = roofline(head, inp, dev)
-    return {'frames_per_step': frames, 'frames_in_flight': frames * pipe.lanes,
-            'value': frames / t, 'unit': 'frames/s', 'ms_per_step': t * 1e3,
-            'roofline_frac': r['frac'], 'roofline_kernel': r['kernel'],
-            'self_attn_frac': r['others']['self_attn_kernel']['frac']}
+    out = {}
+    for fpl in (1, 2, 4):
+        if fpl == skip:
+            continue
+        lanes = [make_inputs(head, dev, args.shapes, fpl, seed=31 + 5 * i) for i in range(max(1, args.lanes))]
+        pipe = FramePipeline(head, lanes)
+        step = (lambda: pipe.launch()) if fpl == 1 else pipe.submit
+
+        def sync():
+            if fpl > 1:
+                pipe.flush()
+            torch.cuda.synchronize()
+        for _ in range(10 * fpl * pipe.lanes):
+            step()
+        sync()
+        t = _replay_rate(step, sync, max(20, args.steps // 2))
+        r = roofline(head, lanes[0], dev)
+        allk = dict(r['others'])
+        allk[r['kernel']] = r
+        out[str(fpl)] = {'frames_per_launch': fpl, 'frames_in_flight': fpl * pipe.lanes,
+                         'value': 1.0 / t, 'unit': 'frames/s',
+                         'decoder_chain_us': allk['chain_kernel(decoder layer)']['ms'] * 1e3,
+                         'decoder_chain_frac': allk['chain_kernel(decoder layer)']['frac'],
+                         'self_attn_frac': allk['self_attn_kernel']['frac'],
+                         'radar_chain_frac': allk['chain_kernel(radar fusion)']['frac']}
+        del pipe, lanes
+        torch.cuda.empty_cache()
+    return out
 
 
 def roofline_chain_once(head, inp, dev):
@@ -839,8 +855,8 @@ def main(argv=None):
             if not args.no_handoff and not args.no_graph:
                 line['with_handoff'] = handoff_side_run(head, dev, args)
                 line['with_handoff_ms'] = line['with_handoff']['ms_per_frame']
-            if args.batch == 1 and not args.no_batched:
-                line['batched'] = batched_side_run(head, dev, args, frames=4)
+            if args.batch == 1 and not args.no_batched and pipe is not None:
+                line['frames_per_launch_sweep'] = sweep_side_run(head, dev, args, pipe.frames_per_launch)
             if not args.no_cpu_baseline:
                 line['cpu_baseline'] = cpu_baseline(sd, inp, args.cpu_seconds)
         print(json.dumps(line), flush=True)

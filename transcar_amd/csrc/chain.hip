@@ -373,39 +373,16 @@ struct ItemSteps {
     __builtin_amdgcn_sched_barrier(0);
     ItemSteps<NG, PF, J + 1>::run(acc, wb, ar, nx, np);
   }
-  // ONE buffer, refilled in place: fragment J of the NEXT item is loaded into the registers of
-  // fragment J as soon as its 4 * NG MFMAs have been issued (the matrix pipe reads its operands at
-  // issue; the load writes them hundreds of cycles later).  The 16-row tiles use this: 256 MFMAs
-  // per 16 KiB item leave every fragment a whole item time (~2300 cycles) to arrive, and without
-  // the second buffer the kernel fits 256 registers -- two workgroups per CU.
-  static __device__ __forceinline__ void run_inplace(Acc<NG>& acc, WBuf& wb, const float4* ar, const float* np) {
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      acc.v[g][0] = MFMA44(ar[g].x, wb.b[J].x, acc.v[g][0], J);
-      acc.v[g][1] = MFMA44(ar[g].y, wb.b[J].y, acc.v[g][1], J);
-      acc.v[g][0] = MFMA44(ar[g].z, wb.b[J].z, acc.v[g][0], J);
-      acc.v[g][1] = MFMA44(ar[g].w, wb.b[J].w, acc.v[g][1], J);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    wb.b[J] = ld4(np + J * 256);
-    __builtin_amdgcn_sched_barrier(0);
-    ItemSteps<NG, PF, J + 1>::run_inplace(acc, wb, ar, np);
-  }
 };
 template <int NG, bool PF>
 struct ItemSteps<NG, PF, 16> {
   static __device__ __forceinline__ void run(Acc<NG>&, const WBuf&, const float4*, WBuf&, const float*) {}
-  static __device__ __forceinline__ void run_inplace(Acc<NG>&, WBuf&, const float4*, const float*) {}
 };
 
 template <int NG, bool PF>
 __device__ __forceinline__ void wcompute(Acc<NG>& acc, const WBuf& wb, const float4* ar, WBuf& nx,
                                          const float* np) {
   ItemSteps<NG, PF, 0>::run(acc, wb, ar, nx, np);
-}
-template <int NG>
-__device__ __forceinline__ void wcompute_inplace(Acc<NG>& acc, WBuf& wb, const float4* ar, const float* np) {
-  ItemSteps<NG, true, 0>::run_inplace(acc, wb, ar, np);
 }
 
 // lane n holds y[4g + i][64*tile + n] in acc.v[g][*][i]
@@ -633,7 +610,11 @@ __device__ __forceinline__ void lin_epilogue16(const LinSpec& s, int tile, const
 }
 
 // linear_step for R = 16 (same contract: w0 may arrive preloaded with the step's first item, the last
-// item fetches `next_first`): one weight buffer refilled in place.
+// item fetches `next_first`): ONE weight buffer refilled in place -- fragment J of the next item is
+// loaded into fragment J's registers right behind its four MFMAs (the matrix pipe reads its operands at
+// issue, the load writes them hundreds of cycles later; 64 MFMAs = 2048 cycles per item leave every
+// fragment an item time to arrive).  Without a second buffer the kernel fits 256 registers: two
+// workgroups per CU.
 template <bool DROP, bool SRC2, typename SpecFn>
 __device__ __forceinline__ bool linear_step16(const LinSpec& s, WBuf& w0, bool preloaded, const float* next_first,
                                               SpecFn make_spec, int step_idx) {
@@ -728,6 +709,7 @@ __device__ __forceinline__ bool linear_step16(const LinSpec& s, WBuf& w0, bool p
 template <int R, bool DROP, bool SRC2, typename SpecFn>
 __device__ __forceinline__ bool linear_step(const LinSpec& s, WBuf& w0, bool preloaded,
                                             const float* next_first, SpecFn make_spec, int step_idx) {
+  // 16-row tiles: ONE weight buffer refilled in place, 16x16x4 MFMAs (linear_step16)
   if constexpr (R == 16) return linear_step16<DROP, SRC2>(s, w0, preloaded, next_first, make_spec, step_idx);
   constexpr int NG = R / 4;
   const int lane = threadIdx.x & 63;
@@ -752,7 +734,6 @@ __device__ __forceinline__ bool linear_step(const LinSpec& s, WBuf& w0, bool pre
   // item = (tile tt, k block kb), kb fastest; tracked incrementally (no divisions)
   int tt = 0, kb = 0;
   const float* wcur = wbase;
-  constexpr bool INPLACE = (R == 16);      // one weight buffer, refilled in place (see ItemSteps::run_inplace)
   auto run = [&](const WBuf& wb, WBuf& nx, auto pf, const float* np_last) {
     constexpr bool PF = decltype(pf)::value;
     const float* np = wcur;
@@ -777,8 +758,7 @@ __device__ __forceinline__ bool linear_step(const LinSpec& s, WBuf& w0, bool pre
       if (SRC2 && a2row != nullptr)
         ar[g] = add4(ar[g], *reinterpret_cast<const float4*>(a2row + 4 * g * s.src2_ld + kb * KB));
     }
-    if constexpr (INPLACE) wcompute_inplace<NG>(acc, nx, ar, nload);      // wb and nx are the same buffer
-    else wcompute<NG, PF>(acc, wb, ar, nx, nload);
+    wcompute<NG, PF>(acc, wb, ar, nx, nload);
     if (stamp_items && tt == 0 && kb < 2) SUB_STAMP(23 + 5 * kb);
     if (kb == nkb - 1) {
       // The epilogue REBUILDS its view of the step from the LDS record (behind an opaque
@@ -803,16 +783,6 @@ __device__ __forceinline__ bool linear_step(const LinSpec& s, WBuf& w0, bool pre
     __builtin_amdgcn_sched_barrier(0);
   }
   SUB_STAMP(2);
-  if constexpr (INPLACE) {
-    const float* fb = wbase;
-#pragma unroll 1
-    for (int it = 0; it < nitems; ++it) {
-      const bool last = it + 1 >= nitems;
-      run(w0, w0, Yes{}, last ? (next_first != nullptr ? next_first + 4 * lane : fb) : nullptr);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    return next_first != nullptr;
-  }
   WBuf w1;
   // Two copies of the item body only (w0 -> w1, w1 -> w0): every item prefetches -- the next
   // item of the step, the first item of the wave's next linear step (`next_first`), or, when
