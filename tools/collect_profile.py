@@ -175,7 +175,7 @@ def main():
                 st, en = int(r['Start_Timestamp']), int(r['End_Timestamp'])
                 lo.append('%-46s %8s %10.1f %10.1f' % (r['K'][:46], r.get('Stream_Id', r.get('Queue_Id', '?')), (st - t0) / 1e3, (en - st) / 1e3))
             span = (max(int(r['End_Timestamp']) for r in lrows[a:b]) - t0) / 1e3
-            lo.append('# %d box decodes (= frames) completed in this window of %.1f us' % (3, span))
+            lo.append('# %d box decodes (= launch sequences of frames_per_launch frames) completed in this window of %.1f us' % (3, span))
         agg2 = defaultdict(list)
         for r in lrows:
             agg2[(r['K'], r['Grid_Size'])].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
