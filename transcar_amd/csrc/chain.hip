@@ -973,7 +973,11 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
 #endif
 
   // dst = [relu] LN(a (+ relu(LN(c; p2,p3)))) (+ d): wave w owns rows w, w+4, ...
+  // All rows of a wave (R/4: 1, 2 or 4) go through the phases together: one fetch of gamma / beta per
+  // wave, the rows' independent reduction chains interleave, stores last (row by row the 16-row tiles
+  // paid four gamma / beta round trips and four serial reduction chains per LayerNorm).
   auto do_ln = [&](const StepRes& r) {
+    constexpr int NR = R / CH_NW;
     const float* a = buf_ptr(S, r.src); const int lda = buf_ld(r.src);
     const float* c = buf_ptr(S, r.src2); const int ldc = buf_ld(r.src2);
     const bool xp = (r.flags & F_LN_XP) != 0;          // `res` names an OUTPUT then: result + query_pos
@@ -981,22 +985,37 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
     float* dst2 = xp ? buf_ptr(S, r.res) : nullptr;
     float* dst = buf_ptr(S, r.dst);
     float* gdst = r.gd;
-    for (int row = wave; row < R; row += CH_NW) {
-      float4 pos4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 gg = ld4(r.p0 + 4 * lane), bb = ld4(r.p1 + 4 * lane);
+    float4 v[NR], pos4[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int row = wave + CH_NW * i;
+      pos4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (xp) {                                        // in flight under the reductions
         int prow = min(m0 + row, M - 1);
         if (k.g_mod[G_POS] > 0) prow = prow % k.g_mod[G_POS];
-        pos4 = ld4(k.g[G_POS] + (size_t)prow * k.g_ld[G_POS] + 4 * lane);
+        pos4[i] = ld4(k.g[G_POS] + (size_t)prow * k.g_ld[G_POS] + 4 * lane);
       }
-      float4 v = *reinterpret_cast<const float4*>(a + row * lda + 4 * lane);
-      if (c != nullptr)
-        v = add4(v, relu4(ln_row(*reinterpret_cast<const float4*>(c + row * ldc + 4 * lane), r.p2, r.p3, lane)));
-      v = ln_row(v, r.p0, r.p1, lane);
-      if (r.flags & F_LN_RELU) v = relu4(v);
-      if (dd != nullptr) v = add4(v, *reinterpret_cast<const float4*>(dd + row * LD2 + 4 * lane));
-      *reinterpret_cast<float4*>(dst + row * LD2 + 4 * lane) = v;
-      if (xp) *reinterpret_cast<float4*>(dst2 + row * LD2 + 4 * lane) = add4(v, pos4);
-      if (gdst != nullptr && m0 + row < M) st4(gdst + (size_t)(m0 + row) * 256 + 4 * lane, v);
+      v[i] = *reinterpret_cast<const float4*>(a + row * lda + 4 * lane);
+    }
+    if (c != nullptr) {
+      const float4 g2 = ld4(r.p2 + 4 * lane), b2 = ld4(r.p3 + 4 * lane);
+      float4 cv[NR];
+#pragma unroll
+      for (int i = 0; i < NR; ++i) cv[i] = *reinterpret_cast<const float4*>(c + (wave + CH_NW * i) * ldc + 4 * lane);
+      ln_rows<NR>(cv, g2, b2);
+#pragma unroll
+      for (int i = 0; i < NR; ++i) v[i] = add4(v[i], relu4(cv[i]));
+    }
+    ln_rows<NR>(v, gg, bb);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int row = wave + CH_NW * i;
+      if (r.flags & F_LN_RELU) v[i] = relu4(v[i]);
+      if (dd != nullptr) v[i] = add4(v[i], *reinterpret_cast<const float4*>(dd + row * LD2 + 4 * lane));
+      *reinterpret_cast<float4*>(dst + row * LD2 + 4 * lane) = v[i];
+      if (xp) *reinterpret_cast<float4*>(dst2 + row * LD2 + 4 * lane) = add4(v[i], pos4[i]);
+      if (gdst != nullptr && m0 + row < M) st4(gdst + (size_t)(m0 + row) * 256 + 4 * lane, v[i]);
     }
   };
   // the part of a linear step the item loop needs ...

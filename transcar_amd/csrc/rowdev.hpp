@@ -26,6 +26,29 @@ __device__ __forceinline__ float4 ln_row(float4 v, const float* g, const float* 
                      d.z * rstd * gg.z + bb.z, d.w * rstd * gg.w + bb.w);
 }
 
+// The same for NR rows at once (gamma / beta already in registers): the rows' reduction chains are
+// independent and interleave.  Same operations per row as ln_row: bit-identical results.
+template <int NR>
+__device__ __forceinline__ void ln_rows(float4 (&v)[NR], const float4 gg, const float4 bb) {
+  float s[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) s[i] = wave_sum(v[i].x + v[i].y + v[i].z + v[i].w);
+  float q[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const float mean = s[i] * (1.0f / 256.0f);
+    v[i] = make_float4(v[i].x - mean, v[i].y - mean, v[i].z - mean, v[i].w - mean);
+  }
+#pragma unroll
+  for (int i = 0; i < NR; ++i) q[i] = wave_sum(v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w);
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const float rstd = 1.0f / sqrtf(q[i] * (1.0f / 256.0f) + 1e-5f);
+    v[i] = make_float4(v[i].x * rstd * gg.x + bb.x, v[i].y * rstd * gg.y + bb.y,
+                       v[i].z * rstd * gg.z + bb.z, v[i].w * rstd * gg.w + bb.w);
+  }
+}
+
 // position-encoder layer 0: relu(LN(W0 p + b0)), W0 [256,3]
 __device__ __forceinline__ float4 posenc_l0_row(float p0, float p1, float p2, const float* w0,
                                                 const float* b0, const float* g, const float* beta,
