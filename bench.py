@@ -62,11 +62,13 @@ def parse(argv=None):
     ap.add_argument('--lanes', type=int, default=3,
                     help='frames in flight per GPU: one hipGraph + HIP stream each '
                          '(transcar_amd/pipeline.py); 1 = strictly one frame at a time')
-    ap.add_argument('--pair', type=int, default=4,
+    ap.add_argument('--pair', type=int, default=0,
                     help='frames per launch: the pipeline hands the head P consecutive frames (one per '
-                         'step, the per-frame API is unchanged) as ONE launch sequence -- P = 4: 16-row tiles '
-                         'on the 16x16x4 MFMA, every streamed weight fragment feeds four frames; 2: 8-row tiles; '
-                         '1 = one frame per launch.  The other settings are measured beside the headline '
+                         'step, the per-frame API is unchanged) as ONE launch sequence -- P >= 3: 16-row tiles '
+                         'on the 16x16x4 MFMA, every streamed weight fragment feeds 16 rows (at P >= 8 two such '
+                         'workgroups per CU inside one launch); 2: 8-row tiles; 1 = one frame per launch.  0 '
+                         '(default) = the largest divisor of --steps up to 10, so that a timed window ends on a '
+                         'launch boundary (10 for 20 / 200 steps).  Other settings are measured beside the headline '
                          '(`frames_per_launch_sweep`), the like-for-like latency `latency_ms_per_frame` always at 1')
     ap.add_argument('--tile-rows', type=int, default=0, choices=[0, 4, 8, 16],
                     help='row-tile height of the fused chains in the frame pipeline (0 = automatic)')
@@ -153,10 +155,19 @@ def build_head(dev):
     return head.to(dev).eval(), sd
 
 
-def make_inputs(head, dev, shapes, batch, seed):
-    """Synthetic frame(s) of BASELINE.md section 3, resident on the device."""
-    feats = synth.make_feats(shapes, seed=seed, batch=batch)      # iid N(0,1)
-    nhwc = [ops.to_nhwc(torch.from_numpy(f).to(dev)) for f in feats]
+def make_inputs(head, dev, shapes, batch, seed, host_feats=True):
+    """Synthetic frame(s) of BASELINE.md section 3, resident on the device.
+    host_feats=False: the iid N(0,1) maps are drawn on the device, channels-last (a lane of ten
+    frames is 1.9 GB: a second per frame through numpy); `feats_np` is None then."""
+    if host_feats:
+        feats = synth.make_feats(shapes, seed=seed, batch=batch)      # iid N(0,1)
+        nhwc = [ops.to_nhwc(torch.from_numpy(f).to(dev)) for f in feats]
+    else:
+        feats = None
+        g = torch.Generator(device=dev)
+        g.manual_seed(1000 + seed)
+        nhwc = [torch.randn((batch * 6, h, w, 256), device=dev, generator=g)
+                for (h, w) in configs.LEVEL_SHAPES[shapes]]
     l2i_np = synth.make_lidar2img()
     l2i = torch.from_numpy(np.stack([l2i_np] * batch).astype(np.float32)).to(dev)
     hw = configs.IMG_SHAPE[:2]
@@ -385,8 +396,10 @@ def handoff_side_run(head, dev, args):
     lanes = []
     fpl = args.batch * max(1, args.pair)
     for i in range(max(1, args.lanes)):
-        inp = make_inputs(head, dev, args.shapes, fpl, seed=201 + 7 * i)
-        inp['nchw'] = [torch.from_numpy(f).to(dev) for f in inp['feats_np']]
+        inp = make_inputs(head, dev, args.shapes, fpl, seed=201 + 7 * i, host_feats=False)
+        # the same maps as the FPN would hand them over: [B, N, C, H, W]
+        inp['nchw'] = [f.view(fpl, 6, f.shape[1], f.shape[2], f.shape[3]).permute(0, 1, 4, 2, 3).contiguous()
+                       for f in inp['nhwc']]
         lanes.append(inp)
     pipe = FramePipeline(head, lanes, tile_rows=args.tile_rows or None)
     for _ in range(3 * pipe.lanes):
@@ -471,10 +484,11 @@ def sweep_side_run(head, dev, args, skip):
     fraction of the f32 MFMA peak of each setting ride along."""
     from transcar_amd.pipeline import FramePipeline
     out = {}
-    for fpl in (1, 2, 4):
+    for fpl in (1, 2, 4, 10):
         if fpl == skip:
             continue
-        lanes = [make_inputs(head, dev, args.shapes, fpl, seed=31 + 5 * i) for i in range(max(1, args.lanes))]
+        lanes = [make_inputs(head, dev, args.shapes, fpl, seed=31 + 5 * i, host_feats=False)
+                 for i in range(max(1, args.lanes))]
         pipe = FramePipeline(head, lanes)
         step = (lambda: pipe.launch()) if fpl == 1 else pipe.submit
 
@@ -482,10 +496,12 @@ def sweep_side_run(head, dev, args, skip):
             if fpl > 1:
                 pipe.flush()
             torch.cuda.synchronize()
-        for _ in range(10 * fpl * pipe.lanes):
-            step()
-        sync()
-        t = _replay_rate(step, sync, max(20, args.steps // 2))
+        t_end = time.perf_counter() + max(0.3, args.warmup_s)     # clocks ramp under load: same warm-up as the headline
+        while time.perf_counter() < t_end:
+            for _ in range(fpl * pipe.lanes):
+                step()
+            sync()
+        t = _replay_rate(step, sync, max(20, args.steps), min_s=0.6)
         r = roofline(head, lanes[0], dev)
         allk = dict(r['others'])
         allk[r['kernel']] = r
@@ -777,10 +793,11 @@ def main(argv=None):
         # works on its own synthetic frame(s).  --pair P: a lane holds P frame slots; the bench
         # submits ONE frame per step and the lane is replayed when its slots are filled
         from transcar_amd.pipeline import FramePipeline
-        pair = max(1, args.pair)
+        pair = args.pair if args.pair > 0 else max(p for p in range(1, 11) if args.steps % p == 0)
+        args.pair = pair                      # the side runs use the same grouping
         fpl = args.batch * pair
-        first = inp if pair == 1 else make_inputs(head, dev, args.shapes, fpl, seed=1 + rank)
-        lanes = [first] + [make_inputs(head, dev, args.shapes, fpl, seed=101 + rank + 7 * i)
+        first = inp if pair == 1 else make_inputs(head, dev, args.shapes, fpl, seed=1 + rank, host_feats=False)
+        lanes = [first] + [make_inputs(head, dev, args.shapes, fpl, seed=101 + rank + 7 * i, host_feats=False)
                            for i in range(1, max(1, args.lanes))]
         from transcar_amd.detr3d_head import head_options
         pipe = FramePipeline(head, lanes, options=head_options(tile_rows=args.tile_rows or None,

@@ -13,10 +13,11 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 python -m pytest tests -x -q -m gpu > "$OUT/pytest_gpu.log" 2>&1
 echo "pytest rc=$?" >> "$OUT/pytest_gpu.log"
-python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"                                   # default: 4 frames per launch x 3 lanes
+python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"                                   # default: 10 frames per launch x 3 lanes
 python bench.py --pair 1 --no-cpu-baseline --no-batched > "$OUT/bench_pair1.json" 2>> "$OUT/bench.err"
 python bench.py --pair 2 --no-cpu-baseline --no-batched --no-handoff > "$OUT/bench_pair2.json" 2>> "$OUT/bench.err"
-python bench.py --pair 8 --no-cpu-baseline --no-batched --no-handoff > "$OUT/bench_pair8.json" 2>> "$OUT/bench.err"
+python bench.py --pair 4 --no-cpu-baseline --no-batched --no-handoff > "$OUT/bench_pair4.json" 2>> "$OUT/bench.err"
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-batched --no-handoff > "$OUT/bench_steps20.json" 2>> "$OUT/bench.err"
 python bench.py --train --steps 50 --warmup 5 > "$OUT/bench_train.json" 2>> "$OUT/bench.err"
 cd /tmp
 Q="--main-only --min-window-s 0.05 --warmup-s 0.05"   # the timed loop only, short windows: small traces
@@ -25,7 +26,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python3 "
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_pair1" -- python3 "$REPO/bench.py" --lanes 1 --pair 1 --steps 50 --warmup 5 $Q > "$OUT/prof_pair1.log" 2>&1
 # the default command (3 lanes): trace of the overlap
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_lanes" -- python3 "$REPO/bench.py" --steps 50 --warmup 5 $Q > "$OUT/prof_lanes.log" 2>&1
-for B in 4 2 1; do
+for B in 10 4 2 1; do
   for C in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
     rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_${C}_b$B" -- python3 "$REPO/bench.py" --batch $B --steps 5 --warmup 2 $Q --no-graph > "$OUT/pmc_${C}_b$B.log" 2>&1
   done
