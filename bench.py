@@ -67,8 +67,8 @@ def parse(argv=None):
                          'step, the per-frame API is unchanged) as ONE launch sequence -- P >= 3: 16-row tiles '
                          'on the 16x16x4 MFMA, every streamed weight fragment feeds 16 rows (at P >= 8 two such '
                          'workgroups per CU inside one launch); 2: 8-row tiles; 1 = one frame per launch.  0 '
-                         '(default) = the largest divisor of --steps up to 10, so that a timed window ends on a '
-                         'launch boundary (10 for 20 / 200 steps).  Other settings are measured beside the headline '
+                         '(default) = 8 when that divides --steps (200), else its largest divisor up to 10 (20 steps: 10), '
+                         'so that a timed window ends on a launch boundary.  Other settings are measured beside the headline '
                          '(`frames_per_launch_sweep`), the like-for-like latency `latency_ms_per_frame` always at 1')
     ap.add_argument('--tile-rows', type=int, default=0, choices=[0, 4, 8, 16],
                     help='row-tile height of the fused chains in the frame pipeline (0 = automatic)')
@@ -484,7 +484,7 @@ def sweep_side_run(head, dev, args, skip):
     fraction of the f32 MFMA peak of each setting ride along."""
     from transcar_amd.pipeline import FramePipeline
     out = {}
-    for fpl in (1, 2, 4, 10):
+    for fpl in (1, 2, 4, 8):
         if fpl == skip:
             continue
         lanes = [make_inputs(head, dev, args.shapes, fpl, seed=31 + 5 * i, host_feats=False)
@@ -793,7 +793,10 @@ def main(argv=None):
         # works on its own synthetic frame(s).  --pair P: a lane holds P frame slots; the bench
         # submits ONE frame per step and the lane is replayed when its slots are filled
         from transcar_amd.pipeline import FramePipeline
-        pair = args.pair if args.pair > 0 else max(p for p in range(1, 11) if args.steps % p == 0)
+        # automatic: 8 frames when that divides the window (450 workgroups of 16 rows: two per CU, the whole
+        # launch resident at once), else the largest divisor of the step count up to 10
+        pair = args.pair if args.pair > 0 else (8 if args.steps % 8 == 0 else
+                                                max(p for p in range(1, 11) if args.steps % p == 0))
         args.pair = pair                      # the side runs use the same grouping
         fpl = args.batch * pair
         first = inp if pair == 1 else make_inputs(head, dev, args.shapes, fpl, seed=1 + rank, host_feats=False)

@@ -197,7 +197,7 @@ def main():
     out_m['_comment'] = ('rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES of the same command; second key = '
                          'frames per launch.  The counter sums matrix-pipe busy cycles over the 1024 SIMDs (8 per '
                          'v_mfma_f32_4x4x1, 32 per 16x16x4 f32); utilisation = busy / (1024 * duration * 2.4 GHz).')
-    for B in ('1', '2', '4', '10'):
+    for B in ('1', '2', '4', '8', '10'):
         per = defaultdict(dict)
         for ctr in ('FETCH_SIZE', 'WRITE_SIZE', 'SQ_VALU_MFMA_BUSY_CYCLES'):
             fs = glob.glob(os.path.join(src, 'pmc_%s_b%s' % (ctr, B), '*', '*counter_collection.csv'))

@@ -26,7 +26,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python3 "
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_pair1" -- python3 "$REPO/bench.py" --lanes 1 --pair 1 --steps 50 --warmup 5 $Q > "$OUT/prof_pair1.log" 2>&1
 # the default command (3 lanes): trace of the overlap
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_lanes" -- python3 "$REPO/bench.py" --steps 50 --warmup 5 $Q > "$OUT/prof_lanes.log" 2>&1
-for B in 10 4 2 1; do
+for B in 10 8 4 2 1; do
   for C in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
     rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_${C}_b$B" -- python3 "$REPO/bench.py" --batch $B --steps 5 --warmup 2 $Q --no-graph > "$OUT/pmc_${C}_b$B.log" 2>&1
   done

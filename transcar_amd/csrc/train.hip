@@ -55,7 +55,10 @@ __device__ __forceinline__ float bg_load_a(const BwdGemmK& p, int gi, int gr, in
   return v;
 }
 
-template <int MODE, int BN>
+// VEC: 16-byte global loads of the operand tiles (every leading dimension, extent along the
+// contiguous index and base address a multiple of 4 floats -- checked by the launchers); the scalar
+// variant (one predicated 4-byte load per element) remains for the 10- / 24-wide heads.
+template <int MODE, int BN, bool VEC>
 __global__ __launch_bounds__(256) void bwd_gemm_kernel(BwdGemmK p) {
   constexpr int NT = BN / 16;
   constexpr int AE = 64 * BG_RK / 256;      // A elements per thread and step (8)
@@ -63,8 +66,8 @@ __global__ __launch_bounds__(256) void bwd_gemm_kernel(BwdGemmK p) {
   constexpr int LDA_D = BG_RK + 1;          // DATA:   As[i][r]
   constexpr int LDA_W = 64 + 16;            // WEIGHT: As[r][i]
   constexpr int LDB = BN + 16;
-  __shared__ float As[(64 * LDA_D > BG_RK * LDA_W) ? 64 * LDA_D : BG_RK * LDA_W];
-  __shared__ float Bs[BG_RK * LDB];
+  __shared__ __align__(16) float As[(64 * LDA_D > BG_RK * LDA_W) ? 64 * LDA_D : BG_RK * LDA_W];
+  __shared__ __align__(16) float Bs[BG_RK * LDB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i0 = blockIdx.y * 64, j0 = blockIdx.x * BN;
   const int rbeg = blockIdx.z * p.rchunk, rend = min(p.R, rbeg + p.rchunk);
@@ -76,36 +79,96 @@ __global__ __launch_bounds__(256) void bwd_gemm_kernel(BwdGemmK p) {
   float ra[AE], rb[BE];
 
   auto fetch = [&](int r0) {
+    if constexpr (VEC) {
+      // A: 4 consecutive elements along the contiguous index (DATA: r, WEIGHT: i)
 #pragma unroll
-    for (int e = 0; e < AE; ++e) {
-      const int idx = tid + 256 * e;
-      int i, r;
-      if (MODE == BWD_DATA) { r = idx & (BG_RK - 1); i = idx / BG_RK; }
-      else { i = idx & 63; r = idx >> 6; }
-      ra[e] = bg_load_a<MODE>(p, i0 + i, r0 + r, rend);
+      for (int e = 0; e < AE / 4; ++e) {
+        const int idx = tid + 256 * e;
+        int i, r;
+        if (MODE == BWD_DATA) { r = (idx & (BG_RK / 4 - 1)) * 4; i = idx / (BG_RK / 4); }
+        else { i = (idx & 15) * 4; r = idx >> 4; }
+        const int gi = i0 + i, gr = r0 + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gi < p.I && gr < rend) {            // extents are multiples of 4: the four are in or out together
+          const size_t off = MODE == BWD_DATA ? (size_t)gi * p.ldA + gr : (size_t)gr * p.ldA + gi;
+          v = ld4(p.A + off);
+          if (p.relu != nullptr) {
+            const float4 m = ld4(p.relu + off);
+            if (m.x <= 0.f) v.x = 0.f;
+            if (m.y <= 0.f) v.y = 0.f;
+            if (m.z <= 0.f) v.z = 0.f;
+            if (m.w <= 0.f) v.w = 0.f;
+          }
+          if (p.gate != nullptr) {
+            if (MODE == BWD_DATA) { if (p.gate[gi] <= 0) v = make_float4(0.f, 0.f, 0.f, 0.f); }
+            else if (p.gate[gr] <= 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
+        ra[4 * e] = v.x; ra[4 * e + 1] = v.y; ra[4 * e + 2] = v.z; ra[4 * e + 3] = v.w;
+      }
+#pragma unroll
+      for (int e = 0; e < BE / 4; ++e) {
+        const int idx = tid + 256 * e;
+        const int j = (idx % (BN / 4)) * 4, r = idx / (BN / 4);
+        const int gj = j0 + j, gr = r0 + r;
+        const float4 v = (gj < p.J && gr < rend) ? ld4(p.Bm + (size_t)gr * p.ldB + gj) : make_float4(0.f, 0.f, 0.f, 0.f);
+        rb[4 * e] = v.x; rb[4 * e + 1] = v.y; rb[4 * e + 2] = v.z; rb[4 * e + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < AE; ++e) {
+        const int idx = tid + 256 * e;
+        int i, r;
+        if (MODE == BWD_DATA) { r = idx & (BG_RK - 1); i = idx / BG_RK; }
+        else { i = idx & 63; r = idx >> 6; }
+        ra[e] = bg_load_a<MODE>(p, i0 + i, r0 + r, rend);
+      }
+#pragma unroll
+      for (int e = 0; e < BE; ++e) {
+        const int idx = tid + 256 * e;
+        const int j = idx % BN, r = idx / BN;
+        const int gj = j0 + j, gr = r0 + r;
+        rb[e] = (gj < p.J && gr < rend) ? p.Bm[(size_t)gr * p.ldB + gj] : 0.f;
+      }
     }
+  };
+  auto stage = [&]() {
+    if constexpr (VEC) {
 #pragma unroll
-    for (int e = 0; e < BE; ++e) {
-      const int idx = tid + 256 * e;
-      const int j = idx % BN, r = idx / BN;
-      const int gj = j0 + j, gr = r0 + r;
-      rb[e] = (gj < p.J && gr < rend) ? p.Bm[(size_t)gr * p.ldB + gj] : 0.f;
+      for (int e = 0; e < AE / 4; ++e) {
+        const int idx = tid + 256 * e;
+        if (MODE == BWD_DATA) {
+          float* d = &As[(idx / (BG_RK / 4)) * LDA_D + (idx & (BG_RK / 4 - 1)) * 4];     // row stride 33: scalar stores
+          d[0] = ra[4 * e]; d[1] = ra[4 * e + 1]; d[2] = ra[4 * e + 2]; d[3] = ra[4 * e + 3];
+        } else {
+          *reinterpret_cast<float4*>(&As[(idx >> 4) * LDA_W + (idx & 15) * 4]) =
+              make_float4(ra[4 * e], ra[4 * e + 1], ra[4 * e + 2], ra[4 * e + 3]);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < BE / 4; ++e) {
+        const int idx = tid + 256 * e;
+        *reinterpret_cast<float4*>(&Bs[(idx / (BN / 4)) * LDB + (idx % (BN / 4)) * 4]) =
+            make_float4(rb[4 * e], rb[4 * e + 1], rb[4 * e + 2], rb[4 * e + 3]);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < AE; ++e) {
+        const int idx = tid + 256 * e;
+        if (MODE == BWD_DATA) As[(idx / BG_RK) * LDA_D + (idx & (BG_RK - 1))] = ra[e];
+        else As[(idx >> 6) * LDA_W + (idx & 63)] = ra[e];
+      }
+#pragma unroll
+      for (int e = 0; e < BE; ++e) {
+        const int idx = tid + 256 * e;
+        Bs[(idx / BN) * LDB + idx % BN] = rb[e];
+      }
     }
   };
 
   fetch(rbeg);
   for (int r0 = rbeg; r0 < rend; r0 += BG_RK) {
-#pragma unroll
-    for (int e = 0; e < AE; ++e) {
-      const int idx = tid + 256 * e;
-      if (MODE == BWD_DATA) As[(idx / BG_RK) * LDA_D + (idx & (BG_RK - 1))] = ra[e];
-      else As[(idx >> 6) * LDA_W + (idx & 63)] = ra[e];
-    }
-#pragma unroll
-    for (int e = 0; e < BE; ++e) {
-      const int idx = tid + 256 * e;
-      Bs[(idx / BN) * LDB + idx % BN] = rb[e];
-    }
+    stage();
     __syncthreads();
     if (r0 + BG_RK < rend) fetch(r0 + BG_RK);
     if (do_colsum && tid < 64) {
@@ -142,6 +205,12 @@ __global__ __launch_bounds__(256) void bwd_gemm_kernel(BwdGemmK p) {
   if (do_colsum && tid < 64 && i0 + tid < p.I) unsafeAtomicAdd(p.colsum + i0 + tid, csum);
 }
 
+static bool bg_vec_ok(const BwdGemmK& p, int contiguous_a_extent) {
+  auto al = [](const void* q) { return (reinterpret_cast<size_t>(q) & 15) == 0; };
+  return (p.ldA & 3) == 0 && (p.ldB & 3) == 0 && (p.J & 3) == 0 && (contiguous_a_extent & 3) == 0 &&
+         al(p.A) && al(p.Bm) && (p.relu == nullptr || al(p.relu));
+}
+
 int launch_linear_bwd_data(const float* dy, const float* relu_out, const int* row_gate,
                            const float* w, const float* in_relu_mask, float* dx, int M, int K,
                            int N, float alpha, int accumulate, hipStream_t s) {
@@ -151,10 +220,13 @@ int launch_linear_bwd_data(const float* dy, const float* relu_out, const int* ro
   p.colsum = nullptr; p.ldA = N; p.ldB = K; p.ldC = K; p.I = M; p.J = K; p.R = N;
   p.rchunk = ((N + BG_RK - 1) / BG_RK) * BG_RK; p.accumulate = accumulate; p.alpha = alpha;
   const int mt = (M + 63) / 64;
-  if (mt * ((K + 63) / 64) >= 200)          // enough 64-wide tiles to fill the chip
-    hipLaunchKernelGGL((bwd_gemm_kernel<BWD_DATA, 64>), dim3((K + 63) / 64, mt, 1), dim3(256), 0, s, p);
-  else
-    hipLaunchKernelGGL((bwd_gemm_kernel<BWD_DATA, 32>), dim3((K + 31) / 32, mt, 1), dim3(256), 0, s, p);
+  const bool vec = bg_vec_ok(p, N);         // A = dY[m][n]: contiguous along the reduction index n
+  const bool wide = mt * ((K + 63) / 64) >= 200;          // enough 64-wide tiles to fill the chip
+  const dim3 grid(wide ? (K + 63) / 64 : (K + 31) / 32, mt, 1);
+  if (wide && vec) hipLaunchKernelGGL((bwd_gemm_kernel<BWD_DATA, 64, true>), grid, dim3(256), 0, s, p);
+  else if (wide) hipLaunchKernelGGL((bwd_gemm_kernel<BWD_DATA, 64, false>), grid, dim3(256), 0, s, p);
+  else if (vec) hipLaunchKernelGGL((bwd_gemm_kernel<BWD_DATA, 32, true>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((bwd_gemm_kernel<BWD_DATA, 32, false>), grid, dim3(256), 0, s, p);
   return check_launch("linear_bwd_data");
 }
 
@@ -167,9 +239,11 @@ int launch_linear_bwd_weight(const float* x, const float* dy, const float* relu_
   p.colsum = db; p.ldA = N; p.ldB = K; p.ldC = K; p.I = N; p.J = K; p.R = M;
   p.rchunk = 64; p.accumulate = 1; p.alpha = alpha;
   TC_REQUIRE(dw != nullptr, "linear_bwd_weight: dw is NULL");
-  hipLaunchKernelGGL((bwd_gemm_kernel<BWD_WEIGHT, 64>),
-                     dim3((K + 63) / 64, (N + 63) / 64, (M + p.rchunk - 1) / p.rchunk), dim3(256),
-                     0, s, p);
+  const dim3 grid((K + 63) / 64, (N + 63) / 64, (M + p.rchunk - 1) / p.rchunk);
+  if (bg_vec_ok(p, N))                      // A = dY[m][n]: contiguous along the output row index n
+    hipLaunchKernelGGL((bwd_gemm_kernel<BWD_WEIGHT, 64, true>), grid, dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL((bwd_gemm_kernel<BWD_WEIGHT, 64, false>), grid, dim3(256), 0, s, p);
   return check_launch("linear_bwd_weight");
 }
 
