@@ -22,10 +22,10 @@ python bench.py --train --steps 50 --warmup 5 > "$OUT/bench_train.json" 2>> "$OU
 cd /tmp
 Q="--main-only --min-window-s 0.05 --warmup-s 0.05"   # the timed loop only, short windows: small traces
 # per-kernel durations, one launch sequence at a time (with frames in flight the kernels of different lanes share the GPU)
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python3 "$REPO/bench.py" --lanes 1 --steps 50 --warmup 5 $Q > "$OUT/prof.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python3 "$REPO/bench.py" --lanes 1 --pair 8 --steps 48 --warmup 8 $Q > "$OUT/prof.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_pair1" -- python3 "$REPO/bench.py" --lanes 1 --pair 1 --steps 50 --warmup 5 $Q > "$OUT/prof_pair1.log" 2>&1
 # the default command (3 lanes): trace of the overlap
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_lanes" -- python3 "$REPO/bench.py" --steps 50 --warmup 5 $Q > "$OUT/prof_lanes.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_lanes" -- python3 "$REPO/bench.py" --pair 8 --steps 48 --warmup 8 $Q > "$OUT/prof_lanes.log" 2>&1
 for B in 10 8 4 2 1; do
   for C in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
     rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_${C}_b$B" -- python3 "$REPO/bench.py" --batch $B --steps 5 --warmup 2 $Q --no-graph > "$OUT/pmc_${C}_b$B.log" 2>&1
