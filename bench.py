@@ -388,7 +388,7 @@ def single_lane(pipe, args):
             'ms_per_frame_synced': t_sync * 1e3 / args.batch}
 
 
-def handoff_side_run(head, dev, args):
+def handoff_side_run(head, dev, args, streams=None):
     """The same frame WITH the reference's hand-off inside it: the FPN returns NCHW maps
     (DET:62-66), so every lane's graph starts with the NCHW -> NHWC transposes of its four levels
     (tc_nchw_to_nhwc_levels, one launch).  A channels_last FPN skips this (zero-copy)."""
@@ -401,7 +401,7 @@ def handoff_side_run(head, dev, args):
         inp['nchw'] = [f.view(fpl, 6, f.shape[1], f.shape[2], f.shape[3]).permute(0, 1, 4, 2, 3).contiguous()
                        for f in inp['nhwc']]
         lanes.append(inp)
-    pipe = FramePipeline(head, lanes, tile_rows=args.tile_rows or None)
+    pipe = FramePipeline(head, lanes, tile_rows=args.tile_rows or None, streams=streams)
     for _ in range(3 * pipe.lanes):
         pipe.launch()
     n = max(20, args.steps)
@@ -419,13 +419,13 @@ def handoff_side_run(head, dev, args):
                           'frac': nbytes / tr_ms / 1e6 / HBM_PEAK_GBS}}
 
 
-def staged_side_run(head, lanes_inputs, args):
+def staged_side_run(head, lanes_inputs, args, streams=None):
     """Input delivery with the H2D copies inside the lanes' graphs (FramePipeline(host_staging=True)):
     per frame the producer writes tokens + lidar2img into the lane's pinned staging tensors on the
     CPU (after a host-side wait for that lane's previous replay) and replays -- no copy call and no
     stream hand-shake per frame."""
     from transcar_amd.pipeline import FramePipeline
-    pipe = FramePipeline(head, lanes_inputs, tile_rows=args.tile_rows or None, host_staging=True)
+    pipe = FramePipeline(head, lanes_inputs, tile_rows=args.tile_rows or None, host_staging=True, streams=streams)
     src = [dict(tokens=h['tokens'].clone(), l2i=h['l2i'].clone()) for h in pipe.host]
     state = {'i': 0}
 
@@ -476,7 +476,7 @@ def producer_side_run(pipe, args):
                 'feature_bytes_per_frame': sum(int(f.numel()) * 4 for f in spare) // fpl}}
 
 
-def sweep_side_run(head, dev, args, skip):
+def sweep_side_run(head, dev, args, skip, streams=None):
     """Not the headline: the same pipeline at the other frames-per-launch settings (same lanes,
     the caller submits one frame per step everywhere), so that one bench line shows what pairing
     buys: 1 = one frame per launch (4-row tiles, a workgroup bound by its weight stream, DESIGN.md
@@ -489,7 +489,7 @@ def sweep_side_run(head, dev, args, skip):
             continue
         lanes = [make_inputs(head, dev, args.shapes, fpl, seed=31 + 5 * i, host_feats=False)
                  for i in range(max(1, args.lanes))]
-        pipe = FramePipeline(head, lanes)
+        pipe = FramePipeline(head, lanes, streams=streams)      # the headline pipeline's (idle) streams
         step = (lambda: pipe.launch()) if fpl == 1 else pipe.submit
 
         def sync():
@@ -871,12 +871,13 @@ def main(argv=None):
         if world == 1:
             if pipe is not None and not args.main_only:
                 line['with_input_delivery'] = producer_side_run(pipe, args)
-                line['with_input_delivery']['tokens_l2i_h2d_in_graph'] = staged_side_run(head, pipe.inputs, args)
+                line['with_input_delivery']['tokens_l2i_h2d_in_graph'] = staged_side_run(head, pipe.inputs, args, streams=pipe.streams)
             if not args.no_handoff and not args.no_graph:
-                line['with_handoff'] = handoff_side_run(head, dev, args)
+                line['with_handoff'] = handoff_side_run(head, dev, args, streams=pipe.streams)
                 line['with_handoff_ms'] = line['with_handoff']['ms_per_frame']
             if args.batch == 1 and not args.no_batched and pipe is not None:
-                line['frames_per_launch_sweep'] = sweep_side_run(head, dev, args, pipe.frames_per_launch)
+                line['frames_per_launch_sweep'] = sweep_side_run(head, dev, args, pipe.frames_per_launch,
+                                                                 streams=pipe.streams)
             if not args.no_cpu_baseline:
                 line['cpu_baseline'] = cpu_baseline(sd, inp, args.cpu_seconds)
         print(json.dumps(line), flush=True)

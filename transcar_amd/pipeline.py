@@ -50,7 +50,8 @@ class FramePipeline:
     8 at one frame per lane buys throughput with >= 3 lanes and costs latency.
     """
 
-    def __init__(self, head, static_inputs, decode=True, tile_rows=None, options=None, host_staging=False):
+    def __init__(self, head, static_inputs, decode=True, tile_rows=None, options=None, host_staging=False,
+                 streams=None):
         if not static_inputs:
             raise ValueError('at least one lane')
         from .detr3d_head import head_options
@@ -62,7 +63,14 @@ class FramePipeline:
             raise ValueError('all lanes must have the same number of frame slots')
         self._filled = [0] * len(self.inputs)
         self._fill_lane = 0
-        self.streams = [torch.cuda.Stream() for _ in self.inputs]
+        # streams: reuse the HIP streams of another (idle) pipeline.  A process has a handful of hardware
+        # queues (GPU_MAX_HW_QUEUES, 4 by default) and streams are mapped onto them as they are created:
+        # the lanes of a THIRD or fourth pipeline of a process can end up sharing a queue, i.e. serialised
+        # (bench.py's side runs measured 3 lanes at the 2-lane rate that way).
+        if streams is not None and len(streams) < len(self.inputs):
+            raise ValueError('streams: need one per lane')
+        self.streams = list(streams[:len(self.inputs)]) if streams is not None else \
+            [torch.cuda.Stream() for _ in self.inputs]
         self.done = [torch.cuda.Event() for _ in self.inputs]
         self.options = options if options is not None else head_options(tile_rows=tile_rows)
         # host_staging: every lane gets pinned host tensors for the small per-frame inputs that come
