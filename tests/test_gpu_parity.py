@@ -820,3 +820,40 @@ def test_missing_gpu_inputs_fail_loudly(T, head):
     feats = [torch.from_numpy(f) for f in synth.make_feats('tiny', seed=1)]
     with pytest.raises(T.TransCARHipError):
         head(feats, synth.make_img_metas(1, radar=synth.make_radar_frame()))
+
+
+@pytest.mark.parametrize('case', ['ramp_up', 'ramp_down', 'huge_negative_start', 'spikes', 'short_ragged'])
+def test_sdpa_lazy_recentring_extreme_scores(T, case):
+    """The attention core re-centres its running reference only when a score exceeds it by 2^8
+    (self_attn.hip): score sequences built to stress that -- monotone ramps over the keys (every tile
+    above / below the last), a first tile hundreds of octaves below the rest, isolated spikes, a key
+    count that leaves several waves without a tile -- against softmax(S) V in float64."""
+    from transcar_amd import ops
+    rng = np.random.RandomState(7)
+    B, H, D = 2, 8, 32
+    Q = 37 if case == 'short_ragged' else 900
+    C = H * D
+    q = rng.standard_normal((B, Q, C)).astype(np.float32)
+    k = rng.standard_normal((B, Q, C)).astype(np.float32)
+    v = rng.standard_normal((B, Q, C)).astype(np.float32)
+    # one channel per head carries a key-dependent offset: q[..., 0] = 1 and k[..., 0] = f(key)
+    f = {'ramp_up': np.linspace(-150.0, 150.0, Q), 'ramp_down': np.linspace(150.0, -150.0, Q),
+         'huge_negative_start': np.where(np.arange(Q) < 16, -400.0, rng.uniform(-3, 3, Q)),
+         'spikes': np.where(rng.uniform(size=Q) < 0.01, 120.0, 0.0),
+         'short_ragged': np.linspace(-40.0, 40.0, Q)}[case].astype(np.float32)
+    for h in range(H):
+        q[:, :, h * D] = 1.0
+        k[:, :, h * D] = f[None, :]
+    # the kernel's q is pre-scaled by log2(e) / sqrt(D) and its softmax is 2^x: S = q k^T / sqrt(D) in nats
+    qs = torch.from_numpy(q) * (1.4426950408889634 / np.sqrt(D))
+    qpad = ((Q + 15) // 16) * 16
+    vt = torch.zeros((B, C, qpad), dtype=torch.float32)
+    vt[:, :, :Q] = torch.from_numpy(v).permute(0, 2, 1)
+    got = ops.sdpa(gpu(qs), gpu(k), gpu(vt)).cpu().double()
+    qd = torch.from_numpy(q).double().view(B, Q, H, D).permute(0, 2, 1, 3)
+    kd = torch.from_numpy(k).double().view(B, Q, H, D).permute(0, 2, 1, 3)
+    vd = torch.from_numpy(v).double().view(B, Q, H, D).permute(0, 2, 1, 3)
+    p = torch.softmax(qd @ kd.transpose(-1, -2) / np.sqrt(D), -1)
+    want = (p @ vd).permute(0, 2, 1, 3).reshape(B, Q, C)
+    assert torch.isfinite(got).all()
+    np.testing.assert_allclose(got.numpy(), want.numpy(), atol=2e-5, rtol=1e-4)
