@@ -76,6 +76,9 @@ def parse(argv=None):
     ap.add_argument('--last-cls-only', action='store_true',
                     help='inference opt-in tc_head_options.last_level_cls_only: final_cls / final_cls2 are not '
                          'evaluated (get_bboxes decodes level 3 only); NOT the reference output contract')
+    ap.add_argument('--no-radar-compact', action='store_true',
+                    help='tc_head_options.radar_row_order = 1: the radar chain keeps the queries in their own order '
+                         '(default: beyond one frame per launch, queries with a radar hit go first)')
     ap.add_argument('--main-only', action='store_true',
                     help='only the main timed loop: no single-lane, roofline, delivery, hand-off, batched or CPU '
                          'side measurements (kernel traces of tools/profile_round.sh)')
@@ -804,7 +807,8 @@ def main(argv=None):
                            for i in range(1, max(1, args.lanes))]
         from transcar_amd.detr3d_head import head_options
         pipe = FramePipeline(head, lanes, options=head_options(tile_rows=args.tile_rows or None,
-                                                              last_level_cls_only=args.last_cls_only))
+                                                              last_level_cls_only=args.last_cls_only,
+                                                              radar_compact=False if args.no_radar_compact else None))
 
     def step():
         if pipe is None:
@@ -857,7 +861,8 @@ def main(argv=None):
             # one frame at a time, host sync per frame: the reference's own method
             # (tools/analysis_tools/benchmark.py:64-91) -- the latency of a frame
             from transcar_amd.pipeline import FramePipeline
-            pipe1 = pipe if pipe.frames_per_launch == args.batch else FramePipeline(head, [inp])
+            pipe1 = pipe if pipe.frames_per_launch == args.batch else \
+                FramePipeline(head, [inp], options=head_options(radar_compact=False if args.no_radar_compact else None))
             line['single_lane'] = single_lane(pipe1, args)
             line['latency_ms_per_frame'] = line['single_lane']['ms_per_frame_synced']
         if not args.no_roofline:

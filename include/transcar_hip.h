@@ -142,7 +142,11 @@ typedef struct {
    * site = 16 + 8 * layer + {0 attention probabilities, 1 self-attention output, 2 cross-
    * attention output, 3 FFN hidden, 4 FFN output}. */
   float decoder_dropout_p;
-  float reserved1;
+  int radar_row_order;      /* the radar chain's row order: 0 = automatic, 1 = the queries' own order, 2 = queries
+                               with a radar return inside their first gate first, so that the row tiles
+                               without any skip the gated attention part (two small extra launches: worth it
+                               beyond one frame per launch, which is what automatic does).  Outputs are
+                               bit-identical either way */
   unsigned long long dropout_seed;
 } tc_head_options;
 

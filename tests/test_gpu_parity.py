@@ -857,3 +857,25 @@ def test_sdpa_lazy_recentring_extreme_scores(T, case):
     want = (p @ vd).permute(0, 2, 1, 3).reshape(B, Q, C)
     assert torch.isfinite(got).all()
     np.testing.assert_allclose(got.numpy(), want.numpy(), atol=2e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize('tile_rows', [0, 16])
+def test_radar_row_order_is_invisible_in_the_outputs(T, head, tile_rows):
+    """tc_head_options.radar_row_order: with the queries that have a radar return inside their first gate
+    processed first (row tiles without any skip the q projection / gated attention / out_proj), scores,
+    boxes and hit counts are bit for bit those of the queries' own order -- two samples per launch (a tile
+    straddles the sample boundary), 4-row and 16-row tiles."""
+    import bench
+    bench._imports()
+    from transcar_amd.detr3d_head import head_options
+    inp = bench.make_inputs(head, dev(), 'tiny', 2, seed=23)
+    outs = {}
+    for name, compact in (('own', False), ('hits_first', True)):
+        o = head.forward_nhwc(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'], inp['pad_mult'], aux=True,
+                              options=head_options(tile_rows=tile_rows or None, radar_compact=compact))
+        torch.cuda.synchronize()
+        outs[name] = (o['all_cls_scores'].clone(), o['all_bbox_preds'].clone(), o['aux']['radar_hit_counts'].clone())
+    hits = outs['own'][2]
+    assert int((hits > 0).sum()) > 100 and int((hits == 0).sum()) > 1000        # both kinds of rows exist
+    for a_, b_ in zip(outs['own'], outs['hits_first']):
+        assert torch.equal(a_, b_)

@@ -101,7 +101,7 @@ class tc_head_aux(C.Structure):
 class tc_head_options(C.Structure):
     _fields_ = [('chain_tile_rows', C.c_int), ('unfused', C.c_int),
                 ('last_level_cls_only', C.c_int), ('reuse_radar_kv', C.c_int),
-                ('decoder_dropout_p', C.c_float), ('reserved1', C.c_float),
+                ('decoder_dropout_p', C.c_float), ('radar_row_order', C.c_int),
                 ('dropout_seed', C.c_ulonglong)]
 
 

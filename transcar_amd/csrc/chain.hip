@@ -106,6 +106,11 @@ template <int N> struct Recs { StepAll s[N]; };
 // 512 + 4) spans units 1 and 2.  query_pos is not held at all: the LayerNorm in front of the two
 // linears that need x + query_pos writes that sum next to x (F_LN_XP).  R = 16: 66.6 KB + records
 // = 76 KB -- two workgroups per CU.
+// radar: the gate's hit tokens per row, 64 per word (T <= 64 * HM_WORDS), live from K_RADAR_GATE to
+// K_RADAR_ATTN in the row's slice of `l` (free until the layer's last two steps) -- the radar program at
+// R = 16 is 81.4 KB: 544 bytes more and only one workgroup fits a CU
+constexpr int HM_WORDS = 8;
+static_assert(HM_WORDS * 8 <= LDL * 4 && (LDL * 4) % 8 == 0, "hit masks live in a row of the logit buffer");
 template <int R, int NREC>
 struct ChainLds {
   StepAll recs[NREC];
@@ -114,6 +119,7 @@ struct ChainLds {
   float box[R][12];
   float cen[R][4];
   int gate[R];
+  int rowg[R];                 // radar: the global row of tile position i (ChainDev::row_perm, else m0 + i)
 };
 static_assert(LD5 * 1 <= 2 * LD2, "the 512-wide tile must fit two units");
 
@@ -130,7 +136,7 @@ static_assert(LD5 * 1 <= 2 * LD2, "the 512-wide tile must fit two units");
 // ---- step tables -----------------------------------------------------------
 enum Buf : short { B_NONE = -1, B_A = 0 /* units 1+2, row stride LD5 */, B_X /* unit 0 */, B_U1, B_U2, B_U3, B_L };
 enum Kind : short {
-  K_END = 0, K_LOAD, K_LINEAR, K_LN, K_POSENC, K_SAMPLE, K_REFUPD, K_TOKENS, K_RADAR_ATTN, K_BOXADD,
+  K_END = 0, K_LOAD, K_LINEAR, K_LN, K_POSENC, K_SAMPLE, K_REFUPD, K_TOKENS, K_RADAR_ATTN, K_BOXADD, K_RADAR_GATE,
   K_NOP   // a step switched off at run time (no next layer): only its barrier remains
 };
 enum NSpecial : short { N_LOGITS = -1, N_CODE = -2, N_CLS = -3 };
@@ -143,7 +149,9 @@ enum Flags : short {
   F_WAVE1 = 32,       // linear: column tile t goes to wave (t + 1) % 4 -- a narrow step (one tile)
                       //   then runs BESIDE the preceding narrow step, which keeps wave 0 busy
   F_NOT_W0 = 64,      // posenc: rows go to waves 1..3 only (wave 0 is in a narrow linear step)
-  F_LN_XP = 128       // ln: also write (result + query_pos row) into the buffer named by `res`
+  F_LN_XP = 128,      // ln: also write (result + query_pos row) into the buffer named by `res`
+  F_IFHIT = 256       // radar: the step only matters for rows with a radar hit -- skipped when no row of the
+                      //   tile has one (a linear step then copies `res` to `dst`: x + gate * (...) = x)
 };
 // global tensors, indices into ChainK::g
 enum GSel : short {
@@ -222,10 +230,15 @@ constexpr StepDesc PROG_RADAR_ENC_B_T[] = {
     {K_END, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
 // radar layer pairs (+14*r): 0 attn.in_proj 1 attn.out_proj 2 norm2 3 linear1 4 linear2 5 norm3
 //   6 cls.0 7 cls.n1 8 cls.3 9 cls.n4 10 cls.6 11 reg.0 12 reg.2 13 reg.4
+// The gate goes first: ~76 % of the queries have no radar return inside their circles (G5 rig: 214 / 219 /
+// 69 of 900 have one), and for a tile without a single hit the q projection, the attention and the
+// out_proj are x + 0 * (...): skipped (F_IFHIT).  launch_radar_compact orders the rows so that such tiles
+// are the rule, not a 0.76^R accident.
 constexpr StepDesc PROG_RADAR_LAYER_T[] = {
-    {K_LINEAR, 0, -1, 256, 256, B_X, B_NONE, B_U1, B_NONE, 0, F_SCALEQ, G_NONE, G_NONE, 1},  // q projection
-    {K_RADAR_ATTN, 0, 0, 0, 0, B_U1, B_NONE, B_U2, B_NONE, 0, 0, G_NONE, G_NONE, 1},
-    {K_LINEAR, 1, -1, 256, 256, B_U2, B_NONE, B_U3, B_X, 0, F_GATE, G_NONE, G_NONE, 1},      // x + gate*out_proj
+    {K_RADAR_GATE, 0, 0, 0, 0, B_NONE, B_NONE, B_NONE, B_NONE, 0, 0, G_NONE, G_NONE, 1},     // hit counts of the R rows
+    {K_LINEAR, 0, -1, 256, 256, B_X, B_NONE, B_U1, B_NONE, 0, F_SCALEQ | F_IFHIT, G_NONE, G_NONE, 1},  // q projection
+    {K_RADAR_ATTN, 0, 0, 0, 0, B_U1, B_NONE, B_U2, B_NONE, 0, F_IFHIT, G_NONE, G_NONE, 1},
+    {K_LINEAR, 1, -1, 256, 256, B_U2, B_NONE, B_U3, B_X, 0, F_GATE | F_IFHIT, G_NONE, G_NONE, 1},      // x + gate*out_proj
     {K_LN, 2, -1, 0, 0, B_U3, B_NONE, B_X, B_NONE, 0, 0, G_NONE, G_NONE, 1},                 // rf_norm2
     {K_LINEAR, 3, -1, 256, 512, B_X, B_NONE, B_A, B_NONE, 1, 0, G_NONE, G_NONE, 1},
     {K_LINEAR, 4, -1, 512, 256, B_A, B_NONE, B_U3, B_X, 0, 0, G_NONE, G_NONE, 1},
@@ -265,6 +278,7 @@ struct ChainDev {
   int cen_from_box;            // the first layer run is not fusion layer 1: gate centre = previous box
   float rmin[TC_MAX_RADAR_LAYERS], rmax[TC_MAX_RADAR_LAYERS];
   float* all_box; int* hits;
+  const int* row_perm;         // radar: optional row order (launch_radar_compact), rows stay in their sample
 };
 // ... plus what only the host-side resolver needs
 struct ChainK : ChainDev {
@@ -306,6 +320,7 @@ struct LinSpec {
   int sub_on;
   int drop_site;               // DROP instantiations: site + 1 of this step's output dropout (0: none)
   unsigned long long drop_seed; unsigned drop_thr; float drop_scale;
+  const int* rowg;             // radar: LDS table tile position -> global row for the gdst stores (null: m0 + i)
 };
 
 // One work item = (64-column output tile, 64-deep k block): 16 x 16-byte weight
@@ -451,12 +466,14 @@ __device__ __forceinline__ void lin_epilogue(const LinSpec& s, int tile, const A
       for (int i = 0; i < 4; ++i) s.dst[(4 * g + i) * s.dst_ld + col] = y[g][i];
   }
   if (s.gdst != nullptr) {
-    float* gp = s.gdst + (size_t)s.m0 * s.gdst_ld + col;
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        if (s.m0 + 4 * g + i < s.M) stg1(gp + (size_t)(4 * g + i) * s.gdst_ld, y[g][i]);
+        if (s.m0 + 4 * g + i < s.M) {
+          const int grow = s.rowg != nullptr ? s.rowg[4 * g + i] : s.m0 + 4 * g + i;
+          stg1(s.gdst + (size_t)grow * s.gdst_ld + col, y[g][i]);
+        }
   }
   if (s.gt != nullptr) {
 #pragma unroll
@@ -579,10 +596,12 @@ __device__ __forceinline__ void lin_epilogue16(const LinSpec& s, int tile, const
       for (int i = 0; i < 4; ++i) s.dst[(4 * g + i) * s.dst_ld + col] = y[j][i];
     }
     if (s.gdst != nullptr) {
-      float* gp = s.gdst + (size_t)s.m0 * s.gdst_ld + col;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        if (s.m0 + 4 * g + i < s.M) stg1(gp + (size_t)(4 * g + i) * s.gdst_ld, y[j][i]);
+        if (s.m0 + 4 * g + i < s.M) {
+          const int grow = s.rowg != nullptr ? s.rowg[4 * g + i] : s.m0 + 4 * g + i;
+          stg1(s.gdst + (size_t)grow * s.gdst_ld + col, y[j][i]);
+        }
     }
     if (s.gt != nullptr) {
       const int row0 = s.m0 + 4 * g;
@@ -940,15 +959,21 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
   START_STAMP(43);
 
   if (PROG == PROG_RADAR) {     // HEAD:539, 543-547, 596-598
+    // tile position -> row: the identity, or the order of launch_radar_compact (hit rows first)
+    auto row_of = [&](int row) {
+      const int pos = min(m0 + row, M - 1);
+      return k.row_perm != nullptr ? k.row_perm[pos] : pos;
+    };
+    if (threadIdx.x < R) S.rowg[threadIdx.x] = row_of(threadIdx.x);
     for (int row = wave; row < R; row += CH_NW) {
-      const int grow = min(m0 + row, M - 1);
+      const int grow = row_of(row);
       *reinterpret_cast<float4*>(&S.unit[0][row][4 * lane]) = ld4(k.g[G_QF] + (size_t)grow * 256 + 4 * lane);
     }
     {
       // one (row, column) per thread: columns 0..code-1 the previous box, 12..14 the gate centre
       const int row = threadIdx.x >> 4, j = threadIdx.x & 15;
       if (row < R) {
-        const int grow = min(m0 + row, M - 1);
+        const int grow = row_of(row);
         if (j < k.code) S.box[row][j] = k.box_in[(size_t)grow * k.code + j];
         if (j >= 12 && j < 15) {
           const int c = j - 12;
@@ -1034,6 +1059,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
     s.dbg = k.dbg;
     s.sub_on = 0;
     s.drop_site = 0; s.drop_seed = 0; s.drop_thr = 0; s.drop_scale = 1.0f;
+    s.rowg = nullptr;
     return s;
   };
   // ... and the part its epilogue needs, rebuilt per tile from the 64-byte LDS record
@@ -1056,10 +1082,19 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
     s.dbg = 0;
     s.sub_on = 0;
     s.drop_site = 0; s.drop_seed = 0; s.drop_thr = 0; s.drop_scale = 1.0f;
+    s.rowg = (PROG == PROG_RADAR && k.row_perm != nullptr) ? &S.rowg[0] : nullptr;
     if (DROP) {
       s.drop_site = e.drop_site; s.drop_seed = k.drop.seed; s.drop_thr = k.drop.thr; s.drop_scale = k.drop.scale;
     }
     return s;
+  };
+
+  // radar program: does any row of this tile have a radar return inside its gate (this layer)?
+  auto tile_has_hit = [&]() {
+    int any = 0;
+#pragma unroll
+    for (int i = 0; i < R; ++i) any |= S.gate[i];
+    return __builtin_amdgcn_readfirstlane(any) > 0;
   };
 
   int idx = (CHAIN_DBG(k.dbg) & 16) ? total : early_n;          // the leading loads are already in LDS
@@ -1077,7 +1112,20 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
       for (;;) {
         const StepRes r = load_uniform<StepRes>(S.recs[idx].r);
         const int kd = r.kind;
-        if (kd == K_LINEAR) {
+        bool skip = false;
+        if constexpr (PROG == PROG_RADAR) {
+          if (kd == K_LINEAR && (r.flags & F_IFHIT)) skip = !tile_has_hit();
+        }
+        if (skip) {
+          // every row gate is 0: dst = res + 0 * (...) (a step without a residual only feeds skipped steps).
+          // w0 may hold this step's first item: pre_idx then names a step that is not the next one -> fresh load
+          if (r.res != B_NONE && r.dst != B_NONE) {
+            const float* rs = buf_ptr(S, r.res); const int rld = buf_ld(r.res);
+            float* dd = buf_ptr(S, r.dst);
+            for (int row = wave; row < R; row += CH_NW)
+              *reinterpret_cast<float4*>(dd + row * LD2 + 4 * lane) = *reinterpret_cast<const float4*>(rs + row * rld + 4 * lane);
+          }
+        } else if (kd == K_LINEAR) {
           LinSpec s = lin_spec(r);
 #ifdef TC_CHAIN_STAMPS
           s.sub_on = (r.si == g_sub_step && r.rep == 0);
@@ -1208,10 +1256,56 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
         }
       } break;
       } break;
-      case K_RADAR_ATTN: { if constexpr (PROG == PROG_RADAR) {   // distance-gated attention (HEAD:549-579)
+      case K_RADAR_GATE: { if constexpr (PROG == PROG_RADAR) {   // the gate of HEAD:549-567 alone: hit counts + masks
+        // the tokens' xy once per wave when they fit four words (T <= 256, the packed default; a tile's
+        // rows are one sample's, two at a sample boundary); masks are kept up to 64 * HM_WORDS tokens
+        constexpr int GW = 4;
+        const bool keep = k.T <= 64 * HM_WORDS, cached = k.T <= 64 * GW;
+        const int b0 = S.rowg[wave] / k.Q;
+        float ty0[GW], ty1[GW];
+        if (cached) {
+          const float* rxy = k.tokens + (size_t)b0 * k.T * k.RI;
+#pragma unroll
+          for (int w = 0; w < GW; ++w) {
+            const int t = min(64 * w + lane, k.T - 1);
+            ty0[w] = rxy[(size_t)t * k.RI]; ty1[w] = rxy[(size_t)t * k.RI + 1];
+          }
+        }
 #pragma unroll 1
         for (int row = wave; row < R; row += CH_NW) {
-          const int grow = min(m0 + row, M - 1);
+          const int grow = S.rowg[row];
+          const int b = grow / k.Q;
+          int count = 0;
+          if (cached && b == b0) {
+            const GateGeom gg(S.cen[row][0], S.cen[row][1], S.box[row][3], S.box[row][6], S.box[row][7],
+                              k.rmin[rep], k.rmax[rep]);
+#pragma unroll
+            for (int w = 0; w < GW; ++w) {
+              if (64 * w < k.T) {                            // wave-uniform
+                const unsigned long long mask =
+                    __ballot(64 * w + lane < k.T && gg.hit(ty0[w], ty1[w], sqnorm2(ty0[w], ty1[w])));
+                count += __popcll(mask);
+                if (k.T - 1 >= 64 * w && k.T - 1 < 64 * w + 64 && ((mask >> (k.T - 1 - 64 * w)) & 1ull)) count += k.pad_mult - 1;
+                if (lane == 0) reinterpret_cast<unsigned long long*>(&S.l[row][0])[w] = mask;
+              }
+            }
+          } else {
+            count = radar_gate_count(S.cen[row][0], S.cen[row][1], S.box[row][3], S.box[row][6], S.box[row][7],
+                                     k.rmin[rep], k.rmax[rep], k.tokens + (size_t)b * k.T * k.RI, k.RI, k.T,
+                                     k.pad_mult, lane, keep ? reinterpret_cast<unsigned long long*>(&S.l[row][0]) : nullptr);
+          }
+          if (lane == 0) {
+            S.gate[row] = count;
+            if (m0 + row < M) k.hits[(size_t)rep * M + grow] = count;
+          }
+        }
+      } break;
+      } break;
+      case K_RADAR_ATTN: { if constexpr (PROG == PROG_RADAR) {   // distance-gated attention (HEAD:549-579)
+        if ((r.flags & F_IFHIT) && !tile_has_hit()) break;      // its output only feeds the (skipped) out_proj
+#pragma unroll 1
+        for (int row = wave; row < R; row += CH_NW) {
+          const int grow = S.rowg[row];
           const int b = grow / k.Q;
           const float4 q4 = *reinterpret_cast<const float4*>(buf_ptr(S, r.src) + row * LD2 + 4 * lane);
           const float* kv = (rep == 0 ? k.g[G_KV0] : rep == 1 ? k.g[G_KV1] : k.g[G_KV2]);
@@ -1219,12 +1313,10 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
           const float4 o = radar_attn_row(S.cen[row][0], S.cen[row][1], S.box[row][3], S.box[row][6],
                                           S.box[row][7], k.rmin[rep], k.rmax[rep], q4,
                                           k.tokens + (size_t)b * k.T * k.RI, k.RI,
-                                          kv + (size_t)b * k.T * 512, 512, k.T, k.pad_mult, lane, count);
+                                          kv + (size_t)b * k.T * 512, 512, k.T, k.pad_mult, lane, count, DropK(), 0,
+                                          k.T <= 64 * HM_WORDS ? reinterpret_cast<const unsigned long long*>(&S.l[row][0]) : nullptr);
           *reinterpret_cast<float4*>(buf_ptr(S, r.dst) + row * LD2 + 4 * lane) = o;
-          if (lane == 0) {
-            S.gate[row] = count;
-            if (m0 + row < M) k.hits[(size_t)rep * M + m0 + row] = count;
-          }
+          if (lane == 0) S.gate[row] = count;        // the same count as K_RADAR_GATE's (same predicate)
         }
       } break;
       } break;
@@ -1235,7 +1327,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
           float bx = S.l[row][j];
           if (c >= 0) { bx += S.cen[row][c]; S.cen[row][c] = bx; }   // only this thread touches cen[row][c]
           S.box[row][j] = bx;
-          if (m0 + row < M) k.all_box[((size_t)rep * M + m0 + row) * k.code + j] = bx;
+          if (m0 + row < M) k.all_box[((size_t)rep * M + S.rowg[row]) * k.code + j] = bx;
         }
       } break;
       } break;
@@ -1584,6 +1676,7 @@ int launch_radar_chain(const RadarChainArgs& a, hipStream_t s) {
   init_k(k);
   k.program = PROG_RADAR; k.M = a.M; k.Q = a.Q; k.code = a.code; k.ncls = a.ncls; k.nlayers = a.nlayers;
   k.w16_delta = a.w[0].packed16_delta;
+  k.row_perm = a.row_perm;
   k.has_next = 1;
   for (int r = 0; r < a.nlayers; ++r) {
     const tc_radar_layer& w = a.w[r];

@@ -123,6 +123,7 @@ struct HeadWs {
   float *tp0, *tp1, *f0, *f1, *f2, *radar_feat, *kv, *qproj, *rattn, *cxy, *addref, *qf;
   float* kv3[TC_MAX_RADAR_LAYERS];
   int* hits;
+  int *perm, *hitflag;        // row order of the radar chain (launch_radar_compact) + its scratch
   int qpad;
 };
 
@@ -152,6 +153,7 @@ static size_t head_ws_layout(const tc_head_weights* w, int B, int T, void* base,
   h.cxy = a.take<float>(rows * 2); h.addref = a.take<float>(rows * 3);
   h.qf = a.take<float>(rows * C);
   h.hits = a.take<int>((size_t)TC_MAX_RADAR_LAYERS * rows);
+  h.perm = a.take<int>(rows); h.hitflag = a.take<int>(rows);
   if (out) *out = h;
   return a.off;
 }
@@ -260,6 +262,12 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
   for (int i = 0; i < 6; ++i) rc.pc[i] = w->pc_range[i];
   rc.all_cls = all_cls_scores; rc.all_box = all_bbox_preds; rc.hits = h.hits;
   rc.tile_rows = opt.chain_tile_rows; rc.last_cls_only = opt.last_level_cls_only;
+  if (opt.radar_row_order == 2 || (opt.radar_row_order == 0 && rows > 1024)) {
+    // queries with a radar return inside their first gate go first: the other tiles skip the gated part
+    TC_TRY(launch_radar_compact(rc.ref_last, rc.box_m, code, 0, w->pc_range, radar_tokens, w->radar_in_dims, B, Q, T,
+                                w->radar[0].radius_min, w->radar[0].radius_max, h.hitflag, h.perm, s));
+    rc.row_perm = h.perm;
+  }
   TC_TRY(launch_radar_chain(rc, s));
   if (aux && aux->radar_hit_counts)
     TC_HIP(hipMemcpyAsync(aux->radar_hit_counts, h.hits, (size_t)w->num_radar_layers * rows * 4,
@@ -544,6 +552,12 @@ int tc_radar_fusion_fwd(const tc_head_weights* packed_view, const float* hs_last
   rc.all_box = all_bbox_preds + (size_t)first_layer * rows * code;
   rc.hits = h.hits; rc.tile_rows = opt.chain_tile_rows; rc.last_cls_only = opt.last_level_cls_only;
   rc.cen_from_box = first_layer > 0;
+  if (opt.radar_row_order == 2 || (opt.radar_row_order == 0 && rows > 1024)) {
+    TC_TRY(launch_radar_compact(ref_last, prev_box, code, rc.cen_from_box, w->pc_range, radar_tokens, w->radar_in_dims,
+                                B, Q, T, w->radar[first_layer].radius_min, w->radar[first_layer].radius_max,
+                                h.hitflag, h.perm, s));
+    rc.row_perm = h.perm;
+  }
   TC_TRY(launch_radar_chain(rc, s));
   if (hit_counts != nullptr)
     TC_HIP(hipMemcpyAsync(hit_counts + (size_t)first_layer * rows, h.hits, (size_t)num_layers * rows * 4,
@@ -663,6 +677,8 @@ int tc_head_forward(const tc_head_weights* w, const tc_head_weights* packed_view
   tc_head_options opt;
   memset(&opt, 0, sizeof(opt));
   if (options != nullptr) opt = *options;
+  TC_REQUIRE(opt.radar_row_order >= 0 && opt.radar_row_order <= 2, "options.radar_row_order=%d (0 automatic, 1 own order, 2 hits first)",
+             opt.radar_row_order);
   TC_REQUIRE(opt.chain_tile_rows == 0 || opt.chain_tile_rows == 4 || opt.chain_tile_rows == 8 ||
                  opt.chain_tile_rows == 16,
              "options.chain_tile_rows=%d (0 = automatic, 4, 8 or 16)", opt.chain_tile_rows);

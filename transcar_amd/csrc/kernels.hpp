@@ -127,8 +127,15 @@ struct RadarChainArgs {
   int tile_rows = 0;
   int last_cls_only = 0;                     // skip final_cls of all but the last layer (inference opt-in)
   int cen_from_box = 0;                      // w[0] is not fusion layer 1: gate centre from box_m (HEAD:615-617)
+  const int* row_perm = nullptr;             // optional [M]: tile position -> row (launch_radar_compact)
 };
 int launch_radar_chain(const RadarChainArgs& a, hipStream_t s);
+
+// ---- radar_compact.hip: row order for the radar chain (queries with a radar hit first) --------
+// flags [B*Q] scratch, perm [B*Q]: perm[b*Q + i] = a row of sample b
+int launch_radar_compact(const float* ref_last, const float* box, int code, int cen_from_box,
+                         const float* pc6_host, const float* tokens, int RI, int B, int Q, int T,
+                         float rmin, float rmax, int* flags, int* perm, hipStream_t s);
 
 // ---- self_attn.hip ---------------------------------------------------------
 // q,k: [B*Q, ld] token-major with head h at column h*32; vt: [B, C, ldt] (V transposed)

@@ -1,0 +1,121 @@
+// Row order for the fused radar chain (chain.hip, PROG_RADAR): queries with a radar return inside
+// their gate first.
+//
+// About three of four queries have no radar token inside their three circles (HEAD:549-567; G5 rig:
+// 214 / 219 / 69 of 900 have one), and for a row tile without a single hit the chain skips the q
+// projection, the gated attention and the out_proj (x + 0 * (...) = x, F_IFHIT in chain.hip).  A tile
+// of 16 consecutive queries is hit-free with probability 0.76^16; ordered by the gate of the first
+// fusion layer three of four tiles are.  The order is a HINT: every layer's tiles decide from their own
+// gates, rows are computed independently of their tile mates, outputs go back to the original row --
+// bit-identical results, whatever the order.
+//
+//   radar_hit_flags_kernel   wave per query: the first layer's gate (the chain's own predicate,
+//                            rowdev.hpp GateGeom) against the sample's tokens, cached in registers
+//   radar_partition_kernel   one workgroup per sample: stable partition of its Q rows, hits first;
+//                            perm[b*Q + i] = row (of the same sample: b = row / Q keeps its meaning)
+#include "kernels.hpp"
+#include "rowdev.hpp"
+
+namespace tc {
+
+struct CompactK {
+  const float* ref_last; const float* box; const float* tokens;
+  int code, cen_from_box, RI, B, Q, T;
+  float pc[6]; float rmin, rmax;
+  int* flags;
+};
+
+__global__ __launch_bounds__(256) void radar_hit_flags_kernel(CompactK p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int RPW = 4;                                   // rows per wave
+  const int M = p.B * p.Q;
+  const int row0 = (blockIdx.x * 4 + wave) * RPW;
+  if (row0 >= M) return;
+  const int b0 = row0 / p.Q;
+  constexpr int GW = 4;
+  const bool cached = p.T <= 64 * GW;
+  float ty0[GW], ty1[GW];
+  if (cached) {
+    const float* rxy = p.tokens + (size_t)b0 * p.T * p.RI;
+#pragma unroll
+    for (int w = 0; w < GW; ++w) {
+      const int t = min(64 * w + lane, p.T - 1);
+      ty0[w] = rxy[(size_t)t * p.RI]; ty1[w] = rxy[(size_t)t * p.RI + 1];
+    }
+  }
+  for (int i = 0; i < RPW; ++i) {
+    const int row = row0 + i;
+    if (row >= M) break;
+    const int b = row / p.Q;
+    const float* bx = p.box + (size_t)row * p.code;
+    float cx, cy;
+    if (p.cen_from_box) { cx = bx[0]; cy = bx[1]; }        // HEAD:615-617
+    else {                                                 // HEAD:543-547
+      cx = __fadd_rn(__fmul_rn(p.ref_last[(size_t)row * 3 + 0], p.pc[3] - p.pc[0]), p.pc[0]);
+      cy = __fadd_rn(__fmul_rn(p.ref_last[(size_t)row * 3 + 1], p.pc[4] - p.pc[1]), p.pc[1]);
+    }
+    bool any = false;
+    if (cached && b == b0) {
+      const GateGeom gg(cx, cy, bx[3], bx[6], bx[7], p.rmin, p.rmax);
+#pragma unroll
+      for (int w = 0; w < GW; ++w)
+        if (64 * w < p.T) any |= __ballot(64 * w + lane < p.T && gg.hit(ty0[w], ty1[w], sqnorm2(ty0[w], ty1[w]))) != 0;
+    } else {
+      any = radar_gate_count(cx, cy, bx[3], bx[6], bx[7], p.rmin, p.rmax, p.tokens + (size_t)b * p.T * p.RI, p.RI,
+                             p.T, 1, lane) > 0;
+    }
+    if (lane == 0) p.flags[row] = any ? 1 : 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void radar_partition_kernel(const int* __restrict__ flags, int Q, int* __restrict__ perm) {
+  __shared__ int wsum[2][4];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int* f = flags + (size_t)b * Q;
+  // total number of hit rows of the sample, then two running offsets (hits from 0, the others behind them)
+  int nh = 0;
+  for (int i = threadIdx.x; i < Q; i += 256) nh += f[i];
+  for (int o = 32; o > 0; o >>= 1) nh += __shfl_xor(nh, o, 64);
+  if (lane == 0) wsum[0][wave] = nh;
+  __syncthreads();
+  const int total_hits = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
+  __syncthreads();
+  int hit_base = 0, miss_base = total_hits;
+  for (int i0 = 0; i0 < Q; i0 += 256) {
+    const int i = i0 + threadIdx.x;
+    const int v = i < Q ? f[i] : 0;
+    const bool in = i < Q;
+    const unsigned long long mh = __ballot(in && v != 0), mm = __ballot(in && v == 0);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (lane == 0) { wsum[0][wave] = __popcll(mh); wsum[1][wave] = __popcll(mm); }
+    __syncthreads();
+    int ph = 0, pm = 0, th = 0, tm = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (w < wave) { ph += wsum[0][w]; pm += wsum[1][w]; }
+      th += wsum[0][w]; tm += wsum[1][w];
+    }
+    if (in) {
+      const int pos = v != 0 ? hit_base + ph + __popcll(mh & below) : miss_base + pm + __popcll(mm & below);
+      perm[(size_t)b * Q + pos] = b * Q + i;
+    }
+    hit_base += th; miss_base += tm;
+    __syncthreads();
+  }
+}
+
+int launch_radar_compact(const float* ref_last, const float* box, int code, int cen_from_box,
+                         const float* pc6_host, const float* tokens, int RI, int B, int Q, int T,
+                         float rmin, float rmax, int* flags, int* perm, hipStream_t s) {
+  TC_REQUIRE(B > 0 && Q > 0 && T > 0 && flags != nullptr && perm != nullptr, "radar_compact: bad arguments");
+  CompactK p;
+  p.ref_last = ref_last; p.box = box; p.tokens = tokens; p.code = code; p.cen_from_box = cen_from_box;
+  p.RI = RI; p.B = B; p.Q = Q; p.T = T; p.rmin = rmin; p.rmax = rmax; p.flags = flags;
+  for (int i = 0; i < 6; ++i) p.pc[i] = pc6_host[i];
+  const int M = B * Q;
+  hipLaunchKernelGGL(radar_hit_flags_kernel, dim3((M + 15) / 16), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(radar_partition_kernel, dim3(B), dim3(256), 0, s, flags, Q, perm);
+  return check_launch("radar_compact");
+}
+
+}  // namespace tc

@@ -222,34 +222,76 @@ __device__ __forceinline__ float sqnorm2(float a, float b) {
 // DROP (training forward): dropout on the attention probabilities (nn.MultiheadAttention
 // dropout = 0.1, HEAD:129): the softmax denominator counts every hit token, the weighted sum only
 // the kept ones, scaled by 1 / (1 - p); mask index ((row * 8 + head) * tokens_ref + token).
-template <bool DROP = false>
-__device__ __forceinline__ float4 radar_attn_row(float cx, float cy, float b3, float b6, float b7,
-                                                 float rmin, float rmax, float4 q4,
-                                                 const float* rxy, int ld_xy, const float* kv,
-                                                 int ldkv, int T, int pad_mult, int lane, int& count,
-                                                 DropK drop = DropK(), int row = 0) {
-  // gate geometry, HEAD:553-567
-  const float len = expf(b3);
-  const float rs = -b6, rc = -b7;
-  const float ox = __fmul_rn(__fmul_rn(len, 0.25f), rs), oy = __fmul_rn(__fmul_rn(len, 0.25f), rc);
-  const float fx = __fadd_rn(cx, ox), fy = __fadd_rn(cy, oy);
-  const float bxx = __fsub_rn(cx, ox), byy = __fsub_rn(cy, oy);
-  const float rad = fminf(fmaxf(len / 2.0f, rmin), rmax);
-  const float cn = sqnorm2(cx, cy), fn = sqnorm2(fx, fy), bn = sqnorm2(bxx, byy);
-  float m = -INFINITY, l = 0.0f;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  count = 0;
+// gate geometry of one query, HEAD:553-567: three circles (centre, front, back) of one radius
+struct GateGeom {
+  float cx, cy, fx, fy, bx, by, cn, fn, bn, rad;
+  __device__ __forceinline__ GateGeom(float cx_, float cy_, float b3, float b6, float b7, float rmin, float rmax) {
+    const float len = expf(b3);
+    const float rs = -b6, rc = -b7;
+    const float ox = __fmul_rn(__fmul_rn(len, 0.25f), rs), oy = __fmul_rn(__fmul_rn(len, 0.25f), rc);
+    cx = cx_; cy = cy_;
+    fx = __fadd_rn(cx, ox); fy = __fadd_rn(cy, oy);
+    bx = __fsub_rn(cx, ox); by = __fsub_rn(cy, oy);
+    rad = fminf(fmaxf(len / 2.0f, rmin), rmax);
+    cn = sqnorm2(cx, cy); fn = sqnorm2(fx, fy); bn = sqnorm2(bx, by);
+  }
+  __device__ __forceinline__ bool hit(float y0, float y1, float yn) const {
+    return (cdist_mm(cx, cy, cn, y0, y1, yn) < rad) || (cdist_mm(fx, fy, fn, y0, y1, yn) < rad) ||
+           (cdist_mm(bx, by, bn, y0, y1, yn) < rad);
+  }
+};
+
+// The gate alone: number of radar tokens inside the three circles (the last token counts pad_mult
+// times, as in radar_attn_row).  Same predicate, same arithmetic: the two always agree.
+__device__ __forceinline__ int radar_gate_count(float cx, float cy, float b3, float b6, float b7, float rmin,
+                                                float rmax, const float* rxy, int ld_xy, int T, int pad_mult,
+                                                int lane, unsigned long long* masks_out = nullptr) {
+  const GateGeom gg(cx, cy, b3, b6, b7, rmin, rmax);
+  int count = 0;
   for (int t0 = 0; t0 < T; t0 += 64) {
     const int t = t0 + lane;
     bool hit = false;
     if (t < T) {
       const float* y = rxy + (size_t)t * ld_xy;
       const float y0 = y[0], y1 = y[1];
-      const float yn = sqnorm2(y0, y1);
-      hit = (cdist_mm(cx, cy, cn, y0, y1, yn) < rad) || (cdist_mm(fx, fy, fn, y0, y1, yn) < rad) ||
-            (cdist_mm(bxx, byy, bn, y0, y1, yn) < rad);
+      hit = gg.hit(y0, y1, sqnorm2(y0, y1));
     }
-    unsigned long long mask = __ballot(hit);
+    const unsigned long long mask = __ballot(hit);
+    count += __popcll(mask);
+    if (T - 1 >= t0 && T - 1 < t0 + 64 && ((mask >> (T - 1 - t0)) & 1ull)) count += pad_mult - 1;
+    if (masks_out != nullptr && lane == 0) masks_out[t0 >> 6] = mask;
+  }
+  return count;
+}
+
+template <bool DROP = false>
+__device__ __forceinline__ float4 radar_attn_row(float cx, float cy, float b3, float b6, float b7,
+                                                 float rmin, float rmax, float4 q4,
+                                                 const float* rxy, int ld_xy, const float* kv,
+                                                 int ldkv, int T, int pad_mult, int lane, int& count,
+                                                 DropK drop = DropK(), int row = 0,
+                                                 const unsigned long long* hit_masks = nullptr) {
+  // hit_masks (chain.hip, K_RADAR_GATE): the gate of this row already evaluated, one 64-token word per
+  // chunk -- the same predicate, so the same tokens
+  const GateGeom gg(cx, cy, b3, b6, b7, rmin, rmax);
+  float m = -INFINITY, l = 0.0f;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  count = 0;
+  for (int t0 = 0; t0 < T; t0 += 64) {
+    unsigned long long mask;
+    if (hit_masks != nullptr) {
+      mask = hit_masks[t0 >> 6];
+    } else {
+      const int t = t0 + lane;
+      bool hit = false;
+      if (t < T) {
+        const float* y = rxy + (size_t)t * ld_xy;
+        const float y0 = y[0], y1 = y[1];
+        const float yn = sqnorm2(y0, y1);
+        hit = gg.hit(y0, y1, yn);
+      }
+      mask = __ballot(hit);
+    }
     while (mask) {
       const int j = __ffsll((long long)mask) - 1;
       mask &= mask - 1;

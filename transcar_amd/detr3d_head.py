@@ -48,7 +48,7 @@ DEFAULT_TILE_ROWS = _env_tile_rows()
 
 
 def head_options(tile_rows=None, unfused=None, last_level_cls_only=False,
-                 decoder_dropout_p=0.0, dropout_seed=0):
+                 decoder_dropout_p=0.0, dropout_seed=0, radar_compact=None):
     """tc_head_options for one forward.  unfused=None: the TRANSCAR_UNFUSED=1
     environment switch of the operator-by-operator cross-check path (a host-side
     knob: the library itself reads no environment)."""
@@ -58,6 +58,8 @@ def head_options(tile_rows=None, unfused=None, last_level_cls_only=False,
     o.unfused = int(os.environ.get('TRANSCAR_UNFUSED', '0') == '1') if unfused is None else int(bool(unfused))
     o.last_level_cls_only = int(bool(last_level_cls_only))
     o.decoder_dropout_p = float(decoder_dropout_p)
+    # radar_compact: None = automatic (beyond one frame per launch), False / True = never / always
+    o.radar_row_order = 0 if radar_compact is None else (2 if radar_compact else 1)
     o.dropout_seed = int(dropout_seed) & 0xFFFFFFFFFFFFFFFF
     return o
 
