@@ -239,6 +239,15 @@ struct GateGeom {
     return (cdist_mm(cx, cy, cn, y0, y1, yn) < rad) || (cdist_mm(fx, fy, fn, y0, y1, yn) < rad) ||
            (cdist_mm(bx, by, bn, y0, y1, yn) < rad);
   }
+  // the same on squared distances (no correctly-rounded square roots): may differ from hit() for a token
+  // within rounding of a circle -- only for the row-ORDER hint of radar_compact.hip, never for a result
+  __device__ __forceinline__ bool hit_approx(float y0, float y1, float yn) const {
+    const float r2 = rad * rad;
+    const float dc = fmaf(-2.0f * cx, y0, fmaf(-2.0f * cy, y1, cn + yn));
+    const float df = fmaf(-2.0f * fx, y0, fmaf(-2.0f * fy, y1, fn + yn));
+    const float db = fmaf(-2.0f * bx, y0, fmaf(-2.0f * by, y1, bn + yn));
+    return fminf(dc, fminf(df, db)) < r2;
+  }
 };
 
 // The gate alone: number of radar tokens inside the three circles (the last token counts pad_mult
