@@ -309,6 +309,15 @@ int tc_radar_fusion_fwd(const tc_head_weights* packed_view, const float* hs_last
                         const tc_head_options* options, void* workspace, size_t workspace_bytes,
                         tc_stream_t stream);
 
+/* Self-check of the gate predicate (HEAD:568-571: cdist < radius for any of three circles).  The
+ * kernels compare SQUARED distances against t* = the smallest float whose correctly-rounded square root
+ * reaches the radius -- sqrtf is monotone, so that is the reference's comparison, without a square root
+ * per (query, token, circle).  This entry evaluates both forms on n_radii radii of the clamp range
+ * [0.5, 2] (the clamp values themselves included) x (every float within 256 ulps of radius^2 + 4096 random
+ * ones) and adds the number of disagreements to *mismatches (device, 8 bytes, zeroed by the caller). */
+int tc_radar_gate_selfcheck(int n_radii, unsigned long long seed, unsigned long long* mismatches,
+                            tc_stream_t stream);
+
 /* NMSFreeCoder.decode_single + get_bboxes z-shift (CODER:39-90, UTIL:26-52,
  * HEAD:1018): sigmoid, top-`max_num` of Q*num_classes scores, gather,
  * denormalise, centre-range mask, z -= h/2.

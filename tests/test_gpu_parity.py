@@ -879,3 +879,14 @@ def test_radar_row_order_is_invisible_in_the_outputs(T, head, tile_rows):
     assert int((hits > 0).sum()) > 100 and int((hits == 0).sum()) > 1000        # both kinds of rows exist
     for a_, b_ in zip(outs['own'], outs['hits_first']):
         assert torch.equal(a_, b_)
+
+
+def test_gate_predicate_without_square_roots_is_the_reference_comparison(T):
+    """GateGeom::hit compares squared distances with the smallest float whose square root reaches the radius
+    (rowdev.hpp sqrt_threshold) instead of `cdist < radius` (HEAD:568-571).  On the device: 4096 radii of the
+    clamp range x (every float within 256 ulps of radius^2 + 4096 random ones) -- not one disagreement."""
+    from transcar_amd import _lib as L
+    bad = torch.zeros(1, dtype=torch.int64, device=dev())
+    L.check(L.lib().tc_radar_gate_selfcheck(4096, 12345, bad.data_ptr(), None), 'selfcheck')
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 0

@@ -565,6 +565,11 @@ int tc_radar_fusion_fwd(const tc_head_weights* packed_view, const float* hs_last
   return 0;
 }
 
+int tc_radar_gate_selfcheck(int n_radii, unsigned long long seed, unsigned long long* mismatches,
+                            tc_stream_t stream) {
+  return launch_gate_selfcheck(n_radii, seed, mismatches, as_stream(stream));
+}
+
 size_t tc_box_decode_workspace_bytes(int B, int Q, int num_classes) {
   return box_decode_ws_bytes(B, Q, num_classes);
 }

@@ -137,6 +137,8 @@ int launch_radar_compact(const float* ref_last, const float* box, int code, int 
                          const float* pc6_host, const float* tokens, int RI, int B, int Q, int T,
                          float rmin, float rmax, int* flags, int* perm, hipStream_t s);
 
+int launch_gate_selfcheck(int n_radii, unsigned long long seed, unsigned long long* mismatches, hipStream_t s);
+
 // ---- self_attn.hip ---------------------------------------------------------
 // q,k: [B*Q, ld] token-major with head h at column h*32; vt: [B, C, ldt] (V transposed)
 // drop (may be null / thr 0 = eval): dropout on the attention probabilities, index ((b*H+h)*Q+i)*Q+j

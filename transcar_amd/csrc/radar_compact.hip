@@ -109,6 +109,42 @@ __global__ __launch_bounds__(256) void radar_partition_kernel(const int* __restr
   }
 }
 
+// ---- self-check of GateGeom::hit's square-root-free comparison (tc_radar_gate_selfcheck) -------------
+__global__ __launch_bounds__(256) void gate_selfcheck_kernel(int n_radii, unsigned long long seed,
+                                                             unsigned long long* mismatches) {
+  const int r = blockIdx.x;
+  if (r >= n_radii) return;
+  // radius r: the three clamp values first, then pseudo-random ones in [0.5, 2]
+  unsigned long long h = (seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(r + 1));
+  h ^= h >> 30; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 27; h *= 0x94D049BB133111EBull; h ^= h >> 31;
+  float rad = 0.5f + 1.5f * (float)(h >> 40) * (1.0f / 16777216.0f);
+  if (r == 0) rad = 0.5f;
+  if (r == 1) rad = 1.0f;
+  if (r == 2) rad = 2.0f;
+  const float tstar = sqrt_threshold(rad);
+  const unsigned centre = __builtin_bit_cast(unsigned, rad * rad);
+  unsigned long long bad = 0;
+  for (int i = threadIdx.x; i < 512 + 4096; i += 256) {
+    float t;
+    if (i < 512) t = __builtin_bit_cast(float, centre - 256u + (unsigned)i);
+    else {
+      unsigned long long g = h + 0xD1B54A32D192ED03ull * (unsigned long long)i;
+      g ^= g >> 29; g *= 0xBF58476D1CE4E5B9ull; g ^= g >> 32;
+      t = -1.0f + 10.0f * (float)(g >> 40) * (1.0f / 16777216.0f);      // [-1, 9): both sides, and below the clamp
+    }
+    const bool ref = sqrtf(fmaxf(t, 1e-30f)) < rad;
+    const bool fast = fmaxf(t, 1e-30f) < tstar;
+    bad += ref != fast;
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
+
+int launch_gate_selfcheck(int n_radii, unsigned long long seed, unsigned long long* mismatches, hipStream_t s) {
+  TC_REQUIRE(n_radii > 0 && mismatches != nullptr, "radar_gate_selfcheck: bad arguments");
+  hipLaunchKernelGGL(gate_selfcheck_kernel, dim3(n_radii), dim3(256), 0, s, n_radii, seed, mismatches);
+  return check_launch("radar_gate_selfcheck");
+}
+
 int launch_radar_compact(const float* ref_last, const float* box, int code, int cen_from_box,
                          const float* pc6_host, const float* tokens, int RI, int B, int Q, int T,
                          float rmin, float rmax, int* flags, int* perm, hipStream_t s) {

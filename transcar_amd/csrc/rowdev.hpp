@@ -204,12 +204,29 @@ __device__ __forceinline__ float4 cam_sample_row(const CamK& p, int row, int b, 
 
 // ---- distance-gated radar attention of one query (HEAD:549-579) -------------
 // torch.cdist(p=2) via _euclidean_dist: [-2x, |x|^2, 1] . [y, 1, |y|^2]
-__device__ __forceinline__ float cdist_mm(float x0, float x1, float xn, float y0, float y1, float yn) {
+// the squared distance exactly as _euclidean_dist forms it (before clamp and square root)
+__device__ __forceinline__ float cdist_sq(float x0, float x1, float xn, float y0, float y1, float yn) {
   float t = __fmul_rn(__fmul_rn(-2.0f, x0), y0);
   t = fmaf(__fmul_rn(-2.0f, x1), y1, t);
   t = __fadd_rn(t, xn);
   t = __fadd_rn(t, yn);
-  return sqrtf(fmaxf(t, 1e-30f));
+  return t;
+}
+__device__ __forceinline__ float cdist_mm(float x0, float x1, float xn, float y0, float y1, float yn) {
+  return sqrtf(fmaxf(cdist_sq(x0, x1, xn, y0, y1, yn), 1e-30f));
+}
+// The smallest float t with sqrtf(t) >= rad: sqrtf is monotone, so  sqrtf(max(t, 1e-30)) < rad  <=>
+// max(t, 1e-30) < t*  -- the gate's comparison without a correctly-rounded square root per (query, token,
+// circle).  Found from rad * rad by stepping single floats (a few sqrtf per QUERY).
+__device__ __forceinline__ float sqrt_threshold(float rad) {
+  float c = rad * rad;
+  for (int i = 0; i < 8 && sqrtf(c) >= rad; ++i) c = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, c) - 1u);
+  for (int i = 0; i < 8; ++i) {
+    const float up = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, c) + 1u);
+    if (sqrtf(up) >= rad) return up;
+    c = up;
+  }
+  return c;        // not reached for rad in the clamp range [0.5, 2]
 }
 __device__ __forceinline__ float sqnorm2(float a, float b) {
   return __fadd_rn(__fmul_rn(a, a), __fmul_rn(b, b));
@@ -224,7 +241,7 @@ __device__ __forceinline__ float sqnorm2(float a, float b) {
 // the kept ones, scaled by 1 / (1 - p); mask index ((row * 8 + head) * tokens_ref + token).
 // gate geometry of one query, HEAD:553-567: three circles (centre, front, back) of one radius
 struct GateGeom {
-  float cx, cy, fx, fy, bx, by, cn, fn, bn, rad;
+  float cx, cy, fx, fy, bx, by, cn, fn, bn, rad, tstar;
   __device__ __forceinline__ GateGeom(float cx_, float cy_, float b3, float b6, float b7, float rmin, float rmax) {
     const float len = expf(b3);
     const float rs = -b6, rc = -b7;
@@ -234,8 +251,16 @@ struct GateGeom {
     bx = __fsub_rn(cx, ox); by = __fsub_rn(cy, oy);
     rad = fminf(fmaxf(len / 2.0f, rmin), rmax);
     cn = sqnorm2(cx, cy); fn = sqnorm2(fx, fy); bn = sqnorm2(bx, by);
+    tstar = sqrt_threshold(rad);
   }
+  // (cdist < rad) for any of the three circles, HEAD:568-571 -- on the squared distances against tstar
   __device__ __forceinline__ bool hit(float y0, float y1, float yn) const {
+    const float tc_ = fmaxf(cdist_sq(cx, cy, cn, y0, y1, yn), 1e-30f), tf = fmaxf(cdist_sq(fx, fy, fn, y0, y1, yn), 1e-30f),
+                tb = fmaxf(cdist_sq(bx, by, bn, y0, y1, yn), 1e-30f);
+    return fminf(tc_, fminf(tf, tb)) < tstar;
+  }
+  // the literal form (a square root per circle): the device check of the equivalence, tests only
+  __device__ __forceinline__ bool hit_sqrt(float y0, float y1, float yn) const {
     return (cdist_mm(cx, cy, cn, y0, y1, yn) < rad) || (cdist_mm(fx, fy, fn, y0, y1, yn) < rad) ||
            (cdist_mm(bx, by, bn, y0, y1, yn) < rad);
   }
