@@ -712,6 +712,13 @@ def train_bench(args, head, inp, dev, rank, world):
         torch.distributed.destroy_process_group()
 
 
+def auto_frames_per_launch(steps):
+    """--pair 0: 8 frames per launch when that divides the timed window (450 workgroups of 16 rows: two per
+    CU, the whole launch resident at once), else the window's largest divisor up to 10 -- a window of K
+    steps then ends on a launch boundary (no partly filled launch inside the timed region)."""
+    return 8 if steps % 8 == 0 else max(p for p in range(1, 11) if steps % p == 0)
+
+
 def backend_name(args):
     b = args.backend or ('gloo' if args.dry_run else 'nccl')
     return 'RCCL' if b == 'nccl' else b
@@ -798,8 +805,7 @@ def main(argv=None):
         from transcar_amd.pipeline import FramePipeline
         # automatic: 8 frames when that divides the window (450 workgroups of 16 rows: two per CU, the whole
         # launch resident at once), else the largest divisor of the step count up to 10
-        pair = args.pair if args.pair > 0 else (8 if args.steps % 8 == 0 else
-                                                max(p for p in range(1, 11) if args.steps % p == 0))
+        pair = args.pair if args.pair > 0 else auto_frames_per_launch(args.steps)
         args.pair = pair                      # the side runs use the same grouping
         fpl = args.batch * pair
         first = inp if pair == 1 else make_inputs(head, dev, args.shapes, fpl, seed=1 + rank, host_feats=False)

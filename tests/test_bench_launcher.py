@@ -66,3 +66,18 @@ def test_a_dead_rank_fails_the_launch():
     # no GPU in this container and no --dry-run: every rank asserts
     assert r.returncode != 0
     assert 'needs MI355X' in r.stderr
+
+
+def test_automatic_frames_per_launch_divides_the_window():
+    """--pair 0: a timed window of K steps ends on a launch boundary (8 when it divides K, else the
+    largest divisor up to 10)."""
+    import bench
+    assert bench.auto_frames_per_launch(200) == 8
+    assert bench.auto_frames_per_launch(20) == 10          # the driver's command
+    assert bench.auto_frames_per_launch(50) == 10
+    assert bench.auto_frames_per_launch(48) == 8
+    assert bench.auto_frames_per_launch(7) == 7
+    assert bench.auto_frames_per_launch(13) == 1
+    for k in range(1, 300):
+        p = bench.auto_frames_per_launch(k)
+        assert 1 <= p <= 10 and k % p == 0
