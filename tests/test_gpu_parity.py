@@ -890,3 +890,27 @@ def test_gate_predicate_without_square_roots_is_the_reference_comparison(T):
     L.check(L.lib().tc_radar_gate_selfcheck(4096, 12345, bad.data_ptr(), None), 'selfcheck')
     torch.cuda.synchronize()
     assert int(bad.item()) == 0
+
+
+def test_pipelines_can_share_streams(T, head):
+    """FramePipeline(streams=other.streams): a second pipeline on the (idle) first one's HIP streams -- the
+    lanes of a third pipeline with streams of its own can end up on shared hardware queues -- gives the
+    same results; too few streams are refused."""
+    import bench
+    bench._imports()
+    from transcar_amd.pipeline import FramePipeline
+    lanes = [bench.make_inputs(head, dev(), 'tiny', 1, seed=41 + i) for i in range(2)]
+    a = FramePipeline(head, lanes)
+    for _ in range(2):
+        a.launch()
+    a.synchronize()
+    want = [a.outputs[i][0]['all_bbox_preds'].clone() for i in range(2)]
+    b = FramePipeline(head, lanes, streams=a.streams)
+    assert all(x is y for x, y in zip(a.streams, b.streams))
+    for _ in range(2):
+        b.launch()
+    b.synchronize()
+    for i in range(2):
+        assert torch.equal(b.outputs[i][0]['all_bbox_preds'], want[i])
+    with pytest.raises(ValueError):
+        FramePipeline(head, lanes, streams=a.streams[:1])
