@@ -914,3 +914,25 @@ def test_pipelines_can_share_streams(T, head):
         assert torch.equal(b.outputs[i][0]['all_bbox_preds'], want[i])
     with pytest.raises(ValueError):
         FramePipeline(head, lanes, streams=a.streams[:1])
+
+
+@pytest.mark.parametrize('tile_rows', [8, 16])
+def test_a_frame_in_a_batch_equals_the_frame_alone(T, head, tile_rows):
+    """Size independence of the whole path at a fixed tile height: every kernel is row-local except the
+    per-(sample, head) attention, so frame b of a three-frame launch (tiles straddle the sample boundaries,
+    the radar rows are re-ordered per sample) is BIT-IDENTICAL to the same frame launched alone."""
+    import bench
+    bench._imports()
+    from transcar_amd.detr3d_head import head_options
+    B = 3
+    inp = bench.make_inputs(head, dev(), 'tiny', B, seed=61)
+    opt = head_options(tile_rows=tile_rows, radar_compact=True)
+    full = head.forward_nhwc(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'], inp['pad_mult'], aux=True, options=opt)
+    torch.cuda.synchronize()
+    full = {k: full[k].clone() for k in ('all_cls_scores', 'all_bbox_preds')}
+    for b in range(B):
+        one = head.forward_nhwc([f[6 * b:6 * b + 6] for f in inp['nhwc']], inp['l2i'][b:b + 1], inp['hw'],
+                                inp['tokens'][b:b + 1], inp['pad_mult'], aux=True, options=opt)
+        torch.cuda.synchronize()
+        assert torch.equal(one['all_cls_scores'][:, 0], full['all_cls_scores'][:, b])
+        assert torch.equal(one['all_bbox_preds'][:, 0], full['all_bbox_preds'][:, b])
