@@ -936,3 +936,34 @@ def test_a_frame_in_a_batch_equals_the_frame_alone(T, head, tile_rows):
         torch.cuda.synchronize()
         assert torch.equal(one['all_cls_scores'][:, 0], full['all_cls_scores'][:, b])
         assert torch.equal(one['all_bbox_preds'][:, 0], full['all_bbox_preds'][:, b])
+
+
+def test_full_size_launch_of_eight_frames_is_frame_by_frame_the_single_frame_path(T):
+    """The bench's own configuration (ResNet-101 FPN shapes, iid-noise maps, 8 frames per launch, 16-row tiles
+    on the 16x16x4 MFMA, two workgroups per CU, radar rows compacted): frames 0, 3 and 7 of the launch are
+    bit-identical to the same frames launched alone at the same tile height, and the decoded boxes with them --
+    a size-independent property at BASELINE.json's full size, where the oracle takes minutes per frame."""
+    import bench
+    bench._imports()
+    from transcar_amd import ops
+    from transcar_amd.detr3d_head import head_options
+    head, _ = bench.build_head(dev())
+    B = 8
+    inp = bench.make_inputs(head, dev(), 'res101', B, seed=71, host_feats=False)
+    opt = head_options(tile_rows=16)
+    full = head.forward_nhwc(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'], inp['pad_mult'], options=opt)
+    torch.cuda.synchronize()
+    cls, box = full['all_cls_scores'].clone(), full['all_bbox_preds'].clone()
+    assert torch.isfinite(cls).all() and torch.isfinite(box).all()
+    dec_full = ops.box_decode_topk(cls[-1], box[-1], head.bbox_coder.post_center_range, head.bbox_coder.max_num)
+    dec_full = [d.clone() for d in dec_full]
+    for b in (0, 3, 7):
+        one = head.forward_nhwc([f[6 * b:6 * b + 6] for f in inp['nhwc']], inp['l2i'][b:b + 1], inp['hw'],
+                                inp['tokens'][b:b + 1], inp['pad_mult'], options=opt)
+        torch.cuda.synchronize()
+        assert torch.equal(one['all_cls_scores'][:, 0], cls[:, b])
+        assert torch.equal(one['all_bbox_preds'][:, 0], box[:, b])
+        dec = ops.box_decode_topk(one['all_cls_scores'][-1], one['all_bbox_preds'][-1],
+                                  head.bbox_coder.post_center_range, head.bbox_coder.max_num)
+        for a_, b_ in zip(dec, dec_full):
+            assert torch.equal(a_[0], b_[b])
