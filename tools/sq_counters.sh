@@ -15,14 +15,17 @@ done
 find "$R/gpurun_out/sqpmc" -name "*.db" -delete
 find "$R/gpurun_out/sqpmc" -name "*kernel_trace.csv" -delete
 python3 - <<'PY'
-import csv, glob, collections
+import csv, glob, collections, re, os
+root = os.path.join(os.environ.get('GRAFT_REPO_ROOT', '.'), 'gpurun_out', 'sqpmc')
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob('/root/repo/gpurun_out/sqpmc/*/*/*counter_collection.csv') + glob.glob('/root/repo/gpurun_out/sqpmc/*/*counter_collection.csv'):
+for f in glob.glob(root + '/*/*/*counter_collection.csv') + glob.glob(root + '/*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
-        k = 'chain_dual' if 'chain_dual' in k else 'chain<%s>' % k.split('chain_kernelILi')[1][:8] if 'chain_kernel' in k else 'self_attn' if 'self_attn' in k else 'box_decode' if 'box_decode' in k else None
-        if k:
-            acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
+        m = re.search(r'chain_kernel<(\d+), *(\d+)', k)
+        k2 = 'chain_dual' if 'chain_dual' in k else ('chain<%s,%s>' % m.groups() if m else ('self_attn' if 'self_attn' in k else
+              ('box_decode' if 'box_decode' in k else ('radar_compact' if 'radar_hit' in k or 'radar_part' in k else None))))
+        if k2:
+            acc[k2][r['Counter_Name']].append(float(r['Counter_Value']))
 for k in sorted(acc):
     print(k)
     for c in sorted(acc[k]):
