@@ -17,9 +17,9 @@ import bench                                              # noqa: E402
 from transcar_amd import _lib as L                         # noqa: E402
 
 DEC = ['load attn_o', 'load x', 'out_proj', 'norm0 (+x+pos)', 'attn_w(24)', 'posenc l0', 'SAMPLE', 'pe.3',
-       'output_proj', 'norm1', 'ffn0', 'ffn1', 'norm2 (+x+pos)', 'reg.0', 'next QK', 'next V', 'reg.2', 'reg.4', 'refupd']
+       'output_proj', 'norm1', 'ffn0', 'ffn1', 'norm2 (+x+pos)', 'reg.0', 'next QK', 'next V', 'reg.2', 'reg.4 (dot)', 'refupd']
 RAD = ['radar gate', 'q proj', 'RADAR ATTN', 'out_proj', 'norm2', 'linear1', 'linear2', 'norm3', 'cls.0', 'reg.0', 'cls LN1',
-       'reg.2', 'cls.3', 'cls LN4', 'reg.4 (w0)', 'cls.6 (w1)', 'boxadd']
+       'reg.2', 'cls.3', 'cls LN4', 'reg.4 (dot)', 'cls.6 (dot)', 'boxadd']
 
 
 def main():

@@ -137,6 +137,7 @@ static_assert(LD5 * 1 <= 2 * LD2, "the 512-wide tile must fit two units");
 enum Buf : short { B_NONE = -1, B_A = 0 /* units 1+2, row stride LD5 */, B_X /* unit 0 */, B_U1, B_U2, B_U3, B_L };
 enum Kind : short {
   K_END = 0, K_LOAD, K_LINEAR, K_LN, K_POSENC, K_SAMPLE, K_REFUPD, K_TOKENS, K_RADAR_ATTN, K_BOXADD, K_RADAR_GATE,
+  K_NARROW,   // y[R, N <= 12] = x[R, 256] W^T + b: one 16x16 MFMA sub-tile, k split over the waves, W in the nn.Linear layout
   K_NOP   // a step switched off at run time (no next layer): only its barrier remains
 };
 enum NSpecial : short { N_LOGITS = -1, N_CODE = -2, N_CLS = -3 };
@@ -183,7 +184,7 @@ constexpr StepDesc PROG_DECODER_T[] = {
     {K_LINEAR, 16, -1, 256, 512, B_U1, B_NONE, B_NONE, B_NONE, 0, F_SCALEQ | F_SKIP_NONEXT, G_QK, G_NONE, 0},
     {K_LINEAR, 16, -1, 256, 256, B_X, B_NONE, B_NONE, B_NONE, 0, F_WOFF | F_SKIP_NONEXT, G_NONE, G_VT, 1},
     {K_LINEAR, 14, -1, 256, 256, B_U2, B_NONE, B_U3, B_NONE, 1, 0, G_NONE, G_NONE, 1},    // reg.2
-    {K_LINEAR, 15, -1, 256, N_CODE, B_U3, B_NONE, B_L, B_NONE, 0, 0, G_NONE, G_NONE, 1},  // reg.4
+    {K_NARROW, 15, -1, 256, N_CODE, B_U3, B_U1, B_L, B_NONE, 0, 0, G_NONE, G_NONE, 1},    // reg.4 (partial sums: U1)
     {K_REFUPD, 0, 0, 0, 0, B_L, B_NONE, B_NONE, B_NONE, 0, 0, G_NONE, G_NONE, 0},
     {K_END, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
 // prologue pairs: 0 reference_points 16 layer-0 in_proj
@@ -249,9 +250,9 @@ constexpr StepDesc PROG_RADAR_LAYER_T[] = {
     {K_LINEAR, 12, -1, 256, 256, B_U2, B_NONE, B_U3, B_NONE, 1, 0, G_NONE, G_NONE, 1},       // final_reg.2
     {K_LINEAR, 8, -1, 256, 256, B_U1, B_NONE, B_U2, B_NONE, 0, 0, G_NONE, G_NONE, 1},        // final_cls.3
     {K_LN, 9, -1, 0, 0, B_U2, B_NONE, B_U2, B_NONE, 0, F_LN_RELU, G_NONE, G_NONE, 1},        // in place
-    // the two 10-column steps side by side: final_reg.4 on wave 0, final_cls.6 on wave 1
-    {K_LINEAR, 13, -1, 256, N_CODE, B_U3, B_NONE, B_L, B_NONE, 0, 0, G_NONE, G_NONE, 0},     // final_reg.4
-    {K_LINEAR, 10, -1, 256, N_CLS, B_U2, B_NONE, B_NONE, B_NONE, 0, F_WAVE1, G_CLS, G_NONE, 1},  // final_cls.6
+    // the two 10-column heads: one MFMA sub-tile each, k split over the four waves (K_NARROW)
+    {K_NARROW, 13, -1, 256, N_CODE, B_U3, B_U1, B_L, B_NONE, 0, 0, G_NONE, G_NONE, 1},       // final_reg.4 (partial sums: U1)
+    {K_NARROW, 10, -1, 256, N_CLS, B_U2, B_U1, B_NONE, B_NONE, 0, 0, G_CLS, G_NONE, 1},      // final_cls.6
     {K_BOXADD, 0, 0, 0, 0, B_L, B_NONE, B_NONE, B_NONE, 0, 0, G_NONE, G_NONE, 1},
     {K_END, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
 
@@ -1256,6 +1257,68 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
         }
       } break;
       } break;
+      case K_NARROW: { if constexpr (PROG == PROG_DECODER || PROG == PROG_RADAR) {
+        // The 10-column heads (reg.4, final_reg.4, final_cls.6): as a 64-column tile of the item loop they
+        // kept ONE wave busy for four items (13 000 cycles at 16 rows) while three waited at the barrier.
+        // Here: ONE 16-column MFMA sub-tile, the 16 k groups of 16 split over the four waves (16
+        // v_mfma_f32_16x16x4 each), partial sums through the LDS buffer named by `src2`, wave 0 adds them in
+        // a fixed order.  W is read in the nn.Linear layout [N][256] (not packed): lane 16g + c's float4 at
+        // W[c][16 kg + 4g ..] IS the B operand of the k group's four MFMAs.  Same code at every tile height
+        // (rows >= R repeat row R - 1, never stored).
+        const int N = r.N;                                // <= 12 (launchers check code / num_classes)
+        const int c = lane & 15, g = lane >> 4;
+        const float* Wn = uptr(r.p0) + (size_t)min(c, N - 1) * 256 + 4 * g;
+        const float* src = buf_ptr(S, r.src) + min(c, R - 1) * buf_ld(r.src) + 4 * g;
+        float4 av[4], bw[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          bw[q] = ld4(Wn + 16 * (4 * wave + q));
+          av[q] = *reinterpret_cast<const float4*>(src + 16 * (4 * wave + q));
+        }
+        const float bias = r.p1 != nullptr ? ldg1(uptr(r.p1) + min(c, N - 1)) : 0.0f;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc = MFMA16(av[q].x, bw[q].x, acc); acc = MFMA16(av[q].y, bw[q].y, acc);
+          acc = MFMA16(av[q].z, bw[q].z, acc); acc = MFMA16(av[q].w, bw[q].w, acc);
+        }
+        float* part = buf_ptr(S, r.src2);                 // [4 waves][16 rows][16 columns]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part[(wave * 16 + 4 * g + i) * 16 + c] = acc[i];
+        __syncthreads();
+        if (wave == 0 && c < N) {
+          float y[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int row = 4 * g + i;
+            float v = part[row * 16 + c];
+#pragma unroll
+            for (int w = 1; w < CH_NW; ++w) v += part[(w * 16 + row) * 16 + c];
+            y[i] = v + bias;
+          }
+          // (the LDS and the global stores in ONE predicated loop body trip a hipcc back-end error:
+          // "Illegal instruction detected: Operand has incorrect register class")
+          if (r.dst != B_NONE) {
+            float* dd = buf_ptr(S, r.dst) + c;
+            const int dld = buf_ld(r.dst);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (4 * g + i < R) dd[(4 * g + i) * dld] = y[i];
+          }
+          if (r.gd != nullptr) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int row = 4 * g + i;
+              if (row < R && m0 + row < M) {
+                int grow = m0 + row;
+                if constexpr (PROG == PROG_RADAR) grow = S.rowg[row];
+                stg1(r.gd + (size_t)grow * r.gld + c, y[i]);
+              }
+            }
+          }
+        }
+      } break;
+      } break;
       case K_RADAR_GATE: { if constexpr (PROG == PROG_RADAR) {   // the gate of HEAD:549-567 alone: hit counts + masks
         // the tokens' xy once per wave when they fit four words (T <= 256, the packed default; a tile's
         // rows are one sample's, two at a sample boundary); masks are kept up to 64 * HM_WORDS tokens
@@ -1397,7 +1460,7 @@ void resolve_program(ChainK& k, StepAll* out) {
     // only and levels 1-2 hand only their BOX to the next gate (HEAD:615-617, 1003-1023), so the
     // class MLPs (pairs 6..10: final_cls.0 / n1 / .3 / n4 / .6) of the earlier layers are dropped
     if (PROG == PROG_RADAR && k.last_cls_only && rep + 1 < nrep && d.wp >= 6 && d.wp <= 10 &&
-        (d.kind == K_LINEAR || d.kind == K_LN))
+        (d.kind == K_LINEAR || d.kind == K_LN || d.kind == K_NARROW))
       r.kind = K_NOP;
     if (d.gsel != G_NONE) { r.gd = k.g[d.gsel]; r.gld = k.g_ld[d.gsel]; r.gmod = k.g_mod[d.gsel]; }
     if (d.gtsel != G_NONE) r.gt = k.g[d.gtsel];
@@ -1409,6 +1472,12 @@ void resolve_program(ChainK& k, StepAll* out) {
       r.p0 = pr.w + (size_t)woff * ((r.K + 63) & ~63);   // packed: a 64-row tile = 64 * kpad floats
       if (R == 16) r.p0 += k.w16_delta;                   // the 16x16x4 copy (pack.hip); launch_r checks delta != 0
       r.p1 = pr.b ? pr.b + woff : nullptr;
+      if (d.gsel == G_CLS) r.gd += (size_t)rep * k.M * k.ncls;
+    } else if (d.kind == K_NARROW) {
+      // NOT packed (tc_head_pack_weights leaves these three heads in the nn.Linear layout): W [N][256]
+      const tc_linear pr = k.pairs[pair0 + d.wp];
+      r.N = d.N == N_CODE ? k.code : d.N == N_CLS ? k.ncls : d.N;
+      r.p0 = pr.w; r.p1 = pr.b;
       if (d.gsel == G_CLS) r.gd += (size_t)rep * k.M * k.ncls;
     } else if (d.kind == K_LN || d.kind == K_POSENC) {
       const tc_linear n = k.pairs[pair0 + d.wp];

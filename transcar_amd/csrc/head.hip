@@ -276,14 +276,17 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
 }
 
 // ---- packed weights for the fused chains (pack.hip) --------------------------
-struct PackItem { const float* src; int N, K; const float** slot; };
+struct PackItem { const float* src; int N, K; const float** slot; bool narrow; };
 
 static int collect_pack_items(const tc_head_weights* w, tc_head_weights* v, PackItem* it) {
   const int C = w->embed_dims, F = w->ffn_dims, NL = w->num_cams * w->num_levels;
   const int code = w->code_size, ncls = w->num_classes;
   int n = 0;
-  auto add = [&](const tc_linear& src, tc_linear& dst, int N, int K) {
-    it[n].src = src.w; it[n].N = N; it[n].K = K; it[n].slot = &dst.w; ++n;
+  // narrow: the three 10-column heads the chains evaluate as wave-per-row dot products (K_NARROW): they
+  // stay in the nn.Linear layout (the view keeps the caller's pointer: nothing to re-pack after an
+  // optimizer step); listed so that the item order / counts stay what tc_head_repack_trainable assumes
+  auto add = [&](const tc_linear& src, tc_linear& dst, int N, int K, bool narrow = false) {
+    it[n].src = src.w; it[n].N = N; it[n].K = K; it[n].slot = &dst.w; it[n].narrow = narrow; ++n;
   };
   add(w->reference_points, v->reference_points, 3, C);
   for (int l = 0; l < w->num_layers; ++l) {
@@ -297,7 +300,7 @@ static int collect_pack_items(const tc_head_weights* w, tc_head_weights* v, Pack
     add(a.ffn1, b.ffn1, C, F);
     add(a.reg.l0, b.reg.l0, C, C);
     add(a.reg.l2, b.reg.l2, C, C);
-    add(a.reg.l4, b.reg.l4, code, C);
+    add(a.reg.l4, b.reg.l4, code, C, true);
   }
   if (w->num_radar_layers > 0) {
     add(w->radar_position_encoder.l3, v->radar_position_encoder.l3, C, C);
@@ -312,10 +315,10 @@ static int collect_pack_items(const tc_head_weights* w, tc_head_weights* v, Pack
       add(a.linear2, b.linear2, C, F);
       add(a.final_cls.l0, b.final_cls.l0, C, C);
       add(a.final_cls.l3, b.final_cls.l3, C, C);
-      add(a.final_cls.l6, b.final_cls.l6, ncls, C);
+      add(a.final_cls.l6, b.final_cls.l6, ncls, C, true);
       add(a.final_reg.l0, b.final_reg.l0, C, C);
       add(a.final_reg.l2, b.final_reg.l2, C, C);
-      add(a.final_reg.l4, b.final_reg.l4, code, C);
+      add(a.final_reg.l4, b.final_reg.l4, code, C, true);
     }
   }
   return n;
@@ -589,7 +592,8 @@ size_t tc_head_packed_bytes(const tc_head_weights* w) {
   PackItem items[MAX_PACK_ITEMS];
   const int n = collect_pack_items(w, &view, items);
   size_t total = 0;
-  for (int i = 0; i < n; ++i) total += 2 * arena_slice(packed_floats(items[i].N, items[i].K), 4);   // + the 16x16x4 copies
+  for (int i = 0; i < n; ++i)
+    if (!items[i].narrow) total += 2 * arena_slice(packed_floats(items[i].N, items[i].K), 4);   // + the 16x16x4 copies
   // layer-0 constants + the scratch they are computed from (see tc_head_pack_weights)
   const size_t Q = w->num_query, C = w->embed_dims, qpad = ((Q + 15) / 16) * 16;
   total += arena_slice(Q * 3, 4) + arena_slice(Q * C, 4) + arena_slice(Q * 2 * C, 4) + arena_slice(C * qpad, 4);
@@ -609,15 +613,18 @@ int tc_head_pack_weights(const tc_head_weights* w, void* packed, size_t packed_b
   // sizes, in the 16x16x4 layout -- one distance (packed16_delta floats) from any address of a
   // weight (or of a row block of it) to its counterpart
   size_t region_a = 0;
-  for (int i = 0; i < n; ++i) region_a += arena_slice(packed_floats(items[i].N, items[i].K), 4);
+  for (int i = 0; i < n; ++i)
+    if (!items[i].narrow) region_a += arena_slice(packed_floats(items[i].N, items[i].K), 4);
   const size_t delta = region_a / sizeof(float);
   for (int i = 0; i < n; ++i) {
     TC_REQUIRE(items[i].src != nullptr, "pack_weights: weight %d is null", i);
+    if (items[i].narrow) continue;                     // the view keeps the nn.Linear pointer
     float* dst = a.take<float>(packed_floats(items[i].N, items[i].K));
     TC_TRY(launch_pack_linear(items[i].src, items[i].N, items[i].K, dst, dst + delta, as_stream(stream)));
     *items[i].slot = dst;
   }
-  for (int i = 0; i < n; ++i) a.take<float>(packed_floats(items[i].N, items[i].K));     // region B
+  for (int i = 0; i < n; ++i)
+    if (!items[i].narrow) a.take<float>(packed_floats(items[i].N, items[i].K));     // region B
   packed_view->packed16_delta = delta;
   for (int l = 0; l < TC_MAX_LAYERS; ++l) packed_view->layers[l].packed16_delta = delta;
   for (int l = 0; l < TC_MAX_RADAR_LAYERS; ++l) packed_view->radar[l].packed16_delta = delta;
@@ -659,6 +666,7 @@ int tc_head_repack_trainable(const tc_head_weights* w, tc_head_weights* packed_v
   const int first = 1 + 10 * w->num_layers;
   for (int i = first; i < n; ++i) {
     TC_REQUIRE(items[i].src != nullptr, "repack_trainable: weight %d is null", i);
+    if (items[i].narrow) continue;                     // read in place by the chains
     // scratch is a copy of the packed view: its slot still holds the packed destination
     float* dst = const_cast<float*>(*items[i].slot);
     TC_TRY(launch_pack_linear(items[i].src, items[i].N, items[i].K, dst, dst + packed_view->packed16_delta,
