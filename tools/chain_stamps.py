@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-step cycle counts of the fused row chains (debug build with s_memtime
 stamps):   make -C transcar_amd/csrc STAMPS=1
-           TRANSCAR_HIP_LIB=transcar_amd/lib/libtranscar_hip_stamps.so python tools/chain_stamps.py [decoder|radar]
+           TRANSCAR_ALLOW_STAMPS=1 TRANSCAR_HIP_LIB=build/hip_stamps/libtranscar_hip_stamps.so python tools/chain_stamps.py [decoder|radar]
 Prints, for workgroup 100 and each of its 4 waves, the cycles (100 MHz s_memtime
 ticks x 24 = 2.4 GHz core cycles) each step took and the wait at its barrier."""
 import ctypes as C

@@ -9,7 +9,11 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-#: TRANSCAR_HIP_LIB selects another build of the same ABI (the STAMPS debug build)
+#: TRANSCAR_HIP_LIB selects another build of the same ABI.  The STAMPS debug build
+#: (`make STAMPS=1`: s_memtime stamps and the TRANSCAR_CHAIN_DBG timing switches, which
+#: produce WRONG results) is refused unless TRANSCAR_ALLOW_STAMPS=1 is set as well
+#: (tools/chain_stamps.py); it is built under build/hip_stamps/, not into transcar_amd/lib/,
+#: and is never the product.
 LIB_PATH = os.environ.get('TRANSCAR_HIP_LIB') or os.path.join(_HERE, 'lib', 'libtranscar_hip.so')
 
 TC_MAX_LEVELS = 4
@@ -203,6 +207,10 @@ def lib():
                 'CPU fallback; run __graft_entry__.build() or '
                 '`make -C transcar_amd/csrc`.' % LIB_PATH)
         dll = C.CDLL(LIB_PATH)
+        if hasattr(dll, 'tc_debug_chain_stamps') and os.environ.get('TRANSCAR_ALLOW_STAMPS') != '1':
+            raise TransCARHipError(
+                '%s is the STAMPS debug build (timing switches with wrong results); set '
+                'TRANSCAR_ALLOW_STAMPS=1 to use it for tools/chain_stamps.py' % LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(dll, name)        # AttributeError if a symbol is gone
             fn.restype = res
