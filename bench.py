@@ -422,31 +422,6 @@ def handoff_side_run(head, dev, args, streams=None):
                           'frac': nbytes / tr_ms / 1e6 / HBM_PEAK_GBS}}
 
 
-def staged_side_run(head, lanes_inputs, args, streams=None):
-    """Input delivery with the H2D copies inside the lanes' graphs (FramePipeline(host_staging=True)):
-    per frame the producer writes tokens + lidar2img into the lane's pinned staging tensors on the
-    CPU (after a host-side wait for that lane's previous replay) and replays -- no copy call and no
-    stream hand-shake per frame."""
-    from transcar_amd.pipeline import FramePipeline
-    pipe = FramePipeline(head, lanes_inputs, tile_rows=args.tile_rows or None, host_staging=True, streams=streams)
-    src = [dict(tokens=h['tokens'].clone(), l2i=h['l2i'].clone()) for h in pipe.host]
-    state = {'i': 0}
-
-    def step():
-        i = state['i']
-        state['i'] = (i + 1) % pipe.lanes
-        pipe.host_wait(i)
-        h = pipe.host_inputs(i)
-        h['tokens'].copy_(src[i]['tokens'])            # CPU memcpy into pinned memory
-        h['l2i'].copy_(src[i]['l2i'])
-        pipe.launch(i)
-    for _ in range(3 * pipe.lanes):
-        step()
-    fpl = pipe.frames_per_launch
-    t = _replay_rate(step, torch.cuda.synchronize, max(20, args.steps)) / fpl
-    return {'value': 1.0 / t, 'unit': 'frames/s', 'ms_per_frame': t * 1e3}
-
-
 def producer_side_run(pipe, args):
     """Frames whose inputs ARRIVE: before every replay the producer (current stream) refills the
     lane's static inputs -- radar tokens and lidar2img from pinned host memory (H2D; they come from
@@ -882,7 +857,6 @@ def main(argv=None):
         if world == 1:
             if pipe is not None and not args.main_only:
                 line['with_input_delivery'] = producer_side_run(pipe, args)
-                line['with_input_delivery']['tokens_l2i_h2d_in_graph'] = staged_side_run(head, pipe.inputs, args, streams=pipe.streams)
             if not args.no_handoff and not args.no_graph:
                 line['with_handoff'] = handoff_side_run(head, dev, args, streams=pipe.streams)
                 line['with_handoff_ms'] = line['with_handoff']['ms_per_frame']

@@ -178,8 +178,10 @@ int tc_nchw_to_nhwc_levels(const float* const* src, float* const* dst, int num_l
  *   point_range HOST [6] float64 (HEAD:304: -51.2 -51.2 -5 51.2 51.2 3), strict inequalities in
  *              float64 as in the reference (a point at exactly 51.2 is dropped)
  *   tokens     device [T,36]: kept points in order, then rows of 500.0 (HEAD:523-530)
- *   count      device [1] (may be NULL): number of kept points; > T-1 means the frame does not fit
- *              T tokens (rows beyond T are dropped; the reference keeps 1500)
+ *   count      device [1] (may be NULL): number of points the range filter kept.  With T < 1500
+ *              row T-1 is ALWAYS a 500.0 pad row (it carries pad_mult): at most T-1 points are
+ *              written, count > T-1 means the frame did not fit (use T = 1500 for such frames;
+ *              the reference keeps the first 1500)
  * With tokens [T,36] the head is called with pad_mult = 1500 - T + 1. */
 int tc_radar_build_tokens(const double* raw, const double* times, const int* chan_start, int num_chan,
                           const double* radar_rot, const double* lidar_rot, const double* point_range,

@@ -340,7 +340,7 @@ def test_radar_ingest_on_device(T, case):
     n = int(count.item())
     assert n == want_rows.shape[0]
     got = tokens[0].cpu().numpy()
-    k = min(n, Tn)
+    k = min(n, Tn - 1)                                      # T < 1500: row T - 1 always stays a pad row (pad_mult)
     want = np.full((Tn, 36), 500.0, np.float32)
     want[:k] = want_rows[:k].astype(np.float32)
     exact = [c for c in range(36) if c not in (9, 10, 11, 12, 13, 14)]
@@ -354,6 +354,9 @@ def test_radar_ingest_on_device(T, case):
         assert np.all(np.abs(got[:n, vel] - gold_rows[:, vel]) <= np.spacing(np.abs(gold_rows[:, vel]).astype(np.float32)))
     if case == 'overflow':
         assert n > Tn - 1                                   # the caller sees that the frame did not fit
+        np.testing.assert_array_equal(got[Tn - 1], np.full(36, 500.0, np.float32))
+        with pytest.raises(T.TransCARHipError):             # ... and the checked form refuses it
+            T.ops.radar_build_tokens(frame, Tn, dev(), check=True)
     elif case != 'empty':
         # and the head consumes them: same result as the host-built tokens
         tok_np, pm = R.pack_tokens([want_rows], T=Tn)
@@ -741,24 +744,6 @@ def test_pipeline_producer_rewrites_lane_inputs(T, head):
     for fidx in range(nframes):
         for a_, b_ in zip(got[fidx], want[fidx]):
             assert torch.equal(a_, b_), 'frame %d' % fidx
-    # the same with the H2D copies inside the lanes' graphs: the producer only touches pinned host memory
-    spipe = FramePipeline(head, lanes, host_staging=True)
-    got2 = [None] * nframes
-    for fidx in range(nframes):
-        lane = fidx % nl
-        spipe.host_wait(lane)
-        h = spipe.host_inputs(lane)
-        h['tokens'].copy_(host[fidx]['tokens'])
-        h['l2i'].copy_(host[fidx]['l2i'])
-        spipe.write_inputs(lane, nhwc=host[fidx]['nhwc'])
-        _, (outs, dec) = spipe.launch(lane)
-        with torch.cuda.stream(spipe.streams[lane]):
-            got2[fidx] = (outs['all_bbox_preds'].clone(), outs['all_cls_scores'].clone(), dec[0].clone())
-    spipe.synchronize()
-    torch.cuda.synchronize()
-    for fidx in range(nframes):
-        for a_, b_ in zip(got2[fidx], want[fidx]):
-            assert torch.equal(a_, b_), 'staged frame %d' % fidx
     # a frame packed to another token count is refused, not silently mis-read
     tok_np, pm = R.pack_tokens([frames[0]['radar_feats'][0]], T=320)
     with pytest.raises(T.TransCARHipError):

@@ -1528,11 +1528,11 @@ template <int RA, int RB, int PROGB>
 int launch_dual_r(const ChainK& ka_, const ChainK& kb_, hipStream_t s, const char* what) {
   constexpr size_t lds = chain_lds_bytes<RA, PROG_DECODER>() > chain_lds_bytes<RB, PROGB>() ? chain_lds_bytes<RA, PROG_DECODER>() : chain_lds_bytes<RB, PROGB>();
   static DeviceOnce once;
-  if (once.need()) {
+  if (const int once_dev = once.need(); once_dev >= 0) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_dual_kernel<RA, RB, PROGB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("chain: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    once.done();
+    once.done(once_dev);
   }
   ChainK ka = ka_, kb = kb_;
   TC_REQUIRE((RA != 16 || ka.w16_delta != 0) && (RB != 16 || kb.w16_delta != 0),
@@ -1550,12 +1550,12 @@ int launch_dual_r(const ChainK& ka_, const ChainK& kb_, hipStream_t s, const cha
 template <int R, int PROG, bool DROP = false>
 int launch_r(const ChainK& k_, hipStream_t s, const char* what) {
   static DeviceOnce once;
-  if (once.need()) {
+  if (const int once_dev = once.need(); once_dev >= 0) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<R, PROG, DROP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)chain_lds_bytes<R, PROG>());
     if (e != hipSuccess) { set_error("chain: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    once.done();
+    once.done(once_dev);
   }
   ChainK k = k_;
   TC_REQUIRE(R != 16 || k.w16_delta != 0,

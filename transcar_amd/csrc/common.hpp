@@ -27,13 +27,15 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 // "done once per DEVICE" (hipFuncSetAttribute is per device: a second GPU used by the same
 // process needs its own call).  Racing first calls both set the attribute -- harmless.
 struct DeviceOnce {
-  unsigned long long mask[4] = {0, 0, 0, 0};     // up to 256 devices
-  int dev = 0;
-  bool need() {
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 256) { dev = -1; return true; }
-    return ((__atomic_load_n(&mask[dev >> 6], __ATOMIC_ACQUIRE) >> (dev & 63)) & 1ull) == 0;
+  unsigned long long mask[4] = {0, 0, 0, 0};     // up to 256 devices; the only shared state
+  // returns the calling thread's device when its attribute call is still to be made, -1 when done
+  // (the device travels through the caller: two host threads on different GPUs share this object)
+  int need() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 256) return 256;     // unknown: always set
+    return ((__atomic_load_n(&mask[dev >> 6], __ATOMIC_ACQUIRE) >> (dev & 63)) & 1ull) == 0 ? dev : -1;
   }
-  void done() { if (dev >= 0) __atomic_fetch_or(&mask[dev >> 6], 1ull << (dev & 63), __ATOMIC_RELEASE); }
+  void done(int dev) { if (dev >= 0 && dev < 256) __atomic_fetch_or(&mask[dev >> 6], 1ull << (dev & 63), __ATOMIC_RELEASE); }
 };
 
 // bump allocator over the caller's workspace (256-byte aligned slices)

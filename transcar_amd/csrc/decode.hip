@@ -161,11 +161,11 @@ int launch_box_decode(const float* cls, const float* box, int B, int Q, int ncls
   p.boxes = boxes; p.scores = scores; p.labels = labels; p.valid = valid;
   const size_t lds = (size_t)DEC_MAXN * 8 + DEC_MAXK * 8 + 256 * 4 + 16;
   static DeviceOnce once;
-  if (once.need()) {
+  if (const int once_dev = once.need(); once_dev >= 0) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(box_decode_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("box_decode: %s", hipGetErrorString(e)); return (int)e; }
-    once.done();
+    once.done(once_dev);
   }
   hipLaunchKernelGGL(box_decode_kernel, dim3(B), dim3(DEC_THREADS), lds, s, p);
   return check_launch("box_decode");

@@ -508,6 +508,20 @@ int tc_radar_gated_xattn_fwd(const tc_mha* w, const float* query, const float* c
   return linear(rattn, C, w->out_proj, rows, C, C, 0, out, C, s, nullptr, query, C, hits);
 }
 
+// per-call options of the whole-path entry points (tc_head_forward, tc_radar_fusion_fwd): defaults + validation
+static int read_options(const tc_head_options* options, tc_head_options& opt) {
+  memset(&opt, 0, sizeof(opt));
+  if (options != nullptr) opt = *options;
+  TC_REQUIRE(opt.radar_row_order >= 0 && opt.radar_row_order <= 2, "options.radar_row_order=%d (0 automatic, 1 own order, 2 hits first)",
+             opt.radar_row_order);
+  TC_REQUIRE(opt.chain_tile_rows == 0 || opt.chain_tile_rows == 4 || opt.chain_tile_rows == 8 ||
+                 opt.chain_tile_rows == 16,
+             "options.chain_tile_rows=%d (0 = automatic, 4, 8 or 16)", opt.chain_tile_rows);
+  TC_REQUIRE(opt.decoder_dropout_p >= 0.0f && opt.decoder_dropout_p < 1.0f, "options.decoder_dropout_p=%g",
+             (double)opt.decoder_dropout_p);
+  return 0;
+}
+
 int tc_radar_fusion_fwd(const tc_head_weights* packed_view, const float* hs_last, const float* ref_last,
                         const float* prev_box, const float* radar_tokens, int B, int T, int pad_mult,
                         int first_layer, int num_layers, float* all_cls_scores, float* all_bbox_preds,
@@ -522,8 +536,7 @@ int tc_radar_fusion_fwd(const tc_head_weights* packed_view, const float* hs_last
              "radar_fusion: null argument");
   TC_REQUIRE(B >= 1 && T >= 1 && pad_mult >= 1, "radar_fusion: B=%d T=%d pad_mult=%d", B, T, pad_mult);
   tc_head_options opt;
-  memset(&opt, 0, sizeof(opt));
-  if (options != nullptr) opt = *options;
+  TC_TRY(read_options(options, opt));
   HeadWs h;
   const size_t need = head_ws_layout(w, B, T, workspace, workspace_bytes, &h);
   TC_REQUIRE(need <= workspace_bytes, "workspace too small: need %zu, have %zu", need, workspace_bytes);
@@ -688,15 +701,7 @@ int tc_head_forward(const tc_head_weights* w, const tc_head_weights* packed_view
                     tc_stream_t stream) {
   TC_TRY(check_dims(w));
   tc_head_options opt;
-  memset(&opt, 0, sizeof(opt));
-  if (options != nullptr) opt = *options;
-  TC_REQUIRE(opt.radar_row_order >= 0 && opt.radar_row_order <= 2, "options.radar_row_order=%d (0 automatic, 1 own order, 2 hits first)",
-             opt.radar_row_order);
-  TC_REQUIRE(opt.chain_tile_rows == 0 || opt.chain_tile_rows == 4 || opt.chain_tile_rows == 8 ||
-                 opt.chain_tile_rows == 16,
-             "options.chain_tile_rows=%d (0 = automatic, 4, 8 or 16)", opt.chain_tile_rows);
-  TC_REQUIRE(opt.decoder_dropout_p >= 0.0f && opt.decoder_dropout_p < 1.0f, "options.decoder_dropout_p=%g",
-             (double)opt.decoder_dropout_p);
+  TC_TRY(read_options(options, opt));
   TC_REQUIRE(feats != nullptr && feats->num_levels == w->num_levels, "feats: num_levels mismatch");
   TC_REQUIRE(B >= 1, "B=%d", B);
   TC_REQUIRE(w->num_radar_layers == 0 || (radar_tokens != nullptr && T >= 1 && pad_mult >= 1),

@@ -15,6 +15,7 @@ namespace tc {
 namespace {
 
 constexpr int RI_RAW = 18, RI_OUT = 36, MAX_CHAN = 8, NT = 256;
+constexpr int REF_TOKENS = 1500;     // HEAD:526: the reference always attends over 1500 tokens
 
 struct IngestK {
   const double* raw;        // [N, 18] point-major
@@ -52,6 +53,10 @@ __global__ __launch_bounds__(NT) void radar_ingest_kernel(IngestK k) {
     if (m) atomicMax(&tmax[c], m);
   }
   __syncthreads();
+  // T < 1500: row T - 1 stands for the 1500 - T + 1 pad rows the head folds into it (pad_mult), so it must
+  // STAY a 500.0 pad row -- a real return there would be weighted pad_mult times by the gate and the
+  // attention.  At most T - 1 points are kept then; `count` (> T - 1) tells the caller the frame did not fit.
+  const int limit = k.T < REF_TOKENS ? k.T - 1 : k.T;
   for (int i0 = 0; i0 < k.N; i0 += NT) {
     const int i = i0 + tid;
     bool keep = false;
@@ -64,7 +69,7 @@ __global__ __launch_bounds__(NT) void radar_ingest_kernel(IngestK k) {
     int off = base;
     for (int w = 0; w < wave; ++w) off += wave_cnt[w];
     off += __popcll(bal & ((1ull << lane) - 1ull));
-    if (keep && off < k.T) {
+    if (keep && off < limit) {
       int c = 0;
       while (c + 1 < k.num_chan && i >= k.chan_start[c + 1]) ++c;
       const double* R = k.rot_radar[c];
@@ -101,7 +106,7 @@ __global__ __launch_bounds__(NT) void radar_ingest_kernel(IngestK k) {
     __syncthreads();
   }
   // pad tokens (HEAD:526-530)
-  const int filled = min(base, k.T);
+  const int filled = min(base, limit);
   for (int j = filled * RI_OUT + tid; j < k.T * RI_OUT; j += NT) k.tokens[j] = 500.0f;
   if (tid == 0 && k.count != nullptr) k.count[0] = base;
 }

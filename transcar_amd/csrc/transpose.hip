@@ -20,7 +20,7 @@ namespace {
 
 constexpr int TP = 64, TCH = 64, TLD = 65;
 
-struct TrLevel { const float* src; float* dst; int HW, px_tiles, first_tile, vec; };
+struct TrLevel { const float* src; float* dst; int HW, px_tiles, first_tile, vec, vst; };
 struct TrArgs { TrLevel lv[TC_MAX_LEVELS]; int num_levels, C, c_tiles, n_img; };
 
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(TrArgs a) {
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(TrArgs a) {
     for (int i = 0; i < 16; ++i) tile[i * 4 + ty][tx] = v[i];
   }
   __syncthreads();
-  if ((C & 3) == 0) {
+  if (lv.vst) {
     // thread -> (pixel p0 + (tid >> 4) + 16 i, channels c0 + 4 (tid & 15) ..+3)
     const int cc = 4 * (tid & 15);
 #pragma unroll
@@ -95,7 +95,7 @@ int launch_nchw_to_nhwc_levels(const float* const* src, float* const* dst, int n
   long long tiles = 0;
   for (int l = 0; l < TC_MAX_LEVELS; ++l) {
     TrLevel& lv = a.lv[l];
-    if (l >= num_levels) { lv = TrLevel{nullptr, nullptr, 0, 1, 0x7fffffff, 0}; continue; }
+    if (l >= num_levels) { lv = TrLevel{nullptr, nullptr, 0, 1, 0x7fffffff, 0, 0}; continue; }
     TC_REQUIRE(src[l] != nullptr && dst[l] != nullptr && H[l] > 0 && W[l] > 0,
                "nchw_to_nhwc: level %d is empty", l);
     lv.src = src[l]; lv.dst = dst[l]; lv.HW = H[l] * W[l];
@@ -103,6 +103,8 @@ int launch_nchw_to_nhwc_levels(const float* const* src, float* const* dst, int n
     lv.first_tile = (int)tiles;
     // 16-byte loads need every channel row 16-byte aligned
     lv.vec = ((lv.HW & 3) == 0 && (reinterpret_cast<size_t>(src[l]) & 15) == 0) ? 1 : 0;
+    // 16-byte stores along the channels: C % 4 == 0 AND a 16-byte aligned destination (a caller's `out` view)
+    lv.vst = ((C & 3) == 0 && (reinterpret_cast<size_t>(dst[l]) & 15) == 0) ? 1 : 0;
     tiles += (long long)lv.px_tiles * a.c_tiles * n_img;
     TC_REQUIRE(tiles < (1ll << 31), "nchw_to_nhwc: too many tiles");
   }

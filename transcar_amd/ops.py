@@ -262,7 +262,7 @@ def radar_fusion(head, hs_last, ref_last, prev_box, tokens, pad_mult, first_laye
     L.check(L.lib().tc_radar_fusion_fwd(
         C.byref(pv), _p(hs_last), _p(ref_last), _p(prev_box), _p(tokens), B, T, int(pad_mult),
         int(first_layer), int(num_layers), _p(cls), _p(box), _p(hits),
-        C.byref(options) if options is not None else None, _p(ws), nbytes, _stream()),
+        C.byref(options) if options is not None else None, _p(ws), ws.numel() * ws.element_size(), _stream()),
         'tc_radar_fusion_fwd')
     return cls, box, hits
 
@@ -306,12 +306,15 @@ def radar_raw_arrays(frame):
     return raw, np.concatenate(times) if start[-1] else np.zeros(0), np.asarray(start, np.int32), rr, lr
 
 
-def radar_build_tokens(frame, T, device, out=None, point_range=None):
+def radar_build_tokens(frame, T, device, out=None, point_range=None, check=False):
     """Radar ingest of one sample on the device (tc_radar_build_tokens, HEAD:301-536): the raw
     rows go up as they are (H2D of N x 19 float64), one launch writes the [T,36] token matrix.
     Returns (tokens [1,T,36] -- ``out`` when given, e.g. a pipeline lane's static tensor --,
     count: int32 device tensor with the number of points kept by the range filter,
-    pad_mult = 1500 - T + 1)."""
+    pad_mult = 1500 - T + 1).  With T < 1500 at most T - 1 points are written (row T - 1 carries
+    pad_mult and stays a pad row); ``check=True`` reads `count` back (one D2H sync) and raises when
+    the frame did not fit -- a pipeline checks its lanes' counts after the replay instead
+    (FramePipeline.radar_overflow)."""
     from . import radar as R
     raw, times, start, rr, lr = radar_raw_arrays(frame)
     n = int(start[-1])
@@ -327,7 +330,19 @@ def radar_build_tokens(frame, T, device, out=None, point_range=None):
         _p(raw_d), _p(times_d), start.ctypes.data_as(C.POINTER(C.c_int)), len(R.RADAR_CHANNELS),
         rr.ctypes.data_as(C.POINTER(C.c_double)), lr.ctypes.data_as(C.POINTER(C.c_double)), pr,
         _p(out), int(T), _p(count), _stream()), 'tc_radar_build_tokens')
+    if check:
+        radar_check_fits(count, T)
     return out, count, R.NUM_RADAR_TOKENS - T + 1
+
+
+def radar_check_fits(count, T):
+    """Raise when the device ingest kept more points than a [T,36] token matrix can hold
+    (T < 1500: T - 1 points + the pad row; T = 1500: the reference's own truncation)."""
+    from . import radar as R
+    n = int(count.max().item())
+    if T < R.NUM_RADAR_TOKENS and n > T - 1:
+        raise L.TransCARHipError('radar ingest: %d points kept, T=%d holds %d (+ the pad row): use a '
+                                 'larger T (up to %d)' % (n, T, T - 1, R.NUM_RADAR_TOKENS))
 
 
 def box_decode_topk(cls_scores, bbox_preds, post_center_range, max_num=300):

@@ -50,8 +50,7 @@ class FramePipeline:
     8 at one frame per lane buys throughput with >= 3 lanes and costs latency.
     """
 
-    def __init__(self, head, static_inputs, decode=True, tile_rows=None, options=None, host_staging=False,
-                 streams=None):
+    def __init__(self, head, static_inputs, decode=True, tile_rows=None, options=None, streams=None):
         if not static_inputs:
             raise ValueError('at least one lane')
         from .detr3d_head import head_options
@@ -73,27 +72,12 @@ class FramePipeline:
             [torch.cuda.Stream() for _ in self.inputs]
         self.done = [torch.cuda.Event() for _ in self.inputs]
         self.options = options if options is not None else head_options(tile_rows=tile_rows)
-        # host_staging: every lane gets pinned host tensors for the small per-frame inputs that come
-        # from the data loader (radar tokens, lidar2img); their H2D copies are nodes of the lane's
-        # graph.  The producer fills the staging tensors on the CPU (`host_inputs(lane)` after
-        # `host_wait(lane)`) and calls `launch`: no copy call, no stream hand-shake per frame.
-        self.host = None
-        if host_staging:
-            self.host = [dict(tokens=torch.empty(i['tokens'].shape, dtype=torch.float32).pin_memory(),
-                              l2i=torch.empty(i['l2i'].shape, dtype=torch.float32).pin_memory())
-                         for i in self.inputs]
-            for h, i in zip(self.host, self.inputs):
-                h['tokens'].copy_(i['tokens'])
-                h['l2i'].copy_(i['l2i'])
         self.graphs, self.outputs = [], []
         self._next = 0
         self._capture()
 
     def _step(self, i):
         inp = self.inputs[i]
-        if self.host is not None:              # H2D of the staged inputs as part of the launch sequence
-            inp['tokens'].copy_(self.host[i]['tokens'], non_blocking=True)
-            inp['l2i'].copy_(self.host[i]['l2i'], non_blocking=True)
         if inp.get('nchw') is not None:
             ops.to_nhwc_levels(inp['nchw'], out=inp['nhwc'])
         outs = self.head.forward_nhwc(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'],
@@ -141,11 +125,17 @@ class FramePipeline:
             raise TransCARHipError(
                 'FramePipeline: the head re-allocated device buffers (packed weights / workspaces) '
                 'after these graphs were captured; call recapture()')
-        self.head.sync_packed_weights()                # an optimizer step since the last replay (current stream)
+        if getattr(self.head, '_packed_dirty', False):
+            # an optimizer step since the last replay: the re-pack (current stream) overwrites the packed
+            # buffer that EVERY lane's graph reads -- it must come after all replays still in flight
+            cur = torch.cuda.current_stream()
+            for ev in self.done:
+                cur.wait_event(ev)
+            self.head.sync_packed_weights()
         i = self._next if lane is None else lane
         self._next = (i + 1) % self.lanes
         s = self.streams[i]
-        s.wait_stream(torch.cuda.current_stream())     # the producer's writes come first
+        s.wait_stream(torch.cuda.current_stream())     # the producer's writes (and a re-pack) come first
         with torch.cuda.stream(s):
             self.graphs[i].replay()
             self.done[i].record(s)
@@ -179,17 +169,6 @@ class FramePipeline:
             self._filled[lane] = 0
             self._fill_lane = (lane + 1) % self.lanes
         return n
-
-    def host_wait(self, lane):
-        """Block the HOST until lane's last replay has finished: its pinned staging tensors
-        (`host_inputs(lane)`) may be overwritten afterwards."""
-        self.done[lane].synchronize()
-
-    def host_inputs(self, lane):
-        """The lane's pinned staging tensors (dict tokens [P,T,36], l2i [P,N,4,4]); host_staging only."""
-        if self.host is None:
-            raise TransCARHipError('FramePipeline was built without host_staging')
-        return self.host[lane]
 
     def producer_wait(self, lane):
         """The current stream waits until lane's last replay has finished: after this, work
