@@ -34,7 +34,7 @@ extern "C" {
 #define TC_MAX_LEVELS 4
 #define TC_MAX_LAYERS 8
 #define TC_MAX_RADAR_LAYERS 3
-#define TC_ABI_VERSION 7
+#define TC_ABI_VERSION 8
 
 typedef void* tc_stream_t;
 
@@ -186,6 +186,24 @@ int tc_nchw_to_nhwc_levels(const float* const* src, float* const* dst, int num_l
 int tc_radar_build_tokens(const double* raw, const double* times, const int* chan_start, int num_chan,
                           const double* radar_rot, const double* lidar_rot, const double* point_range,
                           float* tokens, int T, int* count, tc_stream_t stream);
+
+/* The same for P samples in ONE launch with the per-sample parameters in DEVICE memory, so that a captured
+ * hipGraph can replay it on new frames (FramePipeline: the first node of a lane's graph; Detr3DHead.forward
+ * with raw sweeps in img_metas).  Replaces the same reference lines (HEAD:301-536).
+ *   raw    device [P, cap, 18] float64, sample b's points at rows [0, chan_start[num_chan]) of its slab
+ *   times  device [P, cap] float64
+ *   desc   device [P]: chan_start / num_chan / rotations / point_range of each sample (clamped to [0, cap])
+ *   tokens device [P, T, 36]; count device [P] (may be NULL) -- semantics as tc_radar_build_tokens */
+#define TC_MAX_RADAR_CHANNELS 8
+typedef struct {
+  int chan_start[TC_MAX_RADAR_CHANNELS + 1];
+  int num_chan;
+  double radar_rot[TC_MAX_RADAR_CHANNELS * 9];
+  double lidar_rot[9];
+  double point_range[6];
+} tc_radar_frame_desc;
+int tc_radar_build_tokens_batch(const double* raw, const double* times, const tc_radar_frame_desc* desc,
+                                int P, int cap, float* tokens, int T, int* count, tc_stream_t stream);
 
 /* ---- operators, one per reference call site ---- */
 

@@ -255,6 +255,12 @@ def g8_train_grads(ref, tag='tiny'):
 def main():
     ref = RH.load_reference()
     head, _ = ref_head()
+    if len(sys.argv) > 1 and sys.argv[1] == 'vovnet':
+        # round 3: BASELINE.json configs[4] (VoVNet FPN shapes 232x400 ... 29x50): the head's inference
+        # fixture and one training iteration's gradients, from the reference itself
+        g345_head(head, ref, 'vovnet', 'vovnet')
+        g8_train_grads(ref, 'vovnet')
+        return
     g1_feature_sampling(ref)
     g2_cross_atten(head)
     g345_head(head, ref, 'tiny', 'tiny')

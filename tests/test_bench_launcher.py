@@ -68,16 +68,15 @@ def test_a_dead_rank_fails_the_launch():
     assert 'needs MI355X' in r.stderr
 
 
-def test_automatic_frames_per_launch_divides_the_window():
-    """--pair 0: a timed window of K steps ends on a launch boundary (8 when it divides K, else the
-    largest divisor up to 10)."""
-    import bench
-    assert bench.auto_frames_per_launch(200) == 8
-    assert bench.auto_frames_per_launch(20) == 10          # the driver's command
-    assert bench.auto_frames_per_launch(50) == 10
-    assert bench.auto_frames_per_launch(48) == 8
-    assert bench.auto_frames_per_launch(7) == 7
-    assert bench.auto_frames_per_launch(13) == 1
-    for k in range(1, 300):
-        p = bench.auto_frames_per_launch(k)
-        assert 1 <= p <= 10 and k % p == 0
+def test_automatic_frames_per_launch_keeps_every_tile_resident():
+    """--pair 0: the most frames whose 16-row tiles are resident at once, two workgroups per CU -- 900 queries on
+    the 256 CUs of an MI355X: 9 frames = 507 workgroups (10 would be 563: a second scheduling round).  The window
+    length does not enter: its remainder is one partial launch."""
+    from transcar_amd.pipeline import resident_frames_per_launch as rfl
+    assert rfl(900, num_cus=256) == 9
+    assert -(-9 * 900 // 16) <= 512 < -(-10 * 900 // 16)
+    assert rfl(300, num_cus=256) == 27
+    assert rfl(10000, num_cus=256) == 1
+    for q in range(100, 3000, 37):
+        p = rfl(q, num_cus=256)
+        assert p >= 1 and (p == 1 or -(-p * q // 16) <= 512)

@@ -220,6 +220,18 @@ def test_radar_layers_teacher_forced_on_bench_inputs(rig, tile_rows):
                         LAYER_TOL, 'fusion layer 1 box')
     _hit_aware(cls[0, 0].cpu().numpy(), want_cls[0], hits[0, 0].cpu().numpy(), want_hits[0],
                LAYER_TOL, 'fusion layer 1 cls')
+    # fusion layers 2 and 3 of the SAME launch: layer r gates on layer r-1's own box, so a
+    # query is compared once its gate decisions agree in every layer so far (a flipped gate changes the query's
+    # later inputs); at most 2 new disagreements per layer, the layer-wise tolerance accumulates
+    agree_all = agree0.copy()
+    for r in (1, 2):
+        now = hits[r, 0].cpu().numpy() == want_hits[r]
+        assert int((agree_all & ~now).sum()) <= 2, 'fusion layer %d: %d new gate disagreements' % (r + 1, int((agree_all & ~now).sum()))
+        agree_all &= now
+        for name, got_, want_ in (('box', box[r, 0], want_box[r]), ('cls', cls[r, 0], want_cls[r])):
+            d = np.abs(got_.cpu().numpy() - want_)[agree_all]
+            assert d.max() <= LAYER_TOL * (r + 1), 'one launch, fusion layer %d %s: max|d| = %.3g' % (r + 1, name, d.max())
+    assert int(agree_all.sum()) >= want_hits.shape[1] - 6
     # -- one layer at a time, teacher-forced.  Layer r's query features are not an output of the
     # head; recompute them with the oracle's layer function from its own previous state.
     qf = dbg['hs'][-1].permute(1, 0, 2)                       # [Q,1,C]

@@ -249,10 +249,11 @@ def test_train_forward_equals_eval_forward(A, golden_dir):
     assert float((t['all_bbox_preds'] - e['all_bbox_preds']).abs().max()) < 2e-4
 
 
-@pytest.mark.parametrize('tag', ['tiny', 'res101'])
+@pytest.mark.parametrize('tag', ['tiny', 'res101', 'vovnet'])
 def test_training_iteration_gradients_match_reference(A, golden_dir, tag):
     """tag res101: BASELINE.json configs[2] at its full FPN shapes (every training test
-    ran at tiny shapes only)."""
+    ran at tiny shapes only); vovnet: configs[4]'s VoVNet FPN shapes (only inference was
+    tested there)."""
     g8 = np.load(os.path.join(golden_dir, g8_name(tag)))
     h = train_head(golden_dir).train()
     feats, metas, gt, labels = frame_inputs(golden_dir, tag)
@@ -331,10 +332,10 @@ def test_trainer_step_updates_flat_bucket_and_packed_weights(A, golden_dir):
     assert float(sum(last.values())) < first
 
 
-@pytest.mark.parametrize('tag', ['tiny', 'res101'])
+@pytest.mark.parametrize('tag', ['tiny', 'res101', 'vovnet'])
 def test_fused_training_path_gradients_match_reference(A, golden_dir, tag):
     """tc_radar_train_fwd / _bwd (the trainable stack as two C calls) against fixture G8
-    (tiny and ResNet-101 FPN shapes) and against the per-operator autograd path on the same frame."""
+    (tiny, ResNet-101 and VoVNet FPN shapes) and against the per-operator autograd path on the same frame."""
     from transcar_amd import ops
     from transcar_amd.trainer import FusionTrainer
     g8 = np.load(os.path.join(golden_dir, g8_name(tag)))

@@ -67,7 +67,7 @@ def _radar_frame_like_golden(g):
                                   centres=g['radar_centres'])
 
 
-@pytest.mark.parametrize('tag', ['tiny', 'res101'])
+@pytest.mark.parametrize('tag', ['tiny', 'res101', 'vovnet'])
 def test_g5_full_head(golden_dir, sd, tag):
     g = _g(golden_dir, 'g5_head_%s.npz' % tag)
     feats = [torch.from_numpy(f) for f in synth.make_feats(tag, seed=1, smooth=(4, 6))]

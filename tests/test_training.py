@@ -174,7 +174,7 @@ def check_grads_against_g8(grads, g8, rtol, what):
     return checked
 
 
-@pytest.mark.parametrize('tag', ['tiny', 'res101'])
+@pytest.mark.parametrize('tag', ['tiny', 'res101', 'vovnet'])
 def test_oracle_backward_matches_reference(golden_dir, tag):
     g8 = np.load(os.path.join(golden_dir, g8_name(tag)))
     feats, l2i, frame, boxes, labels = g8_inputs(golden_dir, tag)

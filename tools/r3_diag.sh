@@ -14,19 +14,19 @@ if [ "${SKIP_TESTS:-0}" != 1 ]; then
 fi
 ST=$REPO/build/hip_stamps/libtranscar_hip_stamps.so
 if [ -f "$ST" ]; then
-  for B in ${STAMP_BATCHES:-8}; do
+  for B in ${STAMP_BATCHES-8}; do
     TRANSCAR_ALLOW_STAMPS=1 TRANSCAR_HIP_LIB=$ST STAMPS_BATCH=$B timeout 300 python tools/chain_stamps.py decoder > "$OUT/stamps_dec_b$B.txt" 2>&1
     TRANSCAR_ALLOW_STAMPS=1 TRANSCAR_HIP_LIB=$ST STAMPS_BATCH=$B timeout 300 python tools/chain_stamps.py radar > "$OUT/stamps_rad_b$B.txt" 2>&1
   done
 fi
 Q="--main-only"
 : > "$OUT/bench_sweep.jsonl"
-for cfg in ${SWEEP:-"8 200 20" "9 180 20" "9 20 5" "7 20 5" "10 20 5" "8 20 5"}; do
-  set -- $cfg
+for cfg in ${SWEEP-8:200:20 9:180:20 9:20:5 7:20:5 10:20:5}; do
+  IFS=: read -r a b c <<< "$cfg"; set -- $a $b $c
   echo "# pair $1 steps $2 warmup $3" >> "$OUT/bench_sweep.jsonl"
   timeout 300 python bench.py --pair $1 --steps $2 --warmup $3 $Q >> "$OUT/bench_sweep.jsonl" 2>> "$OUT/bench.err"
 done
-for P in ${ROOF:-9}; do
+for P in ${ROOF-9}; do
   timeout 300 python bench.py --pair $P --steps $((P * 20)) --no-cpu-baseline --no-batched --no-handoff > "$OUT/bench_roof_p$P.json" 2>> "$OUT/bench.err"
 done
 python - <<'PY'

@@ -19,13 +19,22 @@ LIB_PATH = os.environ.get('TRANSCAR_HIP_LIB') or os.path.join(_HERE, 'lib', 'lib
 TC_MAX_LEVELS = 4
 TC_MAX_LAYERS = 8
 TC_MAX_RADAR_LAYERS = 3
-TC_ABI_VERSION = 7
+TC_ABI_VERSION = 8
 
 c_fp = C.c_void_p      # device pointers travel as integers
 
 
 class TransCARHipError(RuntimeError):
     pass
+
+
+TC_MAX_RADAR_CHANNELS = 8
+
+
+class tc_radar_frame_desc(C.Structure):
+    _fields_ = [('chan_start', C.c_int * (TC_MAX_RADAR_CHANNELS + 1)), ('num_chan', C.c_int),
+                ('radar_rot', C.c_double * (TC_MAX_RADAR_CHANNELS * 9)), ('lidar_rot', C.c_double * 9),
+                ('point_range', C.c_double * 6)]
 
 
 class tc_linear(C.Structure):
@@ -121,6 +130,7 @@ SIGNATURES = {
     'tc_nchw_to_nhwc_levels': (_i, [_P(_vp), _P(_vp), _i, _i, _i, _P(_i), _P(_i), _vp]),
     'tc_radar_build_tokens': (_i, [_vp, _vp, _P(_i), _i, _P(C.c_double), _P(C.c_double),
                                    _P(C.c_double), _vp, _i, _vp, _vp]),
+    'tc_radar_build_tokens_batch': (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp]),
     'tc_linear_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'tc_add_layernorm_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'tc_refine_reference_fwd': (_i, [_vp, _i, _vp, _vp, _i, _vp]),

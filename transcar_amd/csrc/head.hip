@@ -357,6 +357,11 @@ int tc_radar_build_tokens(const double* raw, const double* times, const int* cha
                              count, as_stream(stream));
 }
 
+int tc_radar_build_tokens_batch(const double* raw, const double* times, const tc_radar_frame_desc* desc,
+                                int P, int cap, float* tokens, int T, int* count, tc_stream_t stream) {
+  return launch_radar_ingest_batch(raw, times, desc, P, cap, tokens, T, count, as_stream(stream));
+}
+
 int tc_linear_fwd(const float* x, const float* x2, const float* w, const float* b, const float* res,
                   float* y, int M, int K, int N, int act, tc_stream_t stream) {
   tc_linear lw{w, b};

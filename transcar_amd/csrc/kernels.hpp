@@ -196,6 +196,8 @@ int launch_nchw_to_nhwc_levels(const float* const* src, float* const* dst, int n
 int launch_radar_ingest(const double* raw, const double* times, const int* chan_start_host, int num_chan,
                         const double* radar_rot_host, const double* lidar_rot_host,
                         const double* point_range_host, float* tokens, int T, int* count, hipStream_t s);
+int launch_radar_ingest_batch(const double* raw, const double* times, const tc_radar_frame_desc* desc, int P, int cap,
+                              float* tokens, int T, int* count, hipStream_t s);
 
 // ---- decode.hip ------------------------------------------------------------
 int launch_box_decode(const float* cls, const float* box, int B, int Q, int ncls, int code,

@@ -38,7 +38,7 @@ __device__ __forceinline__ double unord(unsigned long long u) {
   return __longlong_as_double((long long)b);
 }
 
-__global__ __launch_bounds__(NT) void radar_ingest_kernel(IngestK k) {
+__device__ __forceinline__ void radar_ingest_body(const IngestK& k) {
   __shared__ unsigned long long tmax[MAX_CHAN];
   __shared__ int wave_cnt[NT / 64];
   __shared__ int base;
@@ -111,7 +111,51 @@ __global__ __launch_bounds__(NT) void radar_ingest_kernel(IngestK k) {
   if (tid == 0 && k.count != nullptr) k.count[0] = base;
 }
 
+// one sample, its parameters by value (kernel arguments)
+__global__ __launch_bounds__(NT) void radar_ingest_kernel(IngestK k) { radar_ingest_body(k); }
+
+// P samples in one launch, workgroup b = sample b, its parameters from a DEVICE-resident descriptor: the form a
+// captured hipGraph can replay on new frames (a lane's producer refills raw rows + descriptors, nothing is baked
+// into the graph's kernel arguments).  raw [P, cap, 18], times [P, cap], tokens [P, T, 36], count [P].
+struct IngestBatchK { const double* raw; const double* times; const tc_radar_frame_desc* desc; int cap, T; float* tokens; int* count; };
+__global__ __launch_bounds__(NT) void radar_ingest_batch_kernel(IngestBatchK a) {
+  __shared__ IngestK sk;
+  const int b = blockIdx.x;
+  if (threadIdx.x == 0) {
+    const tc_radar_frame_desc& d = a.desc[b];
+    sk.raw = a.raw + (size_t)b * a.cap * RI_RAW;
+    sk.times = a.times + (size_t)b * a.cap;
+    int nc = d.num_chan < 1 ? 1 : d.num_chan > MAX_CHAN ? MAX_CHAN : d.num_chan;
+    sk.num_chan = nc;
+    int prev = 0;
+    for (int c = 0; c <= MAX_CHAN; ++c) {             // ascending, inside [0, cap]: a bad descriptor cannot read out of bounds
+      int v = d.chan_start[c <= nc ? c : nc];
+      v = c == 0 ? 0 : (v < prev ? prev : v > a.cap ? a.cap : v);
+      sk.chan_start[c] = v; prev = v;
+    }
+    sk.N = sk.chan_start[nc]; sk.T = a.T;
+    for (int c = 0; c < MAX_CHAN; ++c)
+      for (int j = 0; j < 9; ++j) sk.rot_radar[c][j] = c < nc ? d.radar_rot[c * 9 + j] : 0.0;
+    for (int j = 0; j < 9; ++j) sk.rot_ref[j] = d.lidar_rot[j];
+    for (int j = 0; j < 3; ++j) { sk.lo[j] = d.point_range[j]; sk.hi[j] = d.point_range[3 + j]; }
+    sk.tokens = a.tokens + (size_t)b * a.T * RI_OUT;
+    sk.count = a.count != nullptr ? a.count + b : nullptr;
+  }
+  __syncthreads();
+  radar_ingest_body(sk);
+}
+
 }  // namespace
+
+int launch_radar_ingest_batch(const double* raw, const double* times, const tc_radar_frame_desc* desc, int P, int cap,
+                              float* tokens, int T, int* count, hipStream_t s) {
+  static_assert(TC_MAX_RADAR_CHANNELS == MAX_CHAN, "descriptor layout");
+  TC_REQUIRE(P >= 1 && cap >= 1 && T >= 1, "radar_ingest_batch: P=%d cap=%d T=%d", P, cap, T);
+  TC_REQUIRE(raw != nullptr && times != nullptr && desc != nullptr && tokens != nullptr, "radar_ingest_batch: null argument");
+  IngestBatchK a{raw, times, desc, cap, T, tokens, count};
+  hipLaunchKernelGGL(radar_ingest_batch_kernel, dim3(P), dim3(NT), 0, s, a);
+  return check_launch("radar_ingest_batch");
+}
 
 int launch_radar_ingest(const double* raw, const double* times, const int* chan_start_host, int num_chan,
                         const double* radar_rot_host, const double* lidar_rot_host,

@@ -175,6 +175,10 @@ class Detr3DHead(BaseModule):
         #: the trainable (radar) weights changed in place since they were last re-packed
         #: (an optimizer step): the next forward / pipeline replay that reads them re-packs first
         self._packed_dirty = False
+        #: 'device' (default): raw radar sweeps in img_metas are turned into tokens by tc_radar_build_tokens_batch;
+        #: 'host': the reference's numpy route (transcar_amd/radar.py)
+        self.radar_ingest = 'device'
+        self._radar_stage = {}
         #: bumped whenever a device buffer a captured hipGraph may point at (packed weights,
         #: lane workspaces) is re-allocated: FramePipeline refuses to replay a stale capture
         self.buffers_generation = 0
@@ -350,16 +354,42 @@ class Detr3DHead(BaseModule):
     # ------------------------------------------------------------------
     # forward
     # ------------------------------------------------------------------
-    def radar_tokens(self, img_metas, device):
-        """img_metas[i]['radar'] -> (tokens [B,T,36] on device, pad_mult)."""
-        feats = []
+    def radar_tokens(self, img_metas, device, T=None, ingest=None):
+        """img_metas[i]['radar'] -> (tokens [B,T,36] on device, pad_mult).
+
+        Raw sweeps (the dict layout of transcar_amd/radar.py, what the devkit returns for HEAD:301-309) are
+        turned into the 36-feature rows ON THE DEVICE (``self.radar_ingest == 'device'``, the default:
+        tc_radar_build_tokens_batch -- the raw rows go up as they are, one launch builds all samples' tokens;
+        float64 arithmetic as HEAD:311-521, bit-equal to the host builder except the six rotated-velocity
+        columns, which agree to 1 ulp); [n,36] feature arrays, or ``ingest='host'``, take the numpy route of
+        the reference.  T: fixed token count (default: the smallest multiple of 64 that holds the frame)."""
+        raws = []
         for m in img_metas:
             if 'radar' not in m:
                 raise KeyError(
                     "img_metas[i]['radar'] is required: raw sweeps "
                     '(transcar_amd/radar.py) or an [n,36] feature array')
-            feats.append(radar.build_radar_features(m['radar']))
-        tokens, pad_mult = radar.pack_tokens(feats)
+            raws.append(m['radar'])
+        mode = ingest or getattr(self, 'radar_ingest', 'device')
+        if mode == 'device' and all(isinstance(r, dict) for r in raws):
+            n_raw = [sum(int(np.asarray(r['points'][c]).shape[1]) for c in radar.RADAR_CHANNELS) for r in raws]
+            if T is None:
+                T = ops.radar_tokens_T(max(n_raw))       # n_raw >= the points the range filter keeps
+            B = len(raws)
+            cap = max(64, ((max(n_raw) + 63) // 64) * 64)
+            key = (B, str(device))
+            stage = self._radar_stage.get(key)
+            if stage is None or stage.cap < cap:
+                stage = self._radar_stage[key] = ops.RadarRawStage(B, cap, device)
+            for b, r in enumerate(raws):
+                stage.put(b, r)
+            tokens = torch.empty((B, T, radar.NUM_FEATURES), dtype=torch.float32, device=device)
+            _, pad_mult = stage.build(tokens)
+            if T < radar.NUM_RADAR_TOKENS and max(n_raw) > T - 1:
+                ops.radar_check_fits(stage.count, T)     # an explicit T: the kept points must fit (one D2H sync)
+            return tokens, pad_mult
+        feats = [radar.build_radar_features(r) for r in raws]
+        tokens, pad_mult = radar.pack_tokens(feats, T=T)
         return torch.from_numpy(tokens).to(device), pad_mult
 
     def forward_nhwc(self, feats_nhwc, lidar2img, img_hw, tokens, pad_mult,

@@ -335,6 +335,93 @@ def radar_build_tokens(frame, T, device, out=None, point_range=None, check=False
     return out, count, R.NUM_RADAR_TOKENS - T + 1
 
 
+class RadarRawStage:
+    """Raw radar of P samples staged for tc_radar_build_tokens_batch: device slabs raw [P,cap,18] f64,
+    times [P,cap] f64, descriptors [P] (chan_start / rotations / point range) and count [P], plus pinned host
+    mirrors.  ``put(slot, frame)`` packs one sample on the host (no arithmetic beyond quaternion -> rotation
+    matrix) and enqueues its three H2D copies on the current stream; ``build(tokens)`` is ONE launch that
+    writes the [P,T,36] token tensor (graph-capturable: nothing of a frame is baked into its arguments)."""
+
+    def __init__(self, P, cap, device, point_range=None):
+        from . import radar as R
+        self.P, self.cap, self.device = int(P), int(cap), device
+        self.point_range = [float(v) for v in (point_range or R.POINT_RANGE)]
+        dsz = C.sizeof(L.tc_radar_frame_desc)
+        self.raw = torch.zeros((P, cap, 18), dtype=torch.float64, device=device)
+        self.times = torch.zeros((P, cap), dtype=torch.float64, device=device)
+        self.desc = torch.zeros((P, dsz), dtype=torch.uint8, device=device)
+        self.count = torch.zeros(P, dtype=torch.int32, device=device)
+        self.h_raw = torch.zeros((P, cap, 18), dtype=torch.float64).pin_memory()
+        self.h_times = torch.zeros((P, cap), dtype=torch.float64).pin_memory()
+        self.h_desc = torch.zeros((P, dsz), dtype=torch.uint8).pin_memory()
+        self.n_raw = [0] * P
+        self._copied = [None] * P           # per slot: event behind its last H2D (the pinned mirror is reused)
+        for j in range(P):
+            self._pack(j, None)
+        self.desc.copy_(self.h_desc)
+
+    def _pack(self, slot, frame):
+        from . import radar as R
+        d = L.tc_radar_frame_desc()
+        d.num_chan = len(R.RADAR_CHANNELS)
+        n = 0
+        if frame is not None:
+            raw, times, start, rr, lr = radar_raw_arrays(frame)
+            n = int(start[-1])
+            if n > self.cap:
+                raise L.TransCARHipError('radar frame with %d raw points, the stage holds %d per sample' % (n, self.cap))
+            if n:
+                self.h_raw[slot, :n] = torch.from_numpy(raw)
+                self.h_times[slot, :n] = torch.from_numpy(times)
+            for c in range(len(start)):
+                d.chan_start[c] = int(start[c])
+            for c in range(len(start), L.TC_MAX_RADAR_CHANNELS + 1):
+                d.chan_start[c] = n
+            for i, v in enumerate(rr.reshape(-1)):
+                d.radar_rot[i] = float(v)
+            for i, v in enumerate(lr.reshape(-1)):
+                d.lidar_rot[i] = float(v)
+        for i, v in enumerate(self.point_range):
+            d.point_range[i] = v
+        self.h_desc[slot] = torch.frombuffer(bytearray(bytes(d)), dtype=torch.uint8)
+        self.n_raw[slot] = n
+        return n
+
+    def put(self, slot, frame):
+        """Stage one sample (raw sweeps dict of transcar_amd/radar.py) into slot `slot`: host pack + 3 async H2D."""
+        if self._copied[slot] is not None:
+            self._copied[slot].synchronize()        # the previous copy out of this slot's pinned mirror has run
+        n = self._pack(slot, frame)
+        if n:
+            self.raw[slot, :n].copy_(self.h_raw[slot, :n], non_blocking=True)
+            self.times[slot, :n].copy_(self.h_times[slot, :n], non_blocking=True)
+        self.desc[slot].copy_(self.h_desc[slot], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._copied[slot] = ev
+        return n
+
+    def build(self, tokens, n=None):
+        """One launch: the first n (default all) samples' raw rows -> tokens[:n] ([n,T,36], contiguous)."""
+        from . import radar as R
+        n = self.P if n is None else int(n)
+        T = int(tokens.shape[1])
+        if tokens.dim() != 3 or tokens.shape[0] < n or tokens.shape[2] != R.NUM_FEATURES or not tokens.is_contiguous() \
+                or tokens.dtype != torch.float32:
+            raise L.TransCARHipError('tokens must be a contiguous fp32 [>=%d,T,%d] tensor' % (n, R.NUM_FEATURES))
+        L.check(L.lib().tc_radar_build_tokens_batch(_p(self.raw), _p(self.times), _p(self.desc), n, self.cap,
+                                                    _p(tokens), T, _p(self.count), _stream()),
+                'tc_radar_build_tokens_batch')
+        return tokens, R.NUM_RADAR_TOKENS - T + 1
+
+
+def radar_tokens_T(n_points, granule=64):
+    """Token count for frames of at most n_points kept (or raw) points: the smallest multiple of `granule`
+    that holds them plus the pad row, at most 1500 (radar.pack_tokens's rule)."""
+    from . import radar as R
+    return min(R.NUM_RADAR_TOKENS, ((min(int(n_points), R.NUM_RADAR_TOKENS) + 1 + granule - 1) // granule) * granule)
+
+
 def radar_check_fits(count, T):
     """Raise when the device ingest kept more points than a [T,36] token matrix can hold
     (T < 1500: T - 1 points + the pad row; T = 1500: the reference's own truncation)."""

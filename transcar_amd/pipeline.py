@@ -37,6 +37,18 @@ from . import ops
 from ._lib import TransCARHipError
 
 
+def resident_frames_per_launch(num_query, device=None, tile_rows=16, workgroups_per_cu=2, num_cus=None):
+    """The largest number of frames whose row tiles are all resident at once: the fused chains run
+    `workgroups_per_cu` workgroups of `tile_rows` queries per CU, so P frames are ceil(P * Q / tile_rows)
+    workgroups on 2 x 256 slots of an MI355X -- Q = 900: 9 frames = 507 workgroups.  One frame more (563) sends
+    51 workgroups into a second round on a nearly empty chip (decoder chain 236.8 us instead of 156: 38 % of
+    the f32 MFMA peak instead of 52 %, profiles/r2_*, r3_*).  A stream of K frames is launched as K // P full
+    launches and one partial launch (`FramePipeline.flush`)."""
+    cus = num_cus or torch.cuda.get_device_properties(
+        device if device is not None else torch.cuda.current_device()).multi_processor_count
+    return max(1, (cus * workgroups_per_cu * tile_rows) // int(num_query))
+
+
 class FramePipeline:
     """``lanes`` frames in flight.
 
@@ -50,11 +62,13 @@ class FramePipeline:
     8 at one frame per lane buys throughput with >= 3 lanes and costs latency.
     """
 
-    def __init__(self, head, static_inputs, decode=True, tile_rows=None, options=None, streams=None):
+    def __init__(self, head, static_inputs, decode=True, tile_rows=None, options=None, streams=None,
+                 partial_graphs=True, radar_raw_capacity=None):
         if not static_inputs:
             raise ValueError('at least one lane')
         from .detr3d_head import head_options
         self.head, self.decode = head, decode
+        self.partial_graphs = bool(partial_graphs)
         self.inputs = list(static_inputs)
         #: frames per launch = the batch size of the lanes' static inputs
         self.frames_per_launch = int(self.inputs[0]['l2i'].shape[0])
@@ -72,14 +86,37 @@ class FramePipeline:
             [torch.cuda.Stream() for _ in self.inputs]
         self.done = [torch.cuda.Event() for _ in self.inputs]
         self.options = options if options is not None else head_options(tile_rows=tile_rows)
+        # radar_raw_capacity = N: every lane also owns a raw-radar stage (ops.RadarRawStage: device slabs for
+        # N raw points per frame slot + descriptors) and its graph STARTS with the device-side radar ingest
+        # (tc_radar_build_tokens_batch, HEAD:301-536) writing the lane's static `tokens`; the producer hands
+        # over raw sweeps (`write_inputs(lane, radar_frame=..., slot=j)`: host pack + three small H2D copies)
+        self.radar_stage = None
+        if radar_raw_capacity:
+            dev = self.inputs[0]['l2i'].device
+            self.radar_stage = [ops.RadarRawStage(self.frames_per_launch, int(radar_raw_capacity), dev)
+                                for _ in self.inputs]
         self.graphs, self.outputs = [], []
+        #: (lane, n) -> (graph, outputs): a partly filled lane (``flush`` with n < frames_per_launch valid
+        #: slots) replays a graph over its first n slots only, captured the first time that n occurs
+        self._partial = {}
+        self.last_flush = None
         self._next = 0
         self._capture()
 
-    def _step(self, i):
+    def _step(self, i, n=None):
         inp = self.inputs[i]
+        P = self.frames_per_launch
+        if n is not None and n != P:
+            # the first n frame slots of the lane's static tensors (dim 0 = P or P * num_cams), as views
+            def head_of(t):
+                return t[:(t.shape[0] // P) * n]
+            inp = dict(inp, nhwc=[head_of(t) for t in inp['nhwc']], l2i=inp['l2i'][:n], tokens=inp['tokens'][:n])
+            if inp.get('nchw') is not None:
+                inp['nchw'] = [head_of(t) for t in self.inputs[i]['nchw']]
         if inp.get('nchw') is not None:
             ops.to_nhwc_levels(inp['nchw'], out=inp['nhwc'])
+        if self.radar_stage is not None:       # raw sweeps -> this launch's tokens (first node of the graph)
+            self.radar_stage[i].build(self.inputs[i]['tokens'], n=n)
         outs = self.head.forward_nhwc(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'],
                                       inp['pad_mult'], lane=i, options=self.options)
         if not self.decode:
@@ -90,6 +127,7 @@ class FramePipeline:
 
     def _capture(self):
         self.graphs, self.outputs = [], []
+        self._partial = {}
         with torch.no_grad():
             for i, s in enumerate(self.streams):
                 s.wait_stream(torch.cuda.current_stream())
@@ -107,6 +145,23 @@ class FramePipeline:
         # the graphs hold raw pointers into the head's packed weights and lane workspaces
         self._generation = self.head.buffers_generation
 
+    def _capture_partial(self, lane, n):
+        """Graph of lane `lane` over its first n frame slots (first use of that n: host-synchronous)."""
+        self.synchronize()
+        s = self.streams[lane]
+        with torch.no_grad():
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(2):
+                    self._step(lane, n)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s, capture_error_mode='thread_local'):
+                out = self._step(lane, n)
+        torch.cuda.synchronize()
+        self._partial[(lane, n)] = (g, out)
+        return g, out
+
     def recapture(self):
         """Capture the lanes again (after the head re-allocated its packed weights or
         workspaces: ``.to()``, a checkpoint of another size)."""
@@ -117,10 +172,16 @@ class FramePipeline:
     def lanes(self):
         return len(self.graphs)
 
-    def launch(self, lane=None):
-        """Enqueue one frame on the next lane (round robin) and return
+    def launch(self, lane=None, n=None):
+        """Enqueue one launch sequence on the next lane (round robin) and return
         (lane, (outs, decoded)): the lane's static output tensors, valid once
-        ``wait(lane)`` returns and until the lane is launched again."""
+        ``wait(lane)`` returns and until the lane is launched again.
+        n (1 <= n < frames_per_launch): only the lane's first n frame slots (a graph of its own, with
+        output tensors of batch n)."""
+        if n is not None and (n == self.frames_per_launch or not self.partial_graphs):
+            n = None
+        if n is not None and not 1 <= n < self.frames_per_launch:
+            raise TransCARHipError('launch: n=%r of %d frame slots' % (n, self.frames_per_launch))
         if self.head.buffers_generation != self._generation:
             raise TransCARHipError(
                 'FramePipeline: the head re-allocated device buffers (packed weights / workspaces) '
@@ -134,12 +195,14 @@ class FramePipeline:
             self.head.sync_packed_weights()
         i = self._next if lane is None else lane
         self._next = (i + 1) % self.lanes
+        graph, outputs = (self.graphs[i], self.outputs[i]) if n is None else \
+            (self._partial.get((i, n)) or self._capture_partial(i, n))
         s = self.streams[i]
         s.wait_stream(torch.cuda.current_stream())     # the producer's writes (and a re-pack) come first
         with torch.cuda.stream(s):
-            self.graphs[i].replay()
+            graph.replay()
             self.done[i].record(s)
-        return i, self.outputs[i]
+        return i, outputs
 
     def submit(self, write=None):
         """Hand over ONE frame: it takes the next free slot (lane, slot) of the lane being filled;
@@ -160,12 +223,15 @@ class FramePipeline:
         return lane, slot, launched
 
     def flush(self):
-        """Replay a partly filled lane (its unfilled slots hold stale frames whose results the
-        caller ignores).  Returns the number of valid slots launched (0: nothing pending)."""
+        """Launch a partly filled lane: only its n filled slots run (a graph over the first n frame slots,
+        captured the first time that n occurs; with ``partial_graphs=False`` the full graph is replayed and
+        the unfilled slots hold stale frames whose results the caller ignores).  Returns the number of valid
+        slots launched (0: nothing pending); ``last_flush`` = (lane, n, (outs, decoded)) of that launch."""
         lane = self._fill_lane
         n = self._filled[lane]
         if n:
-            self.launch(lane)
+            _, out = self.launch(lane, n=n)
+            self.last_flush = (lane, n, out)
             self._filled[lane] = 0
             self._fill_lane = (lane + 1) % self.lanes
         return n
@@ -175,7 +241,8 @@ class FramePipeline:
         enqueued on the current stream may overwrite the lane's static inputs."""
         torch.cuda.current_stream().wait_event(self.done[lane])
 
-    def write_inputs(self, lane, nhwc=None, nchw=None, l2i=None, tokens=None, pad_mult=None, slot=None):
+    def write_inputs(self, lane, nhwc=None, nchw=None, l2i=None, tokens=None, pad_mult=None, slot=None,
+                     radar_frame=None):
         """Refill a lane's static inputs in place from the current stream (device tensors or
         pinned host tensors: ``copy_`` is asynchronous), ordered after the lane's previous
         replay.  tokens must have the captured shape and pad_mult (radar.pack_tokens(T=...)).
@@ -186,6 +253,16 @@ class FramePipeline:
         if slot is not None and not 0 <= slot < P:
             raise TransCARHipError('slot %r of %d' % (slot, P))
         self.producer_wait(lane)
+        if radar_frame is not None:
+            # raw sweeps of ONE frame (slot j; slot None: a list with one frame per slot) for the lane's
+            # device-side ingest node
+            if self.radar_stage is None:
+                raise TransCARHipError('FramePipeline was built without radar_raw_capacity')
+            frames = [radar_frame] if slot is not None or isinstance(radar_frame, dict) else list(radar_frame)
+            if slot is None and len(frames) != P:
+                raise TransCARHipError('radar_frame: %d frames for %d slots' % (len(frames), P))
+            for j, fr in enumerate(frames):
+                self.radar_stage[lane].put(slot if slot is not None else j, fr)
 
         def view(dst):          # the part of a static tensor one frame slot owns (dim 0 = P or P * num_cams)
             if slot is None:
@@ -216,6 +293,15 @@ class FramePipeline:
                     'radar.pack_tokens(T=%d)' % (tuple(tokens.shape), pad_mult, tuple(dst.shape),
                                                  inp['pad_mult'], inp['tokens'].shape[1]))
             dst.copy_(tokens, non_blocking=True)
+
+    def radar_overflow(self, lane):
+        """After ``wait(lane)``: True if a frame of the lane's last launch kept more radar points than the
+        captured token count holds (T - 1 + the pad row): its result is the truncated frame's, use a larger T."""
+        if self.radar_stage is None:
+            return False
+        T = int(self.inputs[lane]['tokens'].shape[1])
+        from . import radar as R
+        return bool(T < R.NUM_RADAR_TOKENS and int(self.radar_stage[lane].count.max().item()) > T - 1)
 
     def wait(self, lane):
         self.streams[lane].synchronize()
