@@ -536,7 +536,7 @@ def test_head_batch_equals_singles(T, head, nb):
     nb = 2 runs the row chains on 8-row tiles, nb = 3 on 16-row tiles (B = 1: 4 rows).
     (i) At the batch's own tile height every sample is BIT-IDENTICAL to its single run; (ii) against the
     single run at ITS automatic height (4 rows: another summation order) the rows whose radar gates made
-    the same decisions agree to 1e-4 and at most 2 queries per sample and layer decide differently."""
+    the same decisions agree to 3e-4 and at most 2 queries per sample and layer decide differently."""
     from transcar_amd import ops
     from transcar_amd.detr3d_head import head_options
     l2i = synth.make_lidar2img()
@@ -566,7 +566,7 @@ def test_head_batch_equals_singles(T, head, nb):
         ok = np.logical_and.accumulate(agree, 0)             # a flipped gate also changes the later layers' inputs
         for k in ('all_cls_scores', 'all_bbox_preds'):
             d = np.abs(own[k][:, 0].cpu().numpy() - ob[k][:, i].cpu().numpy()).max(-1)
-            assert float(d[ok].max()) < 1e-4, (k, i, float(d[ok].max()))
+            assert float(d[ok].max()) < 3e-4, (k, i, float(d[ok].max()))      # 16x16x4 vs 4x4x1 summation order, 9 layers
 
 
 def test_module_api_matches_fused_head(T, head):
