@@ -109,6 +109,8 @@ def parse(argv=None):
     ap.add_argument('--share-gpu', action='store_true',
                     help='testing on a 1-GPU box only: rank r uses GPU r %% device_count '
                          '(RCCL refuses two ranks on one GPU: use --backend gloo)')
+    ap.add_argument('--no-pin', action='store_true',
+                    help='multi-GPU: do not restrict a rank to the CPUs of the NUMA node of its GPU')
     ap.add_argument('--dry-run', action='store_true',
                     help='no GPU work: spawn / rendezvous (gloo) / rank census / the collectives of '
                          'the chosen mode on CPU tensors / the JSON line.  Runs in a CPU container')
@@ -122,6 +124,66 @@ def _free_port():
     port = s.getsockname()[1]
     s.close()
     return port
+
+
+def gpu_numa_topology(sys_root='/sys'):
+    """[(pci address, numa node)] of the AMD GPUs of this host in PCI order (the order HIP enumerates them in),
+    from /sys/class/drm/card*/device -- no GPU call, usable before torch is imported."""
+    import glob
+    gpus = {}
+    for dev in glob.glob(os.path.join(sys_root, 'class', 'drm', 'card[0-9]*', 'device')):
+        try:
+            if open(os.path.join(dev, 'vendor')).read().strip().lower() != '0x1002':
+                continue
+            if not os.path.isdir(os.path.join(dev, 'drm')):
+                continue
+            # render-capable display/compute functions only (class 0x03xxxx display, 0x12xxxx processing accelerator)
+            cls = open(os.path.join(dev, 'class')).read().strip().lower()
+            if not (cls.startswith('0x03') or cls.startswith('0x12')):
+                continue
+            addr = os.path.basename(os.path.realpath(dev))
+            gpus[addr] = int(open(os.path.join(dev, 'numa_node')).read().strip())
+        except (OSError, ValueError):
+            continue
+    return sorted(gpus.items())
+
+
+def parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        a, _, b = part.partition('-')
+        cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def pin_to_gpu_numa_node(local_rank, sys_root='/sys'):
+    """One process per GPU on a two-socket host (tools/dist_train.sh:7-9 leaves placement to the OS): restrict this
+    rank to the CPUs of the NUMA node its GPU hangs off, BEFORE torch / HIP start their threads, so that launch
+    threads, pinned staging buffers and the RCCL proxy thread live next to the GPU.  Returns what was done (for
+    the JSON line); a host without the sysfs entries, or with numa_node -1, is left alone."""
+    info = {'local_rank': int(local_rank), 'numa_node': None, 'cpus': None, 'pinned': False}
+    try:
+        topo = gpu_numa_topology(sys_root)
+        if not topo or local_rank >= len(topo):
+            info['why'] = 'no sysfs entry for GPU %d (%d AMD GPUs listed)' % (local_rank, len(topo))
+            return info
+        addr, node = topo[local_rank]
+        info.update(pci=addr, numa_node=node)
+        if node < 0:
+            info['why'] = 'numa_node -1 (single-node host or not reported)'
+            return info
+        cpus = parse_cpulist(open(os.path.join(sys_root, 'devices', 'system', 'node', 'node%d' % node, 'cpulist')).read())
+        allowed = cpus & set(os.sched_getaffinity(0))
+        if not allowed:
+            info['why'] = 'the node has no CPU this process may use'
+            return info
+        os.sched_setaffinity(0, allowed)
+        info.update(cpus=len(allowed), pinned=True)
+    except (OSError, ValueError, AttributeError) as e:
+        info['why'] = repr(e)
+    return info
 
 
 def spawn_ranks(args, argv):
@@ -770,7 +832,7 @@ def timed_windows(step, sync, args, dev, world):
         extra = min(100000, int((args.warmup_s - dt) / max(dt / args.warmup, 1e-6)) + 1)
         for _ in range(extra):
             step()
-    windows, total = [], 0.0
+    windows, own, total = [], [], 0.0
     while True:
         D.barrier()
         sync()
@@ -778,6 +840,7 @@ def timed_windows(step, sync, args, dev, world):
         for _ in range(args.steps):
             step()
         sync()
+        own.append(time.perf_counter() - t0)          # this rank alone, before it waits for the slowest one
         D.barrier()
         dt = D.max_over_ranks(time.perf_counter() - t0, cpu_or_dev)
         windows.append(dt)
@@ -787,10 +850,18 @@ def timed_windows(step, sync, args, dev, world):
     med = float(np.median(windows))
     return med, dict(windows=len(windows), warmup_steps_run=args.warmup + extra,
                      window_ms_min=min(windows) * 1e3, window_ms_median=med * 1e3,
-                     window_ms_max=max(windows) * 1e3)
+                     window_ms_max=max(windows) * 1e3, own_window_ms_median=float(np.median(own)) * 1e3)
 
 
-def train_bench(args, head, inp, dev, rank, world):
+def per_rank_summary(own_ms, steps, frames_per_step):
+    """frames/s of every rank from its OWN median window (no waiting for the slowest rank inside it):
+    the spread says whether `value` (MAX over ranks) is one slow rank or all of them."""
+    rates = [steps * frames_per_step / (ms * 1e-3) if ms > 0 else 0.0 for ms in own_ms]
+    return {'frames_per_s': rates, 'min': min(rates), 'median': float(np.median(rates)), 'max': max(rates),
+            'unit': 'frames/s', 'definition': 'steps / own median window of the rank (value uses the MAX over ranks)'}
+
+
+def train_bench(args, head, inp, dev, rank, world, affinity=None):
     """BASELINE.json configs[2]: batch-per-GPU 1 DDP training of the trainable
     (radar) part of the head.  A step = frozen decoder forward + radar stack
     forward (tc_radar_train_fwd) + Hungarian/focal/L1 loss (device kernels, scipy
@@ -820,7 +891,9 @@ def train_bench(args, head, inp, dev, rank, world):
 
     census = rank_census(dev, world)
     med, win = timed_windows(step, torch.cuda.synchronize, args, dev, world)
+    own = D.gather_floats(win['own_window_ms_median'], dev if world > 1 else None)
     line = {
+        'per_rank': per_rank_summary(own, args.steps, B), 'cpu_affinity': affinity,
         'metric': 'training frames/sec: fusion head iteration (frozen DETR3D decoder fwd + radar '
                   'stack fwd/bwd + loss + grad all-reduce + AdamW), FPN features resident in HBM',
         'value': args.steps * B * world / med, 'unit': 'frames/s', 'n_gpus': world,
@@ -863,7 +936,7 @@ def launcher_name():
         ('torch.distributed.run' if 'TORCHELASTIC_RUN_ID' in os.environ else 'single process')
 
 
-def dry_run(args):
+def dry_run(args, affinity=None):
     """CPU stand-in of a rank (no GPU anywhere): rendezvous over gloo, the rank census, and the
     collectives of the chosen mode on CPU tensors of the real sizes -- inference: barrier + MAX of
     the timing only; training: one all-reduce of the 10 MB flat gradient bucket per step."""
@@ -882,6 +955,7 @@ def dry_run(args):
             bucket.all_reduce()
 
     med, win = timed_windows(step, lambda: None, args, None, 1 if world == 1 else world)
+    own = D.gather_floats(win['own_window_ms_median'])
     ok = True
     if bucket is not None and world > 1:
         ok = bool((bucket.grads == world * (world + 1) / 2).all())
@@ -889,7 +963,9 @@ def dry_run(args):
             'unit': 'frames/s', 'n_gpus': world, 'rccl_ranks': census, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': med / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'dry_run': True, 'timing': win, 'bucket_all_reduce_ok': ok,
+            'dry_run': True, 'timing': win, 'bucket_all_reduce_ok': ok, 'cpu_affinity': affinity,
+            'per_rank': per_rank_summary(own, args.steps, 1), 'roofline': None,
+            'cpu_baseline': None,
             'config': {'workload': 'none (dry run)', 'mode': 'train' if args.train else 'inference',
                        'launcher': launcher_name(),
                        'parallelism': 'dp%d (%s)' % (world, backend_name(args)),
@@ -913,12 +989,15 @@ def main(argv=None):
     if env_world is not None and int(env_world) != args.gpus:
         print('bench.py: --gpus %d but WORLD_SIZE=%s: the launcher environment wins'
               % (args.gpus, env_world), file=sys.stderr)
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    # before torch (its thread pools inherit the mask): a rank of a multi-GPU job lives on its GPU's NUMA node
+    affinity = pin_to_gpu_numa_node(local) if (env_world is not None and int(env_world) > 1 and not args.no_pin) \
+        else {'local_rank': local, 'pinned': False, 'why': 'single rank: all host cores (cpu_baseline uses them)'}
     _imports()
     if args.unfused:
         os.environ['TRANSCAR_UNFUSED'] = '1'
     if args.dry_run:
-        return dry_run(args)
-    local = int(os.environ.get('LOCAL_RANK', 0))
+        return dry_run(args, affinity)
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs (--dry-run for the CPU launcher check)'
     if args.share_gpu:
         local %= torch.cuda.device_count()
@@ -929,7 +1008,7 @@ def main(argv=None):
     head, sd = build_head(dev)
     inp = make_inputs(head, dev, args.shapes, args.batch, seed=1 + rank)
     if args.train:
-        return train_bench(args, head, inp, dev, rank, world)
+        return train_bench(args, head, inp, dev, rank, world, affinity)
 
     pipe, pair = None, 1
     if not args.no_graph:
@@ -964,7 +1043,9 @@ def main(argv=None):
 
     census = rank_census(dev, world)
     med, win = timed_windows(step, sync, args, dev, world)
+    own = D.gather_floats(win['own_window_ms_median'], dev if world > 1 else None)
     frames = args.steps * args.batch * world
+    in_flight = 1 if pipe is None else min(pipe.lanes * pipe.frames_per_launch, args.steps * args.batch)
     line = {
         'metric': 'nuScenes frames/sec (6-cam+radar, 900 queries): fusion decoder '
                   '(Detr3DHead.forward + box decode), FPN features resident in HBM',
@@ -983,6 +1064,8 @@ def main(argv=None):
         'dtype': 'f32',
         'data': 'synthetic',
         'timing': win,
+        'per_rank': per_rank_summary(own, args.steps, args.batch),
+        'cpu_affinity': affinity,
         'config': {'workload': 'BASELINE.json configs[1]: synthetic 6 cameras, ResNet-101 FPN '
                                'levels %s x 256 ch (fp32, channels-last), 900 queries, 255 radar '
                                'points, %d frame(s)/step/GPU, %dxMI355X inference'
@@ -990,7 +1073,8 @@ def main(argv=None):
                    'shapes': args.shapes, 'frames_per_step_per_gpu': args.batch,
                    'launch': 'eager' if pipe is None else 'hipGraph replay',
                    'frames_per_launch': 1 if pipe is None else pipe.frames_per_launch,
-                   'frames_in_flight': 1 if pipe is None else pipe.lanes * pipe.frames_per_launch,
+                   # a window of K steps never has more than K frames in flight
+                   'frames_in_flight': in_flight,
                    'chain_tile_rows': args.tile_rows or 'auto',
                    'last_level_cls_only': bool(args.last_cls_only),
                    'launcher': launcher_name(),
@@ -1026,8 +1110,11 @@ def main(argv=None):
             if args.batch == 1 and not args.no_batched and pipe is not None:
                 line['frames_per_launch_sweep'] = sweep_side_run(head, dev, args, pipe.frames_per_launch,
                                                                  streams=pipe.streams)
-            if not args.no_cpu_baseline:
-                line['cpu_baseline'] = cpu_baseline(sd, inp, args.cpu_seconds)
+        # the reported CPU baseline (the oracle on this host's cores): in the line at every world size, so that
+        # the N = 1 point of a scaling run and the plain bench line have one schema.  A rank of a multi-GPU job
+        # is pinned to its GPU's NUMA node: `usable_cores` says what the baseline could use.
+        if not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(sd, inp, args.cpu_seconds)
         print(json.dumps(line), flush=True)
     D.barrier()
     if world > 1:

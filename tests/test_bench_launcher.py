@@ -80,3 +80,59 @@ def test_automatic_frames_per_launch_keeps_every_tile_resident():
     for q in range(100, 3000, 37):
         p = rfl(q, num_cus=256)
         assert p >= 1 and (p == 1 or -(-p * q // 16) <= 512)
+
+
+CONTRACT = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+            'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'per_rank', 'cpu_affinity',
+            'rccl_ranks', 'timing')
+
+
+def test_every_world_size_prints_one_schema():
+    """The N = 1 point of the driver's scaling run and the plain bench line must be comparable: the single
+    process, `--gpus 2` (bench.py's own launcher) and torch.distributed.run all print the contract's keys plus
+    `per_rank` (frames/s of each rank from its own windows: min / median / max) and `cpu_affinity`."""
+    one = _run([sys.executable, 'bench.py'] + FAST)
+    two = _run([sys.executable, 'bench.py', '--gpus', '2'] + FAST)
+    for line in (one, two):
+        for k in CONTRACT:
+            assert k in line, k
+    assert set(one) == set(two)
+    assert len(one['per_rank']['frames_per_s']) == 1 and len(two['per_rank']['frames_per_s']) == 2
+    assert two['per_rank']['min'] <= two['per_rank']['median'] <= two['per_rank']['max']
+    assert one['cpu_affinity']['pinned'] is False            # a single rank keeps every core (cpu_baseline)
+
+
+def test_rank_is_pinned_to_the_numa_node_of_its_gpu(tmp_path):
+    """pin_to_gpu_numa_node reads /sys only (no GPU call: it runs before torch is imported): GPU i = the i-th AMD
+    display / accelerator function in PCI order; its numa_node's cpulist becomes the rank's affinity mask."""
+    import bench
+    sysr = tmp_path / 'sys'
+    mine = sorted(os.sched_getaffinity(0))
+    half = max(1, len(mine) // 2)
+    nodes = {0: mine[:half], 1: mine[half:] or mine[:half]}
+    for n, cpus in nodes.items():
+        d = sysr / 'devices' / 'system' / 'node' / ('node%d' % n)
+        d.mkdir(parents=True)
+        (d / 'cpulist').write_text(','.join(str(c) for c in cpus) + '\n')
+    pci = sysr / 'devices' / 'pci'
+    for i, (addr, vendor, cls, node) in enumerate([('0000:05:00.0', '0x1002', '0x120000', 0),
+                                                   ('0000:85:00.0', '0x1002', '0x120000', 1),
+                                                   ('0000:03:00.0', '0x1a03', '0x030000', 0)]):      # a BMC VGA: skipped
+        dev = pci / addr
+        (dev / 'drm').mkdir(parents=True)
+        (dev / 'vendor').write_text(vendor + '\n')
+        (dev / 'class').write_text(cls + '\n')
+        (dev / 'numa_node').write_text('%d\n' % node)
+        card = sysr / 'class' / 'drm' / ('card%d' % i)
+        card.mkdir(parents=True)
+        (card / 'device').symlink_to(dev, target_is_directory=True)
+    assert bench.gpu_numa_topology(str(sysr)) == [('0000:05:00.0', 0), ('0000:85:00.0', 1)]
+    assert bench.parse_cpulist('0-3,8,10-11') == {0, 1, 2, 3, 8, 10, 11}
+    before = os.sched_getaffinity(0)
+    try:
+        info = bench.pin_to_gpu_numa_node(1, str(sysr))
+        assert info['pinned'] and info['numa_node'] == 1 and info['pci'] == '0000:85:00.0'
+        assert os.sched_getaffinity(0) == set(nodes[1])
+    finally:
+        os.sched_setaffinity(0, before)
+    assert bench.pin_to_gpu_numa_node(5, str(sysr))['pinned'] is False      # no such GPU: left alone

@@ -14,6 +14,16 @@ import torch
 import torch.distributed as dist
 
 
+def gather_floats(value, device=None):
+    """A python float of every rank -> list ordered by rank (on every rank)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [float(value)]
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else 'cpu')
+    parts = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    return [float(p.item()) for p in parts]
+
+
 def env_rank_world():
     return int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
 
