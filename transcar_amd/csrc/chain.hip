@@ -1323,6 +1323,14 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
         // the tokens' xy once per wave when they fit four words (T <= 256, the packed default; a tile's
         // rows are one sample's, two at a sample boundary); masks are kept up to 64 * HM_WORDS tokens
         constexpr int GW = 4;
+        // the per-row constants of the gate (expf, clamp, sqrt_threshold: ~300 instructions) once per row, one
+        // thread each, into the spare columns of the row's box / centre records (code <= 10 of 12, 3 of 4)
+        if (threadIdx.x < R) {
+          const int i = threadIdx.x;
+          const GateGeom::Pre pp = GateGeom::precompute(S.box[i][3], S.box[i][6], S.box[i][7], k.rmin[rep], k.rmax[rep]);
+          S.box[i][10] = pp.ox; S.box[i][11] = pp.oy; S.cen[i][3] = pp.tstar;
+        }
+        __syncthreads();
         const bool keep = k.T <= 64 * HM_WORDS, cached = k.T <= 64 * GW;
         const int b0 = S.rowg[wave] / k.Q;
         float ty0[GW], ty1[GW];
@@ -1340,8 +1348,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
           const int b = grow / k.Q;
           int count = 0;
           if (cached && b == b0) {
-            const GateGeom gg(S.cen[row][0], S.cen[row][1], S.box[row][3], S.box[row][6], S.box[row][7],
-                              k.rmin[rep], k.rmax[rep]);
+            const GateGeom gg(S.cen[row][0], S.cen[row][1], GateGeom::Pre{S.box[row][10], S.box[row][11], S.cen[row][3]});
 #pragma unroll
             for (int w = 0; w < GW; ++w) {
               if (64 * w < k.T) {                            // wave-uniform
@@ -1373,8 +1380,8 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
           const float4 q4 = *reinterpret_cast<const float4*>(buf_ptr(S, r.src) + row * LD2 + 4 * lane);
           const float* kv = (rep == 0 ? k.g[G_KV0] : rep == 1 ? k.g[G_KV1] : k.g[G_KV2]);
           int count = 0;
-          const float4 o = radar_attn_row(S.cen[row][0], S.cen[row][1], S.box[row][3], S.box[row][6],
-                                          S.box[row][7], k.rmin[rep], k.rmax[rep], q4,
+          const GateGeom gg(S.cen[row][0], S.cen[row][1], GateGeom::Pre{S.box[row][10], S.box[row][11], S.cen[row][3]});
+          const float4 o = radar_attn_row_g(gg, q4,
                                           k.tokens + (size_t)b * k.T * k.RI, k.RI,
                                           kv + (size_t)b * k.T * 512, 512, k.T, k.pad_mult, lane, count, DropK(), 0,
                                           k.T <= 64 * HM_WORDS ? reinterpret_cast<const unsigned long long*>(&S.l[row][0]) : nullptr);
@@ -1739,7 +1746,8 @@ int launch_decoder_chain_with_encoders(const DecoderChainArgs& d, const RadarEnc
 }
 
 int launch_radar_chain(const RadarChainArgs& a, hipStream_t s) {
-  TC_REQUIRE(a.code <= 12 && a.ncls <= 32, "radar_chain: code=%d ncls=%d", a.code, a.ncls);
+  // code <= 10: columns 10, 11 of a row's box record carry the gate's precomputed offsets (K_RADAR_GATE)
+  TC_REQUIRE(a.code <= 10 && a.ncls <= 32, "radar_chain: code=%d ncls=%d", a.code, a.ncls);
   TC_REQUIRE(a.nlayers >= 1 && a.nlayers <= TC_MAX_RADAR_LAYERS, "radar_chain: nlayers=%d", a.nlayers);
   ChainK k;
   init_k(k);

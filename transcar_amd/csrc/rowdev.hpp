@@ -253,6 +253,26 @@ struct GateGeom {
     cn = sqnorm2(cx, cy); fn = sqnorm2(fx, fy); bn = sqnorm2(bx, by);
     tstar = sqrt_threshold(rad);
   }
+  // The expensive part of the constructor above (expf, the clamp, sqrt_threshold's square roots: ~300
+  // instructions that every lane of every wave repeated per row) evaluated ONCE per row by one thread:
+  // (ox, oy, tstar) = Pre; the remaining adds and norms are the same operations in the same order.
+  struct Pre { float ox, oy, tstar; };
+  static __device__ __forceinline__ Pre precompute(float b3, float b6, float b7, float rmin, float rmax) {
+    const float len = expf(b3);
+    const float rs = -b6, rc = -b7;
+    Pre p;
+    p.ox = __fmul_rn(__fmul_rn(len, 0.25f), rs); p.oy = __fmul_rn(__fmul_rn(len, 0.25f), rc);
+    p.tstar = sqrt_threshold(fminf(fmaxf(len / 2.0f, rmin), rmax));
+    return p;
+  }
+  __device__ __forceinline__ GateGeom(float cx_, float cy_, const Pre& p) {
+    cx = cx_; cy = cy_;
+    fx = __fadd_rn(cx, p.ox); fy = __fadd_rn(cy, p.oy);
+    bx = __fsub_rn(cx, p.ox); by = __fsub_rn(cy, p.oy);
+    rad = 0.0f;                    // hit() does not use it
+    cn = sqnorm2(cx, cy); fn = sqnorm2(fx, fy); bn = sqnorm2(bx, by);
+    tstar = p.tstar;
+  }
   // (cdist < rad) for any of the three circles, HEAD:568-571 -- on the squared distances against tstar
   __device__ __forceinline__ bool hit(float y0, float y1, float yn) const {
     const float tc_ = fmaxf(cdist_sq(cx, cy, cn, y0, y1, yn), 1e-30f), tf = fmaxf(cdist_sq(fx, fy, fn, y0, y1, yn), 1e-30f),
@@ -299,15 +319,13 @@ __device__ __forceinline__ int radar_gate_count(float cx, float cy, float b3, fl
 }
 
 template <bool DROP = false>
-__device__ __forceinline__ float4 radar_attn_row(float cx, float cy, float b3, float b6, float b7,
-                                                 float rmin, float rmax, float4 q4,
-                                                 const float* rxy, int ld_xy, const float* kv,
-                                                 int ldkv, int T, int pad_mult, int lane, int& count,
-                                                 DropK drop = DropK(), int row = 0,
-                                                 const unsigned long long* hit_masks = nullptr) {
+__device__ __forceinline__ float4 radar_attn_row_g(const GateGeom& gg, float4 q4,
+                                                   const float* rxy, int ld_xy, const float* kv,
+                                                   int ldkv, int T, int pad_mult, int lane, int& count,
+                                                   DropK drop = DropK(), int row = 0,
+                                                   const unsigned long long* hit_masks = nullptr) {
   // hit_masks (chain.hip, K_RADAR_GATE): the gate of this row already evaluated, one 64-token word per
   // chunk -- the same predicate, so the same tokens
-  const GateGeom gg(cx, cy, b3, b6, b7, rmin, rmax);
   float m = -INFINITY, l = 0.0f;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   count = 0;
@@ -357,6 +375,17 @@ __device__ __forceinline__ float4 radar_attn_row(float cx, float cy, float b3, f
     return make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
   }
   return make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+template <bool DROP = false>
+__device__ __forceinline__ float4 radar_attn_row(float cx, float cy, float b3, float b6, float b7,
+                                                 float rmin, float rmax, float4 q4,
+                                                 const float* rxy, int ld_xy, const float* kv,
+                                                 int ldkv, int T, int pad_mult, int lane, int& count,
+                                                 DropK drop = DropK(), int row = 0,
+                                                 const unsigned long long* hit_masks = nullptr) {
+  const GateGeom gg(cx, cy, b3, b6, b7, rmin, rmax);
+  return radar_attn_row_g<DROP>(gg, q4, rxy, ld_xy, kv, ldkv, T, pad_mult, lane, count, drop, row, hit_masks);
 }
 
 }  // namespace tc
