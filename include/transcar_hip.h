@@ -370,6 +370,10 @@ int tc_head_pack_weights(const tc_head_weights* w, void* packed, size_t packed_b
  * packed buffer; the frozen decoder's weights and the layer-0 constants stay. */
 int tc_head_repack_trainable(const tc_head_weights* w, tc_head_weights* packed_view,
                              tc_stream_t stream);
+/* The same with a choice of copies: 1 = only the 4x4x1 layout (what the 4- and 8-row chains of a training
+ * iteration read, tc_radar_train_fwd_fused), 3 = both layouts.  One launch for all trainable weights. */
+int tc_head_repack_trainable_ex(const tc_head_weights* w, tc_head_weights* packed_view, int copies,
+                                tc_stream_t stream);
 /* packed_view == NULL selects the operator-by-operator launch sequence (~160
  * launches instead of 16); results agree to fp32 rounding. */
 int tc_head_forward(const tc_head_weights* w, const tc_head_weights* packed_view,
@@ -490,6 +494,16 @@ int tc_radar_train_fwd(const tc_head_weights* w, const float* hs_last, const flo
                        const float* last_box, const float* radar_tokens, int B, int T, int pad_mult,
                        float* all_cls_scores, float* all_bbox_preds, void* tape, size_t tape_bytes,
                        float dropout_p, unsigned long long dropout_seed, tc_stream_t stream);
+/* tc_radar_train_fwd as launches of the fused row chains: ONE launch for the encoders + K|V (token rows), ONE for
+ * the three fusion layers (query rows; the dropout sites in the epilogues / the attention core, every tape tensor
+ * stored as it is produced) + the reference set-up.  Same tape, same outputs (to fp32 rounding of the different
+ * summation order), same (seed, site, index) dropout masks: tc_radar_train_bwd takes either tape.
+ * `packed_view`: the head's packed weights holding the CURRENT parameters (after an optimizer step:
+ * tc_head_repack_trainable_ex(w, view, 1, stream), one launch).  Replaces HEAD:531-729 in train mode. */
+int tc_radar_train_fwd_fused(const tc_head_weights* packed_view, const float* hs_last, const float* ref_last,
+                             const float* last_box, const float* radar_tokens, int B, int T, int pad_mult,
+                             float* all_cls_scores, float* all_bbox_preds, void* tape, size_t tape_bytes,
+                             float dropout_p, unsigned long long dropout_seed, tc_stream_t stream);
 int tc_radar_train_bwd(const tc_head_weights* w, const tc_head_weights* grads, const float* hs_last,
                        const float* last_box, const float* radar_tokens, int B, int T, int pad_mult,
                        const float* all_bbox_preds, const float* d_all_cls, const float* d_all_box,

@@ -659,3 +659,30 @@ def test_optimizer_step_defers_the_repack_to_the_next_inference_consumer(A, gold
         fresh = h.forward_nhwc(nhwc, l2i, img_hw, tokens, pad_mult)['all_cls_scores']
         torch.cuda.synchronize()
     assert torch.equal(fresh, after)
+
+
+@pytest.mark.parametrize('tag', ['tiny', 'res101'])
+def test_chain_forward_equals_operator_forward_with_dropout(A, golden_dir, tag):
+    """tc_radar_train_fwd_fused (the stack's forward as launches of the fused row chains, the tape stored as it
+    is produced) against tc_radar_train_fwd (one launch per operator) with the SAME dropout masks (p = 0.1, same
+    seed): same outputs, same losses, and -- through the one backward both tapes feed -- the same gradients."""
+    from transcar_amd import ops
+    from transcar_amd.trainer import FusionTrainer
+    h = train_head(golden_dir)
+    feats, metas, gt, labels = frame_inputs(golden_dir, tag)
+    nhwc = [ops.to_nhwc(f) for f in feats]
+    l2i = ops.lidar2img_tensor(metas, dev())
+    img_hw = metas[0]['img_shape'][0][:2]
+    tokens, pad_mult = h.radar_tokens(metas, dev())
+    tr = FusionTrainer(h, dropout=0.1, seed=7, decoder_dropout=0.0)
+    res = {}
+    for chain in (True, False):
+        tr.chain_forward = chain
+        h._train_forwards = 11                                   # same forward counter: same masks
+        losses = tr.step_fused_nhwc(nhwc, l2i, img_hw, tokens, pad_mult, [gt], [labels], update=False)
+        res[chain] = ({k: float(v) for k, v in losses.items()}, tr.bucket.grads.clone(), tr.last_dropout_seed)
+    assert res[True][2] == res[False][2]
+    for k, v in res[False][0].items():
+        assert abs(res[True][0][k] - v) < 2e-4 * max(1.0, abs(v)), (k, res[True][0][k], v)
+    d = (res[True][1] - res[False][1]).abs().max() / res[False][1].abs().max()
+    assert float(d) < 5e-4, float(d)

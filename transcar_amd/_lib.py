@@ -190,6 +190,9 @@ SIGNATURES = {
     'tc_radar_train_tape_bytes': (_sz, [_P(tc_head_weights), _i, _i]),
     'tc_radar_train_fwd': (_i, [_P(tc_head_weights), _vp, _vp, _vp, _vp, _i, _i,
                                 _i, _vp, _vp, _vp, _sz, _f, C.c_ulonglong, _vp]),
+    'tc_radar_train_fwd_fused': (_i, [_P(tc_head_weights), _vp, _vp, _vp, _vp, _i, _i,
+                                      _i, _vp, _vp, _vp, _sz, _f, C.c_ulonglong, _vp]),
+    'tc_head_repack_trainable_ex': (_i, [_P(tc_head_weights), _P(tc_head_weights), _i, _vp]),
     'tc_radar_train_bwd': (_i, [_P(tc_head_weights), _P(tc_head_weights), _vp,
                                 _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz,
                                 _f, C.c_ulonglong, _vp]),

@@ -151,8 +151,10 @@ enum Flags : short {
                       //   then runs BESIDE the preceding narrow step, which keeps wave 0 busy
   F_NOT_W0 = 64,      // posenc: rows go to waves 1..3 only (wave 0 is in a narrow linear step)
   F_LN_XP = 128,      // ln: also write (result + query_pos row) into the buffer named by `res`
-  F_IFHIT = 256       // radar: the step only matters for rows with a radar hit -- skipped when no row of the
+  F_IFHIT = 256,      // radar: the step only matters for rows with a radar hit -- skipped when no row of the
                       //   tile has one (a linear step then copies `res` to `dst`: x + gate * (...) = x)
+  F_GPRE = 512        // linear: the global store happens BEFORE the residual add (training tape: the FFN output
+                      //   rf_dropout3(linear2(.)) itself, not x + it)
 };
 // global tensors, indices into ChainK::g
 enum GSel : short {
@@ -256,7 +258,24 @@ constexpr StepDesc PROG_RADAR_LAYER_T[] = {
     {K_BOXADD, 0, 0, 0, 0, B_L, B_NONE, B_NONE, B_NONE, 0, 0, G_NONE, G_NONE, 1},
     {K_END, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
 
-enum Program : int { PROG_PROLOGUE = 0, PROG_DECODER, PROG_RADAR_ENC, PROG_RADAR, PROG_RADAR_ENC_A, PROG_RADAR_ENC_B };
+// PROG_RADAR_TRAIN / PROG_RADAR_ENC_TRAIN: the same step tables as PROG_RADAR / PROG_RADAR_ENC run as the
+// FORWARD OF A TRAINING ITERATION (tc_radar_train_fwd_fused): every activation the backward needs is stored on
+// the tape as it is produced (the steps' global destinations), the four dropout sites of a fusion layer are
+// applied in the epilogues / the attention core (counter-based masks), no step is skipped for hit-free tiles
+// (the tape must be complete) and q stays unscaled on the tape (the attention core scales it).
+enum Program : int { PROG_PROLOGUE = 0, PROG_DECODER, PROG_RADAR_ENC, PROG_RADAR, PROG_RADAR_ENC_A, PROG_RADAR_ENC_B,
+                     PROG_RADAR_TRAIN, PROG_RADAR_ENC_TRAIN };
+constexpr bool prog_is_radar(int p) { return p == PROG_RADAR || p == PROG_RADAR_TRAIN; }
+constexpr bool prog_is_enc_full(int p) { return p == PROG_RADAR_ENC || p == PROG_RADAR_ENC_TRAIN; }
+// tape tensors of a fusion layer (layer r: base + r * tape_stride floats) ...
+enum TSel : short { T_NONE = -1, T_QP = 0, T_AO, T_X1, T_X2, T_H, T_FF, T_X3, T_C0, T_C1, T_C2, T_C3, T_T0, T_T1, T_TREG,
+                    // ... and of the encoders
+                    E_U0, E_U1, E_U2, E_POS, E_F0, E_F1, E_F2, E_MEM, T_COUNT };
+// tape tensor written by step `si` of the radar layer table / the encoder table (second: a step's other output)
+constexpr short RADAR_TAPE[17] = {T_NONE, T_QP, T_AO, T_X1, T_X2, T_H, T_FF, T_X3, T_C0, T_T0, T_C1, T_T1, T_C2, T_C3,
+                                  T_TREG, T_NONE, T_NONE};
+constexpr short ENC_TAPE[10] = {T_NONE, E_U1, E_F0, E_U2, E_F1, E_F2, E_MEM, T_NONE, T_NONE, T_NONE};
+constexpr short ENC_TAPE2[10] = {T_NONE, E_U0, T_NONE, T_NONE, T_NONE, T_NONE, E_POS, T_NONE, T_NONE, T_NONE};
 constexpr int MAX_PAIRS = 48;
 constexpr int RADAR_PAIRS = 14;
 
@@ -280,6 +299,9 @@ struct ChainDev {
   float rmin[TC_MAX_RADAR_LAYERS], rmax[TC_MAX_RADAR_LAYERS];
   float* all_box; int* hits;
   const int* row_perm;         // radar: optional row order (launch_radar_compact), rows stay in their sample
+  // training forward (PROG_RADAR_TRAIN / PROG_RADAR_ENC_TRAIN)
+  float* tape[T_COUNT]; size_t tape_stride; size_t hits_stride;   // hits of layer r at hits + r * hits_stride (0: M)
+  DropK rdrop;                 // radar dropout: seed / thr / scale / tokens_ref (site = 4 * layer + {0..3})
 };
 // ... plus what only the host-side resolver needs
 struct ChainK : ChainDev {
@@ -290,16 +312,18 @@ struct ChainK : ChainDev {
 constexpr int table_steps(int prog) {
   return (prog == PROG_DECODER ? (int)(sizeof(PROG_DECODER_T) / sizeof(StepDesc))
           : prog == PROG_PROLOGUE ? (int)(sizeof(PROG_PROLOGUE_T) / sizeof(StepDesc))
-          : prog == PROG_RADAR_ENC ? (int)(sizeof(PROG_RADAR_ENC_T) / sizeof(StepDesc))
+          : prog_is_enc_full(prog) ? (int)(sizeof(PROG_RADAR_ENC_T) / sizeof(StepDesc))
           : prog == PROG_RADAR_ENC_A ? (int)(sizeof(PROG_RADAR_ENC_A_T) / sizeof(StepDesc))
           : prog == PROG_RADAR_ENC_B ? (int)(sizeof(PROG_RADAR_ENC_B_T) / sizeof(StepDesc))
                                      : (int)(sizeof(PROG_RADAR_LAYER_T) / sizeof(StepDesc))) - 1;
 }
-constexpr int rec_cap(int prog) { return table_steps(prog) * (prog == PROG_RADAR ? TC_MAX_RADAR_LAYERS : 1); }
+constexpr int rec_cap(int prog) { return table_steps(prog) * (prog_is_radar(prog) ? TC_MAX_RADAR_LAYERS : 1); }
+static_assert(sizeof(RADAR_TAPE) / sizeof(short) == table_steps(PROG_RADAR) && sizeof(ENC_TAPE) / sizeof(short) == table_steps(PROG_RADAR_ENC),
+              "tape maps follow the step tables");
 inline const StepDesc* prog_table(int prog) {
   return prog == PROG_DECODER ? PROG_DECODER_T
          : prog == PROG_PROLOGUE ? PROG_PROLOGUE_T
-         : prog == PROG_RADAR_ENC ? PROG_RADAR_ENC_T
+         : prog_is_enc_full(prog) ? PROG_RADAR_ENC_T
          : prog == PROG_RADAR_ENC_A ? PROG_RADAR_ENC_A_T
          : prog == PROG_RADAR_ENC_B ? PROG_RADAR_ENC_B_T : PROG_RADAR_LAYER_T;
 }
@@ -322,6 +346,7 @@ struct LinSpec {
   int drop_site;               // DROP instantiations: site + 1 of this step's output dropout (0: none)
   unsigned long long drop_seed; unsigned drop_thr; float drop_scale;
   const int* rowg;             // radar: LDS table tile position -> global row for the gdst stores (null: m0 + i)
+  int gpre;                    // F_GPRE
 };
 
 // One work item = (64-column output tile, 64-deep k block): 16 x 16-byte weight
@@ -449,6 +474,16 @@ __device__ __forceinline__ void lin_epilogue(const LinSpec& s, int tile, const A
         }
     }
   }
+  // F_GPRE (training tape): the value that goes to global memory is the one BEFORE the residual add (kept in
+  // registers; a second global-store site in this function trips a hipcc back-end error)
+  // -- only in the DROP instantiations (the training programs): the inference kernels are unchanged
+  float yp[NG][4];
+  if constexpr (DROP) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) yp[g][i] = y[g][i];
+  }
   if (s.res != nullptr) {
     float rr[NG][4];
 #pragma unroll
@@ -473,7 +508,9 @@ __device__ __forceinline__ void lin_epilogue(const LinSpec& s, int tile, const A
       for (int i = 0; i < 4; ++i)
         if (s.m0 + 4 * g + i < s.M) {
           const int grow = s.rowg != nullptr ? s.rowg[4 * g + i] : s.m0 + 4 * g + i;
-          stg1(s.gdst + (size_t)grow * s.gdst_ld + col, y[g][i]);
+          float v = y[g][i];
+          if constexpr (DROP) { if (s.gpre) v = yp[g][i]; }
+          stg1(s.gdst + (size_t)grow * s.gdst_ld + col, v);
         }
   }
   if (s.gt != nullptr) {
@@ -959,7 +996,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
   }
   START_STAMP(43);
 
-  if (PROG == PROG_RADAR) {     // HEAD:539, 543-547, 596-598
+  if (prog_is_radar(PROG)) {     // HEAD:539, 543-547, 596-598
     // tile position -> row: the identity, or the order of launch_radar_compact (hit rows first)
     auto row_of = [&](int row) {
       const int pos = min(m0 + row, M - 1);
@@ -1038,6 +1075,9 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
     for (int i = 0; i < NR; ++i) {
       const int row = wave + CH_NW * i;
       if (r.flags & F_LN_RELU) v[i] = relu4(v[i]);
+      if constexpr (PROG == PROG_RADAR_ENC_TRAIN) {      // tape: pos = relu(LN(u2)) before the feature sum
+        if (r.gt != nullptr && m0 + row < M) st4(r.gt + (size_t)(m0 + row) * 256 + 4 * lane, v[i]);
+      }
       if (dd != nullptr) v[i] = add4(v[i], *reinterpret_cast<const float4*>(dd + row * LD2 + 4 * lane));
       *reinterpret_cast<float4*>(dst + row * LD2 + 4 * lane) = v[i];
       if (xp) *reinterpret_cast<float4*>(dst2 + row * LD2 + 4 * lane) = add4(v[i], pos4[i]);
@@ -1060,7 +1100,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
     s.dbg = k.dbg;
     s.sub_on = 0;
     s.drop_site = 0; s.drop_seed = 0; s.drop_thr = 0; s.drop_scale = 1.0f;
-    s.rowg = nullptr;
+    s.rowg = nullptr; s.gpre = 0;
     return s;
   };
   // ... and the part its epilogue needs, rebuilt per tile from the 64-byte LDS record
@@ -1083,9 +1123,14 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
     s.dbg = 0;
     s.sub_on = 0;
     s.drop_site = 0; s.drop_seed = 0; s.drop_thr = 0; s.drop_scale = 1.0f;
-    s.rowg = (PROG == PROG_RADAR && k.row_perm != nullptr) ? &S.rowg[0] : nullptr;
+    s.rowg = (prog_is_radar(PROG) && k.row_perm != nullptr) ? &S.rowg[0] : nullptr;
+    s.gpre = (e.flags & F_GPRE) ? 1 : 0;
     if (DROP) {
-      s.drop_site = e.drop_site; s.drop_seed = k.drop.seed; s.drop_thr = k.drop.thr; s.drop_scale = k.drop.scale;
+      if constexpr (PROG == PROG_RADAR_TRAIN) {      // radar dropout sites 4 r + {1, 2, 3} (HEAD:581-585)
+        s.drop_site = e.drop_site; s.drop_seed = k.rdrop.seed; s.drop_thr = k.rdrop.thr; s.drop_scale = k.rdrop.scale;
+      } else {
+        s.drop_site = e.drop_site; s.drop_seed = k.drop.seed; s.drop_thr = k.drop.thr; s.drop_scale = k.drop.scale;
+      }
     }
     return s;
   };
@@ -1114,7 +1159,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
         const StepRes r = load_uniform<StepRes>(S.recs[idx].r);
         const int kd = r.kind;
         bool skip = false;
-        if constexpr (PROG == PROG_RADAR) {
+        if constexpr (PROG == PROG_RADAR) {           // (the training forward skips nothing: the tape must be complete)
           if (kd == K_LINEAR && (r.flags & F_IFHIT)) skip = !tile_has_hit();
         }
         if (skip) {
@@ -1193,7 +1238,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
         continue;
       }
       } break;
-      case K_TOKENS: { if constexpr (PROG == PROG_RADAR_ENC || PROG == PROG_RADAR_ENC_A) {   // radar token tile, zero padded to 64 columns
+      case K_TOKENS: { if constexpr (prog_is_enc_full(PROG) || PROG == PROG_RADAR_ENC_A) {   // radar token tile, zero padded to 64 columns
         for (int i = threadIdx.x; i < R * 64; i += CH_NT) {
           const int row = i >> 6, c = i & 63;
           const int grow = min(m0 + row, M - 1);
@@ -1201,7 +1246,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
         }
       } break;
       } break;
-      case K_POSENC: { if constexpr (PROG == PROG_DECODER || PROG == PROG_RADAR_ENC || PROG == PROG_RADAR_ENC_A) {   // Linear(3,256) + LN + ReLU of inverse_sigmoid(ref) or of raw token xyz
+      case K_POSENC: { if constexpr (PROG == PROG_DECODER || prog_is_enc_full(PROG) || PROG == PROG_RADAR_ENC_A) {   // Linear(3,256) + LN + ReLU of inverse_sigmoid(ref) or of raw token xyz
         float* dst = buf_ptr(S, r.dst);
         const bool skip0 = (r.flags & F_NOT_W0) != 0;      // wave 0 is busy with the narrow linear step before
         const int row_first = skip0 ? wave - 1 : wave, row_step = skip0 ? CH_NW - 1 : CH_NW;
@@ -1215,8 +1260,19 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
             p1 = inverse_sigmoidf_(k.ref_in[(size_t)grow * 3 + 1]);
             p2 = inverse_sigmoidf_(k.ref_in[(size_t)grow * 3 + 2]);
           }
-          *reinterpret_cast<float4*>(dst + row * LD2 + 4 * lane) =
-              posenc_l0_row(p0, p1, p2, uptr(r.p0), uptr(r.p1), uptr(r.p2), uptr(r.p3), lane);
+          if constexpr (PROG == PROG_RADAR_ENC_TRAIN) {
+            // tape: the pre-LayerNorm values u0 (r.gt) and u1 = relu(LN(u0)) (r.gd)
+            float4 pre;
+            const float4 u1 = posenc_l0_row(p0, p1, p2, uptr(r.p0), uptr(r.p1), uptr(r.p2), uptr(r.p3), lane, &pre);
+            *reinterpret_cast<float4*>(dst + row * LD2 + 4 * lane) = u1;
+            if (m0 + row < M) {
+              st4(r.gt + (size_t)(m0 + row) * 256 + 4 * lane, pre);
+              st4(r.gd + (size_t)(m0 + row) * 256 + 4 * lane, u1);
+            }
+          } else {
+            *reinterpret_cast<float4*>(dst + row * LD2 + 4 * lane) =
+                posenc_l0_row(p0, p1, p2, uptr(r.p0), uptr(r.p1), uptr(r.p2), uptr(r.p3), lane);
+          }
         }
       } break;
       } break;
@@ -1257,7 +1313,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
         }
       } break;
       } break;
-      case K_NARROW: { if constexpr (PROG == PROG_DECODER || PROG == PROG_RADAR) {
+      case K_NARROW: { if constexpr (PROG == PROG_DECODER || prog_is_radar(PROG)) {
         // The 10-column heads (reg.4, final_reg.4, final_cls.6): as a 64-column tile of the item loop they
         // kept ONE wave busy for four items (13 000 cycles at 16 rows) while three waited at the barrier.
         // Here: ONE 16-column MFMA sub-tile, the 16 k groups of 16 split over the four waves (16
@@ -1311,7 +1367,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
               const int row = 4 * g + i;
               if (row < R && m0 + row < M) {
                 int grow = m0 + row;
-                if constexpr (PROG == PROG_RADAR) grow = S.rowg[row];
+                if constexpr (prog_is_radar(PROG)) grow = S.rowg[row];
                 stg1(r.gd + (size_t)grow * r.gld + c, y[i]);
               }
             }
@@ -1319,7 +1375,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
         }
       } break;
       } break;
-      case K_RADAR_GATE: { if constexpr (PROG == PROG_RADAR) {   // the gate of HEAD:549-567 alone: hit counts + masks
+      case K_RADAR_GATE: { if constexpr (prog_is_radar(PROG)) {   // the gate of HEAD:549-567 alone: hit counts + masks
         // the tokens' xy once per wave when they fit four words (T <= 256, the packed default; a tile's
         // rows are one sample's, two at a sample boundary); masks are kept up to 64 * HM_WORDS tokens
         constexpr int GW = 4;
@@ -1366,31 +1422,42 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
           }
           if (lane == 0) {
             S.gate[row] = count;
-            if (m0 + row < M) k.hits[(size_t)rep * M + grow] = count;
+            if (m0 + row < M) k.hits[(size_t)rep * (k.hits_stride ? k.hits_stride : (size_t)M) + grow] = count;
           }
         }
       } break;
       } break;
-      case K_RADAR_ATTN: { if constexpr (PROG == PROG_RADAR) {   // distance-gated attention (HEAD:549-579)
-        if ((r.flags & F_IFHIT) && !tile_has_hit()) break;      // its output only feeds the (skipped) out_proj
+      case K_RADAR_ATTN: { if constexpr (prog_is_radar(PROG)) {   // distance-gated attention (HEAD:549-579)
+        if (PROG == PROG_RADAR && (r.flags & F_IFHIT) && !tile_has_hit()) break;      // its output only feeds the (skipped) out_proj
 #pragma unroll 1
         for (int row = wave; row < R; row += CH_NW) {
           const int grow = S.rowg[row];
           const int b = grow / k.Q;
-          const float4 q4 = *reinterpret_cast<const float4*>(buf_ptr(S, r.src) + row * LD2 + 4 * lane);
+          float4 q4 = *reinterpret_cast<const float4*>(buf_ptr(S, r.src) + row * LD2 + 4 * lane);
           const float* kv = (rep == 0 ? k.g[G_KV0] : rep == 1 ? k.g[G_KV1] : k.g[G_KV2]);
           int count = 0;
           const GateGeom gg(S.cen[row][0], S.cen[row][1], GateGeom::Pre{S.box[row][10], S.box[row][11], S.cen[row][3]});
-          const float4 o = radar_attn_row_g(gg, q4,
-                                          k.tokens + (size_t)b * k.T * k.RI, k.RI,
-                                          kv + (size_t)b * k.T * 512, 512, k.T, k.pad_mult, lane, count, DropK(), 0,
-                                          k.T <= 64 * HM_WORDS ? reinterpret_cast<const unsigned long long*>(&S.l[row][0]) : nullptr);
+          const unsigned long long* hm = k.T <= 64 * HM_WORDS ? reinterpret_cast<const unsigned long long*>(&S.l[row][0]) : nullptr;
+          float4 o;
+          if constexpr (PROG == PROG_RADAR_TRAIN) {
+            // q is unscaled here (it goes to the tape as the projection's output); dropout on the probabilities,
+            // site 4 * layer (nn.MultiheadAttention dropout, HEAD:129), index by the GLOBAL row
+            q4.x *= k.qscale; q4.y *= k.qscale; q4.z *= k.qscale; q4.w *= k.qscale;
+            DropK dk = k.rdrop;
+            dk.site = 4u * (unsigned)rep;
+            o = radar_attn_row_g<true>(gg, q4, k.tokens + (size_t)b * k.T * k.RI, k.RI, kv + (size_t)b * k.T * 512, 512,
+                                       k.T, k.pad_mult, lane, count, dk, grow, hm);
+            if (m0 + row < M) st4(r.gd + (size_t)grow * 256 + 4 * lane, o);          // tape: attention output
+          } else {
+            o = radar_attn_row_g(gg, q4, k.tokens + (size_t)b * k.T * k.RI, k.RI, kv + (size_t)b * k.T * 512, 512,
+                                 k.T, k.pad_mult, lane, count, DropK(), 0, hm);
+          }
           *reinterpret_cast<float4*>(buf_ptr(S, r.dst) + row * LD2 + 4 * lane) = o;
           if (lane == 0) S.gate[row] = count;        // the same count as K_RADAR_GATE's (same predicate)
         }
       } break;
       } break;
-      case K_BOXADD: { if constexpr (PROG == PROG_RADAR) {   // box = reg + reference (HEAD:599-600, 664-665, 722-723); next ref (HEAD:615-617)
+      case K_BOXADD: { if constexpr (prog_is_radar(PROG)) {   // box = reg + reference (HEAD:599-600, 664-665, 722-723); next ref (HEAD:615-617)
         const int row = threadIdx.x >> 4, j = threadIdx.x & 15;     // one (row, box column) per thread
         if (row < R && j < k.code) {
           const int c = j == 0 ? 0 : j == 1 ? 1 : j == 4 ? 2 : -1;
@@ -1451,12 +1518,12 @@ template <int R, int PROG>
 void resolve_program(ChainK& k, StepAll* out) {
   const StepDesc* table = prog_table(PROG);
   constexpr int nsteps = table_steps(PROG);
-  const int nrep = PROG == PROG_RADAR ? k.nlayers : 1;
+  const int nrep = prog_is_radar(PROG) ? k.nlayers : 1;
   const int total = nsteps * nrep;
   memset(out, 0, sizeof(StepAll) * rec_cap(PROG));
   for (int idx = 0; idx < total; ++idx) {
     const int rep = idx / nsteps, si = idx - rep * nsteps;
-    const int pair0 = PROG == PROG_RADAR ? rep * RADAR_PAIRS : 0;
+    const int pair0 = prog_is_radar(PROG) ? rep * RADAR_PAIRS : 0;
     const StepDesc d = table[si];
     StepRes& r = out[idx].r;
     r.K = d.K; r.N = d.N;
@@ -1471,6 +1538,20 @@ void resolve_program(ChainK& k, StepAll* out) {
       r.kind = K_NOP;
     if (d.gsel != G_NONE) { r.gd = k.g[d.gsel]; r.gld = k.g_ld[d.gsel]; r.gmod = k.g_mod[d.gsel]; }
     if (d.gtsel != G_NONE) r.gt = k.g[d.gtsel];
+    bool taped = false;
+    if (PROG == PROG_RADAR_TRAIN) {
+      // q stays unscaled (tape), nothing is skipped
+      if (d.flags & F_SCALEQ) r.flags = (short)(r.flags & ~F_SCALEQ);
+      r.flags = (short)(r.flags & ~F_IFHIT);
+      if (d.kind == K_LINEAR && d.wp == 4) r.flags = (short)(r.flags | F_GPRE);     // tape: the FFN output itself
+      const short ts = RADAR_TAPE[si];
+      if (ts != T_NONE && r.gd == nullptr) { r.gd = k.tape[ts] + (size_t)rep * k.tape_stride; r.gld = 256; taped = true; }
+    }
+    if (PROG == PROG_RADAR_ENC_TRAIN) {
+      const short ts = ENC_TAPE[si], ts2 = ENC_TAPE2[si];
+      if (ts != T_NONE && r.gd == nullptr) { r.gd = k.tape[ts]; r.gld = 256; taped = true; }
+      if (ts2 != T_NONE) r.gt = k.tape[ts2];
+    }
     if (d.kind == K_LINEAR) {
       const tc_linear pr = k.pairs[pair0 + d.wp];
       r.K = d.K == 36 ? k.RI : d.K;
@@ -1480,12 +1561,14 @@ void resolve_program(ChainK& k, StepAll* out) {
       if (R == 16) r.p0 += k.w16_delta;                   // the 16x16x4 copy (pack.hip); launch_r checks delta != 0
       r.p1 = pr.b ? pr.b + woff : nullptr;
       if (d.gsel == G_CLS) r.gd += (size_t)rep * k.M * k.ncls;
+      if (taped) r.gld = r.N;                              // the taped tensor is [M, N]
     } else if (d.kind == K_NARROW) {
       // NOT packed (tc_head_pack_weights leaves these three heads in the nn.Linear layout): W [N][256]
       const tc_linear pr = k.pairs[pair0 + d.wp];
       r.N = d.N == N_CODE ? k.code : d.N == N_CLS ? k.ncls : d.N;
       r.p0 = pr.w; r.p1 = pr.b;
       if (d.gsel == G_CLS) r.gd += (size_t)rep * k.M * k.ncls;
+      if (taped) r.gld = r.N;
     } else if (d.kind == K_LN || d.kind == K_POSENC) {
       const tc_linear n = k.pairs[pair0 + d.wp];
       r.p0 = n.w; r.p1 = n.b;
@@ -1503,6 +1586,12 @@ void resolve_program(ChainK& k, StepAll* out) {
       // mmcv MultiheadAttention's output dropout, Detr3DCrossAtten.dropout (XFMR:378), the FFN's two
       const int off = d.wp == 1 ? 1 : d.wp == 4 ? 2 : d.wp == 10 ? 3 : d.wp == 11 ? 4 : 0;
       if (off) e.drop_site = (int)k.drop.site + off + 1;
+    }
+    if (PROG == PROG_RADAR_TRAIN && d.kind == K_LINEAR) {
+      // rf_dropout2 on out_proj's output (before gate-free residual, HEAD:581), rf_dropout on relu(linear1),
+      // rf_dropout3 on linear2's output (HEAD:584-585): sites 4 r + {1, 2, 3}
+      const int off = d.wp == 1 ? 1 : d.wp == 3 ? 2 : d.wp == 4 ? 3 : 0;
+      if (off) e.drop_site = 4 * rep + off + 1;
     }
     e.dst_off = lds_off<R, PROG>(r.dst); e.dst_ld = buf_ld_h(r.dst);
     e.res_off = lds_off<R, PROG>(r.res); e.res_ld = buf_ld_h(r.res);
@@ -1610,6 +1699,13 @@ int launch(const ChainK& k, hipStream_t s, const char* what) {
       }
       return launch_rows<PROG_DECODER>(k, s, what);
     case PROG_RADAR: return launch_rows<PROG_RADAR>(k, s, what);
+    // training forward: 4-row tiles up to 1024 rows (one frame per GPU, CFG:188), 8 beyond; always the DROP
+    // instantiation (thr 0 keeps everything)
+    case PROG_RADAR_TRAIN:
+      TC_REQUIRE((unsigned long long)k.M * 512ull < (1ull << 32), "radar_train: dropout index space");
+      return tile_rows(k) == 4 ? launch_r<4, PROG_RADAR_TRAIN, true>(k, s, what)
+                               : launch_r<8, PROG_RADAR_TRAIN, true>(k, s, what);
+    case PROG_RADAR_ENC_TRAIN: return launch_r<4, PROG_RADAR_ENC_TRAIN>(k, s, what);
     // the prologue runs once per checkpoint on Q rows (tc_head_pack_weights); stand-alone radar
     // encoders take the fewest workgroups (16-row tiles): 225 + 64 workgroups of 4-row tiles
     // did not fit 256 CUs next to a decoder layer
@@ -1700,6 +1796,11 @@ static int make_radar_enc_k(const RadarEncodeArgs& a, ChainK& k, int part = 0) {
   TC_REQUIRE(a.nlayers == TC_MAX_RADAR_LAYERS, "radar_encode: %d radar layers (3 supported)", a.nlayers);
   init_k(k);
   k.program = part == 1 ? PROG_RADAR_ENC_A : part == 2 ? PROG_RADAR_ENC_B : PROG_RADAR_ENC;
+  if (a.tape != nullptr) {
+    TC_REQUIRE(part == 0, "radar_encode: the training forward runs the whole encoder program");
+    k.program = PROG_RADAR_ENC_TRAIN;
+    for (int i = 0; i < T_COUNT; ++i) k.tape[i] = a.tape[i];
+  }
   k.M = a.M; k.Q = 1; k.RI = a.RI; k.tokens = a.tokens; k.has_next = 1;
   k.w16_delta = a.w16_delta;
   TC_REQUIRE(part == 0 || a.radar_feat != nullptr, "radar_encode: split programs need the radar_feat buffer");
@@ -1777,6 +1878,13 @@ int launch_radar_chain(const RadarChainArgs& a, hipStream_t s) {
   TC_REQUIRE(a.tile_rows == 0 || a.tile_rows == 4 || a.tile_rows == 8 || a.tile_rows == 16,
              "radar_chain: tile_rows=%d (0 = automatic, 4, 8 or 16)", a.tile_rows);
   k.tile_rows = a.tile_rows; k.last_cls_only = a.last_cls_only;
+  if (a.tape != nullptr) {                    // forward of a training iteration: tape + dropout
+    TC_REQUIRE(a.row_perm == nullptr && !a.last_cls_only, "radar_chain: the training forward takes the rows in their own order");
+    k.program = PROG_RADAR_TRAIN;
+    for (int i = 0; i < T_COUNT; ++i) k.tape[i] = a.tape[i];
+    k.tape_stride = a.tape_stride; k.hits_stride = a.hits_stride; k.rdrop = a.drop;
+    if (k.tile_rows == 16 || (k.tile_rows == 0 && a.M > 2048)) k.tile_rows = 8;
+  }
   return launch(k, s, "chain(radar)");
 }
 

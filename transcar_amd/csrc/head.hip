@@ -671,26 +671,36 @@ int tc_head_pack_weights(const tc_head_weights* w, void* packed, size_t packed_b
   return 0;
 }
 
-int tc_head_repack_trainable(const tc_head_weights* w, tc_head_weights* packed_view,
-                             tc_stream_t stream) {
+int tc_head_repack_trainable_ex(const tc_head_weights* w, tc_head_weights* packed_view, int copies,
+                                tc_stream_t stream) {
   TC_TRY(check_dims(w));
   TC_REQUIRE(packed_view != nullptr && packed_view->l0_attn_out != nullptr,
              "repack_trainable: packed_view was not produced by tc_head_pack_weights");
+  TC_REQUIRE(copies == 1 || copies == 3, "repack_trainable: copies=%d (1: the 4x4x1 copy, 3: both)", copies);
   // the same item order as tc_head_pack_weights; the decoder's items (frozen under
-  // tools/train.py:245-252) and the layer-0 constants keep their packed contents
+  // tools/train.py:245-252) and the layer-0 constants keep their packed contents.
+  // ONE launch for all of them (round 2: one launch per weight, 28 launches after every optimizer step).
   tc_head_weights scratch = *packed_view;
   PackItem items[MAX_PACK_ITEMS];
   const int n = collect_pack_items(w, &scratch, items);
   const int first = 1 + 10 * w->num_layers;
+  PackJob jobs[MAX_PACK_ITEMS];
+  int nj = 0;
   for (int i = first; i < n; ++i) {
     TC_REQUIRE(items[i].src != nullptr, "repack_trainable: weight %d is null", i);
     if (items[i].narrow) continue;                     // read in place by the chains
     // scratch is a copy of the packed view: its slot still holds the packed destination
     float* dst = const_cast<float*>(*items[i].slot);
-    TC_TRY(launch_pack_linear(items[i].src, items[i].N, items[i].K, dst, dst + packed_view->packed16_delta,
-                              as_stream(stream)));
+    jobs[nj++] = PackJob{items[i].src, dst, copies == 3 ? dst + packed_view->packed16_delta : nullptr,
+                         items[i].N, items[i].K};
   }
-  return 0;
+  if (nj == 0) return 0;
+  return launch_pack_group(jobs, nj, as_stream(stream));
+}
+
+int tc_head_repack_trainable(const tc_head_weights* w, tc_head_weights* packed_view,
+                             tc_stream_t stream) {
+  return tc_head_repack_trainable_ex(w, packed_view, 3, stream);
 }
 
 size_t tc_head_workspace_bytes(const tc_head_weights* w, int B, int T) {

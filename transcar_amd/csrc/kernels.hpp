@@ -110,6 +110,7 @@ struct RadarEncodeArgs {
   int nlayers; tc_linear kvproj[TC_MAX_RADAR_LAYERS]; float* kv[TC_MAX_RADAR_LAYERS];
   float* radar_feat;                         // optional [M,256]
   size_t w16_delta = 0;
+  float* const* tape = nullptr;              // training forward: tape tensors by TapeSlot (chain.hip TSel order)
 };
 int launch_radar_encode(const RadarEncodeArgs& a, hipStream_t s);
 // a decoder layer and the radar encoders as ONE launch (no side stream / graph branch)
@@ -128,7 +129,14 @@ struct RadarChainArgs {
   int last_cls_only = 0;                     // skip final_cls of all but the last layer (inference opt-in)
   int cen_from_box = 0;                      // w[0] is not fusion layer 1: gate centre from box_m (HEAD:615-617)
   const int* row_perm = nullptr;             // optional [M]: tile position -> row (launch_radar_compact)
+  // forward of a training iteration (tc_radar_train_fwd_fused): tape tensors of fusion layer 0 by TapeSlot,
+  // layer r at + r * tape_stride floats; hit counts of layer r at hits + r * hits_stride; dropout seed / p
+  float* const* tape = nullptr; size_t tape_stride = 0, hits_stride = 0;
+  DropK drop = DropK{0, 0, 1.0f, 0, 1500};
 };
+// order of the tape pointer arrays above (= chain.hip TSel)
+enum TapeSlot { TS_QP = 0, TS_AO, TS_X1, TS_X2, TS_H, TS_SUM, TS_X3, TS_C0, TS_C1, TS_C2, TS_C3, TS_T0, TS_T1, TS_TREG,
+                TS_U0, TS_U1, TS_U2, TS_POS, TS_F0, TS_F1, TS_F2, TS_MEM, TS_COUNT };
 int launch_radar_chain(const RadarChainArgs& a, hipStream_t s);
 
 // ---- radar_compact.hip: row order for the radar chain (queries with a radar hit first) --------
@@ -186,6 +194,9 @@ int launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float l
 size_t packed_floats(int N, int K);
 // P16 (may be null): the copy for the 16-row tiles' 16x16x4 MFMA (pack.hip)
 int launch_pack_linear(const float* W, int N, int K, float* P, float* P16, hipStream_t s);
+// several weights in one launch (P16 of an item may be null: only the 4x4x1 copy)
+struct PackJob { const float* W; float* P; float* P16; int N, K; };
+int launch_pack_group(const PackJob* jobs, int n, hipStream_t s);
 
 // ---- transpose.hip ---------------------------------------------------------
 int launch_nchw_to_nhwc(const float* src, float* dst, int n_img, int C, int H, int W, hipStream_t s);

@@ -52,13 +52,14 @@ __device__ __forceinline__ void ln_rows(float4 (&v)[NR], const float4 gg, const 
 // position-encoder layer 0: relu(LN(W0 p + b0)), W0 [256,3]
 __device__ __forceinline__ float4 posenc_l0_row(float p0, float p1, float p2, const float* w0,
                                                 const float* b0, const float* g, const float* beta,
-                                                int lane) {
+                                                int lane, float4* pre = nullptr) {
   float v[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = 4 * lane + i;
     v[i] = ldg1(w0 + c * 3 + 0) * p0 + ldg1(w0 + c * 3 + 1) * p1 + ldg1(w0 + c * 3 + 2) * p2 + ldg1(b0 + c);
   }
+  if (pre != nullptr) *pre = make_float4(v[0], v[1], v[2], v[3]);      // training tape: the LayerNorm's input
   return relu4(ln_row(make_float4(v[0], v[1], v[2], v[3]), g, beta, lane));
 }
 

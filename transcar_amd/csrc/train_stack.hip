@@ -243,6 +243,64 @@ int tc_radar_train_fwd(const tc_head_weights* w, const float* hs_last, const flo
   return 0;
 }
 
+// The same forward as THREE launches of the fused row chains (chain.hip PROG_RADAR_ENC_TRAIN / PROG_RADAR_TRAIN)
+// plus the reference set-up: the encoder program writes the token-side tape (u0 u1 u2 pos f0 f1 f2 mem and the
+// three layers' K | V), the radar program walks the three fusion layers with the dropout sites in its epilogues
+// and stores every query-side tape tensor as it is produced.  The tape is the one tc_radar_train_fwd writes:
+// tc_radar_train_bwd takes either.  `packed_view`: the head's packed weights, re-packed for the CURRENT
+// parameters (tc_head_repack_trainable_ex(w, view, 1, ...) after an optimizer step).
+int tc_radar_train_fwd_fused(const tc_head_weights* packed_view, const float* hs_last, const float* ref_last,
+                             const float* last_box, const float* radar_tokens, int B, int T, int pad_mult,
+                             float* all_cls_scores, float* all_bbox_preds, void* tape, size_t tape_bytes,
+                             float dropout_p, unsigned long long dropout_seed, tc_stream_t stream) {
+  const tc_head_weights* w = packed_view;
+  TS_TRY(check(w, B, T));
+  TC_REQUIRE(w->l0_attn_out != nullptr, "radar_train_fwd_fused: packed_view was not produced by tc_head_pack_weights");
+  TC_REQUIRE(dropout_p >= 0.0f && dropout_p < 1.0f, "radar_train_fwd_fused: dropout_p=%g", (double)dropout_p);
+  TC_REQUIRE(w->code_size <= 10 && T <= 512, "radar_train_fwd_fused: code_size=%d T=%d", w->code_size, T);
+  Tape t;
+  TC_REQUIRE(tape_layout(w, B, T, tape, tape_bytes, &t) <= tape_bytes, "radar_train_fwd_fused: tape too small");
+  hipStream_t s = as_stream(stream);
+  const int Q = w->num_query, C = w->embed_dims, code = w->code_size, RI = w->radar_in_dims;
+  const int rows = B * Q, rt = B * T;
+  float* slots[TS_COUNT];
+  const LayerTape& l0 = t.L[0];
+  slots[TS_QP] = l0.qp; slots[TS_AO] = l0.ao; slots[TS_X1] = l0.x1; slots[TS_X2] = l0.x2; slots[TS_H] = l0.h;
+  slots[TS_SUM] = l0.ff; slots[TS_X3] = l0.x3; slots[TS_C0] = l0.c0; slots[TS_C1] = l0.c1; slots[TS_C2] = l0.c2;
+  slots[TS_C3] = l0.c3; slots[TS_T0] = l0.t0; slots[TS_T1] = l0.t1; slots[TS_TREG] = l0.treg;
+  slots[TS_U0] = t.u0; slots[TS_U1] = t.u1; slots[TS_U2] = t.u2; slots[TS_POS] = t.pos;
+  slots[TS_F0] = t.f0; slots[TS_F1] = t.f1; slots[TS_F2] = t.f2; slots[TS_MEM] = t.mem;
+  // encoders + K | V of the three layers (HEAD:531-536, 573-575): one launch
+  RadarEncodeArgs re;
+  re.tokens = radar_tokens; re.RI = RI; re.M = rt;
+  re.rpe = w->radar_position_encoder; re.f0 = w->radar_feat0; re.f2 = w->radar_feat2; re.f4 = w->radar_feat4;
+  re.nlayers = w->num_radar_layers;
+  for (int r = 0; r < TC_MAX_RADAR_LAYERS; ++r) {
+    const tc_mha& m = w->radar[r].attn;
+    re.kvproj[r] = tc_linear{m.in_proj.w ? m.in_proj.w + (size_t)C * C : nullptr, m.in_proj.b ? m.in_proj.b + C : nullptr};
+    re.kv[r] = t.L[r].kv;
+  }
+  re.radar_feat = nullptr; re.w16_delta = w->packed16_delta; re.tape = slots;
+  TS_TRY(launch_radar_encode(re, s));
+  // the padded operands of radar_position_encoder.0's weight gradient (backward only)
+  TS_HIP(hipMemsetAsync(t.xyz4, 0, (size_t)rt * 4 * 4, s));
+  TS_TRY(copy_cols(radar_tokens, RI, t.xyz4, 4, rt, 3, 0, s));
+  TS_TRY(launch_radar_ref_l1(ref_last, w->pc_range, t.cxy, t.addref, rows, s));
+  // the three fusion layers: one launch
+  RadarChainArgs rc;
+  rc.qf = hs_last; rc.ref_last = ref_last; rc.box_m = last_box; rc.tokens = radar_tokens; rc.RI = RI;
+  for (int r = 0; r < TC_MAX_RADAR_LAYERS; ++r) { rc.kv[r] = t.L[r].kv; rc.w[r] = w->radar[r]; }
+  rc.nlayers = w->num_radar_layers; rc.Q = Q; rc.T = T; rc.pad_mult = pad_mult; rc.code = code;
+  rc.ncls = w->num_classes; rc.M = rows; rc.qscale = 1.0f / sqrtf((float)(C / w->num_heads));
+  for (int i = 0; i < 6; ++i) rc.pc[i] = w->pc_range[i];
+  rc.all_cls = all_cls_scores; rc.all_box = all_bbox_preds; rc.hits = t.L[0].hits;
+  rc.tape = slots;
+  rc.tape_stride = (size_t)(t.L[1].qp - t.L[0].qp);
+  rc.hits_stride = (size_t)(t.L[1].hits - t.L[0].hits);
+  rc.drop = make_drop(dropout_p, dropout_seed, 0u, (unsigned)w->num_radar_tokens_ref);
+  return launch_radar_chain(rc, s);
+}
+
 int tc_radar_train_bwd(const tc_head_weights* w, const tc_head_weights* grads, const float* hs_last,
                        const float* last_box, const float* radar_tokens, int B, int T, int pad_mult,
                        const float* all_bbox_preds, const float* d_all_cls, const float* d_all_box,

@@ -108,7 +108,8 @@ class FusionTrainer:
     """head: transcar_amd.Detr3DHead on the GPU, built with ``train_cfg``."""
 
     def __init__(self, head, lr=1.5e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01,
-                 max_norm=35.0, device_loss=True, dropout=0.1, seed=0, decoder_dropout=None):
+                 max_norm=35.0, device_loss=True, dropout=0.1, seed=0, decoder_dropout=None,
+                 chain_forward=True):
         self.head = head.freeze_decoder()
         self.bucket = FlatBucket(head.trainable_parameters())
         head.refresh_weights()                      # parameter addresses moved into the bucket
@@ -129,6 +130,10 @@ class FusionTrainer:
         if decoder_dropout is None:
             decoder_dropout = head.decoder_dropout_p() if self.dropout > 0 else 0.0
         self.decoder_dropout = float(decoder_dropout)
+        # step_fused_nhwc: the stack's forward as launches of the fused row chains with the tape stored as it
+        # is produced (tc_radar_train_fwd_fused: 3 launches + 1 re-pack instead of ~66); False = the
+        # operator-by-operator forward tc_radar_train_fwd (the same tape: the cross-check of the tests)
+        self.chain_forward = bool(chain_forward)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -175,10 +180,21 @@ class FusionTrainer:
         Q = head.num_query
         all_cls = torch.empty((3, B, Q, head.cls_out_channels), dtype=torch.float32, device=tokens.device)
         all_box = torch.empty((3, B, Q, head.code_size), dtype=torch.float32, device=tokens.device)
-        L.check(lib.tc_radar_train_fwd(
-            C.byref(w), hs_last.data_ptr(), ref_last.data_ptr(), last_box.data_ptr(), tokens.data_ptr(),
-            B, T, int(pad_mult), all_cls.data_ptr(), all_box.data_ptr(), tape.data_ptr(), tape.numel(),
-            self.dropout, drop_seed, self._stream()), 'tc_radar_train_fwd')
+        if self.chain_forward:
+            # the packed (4x4x1) copy of the trainable weights for the CURRENT parameters: one launch
+            pv = head._packed_view
+            L.check(lib.tc_head_repack_trainable_ex(C.byref(w), C.byref(pv), 1, self._stream()),
+                    'tc_head_repack_trainable_ex')
+            head._packed_dirty = True                  # the 16x16x4 copy (inference at >= 3 frames) is stale
+            L.check(lib.tc_radar_train_fwd_fused(
+                C.byref(pv), hs_last.data_ptr(), ref_last.data_ptr(), last_box.data_ptr(), tokens.data_ptr(),
+                B, T, int(pad_mult), all_cls.data_ptr(), all_box.data_ptr(), tape.data_ptr(), tape.numel(),
+                self.dropout, drop_seed, self._stream()), 'tc_radar_train_fwd_fused')
+        else:
+            L.check(lib.tc_radar_train_fwd(
+                C.byref(w), hs_last.data_ptr(), ref_last.data_ptr(), last_box.data_ptr(), tokens.data_ptr(),
+                B, T, int(pad_mult), all_cls.data_ptr(), all_box.data_ptr(), tape.data_ptr(), tape.numel(),
+                self.dropout, drop_seed, self._stream()), 'tc_radar_train_fwd')
         if self.device_loss:
             from .device_loss import detr_loss_device
             losses, d_cls, d_box, _ = detr_loss_device(head, all_cls, all_box, gt_bboxes_list,
