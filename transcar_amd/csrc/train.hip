@@ -59,7 +59,7 @@ __device__ __forceinline__ float bg_load_a(const BwdGemmK& p, int gi, int gr, in
 // contiguous index and base address a multiple of 4 floats -- checked by the launchers); the scalar
 // variant (one predicated 4-byte load per element) remains for the 10- / 24-wide heads.
 template <int MODE, int BN, bool VEC>
-__global__ __launch_bounds__(256) void bwd_gemm_kernel(BwdGemmK p) {
+__device__ __forceinline__ void bwd_gemm_body(const BwdGemmK& p, const int bx, const int by, const int bz, const int gz) {
   constexpr int NT = BN / 16;
   constexpr int AE = 64 * BG_RK / 256;      // A elements per thread and step (8)
   constexpr int BE = BN * BG_RK / 256;      // B elements per thread and step (8 or 4)
@@ -69,13 +69,13 @@ __global__ __launch_bounds__(256) void bwd_gemm_kernel(BwdGemmK p) {
   __shared__ __align__(16) float As[(64 * LDA_D > BG_RK * LDA_W) ? 64 * LDA_D : BG_RK * LDA_W];
   __shared__ __align__(16) float Bs[BG_RK * LDB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * BN;
-  const int rbeg = blockIdx.z * p.rchunk, rend = min(p.R, rbeg + p.rchunk);
+  const int i0 = by * 64, j0 = bx * BN;
+  const int rbeg = bz * p.rchunk, rend = min(p.R, rbeg + p.rchunk);
   f32x4 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   float csum = 0.f;
-  const bool do_colsum = MODE == BWD_WEIGHT && p.colsum != nullptr && blockIdx.x == 0;
+  const bool do_colsum = MODE == BWD_WEIGHT && p.colsum != nullptr && bx == 0;
   float ra[AE], rb[BE];
 
   auto fetch = [&](int r0) {
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void bwd_gemm_kernel(BwdGemmK p) {
     }
     __syncthreads();
   }
-  const bool atomic = MODE == BWD_WEIGHT || gridDim.z > 1;
+  const bool atomic = MODE == BWD_WEIGHT || gz > 1;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int col = j0 + 16 * t + (lane & 15);
@@ -203,6 +203,32 @@ __global__ __launch_bounds__(256) void bwd_gemm_kernel(BwdGemmK p) {
     }
   }
   if (do_colsum && tid < 64 && i0 + tid < p.I) unsafeAtomicAdd(p.colsum + i0 + tid, csum);
+}
+
+template <int MODE, int BN, bool VEC>
+__global__ __launch_bounds__(256) void bwd_gemm_kernel(BwdGemmK p) {
+  bwd_gemm_body<MODE, BN, VEC>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z);
+}
+
+// Every weight gradient of an iteration in ONE launch (two: the 16-byte-load variant and the scalar one for the
+// 10-wide heads): dW_i += dY_i^T X_i, db_i += colsum dY_i.  The items travel in the kernel-argument segment, a
+// block finds its item from the block offsets.  (Round 2: one launch per weight, 37 per iteration, ~10 us each
+// for a 900 x 256 x 256 product.)
+constexpr int WGROUP_MAX = 48;
+struct WGroupItem { BwdGemmK p; int first_block, gx, gy, gz; };
+struct WGroupK { WGroupItem it[WGROUP_MAX]; int n; };
+template <bool VEC>
+__global__ __launch_bounds__(256) void bwd_weight_group_kernel(WGroupK g) {
+  int i = 0;
+#pragma unroll 1
+  for (int j = 1; j < g.n; ++j)
+    if ((int)blockIdx.x >= g.it[j].first_block) i = j;
+  const WGroupItem& it = g.it[i];
+  int b = (int)blockIdx.x - it.first_block;
+  const int bx = b % it.gx; b /= it.gx;
+  const int by = b % it.gy;
+  const int bz = b / it.gy;
+  bwd_gemm_body<BWD_WEIGHT, 64, VEC>(it.p, bx, by, bz, it.gz);
 }
 
 static bool bg_vec_ok(const BwdGemmK& p, int contiguous_a_extent) {
@@ -245,6 +271,30 @@ int launch_linear_bwd_weight(const float* x, const float* dy, const float* relu_
   else
     hipLaunchKernelGGL((bwd_gemm_kernel<BWD_WEIGHT, 64, false>), grid, dim3(256), 0, s, p);
   return check_launch("linear_bwd_weight");
+}
+
+int launch_linear_bwd_weight_group(const WeightJob* jobs, int n, hipStream_t s) {
+  TC_REQUIRE(n >= 1 && n <= WGROUP_MAX, "linear_bwd_weight_group: %d items (1..%d)", n, WGROUP_MAX);
+  WGroupK g[2];                      // [1]: 16-byte operand loads, [0]: scalar
+  int blocks[2] = {0, 0};
+  g[0].n = g[1].n = 0;
+  for (int i = 0; i < n; ++i) {
+    const WeightJob& j = jobs[i];
+    TC_REQUIRE(j.M > 0 && j.K > 0 && j.N > 0 && j.dw != nullptr && j.x != nullptr && j.dy != nullptr,
+               "linear_bwd_weight_group: bad item %d", i);
+    BwdGemmK p;
+    p.A = j.dy; p.relu = j.relu; p.gate = nullptr; p.Bm = j.x; p.cmask = nullptr; p.C = j.dw;
+    p.colsum = j.db; p.ldA = j.N; p.ldB = j.K; p.ldC = j.K; p.I = j.N; p.J = j.K; p.R = j.M;
+    p.rchunk = 128; p.accumulate = 1; p.alpha = 1.0f;
+    const int v = bg_vec_ok(p, j.N) ? 1 : 0;
+    WGroupItem& it = g[v].it[g[v].n++];
+    it.p = p; it.gx = (j.K + 63) / 64; it.gy = (j.N + 63) / 64; it.gz = (j.M + p.rchunk - 1) / p.rchunk;
+    it.first_block = blocks[v];
+    blocks[v] += it.gx * it.gy * it.gz;
+  }
+  if (g[1].n > 0) hipLaunchKernelGGL((bwd_weight_group_kernel<true>), dim3(blocks[1]), dim3(256), 0, s, g[1]);
+  if (g[0].n > 0) hipLaunchKernelGGL((bwd_weight_group_kernel<false>), dim3(blocks[0]), dim3(256), 0, s, g[0]);
+  return check_launch("linear_bwd_weight_group");
 }
 
 // ---- LayerNorm(a (+b)) (+ReLU) backward, C = 256 ---------------------------
@@ -329,13 +379,6 @@ struct RadBwdK {
   DropK drop;                  // dropout on the attention probabilities (thr 0 = off)
 };
 
-__device__ __forceinline__ float head_sum(float s) {      // 8 lanes = one 32-channel head
-  s += __shfl_xor(s, 1, 64);
-  s += __shfl_xor(s, 2, 64);
-  s += __shfl_xor(s, 4, 64);
-  return s;
-}
-
 __global__ __launch_bounds__(256) void radar_attn_bwd_kernel(RadBwdK p) {
   const int lane = threadIdx.x & 63;
   const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -345,69 +388,11 @@ __global__ __launch_bounds__(256) void radar_attn_bwd_kernel(RadBwdK p) {
   const float* bx = p.box + (size_t)row * p.code;
   float4 q4 = ld4(p.qproj + (size_t)row * p.ldq + 4 * lane);
   q4.x *= p.qscale; q4.y *= p.qscale; q4.z *= p.qscale; q4.w *= p.qscale;
-  const float* rxy = p.rxy + (size_t)b * p.T * p.ld_xy;
-  const float* kv = p.kv + (size_t)b * p.T * p.ldkv;
-  float* dkv = p.dkv + (size_t)b * p.T * p.ldkv;
-  // gate geometry: identical to rowdev.hpp radar_attn_row (HEAD:553-567)
-  const float len = expf(bx[3]);
-  const float rs = -bx[6], rc = -bx[7];
-  const float ox = __fmul_rn(__fmul_rn(len, 0.25f), rs), oy = __fmul_rn(__fmul_rn(len, 0.25f), rc);
-  const float fx = __fadd_rn(cx, ox), fy = __fadd_rn(cy, oy);
-  const float bxx = __fsub_rn(cx, ox), byy = __fsub_rn(cy, oy);
-  const float rad = fminf(fmaxf(len / 2.0f, p.rmin), p.rmax);
-  const float cn = sqnorm2(cx, cy), fn = sqnorm2(fx, fy), bn = sqnorm2(bxx, byy);
   const float4 dO = ld4(p.d_attn + (size_t)row * 256 + 4 * lane);
   const float4 o4 = ld4(p.attn_out + (size_t)row * 256 + 4 * lane);
-  const float D = head_sum(dO.x * o4.x + dO.y * o4.y + dO.z * o4.z + dO.w * o4.w);
-  float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
-  float m = -INFINITY, l = 0.f;
-  // pass 0: softmax statistics over the hit tokens;  pass 1: gradients
-  for (int pass = 0; pass < 2; ++pass) {
-    for (int t0 = 0; t0 < p.T; t0 += 64) {
-      const int t = t0 + lane;
-      bool hit = false;
-      if (t < p.T) {
-        const float* y = rxy + (size_t)t * p.ld_xy;
-        const float y0 = y[0], y1 = y[1];
-        const float yn = sqnorm2(y0, y1);
-        hit = (cdist_mm(cx, cy, cn, y0, y1, yn) < rad) || (cdist_mm(fx, fy, fn, y0, y1, yn) < rad) ||
-              (cdist_mm(bxx, byy, bn, y0, y1, yn) < rad);
-      }
-      unsigned long long mask = __ballot(hit);
-      while (mask) {
-        const int j = __ffsll((long long)mask) - 1;
-        mask &= mask - 1;
-        const int tok = t0 + j;
-        const float mult = (tok == p.T - 1) ? (float)p.pad_mult : 1.0f;
-        const float* kvr = kv + (size_t)tok * p.ldkv + 4 * lane;
-        const float4 k4 = ld4(kvr);
-        const float sc = head_sum(q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w);
-        if (pass == 0) {
-          const float mnew = fmaxf(m, sc);
-          l = l * expf(m - mnew) + mult * expf(sc - mnew);
-          m = mnew;
-        } else {
-          const float4 v4 = ld4(kvr + 256);
-          const float pj = mult * expf(sc - m) / l;
-          // O = sum_j keep_j p_j v_j: dP_j = keep_j (dO . v_j), dV_j = keep_j p_j dO; D = dO . O as without
-          float keep = 1.0f;
-          if (p.drop.thr != 0)
-            keep = drop_keep(p.drop.seed, p.drop.site,
-                             ((unsigned)row * 8u + (unsigned)(lane >> 3)) * p.drop.tokens_ref + (unsigned)tok,
-                             p.drop.thr) ? p.drop.scale : 0.0f;
-          const float dp = keep * head_sum(dO.x * v4.x + dO.y * v4.y + dO.z * v4.z + dO.w * v4.w);
-          const float ds = pj * (dp - D);
-          const float pk = pj * keep;
-          dq.x += ds * k4.x; dq.y += ds * k4.y; dq.z += ds * k4.z; dq.w += ds * k4.w;
-          float* dk = dkv + (size_t)tok * p.ldkv + 4 * lane;
-          unsafeAtomicAdd(dk + 0, ds * q4.x); unsafeAtomicAdd(dk + 1, ds * q4.y);
-          unsafeAtomicAdd(dk + 2, ds * q4.z); unsafeAtomicAdd(dk + 3, ds * q4.w);
-          unsafeAtomicAdd(dk + 256, pk * dO.x); unsafeAtomicAdd(dk + 257, pk * dO.y);
-          unsafeAtomicAdd(dk + 258, pk * dO.z); unsafeAtomicAdd(dk + 259, pk * dO.w);
-        }
-      }
-    }
-  }
+  const float4 dq = radar_attn_bwd_row(cx, cy, bx[3], bx[6], bx[7], p.rmin, p.rmax, q4,
+                                       p.rxy + (size_t)b * p.T * p.ld_xy, p.ld_xy, p.kv + (size_t)b * p.T * p.ldkv,
+                                       p.dkv + (size_t)b * p.T * p.ldkv, p.ldkv, p.T, p.pad_mult, dO, o4, p.drop, row, lane);
   st4(p.dq + (size_t)row * 256 + 4 * lane,
       make_float4(dq.x * p.qscale, dq.y * p.qscale, dq.z * p.qscale, dq.w * p.qscale));
 }

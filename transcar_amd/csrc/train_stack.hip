@@ -410,6 +410,181 @@ int tc_radar_train_bwd(const tc_head_weights* w, const tc_head_weights* grads, c
   return 0;
 }
 
+// ---- the backward as ONE launch of the row chain for the query side + a handful for the token side + ONE
+// grouped weight-gradient launch (round 2: ~130 launches).  Workspace: the transposed packed weights of the
+// three layers, the dY tensors the chain stores, dK | dV of the three layers.
+namespace {
+struct BwdWs {
+  tc_radar_layer wT[TC_MAX_RADAR_LAYERS];
+  float* dy[DY_COUNT]; size_t dy_stride;
+  float* dkv[TC_MAX_RADAR_LAYERS];
+};
+size_t bwd_ws_layout(const tc_head_weights* w, int B, int T, void* base, size_t cap, BwdWs* out) {
+  const size_t rows = (size_t)B * w->num_query, rt = (size_t)B * T;
+  const size_t C = w->embed_dims, F = w->ffn_dims, code = w->code_size, ncls = w->num_classes;
+  Arena a(base, cap);
+  BwdWs b;
+  memset(&b, 0, sizeof(b));
+  for (int r = 0; r < TC_MAX_RADAR_LAYERS; ++r) {
+    tc_radar_layer& l = b.wT[r];
+    l.attn.in_proj.w = a.take<float>(packed_floats((int)C, (int)C));
+    l.attn.out_proj.w = a.take<float>(packed_floats((int)C, (int)C));
+    l.linear1.w = a.take<float>(packed_floats((int)C, (int)F));        // (W1^T: C outputs, F inputs)
+    l.linear2.w = a.take<float>(packed_floats((int)F, (int)C));
+    l.final_cls.l0.w = a.take<float>(packed_floats((int)C, (int)C));
+    l.final_cls.l3.w = a.take<float>(packed_floats((int)C, (int)C));
+    l.final_cls.l6.w = a.take<float>(packed_floats((int)C, (int)ncls));
+    l.final_reg.l0.w = a.take<float>(packed_floats((int)C, (int)C));
+    l.final_reg.l2.w = a.take<float>(packed_floats((int)C, (int)C));
+    l.final_reg.l4.w = a.take<float>(packed_floats((int)C, (int)code));
+  }
+  float* first = nullptr;
+  for (int r = 0; r < TC_MAX_RADAR_LAYERS; ++r) {
+    float* s0 = a.take<float>(rows * code);
+    if (r == 0) { first = s0; b.dy[DY_DBOX] = s0; }
+    float* p1 = a.take<float>(rows * C); float* p2 = a.take<float>(rows * C); float* p3 = a.take<float>(rows * C);
+    float* p4 = a.take<float>(rows * C); float* p5 = a.take<float>(rows * C); float* p6 = a.take<float>(rows * F);
+    float* p7 = a.take<float>(rows * C); float* p8 = a.take<float>(rows * C);
+    if (r == 0) {
+      b.dy[DY_DT1] = p1; b.dy[DY_DT0] = p2; b.dy[DY_DC2] = p3; b.dy[DY_DC0] = p4; b.dy[DY_DFF] = p5; b.dy[DY_DH] = p6;
+      b.dy[DY_DPROJ] = p7; b.dy[DY_DQP] = p8;
+    }
+    if (r == 1) b.dy_stride = (size_t)(s0 - first);
+  }
+  for (int r = 0; r < TC_MAX_RADAR_LAYERS; ++r) b.dkv[r] = a.take<float>(rt * 2 * C);   // contiguous: one memset
+  if (out) *out = b;
+  return a.off;
+}
+}  // namespace
+
+size_t tc_radar_train_bwd_workspace_bytes(const tc_head_weights* w, int B, int T) {
+  if (check(w, B, T) != 0) return 0;
+  return bwd_ws_layout(w, B, T, nullptr, ~size_t(0), nullptr);
+}
+
+int tc_radar_train_bwd_fused(const tc_head_weights* w, const tc_head_weights* grads, const float* hs_last,
+                             const float* last_box, const float* radar_tokens, int B, int T, int pad_mult,
+                             const float* all_bbox_preds, const float* d_all_cls, const float* d_all_box,
+                             void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes,
+                             float dropout_p, unsigned long long dropout_seed, tc_stream_t stream) {
+  TS_TRY(check(w, B, T));
+  TC_REQUIRE(grads != nullptr && workspace != nullptr, "radar_train_bwd_fused: null argument");
+  TC_REQUIRE(dropout_p >= 0.0f && dropout_p < 1.0f, "radar_train_bwd_fused: dropout_p=%g", (double)dropout_p);
+  TC_REQUIRE(w->code_size <= 10, "radar_train_bwd_fused: code_size=%d", w->code_size);
+  Tape t;
+  TC_REQUIRE(tape_layout(w, B, T, tape, tape_bytes, &t) <= tape_bytes, "radar_train_bwd_fused: tape too small");
+  BwdWs ws;
+  TC_REQUIRE(bwd_ws_layout(w, B, T, workspace, workspace_bytes, &ws) <= workspace_bytes,
+             "radar_train_bwd_fused: workspace too small");
+  hipStream_t s = as_stream(stream);
+  const int Q = w->num_query, C = w->embed_dims, F = w->ffn_dims, code = w->code_size;
+  const int ncls = w->num_classes, RI = w->radar_in_dims;
+  const int rows = B * Q, rt = B * T;
+  // 1. the transposed packed weights of the three layers: one launch
+  {
+    PackJob jobs[10 * TC_MAX_RADAR_LAYERS];
+    int n = 0;
+    auto add = [&](const float* W, float* P, int N_out, int K_in) {      // pack (W^T): W is [K_in... no: W is [N_fwd = K_in][K_fwd = N_out]
+      PackJob j;
+      j.W = W; j.P = P; j.P16 = nullptr; j.N = N_out; j.K = K_in; j.transpose = 1; j.ldw = N_out;
+      jobs[n++] = j;
+    };
+    for (int r = 0; r < TC_MAX_RADAR_LAYERS; ++r) {
+      const tc_radar_layer& rl = w->radar[r];
+      const tc_radar_layer& lt = ws.wT[r];
+      // forward W is [N_fwd][K_fwd] (row stride K_fwd); the chain computes dx[K_fwd] = dy[N_fwd] W, i.e. a linear
+      // step with N_out = K_fwd outputs and K_in = N_fwd inputs whose weight (n, k) = W[k][n]: ldw = K_fwd = N_out
+      add(rl.attn.in_proj.w, const_cast<float*>(lt.attn.in_proj.w), C, C);          // Wq: rows 0..C-1 of in_proj
+      add(rl.attn.out_proj.w, const_cast<float*>(lt.attn.out_proj.w), C, C);
+      add(rl.linear1.w, const_cast<float*>(lt.linear1.w), C, F);                    // linear1: [F][C]
+      add(rl.linear2.w, const_cast<float*>(lt.linear2.w), F, C);                    // linear2: [C][F]
+      add(rl.final_cls.l0.w, const_cast<float*>(lt.final_cls.l0.w), C, C);
+      add(rl.final_cls.l3.w, const_cast<float*>(lt.final_cls.l3.w), C, C);
+      add(rl.final_cls.l6.w, const_cast<float*>(lt.final_cls.l6.w), C, ncls);       // [ncls][C]
+      add(rl.final_reg.l0.w, const_cast<float*>(lt.final_reg.l0.w), C, C);
+      add(rl.final_reg.l2.w, const_cast<float*>(lt.final_reg.l2.w), C, C);
+      add(rl.final_reg.l4.w, const_cast<float*>(lt.final_reg.l4.w), C, code);       // [code][C]
+    }
+    TS_TRY(launch_pack_group(jobs, n, s));
+  }
+  // 2. accumulators
+  TS_HIP(hipMemsetAsync(ws.dkv[0], 0, (size_t)TC_MAX_RADAR_LAYERS * rt * 2 * C * 4, s));
+  TS_HIP(hipMemsetAsync(t.dmem, 0, (size_t)rt * C * 4, s));
+  // 3. the query side of all three layers: one launch
+  float* slots[TS_COUNT];
+  memset(slots, 0, sizeof(slots));
+  const LayerTape& l0 = t.L[0];
+  slots[TS_QP] = l0.qp; slots[TS_AO] = l0.ao; slots[TS_X1] = l0.x1; slots[TS_X2] = l0.x2; slots[TS_H] = l0.h;
+  slots[TS_SUM] = l0.ff; slots[TS_X3] = l0.x3; slots[TS_C0] = l0.c0; slots[TS_C1] = l0.c1; slots[TS_C2] = l0.c2;
+  slots[TS_C3] = l0.c3; slots[TS_T0] = l0.t0; slots[TS_T1] = l0.t1; slots[TS_TREG] = l0.treg;
+  RadarBwdChainArgs a;
+  for (int r = 0; r < TC_MAX_RADAR_LAYERS; ++r) {
+    a.wT[r] = ws.wT[r]; a.w[r] = w->radar[r]; a.grads[r] = grads->radar[r];
+    a.kv[r] = t.L[r].kv; a.dkv[r] = ws.dkv[r];
+    const float* box_prev = r == 0 ? last_box : all_bbox_preds + (size_t)(r - 1) * rows * code;
+    a.cxy[r] = r == 0 ? t.cxy : box_prev; a.ld_c[r] = r == 0 ? 2 : code; a.box[r] = box_prev;
+  }
+  a.tape = slots; a.tape_stride = (size_t)(t.L[1].qp - t.L[0].qp);
+  a.hits = t.L[0].hits; a.hits_stride = (size_t)(t.L[1].hits - t.L[0].hits);
+  a.dy = ws.dy; a.dy_stride = ws.dy_stride;
+  a.d_cls = d_all_cls; a.d_box = d_all_box;
+  a.tokens = radar_tokens; a.RI = RI; a.T = T; a.pad_mult = pad_mult;
+  a.nlayers = TC_MAX_RADAR_LAYERS; a.Q = Q; a.M = rows; a.code = code; a.ncls = ncls;
+  a.qscale = 1.0f / sqrtf((float)(C / w->num_heads));
+  a.drop = make_drop(dropout_p, dropout_seed, 0u, (unsigned)w->num_radar_tokens_ref);
+  TS_TRY(launch_radar_chain_bwd(a, s));
+  // 4. the token side: dmem = sum_r dkv_r Wkv_r, then the encoders (data gradients only; weights below)
+  for (int r = 0; r < TC_MAX_RADAR_LAYERS; ++r)
+    TS_TRY(launch_linear_bwd_data(ws.dkv[r], nullptr, nullptr, w->radar[r].attn.in_proj.w + (size_t)C * C, nullptr, t.dmem,
+                                  rt, C, 2 * C, 1.0f, 1, s));
+  const tc_pos_encoder& pe = w->radar_position_encoder;
+  const tc_pos_encoder& gpe = grads->radar_position_encoder;
+  // mem = relu(LN4(u2)) + relu(feat4(f1)): both summands see dmem
+  TS_TRY(launch_linear_bwd_data(t.dmem, t.f2, nullptr, w->radar_feat4.w, t.f1, t.dt128, rt, 128, C, 1.0f, 0, s));
+  TS_TRY(launch_linear_bwd_data(t.dt128, nullptr, nullptr, w->radar_feat2.w, t.f0, t.dt64, rt, 64, 128, 1.0f, 0, s));
+  float* du = t.dkv;                 // [rt, C] scratch of the tape
+  float* du2 = t.dkv + (size_t)rt * C;
+  TS_TRY(ln_bwd(t.u2, nullptr, pe.n4, gpe.n4, t.dmem, t.pos, du, rt, s));
+  TS_TRY(launch_linear_bwd_data(du, nullptr, nullptr, pe.l3.w, nullptr, du2, rt, C, C, 1.0f, 0, s));
+  float* du0 = t.dqp;                // [rows, C] >= [rt, C]?  rows >= rt is not guaranteed: use dA when it is not
+  if ((size_t)rows < (size_t)rt) du0 = t.dh;
+  TS_TRY(ln_bwd(t.u0, nullptr, pe.n1, gpe.n1, du2, t.u1, du0, rt, s));
+  TS_HIP(hipMemsetAsync(t.dw0p, 0, (size_t)C * 4 * 4, s));
+  // 5. every weight gradient: one grouped launch (two with the scalar variant for the 10-wide heads)
+  WeightJob jobs[11 * TC_MAX_RADAR_LAYERS + 5];
+  int n = 0;
+  auto job = [&](const float* x, const float* dy, const tc_linear& g, int M, int K, int N, const float* relu = nullptr) {
+    WeightJob j;
+    j.x = x; j.dy = dy; j.dw = const_cast<float*>(g.w); j.db = const_cast<float*>(g.b); j.M = M; j.K = K; j.N = N; j.relu = relu;
+    jobs[n++] = j;
+  };
+  for (int r = 0; r < TC_MAX_RADAR_LAYERS; ++r) {
+    const tc_radar_layer& gl = grads->radar[r];
+    const LayerTape& l = t.L[r];
+    const size_t off = (size_t)r * ws.dy_stride;
+    const float* qin = r == 0 ? hs_last : t.L[r - 1].x3;
+    job(qin, ws.dy[DY_DQP] + off, tc_linear{gl.attn.in_proj.w, gl.attn.in_proj.b}, rows, C, C);
+    job(t.mem, ws.dkv[r], tc_linear{gl.attn.in_proj.w + (size_t)C * C, gl.attn.in_proj.b + C}, rt, C, 2 * C);
+    job(l.ao, ws.dy[DY_DPROJ] + off, gl.attn.out_proj, rows, C, C);
+    job(l.x2, ws.dy[DY_DH] + off, gl.linear1, rows, C, F);
+    job(l.h, ws.dy[DY_DFF] + off, gl.linear2, rows, F, C);
+    job(l.x3, ws.dy[DY_DC0] + off, gl.final_cls.l0, rows, C, C);
+    job(l.c1, ws.dy[DY_DC2] + off, gl.final_cls.l3, rows, C, C);
+    job(l.c3, d_all_cls + (size_t)r * rows * ncls, gl.final_cls.l6, rows, C, ncls);
+    job(l.x3, ws.dy[DY_DT0] + off, gl.final_reg.l0, rows, C, C);
+    job(l.t0, ws.dy[DY_DT1] + off, gl.final_reg.l2, rows, C, C);
+    job(l.t1, ws.dy[DY_DBOX] + off, gl.final_reg.l4, rows, C, code);
+  }
+  job(t.f1, t.dmem, grads->radar_feat4, rt, 128, C, t.f2);
+  job(t.f0, t.dt128, grads->radar_feat2, rt, 64, 128);
+  job(radar_tokens, t.dt64, grads->radar_feat0, rt, RI, 64);
+  job(t.u1, du, gpe.l3, rt, C, C);
+  job(t.xyz4, du0, tc_linear{t.dw0p, gpe.l0.b}, rt, 4, C);
+  TS_TRY(launch_linear_bwd_weight_group(jobs, n, s));
+  TS_TRY(copy_cols(t.dw0p, 4, const_cast<float*>(gpe.l0.w), 3, C, 3, 1, s));
+  return 0;
+}
+
 // The multipliers (0 or 1 / (1 - p)) of elements 0..n-1 of a dropout site, for tests and for
 // replaying an iteration elsewhere (site = 4 * radar layer + {0 attention probabilities, index
 // ((row * 8 + head) * num_radar_tokens_ref + token); 1 rf_dropout2; 2 rf_dropout; 3 rf_dropout3,

@@ -109,7 +109,7 @@ class FusionTrainer:
 
     def __init__(self, head, lr=1.5e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01,
                  max_norm=35.0, device_loss=True, dropout=0.1, seed=0, decoder_dropout=None,
-                 chain_forward=True):
+                 chain_forward=True, chain_backward=True):
         self.head = head.freeze_decoder()
         self.bucket = FlatBucket(head.trainable_parameters())
         head.refresh_weights()                      # parameter addresses moved into the bucket
@@ -134,6 +134,10 @@ class FusionTrainer:
         # is produced (tc_radar_train_fwd_fused: 3 launches + 1 re-pack instead of ~66); False = the
         # operator-by-operator forward tc_radar_train_fwd (the same tape: the cross-check of the tests)
         self.chain_forward = bool(chain_forward)
+        # ... and its backward as one launch of the backward row chain (query side), a handful for the token
+        # side and one grouped weight-gradient launch (tc_radar_train_bwd_fused: ~16 launches instead of ~130);
+        # False = tc_radar_train_bwd, one launch per operator
+        self.chain_backward = bool(chain_backward)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -210,10 +214,23 @@ class FusionTrainer:
             d_cls, d_box = cls_leaf.grad.contiguous(), box_leaf.grad.contiguous()
         self.bucket.zero_grad()
         g = grad_table(head)
-        L.check(lib.tc_radar_train_bwd(
-            C.byref(w), C.byref(g), hs_last.data_ptr(), last_box.data_ptr(), tokens.data_ptr(), B, T,
-            int(pad_mult), all_box.data_ptr(), d_cls.data_ptr(), d_box.data_ptr(), tape.data_ptr(),
-            tape.numel(), self.dropout, drop_seed, self._stream()), 'tc_radar_train_bwd')
+        if self.chain_backward:
+            if getattr(self, '_bws_key', None) != key:
+                nb = lib.tc_radar_train_bwd_workspace_bytes(C.byref(w), B, T)
+                if nb == 0:
+                    raise L.TransCARHipError(lib.tc_last_error().decode())
+                self._bws = torch.empty(nb, dtype=torch.uint8, device=tokens.device)
+                self._bws_key = key
+            L.check(lib.tc_radar_train_bwd_fused(
+                C.byref(w), C.byref(g), hs_last.data_ptr(), last_box.data_ptr(), tokens.data_ptr(), B, T,
+                int(pad_mult), all_box.data_ptr(), d_cls.data_ptr(), d_box.data_ptr(), tape.data_ptr(),
+                tape.numel(), self._bws.data_ptr(), self._bws.numel(), self.dropout, drop_seed, self._stream()),
+                'tc_radar_train_bwd_fused')
+        else:
+            L.check(lib.tc_radar_train_bwd(
+                C.byref(w), C.byref(g), hs_last.data_ptr(), last_box.data_ptr(), tokens.data_ptr(), B, T,
+                int(pad_mult), all_box.data_ptr(), d_cls.data_ptr(), d_box.data_ptr(), tape.data_ptr(),
+                tape.numel(), self.dropout, drop_seed, self._stream()), 'tc_radar_train_bwd')
         self.last_dropout_seed = drop_seed
         if update:
             self._optimizer_step(lr)
