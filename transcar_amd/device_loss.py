@@ -39,18 +39,31 @@ def detr_loss_device(head, all_cls, all_box, gt_bboxes_list, gt_labels_list):
     code = all_box.shape[-1]
     all_cls = all_cls.detach().contiguous()
     all_box = all_box.detach().contiguous()
-    gts = gt_tensors(gt_bboxes_list, dev)
-    counts = [int(g.shape[0]) for g in gts]
-    Gmax = max(max(counts), 1)
-    gt9 = torch.ones((B, Gmax, 9), dtype=torch.float32, device=dev)
-    lab = torch.zeros((B, Gmax), dtype=torch.int32, device=dev)
-    for b, (g, l) in enumerate(zip(gts, gt_labels_list)):
-        if counts[b]:
-            gt9[b, :counts[b]] = g[:, :9]
-            lab[b, :counts[b]] = l.to(device=dev, dtype=torch.int32)
-    cnt = torch.tensor(counts, dtype=torch.int32, device=dev)
-    gtn = torch.empty((B, Gmax, 10), dtype=torch.float32, device=dev)
-    L.check(lib.tc_normalize_bbox(gt9.data_ptr(), B * Gmax, gtn.data_ptr(), _stream()), 'tc_normalize_bbox')
+    # ground truth of the batch, padded to [B, Gmax]: built once per distinct set of GT tensors (a data loader
+    # hands new tensors every iteration; the per-sample slice copies + a synchronous torch.tensor(list) cost
+    # ~0.5 ms of host time per call)
+    # (the cache holds the tensors, so an address cannot be re-used by another live tensor; _version catches
+    # in-place edits)
+    def _id(t):
+        t = t.tensor if hasattr(t, 'tensor') else t
+        return (int(t.data_ptr()), int(t._version), tuple(t.shape))
+    key = tuple((_id(g), _id(l)) for g, l in zip(gt_bboxes_list, gt_labels_list))
+    cache = getattr(head, '_gt_cache', None)
+    if cache is None or cache[0] != key:
+        gts = gt_tensors(gt_bboxes_list, dev)
+        counts = [int(g.shape[0]) for g in gts]
+        Gmax = max(max(counts), 1)
+        gt9 = torch.ones((B, Gmax, 9), dtype=torch.float32, device=dev)
+        lab = torch.zeros((B, Gmax), dtype=torch.int32, device=dev)
+        for b, (g, l) in enumerate(zip(gts, gt_labels_list)):
+            if counts[b]:
+                gt9[b, :counts[b]] = g[:, :9]
+                lab[b, :counts[b]] = l.to(device=dev, dtype=torch.int32)
+        cnt = torch.from_numpy(np.asarray(counts, dtype=np.int32)).to(dev)
+        gtn = torch.empty((B, Gmax, 10), dtype=torch.float32, device=dev)
+        L.check(lib.tc_normalize_bbox(gt9.data_ptr(), B * Gmax, gtn.data_ptr(), _stream()), 'tc_normalize_bbox')
+        cache = head._gt_cache = (key, counts, Gmax, lab, cnt, gtn, list(gt_bboxes_list), list(gt_labels_list))
+    _, counts, Gmax, lab, cnt, gtn = cache[:6]
     a = head.assigner
     cost = torch.empty((Lyr, B, Q, Gmax), dtype=torch.float32, device=dev)
     L.check(lib.tc_match_cost(
@@ -68,12 +81,15 @@ def detr_loss_device(head, all_cls, all_box, gt_bboxes_list, gt_labels_list):
                 assigned[l, b, rows] = cols
                 num_pos[l] += len(rows)
     # normalisers, HEAD:885-902: mean over ranks of the number of positives, at least 1
-    box_avg = torch.from_numpy(num_pos).to(dev)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        box_avg = torch.from_numpy(num_pos).to(dev)
         dist.all_reduce(box_avg, op=dist.ReduceOp.SUM)
         box_avg = box_avg / dist.get_world_size()
-    cls_avg = box_avg if head.sync_cls_avg_factor else torch.from_numpy(num_pos).to(dev)
-    avg = torch.stack((cls_avg.clamp(min=1.0), box_avg.clamp(min=1.0)), dim=1).contiguous()   # [Lyr,2]
+        cls_avg = box_avg if head.sync_cls_avg_factor else torch.from_numpy(num_pos).to(dev)
+        avg = torch.stack((cls_avg.clamp(min=1.0), box_avg.clamp(min=1.0)), dim=1).contiguous()   # [Lyr,2]
+    else:                                                           # one rank: the clamp on the host, one H2D
+        one = np.maximum(num_pos, 1.0).astype(np.float32)
+        avg = torch.from_numpy(np.ascontiguousarray(np.stack((one, one), axis=1))).to(dev)
     asg = torch.from_numpy(assigned).to(dev)
     losses = torch.zeros((Lyr, 2), dtype=torch.float32, device=dev)
     d_cls = torch.empty_like(all_cls)

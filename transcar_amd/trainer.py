@@ -159,7 +159,8 @@ class FusionTrainer:
                         gt_labels_list, lr=None, update=True):
         """update=False stops after the backward: the gradients sit in the bucket."""
         head, lib = self.head, L.lib()
-        head.train()
+        if not head.training:                      # (Module.train() walks ~380 submodules: 0.7 ms of host time per call)
+            head.train()
         from .detr3d_head import head_options
         drop_seed = head.next_dropout_seed()       # (seed, rank, forward counter): shared with forward_train_nhwc
         with torch.no_grad():
@@ -213,7 +214,11 @@ class FusionTrainer:
             total.backward()                               # d loss / d outputs only
             d_cls, d_box = cls_leaf.grad.contiguous(), box_leaf.grad.contiguous()
         self.bucket.zero_grad()
-        g = grad_table(head)
+        # the gradient pointers are views into the flat bucket: they do not move between iterations
+        gkey = self.bucket.grads.data_ptr()
+        if getattr(self, '_gtab_key', None) != gkey:
+            self._gtab, self._gtab_key = grad_table(head), gkey
+        g = self._gtab
         if self.chain_backward:
             if getattr(self, '_bws_key', None) != key:
                 nb = lib.tc_radar_train_bwd_workspace_bytes(C.byref(w), B, T)
