@@ -96,6 +96,9 @@ def parse(argv=None):
     ap.add_argument('--train-autograd', action='store_true',
                     help='with --train: the per-operator autograd path instead of the two-call '
                          'fused forward/backward of the trainable stack')
+    ap.add_argument('--no-prefetch', action='store_true',
+                    help='with --train: do not enqueue the next iteration\'s frozen decoder forward while the host '
+                         'solves the assignment')
     ap.add_argument('--train', action='store_true',
                     help='time one DDP training iteration of the fusion head (configs[2]) '
                          'instead of inference')
@@ -885,9 +888,17 @@ def train_bench(args, head, inp, dev, rank, world, affinity=None):
     tr = FusionTrainer(thead)
     last = {}
 
+    # the next iteration's frame is known one step ahead (a data loader's look-ahead; here the same synthetic
+    # frame): its FROZEN decoder forward is enqueued while the host solves this iteration's assignment
+    nxt = None if (args.train_autograd or args.no_prefetch) else dict(
+        feats_nhwc=inp['nhwc'], lidar2img=inp['l2i'], img_hw=inp['hw'], tokens=inp['tokens'], pad_mult=inp['pad_mult'])
+
     def step():
-        fn = tr.step_nhwc if args.train_autograd else tr.step_fused_nhwc
-        last['losses'] = fn(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'], inp['pad_mult'], gts, lbs)
+        if args.train_autograd:
+            last['losses'] = tr.step_nhwc(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'], inp['pad_mult'], gts, lbs)
+        else:
+            last['losses'] = tr.step_fused_nhwc(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'], inp['pad_mult'],
+                                                gts, lbs, prefetch=nxt)
 
     census = rank_census(dev, world)
     med, win = timed_windows(step, torch.cuda.synchronize, args, dev, world)

@@ -718,3 +718,39 @@ def test_chain_backward_equals_operator_backward(A, golden_dir, tag, p):
         assert d <= 2e-4 * max(scale, 1e-6) + 1e-7, (n, d, scale)
         worst = max(worst, d / max(scale, 1e-12))
     assert len(res[False]) == 98 - 14 or len(res[False]) >= 84
+
+
+def test_decoder_prefetch_changes_nothing_but_the_schedule(A, golden_dir):
+    """step_fused_nhwc(prefetch=next frame): the frozen decoder's forward of iteration i + 1 is enqueued on a side
+    stream while the host solves iteration i's assignment.  Three optimizer steps with and without it (two frames
+    alternating, dropout on, same seeds): same losses, same parameters up to the rounding of the atomics."""
+    from transcar_amd import ops
+    from transcar_amd.trainer import FusionTrainer
+    feats, metas, gt, labels = frame_inputs(golden_dir)
+    frames = []
+    for i in range(2):
+        f = feats if i == 0 else [torch.from_numpy(x).to(dev()) for x in synth.make_feats('tiny', seed=9, smooth=(4, 6))]
+        nhwc = [ops.to_nhwc(x) for x in f]
+        frames.append(dict(feats_nhwc=nhwc, lidar2img=ops.lidar2img_tensor(metas, dev()),
+                           img_hw=metas[0]['img_shape'][0][:2]))
+    res = {}
+    for pre in (False, True):
+        h = train_head(golden_dir)
+        tokens, pad_mult = h.radar_tokens(metas, dev())
+        for fr in frames:
+            fr.update(tokens=tokens, pad_mult=pad_mult)
+        tr = FusionTrainer(h, dropout=0.1, seed=2, lr=1e-3)
+        hist = []
+        for it in range(3):
+            cur, nxt = frames[it % 2], frames[(it + 1) % 2]
+            losses = tr.step_fused_nhwc(cur['feats_nhwc'], cur['lidar2img'], cur['img_hw'], cur['tokens'], cur['pad_mult'],
+                                        [gt], [labels], prefetch=nxt if pre else None)
+            hist.append({k: float(v) for k, v in losses.items()})
+        torch.cuda.synchronize()
+        res[pre] = (hist, tr.bucket.params.clone())
+    for a_, b_ in zip(res[False][0], res[True][0]):
+        for k in a_:
+            assert abs(a_[k] - b_[k]) <= 2e-5 * max(1.0, abs(a_[k])), (k, a_[k], b_[k])
+    # (AdamW normalises the step: the last-bit differences of the atomically summed gradients show up at ~1e-5)
+    d = (res[True][1] - res[False][1]).abs().max() / res[False][1].abs().max()
+    assert float(d) < 1e-4, float(d)

@@ -28,7 +28,7 @@ def gt_tensors(gt_bboxes_list, device):
     return out
 
 
-def detr_loss_device(head, all_cls, all_box, gt_bboxes_list, gt_labels_list):
+def detr_loss_device(head, all_cls, all_box, gt_bboxes_list, gt_labels_list, before_sync=None):
     """-> (loss dict with the reference's keys, d_all_cls, d_all_box, assigned [Lyr,B,Q] numpy).
     The gradients are those of sum(losses) (mmdet ``_parse_losses``)."""
     if head.assigner is None:
@@ -71,6 +71,8 @@ def detr_loss_device(head, all_cls, all_box, gt_bboxes_list, gt_labels_list):
         cnt.data_ptr(), Gmax, float(a.cls_cost.weight), float(a.reg_cost.weight),
         float(getattr(a.cls_cost, 'alpha', 0.25)), float(getattr(a.cls_cost, 'gamma', 2.0)),
         float(getattr(a.cls_cost, 'eps', 1e-12)), cost.data_ptr(), _stream()), 'tc_match_cost')
+    if before_sync is not None:        # work the device can do while the host waits and solves the assignment
+        before_sync()
     cost_h = cost.cpu().numpy()                                   # the iteration's one sync
     assigned = np.full((Lyr, B, Q), -1, dtype=np.int32)
     num_pos = np.zeros(Lyr, dtype=np.float32)

@@ -155,19 +155,63 @@ class FusionTrainer:
     # fast path: the trainable stack as two C calls (tc_radar_train_fwd / _bwd) instead of
     # ~160 autograd nodes; torch autograd only differentiates the loss itself
     # ------------------------------------------------------------------
+    def _decoder_forward(self, feats_nhwc, lidar2img, img_hw, tokens, pad_mult, seed, lane):
+        from .detr3d_head import head_options
+        with torch.no_grad():
+            return self.head.forward_nhwc(feats_nhwc, lidar2img, img_hw, tokens, pad_mult, aux=True,
+                                          _allow_train=True, decoder_only=True, lane=lane,
+                                          options=head_options(decoder_dropout_p=self.decoder_dropout,
+                                                               dropout_seed=seed))
+
+    @staticmethod
+    def _input_key(feats_nhwc, lidar2img, tokens, pad_mult):
+        return (tuple(int(f.data_ptr()) for f in feats_nhwc), int(lidar2img.data_ptr()), int(tokens.data_ptr()),
+                int(pad_mult), tuple(tokens.shape))
+
+    def prefetch_decoder(self, feats_nhwc, lidar2img, img_hw, tokens, pad_mult):
+        """Enqueue the FROZEN decoder's forward of the NEXT iteration now, on a side stream: it depends on nothing
+        this iteration trains (tools/train.py:245-252 freezes it), so it runs while the host waits for the cost
+        matrix and solves the Hungarian assignment (device idle otherwise: ~0.25 ms of a 1.5 ms iteration) and
+        beside the backward.  The inputs must stay untouched until that iteration; its dropout seed is drawn here
+        (same order of seeds as without prefetching).  step_fused_nhwc(prefetch=...) calls this at the right
+        moment."""
+        head = self.head
+        if not head.training:
+            head.train()
+        cur = torch.cuda.current_stream()
+        if getattr(self, '_pre_stream', None) is None:
+            self._pre_stream = torch.cuda.Stream()
+        seed = head.next_dropout_seed()
+        lane = 1 - getattr(self, '_lane', 0)
+        self._pre_stream.wait_stream(cur)                      # inputs written on the current stream are complete
+        with torch.cuda.stream(self._pre_stream):
+            base = self._decoder_forward(feats_nhwc, lidar2img, img_hw, tokens, pad_mult, seed, lane)
+            ev = torch.cuda.Event()
+            ev.record(self._pre_stream)
+        for t in base['aux'].values():
+            if torch.is_tensor(t):
+                t.record_stream(cur)                           # allocated on the side stream, consumed on this one
+        self._pre = dict(key=self._input_key(feats_nhwc, lidar2img, tokens, pad_mult), seed=seed, base=base, ev=ev,
+                         lane=lane)
+
     def step_fused_nhwc(self, feats_nhwc, lidar2img, img_hw, tokens, pad_mult, gt_bboxes_list,
-                        gt_labels_list, lr=None, update=True):
-        """update=False stops after the backward: the gradients sit in the bucket."""
+                        gt_labels_list, lr=None, update=True, prefetch=None):
+        """update=False stops after the backward: the gradients sit in the bucket.
+        prefetch: dict(feats_nhwc, lidar2img, img_hw, tokens, pad_mult) of the NEXT iteration's frame: its frozen
+        decoder forward is enqueued on a side stream once this iteration's cost matrix is on its way
+        (``prefetch_decoder``); the next call picks the result up when it is handed the same tensors."""
         head, lib = self.head, L.lib()
         if not head.training:                      # (Module.train() walks ~380 submodules: 0.7 ms of host time per call)
             head.train()
-        from .detr3d_head import head_options
-        drop_seed = head.next_dropout_seed()       # (seed, rank, forward counter): shared with forward_train_nhwc
-        with torch.no_grad():
-            base = head.forward_nhwc(feats_nhwc, lidar2img, img_hw, tokens, pad_mult, aux=True,
-                                     _allow_train=True, decoder_only=True,
-                                     options=head_options(decoder_dropout_p=self.decoder_dropout,
-                                                          dropout_seed=drop_seed))
+        pre, self._pre = getattr(self, '_pre', None), None
+        if pre is not None and pre['key'] == self._input_key(feats_nhwc, lidar2img, tokens, pad_mult):
+            torch.cuda.current_stream().wait_event(pre['ev'])
+            base, drop_seed, self._lane = pre['base'], pre['seed'], pre['lane']
+            head.last_dropout_seed = drop_seed
+        else:
+            drop_seed = head.next_dropout_seed()   # (seed, rank, forward counter): shared with forward_train_nhwc
+            base = self._decoder_forward(feats_nhwc, lidar2img, img_hw, tokens, pad_mult, drop_seed,
+                                         getattr(self, '_lane', 0))
         aux = base['aux']
         w = head.head_weights()
         B, T = lidar2img.shape[0], tokens.shape[1]
@@ -202,8 +246,9 @@ class FusionTrainer:
                 self.dropout, drop_seed, self._stream()), 'tc_radar_train_fwd')
         if self.device_loss:
             from .device_loss import detr_loss_device
+            hook = (lambda: self.prefetch_decoder(**prefetch)) if prefetch is not None else None
             losses, d_cls, d_box, _ = detr_loss_device(head, all_cls, all_box, gt_bboxes_list,
-                                                       gt_labels_list)
+                                                       gt_labels_list, before_sync=hook)
         else:                                              # the reference's PyTorch loss + autograd
             cls_leaf = all_cls.requires_grad_(True)
             box_leaf = all_box.requires_grad_(True)
