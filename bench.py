@@ -922,10 +922,90 @@ def train_bench(args, head, inp, dev, rank, world, affinity=None):
                    'final_loss': float(sum(last['losses'].values()))},
     }
     if rank == 0:
+        if not args.no_roofline:
+            line['roofline'] = train_roofline(tr, thead, inp, gts, lbs, nxt, dev)
         print(json.dumps(line), flush=True)
     D.barrier()
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def train_roofline(tr, thead, inp, gts, lbs, nxt, dev):
+    """The training iteration's kernels timed live (HIP events around eager launches of the same C calls the timed
+    loop makes, nothing else on the GPU) against the f32 MFMA peak.  Algorithmic flop of one frame (900 queries,
+    T radar tokens): frozen decoder chain 1.431 GF per layer (the bench's inference figure) and the attention core;
+    the trainable stack's forward = 3 fusion layers (all rows: nothing is skipped in training) + the encoders; its
+    backward = the data gradients (the same products transposed, without the first layer's input) + the weight
+    gradients (one product per weight over all rows)."""
+    import ctypes as C
+    head = thead
+    lib = L.lib()
+    B, T_tok = inp['l2i'].shape[0], int(inp['tokens'].shape[1])
+    Q, Cd, F, code, ncls, RI = head.num_query, head.embed_dims, 512, head.code_size, head.cls_out_channels, 36
+    M = B * Q
+
+    def ev_time(fn, n=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+    # a full iteration once, so that tape / workspace / outputs of the stack exist
+    tr.step_fused_nhwc(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'], inp['pad_mult'], gts, lbs, update=False)
+    torch.cuda.synchronize()
+    seed = 12345
+    dec_ms = ev_time(lambda: tr._decoder_forward(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'], inp['pad_mult'], seed, 0))
+    base = tr._decoder_forward(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'], inp['pad_mult'], seed, 0)
+    aux = base['aux']
+    hs_last, ref_last, last_box = aux['inter_states'][-1].contiguous(), aux['inter_references'][-1].contiguous(), aux['last_box']
+    w, pv = head.head_weights(), head._packed_view
+    all_cls = torch.empty((3, B, Q, ncls), device=dev)
+    all_box = torch.empty((3, B, Q, code), device=dev)
+    tape, bws = tr._tape, tr._bws
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def fwd():
+        L.check(lib.tc_head_repack_trainable_ex(C.byref(w), C.byref(pv), 1, st), 'repack')
+        L.check(lib.tc_radar_train_fwd_fused(C.byref(pv), hs_last.data_ptr(), ref_last.data_ptr(), last_box.data_ptr(),
+                                             inp['tokens'].data_ptr(), B, T_tok, int(inp['pad_mult']), all_cls.data_ptr(),
+                                             all_box.data_ptr(), tape.data_ptr(), tape.numel(), tr.dropout, seed, st), 'fwd')
+    fwd_ms = ev_time(fwd)
+    from transcar_amd.trainer import grad_table
+    g = grad_table(head)
+    d_cls, d_box = torch.randn_like(all_cls) * 1e-3, torch.randn_like(all_box) * 1e-3
+
+    def bwd():
+        L.check(lib.tc_radar_train_bwd_fused(C.byref(w), C.byref(g), hs_last.data_ptr(), last_box.data_ptr(),
+                                             inp['tokens'].data_ptr(), B, T_tok, int(inp['pad_mult']), all_box.data_ptr(),
+                                             d_cls.data_ptr(), d_box.data_ptr(), tape.data_ptr(), tape.numel(),
+                                             bws.data_ptr(), bws.numel(), tr.dropout, seed, st), 'bwd')
+    bwd_ms = ev_time(bwd)
+    tr.bucket.zero_grad()
+    layer = Cd * Cd * 6 + 2 * Cd * F + Cd * (code + ncls)           # MAC per row of one fusion layer's linears
+    enc = 3 * Cd + Cd * Cd + RI * 64 + 64 * 128 + 128 * Cd + 3 * Cd * 2 * Cd
+    stack_fwd = 2.0 * (3 * M * layer + B * T_tok * enc)
+    dec = 6 * 2.0 * M * (5 * Cd * Cd + Cd * 24 + 2 * Cd * F + 3 * Cd * Cd + Cd * code) - 2.0 * M * 3 * Cd * Cd \
+        + 6 * 4.0 * Q * Q * 32 * 8 * B
+    stack_bwd = 2.0 * stack_fwd - 2.0 * M * Cd * Cd                   # no data gradient into the frozen decoder
+    parts = {'frozen decoder forward (6 chains + 6 attention cores, train mode)': (dec, dec_ms),
+             'stack forward (re-pack + encoder chain + fusion chain with tape)': (stack_fwd, fwd_ms),
+             'stack backward (pack^T + backward chain + token side + grouped weight GEMM)': (stack_bwd, bwd_ms)}
+    out = {'bound': 'mfma', 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'parts': {}}
+    tot_f, tot_ms = 0.0, 0.0
+    for k, (fl, ms) in parts.items():
+        out['parts'][k] = {'alg_flop': fl, 'ms': ms, 'achieved': fl / ms / 1e9, 'frac': fl / ms / 1e9 / F32_MFMA_PEAK_TFLOPS}
+        tot_f += fl
+        tot_ms += ms
+    out.update(alg_flop=tot_f, ms=tot_ms, achieved=tot_f / tot_ms / 1e9, frac=tot_f / tot_ms / 1e9 / F32_MFMA_PEAK_TFLOPS,
+               kernel='the three device phases of an iteration (decoder forward, stack forward, stack backward)',
+               traffic=None, note='one frame per GPU (CFG:188): 4-row tiles, bound by the weight stream of a workgroup '
+                                  '(DESIGN.md section 5), not by the matrix pipe')
+    return out
 
 
 def auto_frames_per_launch(head, dev):

@@ -180,3 +180,22 @@ def test_shard_frames_partition():
     for world in (1, 2, 4, 8):
         seen = sorted(i for r in range(world) for i in D.shard_frames(37, r, world))
         assert seen == list(range(37))
+
+
+def test_radar_frame_descriptor_layout_and_rotations():
+    """ops.RadarRawStage packs tc_radar_frame_desc through a numpy structured dtype: same size and field offsets as
+    the ctypes mirror of include/transcar_hip.h, and the vectorised quaternion -> matrix conversion of
+    ops.radar_raw_arrays is bit-identical to radar.quaternion_rotation_matrix (the host builder's)."""
+    import ctypes as C
+    from transcar_amd import _lib as L, ops, radar as R
+    dt = ops.RadarRawStage.DESC_DTYPE
+    assert dt.itemsize == C.sizeof(L.tc_radar_frame_desc)
+    for name in ('chan_start', 'num_chan', 'radar_rot', 'lidar_rot', 'point_range'):
+        assert dt.fields[name][1] == getattr(L.tc_radar_frame_desc, name).offset, name
+    for seed in range(4):
+        fr = synth.make_radar_frame(seed=seed, n_per_radar=[3, 0, 5, 1, 2])
+        raw, times, start, rr, lr = ops.radar_raw_arrays(fr)
+        assert raw.shape == (11, 18) and times.shape == (11,) and list(start) == [0, 3, 3, 8, 9, 11]
+        for i, c in enumerate(R.RADAR_CHANNELS):
+            assert np.array_equal(rr[i], R.quaternion_rotation_matrix(fr['radar_rot'][c]).reshape(9))
+        assert np.array_equal(lr, R.quaternion_rotation_matrix(fr['lidar_rot']).reshape(9))

@@ -301,8 +301,14 @@ def radar_raw_arrays(frame):
         times.append(t)
         start.append(start[-1] + p.shape[1])
     raw = np.ascontiguousarray(np.concatenate(raws, 0)) if start[-1] else np.zeros((0, 18))
-    rr = np.stack([R.quaternion_rotation_matrix(frame['radar_rot'][c]).reshape(9) for c in R.RADAR_CHANNELS])
-    lr = R.quaternion_rotation_matrix(frame['lidar_rot']).reshape(9)
+    # the six quaternions at once (same formula and operation order as radar.quaternion_rotation_matrix)
+    q = np.asarray([frame['radar_rot'][c] for c in R.RADAR_CHANNELS] + [frame['lidar_rot']], dtype=np.float64)
+    q = q / np.asarray([np.linalg.norm(v) for v in q])[:, None]     # (the scalar norm of the host builder: bit-identical)
+    w_, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    m = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w_), 2 * (x * z + y * w_),
+                  2 * (x * y + z * w_), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w_),
+                  2 * (x * z - y * w_), 2 * (y * z + x * w_), 1 - 2 * (x * x + y * y)], axis=1)
+    rr, lr = m[:-1], m[-1]
     return raw, np.concatenate(times) if start[-1] else np.zeros(0), np.asarray(start, np.int32), rr, lr
 
 
@@ -360,10 +366,16 @@ class RadarRawStage:
             self._pack(j, None)
         self.desc.copy_(self.h_desc)
 
+    #: numpy view of tc_radar_frame_desc (same field offsets: checked against the ctypes struct at import)
+    DESC_DTYPE = np.dtype([('chan_start', np.int32, (L.TC_MAX_RADAR_CHANNELS + 1,)), ('num_chan', np.int32),
+                           ('radar_rot', np.float64, (L.TC_MAX_RADAR_CHANNELS * 9,)), ('lidar_rot', np.float64, (9,)),
+                           ('point_range', np.float64, (6,))], align=True)
+
     def _pack(self, slot, frame):
         from . import radar as R
-        d = L.tc_radar_frame_desc()
-        d.num_chan = len(R.RADAR_CHANNELS)
+        d = np.zeros(1, dtype=self.DESC_DTYPE)[0]
+        nc = len(R.RADAR_CHANNELS)
+        d['num_chan'] = nc
         n = 0
         if frame is not None:
             raw, times, start, rr, lr = radar_raw_arrays(frame)
@@ -373,17 +385,12 @@ class RadarRawStage:
             if n:
                 self.h_raw[slot, :n] = torch.from_numpy(raw)
                 self.h_times[slot, :n] = torch.from_numpy(times)
-            for c in range(len(start)):
-                d.chan_start[c] = int(start[c])
-            for c in range(len(start), L.TC_MAX_RADAR_CHANNELS + 1):
-                d.chan_start[c] = n
-            for i, v in enumerate(rr.reshape(-1)):
-                d.radar_rot[i] = float(v)
-            for i, v in enumerate(lr.reshape(-1)):
-                d.lidar_rot[i] = float(v)
-        for i, v in enumerate(self.point_range):
-            d.point_range[i] = v
-        self.h_desc[slot] = torch.frombuffer(bytearray(bytes(d)), dtype=torch.uint8)
+            d['chan_start'][:len(start)] = start
+            d['chan_start'][len(start):] = n
+            d['radar_rot'][:rr.size] = rr.reshape(-1)
+            d['lidar_rot'][:] = lr.reshape(-1)
+        d['point_range'][:] = self.point_range
+        self.h_desc[slot] = torch.from_numpy(np.frombuffer(d.tobytes(), dtype=np.uint8).copy())
         self.n_raw[slot] = n
         return n
 
