@@ -400,10 +400,10 @@ def roofline(head, inp, dev):
     pmc = {}
     try:
         # {kernel: {"<frames per launch>": {"traffic_bytes": ...}}}, written by tools/collect_profile.py
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r2_pmc.json')))
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r3_pmc.json')))
         ent = pmc.get(dom, {}).get(str(B))
         if ent:
-            traffic, src = ent['traffic_bytes'], 'profiles/r2_pmc.json'
+            traffic, src = ent['traffic_bytes'], 'profiles/r3_pmc.json'
     except Exception:
         pass
     # algorithmic flop of the whole path per frame: 6 decoder chains (the last without the next

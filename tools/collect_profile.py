@@ -131,7 +131,7 @@ def main():
     for r in rows:
         r['K'] = prog_label(r['Kernel_Name'])
     dec = [i for i, r in enumerate(rows) if 'box_decode' in r['Kernel_Name']]
-    out = ['# one replay of `bench.py --lanes 1` (hipGraph; 8 frames per launch sequence, the default at 200 steps) from rocprofv3 --kernel-trace on MI355X; us',
+    out = ['# one replay of `bench.py --lanes 1` (hipGraph; 9 frames per launch sequence, the default) from rocprofv3 --kernel-trace on MI355X; us',
            '# %-44s %10s %10s %10s' % ('kernel', 'grid', 'start', 'dur')]
     if len(dec) >= 2:
         a, b = dec[-2] + 1, dec[-1] + 1
@@ -165,7 +165,7 @@ def main():
             r['K'] = prog_label(r['Kernel_Name'])
         lrows.sort(key=lambda r: int(r['Start_Timestamp']))
         dec = [i for i, r in enumerate(lrows) if 'box_decode' in r['Kernel_Name']]
-        lo = ['# `bench.py` (default: 3 lanes in flight, one hipGraph + HIP stream each, 8 frames per launch sequence) from rocprofv3',
+        lo = ['# `bench.py` (default: 3 lanes in flight, one hipGraph + HIP stream each, 9 frames per launch sequence) from rocprofv3',
               '# --kernel-trace on MI355X: the kernels of ~3 consecutive launch sequences in start order; us',
               '# %-44s %8s %10s %10s' % ('kernel', 'stream', 'start', 'dur')]
         if len(dec) >= 40:
@@ -197,7 +197,7 @@ def main():
     out_m['_comment'] = ('rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES of the same command; second key = '
                          'frames per launch.  The counter sums matrix-pipe busy cycles over the 1024 SIMDs (8 per '
                          'v_mfma_f32_4x4x1, 32 per 16x16x4 f32); utilisation = busy / (1024 * duration * 2.4 GHz).')
-    for B in ('1', '2', '4', '8', '10'):
+    for B in ('1', '2', '4', '8', '9', '10'):
         per = defaultdict(dict)
         for ctr in ('FETCH_SIZE', 'WRITE_SIZE', 'SQ_VALU_MFMA_BUSY_CYCLES'):
             fs = glob.glob(os.path.join(src, 'pmc_%s_b%s' % (ctr, B), '*', '*counter_collection.csv'))
