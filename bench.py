@@ -374,7 +374,23 @@ def roofline(head, inp, dev):
     run_radar()                           # encoders + K/V once ...
     ropt.reuse_radar_kv = 1               # ... then the chain alone
     radar_ms = time_events(run_radar)
-    radar_flop = 3 * 2.0 * M * (6 * Cd * Cd + 2 * Cd * F + 2 * Cd * code)
+    radar_flop = 3 * 2.0 * M * (6 * Cd * Cd + 2 * Cd * F + 2 * Cd * code)        # the reference's flop (HEAD:538-729)
+    # EXECUTED flop (the canonical count): the q projection and the out_proj of a fusion layer run only in
+    # row tiles that hold a query with a radar return inside its gate (the others are x + 0 * (...), skipped); the
+    # rows are ordered hits first per sample beyond one frame per launch, so a sample's n hit rows occupy
+    # ceil(n / R) tiles (+ 1 where a tile straddles two samples)
+    hits_l = o['aux']['radar_hit_counts'].cpu().numpy() > 0                         # [3, B, Q]
+    R_tile = 4 if M <= 1024 else 8 if M <= 2048 else 16
+    gated_rows = 0
+    for l in range(3):
+        if M > 1024:                                                                # compacted (automatic rule)
+            gated_rows += sum(min(Q, (-(-int(hits_l[l, b].sum()) // R_tile) + 1) * R_tile) for b in range(B))
+        else:                                                                       # own order: tiles that hold a hit
+            flat = hits_l[l].reshape(-1)
+            pad = (-len(flat)) % R_tile
+            tiles = np.concatenate([flat, np.zeros(pad, bool)]).reshape(-1, R_tile).any(1)
+            gated_rows += int(tiles.sum()) * R_tile
+    radar_flop_exec = radar_flop - 2.0 * (3 * M - gated_rows) * 2 * Cd * Cd
     kern = {
         'chain_kernel(decoder layer)': dict(
             bound='mfma', achieved=chain_flop / chain_ms / 1e9, peak=F32_MFMA_PEAK_TFLOPS,
@@ -383,8 +399,10 @@ def roofline(head, inp, dev):
             bound='mfma', achieved=attn_flop / attn_ms / 1e9, peak=F32_MFMA_PEAK_TFLOPS,
             unit='TFLOP/s', ms=attn_ms, per_frame=6, alg_flop=attn_flop),
         'chain_kernel(radar fusion)': dict(
-            bound='mfma', achieved=radar_flop / radar_ms / 1e9, peak=F32_MFMA_PEAK_TFLOPS,
-            unit='TFLOP/s', ms=radar_ms, per_frame=1, alg_flop=radar_flop),
+            bound='mfma', achieved=radar_flop_exec / radar_ms / 1e9, peak=F32_MFMA_PEAK_TFLOPS,
+            unit='TFLOP/s', ms=radar_ms, per_frame=1, alg_flop=radar_flop_exec, reference_flop=radar_flop,
+            gated_rows=gated_rows, note='achieved / frac count EXECUTED flop: q-proj and out_proj only in row tiles '
+                                        'that hold a query with a radar hit (the reference computes them for every query)'),
         'cam_sample_kernel': dict(
             bound='hbm', achieved=cam_bytes / cam_ms / 1e6, peak=HBM_PEAK_GBS, unit='GB/s',
             ms=cam_ms, per_frame=0, alg_bytes=cam_bytes, visible_pairs=pairs,
@@ -413,12 +431,15 @@ def roofline(head, inp, dev):
     path_flop = (nly * chain_flop - 2.0 * M * 3 * Cd * Cd
                  + (nly - 1) * attn_flop
                  + 2.0 * B * T_tok * (3 * Cd + Cd * Cd + 36 * 64 + 64 * 128 + 128 * Cd + 3 * Cd * 2 * Cd)
-                 + 3 * 2.0 * M * (6 * Cd * Cd + 2 * Cd * F + 2 * Cd * code)) / B
+                 + radar_flop_exec) / B
     r.update(path_flop_per_frame=path_flop)
     r.update(kernel=dom, traffic=traffic, traffic_source=src,
              others={n: dict({kk: v[kk] for kk in ('bound', 'achieved', 'peak', 'unit', 'frac', 'ms', 'per_frame')},
                              traffic=(pmc.get(n, {}).get(str(B)) or {}).get('traffic_bytes'))
                      for n, v in kern.items() if n != dom})
+    for n, v in kern.items():                       # (the radar chain's executed / reference flop ride along)
+        if n != dom and 'reference_flop' in v:
+            r['others'][n].update(alg_flop=v['alg_flop'], reference_flop=v['reference_flop'], note=v['note'])
     return r
 
 
@@ -983,7 +1004,7 @@ def train_roofline(tr, thead, inp, gts, lbs, nxt, dev):
         L.check(lib.tc_radar_train_bwd_fused(C.byref(w), C.byref(g), hs_last.data_ptr(), last_box.data_ptr(),
                                              inp['tokens'].data_ptr(), B, T_tok, int(inp['pad_mult']), all_box.data_ptr(),
                                              d_cls.data_ptr(), d_box.data_ptr(), tape.data_ptr(), tape.numel(),
-                                             bws.data_ptr(), bws.numel(), tr.dropout, seed, st), 'bwd')
+                                             bws.data_ptr(), bws.numel(), tr.dropout, seed, None, st), 'bwd')
     bwd_ms = ev_time(bwd)
     tr.bucket.zero_grad()
     layer = Cd * Cd * 6 + 2 * Cd * F + Cd * (code + ncls)           # MAC per row of one fusion layer's linears

@@ -521,7 +521,12 @@ int tc_radar_train_bwd_fused(const tc_head_weights* w, const tc_head_weights* gr
                              const float* last_box, const float* radar_tokens, int B, int T, int pad_mult,
                              const float* all_bbox_preds, const float* d_all_cls, const float* d_all_box,
                              void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes,
-                             float dropout_p, unsigned long long dropout_seed, tc_stream_t stream);
+                             float dropout_p, unsigned long long dropout_seed, const float* layer_losses,
+                             tc_stream_t stream);
+/* layer_losses: optional device [num_radar_layers, 2] = (loss_cls, loss_bbox) of each level as tc_detr_loss_fwd_bwd
+ * wrote them: a level whose loss is not finite sends no gradient down and non-finite gradient elements count
+ * as 0 (HEAD:915-916 zeroes such a loss with nan_to_num) -- the guard of transcar_amd/device_loss.py inside the
+ * backward instead of eight elementwise launches in front of it.  NULL: the gradients are taken as given. */
 int tc_dropout_mask(float dropout_p, unsigned long long seed, int site, size_t n, float* out,
                     tc_stream_t stream);
 

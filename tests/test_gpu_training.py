@@ -754,3 +754,46 @@ def test_decoder_prefetch_changes_nothing_but_the_schedule(A, golden_dir):
     # (AdamW normalises the step: the last-bit differences of the atomically summed gradients show up at ~1e-5)
     d = (res[True][1] - res[False][1]).abs().max() / res[False][1].abs().max()
     assert float(d) < 1e-4, float(d)
+
+
+def test_backward_chain_guards_non_finite_loss_gradients(A, golden_dir):
+    """HEAD:915-916 zeroes a non-finite loss; its gradient must not reach the bucket either.  With the fused
+    backward that guard lives INSIDE the backward chain (tc_radar_train_bwd_fused(layer_losses=...)): a level whose
+    loss is NaN / inf sends nothing down and non-finite gradient elements count as 0 -- the same gradients as
+    applying torch.where / nan_to_num in front of an unguarded call."""
+    import ctypes as C
+    from transcar_amd import _lib as L, ops
+    from transcar_amd.trainer import FusionTrainer
+    h = train_head(golden_dir)
+    feats, metas, gt, labels = frame_inputs(golden_dir)
+    nhwc = [ops.to_nhwc(f) for f in feats]
+    l2i = ops.lidar2img_tensor(metas, dev())
+    tokens, pad_mult = h.radar_tokens(metas, dev())
+    tr = FusionTrainer(h, dropout=0.1, seed=4, decoder_dropout=0.0)
+    tr.keep_last = True
+    tr.step_fused_nhwc(nhwc, l2i, metas[0]['img_shape'][0][:2], tokens, pad_mult, [gt], [labels], update=False)
+    k = tr._last
+    lib = L.lib()
+    d_cls, d_box = k['d_cls'].clone(), k['d_box'].clone()
+    d_cls[2, 0, 5, 3] = float('nan')
+    d_box[0, 0, 7, 1] = float('inf')
+    losses = torch.tensor([[0.7, 1.1], [float('nan'), 0.9], [0.5, float('inf')]], dtype=torch.float32, device=dev())
+
+    def run(dc, db, lv):
+        tr.bucket.zero_grad()
+        L.check(lib.tc_radar_train_bwd_fused(
+            C.byref(k['w']), C.byref(k['g']), k['hs_last'].data_ptr(), k['last_box'].data_ptr(), k['tokens'].data_ptr(),
+            k['B'], k['T'], k['pad_mult'], k['all_box'].data_ptr(), dc.data_ptr(), db.data_ptr(), k['tape'].data_ptr(),
+            k['tape'].numel(), tr._bws.data_ptr(), tr._bws.numel(), tr.dropout, k['seed'],
+            lv.data_ptr() if lv is not None else None, tr._stream()), 'bwd')
+        torch.cuda.synchronize()
+        return tr.bucket.grads.clone()
+    got = run(d_cls, d_box, losses)
+    fin = torch.isfinite(losses)
+    gc = torch.where(fin[:, 0].view(3, 1, 1, 1), torch.nan_to_num(d_cls, nan=0.0, posinf=0.0, neginf=0.0), torch.zeros_like(d_cls))
+    gb = torch.where(fin[:, 1].view(3, 1, 1, 1), torch.nan_to_num(d_box, nan=0.0, posinf=0.0, neginf=0.0), torch.zeros_like(d_box))
+    want = run(gc.contiguous(), gb.contiguous(), None)
+    assert torch.isfinite(got).all() and torch.isfinite(want).all()
+    assert float(want.abs().max()) > 0
+    d = (got - want).abs().max() / want.abs().max()
+    assert float(d) < 1e-5, float(d)

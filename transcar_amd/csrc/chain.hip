@@ -299,8 +299,8 @@ constexpr StepDesc PROG_RADAR_BWD_T[] = {
     {K_LINEAR, 0, -1, 256, 256, B_U1, B_NONE, B_X, B_X, 0, F_NOT_LAYER0, G_NONE, G_NONE, 1},             // 18 Wq^T + d x1 = d(layer in)
     {K_END, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
 // the dY tensors stored by the steps above (layer r at + r * dy_stride floats) ...
-enum DSel : short { D_NONE = -1, D_DBOX = 0, D_DT1, D_DT0, D_DC2, D_DC0, D_DFF, D_DH, D_DPROJ, D_DQP, D_COUNT };
-constexpr short BWD_STORE[19] = {D_DBOX, D_DT1, D_DT0, D_NONE, D_NONE, D_NONE, D_DC2, D_NONE, D_DC0, D_NONE, D_NONE, D_DFF,
+enum DSel : short { D_NONE = -1, D_DBOX = 0, D_DT1, D_DT0, D_DC2, D_DC0, D_DFF, D_DH, D_DPROJ, D_DQP, D_DCLS, D_COUNT };
+constexpr short BWD_STORE[19] = {D_DBOX, D_DT1, D_DT0, D_NONE, D_DCLS, D_NONE, D_DC2, D_NONE, D_DC0, D_NONE, D_NONE, D_DFF,
                                  D_DH, D_NONE, D_NONE, D_DPROJ, D_NONE, D_DQP, D_NONE};
 enum Program : int { PROG_PROLOGUE = 0, PROG_DECODER, PROG_RADAR_ENC, PROG_RADAR, PROG_RADAR_ENC_A, PROG_RADAR_ENC_B,
                      PROG_RADAR_TRAIN, PROG_RADAR_ENC_TRAIN, PROG_RADAR_BWD };
@@ -351,6 +351,8 @@ struct ChainDev {
   // backward (PROG_RADAR_BWD), by fusion layer
   const float* bwd_cxy[TC_MAX_RADAR_LAYERS]; int bwd_ldc[TC_MAX_RADAR_LAYERS];   // gate centre of the layer's forward
   const float* bwd_box[TC_MAX_RADAR_LAYERS];                                      // ... and its box (previous level)
+  const float* loss_vals;      // [layers, 2] (cls, bbox) losses of the iteration or null: a layer whose loss is not
+                               // finite sends no gradient down (HEAD:915-916 zeroes such a loss), non-finite elements are 0
 };
 // ... plus what only the host-side resolver needs
 struct ChainK : ChainDev {
@@ -1547,10 +1549,12 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
           const int row = i >> 6, c = i & 63;
           const int grow = min(m0 + row, M - 1);
           float v = c < N ? ldg1(src + (size_t)grow * N + c) : 0.0f;
-          if (carry && c < N) {
-            v += S.box[row][c];
-            if (r.gd != nullptr && m0 + row < M) stg1(r.gd + (size_t)grow * N + c, v);
+          if (k.loss_vals != nullptr) {
+            const float lv = k.loss_vals[2 * (k.nlayers - 1 - rep) + (carry ? 1 : 0)];
+            if (!(fabsf(lv) <= 3.0e38f) || !(fabsf(v) <= 3.0e38f)) v = 0.0f;        // NaN / inf
           }
+          if (carry && c < N) v += S.box[row][c];
+          if (c < N && r.gd != nullptr && m0 + row < M) stg1(r.gd + (size_t)grow * N + c, v);
           dst[row * LD2 + c] = v;
         }
         if (carry) {
@@ -2163,7 +2167,7 @@ int launch_radar_chain_bwd(const RadarBwdChainArgs& a, hipStream_t s) {
   k.tape_stride = a.tape_stride; k.hits_stride = a.hits_stride;
   for (int i = 0; i < D_COUNT; ++i) k.dy[i] = a.dy[i];
   k.dy_stride = a.dy_stride;
-  k.d_cls = a.d_cls; k.d_box = a.d_box;
+  k.d_cls = a.d_cls; k.d_box = a.d_box; k.loss_vals = a.loss_vals;
   k.hits = const_cast<int*>(a.hits);
   k.qscale = a.qscale; k.tokens = a.tokens; k.RI = a.RI; k.T = a.T; k.pad_mult = a.pad_mult;
   k.rdrop = a.drop;

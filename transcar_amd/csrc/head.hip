@@ -163,11 +163,20 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
                               const float* lidar2img, float img_h, float img_w,
                               const float* radar_tokens, int T, int pad_mult, float* all_cls_scores,
                               float* all_bbox_preds, const tc_head_aux* aux, const tc_head_options& opt,
-                              const HeadWs& h, hipStream_t s) {
+                              const HeadWs& h_, hipStream_t s) {
   const int Q = w->num_query, C = w->embed_dims, L = w->num_layers, H = w->num_heads;
   const int code = w->code_size, ncls = w->num_classes;
   const int rows = B * Q, rt = B * T;
   const float attn_qscale = 1.4426950408889634f / sqrtf((float)(C / H));   // 2^x softmax
+  // the caller's aux tensors ARE the buffers the chains write (and read back for the next layer): no copies
+  // at the end of the forward (round 2: four device-to-device copies per forward with aux, e.g. every training
+  // iteration)
+  HeadWs h = h_;
+  if (aux != nullptr) {
+    if (aux->inter_states) h.hs = aux->inter_states;
+    if (aux->inter_references) h.inter_refs = aux->inter_references;
+    if (aux->last_box) h.box_m = aux->last_box;
+  }
   unsigned long long* pairs = aux ? aux->sample_pairs : nullptr;
   const bool radar = w->num_radar_layers > 0;
 
@@ -234,8 +243,6 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
     else TC_TRY(launch_decoder_chain(d, s));
   }
   if (aux) {
-    if (aux->inter_states)
-      TC_HIP(hipMemcpyAsync(aux->inter_states, h.hs, (size_t)L * rows * C * 4, hipMemcpyDeviceToDevice, s));
     if (aux->init_reference) {
       if (folded) {
         for (int b = 0; b < B; ++b)
@@ -245,11 +252,6 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
         TC_HIP(hipMemcpyAsync(aux->init_reference, h.init_ref, (size_t)rows * 3 * 4, hipMemcpyDeviceToDevice, s));
       }
     }
-    if (aux->inter_references)
-      TC_HIP(hipMemcpyAsync(aux->inter_references, h.inter_refs, (size_t)L * rows * 3 * 4,
-                            hipMemcpyDeviceToDevice, s));
-    if (aux->last_box)
-      TC_HIP(hipMemcpyAsync(aux->last_box, h.box_m, (size_t)rows * code * 4, hipMemcpyDeviceToDevice, s));
   }
   if (!radar) return 0;
   RadarChainArgs rc;

@@ -137,7 +137,7 @@ struct RadarChainArgs {
 // Backward of the three fusion layers for the query rows as ONE launch of the row chain (chain.hip
 // PROG_RADAR_BWD): data gradients row-local, every dY a weight gradient needs stored (DySlot order), LayerNorm
 // parameter gradients added into `grads`, dK | dV into dkv[r] (atomics; zero them first).
-enum DySlot { DY_DBOX = 0, DY_DT1, DY_DT0, DY_DC2, DY_DC0, DY_DFF, DY_DH, DY_DPROJ, DY_DQP, DY_COUNT };
+enum DySlot { DY_DBOX = 0, DY_DT1, DY_DT0, DY_DC2, DY_DC0, DY_DFF, DY_DH, DY_DPROJ, DY_DQP, DY_DCLS, DY_COUNT };
 struct RadarBwdChainArgs {
   tc_radar_layer wT[TC_MAX_RADAR_LAYERS];      // TRANSPOSED packed weights (pack.hip, PackJob::transpose)
   tc_radar_layer w[TC_MAX_RADAR_LAYERS];       // the forward's parameters (LayerNorm gamma, radii)
@@ -147,6 +147,7 @@ struct RadarBwdChainArgs {
   float* const* tape; size_t tape_stride, hits_stride; const int* hits;
   float* const* dy; size_t dy_stride;
   const float* d_cls; const float* d_box;      // [layers, M, ncls / code]
+  const float* loss_vals = nullptr;            // optional [layers, 2]: non-finite losses / elements send nothing down
   const float* tokens; int RI, T, pad_mult;
   int nlayers, Q, M, code, ncls;
   float qscale;

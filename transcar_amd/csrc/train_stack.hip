@@ -445,6 +445,8 @@ size_t bwd_ws_layout(const tc_head_weights* w, int B, int T, void* base, size_t 
     float* p1 = a.take<float>(rows * C); float* p2 = a.take<float>(rows * C); float* p3 = a.take<float>(rows * C);
     float* p4 = a.take<float>(rows * C); float* p5 = a.take<float>(rows * C); float* p6 = a.take<float>(rows * F);
     float* p7 = a.take<float>(rows * C); float* p8 = a.take<float>(rows * C);
+    float* p9 = a.take<float>(rows * ncls);
+    if (r == 0) b.dy[DY_DCLS] = p9;
     if (r == 0) {
       b.dy[DY_DT1] = p1; b.dy[DY_DT0] = p2; b.dy[DY_DC2] = p3; b.dy[DY_DC0] = p4; b.dy[DY_DFF] = p5; b.dy[DY_DH] = p6;
       b.dy[DY_DPROJ] = p7; b.dy[DY_DQP] = p8;
@@ -466,7 +468,8 @@ int tc_radar_train_bwd_fused(const tc_head_weights* w, const tc_head_weights* gr
                              const float* last_box, const float* radar_tokens, int B, int T, int pad_mult,
                              const float* all_bbox_preds, const float* d_all_cls, const float* d_all_box,
                              void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes,
-                             float dropout_p, unsigned long long dropout_seed, tc_stream_t stream) {
+                             float dropout_p, unsigned long long dropout_seed, const float* layer_losses,
+                             tc_stream_t stream) {
   TS_TRY(check(w, B, T));
   TC_REQUIRE(grads != nullptr && workspace != nullptr, "radar_train_bwd_fused: null argument");
   TC_REQUIRE(dropout_p >= 0.0f && dropout_p < 1.0f, "radar_train_bwd_fused: dropout_p=%g", (double)dropout_p);
@@ -527,7 +530,7 @@ int tc_radar_train_bwd_fused(const tc_head_weights* w, const tc_head_weights* gr
   a.tape = slots; a.tape_stride = (size_t)(t.L[1].qp - t.L[0].qp);
   a.hits = t.L[0].hits; a.hits_stride = (size_t)(t.L[1].hits - t.L[0].hits);
   a.dy = ws.dy; a.dy_stride = ws.dy_stride;
-  a.d_cls = d_all_cls; a.d_box = d_all_box;
+  a.d_cls = d_all_cls; a.d_box = d_all_box; a.loss_vals = layer_losses;
   a.tokens = radar_tokens; a.RI = RI; a.T = T; a.pad_mult = pad_mult;
   a.nlayers = TC_MAX_RADAR_LAYERS; a.Q = Q; a.M = rows; a.code = code; a.ncls = ncls;
   a.qscale = 1.0f / sqrtf((float)(C / w->num_heads));
@@ -570,7 +573,7 @@ int tc_radar_train_bwd_fused(const tc_head_weights* w, const tc_head_weights* gr
     job(l.h, ws.dy[DY_DFF] + off, gl.linear2, rows, F, C);
     job(l.x3, ws.dy[DY_DC0] + off, gl.final_cls.l0, rows, C, C);
     job(l.c1, ws.dy[DY_DC2] + off, gl.final_cls.l3, rows, C, C);
-    job(l.c3, d_all_cls + (size_t)r * rows * ncls, gl.final_cls.l6, rows, C, ncls);
+    job(l.c3, ws.dy[DY_DCLS] + off, gl.final_cls.l6, rows, C, ncls);        // (the guarded copy the chain stored)
     job(l.x3, ws.dy[DY_DT0] + off, gl.final_reg.l0, rows, C, C);
     job(l.t0, ws.dy[DY_DT1] + off, gl.final_reg.l2, rows, C, C);
     job(l.t1, ws.dy[DY_DBOX] + off, gl.final_reg.l4, rows, C, code);

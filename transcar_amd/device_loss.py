@@ -28,7 +28,7 @@ def gt_tensors(gt_bboxes_list, device):
     return out
 
 
-def detr_loss_device(head, all_cls, all_box, gt_bboxes_list, gt_labels_list, before_sync=None):
+def detr_loss_device(head, all_cls, all_box, gt_bboxes_list, gt_labels_list, before_sync=None, defer_guard=False):
     """-> (loss dict with the reference's keys, d_all_cls, d_all_box, assigned [Lyr,B,Q] numpy).
     The gradients are those of sum(losses) (mmdet ``_parse_losses``)."""
     if head.assigner is None:
@@ -105,6 +105,17 @@ def detr_loss_device(head, all_cls, all_box, gt_bboxes_list, gt_labels_list, bef
         _stream()), 'tc_detr_loss_fwd_bwd')
     # HEAD:915-916 zeroes a non-finite loss (torch.nan_to_num); its gradient must not reach the flat
     # bucket / the Adam moments either: a layer whose loss is not finite contributes nothing
+    if defer_guard:
+        # the consumer applies the guard itself (tc_radar_train_bwd_fused(layer_losses=...): inside the backward
+        # chain instead of eight elementwise launches here); the raw per-level losses travel with the gradients
+        raw = losses
+        losses = torch.nan_to_num(losses, nan=0.0)
+        out = {'loss_cls': losses[Lyr - 1, 0], 'loss_bbox': losses[Lyr - 1, 1]}
+        for i in range(Lyr - 1):
+            out['d%d.loss_cls' % i] = losses[i, 0]
+            out['d%d.loss_bbox' % i] = losses[i, 1]
+        out_raw = raw
+        return out, d_cls, d_box, assigned, out_raw
     fin = torch.isfinite(losses)
     d_cls = torch.where(fin[:, 0].view(Lyr, 1, 1, 1), torch.nan_to_num(d_cls, nan=0.0, posinf=0.0, neginf=0.0),
                         torch.zeros_like(d_cls))

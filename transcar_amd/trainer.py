@@ -244,11 +244,16 @@ class FusionTrainer:
                 C.byref(w), hs_last.data_ptr(), ref_last.data_ptr(), last_box.data_ptr(), tokens.data_ptr(),
                 B, T, int(pad_mult), all_cls.data_ptr(), all_box.data_ptr(), tape.data_ptr(), tape.numel(),
                 self.dropout, drop_seed, self._stream()), 'tc_radar_train_fwd')
+        raw_losses = None
         if self.device_loss:
             from .device_loss import detr_loss_device
             hook = (lambda: self.prefetch_decoder(**prefetch)) if prefetch is not None else None
-            losses, d_cls, d_box, _ = detr_loss_device(head, all_cls, all_box, gt_bboxes_list,
-                                                       gt_labels_list, before_sync=hook)
+            if self.chain_backward:      # the non-finite guard of the loss gradients happens inside the backward chain
+                losses, d_cls, d_box, _, raw_losses = detr_loss_device(
+                    head, all_cls, all_box, gt_bboxes_list, gt_labels_list, before_sync=hook, defer_guard=True)
+            else:
+                losses, d_cls, d_box, _ = detr_loss_device(head, all_cls, all_box, gt_bboxes_list,
+                                                           gt_labels_list, before_sync=hook)
         else:                                              # the reference's PyTorch loss + autograd
             cls_leaf = all_cls.requires_grad_(True)
             box_leaf = all_box.requires_grad_(True)
@@ -274,7 +279,8 @@ class FusionTrainer:
             L.check(lib.tc_radar_train_bwd_fused(
                 C.byref(w), C.byref(g), hs_last.data_ptr(), last_box.data_ptr(), tokens.data_ptr(), B, T,
                 int(pad_mult), all_box.data_ptr(), d_cls.data_ptr(), d_box.data_ptr(), tape.data_ptr(),
-                tape.numel(), self._bws.data_ptr(), self._bws.numel(), self.dropout, drop_seed, self._stream()),
+                tape.numel(), self._bws.data_ptr(), self._bws.numel(), self.dropout, drop_seed,
+                raw_losses.data_ptr() if raw_losses is not None else None, self._stream()),
                 'tc_radar_train_bwd_fused')
         else:
             L.check(lib.tc_radar_train_bwd(
@@ -282,6 +288,9 @@ class FusionTrainer:
                 int(pad_mult), all_box.data_ptr(), d_cls.data_ptr(), d_box.data_ptr(), tape.data_ptr(),
                 tape.numel(), self.dropout, drop_seed, self._stream()), 'tc_radar_train_bwd')
         self.last_dropout_seed = drop_seed
+        if getattr(self, 'keep_last', False):        # tests: the operands of the backward call
+            self._last = dict(w=w, g=g, hs_last=hs_last, last_box=last_box, tokens=tokens, B=B, T=T, pad_mult=int(pad_mult),
+                              all_box=all_box, d_cls=d_cls, d_box=d_box, tape=tape, seed=drop_seed)
         if update:
             self._optimizer_step(lr)
         return {k: v.detach() for k, v in losses.items()}
