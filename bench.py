@@ -674,7 +674,7 @@ def pipeline_latency_side_run(pipe, args, n_frames=None):
                           'after its previous launch completed'}
 
 
-def end_to_end_side_run(head, dev, args, n=6):
+def end_to_end_side_run(head, dev, args, n=12):
     """A PROXY for the detector's per-frame loop (tools/analysis_tools/benchmark.py:64-91 times the whole model):
     a stock PyTorch-ROCm conv backbone + FPN (plain torch.nn / MIOpen, channels_last fp32 -- a LOAD GENERATOR with
     the reference FPN's output contract: 4 levels x 256 channels at strides 8..64 of 6 x 928 x 1600 images, NOT the
