@@ -201,7 +201,8 @@ int launch_linear_bwd_weight(const float* x, const float* dy, const float* relu_
                              const int* row_gate, float* dw, float* db, int M, int K, int N,
                              float alpha, hipStream_t s);
 // every weight gradient of an iteration in one launch (masks already applied to dy): dw += dy^T x, db += colsum dy
-struct WeightJob { const float* x; const float* dy; float* dw; float* db; int M, K, N; const float* relu = nullptr; /* dy is zeroed where relu <= 0 */ };
+struct WeightJob { const float* x; const float* dy; float* dw; float* db; int M, K, N; const float* relu = nullptr; /* dy is zeroed where relu <= 0 */
+                   int ldx = 0; /* row stride of x (0: K) -- the first K columns of a wider matrix */ };
 int launch_linear_bwd_weight_group(const WeightJob* jobs, int n, hipStream_t s);
 int launch_ln256_bwd(const float* a, const float* b, const float* gamma, const float* dy,
                      const float* relu_out, float* dz, float* dgamma, float* dbeta, int M,

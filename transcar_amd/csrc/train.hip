@@ -284,7 +284,7 @@ int launch_linear_bwd_weight_group(const WeightJob* jobs, int n, hipStream_t s) 
                "linear_bwd_weight_group: bad item %d", i);
     BwdGemmK p;
     p.A = j.dy; p.relu = j.relu; p.gate = nullptr; p.Bm = j.x; p.cmask = nullptr; p.C = j.dw;
-    p.colsum = j.db; p.ldA = j.N; p.ldB = j.K; p.ldC = j.K; p.I = j.N; p.J = j.K; p.R = j.M;
+    p.colsum = j.db; p.ldA = j.N; p.ldB = j.ldx > 0 ? j.ldx : j.K; p.ldC = j.K; p.I = j.N; p.J = j.K; p.R = j.M;
     p.rchunk = 128; p.accumulate = 1; p.alpha = 1.0f;
     const int v = bg_vec_ok(p, j.N) ? 1 : 0;
     WGroupItem& it = g[v].it[g[v].n++];

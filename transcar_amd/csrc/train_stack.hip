@@ -282,9 +282,6 @@ int tc_radar_train_fwd_fused(const tc_head_weights* packed_view, const float* hs
   }
   re.radar_feat = nullptr; re.w16_delta = w->packed16_delta; re.tape = slots;
   TS_TRY(launch_radar_encode(re, s));
-  // the padded operands of radar_position_encoder.0's weight gradient (backward only)
-  TS_HIP(hipMemsetAsync(t.xyz4, 0, (size_t)rt * 4 * 4, s));
-  TS_TRY(copy_cols(radar_tokens, RI, t.xyz4, 4, rt, 3, 0, s));
   TS_TRY(launch_radar_ref_l1(ref_last, w->pc_range, t.cxy, t.addref, rows, s));
   // the three fusion layers: one launch
   RadarChainArgs rc;
@@ -404,6 +401,9 @@ int tc_radar_train_bwd(const tc_head_weights* w, const tc_head_weights* grads, c
   TS_TRY(lin_bwd(t.u1, du, nullptr, nullptr, pe.l3, gpe.l3, nullptr, du2, 0, rt, C, C, s));
   TS_TRY(ln_bwd(t.u0, nullptr, pe.n1, gpe.n1, du2, t.u1, du, rt, s));
   TS_HIP(hipMemsetAsync(t.dw0p, 0, (size_t)C * 4 * 4, s));
+  // (the padded xyz operand is rebuilt here: the tape of tc_radar_train_fwd_fused does not carry it)
+  TS_HIP(hipMemsetAsync(t.xyz4, 0, (size_t)rt * 4 * 4, s));
+  TS_TRY(copy_cols(radar_tokens, RI, t.xyz4, 4, rt, 3, 0, s));
   TS_TRY(launch_linear_bwd_weight(t.xyz4, du, nullptr, nullptr, t.dw0p, const_cast<float*>(gpe.l0.b), rt, 4, C,
                                   1.0f, s));
   TS_TRY(copy_cols(t.dw0p, 4, const_cast<float*>(gpe.l0.w), 3, C, 3, 1, s));
@@ -418,6 +418,7 @@ struct BwdWs {
   tc_radar_layer wT[TC_MAX_RADAR_LAYERS];
   float* dy[DY_COUNT]; size_t dy_stride;
   float* dkv[TC_MAX_RADAR_LAYERS];
+  float* dmem;
 };
 size_t bwd_ws_layout(const tc_head_weights* w, int B, int T, void* base, size_t cap, BwdWs* out) {
   const size_t rows = (size_t)B * w->num_query, rt = (size_t)B * T;
@@ -453,7 +454,8 @@ size_t bwd_ws_layout(const tc_head_weights* w, int B, int T, void* base, size_t 
     }
     if (r == 1) b.dy_stride = (size_t)(s0 - first);
   }
-  for (int r = 0; r < TC_MAX_RADAR_LAYERS; ++r) b.dkv[r] = a.take<float>(rt * 2 * C);   // contiguous: one memset
+  for (int r = 0; r < TC_MAX_RADAR_LAYERS; ++r) b.dkv[r] = a.take<float>(rt * 2 * C);   // contiguous with dmem: one memset
+  b.dmem = a.take<float>(rt * C);
   if (out) *out = b;
   return a.off;
 }
@@ -511,8 +513,7 @@ int tc_radar_train_bwd_fused(const tc_head_weights* w, const tc_head_weights* gr
     TS_TRY(launch_pack_group(jobs, n, s));
   }
   // 2. accumulators
-  TS_HIP(hipMemsetAsync(ws.dkv[0], 0, (size_t)TC_MAX_RADAR_LAYERS * rt * 2 * C * 4, s));
-  TS_HIP(hipMemsetAsync(t.dmem, 0, (size_t)rt * C * 4, s));
+  TS_HIP(hipMemsetAsync(ws.dkv[0], 0, (size_t)((char*)(ws.dmem + (size_t)rt * C) - (char*)ws.dkv[0]), s));   // dK|dV x 3 + dmem
   // 3. the query side of all three layers: one launch
   float* slots[TS_COUNT];
   memset(slots, 0, sizeof(slots));
@@ -538,27 +539,28 @@ int tc_radar_train_bwd_fused(const tc_head_weights* w, const tc_head_weights* gr
   TS_TRY(launch_radar_chain_bwd(a, s));
   // 4. the token side: dmem = sum_r dkv_r Wkv_r, then the encoders (data gradients only; weights below)
   for (int r = 0; r < TC_MAX_RADAR_LAYERS; ++r)
-    TS_TRY(launch_linear_bwd_data(ws.dkv[r], nullptr, nullptr, w->radar[r].attn.in_proj.w + (size_t)C * C, nullptr, t.dmem,
+    TS_TRY(launch_linear_bwd_data(ws.dkv[r], nullptr, nullptr, w->radar[r].attn.in_proj.w + (size_t)C * C, nullptr, ws.dmem,
                                   rt, C, 2 * C, 1.0f, 1, s));
   const tc_pos_encoder& pe = w->radar_position_encoder;
   const tc_pos_encoder& gpe = grads->radar_position_encoder;
   // mem = relu(LN4(u2)) + relu(feat4(f1)): both summands see dmem
-  TS_TRY(launch_linear_bwd_data(t.dmem, t.f2, nullptr, w->radar_feat4.w, t.f1, t.dt128, rt, 128, C, 1.0f, 0, s));
+  TS_TRY(launch_linear_bwd_data(ws.dmem, t.f2, nullptr, w->radar_feat4.w, t.f1, t.dt128, rt, 128, C, 1.0f, 0, s));
   TS_TRY(launch_linear_bwd_data(t.dt128, nullptr, nullptr, w->radar_feat2.w, t.f0, t.dt64, rt, 64, 128, 1.0f, 0, s));
   float* du = t.dkv;                 // [rt, C] scratch of the tape
   float* du2 = t.dkv + (size_t)rt * C;
-  TS_TRY(ln_bwd(t.u2, nullptr, pe.n4, gpe.n4, t.dmem, t.pos, du, rt, s));
+  TS_TRY(ln_bwd(t.u2, nullptr, pe.n4, gpe.n4, ws.dmem, t.pos, du, rt, s));
   TS_TRY(launch_linear_bwd_data(du, nullptr, nullptr, pe.l3.w, nullptr, du2, rt, C, C, 1.0f, 0, s));
   float* du0 = t.dqp;                // [rows, C] >= [rt, C]?  rows >= rt is not guaranteed: use dA when it is not
   if ((size_t)rows < (size_t)rt) du0 = t.dh;
   TS_TRY(ln_bwd(t.u0, nullptr, pe.n1, gpe.n1, du2, t.u1, du0, rt, s));
-  TS_HIP(hipMemsetAsync(t.dw0p, 0, (size_t)C * 4 * 4, s));
   // 5. every weight gradient: one grouped launch (two with the scalar variant for the 10-wide heads)
   WeightJob jobs[11 * TC_MAX_RADAR_LAYERS + 5];
   int n = 0;
-  auto job = [&](const float* x, const float* dy, const tc_linear& g, int M, int K, int N, const float* relu = nullptr) {
+  auto job = [&](const float* x, const float* dy, const tc_linear& g, int M, int K, int N, const float* relu = nullptr,
+                 int ldx = 0) {
     WeightJob j;
     j.x = x; j.dy = dy; j.dw = const_cast<float*>(g.w); j.db = const_cast<float*>(g.b); j.M = M; j.K = K; j.N = N; j.relu = relu;
+    j.ldx = ldx;
     jobs[n++] = j;
   };
   for (int r = 0; r < TC_MAX_RADAR_LAYERS; ++r) {
@@ -578,14 +580,13 @@ int tc_radar_train_bwd_fused(const tc_head_weights* w, const tc_head_weights* gr
     job(l.t0, ws.dy[DY_DT1] + off, gl.final_reg.l2, rows, C, C);
     job(l.t1, ws.dy[DY_DBOX] + off, gl.final_reg.l4, rows, C, code);
   }
-  job(t.f1, t.dmem, grads->radar_feat4, rt, 128, C, t.f2);
+  job(t.f1, ws.dmem, grads->radar_feat4, rt, 128, C, t.f2);
   job(t.f0, t.dt128, grads->radar_feat2, rt, 64, 128);
   job(radar_tokens, t.dt64, grads->radar_feat0, rt, RI, 64);
   job(t.u1, du, gpe.l3, rt, C, C);
-  job(t.xyz4, du0, tc_linear{t.dw0p, gpe.l0.b}, rt, 4, C);
-  TS_TRY(launch_linear_bwd_weight_group(jobs, n, s));
-  TS_TRY(copy_cols(t.dw0p, 4, const_cast<float*>(gpe.l0.w), 3, C, 3, 1, s));
-  return 0;
+  // radar_position_encoder.0 (Linear(3, C)): X = the tokens' first three columns (xyz), read in place
+  job(radar_tokens, du0, gpe.l0, rt, 3, C, nullptr, RI);
+  return launch_linear_bwd_weight_group(jobs, n, s);
 }
 
 // The multipliers (0 or 1 / (1 - p)) of elements 0..n-1 of a dropout site, for tests and for

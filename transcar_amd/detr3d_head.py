@@ -436,7 +436,16 @@ class Detr3DHead(BaseModule):
         box = torch.empty((3, B, Q, code), dtype=torch.float32, device=dev)
         fv = ops.feats_view(feats_nhwc)
         aux_s, aux_t = None, None
-        if aux:
+        if aux == 'train':
+            # what a training iteration needs of the frozen decoder (FusionTrainer): its states / references / last box,
+            # written in place by the chains -- no init_reference copy, no pair counter (a zero fill + atomics)
+            Lyr = w.num_layers
+            aux_t = dict(
+                inter_states=torch.empty((Lyr, B, Q, self.embed_dims), dtype=torch.float32, device=dev),
+                inter_references=torch.empty((Lyr, B, Q, 3), dtype=torch.float32, device=dev),
+                last_box=torch.empty((B, Q, code), dtype=torch.float32, device=dev))
+            aux_s = L.tc_head_aux(**{k: t.data_ptr() for k, t in aux_t.items()})
+        elif aux:
             Lyr = w.num_layers
             aux_t = dict(
                 inter_states=torch.empty((Lyr, B, Q, self.embed_dims),

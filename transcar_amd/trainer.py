@@ -35,7 +35,11 @@ class FlatBucket:
         dev = self.items[0].device
         n = sum(p.numel() for p in self.items)
         self.params = torch.empty(n, dtype=torch.float32, device=dev)
-        self.grads = torch.zeros(n, dtype=torch.float32, device=dev)
+        # one allocation: the gradients and, behind them, the squared-norm accumulator of the clip (zeroed by the
+        # same fill)
+        self._store = torch.zeros(n + 1, dtype=torch.float32, device=dev)
+        self.grads = self._store[:n]
+        self.sq = self._store[n:]
         self.offsets = []
         off = 0
         for p in self.items:
@@ -47,8 +51,10 @@ class FlatBucket:
             off += k
         self.numel = n
 
-    def zero_grad(self):
-        self.grads.zero_()
+    def zero_grad(self, check_views=True):
+        self._store.zero_()
+        if not check_views:          # nobody re-bound a .grad since the last call (the fused iteration)
+            return
         for p, off in zip(self.items, self.offsets):     # a None grad would detach the view
             if p.grad is None or p.grad.data_ptr() != self.grads.data_ptr() + 4 * off:
                 p.grad = self.grads[off:off + p.numel()].view(p.shape)
@@ -115,7 +121,7 @@ class FusionTrainer:
         head.refresh_weights()                      # parameter addresses moved into the bucket
         self.m = torch.zeros_like(self.bucket.params)
         self.v = torch.zeros_like(self.bucket.params)
-        self.sq = torch.zeros(1, dtype=torch.float32, device=self.bucket.params.device)
+        self.sq = self.bucket.sq               # zeroed with the gradients (FlatBucket.zero_grad)
         self.lr, self.betas, self.eps = lr, betas, eps
         self.weight_decay, self.max_norm = weight_decay, max_norm
         self.iter = 0
@@ -138,6 +144,7 @@ class FusionTrainer:
         # side and one grouped weight-gradient launch (tc_radar_train_bwd_fused: ~16 launches instead of ~130);
         # False = tc_radar_train_bwd, one launch per operator
         self.chain_backward = bool(chain_backward)
+        self._sq_clean = False
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -158,7 +165,7 @@ class FusionTrainer:
     def _decoder_forward(self, feats_nhwc, lidar2img, img_hw, tokens, pad_mult, seed, lane):
         from .detr3d_head import head_options
         with torch.no_grad():
-            return self.head.forward_nhwc(feats_nhwc, lidar2img, img_hw, tokens, pad_mult, aux=True,
+            return self.head.forward_nhwc(feats_nhwc, lidar2img, img_hw, tokens, pad_mult, aux='train',
                                           _allow_train=True, decoder_only=True, lane=lane,
                                           options=head_options(decoder_dropout_p=self.decoder_dropout,
                                                                dropout_seed=seed))
@@ -263,7 +270,7 @@ class FusionTrainer:
             total = sum(v for k, v in losses.items() if 'loss' in k)
             total.backward()                               # d loss / d outputs only
             d_cls, d_box = cls_leaf.grad.contiguous(), box_leaf.grad.contiguous()
-        self.bucket.zero_grad()
+        self.bucket.zero_grad(check_views=getattr(self, '_gtab_key', None) is None)
         # the gradient pointers are views into the flat bucket: they do not move between iterations
         gkey = self.bucket.grads.data_ptr()
         if getattr(self, '_gtab_key', None) != gkey:
@@ -288,6 +295,7 @@ class FusionTrainer:
                 int(pad_mult), all_box.data_ptr(), d_cls.data_ptr(), d_box.data_ptr(), tape.data_ptr(),
                 tape.numel(), self.dropout, drop_seed, self._stream()), 'tc_radar_train_bwd')
         self.last_dropout_seed = drop_seed
+        self._sq_clean = True                  # bucket.zero_grad above cleared it and nothing has added to it since
         if getattr(self, 'keep_last', False):        # tests: the operands of the backward call
             self._last = dict(w=w, g=g, hs_last=hs_last, last_box=last_box, tokens=tokens, B=B, T=T, pad_mult=int(pad_mult),
                               all_box=all_box, d_cls=d_cls, d_box=d_box, tape=tape, seed=drop_seed)
@@ -299,7 +307,9 @@ class FusionTrainer:
         world = self.bucket.all_reduce()
         b, lib = self.bucket, L.lib()
         self.iter += 1
-        self.sq.zero_()
+        if not self._sq_clean:                 # (zeroed with the gradients in the fused iteration)
+            self.sq.zero_()
+        self._sq_clean = False
         L.check(lib.tc_sq_norm(b.grads.data_ptr(), b.numel, self.sq.data_ptr(), self._stream()),
                 'tc_sq_norm')
         L.check(lib.tc_adamw_step(
