@@ -3,7 +3,7 @@
 inputs must keep giving bit-identical outputs per lane (a lane sharing a buffer with another would not;
 neither would a weight fragment overwritten before its MFMAs have read it -- the 16-row tiles refill
 their one weight buffer in place).
-    python tools/pipeline_soak.py [launches] [frames per launch: 1 (4-row tiles) | 2 (8) | 4 (16)]"""
+    python tools/pipeline_soak.py [launches] [frames per launch: 1 (4-row tiles) | 2 (8) | 4 (16) | 9 (16, 507 workgroups: the bench default)]"""
 import os
 import sys
 
@@ -21,7 +21,7 @@ def main():
     dev = torch.device('cuda:0')
     torch.set_grad_enabled(False)
     head, _ = bench.build_head(dev)
-    lanes = [bench.make_inputs(head, dev, 'res101', fpl, seed=1 + i) for i in range(3)]
+    lanes = [bench.make_inputs(head, dev, 'res101', fpl, seed=1 + i, host_feats=fpl <= 2) for i in range(3)]
     pipe = FramePipeline(head, lanes)
     for _ in range(3):
         pipe.launch()
