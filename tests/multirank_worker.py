@@ -1,0 +1,63 @@
+"""Worker of tests/test_gpu_multirank.py: one rank of a data-parallel training job whose ranks SHARE the one GPU of
+the test box (gloo: RCCL refuses two ranks on one device).  Every rank trains on its own frame; after the flat-bucket
+all-reduce the ranks must hold the same parameters (tools/dist_train.sh:7-9, mmcv DDP semantics)."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import transcar_amd as T
+    from transcar_amd import configs, ops, synth
+    from transcar_amd.trainer import FusionTrainer
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(0)
+    sd = synth.make_state_dict(seed=3)
+    cfg = configs.head_cfg()
+    cfg['train_cfg'] = configs.train_cfg_pts
+    head = T.build_head(cfg)
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    head = head.to(dev)
+    l2i = synth.make_lidar2img()
+    frames = []
+    for i in range(2):                                   # two frames per rank, different on every rank
+        feats = [torch.from_numpy(f).to(dev) for f in synth.make_feats('tiny', seed=10 * rank + i + 1, smooth=(4, 6))]
+        radar = synth.make_radar_frame(seed=20 * rank + i + 2, n_per_radar=30 + 5 * rank)
+        metas = synth.make_img_metas(1, l2i, radar=radar)
+        tokens, pm = head.radar_tokens(metas, dev, T=256)
+        frames.append(dict(feats_nhwc=[ops.to_nhwc(f) for f in feats], lidar2img=ops.lidar2img_tensor(metas, dev),
+                           img_hw=metas[0]['img_shape'][0][:2], tokens=tokens, pad_mult=pm))
+    boxes, labels = synth.make_gt(seed=7 + rank, n=12 + 3 * rank)
+    gt = torch.from_numpy(boxes).clone()
+    gt[:, 2] += gt[:, 5] * 0.5
+    gts, lbs = [gt.to(dev)], [torch.from_numpy(labels).to(dev)]
+    tr = FusionTrainer(head, dropout=0.1, seed=5, lr=1e-3)
+    losses = []
+    for it in range(3):
+        cur, nxt = frames[it % 2], frames[(it + 1) % 2]
+        out = tr.step_fused_nhwc(cur['feats_nhwc'], cur['lidar2img'], cur['img_hw'], cur['tokens'], cur['pad_mult'],
+                                 gts, lbs, prefetch=nxt)
+        losses.append(float(sum(out.values())))
+    torch.cuda.synchronize()
+    p = tr.bucket.params.double()
+    mine = dict(rank=rank, sum=float(p.sum()), abs=float(p.abs().sum()), first=p[:8].tolist(), losses=losses,
+                finite=bool(torch.isfinite(p).all()), seed=int(tr.last_dropout_seed))
+    parts = [None] * world
+    dist.all_gather_object(parts, mine)
+    if rank == 0:
+        print('MULTIRANK ' + json.dumps(parts), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

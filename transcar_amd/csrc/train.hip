@@ -449,9 +449,18 @@ int launch_box_ref_bwd(const float* d_box, int code, float* d_prev, int M, hipSt
 }
 
 // ---- optimizer on the flat gradient bucket ----------------------------------
-// sum of squares -> out[0] (+=); the clip coefficient stays on the device
+// sum of squares -> out[0] (+=); the clip coefficient stays on the device.
+// DETERMINISTIC (round 3): the ranks of a data-parallel job evaluate this on the SAME all-reduced bucket and must get
+// the same clip coefficient bit for bit, or the replicas drift apart (a two-rank test found 1.7e-10 relative after
+// three steps with the block sums meeting in float atomics).  Block sums go to a scratch array; the block that
+// draws the last ticket adds them up in index order.  (One optimizer per device at a time: the scratch is a
+// __device__ array of this code object.)
+constexpr int SQ_MAX_BLOCKS = 1024;
+__device__ float g_sq_partial[SQ_MAX_BLOCKS];
+__device__ unsigned g_sq_ticket;
 __global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, size_t n, float* out) {
   __shared__ float red[4];
+  __shared__ unsigned last;
   float acc = 0.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const float v = g[i];
@@ -460,12 +469,32 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, size_t n, f
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) unsafeAtomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    g_sq_partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    __threadfence();                                          // release: the partial before the ticket
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    last = atomicAdd(&g_sq_ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (last == 0u) return;
+  __threadfence();                                            // acquire: every block's partial
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  float t = 0.f;
+  for (unsigned i = threadIdx.x; i < gridDim.x; i += 256)    // fixed order per thread, fixed tree below
+    t += __hip_atomic_load(&g_sq_partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  t = wave_sum(t);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] += (red[0] + red[1]) + (red[2] + red[3]);
+    g_sq_ticket = 0u;                                         // ready for the next launch (stream order)
+  }
 }
 
 int launch_sqnorm(const float* g, size_t n, float* out, hipStream_t s) {
   TC_REQUIRE(n > 0, "sqnorm: n=0");
-  const int grid = (int)min((n + 255) / 256, (size_t)1024);
+  const int grid = (int)min((n + 255) / 256, (size_t)SQ_MAX_BLOCKS);
   hipLaunchKernelGGL(sqnorm_kernel, dim3(grid), dim3(256), 0, s, g, n, out);
   return check_launch("sqnorm");
 }
