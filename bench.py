@@ -1004,7 +1004,7 @@ def train_roofline(tr, thead, inp, gts, lbs, nxt, dev):
         L.check(lib.tc_radar_train_bwd_fused(C.byref(w), C.byref(g), hs_last.data_ptr(), last_box.data_ptr(),
                                              inp['tokens'].data_ptr(), B, T_tok, int(inp['pad_mult']), all_box.data_ptr(),
                                              d_cls.data_ptr(), d_box.data_ptr(), tape.data_ptr(), tape.numel(),
-                                             bws.data_ptr(), bws.numel(), tr.dropout, seed, None, st), 'bwd')
+                                             bws.data_ptr(), bws.numel(), tr.dropout, seed, None, None, st), 'bwd')
     bwd_ms = ev_time(bwd)
     tr.bucket.zero_grad()
     layer = Cd * Cd * 6 + 2 * Cd * F + Cd * (code + ncls)           # MAC per row of one fusion layer's linears

@@ -463,10 +463,13 @@ int tc_dropout(const float* x, int rows, int cols, float dropout_p, unsigned lon
                float* out, tc_stream_t stream);
 
 /* Optimizer on the flat fp32 bucket of the trainable parameters (one RCCL
- * all-reduce): out[0] += sum g^2;  torch.optim.AdamW step with
+ * all-reduce).  tc_sq_norm: out is TC_SQ_NORM_PARTIALS floats (zeroed by the caller);
+ * out[b] += the sum of g^2 over the elements workgroup b owns -- no atomics, so the ranks of a job get the same
+ * bits from the same all-reduced bucket; sum(out[]) = sum g^2.  tc_adamw_step: torch.optim.AdamW step with
  * mmcv's grad clip (CFG:214 max_norm=35; coef = max_norm/(norm+1e-6) if < 1)
- * evaluated on the device from sq_norm[0] (NULL or max_norm <= 0: no clip);
- * g is multiplied by grad_scale first (1/world_size after a SUM all-reduce). */
+ * evaluated on the device from sq_norm[0 .. TC_SQ_NORM_PARTIALS), added up in index order (NULL or
+ * max_norm <= 0: no clip); g is multiplied by grad_scale first (1/world_size after a SUM all-reduce). */
+#define TC_SQ_NORM_PARTIALS 256
 int tc_sq_norm(const float* g, size_t n, float* out, tc_stream_t stream);
 int tc_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr,
                   float beta1, float beta2, float eps, float weight_decay, int step,
@@ -522,11 +525,13 @@ int tc_radar_train_bwd_fused(const tc_head_weights* w, const tc_head_weights* gr
                              const float* all_bbox_preds, const float* d_all_cls, const float* d_all_box,
                              void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes,
                              float dropout_p, unsigned long long dropout_seed, const float* layer_losses,
-                             tc_stream_t stream);
+                             float* layer_losses_clean, tc_stream_t stream);
 /* layer_losses: optional device [num_radar_layers, 2] = (loss_cls, loss_bbox) of each level as tc_detr_loss_fwd_bwd
  * wrote them: a level whose loss is not finite sends no gradient down and non-finite gradient elements count
- * as 0 (HEAD:915-916 zeroes such a loss with nan_to_num) -- the guard of transcar_amd/device_loss.py inside the
- * backward instead of eight elementwise launches in front of it.  NULL: the gradients are taken as given. */
+ * as 0 (HEAD:915-916 zeroes a NaN loss) -- the guard of transcar_amd/device_loss.py inside the
+ * backward instead of eight elementwise launches in front of it.  NULL: the gradients are taken as given.
+ * layer_losses_clean: optional device [num_radar_layers, 2], receives layer_losses with NaN -> 0
+ * (HEAD:915-916; an infinite loss stays): the values of the iteration's loss dict, written by the same launch. */
 int tc_dropout_mask(float dropout_p, unsigned long long seed, int site, size_t n, float* out,
                     tc_stream_t stream);
 

@@ -289,9 +289,9 @@ def test_adamw_step_matches_torch(A):
         torch.nn.utils.clip_grad_norm_([p_ref], 35.0)
         opt.step()
         gd = torch.from_numpy(g * 2.0).to(dev())        # SUM over 2 ranks, averaged by grad_scale
-        sq = torch.zeros(1, device=dev())
+        sq = torch.zeros(L.TC_SQ_NORM_PARTIALS, device=dev())
         L.check(L.lib().tc_sq_norm(gd.data_ptr(), n, sq.data_ptr(), s), 'tc_sq_norm')
-        assert abs(float(sq) - float((g.astype(np.float64) * 2) ** 2 @ np.ones(n))) < 1e-3 * float(sq)
+        assert abs(float(sq.sum()) - float((g.astype(np.float64) * 2) ** 2 @ np.ones(n))) < 1e-3 * float(sq.sum())
         L.check(L.lib().tc_adamw_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n,
                                       2e-4, 0.9, 0.999, 1e-8, 0.01, step, 0.5, 35.0, sq.data_ptr(), s),
                 'tc_adamw_step')
@@ -785,10 +785,13 @@ def test_backward_chain_guards_non_finite_loss_gradients(A, golden_dir):
             C.byref(k['w']), C.byref(k['g']), k['hs_last'].data_ptr(), k['last_box'].data_ptr(), k['tokens'].data_ptr(),
             k['B'], k['T'], k['pad_mult'], k['all_box'].data_ptr(), dc.data_ptr(), db.data_ptr(), k['tape'].data_ptr(),
             k['tape'].numel(), tr._bws.data_ptr(), tr._bws.numel(), tr.dropout, k['seed'],
-            lv.data_ptr() if lv is not None else None, tr._stream()), 'bwd')
+            lv.data_ptr() if lv is not None else None, clean.data_ptr() if lv is not None else None,
+            tr._stream()), 'bwd')
         torch.cuda.synchronize()
         return tr.bucket.grads.clone()
+    clean = torch.full((3, 2), -7.0, dtype=torch.float32, device=dev())
     got = run(d_cls, d_box, losses)
+    assert torch.equal(clean, losses.masked_fill(torch.isnan(losses), 0.0))      # HEAD:915-916: the loss dict's values
     fin = torch.isfinite(losses)
     gc = torch.where(fin[:, 0].view(3, 1, 1, 1), torch.nan_to_num(d_cls, nan=0.0, posinf=0.0, neginf=0.0), torch.zeros_like(d_cls))
     gb = torch.where(fin[:, 1].view(3, 1, 1, 1), torch.nan_to_num(d_box, nan=0.0, posinf=0.0, neginf=0.0), torch.zeros_like(d_box))

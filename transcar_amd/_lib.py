@@ -29,6 +29,7 @@ class TransCARHipError(RuntimeError):
 
 
 TC_MAX_RADAR_CHANNELS = 8
+TC_SQ_NORM_PARTIALS = 256
 
 
 class tc_radar_frame_desc(C.Structure):
@@ -199,7 +200,7 @@ SIGNATURES = {
     'tc_radar_train_bwd_workspace_bytes': (_sz, [_P(tc_head_weights), _i, _i]),
     'tc_radar_train_bwd_fused': (_i, [_P(tc_head_weights), _P(tc_head_weights), _vp,
                                       _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp, _sz,
-                                      _f, C.c_ulonglong, _vp, _vp]),
+                                      _f, C.c_ulonglong, _vp, _vp, _vp]),
     'tc_dropout_mask': (_i, [_f, C.c_ulonglong, _i, _sz, _vp, _vp]),
     'tc_normalize_bbox': (_i, [_vp, _i, _vp, _vp]),
     'tc_match_cost': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _f, _f,

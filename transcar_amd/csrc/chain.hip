@@ -353,6 +353,7 @@ struct ChainDev {
   const float* bwd_box[TC_MAX_RADAR_LAYERS];                                      // ... and its box (previous level)
   const float* loss_vals;      // [layers, 2] (cls, bbox) losses of the iteration or null: a layer whose loss is not
                                // finite sends no gradient down (HEAD:915-916 zeroes such a loss), non-finite elements are 0
+  float* loss_out;             // or null: loss_vals with NaN -> 0 for the iteration's loss dict (workgroup 0 writes it)
 };
 // ... plus what only the host-side resolver needs
 struct ChainK : ChainDev {
@@ -1560,6 +1561,11 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
         if (carry) {
           __syncthreads();                 // every thread has read the old carry
           const int layer = k.nlayers - 1 - rep;
+          if (blockIdx.x == 0 && threadIdx.x < 2 && k.loss_vals != nullptr && k.loss_out != nullptr) {
+            // HEAD:915-916 (`loss[torch.isnan(loss)] = 0`): NaN -> 0, an infinite loss stays
+            const float lv = k.loss_vals[2 * layer + threadIdx.x];
+            k.loss_out[2 * layer + threadIdx.x] = lv != lv ? 0.0f : lv;
+          }
           if (threadIdx.x < R * 16) {
             const int row = threadIdx.x >> 4, c = threadIdx.x & 15;
             if (c < 12) S.box[row][c] = (c == 0 || c == 1 || c == 4) ? dst[row * LD2 + c] : 0.0f;
@@ -2167,7 +2173,7 @@ int launch_radar_chain_bwd(const RadarBwdChainArgs& a, hipStream_t s) {
   k.tape_stride = a.tape_stride; k.hits_stride = a.hits_stride;
   for (int i = 0; i < D_COUNT; ++i) k.dy[i] = a.dy[i];
   k.dy_stride = a.dy_stride;
-  k.d_cls = a.d_cls; k.d_box = a.d_box; k.loss_vals = a.loss_vals;
+  k.d_cls = a.d_cls; k.d_box = a.d_box; k.loss_vals = a.loss_vals; k.loss_out = a.loss_out;
   k.hits = const_cast<int*>(a.hits);
   k.qscale = a.qscale; k.tokens = a.tokens; k.RI = a.RI; k.T = a.T; k.pad_mult = a.pad_mult;
   k.rdrop = a.drop;

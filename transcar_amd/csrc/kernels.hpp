@@ -148,6 +148,7 @@ struct RadarBwdChainArgs {
   float* const* dy; size_t dy_stride;
   const float* d_cls; const float* d_box;      // [layers, M, ncls / code]
   const float* loss_vals = nullptr;            // optional [layers, 2]: non-finite losses / elements send nothing down
+  float* loss_out = nullptr;                   // optional [layers, 2]: loss_vals, NaN -> 0
   const float* tokens; int RI, T, pad_mult;
   int nlayers, Q, M, code, ncls;
   float qscale;

@@ -449,20 +449,24 @@ int launch_box_ref_bwd(const float* d_box, int code, float* d_prev, int M, hipSt
 }
 
 // ---- optimizer on the flat gradient bucket ----------------------------------
-// sum of squares -> out[0] (+=); the clip coefficient stays on the device.
+// sum of squares; the clip coefficient stays on the device.
 // DETERMINISTIC (round 3): the ranks of a data-parallel job evaluate this on the SAME all-reduced bucket and must get
 // the same clip coefficient bit for bit, or the replicas drift apart (a two-rank test found 1.7e-10 relative after
-// three steps with the block sums meeting in float atomics).  Block sums go to a scratch array; the block that
-// draws the last ticket adds them up in index order.  (One optimizer per device at a time: the scratch is a
-// __device__ array of this code object.)
-constexpr int SQ_MAX_BLOCKS = 1024;
-__device__ float g_sq_partial[SQ_MAX_BLOCKS];
-__device__ unsigned g_sq_ticket;
-__global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, size_t n, float* out) {
-  __shared__ float red[4];
-  __shared__ unsigned last;
+// three steps with the block sums meeting in float atomics).  out[] is TC_SQ_NORM_PARTIALS slots: workgroup b adds
+// the sum over the elements it owns to out[b] (its own slot: no atomics, a fixed order inside the workgroup);
+// adamw_kernel adds the slots up in index order -- the launch boundary is the hand-off, no fence, no ticket.
+constexpr int SQ_NT = 1024;
+static_assert(TC_SQ_NORM_PARTIALS == 256, "adamw_kernel reads one slot per thread");
+__global__ __launch_bounds__(SQ_NT) void sqnorm_kernel(const float* g, size_t n, float* out) {
+  __shared__ float red[SQ_NT / 64];
   float acc = 0.f;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+  const size_t n4 = (reinterpret_cast<uintptr_t>(g) & 15) == 0 ? n / 4 : 0;
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  for (size_t i = (size_t)blockIdx.x * SQ_NT + threadIdx.x; i < n4; i += (size_t)gridDim.x * SQ_NT) {
+    const float4 v = g4[i];
+    acc += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  for (size_t i = 4 * n4 + (size_t)blockIdx.x * SQ_NT + threadIdx.x; i < n; i += (size_t)gridDim.x * SQ_NT) {
     const float v = g[i];
     acc += v * v;
   }
@@ -470,39 +474,23 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, size_t n, f
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) {
-    g_sq_partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-    __threadfence();                                          // release: the partial before the ticket
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    last = atomicAdd(&g_sq_ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
-  }
-  __syncthreads();
-  if (last == 0u) return;
-  __threadfence();                                            // acquire: every block's partial
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  float t = 0.f;
-  for (unsigned i = threadIdx.x; i < gridDim.x; i += 256)    // fixed order per thread, fixed tree below
-    t += __hip_atomic_load(&g_sq_partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  t = wave_sum(t);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    out[0] += (red[0] + red[1]) + (red[2] + red[3]);
-    g_sq_ticket = 0u;                                         // ready for the next launch (stream order)
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < SQ_NT / 64; ++i) t += red[i];
+    out[blockIdx.x] += t;
   }
 }
 
 int launch_sqnorm(const float* g, size_t n, float* out, hipStream_t s) {
   TC_REQUIRE(n > 0, "sqnorm: n=0");
-  const int grid = (int)min((n + 255) / 256, (size_t)SQ_MAX_BLOCKS);
-  hipLaunchKernelGGL(sqnorm_kernel, dim3(grid), dim3(256), 0, s, g, n, out);
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(TC_SQ_NORM_PARTIALS), dim3(SQ_NT), 0, s, g, n, out);
   return check_launch("sqnorm");
 }
 
 // torch.optim.AdamW step (decoupled weight decay) with mmcv's grad clip
 // (clip_grad_norm_: coef = max_norm / (norm + 1e-6), applied when < 1) and the
-// 1/world_size of the gradient all-reduce folded in.  sqnorm[0] = sum g^2 of the
-// already averaged gradient when grad_scale == 1, else of the raw sum.
+// 1/world_size of the gradient all-reduce folded in.  sum(sqnorm[0 .. TC_SQ_NORM_PARTIALS)) = sum g^2 of
+// the already averaged gradient when grad_scale == 1, else of the raw sum.
 struct AdamK {
   float* p; const float* g; float* m; float* v; size_t n;
   float lr, b1, b2, eps, wd, bc1, bc2, grad_scale, max_norm;
@@ -512,7 +500,12 @@ struct AdamK {
 __global__ __launch_bounds__(256) void adamw_kernel(AdamK a) {
   float coef = a.grad_scale;
   if (a.sqnorm != nullptr && a.max_norm > 0.f) {
-    const float norm = sqrtf(a.sqnorm[0]) * a.grad_scale;
+    // every workgroup adds the slots up itself, in the same order (TC_SQ_NORM_PARTIALS == its 256 threads)
+    __shared__ float red[4];
+    const float part = wave_sum(a.sqnorm[threadIdx.x]);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3])) * a.grad_scale;
     const float c = a.max_norm / (norm + 1e-6f);
     if (c < 1.0f) coef *= c;
   }

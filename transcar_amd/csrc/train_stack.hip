@@ -471,7 +471,7 @@ int tc_radar_train_bwd_fused(const tc_head_weights* w, const tc_head_weights* gr
                              const float* all_bbox_preds, const float* d_all_cls, const float* d_all_box,
                              void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes,
                              float dropout_p, unsigned long long dropout_seed, const float* layer_losses,
-                             tc_stream_t stream) {
+                             float* layer_losses_clean, tc_stream_t stream) {
   TS_TRY(check(w, B, T));
   TC_REQUIRE(grads != nullptr && workspace != nullptr, "radar_train_bwd_fused: null argument");
   TC_REQUIRE(dropout_p >= 0.0f && dropout_p < 1.0f, "radar_train_bwd_fused: dropout_p=%g", (double)dropout_p);
@@ -531,7 +531,7 @@ int tc_radar_train_bwd_fused(const tc_head_weights* w, const tc_head_weights* gr
   a.tape = slots; a.tape_stride = (size_t)(t.L[1].qp - t.L[0].qp);
   a.hits = t.L[0].hits; a.hits_stride = (size_t)(t.L[1].hits - t.L[0].hits);
   a.dy = ws.dy; a.dy_stride = ws.dy_stride;
-  a.d_cls = d_all_cls; a.d_box = d_all_box; a.loss_vals = layer_losses;
+  a.d_cls = d_all_cls; a.d_box = d_all_box; a.loss_vals = layer_losses; a.loss_out = layer_losses_clean;
   a.tokens = radar_tokens; a.RI = RI; a.T = T; a.pad_mult = pad_mult;
   a.nlayers = TC_MAX_RADAR_LAYERS; a.Q = Q; a.M = rows; a.code = code; a.ncls = ncls;
   a.qscale = 1.0f / sqrtf((float)(C / w->num_heads));

@@ -751,7 +751,8 @@ class Detr3DHead(BaseModule):
         loss_bbox = losses.l1_loss(bbox_preds[ok, :10], ntargets[ok, :10], bbox_weights[ok, :10],
                                    avg_factor=num_pos_t,
                                    loss_weight=self.loss_bbox_cfg.get('loss_weight', 1.0))
-        return torch.nan_to_num(loss_cls, nan=0.0), torch.nan_to_num(loss_bbox, nan=0.0)
+        # HEAD:915-916 (the live lines: `loss[torch.isnan(loss)] = 0`; an infinite loss stays infinite)
+        return loss_cls.masked_fill(torch.isnan(loss_cls), 0.0), loss_bbox.masked_fill(torch.isnan(loss_bbox), 0.0)
 
     def loss(self, gt_bboxes_list, gt_labels_list, preds_dicts, gt_bboxes_ignore=None):
         """HEAD:919-1001.  gt boxes: objects with ``gravity_center`` / ``tensor``

@@ -89,11 +89,20 @@ def detr_loss_device(head, all_cls, all_box, gt_bboxes_list, gt_labels_list, bef
         box_avg = box_avg / dist.get_world_size()
         cls_avg = box_avg if head.sync_cls_avg_factor else torch.from_numpy(num_pos).to(dev)
         avg = torch.stack((cls_avg.clamp(min=1.0), box_avg.clamp(min=1.0)), dim=1).contiguous()   # [Lyr,2]
-    else:                                                           # one rank: the clamp on the host, one H2D
+        asg = torch.from_numpy(assigned).to(dev)
+        losses = torch.zeros((Lyr, 2), dtype=torch.float32, device=dev)
+    else:
+        # one rank: the clamp on the host, and ONE upload of [assignment | normalisers | zeroed loss accumulators]
+        # (three 4-byte arrays in one staging buffer: one H2D instead of two H2D and a fill)
         one = np.maximum(num_pos, 1.0).astype(np.float32)
-        avg = torch.from_numpy(np.ascontiguousarray(np.stack((one, one), axis=1))).to(dev)
-    asg = torch.from_numpy(assigned).to(dev)
-    losses = torch.zeros((Lyr, 2), dtype=torch.float32, device=dev)
+        na = Lyr * B * Q
+        stage = np.zeros(na + 4 * Lyr, dtype=np.int32)
+        stage[:na] = assigned.reshape(-1)
+        stage[na:na + 2 * Lyr].view(np.float32)[:] = np.stack((one, one), axis=1).reshape(-1)
+        up = torch.from_numpy(stage).to(dev)
+        asg = up[:na].view(Lyr, B, Q)
+        avg = up[na:na + 2 * Lyr].view(torch.float32).view(Lyr, 2)
+        losses = up[na + 2 * Lyr:].view(torch.float32).view(Lyr, 2)
     d_cls = torch.empty_like(all_cls)
     d_box = torch.empty_like(all_box)
     lc, lb = head.loss_cls_cfg, head.loss_bbox_cfg
@@ -103,27 +112,26 @@ def detr_loss_device(head, all_cls, all_box, gt_bboxes_list, gt_labels_list, bef
         float(lc.get('alpha', 0.25)), float(lc.get('gamma', 2.0)), float(lc.get('loss_weight', 1.0)),
         float(lb.get('loss_weight', 1.0)), losses.data_ptr(), d_cls.data_ptr(), d_box.data_ptr(),
         _stream()), 'tc_detr_loss_fwd_bwd')
-    # HEAD:915-916 zeroes a non-finite loss (torch.nan_to_num); its gradient must not reach the flat
+    # HEAD:915-916 zeroes a NaN loss (`loss[torch.isnan(loss)] = 0`); its gradient must not reach the flat
     # bucket / the Adam moments either: a layer whose loss is not finite contributes nothing
     if defer_guard:
         # the consumer applies the guard itself (tc_radar_train_bwd_fused(layer_losses=...): inside the backward
         # chain instead of eight elementwise launches here); the raw per-level losses travel with the gradients
-        raw = losses
-        losses = torch.nan_to_num(losses, nan=0.0)
-        out = {'loss_cls': losses[Lyr - 1, 0], 'loss_bbox': losses[Lyr - 1, 1]}
-        for i in range(Lyr - 1):
-            out['d%d.loss_cls' % i] = losses[i, 0]
-            out['d%d.loss_bbox' % i] = losses[i, 1]
-        out_raw = raw
-        return out, d_cls, d_box, assigned, out_raw
+        # (... and hands back the NaN-zeroed losses from the same launch: `loss_dict` of that tensor is the result)
+        return None, d_cls, d_box, assigned, losses
     fin = torch.isfinite(losses)
     d_cls = torch.where(fin[:, 0].view(Lyr, 1, 1, 1), torch.nan_to_num(d_cls, nan=0.0, posinf=0.0, neginf=0.0),
                         torch.zeros_like(d_cls))
     d_box = torch.where(fin[:, 1].view(Lyr, 1, 1, 1), torch.nan_to_num(d_box, nan=0.0, posinf=0.0, neginf=0.0),
                         torch.zeros_like(d_box))
-    losses = torch.nan_to_num(losses, nan=0.0)
+    return loss_dict(losses.masked_fill(torch.isnan(losses), 0.0)), d_cls, d_box, assigned
+
+
+def loss_dict(losses):
+    """[Lyr, 2] (cls, bbox) per level -> the reference's keys (HEAD:990-1000: the last level unprefixed, d<i>. before)"""
+    Lyr = losses.shape[0]
     out = {'loss_cls': losses[Lyr - 1, 0], 'loss_bbox': losses[Lyr - 1, 1]}
     for i in range(Lyr - 1):
         out['d%d.loss_cls' % i] = losses[i, 0]
         out['d%d.loss_bbox' % i] = losses[i, 1]
-    return out, d_cls, d_box, assigned
+    return out

@@ -35,9 +35,9 @@ class FlatBucket:
         dev = self.items[0].device
         n = sum(p.numel() for p in self.items)
         self.params = torch.empty(n, dtype=torch.float32, device=dev)
-        # one allocation: the gradients and, behind them, the squared-norm accumulator of the clip (zeroed by the
-        # same fill)
-        self._store = torch.zeros(n + 1, dtype=torch.float32, device=dev)
+        # one allocation: the gradients and, behind them, the squared-norm slots of the clip (tc_sq_norm: one per
+        # workgroup, added up in index order by tc_adamw_step; zeroed by the same fill)
+        self._store = torch.zeros(n + L.TC_SQ_NORM_PARTIALS, dtype=torch.float32, device=dev)
         self.grads = self._store[:n]
         self.sq = self._store[n:]
         self.offsets = []
@@ -283,12 +283,16 @@ class FusionTrainer:
                     raise L.TransCARHipError(lib.tc_last_error().decode())
                 self._bws = torch.empty(nb, dtype=torch.uint8, device=tokens.device)
                 self._bws_key = key
+            clean = torch.empty_like(raw_losses) if raw_losses is not None else None
             L.check(lib.tc_radar_train_bwd_fused(
                 C.byref(w), C.byref(g), hs_last.data_ptr(), last_box.data_ptr(), tokens.data_ptr(), B, T,
                 int(pad_mult), all_box.data_ptr(), d_cls.data_ptr(), d_box.data_ptr(), tape.data_ptr(),
                 tape.numel(), self._bws.data_ptr(), self._bws.numel(), self.dropout, drop_seed,
-                raw_losses.data_ptr() if raw_losses is not None else None, self._stream()),
-                'tc_radar_train_bwd_fused')
+                raw_losses.data_ptr() if raw_losses is not None else None,
+                clean.data_ptr() if clean is not None else None, self._stream()), 'tc_radar_train_bwd_fused')
+            if clean is not None:
+                from .device_loss import loss_dict
+                losses = loss_dict(clean)
         else:
             L.check(lib.tc_radar_train_bwd(
                 C.byref(w), C.byref(g), hs_last.data_ptr(), last_box.data_ptr(), tokens.data_ptr(), B, T,
