@@ -811,7 +811,7 @@ def test_box_decode_vs_oracle(T, head):
     assert np.all(s[:-1] >= s[1:])
 
 
-@pytest.mark.parametrize('case', ['ties', 'all_equal', 'random_batch'])
+@pytest.mark.parametrize('case', ['ties', 'all_equal', 'random_batch', 'tiny_scores', 'saturated', 'extremes', 'few_candidates'])
 def test_box_decode_ties_and_batches(T, case):
     """The radix select stops early when a whole bin is wanted; ties between equal
     scores (which keep it going through the index digits) must still give exactly
@@ -824,17 +824,47 @@ def test_box_decode_ties_and_batches(T, case):
         cls = np.round(cls * 2) / 2            # ~15 distinct values, 9000 keys
     elif case == 'all_equal':
         cls[:] = 0.25
-    box = rng.standard_normal((B, 900, 10)).astype(np.float32) * 0.3
+    elif case == 'tiny_scores':                # every score below 2^-16: the select's lower catch-all bucket
+        cls = (cls * 2 - 20).astype(np.float32)
+    elif case == 'saturated':                  # scores 1 - 2^-24 .. 1 and ties at exactly 1.0: the upper catch-all
+        cls = (np.abs(cls) * 3 + 12).astype(np.float32)
+    elif case == 'extremes':                   # a few hundred saturated, the rest tiny, the 300th in between
+        cls = (cls - 18).astype(np.float32)
+        cls.reshape(-1)[rng.permutation(9000)[:170]] = 25.0
+        cls.reshape(-1)[rng.permutation(9000)[:100]] = rng.standard_normal(100).astype(np.float32)
+    Qn = 20 if case == 'few_candidates' else 900      # 200 candidates < max_num: rows 200.. are empty
+    cls = np.ascontiguousarray(cls[:, :Qn])
+    box = rng.standard_normal((B, Qn, 10)).astype(np.float32) * 0.3
     pcr = configs.pts_bbox_head['bbox_coder']['post_center_range']
     boxes, scores, labels, valid = ops.box_decode_topk(gpu(cls), gpu(box), pcr, 300)
     sg = 1.0 / (1.0 + np.exp(-cls.astype(np.float64)))
     for b in range(B):
         flat = sg[b].reshape(-1)
         order = np.lexsort((np.arange(flat.size), -flat))[:300]      # score desc, index asc
-        np.testing.assert_allclose(scores[b].cpu().numpy(), flat[order], atol=1e-6, rtol=0)
-        if case != 'random_batch':     # (distinct logits may round to one fp32 sigmoid: order free)
+        kk = len(order)
+        np.testing.assert_allclose(scores[b].cpu().numpy()[:kk], flat[order], atol=1e-6, rtol=0)
+        if case in ('ties', 'all_equal'):     # (distinct logits may round to one fp32 sigmoid: order free)
             np.testing.assert_array_equal(labels[b].cpu().numpy(), order % 10)
             np.testing.assert_allclose(boxes[b].cpu().numpy()[:, 0], box[b][order // 10, 0], atol=1e-6)
+        else:
+            # the fp32 scores the kernel saw: ties between them resolve to the lower flat index
+            s32 = (1.0 / (1.0 + np.exp(-cls[b].astype(np.float32).reshape(-1)))).astype(np.float32)
+            got_s = scores[b].cpu().numpy()[:kk]
+            assert np.all(got_s[:-1] >= got_s[1:])
+            lab = labels[b].cpu().numpy()[:kk]
+            bx = boxes[b].cpu().numpy()[:kk, 0]
+            # each output row is a real (query, class) pair with that score, no pair twice
+            cand = {}
+            for i in np.argsort(-s32, kind='stable')[:kk + 200]:
+                cand.setdefault((np.float32(box[b][i // 10, 0]).item(), int(i % 10)), []).append(i)
+            seen = set()
+            for r in range(kk):
+                ids = [i for i in cand.get((np.float32(bx[r]).item(), int(lab[r])), []) if i not in seen and abs(s32[i] - got_s[r]) <= 1e-6]
+                assert ids, (case, r)
+                seen.add(ids[0])
+        if kk < 300:
+            assert np.all(labels[b].cpu().numpy()[kk:] == -1) and not valid[b].cpu().numpy()[kk:].any()
+            assert np.all(scores[b].cpu().numpy()[kk:] == 0)
 
 
 def test_missing_gpu_inputs_fail_loudly(T, head):

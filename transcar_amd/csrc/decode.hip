@@ -1,17 +1,23 @@
 // NMS-free box decoding (CODER:39-90, UTIL:26-52, HEAD:1018): sigmoid, top-300
 // of the 9000 (query, class) scores, gather + denormalise, centre-range mask,
-// z -= h/2.  One workgroup per sample: the 9000 keys live in LDS as 64-bit
-// (score bits << 32 | ~index), so keys are unique, an 8-pass radix SELECT finds
-// the max_num-th largest exactly, and only the <=512 survivors are bitonic
-// sorted.  Ties resolve to the lower flat index (torch.topk leaves tie order
-// unspecified).  <1 % of the frame; latency-bound, not a roofline kernel.
+// z -= h/2.  One workgroup per sample; a key is 64 bits (score bits << 32 | ~index), so keys are
+// unique and an 8-bit radix SELECT finds the max_num-th largest exactly.  Ties resolve to the lower
+// flat index (torch.topk leaves tie order unspecified).  <1 % of the frame, but 4 % of the one-frame
+// latency path when it took 20 us (round 2: four barriers and a one-wave scan per pass, 300 atomics on
+// one LDS word, a 45-stage bitonic sort of 512 keys behind 16 waves' barriers).  Round 3:
+//   * a thread's <= 12 keys stay in registers; the eight passes' histograms are separate (zeroed once):
+//     ONE barrier per pass, every wave does the 256-bin scan itself (no broadcast through LDS);
+//   * the survivors are compacted with one atomic per wave-instruction and ordered by RANK
+//     (rank = the number of larger survivors: two threads per survivor, 16-byte LDS reads) -- one barrier.
 #include "kernels.hpp"
 
 namespace tc {
 
 constexpr int DEC_THREADS = 1024;
-constexpr int DEC_MAXN = 12288;   // Q * num_classes upper bound (96 KB of keys)
+constexpr int DEC_MAXN = 12288;   // Q * num_classes upper bound
+constexpr int DEC_NK = DEC_MAXN / DEC_THREADS;
 constexpr int DEC_MAXK = 512;
+constexpr int DEC_PASSES = 9;     // the bucket pass + up to eight byte passes (bit 63 = the score's sign = 0)
 
 struct DecK {
   const float* cls; const float* box; int Q, ncls, code, K;
@@ -19,115 +25,212 @@ struct DecK {
   float* boxes; float* scores; int* labels; unsigned char* valid;
 };
 
+#ifdef TC_CHAIN_STAMPS
+__device__ long long g_dec_stamps[16];
+#define DEC_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_dec_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DEC_STAMP(i) do {} while (0)
+#endif
+
+struct DecLds {
+  alignas(16) unsigned int hist[DEC_PASSES][256];
+  alignas(16) unsigned long long sel[DEC_MAXK];      // survivors, any order; zero behind them
+  unsigned int rank[DEC_MAXK];                       // survivor -> its place in descending order
+  unsigned int count, ccount;
+};
+
+__device__ __forceinline__ unsigned bucket(unsigned long long k) { return (unsigned)min(max((int)(k >> 51) - 1776, 0), 255); }
+
+// inclusive prefix sum over the 64 lanes (row_shr 1, 2, 4, 8; row_bcast 15 / 31), integers
+template <int CTRL, int ROWS>
+__device__ __forceinline__ int dpp_iadd(int v) { return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROWS, 0xF, false); }
+__device__ __forceinline__ int wave_scan_incl(int v) {
+  v = dpp_iadd<0x111, 0xF>(v); v = dpp_iadd<0x112, 0xF>(v); v = dpp_iadd<0x114, 0xF>(v); v = dpp_iadd<0x118, 0xF>(v);
+  v = dpp_iadd<0x142, 0xA>(v); v = dpp_iadd<0x143, 0xC>(v);
+  return v;
+}
+
 __global__ __launch_bounds__(DEC_THREADS) void box_decode_kernel(DecK p) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);          // [n]
-  unsigned long long* sel = keys + DEC_MAXN;                                         // [512]
-  unsigned int* hist = reinterpret_cast<unsigned int*>(sel + DEC_MAXK);              // [256]
-  unsigned int* misc = hist + 256;                                                   // [4]
-  const int b = blockIdx.x, tid = threadIdx.x;
+  __shared__ DecLds S;
+  extern __shared__ __align__(16) unsigned long long cand[];     // [Q * num_classes] the K-th key's bucket
+  DEC_STAMP(0);
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int n = p.Q * p.ncls;
   const float* cls = p.cls + (size_t)b * n;
-  for (int i = tid; i < n; i += DEC_THREADS) {
-    const float sg = sigmoidf_(cls[i]);          // in [0,1]: bit pattern is order preserving
-    keys[i] = ((unsigned long long)__float_as_uint(sg) << 32) | (unsigned int)(0xFFFFFFFFu - (unsigned)i);
-  }
-  __syncthreads();
-  const int K = min(p.K, n);
-  // radix select: K-th largest 64-bit key
-  unsigned long long prefix = 0, pmask = 0;
-  int remaining = K;
-  for (int pass = 7; pass >= 0; --pass) {
-    for (int i = tid; i < 256; i += DEC_THREADS) hist[i] = 0;
-    __syncthreads();
-    const int sh = pass * 8;
-    if (pass == 7) {
-      // top byte = sign + exponent bits: sigmoid outputs fall into a handful of bins,
-      // so the 64 lanes of a wave would serialise on one LDS word: aggregate per wave
-      for (int i0 = 0; i0 < n; i0 += DEC_THREADS) {
-        const int i = i0 + tid;
-        const bool valid = i < n;
-        const unsigned digit = valid ? (unsigned)(keys[i] >> sh) & 255u : 0u;
-        unsigned long long active = __ballot(valid);
-        while (active) {
-          const int leader = __ffsll((long long)active) - 1;
-          const unsigned d = __shfl(digit, leader, 64);
-          const unsigned long long same = __ballot(valid && digit == d);
-          if ((tid & 63) == leader) atomicAdd(&hist[d], (unsigned)__popcll(same));
-          active &= ~same;
-        }
-      }
-    } else {
-      for (int i = tid; i < n; i += DEC_THREADS) {
-        const unsigned long long k = keys[i];
-        if ((k & pmask) == prefix) atomicAdd(&hist[(unsigned)(k >> sh) & 255u], 1u);
-      }
-    }
-    __syncthreads();
-    if (tid < 64) {
-      // wave-parallel scan from the top bin down (a serial 256-step scan by one
-      // thread cost ~7 us per pass): lane l owns descending bins 255-4l .. 252-4l
-      const int b0 = 255 - 4 * tid;
-      const int c0 = hist[b0], c1 = hist[b0 - 1], c2 = hist[b0 - 2], c3 = hist[b0 - 3];
-      const int sum = c0 + c1 + c2 + c3;
-      int incl = sum;
+  float logit[DEC_NK];
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int up = __shfl_up(incl, o, 64);
-        if (tid >= o) incl += up;
-      }
-      const int excl = incl - sum;
-      if (excl < remaining && remaining <= incl) {     // exactly one lane
-        int cum = excl, bin = b0;
-        if (cum + c0 < remaining) { cum += c0; bin = b0 - 1;
-          if (cum + c1 < remaining) { cum += c1; bin = b0 - 2;
-            if (cum + c2 < remaining) { cum += c2; bin = b0 - 3; } } }
-        misc[0] = bin; misc[1] = remaining - cum;
-        // every key of the chosen bin is wanted: the lower digits cannot change the
-        // selection, the remaining passes (normally the four over the index half of
-        // the key, ties between scores being rare) are skipped
-        misc[3] = (remaining - cum == (int)hist[bin]) ? 1u : 0u;
-      }
+  for (int j = 0; j < DEC_NK; ++j) {
+    const int i = tid + j * DEC_THREADS;
+    logit[j] = i < n ? cls[i] : 0.0f;
+  }
+  // (under the loads)
+  for (int i = tid; i < DEC_PASSES * 256; i += DEC_THREADS) (&S.hist[0][0])[i] = 0u;
+  for (int i = tid; i < DEC_MAXK; i += DEC_THREADS) { S.sel[i] = 0ull; S.rank[i] = 0u; }
+  if (tid == 0) { S.count = 0u; S.ccount = 0u; }
+  unsigned long long key[DEC_NK];
+#pragma unroll
+  for (int j = 0; j < DEC_NK; ++j) {
+    const int i = tid + j * DEC_THREADS;
+    // sigmoid in [0, 1]: the bit pattern is order preserving.  0 marks "no key" (a real key's low word is ~i != 0)
+    key[j] = i < n ? ((unsigned long long)__float_as_uint(sigmoidf_(logit[j])) << 32) | (unsigned int)(0xFFFFFFFFu - (unsigned)i)
+                   : 0ull;
+  }
+  __syncthreads();                                    // histograms zeroed
+  DEC_STAMP(1);
+#pragma unroll
+  for (int j = 0; j < DEC_NK; ++j)
+    if (key[j] != 0ull) atomicAdd(&S.hist[0][bucket(key[j])], 1u);
+  __syncthreads();
+  DEC_STAMP(2);
+  const int K = min(p.K, n);
+  // radix select: the K-th largest key.
+  // Pass 0 does NOT look at a bit field: the exponent byte of a sigmoid output takes a handful of values, the 64
+  // lanes of a wave serialise on one LDS word (17 K cycles even with one add per distinct digit of a
+  // wave-instruction).  Any MONOTONE bucket function will do: bucket(key) = the score's exponent and top four
+  // mantissa bits, v = key >> 51, as v - 1776 clamped to [0, 255] -- sixteen buckets per octave from 2^-16 up to 1;
+  // bucket 0 (everything up to 2^-16) and bucket 255 (v >= 2031) are catch-alls.
+  // A sweep over a thread's 12 keys costs ~2.5 K cycles however little it does (16 waves x 12 keys on 4 SIMDs), so
+  // there are two: the one above (keys + bucket histogram) and ONE that files every key by its bucket -- above the
+  // K-th key's bucket: selected; in it: a candidate (LDS list).  The byte passes then run over the candidates
+  // only.  The keys of a bucket 1..254 share their top 12 bits: the byte passes continue below them; in a
+  // catch-all they start from the top.
+  unsigned long long prefix = 0, pmask = 0, floor_ = 0;
+  int remaining = K, npass = 0, sh = 0;
+  bool done;
+  // every wave scans a histogram's 256 bins from the top down (lane l owns bins 255-4l .. 252-4l): the bin that
+  // holds the remaining-th key, the keys above that bin, the bin's own count -- the same in every wave
+  auto scan = [&](const unsigned int* hist, int& bin, int& cum, int& cnt) {
+    const uint4 h4 = *reinterpret_cast<const uint4*>(&hist[252 - 4 * lane]);
+    const int c0 = (int)h4.w, c1 = (int)h4.z, c2 = (int)h4.y, c3 = (int)h4.x;
+    const int sum = c0 + c1 + c2 + c3;
+    const int incl = wave_scan_incl(sum);
+    const int excl = incl - sum;
+    const bool mine = excl < remaining && remaining <= incl;      // exactly one lane
+    cum = excl; bin = 255 - 4 * lane; cnt = c0;
+    if (cum + c0 < remaining) { cum += c0; bin -= 1; cnt = c1;
+      if (cum + c1 < remaining) { cum += c1; bin -= 1; cnt = c2;
+        if (cum + c2 < remaining) { cum += c2; bin -= 1; cnt = c3; } } }
+    const int owner = __builtin_ctzll(__ballot(mine));
+    bin = __builtin_amdgcn_readlane(bin, owner); cum = __builtin_amdgcn_readlane(cum, owner);
+    cnt = __builtin_amdgcn_readlane(cnt, owner);
+  };
+  const unsigned long long below = (1ull << lane) - 1ull;
+  int fstar, cum, cnt;
+  scan(S.hist[0], fstar, cum, cnt);
+  remaining -= cum;
+  // every key of the chosen bin is wanted: the lower digits cannot change the selection, the remaining
+  // passes (normally those over the index half of the key, ties between scores being rare) are skipped
+  done = remaining == cnt;
+  floor_ = fstar == 0 ? 0ull : (unsigned long long)(fstar + 1776) << 51;         // the bucket's lower bound
+  DEC_STAMP(3);
+  {
+    unsigned long long ms[DEC_NK], mc[DEC_NK];
+    int ts = 0, tc_ = 0;
+#pragma unroll
+    for (int j = 0; j < DEC_NK; ++j) {
+      const int bj = key[j] != 0ull ? (int)bucket(key[j]) : -1;
+      ms[j] = __ballot(bj > fstar || (done && bj == fstar));
+      mc[j] = __ballot(!done && bj == fstar);
+      ts += __popcll(ms[j]); tc_ += __popcll(mc[j]);
     }
-    __syncthreads();
-    prefix |= (unsigned long long)misc[0] << sh;
-    pmask |= 0xFFull << sh;
-    remaining = (int)misc[1];
-    const bool done = misc[3] != 0;
-    __syncthreads();
-    if (done) break;
+    unsigned bs = 0, bc = 0;
+    if (lane == 0) {                                     // one atomic per list and wave
+      if (ts) bs = atomicAdd(&S.count, (unsigned)ts);
+      if (tc_) bc = atomicAdd(&S.ccount, (unsigned)tc_);
+    }
+    bs = (unsigned)__builtin_amdgcn_readfirstlane((int)bs); bc = (unsigned)__builtin_amdgcn_readfirstlane((int)bc);
+#pragma unroll
+    for (int j = 0; j < DEC_NK; ++j) {
+      if ((ms[j] >> lane) & 1ull) { const unsigned pos = bs + (unsigned)__popcll(ms[j] & below); if (pos < DEC_MAXK) S.sel[pos] = key[j]; }
+      if ((mc[j] >> lane) & 1ull) cand[bc + (unsigned)__popcll(mc[j] & below)] = key[j];
+      bs += (unsigned)__popcll(ms[j]); bc += (unsigned)__popcll(mc[j]);
+    }
   }
-  const unsigned long long thr = prefix;    // exactly K keys are >= thr (keys are unique)
-  if (tid == 0) misc[2] = 0;
-  for (int i = tid; i < DEC_MAXK; i += DEC_THREADS) sel[i] = 0;
-  __syncthreads();
-  for (int i = tid; i < n; i += DEC_THREADS) {
-    const unsigned long long k = keys[i];
-    if (k >= thr) { const unsigned pos = atomicAdd(&misc[2], 1u); if (pos < DEC_MAXK) sel[pos] = k; }
-  }
-  __syncthreads();
-  // bitonic sort of 512 keys, descending
-  for (int size = 2; size <= DEC_MAXK; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      if (tid < DEC_MAXK / 2) {
-        const int lo = 2 * tid - (tid & (stride - 1));
-        const int hi = lo + stride;
-        const bool desc = ((lo & size) == 0);
-        const unsigned long long a = sel[lo], c = sel[hi];
-        if ((a < c) == desc) { sel[lo] = c; sel[hi] = a; }
+  DEC_STAMP(4);
+  if (!done) {
+    const bool normal = fstar >= 1 && fstar <= 254;
+    prefix = normal ? floor_ : 0ull;
+    pmask = normal ? 0xFFFull << 51 : 0ull;
+    sh = normal ? 51 : 63;
+    __syncthreads();
+    const int ncand = (int)S.ccount;
+#pragma unroll 1
+    for (;;) {
+      const int w = min(8, sh);                          // the last field is what is left: 3 or 7 bits
+      sh -= w;
+      const unsigned dmask = (1u << w) - 1u;
+      unsigned int* hist = S.hist[++npass];
+      for (int i = tid; i < ncand; i += DEC_THREADS) {
+        const unsigned long long k = cand[i];
+        if ((k & pmask) == prefix) atomicAdd(&hist[(unsigned)(k >> sh) & dmask], 1u);
       }
+      pmask |= (unsigned long long)dmask << sh;
       __syncthreads();
+      int bin;
+      scan(hist, bin, cum, cnt);
+      remaining -= cum;
+      prefix |= (unsigned long long)(unsigned)bin << sh;
+      DEC_STAMP(4 + npass);
+      if (remaining == cnt || sh == 0) break;
+    }
+    // exactly `remaining` candidates are >= prefix (keys are unique; prefix has zeros below the digits examined;
+    // in the upper catch-all an early exit can leave it below the bucket's floor -- the list holds the bucket only)
+    for (int i0 = 0; i0 < ncand; i0 += DEC_THREADS) {
+      const int i = i0 + tid;
+      const unsigned long long k = i < ncand ? cand[i] : 0ull;
+      const unsigned long long m = __ballot(k != 0ull && k >= prefix);
+      if (m != 0ull) {
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(&S.count, (unsigned)__popcll(m));
+        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+        const unsigned pos = base + (unsigned)__popcll(m & below);
+        if (((m >> lane) & 1ull) && pos < DEC_MAXK) S.sel[pos] = k;
+      }
     }
   }
-  for (int i = tid; i < p.K; i += DEC_THREADS) {
+  DEC_STAMP(11);
+  __syncthreads();
+  DEC_STAMP(12);
+  // rank, descending: a survivor's place = the number of survivors above it.  A thread compares FOUR survivors
+  // (registers) with one slice of the list (16-byte LDS reads: with one survivor per thread the 1024 threads
+  // pulled 1.2 MB through the LDS port -- 10 K cycles) and adds its counts to the survivors' rank words.
+  {
+    const int kpad = (K + 3) & ~3;
+    const int groups = kpad >> 2, parts = DEC_THREADS / groups;           // K = 300: 75 groups x 13 slices
+    const int g = tid % groups, part = tid / groups;
+    int chunk = (kpad + parts - 1) / parts;
+    chunk = (chunk + 1) & ~1;
+    if (part < parts) {
+      const ulonglong2 a01 = *reinterpret_cast<const ulonglong2*>(&S.sel[4 * g]);
+      const ulonglong2 a23 = *reinterpret_cast<const ulonglong2*>(&S.sel[4 * g + 2]);
+      int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+      const int j1 = min(kpad, (part + 1) * chunk);
+      for (int j = part * chunk; j < j1; j += 2) {
+        const ulonglong2 o = *reinterpret_cast<const ulonglong2*>(&S.sel[j]);
+        r0 += (o.x > a01.x ? 1 : 0) + (o.y > a01.x ? 1 : 0);
+        r1 += (o.x > a01.y ? 1 : 0) + (o.y > a01.y ? 1 : 0);
+        r2 += (o.x > a23.x ? 1 : 0) + (o.y > a23.x ? 1 : 0);
+        r3 += (o.x > a23.y ? 1 : 0) + (o.y > a23.y ? 1 : 0);
+      }
+      if (r0) atomicAdd(&S.rank[4 * g + 0], (unsigned)r0);
+      if (r1) atomicAdd(&S.rank[4 * g + 1], (unsigned)r1);
+      if (r2) atomicAdd(&S.rank[4 * g + 2], (unsigned)r2);
+      if (r3) atomicAdd(&S.rank[4 * g + 3], (unsigned)r3);
+    }
+  }
+  __syncthreads();
+  DEC_STAMP(13);
+  // thread t decodes survivor t into output row rank[t]; rows K .. max_num - 1 (fewer candidates than max_num): zeros
+  for (int t = tid; t < p.K; t += DEC_THREADS) {
+    const int i = t < K ? (int)S.rank[t] : t;
     float* ob = p.boxes + ((size_t)b * p.K + i) * 9;
-    if (i >= K) {
+    if (t >= K) {
       for (int j = 0; j < 9; ++j) ob[j] = 0.f;
       p.scores[(size_t)b * p.K + i] = 0.f; p.labels[(size_t)b * p.K + i] = -1;
       p.valid[(size_t)b * p.K + i] = 0;
       continue;
     }
-    const unsigned long long k = sel[i];
+    const unsigned long long k = S.sel[t];
     const int idx = (int)(0xFFFFFFFFu - (unsigned int)(k & 0xFFFFFFFFull));
     const float score = __uint_as_float((unsigned int)(k >> 32));
     const int label = idx % p.ncls, bi = idx / p.ncls;
@@ -145,7 +248,14 @@ __global__ __launch_bounds__(DEC_THREADS) void box_decode_kernel(DecK p) {
     p.labels[(size_t)b * p.K + i] = label;
     p.valid[(size_t)b * p.K + i] = ok ? 1 : 0;
   }
+  DEC_STAMP(14);
 }
+
+#ifdef TC_CHAIN_STAMPS
+extern "C" int tc_debug_decode_stamps(long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dec_stamps), sizeof(long long) * 16);
+}
+#endif
 
 size_t box_decode_ws_bytes(int, int, int) { return 256; }
 
@@ -159,11 +269,11 @@ int launch_box_decode(const float* cls, const float* box, int B, int Q, int ncls
   p.cls = cls; p.box = box; p.Q = Q; p.ncls = ncls; p.code = code; p.K = max_num;
   for (int i = 0; i < 6; ++i) p.pcr[i] = pcr6_host[i];
   p.boxes = boxes; p.scores = scores; p.labels = labels; p.valid = valid;
-  const size_t lds = (size_t)DEC_MAXN * 8 + DEC_MAXK * 8 + 256 * 4 + 16;
+  const size_t lds = (size_t)((Q * ncls + 1) & ~1) * 8;
   static DeviceOnce once;
   if (const int once_dev = once.need(); once_dev >= 0) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(box_decode_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, DEC_MAXN * 8);
     if (e != hipSuccess) { set_error("box_decode: %s", hipGetErrorString(e)); return (int)e; }
     once.done(once_dev);
   }
