@@ -148,6 +148,14 @@ typedef struct {
                                beyond one frame per launch, which is what automatic does).  Outputs are
                                bit-identical either way */
   unsigned long long dropout_seed;
+  int phase;                /* the fused forward in two calls (same arguments, same workspace, same stream):
+                               0 = the whole forward; 1 = only what does not read `radar_tokens` -- the prologue and
+                               decoder layers 0 .. L-3 (the radar encoders then ride in the launches of the LAST two
+                               decoder layers instead of the first two: their K/V feed only the fusion stack);
+                               2 = the rest.  Between 1 and 2
+                               the caller builds the tokens (host packing, H2D, tc_radar_build_tokens*) while the
+                               device already runs the decoder: Detr3DHead.forward does exactly that */
+  int reserved_;
 } tc_head_options;
 
 /* ---- library ---- */

@@ -25,7 +25,17 @@ def test_two_ranks_on_one_gpu_end_with_the_same_parameters():
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'multirank_worker.py')], env=env,
                                       cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    outs = [p.communicate(timeout=600) for p in procs]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=240))
+    except subprocess.TimeoutExpired:
+        tails = []
+        for p in procs:                      # never leave a rank behind on the GPU
+            p.kill()
+            o, e = p.communicate()
+            tails.append((o or '')[-800:] + '\n' + (e or '')[-1500:])
+        pytest.fail('a rank did not finish within 240 s:\n' + '\n-----\n'.join(tails))
     for p, (o, e) in zip(procs, outs):
         assert p.returncode == 0, e[-2000:]
     line = [ln for ln in outs[0][0].splitlines() if ln.startswith('MULTIRANK ')]

@@ -1066,6 +1066,41 @@ def test_timed_geometry_is_frame_by_frame_the_single_frame_path(T, fpl):
             assert torch.equal(a_[0], b_[slot]), (lane, slot)
 
 
+@pytest.mark.parametrize('batch', [1, 3])
+def test_forward_in_two_phases_around_the_token_build(T, head, batch):
+    """tc_head_options.phase: phase 1 (prologue + decoder layers 0 .. L-3) is enqueued while the tokens do not exist
+    yet, the caller fills them (here: a copy on the side stream forward_nhwc uses), phase 2 does the rest --
+    every output and aux tensor bit-identical to the one-call forward (4- and 8-row tiles)."""
+    from transcar_amd import ops
+    l2i = synth.make_lidar2img()
+    feats = [gpu(np.concatenate([f] * batch, 0)) for f in synth.make_feats('tiny', seed=1, smooth=SMOOTH)]
+    nhwc = ops.to_nhwc_levels(feats)
+    hw = configs.IMG_SHAPE[:2]
+    metas = synth.make_img_metas(batch, l2i, radar=synth.make_radar_frame(seed=2, n_per_radar=40))
+    tok, pm = head.radar_tokens(metas, dev())
+    l2i_t = ops.lidar2img_tensor(metas, dev())
+    want = head.forward_nhwc(nhwc, l2i_t, hw, tok, pm, aux=True)
+    empty = torch.full_like(tok, float('nan'))
+    calls = []
+
+    def fill():
+        calls.append(1)
+        empty.copy_(tok)
+    got = head.forward_nhwc(nhwc, l2i_t, hw, empty, pm, aux=True, fill_tokens=fill)
+    assert calls == [1]
+    for k in ('all_cls_scores', 'all_bbox_preds'):
+        assert torch.equal(got[k], want[k]), k
+    for k, v in want['aux'].items():
+        assert torch.equal(got['aux'][k], v), k
+    # the phases by hand, and a bad phase is refused
+    o1 = T.detr3d_head.head_options(phase=1)
+    with pytest.raises(T.TransCARHipError):
+        head.forward_nhwc(nhwc, l2i_t, hw, tok, pm, options=T.detr3d_head.head_options(phase=3))
+    with pytest.raises(T.TransCARHipError):
+        head.forward_nhwc(nhwc, l2i_t, hw, tok, pm, options=T.detr3d_head.head_options(phase=1, unfused=True))
+    assert o1.phase == 1
+
+
 def test_device_radar_ingest_inside_forward_and_as_a_graph_node(T, head):
     """VERDICT r2 (missing 4): tc_radar_build_tokens is no island any more.
     (i) ``head(mlvl_feats, img_metas)`` with RAW sweeps in img_metas builds the tokens on the device

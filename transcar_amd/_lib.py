@@ -116,7 +116,7 @@ class tc_head_options(C.Structure):
     _fields_ = [('chain_tile_rows', C.c_int), ('unfused', C.c_int),
                 ('last_level_cls_only', C.c_int), ('reuse_radar_kv', C.c_int),
                 ('decoder_dropout_p', C.c_float), ('radar_row_order', C.c_int),
-                ('dropout_seed', C.c_ulonglong)]
+                ('dropout_seed', C.c_ulonglong), ('phase', C.c_int), ('reserved_', C.c_int)]
 
 
 _P = C.POINTER

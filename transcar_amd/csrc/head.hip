@@ -180,8 +180,12 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
   unsigned long long* pairs = aux ? aux->sample_pairs : nullptr;
   const bool radar = w->num_radar_layers > 0;
 
-  // the radar encoders and K/V projections do not depend on the decoder: they ride in
-  // the launch of decoder layer 0 as 16 extra workgroups (chain_dual_kernel)
+  // the radar encoders and K/V projections do not depend on the decoder: they ride in the launches of two
+  // decoder layers as extra workgroups (chain_dual_kernel): layers 0 and 1 in the one-call forward; the LAST
+  // two when the forward comes in two phases (options.phase) -- their K/V feed only the fusion stack, and a
+  // caller that still has to build the tokens does so while the device runs the layers before
+  const int enc_first = opt.phase != 0 && L > 1 ? L - 2 : 0;
+  const int lid_begin = opt.phase == 2 ? enc_first : 0, lid_end = opt.phase == 1 ? enc_first : L;
   RadarEncodeArgs re;
   if (radar) {
     re.tokens = radar_tokens; re.RI = w->radar_in_dims; re.M = rt;
@@ -200,18 +204,18 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
   // train-mode statistics of the frozen decoder: five dropout sites per layer (sites 16 + 8 l + 0..4)
   const bool ddrop = opt.decoder_dropout_p > 0.0f;
   TC_REQUIRE(!ddrop || (unsigned long long)B * H * Q * Q < (1ull << 32), "decoder dropout: B*H*Q*Q exceeds 32 bits");
-  if (radar && ddrop) TC_TRY(launch_radar_encode(re, s));     // no ride in the decoder launches then
+  if (radar && ddrop && opt.phase != 1) TC_TRY(launch_radar_encode(re, s));     // no ride in the decoder launches then
   // layer 0 up to its attention output is a constant of the checkpoint (pack time) -- in eval
   // mode: with dropout on the attention probabilities it is not
   const bool folded = !ddrop && w->l0_attn_out != nullptr && w->l0_init_reference != nullptr;
-  if (!folded) {
+  if (!folded && opt.phase != 2) {
     PrologueArgs pa;
     pa.qe = w->query_embedding; pa.Q = Q; pa.M = rows; pa.refpts = w->reference_points;
     pa.in_proj = w->layers[0].self_attn.in_proj; pa.init_ref = h.init_ref; pa.qk = h.qk; pa.vt = h.vt;
     pa.qpad = h.qpad; pa.qscale = attn_qscale; pa.w16_delta = w->packed16_delta;
     TC_TRY(launch_prologue(pa, s));
   }
-  for (int lid = 0; lid < L; ++lid) {
+  for (int lid = lid_begin; lid < lid_end; ++lid) {
     const bool l0c = folded && lid == 0;
     const float* ref_in = l0c ? w->l0_init_reference
                               : lid == 0 ? h.init_ref : h.inter_refs + (size_t)(lid - 1) * rows * 3;
@@ -236,12 +240,12 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
     d.cam.img_h = img_h; d.cam.img_w = img_w; d.cam.out = nullptr; d.cam.vis = nullptr;
     d.cam.pair_counter = pairs;
     d.code = code; d.M = rows; d.tile_rows = opt.chain_tile_rows;
-    // the radar encoders ride in the launches of layers 0 and 1, half each (all in layer 0
-    // when there is only one layer)
-    if (radar && !ddrop && lid == 0) TC_TRY(launch_decoder_chain_with_encoders(d, re, L > 1 ? 1 : 0, s));
-    else if (radar && !ddrop && lid == 1) TC_TRY(launch_decoder_chain_with_encoders(d, re, 2, s));
+    // the radar encoders ride in two launches, half each (all in layer 0 when there is only one layer)
+    if (radar && !ddrop && lid == enc_first) TC_TRY(launch_decoder_chain_with_encoders(d, re, L > 1 ? 1 : 0, s));
+    else if (radar && !ddrop && L > 1 && lid == enc_first + 1) TC_TRY(launch_decoder_chain_with_encoders(d, re, 2, s));
     else TC_TRY(launch_decoder_chain(d, s));
   }
+  if (opt.phase == 1) return 0;
   if (aux) {
     if (aux->init_reference) {
       if (folded) {
@@ -526,6 +530,9 @@ static int read_options(const tc_head_options* options, tc_head_options& opt) {
              "options.chain_tile_rows=%d (0 = automatic, 4, 8 or 16)", opt.chain_tile_rows);
   TC_REQUIRE(opt.decoder_dropout_p >= 0.0f && opt.decoder_dropout_p < 1.0f, "options.decoder_dropout_p=%g",
              (double)opt.decoder_dropout_p);
+  TC_REQUIRE(opt.phase >= 0 && opt.phase <= 2, "options.phase=%d (0 whole forward, 1 before the radar tokens, 2 the rest)",
+             opt.phase);
+  TC_REQUIRE(opt.phase == 0 || !opt.unfused, "options.phase=%d needs the fused path", opt.phase);
   return 0;
 }
 

@@ -48,7 +48,7 @@ DEFAULT_TILE_ROWS = _env_tile_rows()
 
 
 def head_options(tile_rows=None, unfused=None, last_level_cls_only=False,
-                 decoder_dropout_p=0.0, dropout_seed=0, radar_compact=None):
+                 decoder_dropout_p=0.0, dropout_seed=0, radar_compact=None, phase=0):
     """tc_head_options for one forward.  unfused=None: the TRANSCAR_UNFUSED=1
     environment switch of the operator-by-operator cross-check path (a host-side
     knob: the library itself reads no environment)."""
@@ -61,6 +61,7 @@ def head_options(tile_rows=None, unfused=None, last_level_cls_only=False,
     # radar_compact: None = automatic (beyond one frame per launch), False / True = never / always
     o.radar_row_order = 0 if radar_compact is None else (2 if radar_compact else 1)
     o.dropout_seed = int(dropout_seed) & 0xFFFFFFFFFFFFFFFF
+    o.phase = int(phase)          # 0: the whole forward; 1 / 2: before / after the radar tokens exist (forward_nhwc)
     return o
 
 
@@ -179,6 +180,7 @@ class Detr3DHead(BaseModule):
         #: 'host': the reference's numpy route (transcar_amd/radar.py)
         self.radar_ingest = 'device'
         self._radar_stage = {}
+        self._ingest_streams = {}       # device -> side stream of the two-phase forward (forward_nhwc(fill_tokens=))
         #: bumped whenever a device buffer a captured hipGraph may point at (packed weights,
         #: lane workspaces) is re-allocated: FramePipeline refuses to replay a stale capture
         self.buffers_generation = 0
@@ -370,6 +372,16 @@ class Detr3DHead(BaseModule):
                     "img_metas[i]['radar'] is required: raw sweeps "
                     '(transcar_amd/radar.py) or an [n,36] feature array')
             raws.append(m['radar'])
+        tokens, pad_mult, fill = self._radar_tokens_plan(raws, device, T, ingest)
+        if fill is not None:
+            fill()
+        return tokens, pad_mult
+
+    def _radar_tokens_plan(self, raws, device, T=None, ingest=None):
+        """-> (tokens [B,T,36], pad_mult, fill).  Device ingest of raw sweeps: `tokens` is allocated but EMPTY and
+        ``fill()`` does the work (host packing of the raw rows, three H2D copies per sample, one launch) -- so that
+        ``forward`` can enqueue the part of the decoder that does not read the tokens first
+        (tc_head_options.phase).  Otherwise the tokens are ready and fill is None."""
         mode = ingest or getattr(self, 'radar_ingest', 'device')
         if mode == 'device' and all(isinstance(r, dict) for r in raws):
             n_raw = [sum(int(np.asarray(r['points'][c]).shape[1]) for c in radar.RADAR_CHANNELS) for r in raws]
@@ -381,20 +393,22 @@ class Detr3DHead(BaseModule):
             stage = self._radar_stage.get(key)
             if stage is None or stage.cap < cap:
                 stage = self._radar_stage[key] = ops.RadarRawStage(B, cap, device)
-            for b, r in enumerate(raws):
-                stage.put(b, r)
             tokens = torch.empty((B, T, radar.NUM_FEATURES), dtype=torch.float32, device=device)
-            _, pad_mult = stage.build(tokens)
-            if T < radar.NUM_RADAR_TOKENS and max(n_raw) > T - 1:
-                ops.radar_check_fits(stage.count, T)     # an explicit T: the kept points must fit (one D2H sync)
-            return tokens, pad_mult
+
+            def fill():
+                for b, r in enumerate(raws):
+                    stage.put(b, r)
+                stage.build(tokens)
+                if T < radar.NUM_RADAR_TOKENS and max(n_raw) > T - 1:
+                    ops.radar_check_fits(stage.count, T)     # an explicit T: the kept points must fit (one D2H sync)
+            return tokens, radar.NUM_RADAR_TOKENS - T + 1, fill
         feats = [radar.build_radar_features(r) for r in raws]
         tokens, pad_mult = radar.pack_tokens(feats, T=T)
-        return torch.from_numpy(tokens).to(device), pad_mult
+        return torch.from_numpy(tokens).to(device), pad_mult, None
 
     def forward_nhwc(self, feats_nhwc, lidar2img, img_hw, tokens, pad_mult,
                      aux=False, _allow_train=False, lane=0, decoder_only=False,
-                     options=None):
+                     options=None, fill_tokens=None):
         """The device-side forward: everything already on the GPU.
         feats_nhwc: list of [B*N,H,W,C]; lidar2img [B,N,4,4]; tokens [B,T,36].
         Only enqueues work on the current stream (graph-capturable).
@@ -403,7 +417,10 @@ class Detr3DHead(BaseModule):
         owns a workspace; the weights are shared.
         decoder_only: stop after the DETR3D decoder (aux carries its states);
         the training iteration recomputes the radar stack itself.
-        options: tc_head_options (``head_options(...)``); None = defaults."""
+        options: tc_head_options (``head_options(...)``); None = defaults.
+        fill_tokens: callable that writes `tokens` (allocated, still empty): the forward is enqueued in two
+        phases around it (tc_head_options.phase) -- the decoder layers that do not read the tokens first, so the
+        device works while the host packs the radar frame."""
         if not _allow_train:
             require_eval(self)
         w = self.head_weights()
@@ -461,15 +478,38 @@ class Detr3DHead(BaseModule):
                 sample_pairs=torch.zeros(1, dtype=torch.int64, device=dev))
             aux_s = L.tc_head_aux(**{k: t.data_ptr()
                                      for k, t in aux_t.items()})
-        L.check(lib.tc_head_forward(
-            C.byref(w), C.byref(packed), C.byref(fv), B,
-            lidar2img.data_ptr(),
-            float(img_hw[0]), float(img_hw[1]), tokens.data_ptr(), T,
-            int(pad_mult), cls.data_ptr(), box.data_ptr(),
-            C.byref(aux_s) if aux_s is not None else None,
-            C.byref(options), ws.data_ptr(), ws.numel(),
-            C.c_void_p(torch.cuda.current_stream().cuda_stream)),
-            'tc_head_forward')
+        def call(opts):
+            L.check(lib.tc_head_forward(
+                C.byref(w), C.byref(packed), C.byref(fv), B,
+                lidar2img.data_ptr(),
+                float(img_hw[0]), float(img_hw[1]), tokens.data_ptr(), T,
+                int(pad_mult), cls.data_ptr(), box.data_ptr(),
+                C.byref(aux_s) if aux_s is not None else None,
+                C.byref(opts), ws.data_ptr(), ws.numel(),
+                C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                'tc_head_forward')
+        if fill_tokens is None:
+            call(options)
+        elif options.unfused or options.phase != 0:
+            fill_tokens()
+            call(options)
+        else:
+            # the copies and the ingest launch go to a side stream: they run beside decoder layers 0 .. L-3
+            cur = torch.cuda.current_stream()
+            side = self._ingest_streams.get(str(dev))
+            if side is None:
+                side = self._ingest_streams[str(dev)] = torch.cuda.Stream(device=dev)
+            side.wait_stream(cur)                 # (what is already enqueued: an earlier forward may still read
+            two = L.tc_head_options()             #  memory the allocator hands out again)
+            C.memmove(C.byref(two), C.byref(options), C.sizeof(two))
+            two.phase = 1
+            call(two)
+            with torch.cuda.stream(side):
+                fill_tokens()
+            tokens.record_stream(side)
+            cur.wait_stream(side)
+            two.phase = 2
+            call(two)
         outs = {'all_cls_scores': cls, 'all_bbox_preds': box,
                 'enc_cls_scores': None, 'enc_bbox_preds': None}
         if aux:
@@ -487,12 +527,22 @@ class Detr3DHead(BaseModule):
         feats_nhwc = ops.to_nhwc_levels(mlvl_feats)       # one launch; channels_last levels zero-copy
         l2i = ops.lidar2img_tensor(img_metas, dev)
         img_hw = img_metas[0]['img_shape'][0][:2]           # XFMR:403-404
-        tokens, pad_mult = self.radar_tokens(img_metas, dev)
+        raws = []
+        for m in img_metas:
+            if 'radar' not in m:
+                raise KeyError(
+                    "img_metas[i]['radar'] is required: raw sweeps "
+                    '(transcar_amd/radar.py) or an [n,36] feature array')
+            raws.append(m['radar'])
+        tokens, pad_mult, fill = self._radar_tokens_plan(raws, dev)
         if self.training:
+            if fill is not None:
+                fill()
             return self.forward_train_nhwc(feats_nhwc, l2i, img_hw, tokens,
                                            pad_mult)
+        # raw sweeps: the decoder layers that do not read the tokens are enqueued BEFORE the host packs the frame
         return self.forward_nhwc(feats_nhwc, l2i, img_hw, tokens, pad_mult,
-                                 aux=aux)
+                                 aux=aux, fill_tokens=fill)
 
     # ------------------------------------------------------------------
     # training forward: frozen decoder (fused HIP chains, no graph) + the

@@ -34,13 +34,22 @@ class NMSFreeCoder:
         if not z_shift:          # CODER returns gravity-centre z; HEAD:1018 shifts
             boxes = boxes.clone()
             boxes[..., 2] = boxes[..., 2] + boxes[..., 5] * 0.5
-        out = []
-        for i in range(boxes.shape[0]):
-            m = valid[i].bool()
-            if self.score_threshold:
-                m = m & (scores[i] > self.score_threshold)
-            out.append({'bboxes': boxes[i][m], 'scores': scores[i][m],
-                        'labels': labels[i][m].long()})
+        # CODER:66-84.  One host sync for the whole batch (the kept rows' indices), then plain gathers: three
+        # boolean-mask selects per sample were three syncs and nine small launches each
+        m = valid.bool()
+        if self.score_threshold:
+            m = m & (scores > self.score_threshold)
+        kept = torch.nonzero(m)                                  # [n, 2] (sample, row), row-major: rows stay sorted
+        counts = torch.bincount(kept[:, 0], minlength=boxes.shape[0]).tolist() if boxes.shape[0] > 1 \
+            else [int(kept.shape[0])]
+        flat = kept[:, 0] * boxes.shape[1] + kept[:, 1]
+        b_all = boxes.reshape(-1, boxes.shape[-1]).index_select(0, flat)
+        s_all = scores.reshape(-1).index_select(0, flat)
+        l_all = labels.reshape(-1).index_select(0, flat).long()
+        out, o = [], 0
+        for n in counts:
+            out.append({'bboxes': b_all[o:o + n], 'scores': s_all[o:o + n], 'labels': l_all[o:o + n]})
+            o += n
         return out
 
     def decode_single(self, cls_scores, bbox_preds):
