@@ -1331,16 +1331,20 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
         float* dst = buf_ptr(S, r.dst);
         const bool skip0 = (r.flags & F_NOT_W0) != 0;      // wave 0 is busy with the narrow linear step before
         const int row_first = skip0 ? wave - 1 : wave, row_step = skip0 ? CH_NW - 1 : CH_NW;
+        // decoder: lane i fetches and inverts the reference point of row i -- one round trip and one
+        // inverse_sigmoid per ROW of the tile (before: per row of the loop below, evaluated by all 64 lanes)
+        float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+        if (r.src != B_A && row_first >= 0) {
+          int grow = min(m0 + min(lane, R - 1), M - 1);
+          if (k.ref_mod > 0) grow = grow % k.ref_mod;
+          q0 = inverse_sigmoidf_(k.ref_in[(size_t)grow * 3 + 0]);
+          q1 = inverse_sigmoidf_(k.ref_in[(size_t)grow * 3 + 1]);
+          q2 = inverse_sigmoidf_(k.ref_in[(size_t)grow * 3 + 2]);
+        }
         for (int row = row_first; row < R && row >= 0; row += row_step) {
           float p0, p1, p2;
           if (r.src == B_A) { const float* tk = &S.unit[1][0][0] + row * LD5; p0 = tk[0]; p1 = tk[1]; p2 = tk[2]; }
-          else {
-            int grow = min(m0 + row, M - 1);
-            if (k.ref_mod > 0) grow = grow % k.ref_mod;
-            p0 = inverse_sigmoidf_(k.ref_in[(size_t)grow * 3 + 0]);
-            p1 = inverse_sigmoidf_(k.ref_in[(size_t)grow * 3 + 1]);
-            p2 = inverse_sigmoidf_(k.ref_in[(size_t)grow * 3 + 2]);
-          }
+          else { p0 = lane_f(q0, row); p1 = lane_f(q1, row); p2 = lane_f(q2, row); }
           if constexpr (PROG == PROG_RADAR_ENC_TRAIN) {
             // tape: the pre-LayerNorm values u0 (r.gt) and u1 = relu(LN(u0)) (r.gd)
             float4 pre;
@@ -1361,14 +1365,29 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
         if (CHAIN_DBG(k.dbg) & 8) break;
         int pairs = 0;
         CAM_STAMP(5);
+        // The projections of ALL the wave's rows first, 16 lanes per row (lane 16 i + c: row wave + 4 i, camera c):
+        // one round trip for the reference points and one for the lidar2img rows per WAVE instead of per row
+        // (stamps: 3 300 of a row's 7 700 cycles were its projection -- two dependent global loads and a
+        // division in front of the first tap).  Same arithmetic per (row, camera): bit-identical.
+        float pu, pv;
+        unsigned long long vm;
+        {
+          const int i = lane >> 4, c = lane & 15;
+          const int prow = wave + CH_NW * min(i, R / CH_NW - 1);
+          const int grow = min(m0 + prow, M - 1);
+          const bool act = i < R / CH_NW && c < k.cam.num_cams;
+          vm = __ballot(cam_project_lane(k.cam, k.ref_mod > 0 ? grow % k.ref_mod : grow, grow / k.Q,
+                                         min(c, k.cam.num_cams - 1), act, pu, pv));
+        }
 #pragma unroll 1
-        for (int row = wave; row < R; row += CH_NW) {
+        for (int i = 0; i < R / CH_NW; ++i) {
+          const int row = wave + CH_NW * i;
           const int grow = min(m0 + row, M - 1);
-          int nvis = 0;
-          const float4 o = cam_sample_row<4>(k.cam, k.ref_mod > 0 ? grow % k.ref_mod : grow, grow / k.Q,
-                                             &S.l[row][0], lane, nvis);
+          const unsigned long long vmask = (vm >> (16 * i)) & 0xFFFFull;
+          const float4 o = cam_sample_core<4>(k.cam, grow / k.Q, &S.l[row][0], lane, vmask, pu, pv,
+                                              [](int, int, int, const float* ptr) { return ld4(ptr); }, 16 * i);
           *reinterpret_cast<float4*>(buf_ptr(S, r.dst) + row * LD2 + 4 * lane) = o;
-          if (m0 + row < M) pairs += nvis;
+          if (m0 + row < M) pairs += __popcll(vmask);
         }
         CAM_STAMP(6);
         if (k.pair_counter != nullptr && lane == 0 && pairs > 0)

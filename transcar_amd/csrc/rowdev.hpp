@@ -143,15 +143,22 @@ __device__ __forceinline__ float lane_f(float v, int j) {
 // Weighted sum over the visible cameras (XFMR:365-373).  u, v: lane c holds camera c's
 // coordinates; lg: the query's num_cams*L attention logits (any address space);
 // fetch(c, l, t, ptr): this lane's 4 channels of tap t of level l of the c-th visible camera.
+// lane0: lane lane0 + c holds camera c's coordinates (0 for a single projected row; the row chains project
+// the four rows of a wave at once, 16 lanes apart)
 template <int L, typename Fetch>
 __device__ __forceinline__ float4 cam_sample_core(const CamK& p, int b, const float* lg, int lane,
-                                                  unsigned long long vmask, float u, float v, Fetch fetch) {
+                                                  unsigned long long vmask, float u, float v, Fetch fetch,
+                                                  int lane0 = 0) {
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   int c = 0;
+  // XFMR:370: the num_cams * L attention weights of the query, one per lane, ONCE (round 3: every lane evaluated
+  // sigmoid(lg[cam * L + l]) for itself inside the camera loop -- ~80 of its ~330 VALU instructions per visible
+  // camera; same function of the same value: bit-identical)
+  const float sg_lane = sigmoidf_(lg[min(lane, p.num_cams * L - 1)]);
   while (vmask) {
     const int cam = __ffsll((long long)vmask) - 1;
     vmask &= vmask - 1;
-    const float u_ = lane_f(u, cam), v_ = lane_f(v, cam);
+    const float u_ = lane_f(u, lane0 + cam), v_ = lane_f(v, lane0 + cam);
     float4 tap[L][4];
     float wgt[L][4];
     float w_lane;
@@ -179,7 +186,7 @@ __device__ __forceinline__ float4 cam_sample_core(const CamK& p, int b, const fl
       if (s.y != s.y) s.y = 0.f;
       if (s.z != s.z) s.z = 0.f;
       if (s.w != s.w) s.w = 0.f;
-      const float a = sigmoidf_(lg[cam * L + l]);   // XFMR:370, mask == 1 here
+      const float a = lane_f(sg_lane, cam * L + l);   // XFMR:370, mask == 1 here
       camacc.x += s.x * a; camacc.y += s.y * a; camacc.z += s.z * a; camacc.w += s.w * a;
     }
     acc.x += camacc.x; acc.y += camacc.y; acc.z += camacc.z; acc.w += camacc.w;
