@@ -22,10 +22,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def one(pattern):
-    g = sorted(glob.glob(pattern))
+    # the NEWEST match: gpurun merges a call's files into gpurun_out/ next to those of earlier calls (pid-named)
+    g = sorted(glob.glob(pattern), key=os.path.getmtime)
     if not g:
         raise SystemExit('missing ' + pattern)
-    return g[0]
+    return g[-1]
+
+
+def newest(pattern):
+    """matches, newest first"""
+    return sorted(glob.glob(pattern), key=os.path.getmtime, reverse=True)
 
 
 def short(name):
@@ -114,7 +120,7 @@ def main():
     if os.path.exists(tb):
         tl = [ln.strip() for ln in open(tb) if ln.strip().startswith('{')]
         open(os.path.join(dst, name + '_train_bench.json'), 'w').write('\n'.join(tl) + '\n')
-    ts = glob.glob(os.path.join(src, 'prof_train', '*', '*kernel_stats.csv'))
+    ts = newest(os.path.join(src, 'prof_train', '*', '*kernel_stats.csv'))
     if ts:
         open(os.path.join(dst, name + '_train_kernel_stats.csv'), 'w').write(open(ts[0]).read())
 
@@ -153,8 +159,8 @@ def main():
     open(os.path.join(dst, name + '_frame_trace.txt'), 'w').write('\n'.join(out) + '\n')
 
     # the default command: several frames in flight (transcar_amd/pipeline.py)
-    lt = glob.glob(os.path.join(src, 'prof_lanes', '*', '*kernel_trace.csv'))
-    ls = glob.glob(os.path.join(src, 'prof_lanes', '*', '*kernel_stats.csv'))
+    lt = newest(os.path.join(src, 'prof_lanes', '*', '*kernel_trace.csv'))
+    ls = newest(os.path.join(src, 'prof_lanes', '*', '*kernel_stats.csv'))
     if lt and ls:
         open(os.path.join(dst, name + '_lanes_kernel_stats.csv'), 'w').write(open(ls[0]).read())
         lrows = list(csv.DictReader(open(lt[0])))
@@ -200,7 +206,7 @@ def main():
     for B in ('1', '2', '4', '8', '9', '10'):
         per = defaultdict(dict)
         for ctr in ('FETCH_SIZE', 'WRITE_SIZE', 'SQ_VALU_MFMA_BUSY_CYCLES'):
-            fs = glob.glob(os.path.join(src, 'pmc_%s_b%s' % (ctr, B), '*', '*counter_collection.csv'))
+            fs = newest(os.path.join(src, 'pmc_%s_b%s' % (ctr, B), '*', '*counter_collection.csv'))
             if not fs:
                 continue
             acc = defaultdict(lambda: [0.0, 0.0, 0])
@@ -229,7 +235,7 @@ def main():
     json.dump(res, open(os.path.join(dst, name + '_pmc.json'), 'w'), indent=1)
     json.dump(out_m, open(os.path.join(dst, name + '_mfma_busy.json'), 'w'), indent=1)
     # one launch sequence of one frame at a time (--pair 1 --lanes 1): the latency anatomy
-    p1 = glob.glob(os.path.join(src, 'prof_pair1', '*', '*kernel_stats.csv'))
+    p1 = newest(os.path.join(src, 'prof_pair1', '*', '*kernel_stats.csv'))
     if p1:
         open(os.path.join(dst, name + '_pair1_kernel_stats.csv'), 'w').write(open(p1[0]).read())
     print(open(os.path.join(dst, name + '_frame_trace.txt')).read())
