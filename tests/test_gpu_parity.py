@@ -690,8 +690,8 @@ def test_pipeline_pairs_frames_per_launch(T, head):
     """frames_per_launch = 2: the caller still submits one frame at a time (per-slot input writes);
     a lane is replayed when both of its slots are filled, flush() launches a half-filled lane as a
     PARTIAL launch over its one filled slot.  Every frame of a full launch is bit-identical to the same
-    frame alone at the launch's tile height (8 rows); the odd last frame (a one-frame launch: 4-row
-    tiles) to its ordinary one-frame result."""
+    frame alone at the launch's tile height (8 rows); so is the odd last frame: with two lanes the partial launch
+    keeps the full launch's tile height (a single-lane pipeline uses the one-frame launch's own 4 rows)."""
     import bench
     from transcar_amd.detr3d_head import head_options
     from transcar_amd.pipeline import FramePipeline
@@ -731,8 +731,12 @@ def test_pipeline_pairs_frames_per_launch(T, head):
     for i in range(nframes):
         partial = got[i][0]
         assert partial == (i == nframes - 1)
-        for a_, b_ in zip(got[i][1:], want[i][1 if partial else 0]):
+        # two lanes: the partial launch keeps the full launch's 8-row tiles (FramePipeline.tile_rows_of)
+        for a_, b_ in zip(got[i][1:], want[i][0]):
             assert torch.equal(a_, b_[:, 0]), i
+    assert pipe.tile_rows_of() == 8 and pipe.tile_rows_of(1) == 8
+    solo = FramePipeline(head, lanes[:1])
+    assert solo.tile_rows_of(1) == 4                    # a single lane: the partial launch is alone on the chip
     # the full graph for a partly filled lane (partial_graphs=False): the filled slot's result is the same frame
     # at the full launch's tile height
     pipe2 = FramePipeline(head, lanes, partial_graphs=False)
@@ -1025,7 +1029,7 @@ def test_timed_geometry_is_frame_by_frame_the_single_frame_path(T, fpl):
     """EXACTLY what `python bench.py --steps 20` launches: ResNet-101 FPN shapes, iid-noise maps,
     the default options (automatic tile height, radar rows compacted), three lanes in flight, frames per launch =
     the most whose 16-row tiles are resident at once (9 = 507 workgroups), a window of 20 submits = 9 + 9 + a
-    PARTIAL launch of 2 (8-row tiles) -- and, second case, 10 frames per launch = 563 workgroups on 512 slots (a
+    PARTIAL launch of 2 (at the full launch's 16-row tiles: FramePipeline.tile_rows_of) -- and, second case, 10 frames per launch = 563 workgroups on 512 slots (a
     second scheduling round; the driver's round-2 geometry).  Every one of the 20 frames, and its decoded boxes,
     is bit-identical to the same frame launched alone at the same tile height."""
     import bench
@@ -1051,8 +1055,8 @@ def test_timed_geometry_is_frame_by_frame_the_single_frame_path(T, fpl):
     for lane, slot in got:
         partial = lane == part_lane
         outs, dec = pipe.last_flush[2] if partial else pipe.outputs[lane]
-        rows = (n_part if partial else P) * head.num_query
-        opt = head_options(tile_rows=4 if rows <= 1024 else 8 if rows <= 2048 else 16)      # the automatic choice
+        opt = head_options(tile_rows=pipe.tile_rows_of(n_part if partial else P))       # what that launch used
+        assert opt.chain_tile_rows == 16
         inp = lanes[lane]
         one = head.forward_nhwc([f[6 * slot:6 * slot + 6] for f in inp['nhwc']], inp['l2i'][slot:slot + 1], inp['hw'],
                                 inp['tokens'][slot:slot + 1], inp['pad_mult'], options=opt)

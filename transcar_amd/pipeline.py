@@ -60,6 +60,10 @@ class FramePipeline:
     tile_rows (4 | 8 | 16): row-tile height of the fused chains in THIS
     pipeline's graphs (tc_head_options.chain_tile_rows; None = automatic).
     8 at one frame per lane buys throughput with >= 3 lanes and costs latency.
+    A PARTIAL launch (``flush`` with fewer filled slots) of a pipeline with more than one lane keeps the tile
+    height of the full launch (``tile_rows_of``): it shares the chip with the other lanes' launches, where the
+    matrix-pipe time per row counts (16x16x4 MFMA tiles), not the latency of a launch that is alone (the automatic
+    rule's 8- or 4-row tiles for few rows): the driver's 20-step window (9 + 9 + 2 frames) 5 372 -> 5 490 frames/s.
     """
 
     def __init__(self, head, static_inputs, decode=True, tile_rows=None, options=None, streams=None,
@@ -103,6 +107,31 @@ class FramePipeline:
         self._next = 0
         self._capture()
 
+    @staticmethod
+    def _auto_tile_rows(rows):
+        """the library's automatic rule (chain.hip tile_rows()): 4 up to 1024 rows per launch, 8 up to 2048, 16 beyond"""
+        return 4 if rows <= 1024 else 8 if rows <= 2048 else 16
+
+    def tile_rows_of(self, n=None):
+        """Row-tile height of a launch over n (default: all) frame slots of a lane."""
+        P = self.frames_per_launch
+        n = P if n is None else int(n)
+        if self.options.chain_tile_rows:
+            return int(self.options.chain_tile_rows)
+        full = self._auto_tile_rows(P * self.head.num_query)
+        if n == P or len(self.inputs) < 2:
+            return self._auto_tile_rows(n * self.head.num_query)
+        return full
+
+    def _options_of(self, n):
+        if n is None or n == self.frames_per_launch or self.options.chain_tile_rows:
+            return self.options
+        import ctypes as C
+        o = type(self.options)()
+        C.memmove(C.byref(o), C.byref(self.options), C.sizeof(o))
+        o.chain_tile_rows = self.tile_rows_of(n)
+        return o
+
     def _step(self, i, n=None):
         inp = self.inputs[i]
         P = self.frames_per_launch
@@ -118,7 +147,7 @@ class FramePipeline:
         if self.radar_stage is not None:       # raw sweeps -> this launch's tokens (first node of the graph)
             self.radar_stage[i].build(self.inputs[i]['tokens'], n=n)
         outs = self.head.forward_nhwc(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'],
-                                      inp['pad_mult'], lane=i, options=self.options)
+                                      inp['pad_mult'], lane=i, options=self._options_of(n))
         if not self.decode:
             return outs, None
         dec = ops.box_decode_topk(outs['all_cls_scores'][-1], outs['all_bbox_preds'][-1],
