@@ -129,9 +129,46 @@ def _free_port():
     return port
 
 
+def kfd_gpu_order(sys_root='/sys'):
+    """PCI addresses of the GPUs in the order the ROCm runtime enumerates them: the KFD topology nodes with SIMDs,
+    by node id (/sys/class/kfd/kfd/topology/nodes/<id>/properties: simd_count, domain, location_id = bus << 8 |
+    device << 3 | function).  [] when the tree is not there or not readable."""
+    import glob
+    out = []
+    try:
+        paths = glob.glob(os.path.join(sys_root, 'class', 'kfd', 'kfd', 'topology', 'nodes', '[0-9]*', 'properties'))
+        for p in sorted(paths, key=lambda q: int(os.path.basename(os.path.dirname(q)))):
+            props = {}
+            for line in open(p):
+                f = line.split()
+                if len(f) >= 2:
+                    props[f[0]] = f[1]
+            if int(props.get('simd_count', '0')) <= 0:
+                continue                                    # a CPU node
+            loc, dom = int(props['location_id']), int(props.get('domain', '0'))
+            out.append('%04x:%02x:%02x.%x' % (dom, (loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 7))
+    except (OSError, ValueError, KeyError):
+        return []
+    return out
+
+
+def _visible(order):
+    """ROCR_VISIBLE_DEVICES, then HIP_/CUDA_VISIBLE_DEVICES (plain index lists only) applied to an enumeration"""
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = os.environ.get(var, '').strip()
+        if var == 'CUDA_VISIBLE_DEVICES' and os.environ.get('HIP_VISIBLE_DEVICES', '').strip():
+            continue
+        if v and all(t.strip().isdigit() for t in v.split(',')):
+            idx = [int(t) for t in v.split(',')]
+            order = [order[i] for i in idx if i < len(order)]
+    return order
+
+
 def gpu_numa_topology(sys_root='/sys'):
-    """[(pci address, numa node)] of the AMD GPUs of this host in PCI order (the order HIP enumerates them in),
-    from /sys/class/drm/card*/device -- no GPU call, usable before torch is imported."""
+    """[(pci address, numa node)] of the AMD GPUs of this host in the order HIP enumerates them: the KFD topology's
+    node order when it is readable (with the *_VISIBLE_DEVICES index lists applied), else PCI order of
+    /sys/class/drm/card*/device -- no GPU call, usable before torch is imported (main() checks the rank's entry
+    against the device's own PCI id afterwards: cpu_affinity.pci_matches_hip)."""
     import glob
     gpus = {}
     for dev in glob.glob(os.path.join(sys_root, 'class', 'drm', 'card[0-9]*', 'device')):
@@ -148,6 +185,9 @@ def gpu_numa_topology(sys_root='/sys'):
             gpus[addr] = int(open(os.path.join(dev, 'numa_node')).read().strip())
         except (OSError, ValueError):
             continue
+    order = [a for a in kfd_gpu_order(sys_root) if a in gpus]
+    if order:
+        return [(a, gpus[a]) for a in _visible(order)]
     return sorted(gpus.items())
 
 
@@ -187,6 +227,43 @@ def pin_to_gpu_numa_node(local_rank, sys_root='/sys'):
     except (OSError, ValueError, AttributeError) as e:
         info['why'] = repr(e)
     return info
+
+
+def hip_pci_address(index):
+    """'dddd:bb:dd.f' of HIP device `index` (torch device properties), or None"""
+    try:
+        p = torch.cuda.get_device_properties(index)
+        return '%04x:%02x:%02x.0' % (int(p.pci_domain_id), int(p.pci_bus_id), int(p.pci_device_id))
+    except (AttributeError, RuntimeError):
+        return None
+
+
+def check_pin_against_device(affinity, local, sys_root='/sys'):
+    """After torch is up: was the sysfs guess (pin_to_gpu_numa_node ran before any GPU call) the PCI function HIP
+    calls device `local`?  Recorded as cpu_affinity.pci_matches_hip; a pinned rank on the wrong node is moved."""
+    if not affinity.get('pci'):
+        return affinity
+    mine = hip_pci_address(local)
+    if mine is None:
+        return affinity
+    affinity['pci_matches_hip'] = mine[:10] == affinity['pci'][:10]        # domain:bus:device
+    if affinity['pci_matches_hip'] or not affinity.get('pinned'):
+        return affinity
+    try:
+        node = dict((a[:10], n) for a, n in gpu_numa_topology(sys_root)).get(mine[:10], -1)
+        if node >= 0:
+            cpus = parse_cpulist(open(os.path.join(sys_root, 'devices', 'system', 'node', 'node%d' % node,
+                                                   'cpulist')).read())
+            allowed = cpus & set(os.sched_getaffinity(0)) or cpus
+            for tid in os.listdir('/proc/self/task'):          # torch's threads exist by now: move them all
+                try:
+                    os.sched_setaffinity(int(tid), allowed)
+                except (OSError, ValueError):
+                    pass
+            affinity.update(pci=mine, numa_node=node, cpus=len(allowed), repinned=True)
+    except (OSError, ValueError):
+        pass
+    return affinity
 
 
 def spawn_ranks(args, argv):
@@ -1115,6 +1192,7 @@ def main(argv=None):
         local %= torch.cuda.device_count()
     torch.cuda.set_device(local)              # before the RCCL communicator is created
     dev = torch.device('cuda', local)
+    check_pin_against_device(affinity, local)
     rank, world = D.init_process_group(backend=args.backend)
     torch.set_grad_enabled(False)
     head, sd = build_head(dev)

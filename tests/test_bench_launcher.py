@@ -136,3 +136,19 @@ def test_rank_is_pinned_to_the_numa_node_of_its_gpu(tmp_path):
     finally:
         os.sched_setaffinity(0, before)
     assert bench.pin_to_gpu_numa_node(5, str(sysr))['pinned'] is False      # no such GPU: left alone
+    # the ROCm runtime's own enumeration (KFD topology nodes) wins over PCI order: here node 2 = 85:00.0 comes first
+    for nid, (simd, loc) in enumerate([(0, 0), (256, 0x8500), (256, 0x0500)]):
+        d = sysr / 'class' / 'kfd' / 'kfd' / 'topology' / 'nodes' / str(nid)
+        d.mkdir(parents=True)
+        (d / 'properties').write_text('cpu_cores_count 64\nsimd_count %d\ndomain 0\nlocation_id %d\n' % (simd, loc))
+    assert bench.kfd_gpu_order(str(sysr)) == ['0000:85:00.0', '0000:05:00.0']
+    assert bench.gpu_numa_topology(str(sysr)) == [('0000:85:00.0', 1), ('0000:05:00.0', 0)]
+    old = {k: os.environ.pop(k, None) for k in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES')}
+    try:
+        os.environ['HIP_VISIBLE_DEVICES'] = '1'
+        assert bench.gpu_numa_topology(str(sysr)) == [('0000:05:00.0', 0)]
+    finally:
+        os.environ.pop('HIP_VISIBLE_DEVICES', None)
+        for k, v in old.items():
+            if v is not None:
+                os.environ[k] = v
