@@ -141,6 +141,49 @@ def test_tuning_knob_validates_without_gpu():
     assert r.returncode != 0 and 'TRANSCAR_CHAIN_ROWS' in r.stderr
 
 
+def test_entry_points_refuse_bad_arguments_without_gpu():
+    """Error behaviour of the C ABI: every call below fails on its argument check -- before anything is launched, so
+    no GPU is needed -- with a non-zero code and a message that names the argument (tc_last_error)."""
+    lib = T.lib()
+    w = _lib.tc_head_weights()
+    w.abi_version = _lib.TC_ABI_VERSION
+    w.num_query, w.embed_dims, w.num_heads, w.ffn_dims = 900, 256, 8, 512
+    w.num_layers, w.num_cams, w.num_levels = 6, 6, 4
+    w.num_classes, w.code_size, w.radar_in_dims, w.num_radar_layers = 10, 10, 36, 0
+    fv = _lib.tc_feats_nhwc()
+    fv.num_levels = 4
+    from transcar_amd.detr3d_head import head_options
+
+    def fwd(opt, B=1):
+        return lib.tc_head_forward(ctypes.byref(w), None, ctypes.byref(fv), B, None, 928.0, 1600.0, None, 0, 0,
+                                   None, None, None, ctypes.byref(opt), None, 0, None)
+    assert fwd(head_options(phase=3)) != 0 and b'phase' in lib.tc_last_error()
+    assert fwd(head_options(phase=1, unfused=True)) != 0 and b'phase' in lib.tc_last_error()
+    o = head_options()
+    o.radar_row_order = 7
+    assert fwd(o) != 0 and b'radar_row_order' in lib.tc_last_error()
+    o = head_options()
+    o.decoder_dropout_p = 1.5
+    assert fwd(o) != 0 and b'decoder_dropout_p' in lib.tc_last_error()
+    assert fwd(head_options(), B=0) != 0 and b'B=' in lib.tc_last_error()
+    w2 = _lib.tc_head_weights()
+    ctypes.memmove(ctypes.byref(w2), ctypes.byref(w), ctypes.sizeof(w))
+    w2.abi_version = _lib.TC_ABI_VERSION - 1               # a caller built against another header
+    assert lib.tc_head_workspace_bytes(ctypes.byref(w2), 1, 256) == 0 and b'abi_version' in lib.tc_last_error()
+    # box decode: max_num outside 1..512, more candidates than the kernel holds, a code size without velocities
+    pcr = (ctypes.c_float * 6)(-61.2, -61.2, -10.0, 61.2, 61.2, 10.0)
+    for args, word in (((1, 900, 10, 10, 0), b'max_num'), ((1, 900, 10, 10, 513), b'max_num'),
+                       ((1, 2000, 10, 10, 300), b'num_classes'), ((1, 900, 10, 7, 300), b'code_size')):
+        B, Q, ncls, code, K = args
+        rc = lib.tc_box_decode_topk(None, None, B, Q, ncls, code, K, pcr, None, None, None, None, None, 0, None)
+        assert rc != 0 and word in lib.tc_last_error(), (args, lib.tc_last_error())
+    # optimizer: an empty bucket, a step count that is not 1-based
+    assert lib.tc_sq_norm(None, 0, None, None) != 0 and b'n=0' in lib.tc_last_error()
+    assert lib.tc_adamw_step(None, None, None, None, 16, 1e-3, 0.9, 0.999, 1e-8, 0.01, 0, 1.0, 35.0, None, None) != 0
+    assert b'step' in lib.tc_last_error()
+    assert lib.tc_dropout_mask(1.0, 1, 0, 16, None, None) != 0            # p = 1 drops everything: refused
+
+
 _WORKER = r'''
 import os, sys
 sys.path.insert(0, %r)
