@@ -614,20 +614,27 @@ __device__ __forceinline__ void lin_epilogue(const LinSpec& s, int tile, const A
 // 1 KiB per wave, refilled in place; 64 MFMAs (4 column sub-tiles x 16 k groups of 4) instead of 256;
 // the A operand of a 16-wide k group is one ds_read_b128 (lane 16g + c: row c, k 16 kg + 4g .. + 3).
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
-struct Acc16 { f32x4 v[4]; };     // v[j][i] = y[4g + i][64 tile + 16j + c] at lane 16g + c
+struct Acc16 { f32x4 v[4]; };     // v[j][i] = y[c][64 tile + 16 j + 4 g + i] at lane 16 g + c (TRANSPOSED product, below)
 
 __device__ __forceinline__ float f4_at(const float4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 
+// The product is formed TRANSPOSED (round 3): the weights are the MFMA's first operand, the activations its
+// second -- per lane the same two values as before, swapped (a 16x16x4 takes one value of each operand from a
+// lane: row / column = lane % 16, k = lane / 16 for both), the same dot products in the same k order, so the
+// results are bit-identical -- but the accumulator then holds D'[n][m] = y[m][n]: a lane owns FOUR CONSECUTIVE
+// COLUMNS of ONE row instead of four rows of one column, and the epilogue's residual reads, LDS stores and
+// global stores are 16-byte accesses (4 per lane and tile instead of 16 scalar ones each; the epilogues were
+// 8 % of the decoder chain, tools/r3_ablate.sh).
 template <int J>
 struct ItemSteps16 {
   // np: wave-uniform address of the next item, lo: the lane's float offset (scalar base + 32-bit
   // vector offset: the address arithmetic of the 16 loads stays on the scalar unit)
   static __device__ __forceinline__ void run(Acc16& acc, WBuf& wb, const float4* ar, const float* np, unsigned lo) {
     const float a = f4_at(ar[J >> 2], J & 3);
-    acc.v[0] = MFMA16(a, wb.b[J].x, acc.v[0]);
-    acc.v[1] = MFMA16(a, wb.b[J].y, acc.v[1]);
-    acc.v[2] = MFMA16(a, wb.b[J].z, acc.v[2]);
-    acc.v[3] = MFMA16(a, wb.b[J].w, acc.v[3]);
+    acc.v[0] = MFMA16(wb.b[J].x, a, acc.v[0]);
+    acc.v[1] = MFMA16(wb.b[J].y, a, acc.v[1]);
+    acc.v[2] = MFMA16(wb.b[J].z, a, acc.v[2]);
+    acc.v[3] = MFMA16(wb.b[J].w, a, acc.v[3]);
     __builtin_amdgcn_sched_barrier(0);
     wb.b[J] = ld4(np + (size_t)(lo + J * 256u));   // fragment J of the next item, into fragment J's registers
     __builtin_amdgcn_sched_barrier(0);
@@ -639,21 +646,28 @@ struct ItemSteps16<16> {
   static __device__ __forceinline__ void run(Acc16&, WBuf&, const float4*, const float*, unsigned) {}
 };
 
-// lin_epilogue for the 16x16 accumulator layout: lane 16g + c holds rows 4g .. 4g + 3 of the columns
-// 64 tile + 16j + c, j = 0..3 (bv[j]: their biases)
+// lin_epilogue for the 16x16 accumulator layout: lane 16g + c holds row c, columns 64 tile + 16j + 4g .. + 3,
+// j = 0..3.  bvl: the bias of column 64 tile + lane (one coalesced load under the MFMAs).  It is added by the
+// matrix pipe: bvl IS the first operand of a rank-1 update -- lane 16g + c supplies A[m' = c][kk = g] =
+// bias[16 g + c] -- and with B[kk][n'] = (kk == j) the product is bias[16 j + m'] in every column n': one more
+// v_mfma per sub-tile, D = fma(bias, 1, acc) + 0 + 0 + 0, the same single rounding as the scalar add it replaces
+// (16 crossbar moves per tile otherwise, or 16 live registers).  N is a multiple of 4 wherever a step has an LDS destination or a residual
+// (256 / 512 / 24 / 64 / 128); the 3-column head of the prologue only stores to global memory, element by element.
 template <bool DROP>
-__device__ __forceinline__ void lin_epilogue16(const LinSpec& s, int tile, const Acc16& acc, int lane, const float* bv) {
+__device__ __forceinline__ void lin_epilogue16(const LinSpec& s, int tile, const Acc16& acc, int lane, float bvl) {
   const int c = lane & 15, g = lane >> 4;
-  const int col0 = tile * 64 + c;
-  if (col0 >= s.N) return;                       // columns 16j + c only grow with j
+  const int colb = tile * 64 + 4 * g;            // + 16 j
   float y[4][4];
+  f32x4 ab[4] = {acc.v[0], acc.v[1], acc.v[2], acc.v[3]};
+  if (s.bias != nullptr) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ab[j] = MFMA16(bvl, g == j ? 1.0f : 0.0f, ab[j]);
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int col = col0 + 16 * j;
-    const float sc = (col < s.scale_cols) ? s.scale : 1.0f;
-    const float bias = s.bias != nullptr ? bv[j] : 0.0f;
+    const float sc = (colb + 16 * j < s.scale_cols) ? s.scale : 1.0f;     // scale_cols is 0 or 256
 #pragma unroll
-    for (int i = 0; i < 4; ++i) y[j][i] = (acc.v[j][i] + bias) * sc;
+    for (int i = 0; i < 4; ++i) y[j][i] = ab[j][i] * sc;
   }
   if (s.act == 1) {
 #pragma unroll
@@ -667,13 +681,12 @@ __device__ __forceinline__ void lin_epilogue16(const LinSpec& s, int tile, const
       for (int i = 0; i < 4; ++i) y[j][i] = sigmoidf_(y[j][i]);
   }
   if (s.gate != nullptr) {
-    int gt_[4];
+    if (s.gate[c] == 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) gt_[i] = s.gate[4 * g + i];
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) if (gt_[i] == 0) y[j][i] = 0.0f;
+        for (int i = 0; i < 4; ++i) y[j][i] = 0.0f;
+    }
   }
   if (DROP) {
     if (s.drop_site != 0) {
@@ -681,54 +694,44 @@ __device__ __forceinline__ void lin_epilogue16(const LinSpec& s, int tile, const
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const unsigned idx = (unsigned)(s.m0 + 4 * g + i) * (unsigned)s.N + (unsigned)(col0 + 16 * j);
+          const unsigned idx = (unsigned)(s.m0 + c) * (unsigned)s.N + (unsigned)(colb + 16 * j + i);
           y[j][i] = drop_keep(s.drop_seed, (unsigned)(s.drop_site - 1), idx, s.drop_thr) ? y[j][i] * s.drop_scale : 0.0f;
         }
     }
   }
   if (s.res != nullptr) {
-    float rr[4][4];
+    float4 rr[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
+      rr[j] = colb + 16 * j < s.N ? *reinterpret_cast<const float4*>(s.res + c * s.res_ld + colb + 16 * j)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        rr[j][i] = col0 + 16 * j < s.N ? s.res[(4 * g + i) * s.res_ld + col0 + 16 * j] : 0.0f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) y[j][i] += rr[j][i];
+    for (int j = 0; j < 4; ++j) { y[j][0] += rr[j].x; y[j][1] += rr[j].y; y[j][2] += rr[j].z; y[j][3] += rr[j].w; }
   }
+  const bool vec = (s.N & 3) == 0;               // wave-uniform
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int col = col0 + 16 * j;
-    if (col >= s.N) break;
-    if (s.dst != nullptr) {
+    const int col = colb + 16 * j;
+    if (col >= s.N) break;                       // columns only grow with j
+    const float4 y4 = make_float4(y[j][0], y[j][1], y[j][2], y[j][3]);
+    if (s.dst != nullptr) *reinterpret_cast<float4*>(s.dst + c * s.dst_ld + col) = y4;      // (N % 4 == 0 here)
+    if (s.gdst != nullptr && s.m0 + c < s.M) {
+      const int grow = s.rowg != nullptr ? s.rowg[c] : s.m0 + c;
+      float* gp = s.gdst + (size_t)grow * s.gdst_ld + col;
+      if (vec && (s.gdst_ld & 3) == 0) st4(gp, y4);
+      else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) s.dst[(4 * g + i) * s.dst_ld + col] = y[j][i];
+        for (int i = 0; i < 4; ++i) if (col + i < s.N) stg1(gp + i, y[j][i]);
+      }
     }
-    if (s.gdst != nullptr) {
+    if (s.gt != nullptr && s.m0 + c < s.M) {
+      // the transposed V of the next layer's attention, [b][column][query]: the 16 lanes of a group write 16
+      // consecutive queries of one column
+      const int row = s.m0 + c;
+      const int bb = row / s.gt_rpb, q = row - bb * s.gt_rpb;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        if (s.m0 + 4 * g + i < s.M) {
-          const int grow = s.rowg != nullptr ? s.rowg[4 * g + i] : s.m0 + 4 * g + i;
-          stg1(s.gdst + (size_t)grow * s.gdst_ld + col, y[j][i]);
-        }
-    }
-    if (s.gt != nullptr) {
-      const int row0 = s.m0 + 4 * g;
-      if (row0 + 3 < s.M && (s.gt_rpb & 3) == 0) {
-        const int bb = row0 / s.gt_rpb, q = row0 - bb * s.gt_rpb;
-        st4(s.gt + ((size_t)bb * s.N + col) * s.gt_ld + q, make_float4(y[j][0], y[j][1], y[j][2], y[j][3]));
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int row = row0 + i;
-          if (row < s.M) {
-            const int bb = row / s.gt_rpb, q = row - bb * s.gt_rpb;
-            stg1(s.gt + ((size_t)bb * s.N + col) * s.gt_ld + q, y[j][i]);
-          }
-        }
-      }
+        if (col + i < s.N) stg1(s.gt + ((size_t)bb * s.N + col + i) * s.gt_ld + q, y[j][i]);
     }
   }
   // Global stores read their data registers late and gfx9 tracks that with vmcnt, which retires in
@@ -762,7 +765,7 @@ __device__ __forceinline__ bool linear_step16(const LinSpec& s, WBuf& w0, bool p
   const unsigned lo = 4u * lane;
   const size_t tile_stride = (size_t)CH_NW * 64 * kpad;
   Acc16 acc;
-  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  float bvl = 0.f;
 #ifdef TC_CHAIN_STAMPS
   constexpr bool stamp_items = true;
 #else
@@ -794,11 +797,9 @@ __device__ __forceinline__ bool linear_step16(const LinSpec& s, WBuf& w0, bool p
     if (kb == 0) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc.v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      // biases in flight under the MFMAs; unconditional loads (see linear_step)
+      // the tile's 64 biases, one per lane, in flight under the MFMAs; an unconditional load (see linear_step)
       const float* bsrc = s.bias != nullptr ? s.bias : s.W;
-      const int col0 = (wave + tt * CH_NW) * 64 + (lane & 15);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bv[j] = ldg1(bsrc + min(col0 + 16 * j, s.N - 1));
+      bvl = ldg1(bsrc + min((wave + tt * CH_NW) * 64 + lane, s.N - 1));
     }
     if (stamp_items && tt == 0 && kb < 2) SUB_STAMP(22 + 5 * kb);
     float4 ar[4];
@@ -815,7 +816,7 @@ __device__ __forceinline__ bool linear_step16(const LinSpec& s, WBuf& w0, bool p
       asm volatile("" : "+s"(tile), "+s"(sidx));         // see linear_step: the epilogue rebuilds its view
       if (!(CHAIN_DBG(s.dbg) & 1)) {
         const LinSpec e = make_spec(sidx);
-        lin_epilogue16<DROP>(e, tile, acc, lane, bv);
+        lin_epilogue16<DROP>(e, tile, acc, lane, bvl);
       }
     }
     wcur = np; tt = nt; kb = nk;
