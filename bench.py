@@ -523,7 +523,7 @@ def roofline(head, inp, dev):
     return r
 
 
-def live_traffic(frames_per_launch, timeout_s=150):
+def live_traffic(frames_per_launch, timeout_s=75):
     """HBM-side bytes per launch of the path's kernels, MEASURED in this run (the figure used to
     come from a committed profile): child passes `rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES --
     python3 bench.py --batch P --no-graph --main-only --steps 3` (separate passes, kernel trace only, the program itself
