@@ -1089,9 +1089,12 @@ def train_bench(args, head, inp, dev, rank, world, affinity=None):
                    'launcher': launcher_name(),
                    'final_loss': float(sum(last['losses'].values()))},
     }
+    # EVERY rank: the roofline's one full iteration carries the all-reduce of the loss normalisers (HEAD:889-902) --
+    # run by rank 0 alone it waited for its peers for ever while they sat in the barrier below
+    roof = None if args.no_roofline else train_roofline(tr, thead, inp, gts, lbs, nxt, dev)
     if rank == 0:
-        if not args.no_roofline:
-            line['roofline'] = train_roofline(tr, thead, inp, gts, lbs, nxt, dev)
+        if roof is not None:
+            line['roofline'] = roof
         print(json.dumps(line), flush=True)
     D.barrier()
     if world > 1:

@@ -47,3 +47,27 @@ def test_two_ranks_on_one_gpu_end_with_the_same_parameters():
     assert a['sum'] == b['sum'] and a['abs'] == b['abs'] and a['first'] == b['first']
     # different frames and different dropout streams (the rank is part of the seed): different local losses
     assert a['losses'] != b['losses'] and a['seed'] != b['seed']
+
+
+def test_training_bench_with_two_ranks_finishes_and_reports_its_roofline():
+    """`bench.py --train --gpus 2` (the ranks share the one GPU, gloo): the launcher starts both ranks, every
+    collective of the run -- the bucket all-reduce, the loss normalisers inside the roofline's extra iteration --
+    is entered by BOTH ranks (round 3: rank 0 alone ran the roofline and the job hung), rank 0 prints one line."""
+    import signal
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--train', '--gpus', '2', '--share-gpu', '--backend', 'gloo',
+           '--steps', '6', '--warmup', '2', '--min-window-s', '0.05', '--warmup-s', '0.05']
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    p = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                         start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=240)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)                # the launcher and its ranks: the process group started here
+        out, err = p.communicate()
+        pytest.fail('bench.py --train --gpus 2 did not finish within 240 s:\n' + (err or '')[-1500:])
+    assert p.returncode == 0, err[-2000:]
+    lines = [ln for ln in out.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out[-1000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['rccl_ranks'] == 2
+    assert d['roofline'] and d['roofline']['parts'] and len(d['per_rank']['frames_per_s']) == 2
