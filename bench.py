@@ -523,6 +523,32 @@ def roofline(head, inp, dev):
     return r
 
 
+PMC_KERNELS = (('chain_kernel(decoder layer)', r'chain_kernel<\d+, 1, '),
+               ('chain_kernel(radar fusion)', r'chain_kernel<\d+, 3, '),
+               ('self_attn_kernel', r'self_attn_kernel'))
+
+
+def parse_counter_csv(path, ctr):
+    """rocprofv3 `*counter_collection.csv` of one --pmc pass -> {kernel label: (mean counter value per launch,
+    launches, mean duration in seconds)} for the path's kernels (the decoder chain's plain launches only: the two
+    that carry the radar encoders are chain_dual_kernel)."""
+    import csv
+    import re
+    rx = [(name, re.compile(pat)) for name, pat in PMC_KERNELS]
+    acc = {}
+    for row in csv.DictReader(open(path)):
+        if row.get('Counter_Name') != ctr:
+            continue
+        for name, r in rx:
+            if r.search(row['Kernel_Name']):
+                a = acc.setdefault(name, [0.0, 0, 0.0])
+                a[0] += float(row['Counter_Value'])
+                a[1] += 1
+                a[2] += (int(row['End_Timestamp']) - int(row['Start_Timestamp'])) * 1e-9
+                break
+    return {name: (v / n, n, dur / n) for name, (v, n, dur) in acc.items() if n}
+
+
 def live_traffic(frames_per_launch, timeout_s=75):
     """HBM-side bytes per launch of the path's kernels, MEASURED in this run (the figure used to
     come from a committed profile): child passes `rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES --
@@ -530,9 +556,7 @@ def live_traffic(frames_per_launch, timeout_s=75):
     behind `--`: the GPU box's rules), the counters averaged per launch and corrected as MI355X_MICROARCH.md's HBM
     section prescribes for gfx950: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  {} when rocprofv3 is missing, this
     process is itself being profiled, or a pass fails -- the caller keeps the committed figure then."""
-    import csv
     import glob
-    import re
     import shutil
     import subprocess
     import tempfile
@@ -541,9 +565,6 @@ def live_traffic(frames_per_launch, timeout_s=75):
     exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
     if not os.path.exists(exe):
         return {}
-    names = (('chain_kernel(decoder layer)', re.compile(r'chain_kernel<\d+, 1, ')),
-             ('chain_kernel(radar fusion)', re.compile(r'chain_kernel<\d+, 3, ')),
-             ('self_attn_kernel', re.compile(r'self_attn_kernel')))
     got = {}
     tmp = tempfile.mkdtemp(prefix='tc_pmc_', dir='/tmp')
     try:
@@ -560,21 +581,11 @@ def live_traffic(frames_per_launch, timeout_s=75):
             files = glob.glob(os.path.join(out, '**', '*counter_collection.csv'), recursive=True)
             if r.returncode != 0 or not files:
                 return {}
-            acc = {}
-            for row in csv.DictReader(open(files[0])):
-                if row.get('Counter_Name') != ctr:
-                    continue
-                for name, rx in names:
-                    if rx.search(row['Kernel_Name']):
-                        a = acc.setdefault(name, [0.0, 0, 0.0])
-                        a[0] += float(row['Counter_Value'])
-                        a[1] += 1
-                        a[2] += (int(row['End_Timestamp']) - int(row['Start_Timestamp'])) * 1e-9
-            for name, (v, n, dur) in acc.items():
-                got.setdefault(name, {})[ctr] = v / max(n, 1)
+            for name, (v, n, dur) in parse_counter_csv(files[0], ctr).items():
+                got.setdefault(name, {})[ctr] = v
                 got[name]['launches'] = n
                 if ctr == 'SQ_VALU_MFMA_BUSY_CYCLES':
-                    got[name]['busy_dur_s'] = dur / max(n, 1)
+                    got[name]['busy_dur_s'] = dur
     except (OSError, ValueError, KeyError, subprocess.SubprocessError):
         return {}
     finally:

@@ -152,3 +152,25 @@ def test_rank_is_pinned_to_the_numa_node_of_its_gpu(tmp_path):
         for k, v in old.items():
             if v is not None:
                 os.environ[k] = v
+
+
+def test_pmc_counter_csv_is_reduced_per_kernel(tmp_path):
+    """bench.py's own PMC passes (roofline.traffic / mfma_busy measured in the run): the rocprofv3 counter csv is
+    averaged per launch over the path's kernels; the dual launches (decoder layer + radar encoder half) and other
+    counters' rows are left out."""
+    import bench
+    f = tmp_path / 'x_counter_collection.csv'
+    kd = 'void tc::(anonymous namespace)::chain_kernel<16, 1, false>(tc::(anonymous namespace)::ChainDev, ...)'
+    kr = 'void tc::(anonymous namespace)::chain_kernel<16, 3, false>(tc::(anonymous namespace)::ChainDev, ...)'
+    ku = 'void tc::(anonymous namespace)::chain_dual_kernel<16, 16, 4>(...)'
+    ka = 'void tc::self_attn_kernel<2, false>(float const*, ...)'
+    rows = [(kd, 'FETCH_SIZE', 100.0, 0, 1000), (kd, 'FETCH_SIZE', 300.0, 2000, 4000), (kd, 'WRITE_SIZE', 7.0, 0, 10),
+            (kr, 'FETCH_SIZE', 50.0, 0, 500), (ku, 'FETCH_SIZE', 999.0, 0, 1), (ka, 'FETCH_SIZE', 10.0, 0, 2000)]
+    f.write_text('Kernel_Name,Counter_Name,Counter_Value,Start_Timestamp,End_Timestamp\n' +
+                 ''.join('"%s",%s,%s,%d,%d\n' % r for r in rows))
+    got = bench.parse_counter_csv(str(f), 'FETCH_SIZE')
+    assert set(got) == {'chain_kernel(decoder layer)', 'chain_kernel(radar fusion)', 'self_attn_kernel'}
+    v, n, dur = got['chain_kernel(decoder layer)']
+    assert v == 200.0 and n == 2 and abs(dur - 1.5e-6) < 1e-12
+    assert got['chain_kernel(radar fusion)'][0] == 50.0 and got['self_attn_kernel'][1] == 1
+    assert bench.parse_counter_csv(str(f), 'WRITE_SIZE') == {'chain_kernel(decoder layer)': (7.0, 1, 1e-8)}
