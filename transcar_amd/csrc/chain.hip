@@ -1482,12 +1482,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
         constexpr int GW = 4;
         // the per-row constants of the gate (expf, clamp, sqrt_threshold: ~300 instructions) once per row, one
         // thread each, into the spare columns of the row's box / centre records (code <= 10 of 12, 3 of 4)
-        if (threadIdx.x < R) {
-          const int i = threadIdx.x;
-          const GateGeom::Pre pp = GateGeom::precompute(S.box[i][3], S.box[i][6], S.box[i][7], k.rmin[rep], k.rmax[rep]);
-          S.box[i][10] = pp.ox; S.box[i][11] = pp.oy; S.cen[i][3] = pp.tstar;
-        }
-        __syncthreads();
+        // (the tokens' xy go out first: their latency runs under the per-row constants and the barrier)
         const bool keep = k.T <= 64 * HM_WORDS, cached = k.T <= 64 * GW;
         const int b0 = S.rowg[wave] / k.Q;
         float ty0[GW], ty1[GW];
@@ -1499,6 +1494,12 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
             ty0[w] = rxy[(size_t)t * k.RI]; ty1[w] = rxy[(size_t)t * k.RI + 1];
           }
         }
+        if (threadIdx.x < R) {
+          const int i = threadIdx.x;
+          const GateGeom::Pre pp = GateGeom::precompute(S.box[i][3], S.box[i][6], S.box[i][7], k.rmin[rep], k.rmax[rep]);
+          S.box[i][10] = pp.ox; S.box[i][11] = pp.oy; S.cen[i][3] = pp.tstar;
+        }
+        __syncthreads();
 #pragma unroll 1
         for (int row = wave; row < R; row += CH_NW) {
           const int grow = S.rowg[row];
