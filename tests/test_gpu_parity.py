@@ -1070,6 +1070,36 @@ def test_timed_geometry_is_frame_by_frame_the_single_frame_path(T, fpl):
             assert torch.equal(a_[0], b_[slot]), (lane, slot)
 
 
+def test_ragged_radar_batch_through_the_plugin_entry(T, head):
+    """One `head(mlvl_feats, img_metas)` call with three samples whose radar frames differ in size (255 points, a
+    ragged handful, none at all): the batch ingest (tc_radar_build_tokens_batch, one launch) writes every sample's
+    token matrix exactly as the single-sample operator does at the batch's token count, and the call's outputs are
+    those of the device forward on these tokens, bit for bit."""
+    from transcar_amd import ops, radar as R
+    l2i = synth.make_lidar2img()
+    gold = g('g5_head_tiny.npz')
+    frames = [synth.make_radar_frame(seed=2, n_per_radar=51, centres=gold['radar_centres']),
+              synth.make_radar_frame(seed=11, n_per_radar=[7, 0, 33, 0, 12]),
+              synth.make_radar_frame(seed=5, n_per_radar=[0, 0, 0, 0, 0])]
+    B = len(frames)
+    feats = [gpu(np.concatenate([f] * B, 0)) for f in synth.make_feats('tiny', seed=1, smooth=SMOOTH)]
+    metas = synth.make_img_metas(B, l2i, radar=frames)
+    got = head(feats, metas)
+    tok, pm = head.radar_tokens(metas, dev())
+    Tn = tok.shape[1]
+    assert tok.shape[0] == B and Tn == ops.radar_tokens_T(255) == 256 and pm == 1500 - Tn + 1
+    for b, fr in enumerate(frames):
+        one, cnt, pm1 = ops.radar_build_tokens(fr, Tn, dev(), check=True)
+        assert pm1 == pm and torch.equal(one[0], tok[b]), b
+        n = sum(int(np.asarray(fr['points'][c]).shape[1]) for c in R.RADAR_CHANNELS)
+        assert int(cnt) <= n
+        assert torch.all(tok[b, int(cnt):, 0] == 500.0)           # pad rows behind the kept points (HEAD:526-530)
+    want = head.forward_nhwc(ops.to_nhwc_levels(feats), ops.lidar2img_tensor(metas, dev()), configs.IMG_SHAPE[:2], tok, pm)
+    for k in ('all_cls_scores', 'all_bbox_preds'):
+        assert torch.equal(got[k], want[k]), k
+    assert torch.isfinite(got['all_bbox_preds']).all()
+
+
 @pytest.mark.parametrize('batch', [1, 3])
 def test_forward_in_two_phases_around_the_token_build(T, head, batch):
     """tc_head_options.phase: phase 1 (prologue + decoder layers 0 .. L-3) is enqueued while the tokens do not exist
