@@ -450,6 +450,37 @@ def test_fused_step_with_device_loss_equals_torch_loss(A, golden_dir):
     assert float((tr.bucket.grads - g_torch).abs().max() / g_torch.abs().max()) < 1e-4
 
 
+def test_fused_iteration_on_a_frame_without_ground_truth(A, golden_dir):
+    """A sample with no annotated box (nuScenes has them): every query is background, the normalisers clamp to 1
+    (HEAD:885-902), only the classification loss is non-zero.  The device loss + backward chain give the torch
+    loss path's losses and gradients, and an optimizer step on them leaves finite parameters."""
+    from transcar_amd import ops
+    from transcar_amd.trainer import FusionTrainer
+    h = train_head(golden_dir)
+    feats, metas, gt, labels = frame_inputs(golden_dir)
+    nhwc = [ops.to_nhwc(f) for f in feats]
+    l2i = ops.lidar2img_tensor(metas, dev())
+    img_hw = metas[0]['img_shape'][0][:2]
+    tokens, pad_mult = h.radar_tokens(metas, dev())
+    gt0, lb0 = gt[:0], labels[:0]
+    tr = FusionTrainer(h, dropout=0.0, lr=1e-3)
+    tr.device_loss = False
+    l_torch = tr.step_fused_nhwc(nhwc, l2i, img_hw, tokens, pad_mult, [gt0], [lb0], update=False)
+    g_torch = tr.bucket.grads.clone()
+    tr.device_loss = True
+    l_dev = tr.step_fused_nhwc(nhwc, l2i, img_hw, tokens, pad_mult, [gt0], [lb0], update=False)
+    assert float(g_torch.abs().max()) > 0
+    for k in l_torch:
+        assert abs(float(l_torch[k]) - float(l_dev[k])) < 1e-5 * max(1.0, abs(float(l_torch[k]))), k
+        if 'bbox' in k:
+            assert float(l_dev[k]) == 0.0
+    assert float((tr.bucket.grads - g_torch).abs().max() / g_torch.abs().max()) < 1e-4
+    p0 = tr.bucket.params.clone()
+    tr.step_fused_nhwc(nhwc, l2i, img_hw, tokens, pad_mult, [gt0], [lb0])
+    torch.cuda.synchronize()
+    assert torch.isfinite(tr.bucket.params).all() and not torch.equal(tr.bucket.params, p0)
+
+
 @pytest.mark.parametrize('path', ['fused', 'autograd'])
 def test_fused_training_with_dropout_matches_reference_formula(A, golden_dir, path):
     """The four dropout sites of every fusion layer (HEAD:129-171, 581-585; p = 0.1) in
