@@ -751,6 +751,42 @@ def test_chain_backward_equals_operator_backward(A, golden_dir, tag, p):
     assert len(res[False]) == 98 - 14 or len(res[False]) >= 84
 
 
+def test_training_iteration_without_any_radar_return(A, golden_dir):
+    """A frame whose radar sweeps are empty (every token a pad row, no query has a hit): the fusion layers pass the
+    decoder state through, the attention path carries no gradient.  The backward chain, the operator-level backward
+    and the autograd path agree on every gradient, all finite; the attention projections' gradients are exactly 0."""
+    from transcar_amd import ops
+    from transcar_amd.trainer import FusionTrainer
+    h = train_head(golden_dir)
+    feats, metas, gt, labels = frame_inputs(golden_dir)
+    metas[0]['radar'] = synth.make_radar_frame(seed=5, n_per_radar=[0, 0, 0, 0, 0])
+    nhwc = [ops.to_nhwc(f) for f in feats]
+    l2i = ops.lidar2img_tensor(metas, dev())
+    img_hw = metas[0]['img_shape'][0][:2]
+    tokens, pad_mult = h.radar_tokens(metas, dev())
+    assert torch.all(tokens[..., 0] == 500.0)
+    tr = FusionTrainer(h, dropout=0.0, decoder_dropout=0.0)
+    res = {}
+    for name, chain in (('chain', True), ('operators', False)):
+        tr.chain_backward = chain
+        tr.step_fused_nhwc(nhwc, l2i, img_hw, tokens, pad_mult, [gt], [labels], update=False)
+        res[name] = {n: q.grad.detach().clone() for n, q in h.trainable_parameters()}
+    tr.bucket.zero_grad()
+    h.train()
+    outs = h.forward_train_nhwc(nhwc, l2i, img_hw, tokens, pad_mult)
+    losses = h.loss([gt], [labels], outs)
+    sum(v for k_, v in losses.items() if 'loss' in k_).backward()
+    res['autograd'] = {n: q.grad.detach().clone() for n, q in h.trainable_parameters()}
+    for n, want in res['autograd'].items():
+        scale = float(want.abs().max())
+        for other in ('chain', 'operators'):
+            got = res[other][n]
+            assert torch.isfinite(got).all(), (other, n)
+            assert float((got - want).abs().max()) <= 3e-4 * max(scale, 1e-6) + 1e-7, (other, n)
+        if 'rf_multihead_attn' in n:
+            assert scale == 0.0, n
+
+
 def test_decoder_prefetch_changes_nothing_but_the_schedule(A, golden_dir):
     """step_fused_nhwc(prefetch=next frame): the frozen decoder's forward of iteration i + 1 is enqueued on a side
     stream while the host solves iteration i's assignment.  Three optimizer steps with and without it (two frames
