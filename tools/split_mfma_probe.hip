@@ -1,0 +1,391 @@
+// Can the 16-row chains' linear steps leave the f32 MFMA (= the vector pipe, 64 flop/clk/SIMD) for the
+// bf16 / f16 matrix cores (1024 flop/clk/SIMD) WITHOUT giving up fp32 accuracy?  
+//
+// Operand splits measured here (all with fp32 accumulation in the MFMA):
+//   bf16x3  x = x1 + x2 + x3, three bf16 planes by round-to-nearest residuals (exact: 3 x 8 significant bits
+//           + the residuals' signs cover fp32's 24), products i + j <= 4  (6 MFMAs) or all 9
+//   f16x2   x = x1 + 2^-11 x2', two f16 planes, the residual scaled by 2^11 so that it stays a normal f16
+//           (representation error <= 2^-24 |x|), products x1 w1 | x1 w2' + x2' w1 (3 MFMAs; x2' w2' <= 2^-24 |x w| dropped)
+// against the f32 MFMA chain the library uses today (v_mfma_f32_16x16x4_f32).
+//
+// Part 1 (accuracy): Y[912, 256] = X[912, 256] W[256, 256]^T on every variant vs an fp64 reference.
+// Part 2 (rate): the chains' item loop -- a workgroup of 4 waves owns 16 (or 32) rows whose activations
+//   sit in LDS as f32, wave w streams the packed weights of its 64-column tile from L2 (all workgroups
+//   the same 3 MB-equivalent buffer, as the decoder layer's weights), 64-deep k items, fragments
+//   refilled in place right behind their MFMAs; the activations are split IN REGISTERS per item (the
+//   LDS of a 16-row tile has no room for planes at two workgroups per CU).  Reports shader cycles per
+//   item per workgroup (s_memtime, median over workgroups) and wall time per launch.
+//
+//   hipcc --offload-arch=gfx950 -O3 tools/split_mfma_probe.hip -o tools/split_mfma_probe
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+enum Mode { M_F32 = 0, M_BF3_6 = 1, M_BF3_9 = 2, M_F16_3 = 3 };
+__host__ __device__ constexpr int planes_of(int m) { return m == M_F32 ? 0 : (m == M_BF3_6 || m == M_BF3_9) ? 3 : 2; }
+// fragments (1 KiB per wave each) of a 64-column x 64-k item
+__host__ __device__ constexpr int frags_of(int m) { return m == M_F32 ? 16 : 8 * planes_of(m); }
+
+constexpr int LDA = 260;
+
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
+  bf16x2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float bf_lo(uint32_t p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }
+__device__ __forceinline__ uint32_t pk_f16(float a, float b) {
+  f16x2 v = {(_Float16)a, (_Float16)b};
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float h_lo(uint32_t p) { return (float)__builtin_bit_cast(f16x2, p)[0]; }
+__device__ __forceinline__ float h_hi(uint32_t p) { return (float)__builtin_bit_cast(f16x2, p)[1]; }
+
+// 8 consecutive k of one row -> the lane's operand fragments of the three bf16 planes
+__device__ __forceinline__ void split_bf3(const float4& a, const float4& b, uint4& p1, uint4& p2, uint4& p3) {
+  const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  uint32_t q1[4], q2[4], q3[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    q1[i] = pk_bf16(x[2 * i], x[2 * i + 1]);
+    const float r0 = x[2 * i] - bf_lo(q1[i]), r1 = x[2 * i + 1] - bf_hi(q1[i]);
+    q2[i] = pk_bf16(r0, r1);
+    const float s0 = r0 - bf_lo(q2[i]), s1 = r1 - bf_hi(q2[i]);
+    q3[i] = pk_bf16(s0, s1);
+  }
+  p1 = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+  p2 = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+  p3 = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+}
+__device__ __forceinline__ void split_f16(const float4& a, const float4& b, uint4& p1, uint4& p2) {
+  const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  uint32_t q1[4], q2[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    q1[i] = pk_f16(x[2 * i], x[2 * i + 1]);
+    const float r0 = (x[2 * i] - h_lo(q1[i])) * 2048.0f, r1 = (x[2 * i + 1] - h_hi(q1[i])) * 2048.0f;
+    q2[i] = pk_f16(r0, r1);
+  }
+  p1 = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+  p2 = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+}
+
+#define MFMA_BF(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
+#define MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, (a)), __builtin_bit_cast(f16x8, (b)), (c), 0, 0, 0)
+#define MFMA_F(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ldg16(const void* p) {
+  const u32x4 v = *(const __attribute__((address_space(1))) u32x4*)(p);
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+// One item = 64 columns x 64 k x (16 RG) rows.  w: FR fragments of the CURRENT item (in registers), refilled in
+// place from `next` (wave-uniform base of the next item) right behind their MFMAs.
+// acc[rg][j]: transposed product D'[n][m], lane 16g + c: row c of group rg, columns 16 j + 4 g .. + 3.
+// MODE F16: acc[rg][j] the x1 w1 part, lo[rg][j] the 2^11-scaled cross terms.
+template <int MODE, int RG>
+struct Item {
+  static constexpr int FR = frags_of(MODE);
+  static __device__ __forceinline__ void run(f32x4 (&acc)[RG][4], f32x4 (&lo)[RG][4], uint4 (&w)[FR], const float* arow,
+                                             const char* next, unsigned lo_off) {
+    if constexpr (MODE == M_F32) {
+      float4 ar[RG][4];
+#pragma unroll
+      for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) ar[rg][kg] = *reinterpret_cast<const float4*>(arow + rg * 16 * LDA + 16 * kg);
+#pragma unroll
+      for (int J = 0; J < 16; ++J) {
+        const float4 wf = __builtin_bit_cast(float4, w[J]);
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg) {
+          const float4 av = ar[rg][J >> 2];
+          const float a = (J & 3) == 0 ? av.x : (J & 3) == 1 ? av.y : (J & 3) == 2 ? av.z : av.w;
+          acc[rg][0] = MFMA_F(wf.x, a, acc[rg][0]);
+          acc[rg][1] = MFMA_F(wf.y, a, acc[rg][1]);
+          acc[rg][2] = MFMA_F(wf.z, a, acc[rg][2]);
+          acc[rg][3] = MFMA_F(wf.w, a, acc[rg][3]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        w[J] = ldg16(next + lo_off + J * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      constexpr int NP = planes_of(MODE);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        uint4 x[RG][3];
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg) {
+          const float4 a = *reinterpret_cast<const float4*>(arow + rg * 16 * LDA + 32 * kk);
+          const float4 b = *reinterpret_cast<const float4*>(arow + rg * 16 * LDA + 32 * kk + 4);
+          if constexpr (NP == 3) split_bf3(a, b, x[rg][0], x[rg][1], x[rg][2]);
+          else { split_f16(a, b, x[rg][0], x[rg][1]); x[rg][2] = x[rg][1]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int f0 = (kk * 4 + j) * NP;
+#pragma unroll
+          for (int rg = 0; rg < RG; ++rg) {
+            if constexpr (MODE == M_BF3_6 || MODE == M_BF3_9) {
+              if constexpr (MODE == M_BF3_9) {
+                acc[rg][j] = MFMA_BF(w[f0 + 2], x[rg][2], acc[rg][j]);
+                acc[rg][j] = MFMA_BF(w[f0 + 2], x[rg][1], acc[rg][j]);
+                acc[rg][j] = MFMA_BF(w[f0 + 1], x[rg][2], acc[rg][j]);
+              }
+              acc[rg][j] = MFMA_BF(w[f0 + 2], x[rg][0], acc[rg][j]);
+              acc[rg][j] = MFMA_BF(w[f0 + 0], x[rg][2], acc[rg][j]);
+              acc[rg][j] = MFMA_BF(w[f0 + 1], x[rg][1], acc[rg][j]);
+              acc[rg][j] = MFMA_BF(w[f0 + 1], x[rg][0], acc[rg][j]);
+              acc[rg][j] = MFMA_BF(w[f0 + 0], x[rg][1], acc[rg][j]);
+              acc[rg][j] = MFMA_BF(w[f0 + 0], x[rg][0], acc[rg][j]);
+            } else {
+              lo[rg][j] = MFMA_H(w[f0 + 1], x[rg][0], lo[rg][j]);
+              lo[rg][j] = MFMA_H(w[f0 + 0], x[rg][1], lo[rg][j]);
+              acc[rg][j] = MFMA_H(w[f0 + 0], x[rg][0], acc[rg][j]);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int p = 0; p < NP; ++p) w[f0 + p] = ldg16(next + lo_off + (f0 + p) * 1024);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
+};
+
+template <int MODE, int RG>
+__global__ __launch_bounds__(256, RG == 1 ? 2 : 1) void loop_kernel(const char* __restrict__ W, const float* __restrict__ X,
+                                                                    float* __restrict__ Y, int nitems, int nrep,
+                                                                    long long* __restrict__ cyc, int store, int M) {
+  extern __shared__ __align__(16) float lds[];          // [16 RG][LDA]
+  constexpr int FR = frags_of(MODE);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int m0 = blockIdx.x * 16 * RG;
+  for (int i = threadIdx.x; i < 16 * RG * 64; i += 256) {
+    const int row = i >> 6, c4 = i & 63;
+    const int grow = min(m0 + row, M - 1);
+    *reinterpret_cast<float4*>(&lds[row * LDA + 4 * c4]) = *reinterpret_cast<const float4*>(X + (size_t)grow * 256 + 4 * c4);
+  }
+  __syncthreads();
+  f32x4 acc[RG][4], lo[RG][4];
+#pragma unroll
+  for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { acc[rg][j] = f32x4{0, 0, 0, 0}; lo[rg][j] = f32x4{0, 0, 0, 0}; }
+  const unsigned lo_off = 16u * lane;
+  const size_t item_bytes = (size_t)FR * 1024;
+  const char* wbase = W + (size_t)wave * nitems * item_bytes;
+  uint4 w[FR];
+#pragma unroll
+  for (int f = 0; f < FR; ++f) w[f] = ldg16(wbase + lo_off + f * 1024);
+  // lane 16 g + c: row c; f32 mode reads 4 k at 16 kg + 4 g, split modes 8 k at 32 kk + 8 g
+  const float* arow0 = lds + (lane & 15) * LDA + (MODE == M_F32 ? 4 : 8) * (lane >> 4);
+  const long long t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 1
+  for (int rep = 0; rep < nrep; ++rep) {
+#pragma unroll 1
+    for (int it = 0; it < nitems; ++it) {
+      const int nx = it + 1 < nitems ? it + 1 : 0;
+      Item<MODE, RG>::run(acc, lo, w, arow0 + 64 * (it & 3), wbase + (size_t)nx * item_bytes, lo_off);
+      if (store && (it & 3) == 3) {
+        // one 64-column tile of Y is complete (K = 256): item it belongs to tile (it >> 2), wave's columns
+        const int tile = (it >> 2) * 4 + wave;
+        const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            f32x4 v = acc[rg][j];
+            if constexpr (MODE == M_F16_3) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) v[i] = v[i] + lo[rg][j][i] * (1.0f / 2048.0f);
+            }
+            const int row = m0 + 16 * rg + c;
+            if (row < M && tile * 64 < 256)
+              *reinterpret_cast<float4*>(Y + (size_t)row * 256 + tile * 64 + 16 * j + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+            acc[rg][j] = f32x4{0, 0, 0, 0}; lo[rg][j] = f32x4{0, 0, 0, 0};
+          }
+      }
+    }
+  }
+  const long long t1 = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0 && cyc != nullptr) cyc[blockIdx.x] = t1 - t0;
+  if (!store) {
+    float s = 0;
+#pragma unroll
+    for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s += acc[rg][j][0] + acc[rg][j][1] + acc[rg][j][2] + acc[rg][j][3] + lo[rg][j][0];
+    if (s == 1234.5678f) Y[0] = s;
+  }
+}
+
+// ---- host: packing ----------------------------------------------------------------------------------
+static uint16_t f2bf(float f) {            // round to nearest even
+  uint32_t u; memcpy(&u, &f, 4);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+static uint16_t f2h(float f) { _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u; }
+static float h2f(uint16_t u) { _Float16 h; memcpy(&h, &u, 2); return (float)h; }
+
+// Wsrc(tile-of-64-columns t, k) -> packed item stream [wave][item][frag][lane][16 B]; item `it` of wave w is
+// column tile 4 (it / 4) + w, k block it % 4 (K = 256) -- `wrap` tiles repeat the 256-column matrix
+static std::vector<char> pack(int mode, const std::vector<float>& W /*[256][256]*/, int nitems) {
+  const int FR = frags_of(mode);
+  std::vector<char> out((size_t)4 * nitems * FR * 1024);
+  for (int w = 0; w < 4; ++w)
+    for (int it = 0; it < nitems; ++it) {
+      const int tile = ((it >> 2) * 4 + w) % 4, kb = it & 3;
+      char* item = out.data() + ((size_t)w * nitems + it) * FR * 1024;
+      for (int lane = 0; lane < 64; ++lane) {
+        const int g = lane >> 4, c = lane & 15;
+        if (mode == M_F32) {
+          for (int J = 0; J < 16; ++J) {
+            float v[4];
+            for (int j = 0; j < 4; ++j) v[j] = W[(size_t)(64 * tile + 16 * j + c) * 256 + 64 * kb + 16 * (J >> 2) + 4 * g + (J & 3)];
+            memcpy(item + J * 1024 + lane * 16, v, 16);
+          }
+        } else {
+          const int NP = planes_of(mode);
+          for (int kk = 0; kk < 2; ++kk)
+            for (int j = 0; j < 4; ++j) {
+              uint16_t pl[3][8];
+              for (int e = 0; e < 8; ++e) {
+                const float x = W[(size_t)(64 * tile + 16 * j + c) * 256 + 64 * kb + 32 * kk + 8 * g + e];
+                if (NP == 3) {
+                  pl[0][e] = f2bf(x); const float r = x - bf2f(pl[0][e]);
+                  pl[1][e] = f2bf(r); const float s = r - bf2f(pl[1][e]);
+                  pl[2][e] = f2bf(s);
+                } else {
+                  pl[0][e] = f2h(x); pl[1][e] = f2h((x - h2f(pl[0][e])) * 2048.0f);
+                }
+              }
+              for (int p = 0; p < NP; ++p) memcpy(item + ((kk * 4 + j) * NP + p) * 1024 + lane * 16, pl[p], 16);
+            }
+        }
+      }
+    }
+  return out;
+}
+
+struct Stat { double maxe, rmse, maxrel; };
+
+template <int MODE, int RG>
+static void run_mode(const char* name, const std::vector<float>& X, const std::vector<float>& W,
+                     const std::vector<double>& Yref, double yscale, int M) {
+  // ---- accuracy: 4 items per wave = the whole 256 x 256 product
+  {
+    std::vector<char> P = pack(MODE, W, 4);
+    char* dP; float *dX, *dY;
+    CK(hipMalloc(&dP, P.size())); CK(hipMalloc(&dX, X.size() * 4)); CK(hipMalloc(&dY, (size_t)M * 256 * 4));
+    CK(hipMemcpy(dP, P.data(), P.size(), hipMemcpyHostToDevice));
+    CK(hipMemcpy(dX, X.data(), X.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(dY, 0, (size_t)M * 256 * 4));
+    const int nb = (M + 16 * RG - 1) / (16 * RG);
+    hipLaunchKernelGGL((loop_kernel<MODE, RG>), dim3(nb), dim3(256), 16 * RG * LDA * 4, 0, dP, dX, dY, 4, 1, nullptr, 1, M);
+    CK(hipDeviceSynchronize());
+    std::vector<float> Y((size_t)M * 256);
+    CK(hipMemcpy(Y.data(), dY, Y.size() * 4, hipMemcpyDeviceToHost));
+    double maxe = 0, se = 0;
+    for (size_t i = 0; i < Y.size(); ++i) { const double e = fabs((double)Y[i] - Yref[i]); maxe = std::max(maxe, e); se += e * e; }
+    printf("ACC  %-10s rows/wg %2d : max|err| %.3e  rms %.3e  (rms|y| %.3f; max err / rms|y| %.3e)\n", name, 16 * RG, maxe,
+           sqrt(se / Y.size()), yscale, maxe / yscale);
+    CK(hipFree(dP)); CK(hipFree(dX)); CK(hipFree(dY));
+  }
+  // ---- rate: 48 items per wave (3.1 M weights = a decoder layer's), 6 passes, every slot of the chip filled
+  {
+    const int nitems = 48, nrep = 6;
+    std::vector<char> P = pack(MODE, W, nitems);
+    char* dP; float *dX, *dY; long long* dC;
+    const int nb = RG == 1 ? 512 : 256;
+    const int Mr = nb * 16 * RG;
+    std::vector<float> Xr((size_t)Mr * 256);
+    for (size_t i = 0; i < Xr.size(); ++i) Xr[i] = X[i % X.size()];
+    CK(hipMalloc(&dP, P.size())); CK(hipMalloc(&dX, Xr.size() * 4)); CK(hipMalloc(&dY, 4096)); CK(hipMalloc(&dC, nb * 8));
+    CK(hipMemcpy(dP, P.data(), P.size(), hipMemcpyHostToDevice));
+    CK(hipMemcpy(dX, Xr.data(), Xr.size() * 4, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int warm = 0; warm < 3; ++warm)
+      hipLaunchKernelGGL((loop_kernel<MODE, RG>), dim3(nb), dim3(256), 16 * RG * LDA * 4, 0, dP, dX, dY, nitems, nrep, dC, 0, Mr);
+    CK(hipDeviceSynchronize());
+    const int NL = 10;
+    CK(hipEventRecord(e0));
+    for (int l = 0; l < NL; ++l)
+      hipLaunchKernelGGL((loop_kernel<MODE, RG>), dim3(nb), dim3(256), 16 * RG * LDA * 4, 0, dP, dX, dY, nitems, nrep, dC, 0, Mr);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<long long> cyc(nb);
+    CK(hipMemcpy(cyc.data(), dC, nb * 8, hipMemcpyDeviceToHost));
+    std::sort(cyc.begin(), cyc.end());
+    const double us = ms * 1e3 / NL;
+    const double items = (double)nitems * nrep;
+    const double flop = 2.0 * Mr * 256.0 * (4.0 * nitems * 64 * 64 / 256.0) * nrep;     // rows x K-equivalent x columns
+    printf("RATE %-10s rows/wg %2d wgs %3d : %8.1f us/launch  %7.0f cyc/item (median wg; min %.0f max %.0f)  "
+           "%6.1f ns per item round of a CU (32 rows) = %6.1f TFLOP/s fp32-equivalent, weight stream %5.0f GB/s per CU\n",
+           name, 16 * RG, nb, us, cyc[nb / 2] / items, cyc[0] / items, cyc[nb - 1] / items,
+           us * 1e3 / items /* every CU holds 32 rows in both geometries */, flop / us * 1e-6,
+           (double)P.size() * nrep * (nb / 256.0) / (us * 1e-6) * 1e-9);
+    CK(hipFree(dP)); CK(hipFree(dX)); CK(hipFree(dY)); CK(hipFree(dC));
+  }
+}
+
+int main() {
+  const int M = 912;
+  std::vector<float> X((size_t)M * 256), W(256 * 256);
+  uint64_t s = 0x9E3779B97F4A7C15ull;
+  auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (double)(s >> 11) / 9007199254740992.0; };
+  auto gauss = [&]() { const double u = rnd() + 1e-300, v = rnd(); return sqrt(-2 * log(u)) * cos(6.283185307179586 * v); };
+  for (auto& x : X) x = (float)(gauss() * 1.5);                       // LayerNorm-scale activations
+  for (auto& w : W) w = (float)((rnd() * 2 - 1) * 0.108);             // xavier uniform, 256 x 256
+  // a few hard cases: large and tiny magnitudes side by side
+  for (int i = 0; i < 256; ++i) { X[5 * 256 + i] *= 300.0f; X[6 * 256 + i] *= 1e-4f; X[7 * 256 + i] = (i & 1) ? 500.0f : -499.9f; }
+  std::vector<double> Yref((size_t)M * 256);
+  double sy = 0;
+  for (int m = 0; m < M; ++m)
+    for (int n = 0; n < 256; ++n) {
+      double a = 0;
+      for (int k = 0; k < 256; ++k) a += (double)X[(size_t)m * 256 + k] * (double)W[(size_t)n * 256 + k];
+      Yref[(size_t)m * 256 + n] = a; sy += a * a;
+    }
+  const double yscale = sqrt(sy / Yref.size());
+  {   // host fp32 fmaf chain for orientation
+    double maxe = 0, se = 0;
+    for (int m = 0; m < M; ++m)
+      for (int n = 0; n < 256; ++n) {
+        float a = 0;
+        for (int k = 0; k < 256; ++k) a = fmaf(X[(size_t)m * 256 + k], W[(size_t)n * 256 + k], a);
+        const double e = fabs((double)a - Yref[(size_t)m * 256 + n]); maxe = std::max(maxe, e); se += e * e;
+      }
+    printf("ACC  %-10s            : max|err| %.3e  rms %.3e\n", "host fmaf", maxe, sqrt(se / Yref.size()));
+  }
+  run_mode<M_F32, 1>("f32", X, W, Yref, yscale, M);
+  run_mode<M_BF3_6, 1>("bf16x3/6", X, W, Yref, yscale, M);
+  run_mode<M_BF3_9, 1>("bf16x3/9", X, W, Yref, yscale, M);
+  run_mode<M_F16_3, 1>("f16x2/3", X, W, Yref, yscale, M);
+  run_mode<M_F32, 2>("f32", X, W, Yref, yscale, M);
+  run_mode<M_BF3_6, 2>("bf16x3/6", X, W, Yref, yscale, M);
+  run_mode<M_F16_3, 2>("f16x2/3", X, W, Yref, yscale, M);
+  return 0;
+}

@@ -96,7 +96,7 @@ def reg_branch_view(seq):
     return L.tc_reg_branch(_lin(seq[0]), _lin(seq[2]), _lin(seq[4]))
 
 
-@HEADS.register_module()
+@HEADS.register_module(export=True)
 class Detr3DHead(BaseModule):
     """Head of Detr3D + the TransCAR radar fusion decoder."""
 

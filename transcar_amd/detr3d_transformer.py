@@ -54,7 +54,7 @@ class FeatureCache:
 _FEATS = FeatureCache()
 
 
-@ATTENTION.register_module()
+@ATTENTION.register_module(export=True)
 class Detr3DCrossAtten(BaseModule):
     """Camera cross-attention of DETR3D (XFMR:217-378)."""
 
@@ -121,7 +121,7 @@ class Detr3DCrossAtten(BaseModule):
         return out.transpose(0, 1)
 
 
-@TRANSFORMER_LAYER_SEQUENCE.register_module()
+@TRANSFORMER_LAYER_SEQUENCE.register_module(export=True)
 class Detr3DTransformerDecoder(TransformerLayerSequence):
     """XFMR:142-214."""
 
@@ -153,7 +153,7 @@ class Detr3DTransformerDecoder(TransformerLayerSequence):
         return output, reference_points
 
 
-@TRANSFORMER.register_module()
+@TRANSFORMER.register_module(export=True)
 class Detr3DTransformer(BaseModule):
     """XFMR:35-139."""
 

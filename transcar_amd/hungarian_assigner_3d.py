@@ -16,7 +16,7 @@ class AssignResult:
         self.max_overlaps, self.labels = max_overlaps, labels
 
 
-@BBOX_ASSIGNERS.register_module()
+@BBOX_ASSIGNERS.register_module(export=True)
 class HungarianAssigner3D:
     def __init__(self, cls_cost=dict(type='ClassificationCost', weight=1.),
                  reg_cost=dict(type='BBoxL1Cost', weight=1.0),

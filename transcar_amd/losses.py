@@ -61,7 +61,7 @@ class FocalLossCost:
         return (pos[:, gt_labels] - neg[:, gt_labels]) * self.weight
 
 
-@MATCH_COST.register_module()
+@MATCH_COST.register_module(export=True)
 class BBox3DL1Cost:
     """match_cost.py:5-26."""
 

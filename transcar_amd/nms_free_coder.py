@@ -8,7 +8,7 @@ from . import ops
 from .registry import BBOX_CODERS
 
 
-@BBOX_CODERS.register_module()
+@BBOX_CODERS.register_module(export=True)
 class NMSFreeCoder:
     def __init__(self, pc_range, voxel_size=None, post_center_range=None,
                  max_num=100, score_threshold=None, num_classes=10):

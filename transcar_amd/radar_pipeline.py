@@ -183,7 +183,7 @@ def radar_info_from_nusc(nusc, sample_token, nsweeps=5, ref_chan='LIDAR_TOP'):
     return info
 
 
-@PIPELINES.register_module()
+@PIPELINES.register_module(export=True)
 class LoadRadarPointsMultiSweep:
     """results['radar_info'] (see radar_info_from_nusc) -> results['radar'], the raw
     multi-sweep arrays ``transcar_amd.radar.build_radar_features`` consumes."""
@@ -209,7 +209,7 @@ class LoadRadarPointsMultiSweep:
         return results
 
 
-@PIPELINES.register_module()
+@PIPELINES.register_module(export=True)
 class BuildRadarFeatures:
     """results['radar'] raw sweeps -> the [n,36] feature array (HEAD:311-524), so the
     head's forward only pads, uploads and attends."""

@@ -3,8 +3,16 @@ this package's classes unchanged (the plugin boundary
 is `type='...'` strings + ctor kwargs).  When a real mmcv/mmdet is importable
 the classes are ALSO registered there, so `plugin_dir='transcar_amd/'` works
 as a drop-in for `projects/mmdet3d_plugin/`.
+
+Only the names the REFERENCE's plugin owns go into the mm registries (`export=True`: Detr3DHead,
+Detr3DTransformer, Detr3DTransformerDecoder, Detr3DCrossAtten, NMSFreeCoder, HungarianAssigner3D,
+BBox3DL1Cost -- projects/mmdet3d_plugin/__init__.py:1-16 registers exactly these on this path).  The
+third-party names the configs also use (MultiheadAttention, DetrTransformerDecoderLayer, FocalLossCost,
+IoUCost: mmcv / mmdet own them) stay in THIS package's registries only -- the head builds its nested
+modules through them -- so another model built in the same process keeps mmcv's own classes.
 """
 import importlib
+import warnings
 
 
 class Registry:
@@ -22,18 +30,22 @@ class Registry:
         except Exception:
             return None
 
-    def register_module(self, name=None, force=False, module=None):
+    def register_module(self, name=None, force=False, module=None, export=False):
+        """`export=True`: a reference-owned name -- also registered in the real mmcv / mmdet registry when one
+        is importable, replacing the reference plugin's class of the same name (that is the drop-in)."""
         def _reg(cls):
             key = name or cls.__name__
             if key in self.module_dict and not force:
                 raise KeyError('%s is already registered in %s' % (key, self.name))
             self.module_dict[key] = cls
-            mm = self._mm_registry()
-            if mm is not None:
-                try:
-                    mm.register_module(name=key, force=True, module=cls)
-                except Exception:
-                    pass
+            if export:
+                mm = self._mm_registry()
+                if mm is not None:
+                    try:
+                        mm.register_module(name=key, force=True, module=cls)
+                    except Exception as e:      # an mm version with another signature: say so, keep going
+                        warnings.warn('transcar_amd: could not register %s in %s.%s: %r'
+                                      % (key, self._mm_path[0], self._mm_path[1], e))
             return cls
         if module is not None:
             return _reg(module)
