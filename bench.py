@@ -73,6 +73,12 @@ def parse(argv=None):
                          '`latency_ms_per_frame` always at 1')
     ap.add_argument('--tile-rows', type=int, default=0, choices=[0, 4, 8, 16],
                     help='row-tile height of the fused chains in the frame pipeline (0 = automatic)')
+    ap.add_argument('--matrix-path', default='auto', choices=['auto', 'f32', 'f16x2'],
+                    help='tc_head_options.matrix_path of the 16-row tiles: f16x2 (= auto) two-plane f16 operands on the '
+                         'matrix cores with fp32 accumulation, f32 the exact fp32 MFMA chains')
+    ap.add_argument('--no-configs', action='store_true',
+                    help='skip the side measurements of BASELINE.json configs[4] (VoVNet shapes) and configs[2] (a training '
+                         'iteration) that ride in the default line')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--last-cls-only', action='store_true',
                     help='inference opt-in tc_head_options.last_level_cls_only: final_cls / final_cls2 are not '
@@ -375,11 +381,30 @@ def cur_stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def roofline(head, inp, dev):
+F16_MFMA_PEAK_TFLOPS = 2516.6  # dense f16 / bf16 matrix peak: 1024 flop / clk / SIMD x 1024 SIMDs x 2.4 GHz
+F16X2_PRODUCTS = 3             # v_mfma_f32_16x16x32_f16 per 32 k of one fp32-accurate product (chain.hip linear_step16h)
+MATRIX_PATH_CODE = {'auto': 0, 'f32': 1, 'f16x2': 2}
+
+
+def matrix_peak(f16x2):
+    """(peak TFLOP/s, definition) of a chain kernel's roofline: fp32-EQUIVALENT flop per second the matrix pipe can
+    deliver on that kernel's arithmetic."""
+    if f16x2:
+        return F16_MFMA_PEAK_TFLOPS / F16X2_PRODUCTS, ('dense f16 MFMA peak %.1f TFLOP/s / %d products per fp32-accurate '
+                                                       'product (two-plane f16 operands)' % (F16_MFMA_PEAK_TFLOPS, F16X2_PRODUCTS))
+    return F32_MFMA_PEAK_TFLOPS, 'dense f32 MFMA peak (v_mfma_f32_16x16x4_f32 = the fp32 vector rate)'
+
+
+def roofline(head, inp, dev, matrix_path='auto'):
     """Live timing of the kernels of the path.  The dominant one (largest share
     of a frame: the fused decoder row chain, 6 launches per frame) is reported
-    against its roofline; the others ride along under "others"."""
+    against its roofline; the others ride along under "others".  The chain kernels of a launch with 16-row tiles
+    (more than 2048 rows) compute on the f16 matrix cores unless matrix_path is 'f32': their peak is the f16 peak
+    divided by the products per fp32-accurate product, the fraction of the f32 MFMA peak rides along."""
     B = inp['l2i'].shape[0]
+    f16x2 = B * head.num_query > 2048 and matrix_path != 'f32'
+    chain_peak, chain_peak_def = matrix_peak(f16x2)
+    mp_code = MATRIX_PATH_CODE[matrix_path]
     Q, Cd, F = head.num_query, head.embed_dims, 512
     M = B * Q
     H, code, NL = 8, head.code_size, 24
@@ -404,7 +429,7 @@ def roofline(head, inp, dev):
             C.byref(pv.layers[3]), C.byref(pv.layers[4].self_attn.in_proj), C.byref(fv), B, Q, 6,
             code, attn_o.data_ptr(), hs2.data_ptr(), qe.data_ptr(), inp['l2i'].data_ptr(),
             ref.data_ptr(), pc, float(inp['hw'][0]), float(inp['hw'][1]), hs_out.data_ptr(),
-            ref_out.data_ptr(), qk.data_ptr(), vt.data_ptr(), qpad, 0, cur_stream()), 'decoder_layer_tail')
+            ref_out.data_ptr(), qk.data_ptr(), vt.data_ptr(), qpad, mp_code << 8, cur_stream()), 'decoder_layer_tail')
     if getattr(roofline, 'chain_only', False):        # tools/chain_stamps.py: one launch, no timing
         run_chain()
         return None
@@ -444,7 +469,7 @@ def roofline(head, inp, dev):
     rws = torch.empty(lib.tc_head_workspace_bytes(C.byref(pv), B, T_tok), dtype=torch.uint8, device=dev)
     rcls = torch.empty((3, B, Q, head.cls_out_channels), device=dev)
     rbox = torch.empty((3, B, Q, code), device=dev)
-    ropt = head_options()
+    ropt = head_options(matrix_path=matrix_path)
 
     def run_radar():
         L.check(lib.tc_radar_fusion_fwd(
@@ -473,13 +498,18 @@ def roofline(head, inp, dev):
     radar_flop_exec = radar_flop - 2.0 * (3 * M - gated_rows) * 2 * Cd * Cd
     kern = {
         'chain_kernel(decoder layer)': dict(
-            bound='mfma', achieved=chain_flop / chain_ms / 1e9, peak=F32_MFMA_PEAK_TFLOPS,
-            unit='TFLOP/s', ms=chain_ms, per_frame=6, alg_flop=chain_flop),
+            bound='mfma', achieved=chain_flop / chain_ms / 1e9, peak=chain_peak, peak_definition=chain_peak_def,
+            unit='TFLOP/s', ms=chain_ms, per_frame=6, alg_flop=chain_flop,
+            arithmetic='f16x2 split operands, fp32 accumulate' if f16x2 else 'f32',
+            # every workgroup streams the layer's packed weights (3.18 MB) through its CU's vector-memory path: what
+            # binds the f16x2 item loop (DESIGN.md section 5 "Round 4"; ~57 B / clk / CU measured by split_mfma_probe)
+            weight_stream_gbs_per_cu=(-(-B * head.num_query // (16 if B * head.num_query > 2048 else 8 if B * head.num_query > 1024 else 4))
+                                      * 795136 * 4 / 256.0) / chain_ms / 1e6),
         'self_attn_kernel': dict(
             bound='mfma', achieved=attn_flop / attn_ms / 1e9, peak=F32_MFMA_PEAK_TFLOPS,
             unit='TFLOP/s', ms=attn_ms, per_frame=6, alg_flop=attn_flop),
         'chain_kernel(radar fusion)': dict(
-            bound='mfma', achieved=radar_flop_exec / radar_ms / 1e9, peak=F32_MFMA_PEAK_TFLOPS,
+            bound='mfma', achieved=radar_flop_exec / radar_ms / 1e9, peak=chain_peak,
             unit='TFLOP/s', ms=radar_ms, per_frame=1, alg_flop=radar_flop_exec, reference_flop=radar_flop,
             gated_rows=gated_rows, note='achieved / frac count EXECUTED flop: q-proj and out_proj only in row tiles '
                                         'that hold a query with a radar hit (the reference computes them for every query)'),
@@ -490,6 +520,8 @@ def roofline(head, inp, dev):
     }
     for kk in kern.values():
         kk['frac'] = kk['achieved'] / kk['peak']
+        if kk['bound'] == 'mfma':
+            kk['frac_of_f32_mfma_peak'] = kk['achieved'] / F32_MFMA_PEAK_TFLOPS
     dom = max(kern, key=lambda n: kern[n]['ms'] * kern[n]['per_frame'])
     r = dict(kern[dom])
     # HBM-side traffic per launch comes from the committed PMC passes (rocprofv3 cannot
@@ -514,7 +546,8 @@ def roofline(head, inp, dev):
                  + radar_flop_exec) / B
     r.update(path_flop_per_frame=path_flop)
     r.update(kernel=dom, traffic=traffic, traffic_source=src,
-             others={n: dict({kk: v[kk] for kk in ('bound', 'achieved', 'peak', 'unit', 'frac', 'ms', 'per_frame')},
+             others={n: dict({kk: v[kk] for kk in ('bound', 'achieved', 'peak', 'unit', 'frac', 'ms', 'per_frame',
+                                                  'frac_of_f32_mfma_peak') if kk in v},
                              traffic=(pmc.get(n, {}).get(str(B)) or {}).get('traffic_bytes'))
                      for n, v in kern.items() if n != dom})
     for n, v in kern.items():                       # (the radar chain's executed / reference flop ride along)
@@ -549,7 +582,7 @@ def parse_counter_csv(path, ctr):
     return {name: (v / n, n, dur / n) for name, (v, n, dur) in acc.items() if n}
 
 
-def live_traffic(frames_per_launch, timeout_s=75):
+def live_traffic(frames_per_launch, timeout_s=75, extra_args=()):
     """HBM-side bytes per launch of the path's kernels, MEASURED in this run (the figure used to
     come from a committed profile): child passes `rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES --
     python3 bench.py --batch P --no-graph --main-only --steps 3` (separate passes, kernel trace only, the program itself
@@ -558,6 +591,7 @@ def live_traffic(frames_per_launch, timeout_s=75):
     process is itself being profiled, or a pass fails -- the caller keeps the committed figure then."""
     import glob
     import shutil
+    import signal
     import subprocess
     import tempfile
     if any(k.startswith('ROCPROF') or k.startswith('ROCP_') for k in os.environ):
@@ -565,21 +599,42 @@ def live_traffic(frames_per_launch, timeout_s=75):
     exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
     if not os.path.exists(exe):
         return {}
+    # the profiled program must be a real interpreter binary: under --pmc the profiler's preloaded library has
+    # initialised the GPU before the program starts, so a shim script that re-execs (pyenv and the like) would be an
+    # exec from a GPU-initialised process, which this pool forbids -- no PATH lookup of "python3"
+    py = os.path.realpath(sys.executable or '')
+    try:
+        with open(py, 'rb') as f:
+            if f.read(4) != b'\x7fELF':
+                return {}
+    except OSError:
+        return {}
     got = {}
     tmp = tempfile.mkdtemp(prefix='tc_pmc_', dir='/tmp')
     try:
         for ctr in ('FETCH_SIZE', 'WRITE_SIZE', 'SQ_VALU_MFMA_BUSY_CYCLES'):
             out = os.path.join(tmp, ctr)
-            cmd = [exe, '--kernel-trace', '--pmc', ctr, '--output-format', 'csv', '-d', out, '--',
-                   sys.executable if os.path.basename(sys.executable).startswith('python') else 'python3',
+            cmd = [exe, '--kernel-trace', '--pmc', ctr, '--output-format', 'csv', '-d', out, '--', py,
                    os.path.join(ROOT, 'bench.py'), '--batch', str(frames_per_launch), '--steps', '3', '--warmup', '1',
-                   '--main-only', '--no-graph', '--min-window-s', '0.02', '--warmup-s', '0.02']
+                   '--main-only', '--no-graph', '--min-window-s', '0.02', '--warmup-s', '0.02'] + list(extra_args)
             env = dict(os.environ, TMPDIR='/tmp')
             for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
                 env.pop(k, None)
-            r = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True, text=True, timeout=timeout_s)
+            # its own session: on a timeout the WHOLE group goes (rocprofv3 and the profiled bench.py behind it), or the
+            # grandchild would keep running on the GPU beside the side measurements that follow
+            proc = subprocess.Popen(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                    start_new_session=True)
+            try:
+                rc = proc.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                proc.wait()
+                return {}
             files = glob.glob(os.path.join(out, '**', '*counter_collection.csv'), recursive=True)
-            if r.returncode != 0 or not files:
+            if rc != 0 or not files:
                 return {}
             for name, (v, n, dur) in parse_counter_csv(files[0], ctr).items():
                 got.setdefault(name, {})[ctr] = v
@@ -712,7 +767,8 @@ def sweep_side_run(head, dev, args, skip, streams=None):
             continue
         lanes = [make_inputs(head, dev, args.shapes, fpl, seed=31 + 5 * i, host_feats=False)
                  for i in range(max(1, args.lanes))]
-        pipe = FramePipeline(head, lanes, streams=streams)      # the headline pipeline's (idle) streams
+        from transcar_amd.detr3d_head import head_options as _ho
+        pipe = FramePipeline(head, lanes, streams=streams, options=_ho(matrix_path=args.matrix_path))      # the headline pipeline's (idle) streams
         step = (lambda: pipe.launch()) if fpl == 1 else pipe.submit
 
         def sync():
@@ -728,7 +784,7 @@ def sweep_side_run(head, dev, args, skip, streams=None):
         # ended in a flush of a partly filled lane and the sweep showed 8 below 4)
         rounds = max(2, -(-max(20, args.steps) // (fpl * pipe.lanes)))
         t = _replay_rate(step, sync, rounds * fpl * pipe.lanes, min_s=0.6)
-        r = roofline(head, lanes[0], dev)
+        r = roofline(head, lanes[0], dev, args.matrix_path)
         allk = dict(r['others'])
         allk[r['kernel']] = r
         out[str(fpl)] = {'frames_per_launch': fpl, 'frames_in_flight': fpl * pipe.lanes,
@@ -954,36 +1010,46 @@ def cpu_baseline(sd, inp, seconds):
         O.get_bboxes(outs, rng)
         return time.perf_counter() - t0
 
-    def run(n, budget, max_frames):
-        """median / min over frames at n threads within `budget` seconds (>= 1 frame after a warm-up)"""
+    def run(n, warm, frames, budget):
+        """`warm` warm-up forwards, then `frames` timed ones at n threads -> median / min.
+        `budget` (seconds) bounds a thrashing thread count: the run stops early once it is spent (>= 1 timed frame)."""
         torch.set_num_threads(n)
-        first = frame()                                  # warm-up (allocator, thread pool)
-        if first > budget:                               # a thrashing thread count: keep the one frame
-            return dict(threads=n, frames=1, ms_per_frame=first * 1e3, min_ms_per_frame=first * 1e3)
-        times, t_end = [], time.perf_counter() + budget
-        while (time.perf_counter() < t_end and len(times) < max_frames) or not times:
+        t_end = time.perf_counter() + budget
+        for _ in range(warm):
+            frame()
+            if time.perf_counter() > t_end:
+                break
+        times = []
+        while len(times) < frames and (not times or time.perf_counter() < t_end):
             times.append(frame())
-        return dict(threads=n, frames=len(times), ms_per_frame=float(np.median(times)) * 1e3,
+        return dict(threads=n, warmups=warm, frames=len(times), ms_per_frame=float(np.median(times)) * 1e3,
                     min_ms_per_frame=float(np.min(times)) * 1e3)
 
     usable = info['usable_cores']
     allc = max(1, min(info['physical_cores'], usable))
+    scale = max(0.25, seconds / 12.0)                    # --cpu-seconds 12 (default) = the full procedure
     with torch.no_grad():
-        one = run(1, seconds * 0.3, 20)
-        # the ops are small (900 x 256): all cores of a big host thrash (73 s/frame at 256
-        # threads measured in round 1) -- reported as it is, bounded to one frame if slow
-        every = run(allc, seconds * 0.25, 20) if allc > 1 else one
-        best = min((one, every), key=lambda r: r['ms_per_frame'])
-        for n in sorted({min(usable, c) for c in (8, 16, 32)} - {1, allc}):
-            r = run(n, seconds * 0.15, 20)
-            if r['ms_per_frame'] < best['ms_per_frame']:
-                best = r
+        # which thread count is best: short probes (1 warm-up + 2 frames) -- the ops are small (900 x 256), all cores
+        # of a big host thrash (73 s / frame at 256 threads in round 1), so the all-cores figure is a bounded probe too
+        probes = {n: run(n, 1, 2, 3.0 * scale) for n in sorted({min(usable, c) for c in (8, 16, 32)} - {1})}
+        every = run(allc, 1, 2, 4.0 * scale) if allc > 1 and allc not in probes else probes.get(allc)
+        cand = dict(probes)
+        if every is not None:
+            cand[allc] = every
+        best_n = min(cand, key=lambda n: cand[n]['ms_per_frame']) if cand else 1
+        # the procedure itself: 5 warm-ups + 20 timed forwards at 1 thread and at the best count
+        one = run(1, 5, 20, 16.0 * scale)
+        best = run(best_n, 5, 20, 10.0 * scale) if best_n != 1 else one
+        if one['ms_per_frame'] < best['ms_per_frame']:
+            best = one
     out = dict(value=1e3 / best['ms_per_frame'], unit='frames/s', cores=best['threads'], kind='port',
                ms_per_frame=best['ms_per_frame'], min_ms_per_frame=best['min_ms_per_frame'],
-               sample='%d frames of the bench workload (B=1: Detr3DHead.forward + box decode), torch '
-                      'CPU fp32, %d threads (best of 1 / %d / 8 / 16 / 32)'
-                      % (best['frames'], best['threads'], allc),
-               one_thread=one, all_physical_cores=every)
+               sample='BASELINE.md section 3: %d warm-ups + %d timed frames of the bench workload (B=1: Detr3DHead.forward + '
+                      'box decode), torch CPU fp32, at 1 thread and at %d threads (the best of the probed counts %s); the '
+                      'other counts are 2-frame probes' % (best['warmups'], best['frames'], best['threads'],
+                                                          sorted(cand) if cand else [1]),
+               one_thread=one, all_physical_cores=dict(every or one, note='bounded probe: 1 warm-up + 2 frames'),
+               probes={str(n): r for n, r in probes.items()})
     out.update(info)
     return out
 
@@ -1043,19 +1109,14 @@ def per_rank_summary(own_ms, steps, frames_per_step):
             'unit': 'frames/s', 'definition': 'steps / own median window of the rank (value uses the MAX over ranks)'}
 
 
-def train_bench(args, head, inp, dev, rank, world, affinity=None):
-    """BASELINE.json configs[2]: batch-per-GPU 1 DDP training of the trainable
-    (radar) part of the head.  A step = frozen decoder forward + radar stack
-    forward (tc_radar_train_fwd) + Hungarian/focal/L1 loss (device kernels, scipy
-    assignment on the host as in the reference) + HIP backward + ONE all-reduce of
-    the flat gradient bucket over RCCL + device-side clip + AdamW + weight re-pack."""
+def _train_setup(head, dev, rank, B):
+    """A trainable copy of the head (tools/train.py's freeze list), its FusionTrainer and B synthetic GT sets."""
     from transcar_amd.trainer import FusionTrainer
     cfg = configs.head_cfg()
     cfg['train_cfg'] = configs.train_cfg_pts
     thead = T.build_head(cfg)
     thead.load_state_dict(head.state_dict(), strict=True)
     thead = thead.to(dev)
-    B = args.batch
     gts, lbs = [], []
     for b in range(B):
         boxes, labels = synth.make_gt(seed=7 + rank * 16 + b, n=24)
@@ -1063,8 +1124,24 @@ def train_bench(args, head, inp, dev, rank, world, affinity=None):
         gt[:, 2] += gt[:, 5] * 0.5
         gts.append(gt.to(dev))
         lbs.append(torch.from_numpy(labels).to(dev))
+    was = torch.is_grad_enabled()
     torch.set_grad_enabled(True)
-    tr = FusionTrainer(thead)
+    try:
+        tr = FusionTrainer(thead)
+    finally:
+        torch.set_grad_enabled(was)
+    return thead, tr, gts, lbs
+
+
+def train_bench(args, head, inp, dev, rank, world, affinity=None):
+    """BASELINE.json configs[2]: batch-per-GPU 1 DDP training of the trainable
+    (radar) part of the head.  A step = frozen decoder forward + radar stack
+    forward (tc_radar_train_fwd) + Hungarian/focal/L1 loss (device kernels, scipy
+    assignment on the host as in the reference) + HIP backward + ONE all-reduce of
+    the flat gradient bucket over RCCL + device-side clip + AdamW + weight re-pack."""
+    B = args.batch
+    thead, tr, gts, lbs = _train_setup(head, dev, rank, B)
+    torch.set_grad_enabled(True)
     last = {}
 
     # the next iteration's frame is known one step ahead (a data loader's look-ahead; here the same synthetic
@@ -1190,6 +1267,97 @@ def train_roofline(tr, thead, inp, gts, lbs, nxt, dev):
     return out
 
 
+def _pipeline_rate(head, dev, args, shapes, fpl, options, streams=None, min_s=0.6, seed0=41):
+    """frames/s of a FramePipeline (args.lanes lanes, fpl frames per launch, whole launches per window) and the
+    pipeline's first lane inputs (for a roofline of the same geometry)."""
+    from transcar_amd.pipeline import FramePipeline
+    lanes = [make_inputs(head, dev, shapes, fpl, seed=seed0 + 5 * i, host_feats=False) for i in range(max(1, args.lanes))]
+    pipe = FramePipeline(head, lanes, streams=streams, options=options)
+    step = (lambda: pipe.launch()) if fpl == 1 else pipe.submit
+
+    def sync():
+        if fpl > 1:
+            pipe.flush()
+        torch.cuda.synchronize()
+    t_end = time.perf_counter() + max(0.3, args.warmup_s)
+    while time.perf_counter() < t_end:
+        for _ in range(fpl * pipe.lanes):
+            step()
+        sync()
+    rounds = max(2, -(-max(20, args.steps) // (fpl * pipe.lanes)))
+    t = _replay_rate(step, sync, rounds * fpl * pipe.lanes, min_s=min_s)
+    return 1.0 / t, pipe, lanes
+
+
+def f32_path_side_run(head, dev, args, fpl, streams=None):
+    """The SAME pipeline with tc_head_options.matrix_path = f32 (v_mfma_f32_16x16x4_f32 in the 16-row tiles, round 3's
+    arithmetic): the plain-fp32 figure beside the headline."""
+    from transcar_amd.detr3d_head import head_options
+    rate, pipe, lanes = _pipeline_rate(head, dev, args, args.shapes, fpl, head_options(matrix_path='f32'), streams)
+    r = roofline(head, lanes[0], dev, 'f32')
+    allk = dict(r['others'])
+    allk[r['kernel']] = r
+    out = {'matrix_path': 'f32', 'value': rate, 'unit': 'frames/s', 'frames_per_launch': fpl,
+           'decoder_chain_us': allk['chain_kernel(decoder layer)']['ms'] * 1e3,
+           'decoder_chain_frac_of_f32_mfma_peak': allk['chain_kernel(decoder layer)']['frac'],
+           'radar_chain_us': allk['chain_kernel(radar fusion)']['ms'] * 1e3}
+    del pipe, lanes
+    torch.cuda.empty_cache()
+    return out
+
+
+def vovnet_side_run(head, dev, args, fpl, streams=None):
+    """BASELINE.json configs[4]'s FPN shapes (VoVNet, start_level = 0: 232x400 ... 29x50 = 757 MB of maps per frame;
+    CFG_VOV:39-47) through the same pipeline: frames/s, the dominant kernel against its roofline, one frame at a time."""
+    from transcar_amd.detr3d_head import head_options
+    from transcar_amd.pipeline import FramePipeline
+    rate, pipe, lanes = _pipeline_rate(head, dev, args, 'vovnet', fpl, head_options(matrix_path=args.matrix_path), streams,
+                                       seed0=61)
+    r = roofline(head, lanes[0], dev, args.matrix_path)
+    one = make_inputs(head, dev, 'vovnet', 1, seed=67, host_feats=False)
+    pipe1 = FramePipeline(head, [one], streams=streams)
+    lat = single_lane(pipe1, args)
+    out = {'workload': 'BASELINE.json configs[4] at one GPU: VoVNet FPN levels %s x 256 ch, 900 queries, 255 radar points'
+                       % (configs.LEVEL_SHAPES['vovnet'],),
+           'value': rate, 'unit': 'frames/s', 'frames_per_launch': fpl, 'lanes': pipe.lanes,
+           'dominant_kernel': r['kernel'], 'dominant_kernel_us': r['ms'] * 1e3, 'dominant_kernel_frac': r['frac'],
+           'dominant_kernel_frac_of_f32_mfma_peak': r.get('frac_of_f32_mfma_peak'),
+           'latency_ms_per_frame': lat['ms_per_frame_synced']}
+    del pipe, pipe1, lanes, one
+    torch.cuda.empty_cache()
+    return out
+
+
+def train_side_run(head, inp, dev, args):
+    """BASELINE.json configs[2] at one GPU inside the inference line: a short `--train` run --
+    ms per iteration of the fused training path (frozen decoder forward in train mode, stack forward / backward as row
+    chains, device loss, flat-bucket clip + AdamW), its launches per iteration and the roofline of its three phases."""
+    thead, tr, gts, lbs = _train_setup(head, dev, 0, 1)
+    frame = make_inputs(head, dev, args.shapes, 1, seed=3)
+    nxt = dict(feats_nhwc=frame['nhwc'], lidar2img=frame['l2i'], img_hw=frame['hw'], tokens=frame['tokens'],
+               pad_mult=frame['pad_mult'])
+    was = torch.is_grad_enabled()
+    torch.set_grad_enabled(True)
+    try:
+        def step():
+            tr.step_fused_nhwc(frame['nhwc'], frame['l2i'], frame['hw'], frame['tokens'], frame['pad_mult'], gts, lbs,
+                               prefetch=nxt)
+        for _ in range(15):
+            step()
+        torch.cuda.synchronize()
+        t = _replay_rate(step, torch.cuda.synchronize, 50, min_s=0.8)
+        roof = train_roofline(tr, thead, frame, gts, lbs, nxt, dev)
+    finally:
+        torch.set_grad_enabled(was)
+    out = {'workload': 'BASELINE.json configs[2] at one GPU: one frame per iteration (CFG:188), %s FPN shapes, 24 GT boxes'
+                       % args.shapes,
+           'ms_per_iteration': t * 1e3, 'value': 1.0 / t, 'unit': 'frames/s', 'prefetch_depth': getattr(tr, 'prefetch_depth', 1),
+           'roofline': {k: roof[k] for k in ('bound', 'peak', 'unit', 'achieved', 'frac', 'ms', 'parts', 'note')}}
+    del tr, thead
+    torch.cuda.empty_cache()
+    return out
+
+
 def auto_frames_per_launch(head, dev):
     """--pair 0: the largest number of frames whose 16-row tiles are resident at once (two workgroups per CU):
     9 frames of 900 queries = 507 workgroups on the 512 slots of an MI355X.  The step count does not matter
@@ -1255,7 +1423,7 @@ def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse(argv)
     if args.main_only:
-        args.no_roofline = args.no_handoff = args.no_batched = args.no_cpu_baseline = True
+        args.no_roofline = args.no_handoff = args.no_batched = args.no_cpu_baseline = args.no_configs = True
     env_world = os.environ.get('WORLD_SIZE')
     if env_world is None and args.gpus > 1:
         return spawn_ranks(args, argv)          # launcher parent: no torch, no GPU
@@ -1301,7 +1469,8 @@ def main(argv=None):
         from transcar_amd.detr3d_head import head_options
         pipe = FramePipeline(head, lanes, options=head_options(tile_rows=args.tile_rows or None,
                                                               last_level_cls_only=args.last_cls_only,
-                                                              radar_compact=False if args.no_radar_compact else None))
+                                                              radar_compact=False if args.no_radar_compact else None,
+                                                              matrix_path=args.matrix_path))
 
     def step():
         if pipe is None:
@@ -1335,15 +1504,24 @@ def main(argv=None):
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,
-        'dtype': 'f32',
+        # the arithmetic the path computes in: fp32 everywhere; the linear steps of launches with 16-row tiles form each
+        # fp32 product from two-plane f16 operands on the matrix cores (three MFMAs, fp32 accumulate) unless
+        # --matrix-path f32 (`f32_path` carries that figure)
+        'dtype': ('f32 (linear steps of the batched launches: f16x2 split operands, %d v_mfma_f32_16x16x32_f16 products, fp32 '
+                  'accumulate; attention core and 4- / 8-row tiles: f32 MFMA)' % F16X2_PRODUCTS)
+                 if (pipe is not None and pipe.tile_rows_of() == 16 and args.matrix_path != 'f32') else 'f32',
         'data': 'synthetic',
         'timing': win,
         'per_rank': per_rank_summary(own, args.steps, args.batch),
         'cpu_affinity': affinity,
-        'config': {'workload': 'BASELINE.json configs[1]: synthetic 6 cameras, ResNet-101 FPN '
-                               'levels %s x 256 ch (fp32, channels-last), 900 queries, 255 radar '
+        'config': {'workload': '%s FPN levels %s x 256 ch (fp32, channels-last), 900 queries, 255 radar '
                                'points, %d frame(s)/step/GPU, %dxMI355X inference'
-                               % (configs.LEVEL_SHAPES[args.shapes], args.batch, world),
+                               % ({'res101': 'BASELINE.json configs[1]: synthetic 6 cameras, ResNet-101',
+                                   'vovnet': 'BASELINE.json configs[4] shapes (CFG_VOV:39-47) at %d GPU(s): synthetic 6 cameras, '
+                                             'VoVNet' % world,
+                                   'tiny': 'parity-test shapes (NOT a BASELINE.json configuration): 6 cameras, tiny'}[args.shapes],
+                                  configs.LEVEL_SHAPES[args.shapes], args.batch, world),
+                   'matrix_path': args.matrix_path,
                    'shapes': args.shapes, 'frames_per_step_per_gpu': args.batch,
                    'launch': 'eager' if pipe is None else 'hipGraph replay',
                    'frames_per_launch': 1 if pipe is None else pipe.frames_per_launch,
@@ -1365,16 +1543,18 @@ def main(argv=None):
             line['latency_ms_per_frame'] = line['single_lane']['ms_per_frame_synced']
         if not args.no_roofline:
             # the dominant kernel as the timed region launches it (frames_per_launch frames per launch)
-            line['roofline'] = roofline(head, pipe.inputs[0] if pipe is not None else inp, dev)
+            line['roofline'] = roofline(head, pipe.inputs[0] if pipe is not None else inp, dev, args.matrix_path)
             line['roofline']['frames_per_launch'] = 1 if pipe is None else pipe.frames_per_launch
-            # every kernel of the path together, at the measured whole-job rate
+            # every kernel of the path together, at the measured whole-job rate -- against the f32 MFMA peak (the
+            # attention core and the small tiles compute on it; > 1 would only say that the f16x2 chains beat it)
             pf = line['roofline']['path_flop_per_frame']
             line['roofline']['path_achieved_tflops'] = pf * line['value'] / world / 1e12
-            line['roofline']['path_frac'] = line['roofline']['path_achieved_tflops'] / line['roofline']['peak']
+            line['roofline']['path_frac'] = line['roofline']['path_achieved_tflops'] / F32_MFMA_PEAK_TFLOPS
+            line['roofline']['path_frac_peak'] = 'f32 MFMA peak %.1f TFLOP/s' % F32_MFMA_PEAK_TFLOPS
             if world == 1 and not args.no_live_pmc and not args.no_graph:
                 # HBM-side bytes of the same launches, measured now (two rocprofv3 --pmc child passes)
                 rl = line['roofline']
-                live = live_traffic(rl['frames_per_launch'])
+                live = live_traffic(rl['frames_per_launch'], extra_args=('--matrix-path', args.matrix_path))
                 src = 'this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE child passes, (2 F + W) * 1024'
                 if rl['kernel'] in live:
                     rl['traffic_committed_profile'] = rl.get('traffic')
@@ -1400,6 +1580,13 @@ def main(argv=None):
             if args.batch == 1 and not args.no_batched and pipe is not None:
                 line['frames_per_launch_sweep'] = sweep_side_run(head, dev, args, pipe.frames_per_launch,
                                                                  streams=pipe.streams)
+            if pipe is not None and not args.main_only and args.batch == 1:
+                if args.matrix_path != 'f32' and pipe.tile_rows_of() == 16:
+                    line['f32_path'] = f32_path_side_run(head, dev, args, pipe.frames_per_launch, streams=pipe.streams)
+                if args.shapes == 'res101' and not args.no_configs:
+                    # configs[4] (VoVNet FPN shapes) and configs[2] (a training iteration) at one GPU, in the same line
+                    line['vovnet'] = vovnet_side_run(head, dev, args, pipe.frames_per_launch, streams=pipe.streams)
+                    line['train'] = train_side_run(head, inp, dev, args)
         # the reported CPU baseline (the oracle on this host's cores): in the line at every world size, so that
         # the N = 1 point of a scaling run and the plain bench line have one schema.  A rank of a multi-GPU job
         # is pinned to its GPU's NUMA node: `usable_cores` says what the baseline could use.

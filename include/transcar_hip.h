@@ -34,7 +34,7 @@ extern "C" {
 #define TC_MAX_LEVELS 4
 #define TC_MAX_LAYERS 8
 #define TC_MAX_RADAR_LAYERS 3
-#define TC_ABI_VERSION 8
+#define TC_ABI_VERSION 9
 
 typedef void* tc_stream_t;
 
@@ -155,8 +155,20 @@ typedef struct {
                                2 = the rest.  Between 1 and 2
                                the caller builds the tokens (host packing, H2D, tc_radar_build_tokens*) while the
                                device already runs the decoder: Detr3DHead.forward does exactly that */
-  int reserved_;
+  int matrix_path;          /* arithmetic of the 16-row tiles' linear steps (frames batched into one launch; 4- and
+                               8-row tiles always run the exact fp32 MFMA): TC_MATRIX_AUTO (0) = TC_MATRIX_F16X2,
+                               the operands as two f16 planes each, three v_mfma_f32_16x16x32_f16 per 32 k with
+                               fp32 accumulation -- fp32-accurate (closer to fp64 than the fp32 FMA chain,
+                               profiles/r4_split_mfma_probe.txt), activations of a linear step must stay below
+                               4.19e6 in magnitude (an overflow shows as inf / NaN, never silently);
+                               TC_MATRIX_F32 (1) = v_mfma_f32_16x16x4_f32, exact fp32 FMA chains */
 } tc_head_options;
+#define TC_MATRIX_AUTO 0
+#define TC_MATRIX_F32 1
+#define TC_MATRIX_F16X2 2
+/* tc_decoder_layer_tail_fwd's tile_rows carries the matrix path in bits 8..9: rows | (TC_MATRIX_* << 8) */
+#define TC_TILE_ROWS(v) ((v) & 0xFF)
+#define TC_TILE_MATRIX(v) (((v) >> 8) & 3)
 
 /* ---- library ---- */
 int tc_abi_version(void);
@@ -284,7 +296,7 @@ int tc_decoder_layer_tail_fwd(const tc_decoder_layer* layer, const tc_linear* ne
                               const float* ref_in, const float* pc_range /*host[6]*/,
                               float img_h, float img_w, float* hs, float* ref_out,
                               float* qk, float* vt, int qpad,
-                              int tile_rows /* 0 automatic, 4, 8, 16 */, tc_stream_t stream);
+                              int tile_rows /* 0 automatic, 4, 8, 16; | TC_MATRIX_* << 8 */, tc_stream_t stream);
 
 /* The attention core of the above on already projected operands (the kernel
  * the roofline is quoted on): out = softmax(q k^T) v per (batch, head).

@@ -971,8 +971,8 @@ def test_pipelines_can_share_streams(T, head):
         FramePipeline(head, lanes, streams=a.streams[:1])
 
 
-@pytest.mark.parametrize('tile_rows', [8, 16])
-def test_a_frame_in_a_batch_equals_the_frame_alone(T, head, tile_rows):
+@pytest.mark.parametrize('tile_rows,matrix', [(8, None), (16, 'f16x2'), (16, 'f32')])
+def test_a_frame_in_a_batch_equals_the_frame_alone(T, head, tile_rows, matrix):
     """Size independence of the whole path at a fixed tile height: every kernel is row-local except the
     per-(sample, head) attention, so frame b of a three-frame launch (tiles straddle the sample boundaries,
     the radar rows are re-ordered per sample) is BIT-IDENTICAL to the same frame launched alone."""
@@ -981,7 +981,7 @@ def test_a_frame_in_a_batch_equals_the_frame_alone(T, head, tile_rows):
     from transcar_amd.detr3d_head import head_options
     B = 3
     inp = bench.make_inputs(head, dev(), 'tiny', B, seed=61)
-    opt = head_options(tile_rows=tile_rows, radar_compact=True)
+    opt = head_options(tile_rows=tile_rows, radar_compact=True, matrix_path=matrix)
     full = head.forward_nhwc(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'], inp['pad_mult'], aux=True, options=opt)
     torch.cuda.synchronize()
     full = {k: full[k].clone() for k in ('all_cls_scores', 'all_bbox_preds')}
@@ -991,6 +991,55 @@ def test_a_frame_in_a_batch_equals_the_frame_alone(T, head, tile_rows):
         torch.cuda.synchronize()
         assert torch.equal(one['all_cls_scores'][:, 0], full['all_cls_scores'][:, b])
         assert torch.equal(one['all_bbox_preds'][:, 0], full['all_bbox_preds'][:, b])
+
+
+def test_f16x2_chains_are_exact_and_repeatable_at_two_workgroups_per_cu(T, head):
+    """Round 4 regression (profiles/r4_f16x2_hazard.txt): the first f16x2 item loop refilled its weight registers in
+    place, as the f32 loop does; with TWO workgroups per CU (8 frames = 450 row tiles) the radar chain then came out
+    wrong on a few queries per launch, differently from run to run, while one frame (one workgroup per CU) was always
+    exact.  Eight frames through tc_radar_fusion_fwd on both matrix paths, both row orders: f16x2 equals f32 to fp32
+    rounding on EVERY query (same gate decisions), and three runs are bit-identical."""
+    import ctypes as C
+    import bench
+    bench._imports()
+    from transcar_amd import _lib as L, ops
+    from transcar_amd.detr3d_head import head_options
+    B = 8
+    inp = bench.make_inputs(head, dev(), 'tiny', B, seed=71, host_feats=False)
+    o = head.forward_nhwc(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'], inp['pad_mult'], aux=True,
+                          options=head_options(tile_rows=16, matrix_path='f32'))
+    torch.cuda.synchronize()
+    hs5 = o['aux']['inter_states'][-1].contiguous().clone()
+    ref5 = o['aux']['inter_references'][-1].contiguous().clone()
+    lbox = o['aux']['last_box'].contiguous().clone()
+    ws = torch.empty(L.lib().tc_head_workspace_bytes(C.byref(head._packed_view), B, inp['tokens'].shape[1]),
+                     dtype=torch.uint8, device=dev())
+
+    def run(mp, compact):
+        opt = head_options(tile_rows=16, matrix_path=mp, radar_compact=compact)
+        c, b, h = ops.radar_fusion(head, hs5, ref5, lbox, inp['tokens'], inp['pad_mult'], 0, 3, options=opt, ws=ws)
+        torch.cuda.synchronize()
+        return c.clone(), b.clone(), h.clone()
+    for compact in (None, False):
+        want = run('f32', compact)
+        assert int((want[2] > 0).sum()) > 200, 'the rig must exercise the gated attention'
+        first = None
+        for rep in range(3):
+            got = run('f16x2', compact)
+            assert torch.equal(got[2], want[2]), 'gate decisions differ'
+            assert float((got[0] - want[0]).abs().max()) < 1e-4 and float((got[1] - want[1]).abs().max()) < 1e-4
+            if first is None:
+                first = got
+            else:
+                assert all(torch.equal(a, b) for a, b in zip(got, first)), 'f16x2 is not repeatable (run %d)' % rep
+    # ... and the whole forward (decoder chains included), run to run
+    outs = []
+    for rep in range(3):
+        o = head.forward_nhwc(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'], inp['pad_mult'],
+                              options=head_options(tile_rows=16, matrix_path='f16x2'))
+        torch.cuda.synchronize()
+        outs.append((o['all_cls_scores'].clone(), o['all_bbox_preds'].clone()))
+    assert all(torch.equal(outs[0][0], x[0]) and torch.equal(outs[0][1], x[1]) for x in outs[1:])
 
 
 def test_full_size_launch_of_eight_frames_is_frame_by_frame_the_single_frame_path(T):

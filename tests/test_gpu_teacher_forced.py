@@ -22,6 +22,7 @@ import torch.nn.functional as F
 
 from oracle import transcar_oracle as O
 from transcar_amd import configs, radar as R, synth
+from transcar_amd.detr3d_head import MATRIX_PATHS
 
 pytestmark = pytest.mark.gpu
 
@@ -95,10 +96,11 @@ def _qkv_from_oracle_state(sd, lid, x, pos):
     return q.float(), k.float(), vt.float()
 
 
-@pytest.mark.parametrize('tile_rows', [0, 8, 16])
-def test_decoder_layers_teacher_forced_on_bench_inputs(rig, tile_rows):
-    """Every tile height of the row chain (0 = the automatic choice, 4-row tiles at one frame; 8; 16 =
-    the v_mfma_f32_16x16x4 path on the second weight copy):
+@pytest.mark.parametrize('tile_rows,matrix', [(0, None), (8, None), (16, 'f16x2'), (16, 'f32')])
+def test_decoder_layers_teacher_forced_on_bench_inputs(rig, tile_rows, matrix):
+    """Every tile height of the row chain (0 = the automatic choice, 4-row tiles at one frame; 8; 16 on BOTH
+    matrix paths: the two-plane f16 operands on the matrix cores -- round 4, the default -- and the
+    v_mfma_f32_16x16x4 path on the second weight copy; the tolerances are the same for all):
     HIP layer l (attention core + fused row chain) on the oracle's layer-(l-1) state and
     reference points, l = 0..5, iid-noise ResNet-101 maps, full-scale refinement MLPs -- measured
     against the fp64 evaluation of the reference formula on the same inputs, next to the fp32
@@ -121,7 +123,7 @@ def test_decoder_layers_teacher_forced_on_bench_inputs(rig, tile_rows):
         nxt = pv.layers[lid + 1].self_attn.in_proj if lid + 1 < L else None
         hs, ref_out, qk_next, vt_next = ops.decoder_layer_tail(
             pv.layers[lid], nxt, rig['nhwc'], attn_o, gpu(x_prev), gpu(qe), l2i, gpu(ref_prev), PCR, HW,
-            tile_rows=tile_rows)
+            tile_rows=tile_rows, matrix_path=MATRIX_PATHS[matrix])
         # the same layer: fp32 oracle (from the rig's trace) and fp64 evaluation of the same formula
         p = 'transformer.decoder.layers.%d.' % lid
         truth = O.decoder_layer(sd64, p, x_prev.permute(1, 0, 2).double(), pos.permute(1, 0, 2).double(),
@@ -187,9 +189,9 @@ def _hit_aware(got, want, got_hits, want_hits, tol, what):
     return agree
 
 
-@pytest.mark.parametrize('tile_rows', [0, 16])
-def test_radar_layers_teacher_forced_on_bench_inputs(rig, tile_rows):
-    """(4-row tiles and the 16-row tiles' 16x16x4 path.)  The fused radar chain, ONE fusion layer at a time: layer r is fed the oracle's query
+@pytest.mark.parametrize('tile_rows,matrix', [(0, None), (16, 'f16x2'), (16, 'f32')])
+def test_radar_layers_teacher_forced_on_bench_inputs(rig, tile_rows, matrix):
+    """(4-row tiles and the 16-row tiles on both matrix paths: two-plane f16 and the f32 16x16x4.)  The fused radar chain, ONE fusion layer at a time: layer r is fed the oracle's query
     features and box of layer r-1 (hs[5] / the decoder's last box for r = 0) and must reproduce the
     oracle's class scores, boxes and hit counts of layer r; then all three layers in one launch from
     the oracle's hs[5] (the launch tc_head_forward makes)."""
@@ -214,7 +216,7 @@ def test_radar_layers_teacher_forced_on_bench_inputs(rig, tile_rows):
     tmp = gpu(dbg['tmp'])                                     # the decoder's last box, metres
     # -- all three layers in one launch (what tc_head_forward does), from the oracle's decoder state
     from transcar_amd.detr3d_head import head_options
-    opt = head_options(tile_rows=tile_rows or None)
+    opt = head_options(tile_rows=tile_rows or None, matrix_path=matrix)
     cls, box, hits = ops.radar_fusion(head, hs5, ref5, tmp, tokens, pad_mult, 0, 3, options=opt)
     agree0 = _hit_aware(box[0, 0].cpu().numpy(), want_box[0], hits[0, 0].cpu().numpy(), want_hits[0],
                         LAYER_TOL, 'fusion layer 1 box')

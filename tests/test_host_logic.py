@@ -162,6 +162,10 @@ def test_entry_points_refuse_bad_arguments_without_gpu():
     o = head_options()
     o.radar_row_order = 7
     assert fwd(o) != 0 and b'radar_row_order' in lib.tc_last_error()
+    o = head_options(matrix_path='f32')
+    assert o.matrix_path == _lib.TC_MATRIX_F32 and head_options().matrix_path == _lib.TC_MATRIX_AUTO
+    o.matrix_path = 3
+    assert fwd(o) != 0 and b'matrix_path' in lib.tc_last_error()
     o = head_options()
     o.decoder_dropout_p = 1.5
     assert fwd(o) != 0 and b'decoder_dropout_p' in lib.tc_last_error()

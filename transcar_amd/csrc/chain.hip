@@ -334,6 +334,7 @@ struct ChainDev {
   DropK drop;                  // decoder program, DROP instantiation only (thr 0: off)
   int dbg;                     // STAMPS build only: TRANSCAR_CHAIN_DBG (timing experiments, wrong results)
   int tile_rows;               // requested row-tile height (0: automatic); host side only
+  int matrix_path;             // TC_MATRIX_* for the 16-row tiles; host side only
   int last_cls_only;           // radar program: class MLPs of the last layer only; host side only
   // decoder
   const float* ref_in; int ref_mod; float* ref_out; float* box_m;
@@ -825,6 +826,164 @@ __device__ __forceinline__ bool linear_step16(const LinSpec& s, WBuf& w0, bool p
   return next_first != nullptr;
 }
 
+// ---- 16-row tiles on the f16 MATRIX CORES, fp32-accurate (round 4) ---------------------------------------
+// The f32 MFMA is the vector pipe (64 flop / clk / SIMD, and it holds the VALU's issue slots); the f16 / bf16
+// MFMAs run on the matrix cores at 16 x that rate.  Operands as TWO f16 planes each,
+//     x = (x1 + 2^-11 x2') / s,   x1 = f16(s x),  x2' = f16((s x - x1) 2^11)        (round to nearest)
+// (s = 2^-6: |x| < 4.19e6 cannot overflow; the residual is exact in fp32 and the 2^11 keeps it a normal f16, so
+// the pair represents s x to <= 2^-24 |s x| wherever |s x| >= 2^-14 -- one ulp of fp32 -- and to < 1.5e-11
+// absolute below that), weights likewise with s = 1 (pack.hip PH).  x w = x1 w1 + 2^-11 (x1 w2' + x2' w1)
+// + 2^-22 x2' w2': three v_mfma_f32_16x16x32_f16 per 32 k (products of f16 values are exact in the fp32
+// accumulator), the last term (<= 2^-24 |x w|) is dropped.  Measured against fp64 on a 912 x 256 x 256
+// product (tools/split_mfma_probe.hip, profiles/r4_split_mfma_probe.txt): rms error 2.6e-6 vs 6.2e-6 for the
+// fp32 FMA chain of v_mfma_f32_16x16x4_f32 (the matrix core adds its 32 products before it rounds).
+// The item loop then is bound by the weight stream (~57 B / clk / CU), not by the pipe: 2 226 cycles per item
+// against 4 702, which is why the planes are f16 x 2 (4 bytes per weight, as fp32) and not bf16 x 3 (6 bytes:
+// 3 429 cycles, same probe).  The activations are split IN REGISTERS per item -- the LDS of a 16-row tile has
+// no room for planes at two workgroups per CU; ~30 VALU instructions per 12 MFMAs, and the f16 MFMA leaves
+// the VALU half of its issue slots.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#define MFMA16H(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, (a)), __builtin_bit_cast(f16x8, (b)), (c), 0, 0, 0)
+constexpr float H_ACT_SCALE = 1.0f / 64.0f;      // s
+constexpr float H_LO_SCALE = 2048.0f;            // 2^11
+struct Acc16H { f32x4 hi[4]; f32x4 lo[4]; };     // hi: s x1 w1; lo: 2^11 s (x1 w2 + x2 w1)
+
+__device__ __forceinline__ unsigned pk_h2(float a, float b) {
+  const f16x2 v = {(_Float16)a, (_Float16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+// 8 consecutive k of one row -> the lane's operand fragments of the two planes
+__device__ __forceinline__ void split_h(const float4& a, const float4& b, float4& p1, float4& p2) {
+  const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  unsigned q1[4], q2[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float t0 = x[2 * i] * H_ACT_SCALE, t1 = x[2 * i + 1] * H_ACT_SCALE;
+    q1[i] = pk_h2(t0, t1);
+    const f16x2 h = __builtin_bit_cast(f16x2, q1[i]);
+    q2[i] = pk_h2((t0 - (float)h[0]) * H_LO_SCALE, (t1 - (float)h[1]) * H_LO_SCALE);
+  }
+  p1 = make_float4(__uint_as_float(q1[0]), __uint_as_float(q1[1]), __uint_as_float(q1[2]), __uint_as_float(q1[3]));
+  p2 = make_float4(__uint_as_float(q2[0]), __uint_as_float(q2[1]), __uint_as_float(q2[2]), __uint_as_float(q2[3]));
+}
+
+// One HALF item (64 columns x 32 k): 8 fragments of 1 KiB -- (sub-tile j, plane p) at wb.b[2 j + p] --, 12 MFMAs;
+// fragments refilled in place from the next half item right behind their MFMAs (as ItemSteps16).
+// TWO register buffers of one half item each (b[0..7], b[8..15]): while half item i issues its MFMAs from one, the
+// fragments of half item i + 1 are loaded into the other -- group by group behind the MFMAs of the same group, so
+// that a register is overwritten a whole half item (12 MFMAs of this wave) after its last read.
+// Round 3's f32 loop refills a fragment IN PLACE, right behind its MFMAs ("the matrix pipe reads its operands at
+// issue": true for v_mfma_f32_16x16x4_f32, which runs on the vector pipe).  With the matrix-core MFMAs that is NOT
+// safe at two workgroups per CU: the first build of this loop (in place) returned wrong sub-tiles in a few row tiles
+// of every launch, differently from run to run -- only with two workgroups per CU (an 84 KB LDS request that keeps
+// them apart: exact), never with this second buffer, never with the stream drained once per half item; refilling
+// one group late (3 MFMAs between read and overwrite) was not enough (tools/r4_diag2.py, profiles/r4_f16x2_hazard.txt).
+// Reading of it: with the SIMD's matrix core shared by two waves an issued MFMA can wait its turn while the wave
+// goes on to issue the load, and the hardware orders VMEM returns only against the issuing wave's vmcnt, not against
+// operand reads still to come.
+template <int J, int BUF>
+struct ItemSteps16H {
+  static __device__ __forceinline__ void run(Acc16H& acc, WBuf& wb, const float4& x1, const float4& x2, const float* np,
+                                             unsigned lo) {
+    constexpr int C0 = 8 * BUF + 2 * J, N0 = 8 * (1 - BUF) + 2 * J;
+    acc.lo[J] = MFMA16H(wb.b[C0 + 1], x1, acc.lo[J]);
+    acc.lo[J] = MFMA16H(wb.b[C0], x2, acc.lo[J]);
+    acc.hi[J] = MFMA16H(wb.b[C0], x1, acc.hi[J]);
+    __builtin_amdgcn_sched_barrier(0);
+    wb.b[N0] = ld4(np + (size_t)(lo + (2 * J) * 256u));
+    wb.b[N0 + 1] = ld4(np + (size_t)(lo + (2 * J + 1) * 256u));
+    __builtin_amdgcn_sched_barrier(0);
+    ItemSteps16H<J + 1, BUF>::run(acc, wb, x1, x2, np, lo);
+  }
+};
+template <int BUF>
+struct ItemSteps16H<4, BUF> {
+  static __device__ __forceinline__ void run(Acc16H&, WBuf&, const float4&, const float4&, const float*, unsigned) {}
+};
+
+// linear_step16 on the PH copy of the weights: same contract (w0 may arrive preloaded with the step's first HALF item
+// in b[0..7], the last half item fetches `next_first`), same accumulator layout, same epilogue.  A step has an even
+// number of half items (K is padded to 64), so every step starts and ends on buffer 0.
+template <bool DROP, typename SpecFn>
+__device__ __forceinline__ bool linear_step16h(const LinSpec& s, WBuf& w0, bool preloaded, const float* next_first,
+                                               SpecFn make_spec, int step_idx) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) - s.woff) & (CH_NW - 1);
+  const int ntiles = (s.N + 63) >> 6;
+  const int kpad = (s.K + 63) & ~63;
+  const int nhalf = kpad / 32;
+  const int my_tiles = wave < ntiles ? (ntiles - wave + CH_NW - 1) / CH_NW : 0;
+  const int nitems = my_tiles * nhalf;
+  // lane 16g + c reads row c, the 8 consecutive k of group g in every 32-wide half item
+  const float* arow = s.src + (lane & 15) * s.src_ld + 8 * (lane >> 4);
+  const float* wbase = s.W + (size_t)wave * 64 * kpad;       // wave-uniform; the lane adds lo
+  const unsigned lo = 4u * lane;
+  const size_t tile_stride = (size_t)CH_NW * 64 * kpad;
+  Acc16H acc;
+  float bvl = 0.f;
+  SUB_STAMP(1);
+  if (CHAIN_DBG(s.dbg) & 32) return false;
+  if (!preloaded) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w0.b[i] = ld4(wbase + (size_t)(lo + i * 256u));
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  SUB_STAMP(2);
+  __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): see linear_step16
+  int tt = 0, kh = 0;
+  const float* wcur = wbase;
+#pragma unroll 1
+  for (int it = 0; it < nitems; it += 2) {
+    // ---- even half item: buffer 0 -> MFMAs, buffer 1 <- the next (odd) half item of the same tile
+    {
+      if (kh == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc.hi[j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc.lo[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        const float* bsrc = s.bias != nullptr ? s.bias : s.W;
+        bvl = ldg1(bsrc + min((wave + tt * CH_NW) * 64 + lane, s.N - 1));
+      }
+      float4 x1, x2;
+      split_h(*reinterpret_cast<const float4*>(arow + kh * 32), *reinterpret_cast<const float4*>(arow + kh * 32 + 4), x1, x2);
+      ItemSteps16H<0, 0>::run(acc, w0, x1, x2, wcur + 8 * 256, lo);
+      wcur += 8 * 256; ++kh;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- odd half item: buffer 1 -> MFMAs, buffer 0 <- the half item after it (next tile, or the wave's next step; at
+    // the end of a run of steps a dead re-read of this step's first half item: a load behind a branch would make
+    // hipcc drain the stream at the join)
+    {
+      const float* np = wcur;
+      int nt = tt, nk = kh;
+      if (++nk == nhalf) { nk = 0; ++nt; np = wbase + (size_t)nt * tile_stride; }
+      else np += 8 * 256;
+      const bool last = it + 2 >= nitems;
+      const float* nload = last ? (next_first != nullptr ? next_first : wbase) : np;
+      float4 x1, x2;
+      split_h(*reinterpret_cast<const float4*>(arow + kh * 32), *reinterpret_cast<const float4*>(arow + kh * 32 + 4), x1, x2);
+      ItemSteps16H<0, 1>::run(acc, w0, x1, x2, nload, lo);
+      if (kh == nhalf - 1) {
+        int tile = wave + tt * CH_NW;
+        int sidx = step_idx;
+        asm volatile("" : "+s"(tile), "+s"(sidx));         // see linear_step: the epilogue rebuilds its view
+        if (!(CHAIN_DBG(s.dbg) & 1)) {
+          Acc16 y;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              y.v[j][i] = fmaf(acc.lo[j][i], 1.0f / (H_LO_SCALE * H_ACT_SCALE), acc.hi[j][i] * (1.0f / H_ACT_SCALE));
+          const LinSpec e = make_spec(sidx);
+          lin_epilogue16<DROP>(e, tile, y, lane, bvl);
+        }
+      }
+      wcur = np; tt = nt; kh = nk;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  return next_first != nullptr;
+}
+
 // y[R, N] = epilogue(src[R, K] W^T): called by all CH_NT threads, no internal barrier.
 //
 // A wave's work items (its column tiles x 64-deep k blocks) alternate between two
@@ -837,10 +996,12 @@ __device__ __forceinline__ bool linear_step16(const LinSpec& s, WBuf& w0, bool p
 // SRC2: the A operand is src + src2 (the prologue's x + query_pos only: a run-time test of the pointer
 // put branches between the operand reads of every item, and hipcc waits vmcnt(0) at their joins, i.e.
 // for the item's whole weight fetch)
-template <int R, bool DROP, bool SRC2, typename SpecFn>
+template <int R, bool DROP, bool SRC2, int MM, typename SpecFn>
 __device__ __forceinline__ bool linear_step(const LinSpec& s, WBuf& w0, bool preloaded,
                                             const float* next_first, SpecFn make_spec, int step_idx) {
-  // 16-row tiles: ONE weight buffer refilled in place, 16x16x4 MFMAs (linear_step16)
+  // 16-row tiles: ONE weight buffer refilled in place, 16x16x4 f32 MFMAs (linear_step16) or the two-plane f16
+  // form on the matrix cores (linear_step16h, MM = 1)
+  if constexpr (R == 16 && MM == 1) return linear_step16h<DROP>(s, w0, preloaded, next_first, make_spec, step_idx);
   if constexpr (R == 16) return linear_step16<DROP, SRC2>(s, w0, preloaded, next_first, make_spec, step_idx);
   constexpr int NG = R / 4;
   const int lane = threadIdx.x & 63;
@@ -1007,8 +1168,9 @@ __device__ long long g_wg_span[1024][2];
 // uses.  (One code image for all four programs made the R = 4 kernel spill 9 dwords to a
 // private segment under the combined pressure of the camera-sampling and radar-attention
 // bodies; the specialised kernels are smaller and were 3.5 % faster per frame.)
-template <int R, int PROG, bool DROP = false>
+template <int R, int PROG, bool DROP = false, int MM = 0>
 __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __restrict__ recs, const int block) {
+  static_assert(MM == 0 || (R == 16 && PROG != PROG_PROLOGUE), "the f16 two-plane path exists for 16-row tiles");
   extern __shared__ __align__(16) unsigned char smem_raw[];
   using Lds = ChainLds<R, rec_cap(PROG)>;
   Lds& S = *reinterpret_cast<Lds*>(smem_raw);
@@ -1261,7 +1423,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
 #endif
           if (((wave - s.woff) & (CH_NW - 1)) < ((s.N + 63) >> 6)) {   // else: no column tile here, w0 keeps waiting
             const PreRec pr = load_uniform<PreRec>(S.recs[idx].p[wave]);
-            const bool have = linear_step<R, DROP, PROG == PROG_PROLOGUE>(s, w0, pre_idx == idx, pr.first, epi_spec, idx);
+            const bool have = linear_step<R, DROP, PROG == PROG_PROLOGUE, MM>(s, w0, pre_idx == idx, pr.first, epi_spec, idx);
             pre_idx = have ? pr.nidx : -1;
           }
         } else if (kd == K_LN) {
@@ -1725,21 +1887,21 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
   WG_STAMP(1);
 }
 
-template <int R, int PROG, bool DROP = false>
+template <int R, int PROG, bool DROP = false, int MM = 0>
 __global__ __launch_bounds__(CH_NT, 2) void chain_kernel(ChainDev k, Recs<rec_cap(PROG)> recs) {
-  chain_body<R, PROG, DROP>(k, recs.s, blockIdx.x);
+  chain_body<R, PROG, DROP, MM>(k, recs.s, blockIdx.x);
 }
 
 // Two programs in one launch: workgroups [0, na) run the decoder layer `ka` on RA-row
 // tiles, the rest the radar encoders `kb` on RB-row tiles.  Decoder layer 0 carries the
 // encoders this way: as a branch of the hipGraph on a side stream, the fork and the join
 // each left a ~10 us hole in the replayed frame (profiles: rocprofv3 kernel trace).
-template <int RA, int RB, int PROGB>
+template <int RA, int RB, int PROGB, int MM = 0>
 __global__ __launch_bounds__(CH_NT, 2) void chain_dual_kernel(ChainDev ka, ChainDev kb, int na,
                                                            Recs<rec_cap(PROG_DECODER)> ra,
                                                            Recs<rec_cap(PROGB)> rb) {
-  if ((int)blockIdx.x < na) chain_body<RA, PROG_DECODER>(ka, ra.s, blockIdx.x);
-  else chain_body<RB, PROGB>(kb, rb.s, (int)blockIdx.x - na);
+  if ((int)blockIdx.x < na) chain_body<RA, PROG_DECODER, false, MM>(ka, ra.s, blockIdx.x);
+  else chain_body<RB, PROGB, false, MM>(kb, rb.s, (int)blockIdx.x - na);
 }
 
 // ---- host side: the step table of a program -> resolved records --------------------------
@@ -1761,7 +1923,7 @@ template <int R, int PROG>
 constexpr size_t chain_lds_bytes() { return sizeof(ChainLds<R, rec_cap(PROG)>); }
 inline int buf_ld_h(int id) { return id == B_A ? LD5 : id == B_L ? LDL : LD2; }
 
-template <int R, int PROG>
+template <int R, int PROG, int MM = 0>
 void resolve_program(ChainK& k, StepAll* out) {
   const StepDesc* table = prog_table(PROG);
   constexpr int nsteps = table_steps(PROG);
@@ -1827,7 +1989,7 @@ void resolve_program(ChainK& k, StepAll* out) {
       r.N = d.N == N_LOGITS ? k.nlogits : d.N == N_CODE ? k.code : d.N == N_CLS ? k.ncls : d.N;
       const int woff = (d.flags & F_WOFF) ? 512 : 0;
       r.p0 = pr.w + (size_t)woff * ((r.K + 63) & ~63);   // packed: a 64-row tile = 64 * kpad floats
-      if (R == 16) r.p0 += k.w16_delta;                   // the 16x16x4 copy (pack.hip); launch_r checks delta != 0
+      if (R == 16) r.p0 += (MM == 1 ? 2 : 1) * k.w16_delta;   // the 16x16x4 copy / the two-plane f16 copy behind it (pack.hip); launch_r checks delta != 0
       r.p1 = pr.b ? pr.b + woff : nullptr;
       if (PROG == PROG_RADAR_BWD) r.p1 = nullptr;         // dx = dy W: no bias
       if (d.gsel == G_CLS) r.gd += (size_t)rep * k.M * k.ncls;
@@ -1890,12 +2052,12 @@ void resolve_program(ChainK& k, StepAll* out) {
   k.early_n = early;
 }
 
-template <int RA, int RB, int PROGB>
+template <int RA, int RB, int PROGB, int MM = 0>
 int launch_dual_r(const ChainK& ka_, const ChainK& kb_, hipStream_t s, const char* what) {
   constexpr size_t lds = chain_lds_bytes<RA, PROG_DECODER>() > chain_lds_bytes<RB, PROGB>() ? chain_lds_bytes<RA, PROG_DECODER>() : chain_lds_bytes<RB, PROGB>();
   static DeviceOnce once;
   if (const int once_dev = once.need(); once_dev >= 0) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_dual_kernel<RA, RB, PROGB>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_dual_kernel<RA, RB, PROGB, MM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("chain: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     once.done(once_dev);
@@ -1905,19 +2067,19 @@ int launch_dual_r(const ChainK& ka_, const ChainK& kb_, hipStream_t s, const cha
              "%s: 16-row tiles need weights from a tc_head_pack_weights view (packed16_delta is 0)", what);
   Recs<rec_cap(PROG_DECODER)> ra;
   Recs<rec_cap(PROGB)> rb;
-  resolve_program<RA, PROG_DECODER>(ka, ra.s);
-  resolve_program<RB, PROGB>(kb, rb.s);
+  resolve_program<RA, PROG_DECODER, MM>(ka, ra.s);
+  resolve_program<RB, PROGB, MM>(kb, rb.s);
   const int na = (ka.M + RA - 1) / RA, nb = (kb.M + RB - 1) / RB;
-  hipLaunchKernelGGL((chain_dual_kernel<RA, RB, PROGB>), dim3(na + nb), dim3(CH_NT), lds, s,
+  hipLaunchKernelGGL((chain_dual_kernel<RA, RB, PROGB, MM>), dim3(na + nb), dim3(CH_NT), lds, s,
                      static_cast<const ChainDev&>(ka), static_cast<const ChainDev&>(kb), na, ra, rb);
   return check_launch(what);
 }
 
-template <int R, int PROG, bool DROP = false>
+template <int R, int PROG, bool DROP = false, int MM = 0>
 int launch_r(const ChainK& k_, hipStream_t s, const char* what) {
   static DeviceOnce once;
   if (const int once_dev = once.need(); once_dev >= 0) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<R, PROG, DROP>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<R, PROG, DROP, MM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)chain_lds_bytes<R, PROG>());
     if (e != hipSuccess) { set_error("chain: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
@@ -1927,9 +2089,9 @@ int launch_r(const ChainK& k_, hipStream_t s, const char* what) {
   TC_REQUIRE(R != 16 || k.w16_delta != 0,
              "%s: 16-row tiles need weights from a tc_head_pack_weights view (packed16_delta is 0)", what);
   Recs<rec_cap(PROG)> recs;
-  resolve_program<R, PROG>(k, recs.s);
+  resolve_program<R, PROG, MM>(k, recs.s);
   constexpr size_t lds = chain_lds_bytes<R, PROG>();
-  hipLaunchKernelGGL((chain_kernel<R, PROG, DROP>), dim3((k.M + R - 1) / R), dim3(CH_NT), lds, s,
+  hipLaunchKernelGGL((chain_kernel<R, PROG, DROP, MM>), dim3((k.M + R - 1) / R), dim3(CH_NT), lds, s,
                      static_cast<const ChainDev&>(k), recs);
   return check_launch(what);
 }
@@ -1951,11 +2113,18 @@ void init_k(ChainK& k) {
 // tc_decoder_layer_tail_fwd): no process-global state.
 int tile_rows(const ChainK& k) { return k.tile_rows ? k.tile_rows : (k.M <= 1024 ? 4 : k.M <= 2048 ? 8 : 16); }
 
+// The matrix path of the 16-row tiles (tc_head_options.matrix_path): automatic = the two-plane f16 form on the
+// matrix cores (measured: DESIGN.md section 5 "Round 4"); TC_MATRIX_F32 keeps the exact fp32 FMA chains of
+// v_mfma_f32_16x16x4_f32.  4- and 8-row tiles always compute in fp32 (their item loops are bound by the weight
+// stream, and both copies are 4 bytes per weight).
+bool use_f16x2(const ChainK& k) { return k.matrix_path != TC_MATRIX_F32; }
+
 template <int PROG>
 int launch_rows(const ChainK& k, hipStream_t s, const char* what) {
   const int rows = tile_rows(k);
   if (rows == 4) return launch_r<4, PROG>(k, s, what);
   if (rows == 8) return launch_r<8, PROG>(k, s, what);
+  if (use_f16x2(k)) return launch_r<16, PROG, false, 1>(k, s, what);
   return launch_r<16, PROG>(k, s, what);
 }
 
@@ -1984,7 +2153,7 @@ int launch(const ChainK& k, hipStream_t s, const char* what) {
     // encoders take the fewest workgroups (16-row tiles): 225 + 64 workgroups of 4-row tiles
     // did not fit 256 CUs next to a decoder layer
     case PROG_PROLOGUE: return launch_r<4, PROG_PROLOGUE>(k, s, what);
-    default: return launch_r<16, PROG_RADAR_ENC>(k, s, what);
+    default: return use_f16x2(k) ? launch_r<16, PROG_RADAR_ENC, false, 1>(k, s, what) : launch_r<16, PROG_RADAR_ENC>(k, s, what);
   }
 }
 
@@ -2054,6 +2223,7 @@ static int make_decoder_k(const DecoderChainArgs& a, ChainK& k) {
   TC_REQUIRE(a.tile_rows == 0 || a.tile_rows == 4 || a.tile_rows == 8 || a.tile_rows == 16,
              "decoder_chain: tile_rows=%d (0 = automatic, 4, 8 or 16)", a.tile_rows);
   k.tile_rows = a.tile_rows;
+  k.matrix_path = a.matrix_path;
   k.drop = a.drop;
   return 0;
 }
@@ -2076,7 +2246,7 @@ static int make_radar_enc_k(const RadarEncodeArgs& a, ChainK& k, int part = 0) {
     for (int i = 0; i < T_COUNT; ++i) k.tape[i] = a.tape[i];
   }
   k.M = a.M; k.Q = 1; k.RI = a.RI; k.tokens = a.tokens; k.has_next = 1;
-  k.w16_delta = a.w16_delta;
+  k.w16_delta = a.w16_delta; k.matrix_path = a.matrix_path;
   TC_REQUIRE(part == 0 || a.radar_feat != nullptr, "radar_encode: split programs need the radar_feat buffer");
   k.g[G_RFEAT] = a.radar_feat; k.g_ld[G_RFEAT] = 256;
   k.pairs[0] = a.rpe.l0; k.pairs[1] = tc_linear{a.rpe.n1.g, a.rpe.n1.b}; k.pairs[2] = a.rpe.l3;
@@ -2107,16 +2277,17 @@ int launch_decoder_chain_with_encoders(const DecoderChainArgs& d, const RadarEnc
   TC_REQUIRE(kd.drop.thr == 0, "decoder dropout: launch the encoders on their own (launch_radar_encode)");
   const int rows = tile_rows(kd);
   const char* what = "chain(decoder + radar_encode)";
-#define TC_DUAL(RA, RB)                                                               \
-  (part == 1 ? launch_dual_r<RA, RB, PROG_RADAR_ENC_A>(kd, ke, s, what)               \
-   : part == 2 ? launch_dual_r<RA, RB, PROG_RADAR_ENC_B>(kd, ke, s, what)             \
-               : launch_dual_r<RA, RB, PROG_RADAR_ENC>(kd, ke, s, what))
+#define TC_DUAL(RA, RB, MM)                                                           \
+  (part == 1 ? launch_dual_r<RA, RB, PROG_RADAR_ENC_A, MM>(kd, ke, s, what)           \
+   : part == 2 ? launch_dual_r<RA, RB, PROG_RADAR_ENC_B, MM>(kd, ke, s, what)         \
+               : launch_dual_r<RA, RB, PROG_RADAR_ENC, MM>(kd, ke, s, what))
   // 4-row decoder tiles run two workgroups per CU (256 VGPRs): the encoder rows then use 4-row
   // tiles too -- a 16-row body in the same kernel would spill ~100 registers at that budget,
   // and 225 + T/4 workgroups fit the chip at two per CU
-  if (rows == 4) return TC_DUAL(4, 4);
-  if (rows == 8) return TC_DUAL(8, 8);
-  return TC_DUAL(16, 16);
+  if (rows == 4) return TC_DUAL(4, 4, 0);
+  if (rows == 8) return TC_DUAL(8, 8, 0);
+  if (use_f16x2(kd)) return TC_DUAL(16, 16, 1);
+  return TC_DUAL(16, 16, 0);
 #undef TC_DUAL
 }
 
@@ -2151,7 +2322,7 @@ int launch_radar_chain(const RadarChainArgs& a, hipStream_t s) {
   k.all_box = a.all_box; k.hits = a.hits;
   TC_REQUIRE(a.tile_rows == 0 || a.tile_rows == 4 || a.tile_rows == 8 || a.tile_rows == 16,
              "radar_chain: tile_rows=%d (0 = automatic, 4, 8 or 16)", a.tile_rows);
-  k.tile_rows = a.tile_rows; k.last_cls_only = a.last_cls_only;
+  k.tile_rows = a.tile_rows; k.last_cls_only = a.last_cls_only; k.matrix_path = a.matrix_path;
   if (a.tape != nullptr) {                    // forward of a training iteration: tape + dropout
     TC_REQUIRE(a.row_perm == nullptr && !a.last_cls_only, "radar_chain: the training forward takes the rows in their own order");
     k.program = PROG_RADAR_TRAIN;

@@ -198,7 +198,7 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
       re.kv[r] = h.kv3[r];
     }
     re.radar_feat = h.radar_feat;
-    re.w16_delta = w->packed16_delta;
+    re.w16_delta = w->packed16_delta; re.matrix_path = opt.matrix_path;
   }
 
   // train-mode statistics of the frozen decoder: five dropout sites per layer (sites 16 + 8 l + 0..4)
@@ -239,7 +239,7 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
     for (int i = 0; i < 6; ++i) d.cam.pc[i] = w->pc_range[i];
     d.cam.img_h = img_h; d.cam.img_w = img_w; d.cam.out = nullptr; d.cam.vis = nullptr;
     d.cam.pair_counter = pairs;
-    d.code = code; d.M = rows; d.tile_rows = opt.chain_tile_rows;
+    d.code = code; d.M = rows; d.tile_rows = opt.chain_tile_rows; d.matrix_path = opt.matrix_path;
     // the radar encoders ride in two launches, half each (all in layer 0 when there is only one layer)
     if (radar && !ddrop && lid == enc_first) TC_TRY(launch_decoder_chain_with_encoders(d, re, L > 1 ? 1 : 0, s));
     else if (radar && !ddrop && L > 1 && lid == enc_first + 1) TC_TRY(launch_decoder_chain_with_encoders(d, re, 2, s));
@@ -267,7 +267,7 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
   rc.ncls = ncls; rc.M = rows; rc.qscale = 1.0f / sqrtf((float)(C / H));
   for (int i = 0; i < 6; ++i) rc.pc[i] = w->pc_range[i];
   rc.all_cls = all_cls_scores; rc.all_box = all_bbox_preds; rc.hits = h.hits;
-  rc.tile_rows = opt.chain_tile_rows; rc.last_cls_only = opt.last_level_cls_only;
+  rc.tile_rows = opt.chain_tile_rows; rc.last_cls_only = opt.last_level_cls_only; rc.matrix_path = opt.matrix_path;
   if (opt.radar_row_order == 2 || (opt.radar_row_order == 0 && rows > 1024)) {
     // queries with a radar return inside their first gate go first: the other tiles skip the gated part
     TC_TRY(launch_radar_compact(rc.ref_last, rc.box_m, code, 0, w->pc_range, radar_tokens, w->radar_in_dims, B, Q, T,
@@ -474,7 +474,8 @@ int tc_decoder_layer_tail_fwd(const tc_decoder_layer* layer, const tc_linear* ne
   for (int i = 0; i < 6; ++i) d.cam.pc[i] = pc_range[i];
   d.cam.img_h = img_h; d.cam.img_w = img_w; d.cam.out = nullptr; d.cam.vis = nullptr;
   d.cam.pair_counter = nullptr;
-  d.code = code_size; d.M = B * Q; d.tile_rows = tile_rows;
+  d.code = code_size; d.M = B * Q; d.tile_rows = TC_TILE_ROWS(tile_rows); d.matrix_path = TC_TILE_MATRIX(tile_rows);
+  TC_REQUIRE(d.matrix_path <= TC_MATRIX_F16X2 && (tile_rows >> 10) == 0, "decoder_layer_tail: tile_rows=0x%x", tile_rows);
   return launch_decoder_chain(d, as_stream(stream));
 }
 
@@ -533,6 +534,8 @@ static int read_options(const tc_head_options* options, tc_head_options& opt) {
   TC_REQUIRE(opt.phase >= 0 && opt.phase <= 2, "options.phase=%d (0 whole forward, 1 before the radar tokens, 2 the rest)",
              opt.phase);
   TC_REQUIRE(opt.phase == 0 || !opt.unfused, "options.phase=%d needs the fused path", opt.phase);
+  TC_REQUIRE(opt.matrix_path >= TC_MATRIX_AUTO && opt.matrix_path <= TC_MATRIX_F16X2,
+             "options.matrix_path=%d (0 automatic, 1 fp32 MFMA, 2 two-plane f16 MFMA)", opt.matrix_path);
   return 0;
 }
 
@@ -569,7 +572,7 @@ int tc_radar_fusion_fwd(const tc_head_weights* packed_view, const float* hs_last
     re.kv[r] = h.kv3[r];
   }
   re.radar_feat = h.radar_feat;
-  re.w16_delta = w->packed16_delta;
+  re.w16_delta = w->packed16_delta; re.matrix_path = opt.matrix_path;
   if (!opt.reuse_radar_kv) TC_TRY(launch_radar_encode(re, s));
   RadarChainArgs rc;
   rc.qf = hs_last; rc.ref_last = ref_last; rc.box_m = prev_box; rc.tokens = radar_tokens;
@@ -580,7 +583,7 @@ int tc_radar_fusion_fwd(const tc_head_weights* packed_view, const float* hs_last
   for (int i = 0; i < 6; ++i) rc.pc[i] = w->pc_range[i];
   rc.all_cls = all_cls_scores + (size_t)first_layer * rows * ncls;
   rc.all_box = all_bbox_preds + (size_t)first_layer * rows * code;
-  rc.hits = h.hits; rc.tile_rows = opt.chain_tile_rows; rc.last_cls_only = opt.last_level_cls_only;
+  rc.hits = h.hits; rc.tile_rows = opt.chain_tile_rows; rc.last_cls_only = opt.last_level_cls_only; rc.matrix_path = opt.matrix_path;
   rc.cen_from_box = first_layer > 0;
   if (opt.radar_row_order == 2 || (opt.radar_row_order == 0 && rows > 1024)) {
     TC_TRY(launch_radar_compact(ref_last, prev_box, code, rc.cen_from_box, w->pc_range, radar_tokens, w->radar_in_dims,
@@ -620,7 +623,7 @@ size_t tc_head_packed_bytes(const tc_head_weights* w) {
   const int n = collect_pack_items(w, &view, items);
   size_t total = 0;
   for (int i = 0; i < n; ++i)
-    if (!items[i].narrow) total += 2 * arena_slice(packed_floats(items[i].N, items[i].K), 4);   // + the 16x16x4 copies
+    if (!items[i].narrow) total += 3 * arena_slice(packed_floats(items[i].N, items[i].K), 4);   // + the 16x16x4 and the two-plane f16 copies
   // layer-0 constants + the scratch they are computed from (see tc_head_pack_weights)
   const size_t Q = w->num_query, C = w->embed_dims, qpad = ((Q + 15) / 16) * 16;
   total += arena_slice(Q * 3, 4) + arena_slice(Q * C, 4) + arena_slice(Q * 2 * C, 4) + arena_slice(C * qpad, 4);
@@ -638,7 +641,8 @@ int tc_head_pack_weights(const tc_head_weights* w, void* packed, size_t packed_b
   Arena a(packed, packed_bytes);
   // region A: every weight in the 4x4x1 layout; region B: the same weights, same order and slice
   // sizes, in the 16x16x4 layout -- one distance (packed16_delta floats) from any address of a
-  // weight (or of a row block of it) to its counterpart
+  // weight (or of a row block of it) to its counterpart; region C: the two-plane f16 copy (4 bytes per weight
+  // too), 2 * packed16_delta from region A
   size_t region_a = 0;
   for (int i = 0; i < n; ++i)
     if (!items[i].narrow) region_a += arena_slice(packed_floats(items[i].N, items[i].K), 4);
@@ -647,11 +651,12 @@ int tc_head_pack_weights(const tc_head_weights* w, void* packed, size_t packed_b
     TC_REQUIRE(items[i].src != nullptr, "pack_weights: weight %d is null", i);
     if (items[i].narrow) continue;                     // the view keeps the nn.Linear pointer
     float* dst = a.take<float>(packed_floats(items[i].N, items[i].K));
-    TC_TRY(launch_pack_linear(items[i].src, items[i].N, items[i].K, dst, dst + delta, as_stream(stream)));
+    TC_TRY(launch_pack_linear(items[i].src, items[i].N, items[i].K, dst, dst + delta, dst + 2 * delta, as_stream(stream)));
     *items[i].slot = dst;
   }
-  for (int i = 0; i < n; ++i)
-    if (!items[i].narrow) a.take<float>(packed_floats(items[i].N, items[i].K));     // region B
+  for (int rgn = 0; rgn < 2; ++rgn)
+    for (int i = 0; i < n; ++i)
+      if (!items[i].narrow) a.take<float>(packed_floats(items[i].N, items[i].K));     // regions B, C
   packed_view->packed16_delta = delta;
   for (int l = 0; l < TC_MAX_LAYERS; ++l) packed_view->layers[l].packed16_delta = delta;
   for (int l = 0; l < TC_MAX_RADAR_LAYERS; ++l) packed_view->radar[l].packed16_delta = delta;
@@ -700,8 +705,9 @@ int tc_head_repack_trainable_ex(const tc_head_weights* w, tc_head_weights* packe
     if (items[i].narrow) continue;                     // read in place by the chains
     // scratch is a copy of the packed view: its slot still holds the packed destination
     float* dst = const_cast<float*>(*items[i].slot);
-    jobs[nj++] = PackJob{items[i].src, dst, copies == 3 ? dst + packed_view->packed16_delta : nullptr,
-                         items[i].N, items[i].K};
+    jobs[nj] = PackJob{items[i].src, dst, copies == 3 ? dst + packed_view->packed16_delta : nullptr,
+                       items[i].N, items[i].K};
+    jobs[nj++].PH = copies == 3 ? dst + 2 * packed_view->packed16_delta : nullptr;
   }
   if (nj == 0) return 0;
   return launch_pack_group(jobs, nj, as_stream(stream));

@@ -97,6 +97,7 @@ struct DecoderChainArgs {
   CamSampleArgs cam;                         // feats, lidar2img, pc, img size (ref/logits/out unused)
   int code, M;
   int tile_rows = 0;                         // 0: automatic (4 up to 1024 rows, 8 up to 2048, 16 beyond), 4, 8, 16
+  int matrix_path = 0;                       // 16-row tiles: TC_MATRIX_AUTO / _F32 / _F16X2 (tc_head_options.matrix_path)
   // train-mode statistics of the frozen decoder (thr 0 = eval): drop.site is the site of THIS
   // layer's attention probabilities (16 + 8 * layer); the chain's four sites are drop.site + 1
   // (self-attention output), + 2 (cross-attention output, XFMR:378), + 3 (FFN hidden), + 4 (FFN output)
@@ -111,6 +112,7 @@ struct RadarEncodeArgs {
   float* radar_feat;                         // optional [M,256]
   size_t w16_delta = 0;
   float* const* tape = nullptr;              // training forward: tape tensors by TapeSlot (chain.hip TSel order)
+  int matrix_path = 0;                       // as DecoderChainArgs (the stand-alone encoder program runs 16-row tiles)
 };
 int launch_radar_encode(const RadarEncodeArgs& a, hipStream_t s);
 // a decoder layer and the radar encoders as ONE launch (no side stream / graph branch)
@@ -126,6 +128,7 @@ struct RadarChainArgs {
   float qscale; float pc[6];
   float* all_cls; float* all_box; int* hits;
   int tile_rows = 0;
+  int matrix_path = 0;                       // as DecoderChainArgs
   int last_cls_only = 0;                     // skip final_cls of all but the last layer (inference opt-in)
   int cen_from_box = 0;                      // w[0] is not fusion layer 1: gate centre from box_m (HEAD:615-617)
   const int* row_perm = nullptr;             // optional [M]: tile position -> row (launch_radar_compact)
@@ -219,10 +222,11 @@ int launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float l
 // ---- pack.hip: one-time weight re-layout for the fused chains ---------------
 size_t packed_floats(int N, int K);
 // P16 (may be null): the copy for the 16-row tiles' 16x16x4 MFMA (pack.hip)
-int launch_pack_linear(const float* W, int N, int K, float* P, float* P16, hipStream_t s);
+// PH (may be null): the two-plane f16 copy for the 16-row tiles on the f16 matrix cores
+int launch_pack_linear(const float* W, int N, int K, float* P, float* P16, float* PH, hipStream_t s);
 // several weights in one launch (P16 of an item may be null: only the 4x4x1 copy)
 //   transpose: the matrix to pack is W^T -- element (n, k) = W[k * ldw + n] (the backward row chain: dx = dy W)
-struct PackJob { const float* W; float* P; float* P16; int N, K; int transpose = 0, ldw = 0; };
+struct PackJob { const float* W; float* P; float* P16; int N, K; int transpose = 0, ldw = 0; float* PH = nullptr; };
 int launch_pack_group(const PackJob* jobs, int n, hipStream_t s);
 
 // ---- transpose.hip ---------------------------------------------------------

@@ -17,13 +17,41 @@
 // (kg = 16-wide k group of the item, i = MFMA of the group, j = 16-column sub-tile): again 1 KiB
 // contiguous per wave-instruction, one float4 = the B operands of the four sub-tiles' MFMAs, and the
 // A operand of a k group is one ds_read_b128 per lane (row c... 4 consecutive k at 16 kg + 4g).
+//
+// Round 4: a third copy for the 16-row tiles on the f16 matrix cores (chain.hip linear_step16h).  Every weight
+// as TWO f16 planes, hi = f16(w) and lo = f16((w - hi) * 2^11) (round to nearest; the residual is exact in
+// fp32 and the scale keeps it a normal f16: |w - (hi + 2^-11 lo)| <= 2^-24 |w|), in the operand order of
+// v_mfma_f32_16x16x32_f16 -- lane 16g + c of a fragment holds 8 consecutive k of one output column:
+//     PH[t][k/64][kk][j][p][lane 16g + c][e] = plane p of W[64t + 16j + c][64 (k/64) + 32 kk + 8g + e]
+// (kk = 32-deep half of the item, j = 16-column sub-tile, p = hi / lo, e = 0..7): 16 fragments of 1 KiB per
+// item, the same 4 bytes per weight as the fp32 copies, the same tile / item offsets.
 #include "kernels.hpp"
 
 namespace tc {
 
+// 32-bit word `wq` (elements 2 wq, 2 wq + 1) of lane `lane` in fragment kq & 15 of item (t, kq >> 4)
+__device__ __forceinline__ unsigned pack_h_word(const float* __restrict__ W, int N, int K, int transpose, int ldw,
+                                                int t, int kq, int lane, int wq) {
+  const int f = kq & 15, kb = kq >> 4;
+  const int p = f & 1, j = (f >> 1) & 3, kk = f >> 3;
+  const int g = lane >> 4, c = lane & 15;
+  const int n = 64 * t + 16 * j + c;
+  const int k0 = 64 * kb + 32 * kk + 8 * g + 2 * wq;
+  unsigned short h[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int k = k0 + e;
+    const float x = (n < N && k < K) ? (transpose ? W[(size_t)k * ldw + n] : W[(size_t)n * K + k]) : 0.0f;
+    const _Float16 hi = (_Float16)x;
+    const _Float16 v = p == 0 ? hi : (_Float16)((x - (float)hi) * 2048.0f);
+    h[e] = __builtin_bit_cast(unsigned short, v);
+  }
+  return (unsigned)h[0] | ((unsigned)h[1] << 16);
+}
+
 __global__ __launch_bounds__(256) void pack_linear_kernel(const float* __restrict__ W, int N, int K,
                                                           float* __restrict__ P, float* __restrict__ P16,
-                                                          int ntile, int nkq) {
+                                                          float* __restrict__ PH, int ntile, int nkq) {
   const size_t total = (size_t)ntile * nkq * 256;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int j = i & 3;
@@ -39,13 +67,14 @@ __global__ __launch_bounds__(256) void pack_linear_kernel(const float* __restric
       const int k16 = 64 * (kq >> 4) + 16 * ((kq & 15) >> 2) + 4 * g + (kq & 3);
       P16[i] = (n16 < N && k16 < K) ? W[(size_t)n16 * K + k16] : 0.0f;
     }
+    if (PH != nullptr) reinterpret_cast<unsigned*>(PH)[i] = pack_h_word(W, N, K, 0, 0, t, kq, lane, j);
   }
 }
 
 // Several weights in ONE launch (the trainable part after an optimizer step: 28 matrices, one launch instead of
 // 28): the items travel in the kernel-argument segment, a block finds its item from the block offsets.
 constexpr int PACK_GROUP_MAX = 48;
-struct PackGroupItem { const float* W; float* P; float* P16; int N, K, ntile, nkq, first_block, transpose, ldw; };
+struct PackGroupItem { const float* W; float* P; float* P16; float* PH; int N, K, ntile, nkq, first_block, transpose, ldw; };
 struct PackGroupK { PackGroupItem it[PACK_GROUP_MAX]; int n; };
 constexpr int PACK_EPT = 8;               // elements per thread
 __global__ __launch_bounds__(256) void pack_group_kernel(PackGroupK g) {
@@ -73,6 +102,8 @@ __global__ __launch_bounds__(256) void pack_group_kernel(PackGroupK g) {
       const int k16 = 64 * (kq >> 4) + 16 * ((kq & 15) >> 2) + 4 * gq + (kq & 3);
       it.P16[idx] = (n16 < it.N && k16 < it.K) ? (it.transpose ? it.W[(size_t)k16 * it.ldw + n16] : it.W[(size_t)n16 * it.K + k16]) : 0.0f;
     }
+    if (it.PH != nullptr)
+      reinterpret_cast<unsigned*>(it.PH)[idx] = pack_h_word(it.W, it.N, it.K, it.transpose, it.ldw, t, kq, lane, j);
   }
 }
 
@@ -84,7 +115,7 @@ int launch_pack_group(const PackJob* jobs, int n, hipStream_t s) {
   for (int i = 0; i < n; ++i) {
     TC_REQUIRE(jobs[i].W != nullptr && jobs[i].P != nullptr && jobs[i].N > 0 && jobs[i].K > 0, "pack_group: bad item %d", i);
     PackGroupItem& it = g.it[i];
-    it.W = jobs[i].W; it.P = jobs[i].P; it.P16 = jobs[i].P16; it.N = jobs[i].N; it.K = jobs[i].K;
+    it.W = jobs[i].W; it.P = jobs[i].P; it.P16 = jobs[i].P16; it.PH = jobs[i].PH; it.N = jobs[i].N; it.K = jobs[i].K;
     it.transpose = jobs[i].transpose; it.ldw = jobs[i].ldw;
     it.ntile = (it.N + 63) / 64; it.nkq = ((it.K + 63) / 64) * 16;
     it.first_block = blocks;
@@ -99,12 +130,12 @@ size_t packed_floats(int N, int K) {
   return (size_t)((N + 63) / 64) * 64 * ((K + 63) / 64) * 64;
 }
 
-int launch_pack_linear(const float* W, int N, int K, float* P, float* P16, hipStream_t s) {
+int launch_pack_linear(const float* W, int N, int K, float* P, float* P16, float* PH, hipStream_t s) {
   TC_REQUIRE(W != nullptr && P != nullptr && N > 0 && K > 0, "pack_linear: bad arguments");
   const int ntile = (N + 63) / 64, nkq = ((K + 63) / 64) * 16;
   const size_t total = (size_t)ntile * nkq * 256;
   const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
-  hipLaunchKernelGGL(pack_linear_kernel, dim3(blocks), dim3(256), 0, s, W, N, K, P, P16, ntile, nkq);
+  hipLaunchKernelGGL(pack_linear_kernel, dim3(blocks), dim3(256), 0, s, W, N, K, P, P16, PH, ntile, nkq);
   return check_launch("pack_linear");
 }
 

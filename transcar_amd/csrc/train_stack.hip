@@ -257,7 +257,11 @@ int tc_radar_train_fwd_fused(const tc_head_weights* packed_view, const float* hs
   TS_TRY(check(w, B, T));
   TC_REQUIRE(w->l0_attn_out != nullptr, "radar_train_fwd_fused: packed_view was not produced by tc_head_pack_weights");
   TC_REQUIRE(dropout_p >= 0.0f && dropout_p < 1.0f, "radar_train_fwd_fused: dropout_p=%g", (double)dropout_p);
-  TC_REQUIRE(w->code_size <= 10 && T <= 512, "radar_train_fwd_fused: code_size=%d T=%d", w->code_size, T);
+  // (round 3 refused T > 512 here although the chains take any T <= 1500 -- beyond 512 tokens the gate's hit masks
+  // are not kept in LDS and the attention step re-evaluates the gate, as the inference chain does; a frame with more
+  // than 511 radar points then failed mid-training: ADVICE r3.  Covered at T = 576 and T = 1500 by
+  // tests/test_gpu_training.py::test_fused_training_with_many_radar_tokens.)
+  TC_REQUIRE(w->code_size <= 10, "radar_train_fwd_fused: code_size=%d", w->code_size);
   Tape t;
   TC_REQUIRE(tape_layout(w, B, T, tape, tape_bytes, &t) <= tape_bytes, "radar_train_fwd_fused: tape too small");
   hipStream_t s = as_stream(stream);
@@ -419,6 +423,7 @@ struct BwdWs {
   float* dy[DY_COUNT]; size_t dy_stride;
   float* dkv[TC_MAX_RADAR_LAYERS];
   float* dmem;
+  float* du0;                  // [rt, C]: gradient of the position encoder's first LayerNorm input
 };
 size_t bwd_ws_layout(const tc_head_weights* w, int B, int T, void* base, size_t cap, BwdWs* out) {
   const size_t rows = (size_t)B * w->num_query, rt = (size_t)B * T;
@@ -456,6 +461,7 @@ size_t bwd_ws_layout(const tc_head_weights* w, int B, int T, void* base, size_t 
   }
   for (int r = 0; r < TC_MAX_RADAR_LAYERS; ++r) b.dkv[r] = a.take<float>(rt * 2 * C);   // contiguous with dmem: one memset
   b.dmem = a.take<float>(rt * C);
+  b.du0 = a.take<float>(rt * C);     // its own slice: a tape scratch sized by the QUERY rows overran for T > 2 Q
   if (out) *out = b;
   return a.off;
 }
@@ -550,8 +556,7 @@ int tc_radar_train_bwd_fused(const tc_head_weights* w, const tc_head_weights* gr
   float* du2 = t.dkv + (size_t)rt * C;
   TS_TRY(ln_bwd(t.u2, nullptr, pe.n4, gpe.n4, ws.dmem, t.pos, du, rt, s));
   TS_TRY(launch_linear_bwd_data(du, nullptr, nullptr, pe.l3.w, nullptr, du2, rt, C, C, 1.0f, 0, s));
-  float* du0 = t.dqp;                // [rows, C] >= [rt, C]?  rows >= rt is not guaranteed: use dA when it is not
-  if ((size_t)rows < (size_t)rt) du0 = t.dh;
+  float* du0 = ws.du0;               // [rt, C]
   TS_TRY(ln_bwd(t.u0, nullptr, pe.n1, gpe.n1, du2, t.u1, du0, rt, s));
   // 5. every weight gradient: one grouped launch (two with the scalar variant for the 10-wide heads)
   WeightJob jobs[11 * TC_MAX_RADAR_LAYERS + 5];

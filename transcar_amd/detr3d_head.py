@@ -47,8 +47,11 @@ def _env_tile_rows():
 DEFAULT_TILE_ROWS = _env_tile_rows()
 
 
+MATRIX_PATHS = {None: L.TC_MATRIX_AUTO, 'auto': L.TC_MATRIX_AUTO, 'f32': L.TC_MATRIX_F32, 'f16x2': L.TC_MATRIX_F16X2}
+
+
 def head_options(tile_rows=None, unfused=None, last_level_cls_only=False,
-                 decoder_dropout_p=0.0, dropout_seed=0, radar_compact=None, phase=0):
+                 decoder_dropout_p=0.0, dropout_seed=0, radar_compact=None, phase=0, matrix_path=None):
     """tc_head_options for one forward.  unfused=None: the TRANSCAR_UNFUSED=1
     environment switch of the operator-by-operator cross-check path (a host-side
     knob: the library itself reads no environment)."""
@@ -62,6 +65,8 @@ def head_options(tile_rows=None, unfused=None, last_level_cls_only=False,
     o.radar_row_order = 0 if radar_compact is None else (2 if radar_compact else 1)
     o.dropout_seed = int(dropout_seed) & 0xFFFFFFFFFFFFFFFF
     o.phase = int(phase)          # 0: the whole forward; 1 / 2: before / after the radar tokens exist (forward_nhwc)
+    # 16-row tiles: 'f16x2' (= automatic) two-plane f16 operands on the matrix cores, 'f32' the exact fp32 MFMA
+    o.matrix_path = MATRIX_PATHS[matrix_path] if not isinstance(matrix_path, int) else int(matrix_path)
     return o
 
 

@@ -216,11 +216,12 @@ def sdpa(q, k, vt, num_heads=8):
 
 def decoder_layer_tail(packed_layer, packed_next_in_proj, feats_nhwc, attn_o, x_in,
                        query_embedding, lidar2img, ref_in, pc_range, img_hw, code_size=10,
-                       num_cams=6, tile_rows=0):
+                       num_cams=6, tile_rows=0, matrix_path=0):
     """One decoder layer after its attention core as the fused row chain
     (tc_decoder_layer_tail_fwd).  packed_*: members of the head's packed view
     (``head._packed_view.layers[l]``, ``.layers[l + 1].self_attn.in_proj`` or
-    None).  Returns (hs [B,Q,C], ref_out [B,Q,3], qk [B,Q,2C], vt [B,C,qpad])."""
+    None).  matrix_path: TC_MATRIX_* of 16-row tiles (tc_head_options.matrix_path).
+    Returns (hs [B,Q,C], ref_out [B,Q,3], qk [B,Q,2C], vt [B,C,qpad])."""
     for n, t in (('attn_o', attn_o), ('x_in', x_in), ('ref_in', ref_in), ('lidar2img', lidar2img)):
         _chk(t, n)
     B, Q, Cdim = x_in.shape
@@ -235,7 +236,7 @@ def decoder_layer_tail(packed_layer, packed_next_in_proj, feats_nhwc, attn_o, x_
         C.byref(packed_layer), C.byref(packed_next_in_proj) if packed_next_in_proj is not None else None,
         C.byref(fv), B, Q, num_cams, code_size, _p(attn_o), _p(x_in), _p(query_embedding),
         _p(lidar2img), _p(ref_in), L.f6(pc_range), float(img_hw[0]), float(img_hw[1]), _p(hs),
-        _p(ref_out), _p(qk), _p(vt), qpad, int(tile_rows), _stream()), 'tc_decoder_layer_tail_fwd')
+        _p(ref_out), _p(qk), _p(vt), qpad, int(tile_rows) | (int(matrix_path) << 8), _stream()), 'tc_decoder_layer_tail_fwd')
     return hs, ref_out, qk, vt
 
 

@@ -104,6 +104,7 @@ class FramePipeline:
         #: slots) replays a graph over its first n slots only, captured the first time that n occurs
         self._partial = {}
         self.last_flush = None
+        self._last = [None] * len(self.streams)        # per lane: (valid frame slots, outputs) of its last launch
         self._next = 0
         self._capture()
 
@@ -231,7 +232,16 @@ class FramePipeline:
         with torch.cuda.stream(s):
             graph.replay()
             self.done[i].record(s)
+        self._last[i] = (self.frames_per_launch if n is None else n, outputs)
         return i, outputs
+
+    def results(self, lane):
+        """(n, (outs, decoded)) of the lane's LAST launch, full or partial: the first n frame slots are valid (a
+        partial launch -- ``flush`` -- has output tensors of batch n of its own; ``outputs[lane]`` are the FULL
+        graph's tensors and keep the frames of the lane's last full launch).  Valid after ``wait(lane)``."""
+        if self._last[lane] is None:
+            raise TransCARHipError('lane %d has not been launched' % lane)
+        return self._last[lane]
 
     def submit(self, write=None):
         """Hand over ONE frame: it takes the next free slot (lane, slot) of the lane being filled;
@@ -330,7 +340,9 @@ class FramePipeline:
             return False
         T = int(self.inputs[lane]['tokens'].shape[1])
         from . import radar as R
-        return bool(T < R.NUM_RADAR_TOKENS and int(self.radar_stage[lane].count.max().item()) > T - 1)
+        # only the slots the last launch filled: after a partial launch the others hold counts of older frames
+        n = self._last[lane][0] if self._last[lane] is not None else self.frames_per_launch
+        return bool(T < R.NUM_RADAR_TOKENS and int(self.radar_stage[lane].count[:n].max().item()) > T - 1)
 
     def wait(self, lane):
         self.streams[lane].synchronize()
