@@ -105,6 +105,10 @@ def parse(argv=None):
     ap.add_argument('--train-autograd', action='store_true',
                     help='with --train: the per-operator autograd path instead of the two-call '
                          'fused forward/backward of the trainable stack')
+    ap.add_argument('--prefetch-depth', type=int, default=0,
+                    help='with --train: frames of look-ahead whose FROZEN decoder forward runs as one batched launch '
+                         'sequence (FusionTrainer(prefetch_depth=...)); 0 = the frames whose 16-row tiles are resident at '
+                         'once (9 for 900 queries), 1 = round 3\'s one-frame look-ahead')
     ap.add_argument('--no-prefetch', action='store_true',
                     help='with --train: do not enqueue the next iteration\'s frozen decoder forward while the host '
                          'solves the assignment')
@@ -1109,7 +1113,49 @@ def per_rank_summary(own_ms, steps, frames_per_step):
             'unit': 'frames/s', 'definition': 'steps / own median window of the rank (value uses the MAX over ranks)'}
 
 
-def _train_setup(head, dev, rank, B):
+class LookAheadFrames:
+    """The synthetic loader of the training bench: P frames collated on the device, stored twice in a row so that
+    every window of P consecutive frames (cyclically) is ONE contiguous view -- the look-ahead a data loader provides.
+    ``next()``: the frame of this iteration (B samples); ``prefetch()``: the window of the P frames that follow it."""
+
+    def __init__(self, head, dev, shapes, P, B, seed):
+        self.P, self.B = P, B
+        one = make_inputs(head, dev, shapes, P * B, seed=seed, host_feats=False)
+        self.hw, self.pad_mult = one['hw'], one['pad_mult']
+        self.nhwc = [torch.cat([f, f], 0).contiguous() for f in one['nhwc']]
+        self.l2i = torch.cat([one['l2i'], one['l2i']], 0).contiguous()
+        self.tokens = torch.cat([one['tokens'], one['tokens']], 0).contiguous()
+        self.ncam = self.nhwc[0].shape[0] // (2 * P * B)
+        self.cur = 0                             # iterations handed out so far
+        self.fifo = []                           # positions of the frames of look-aheads under way
+        del one
+
+    def _view(self, pos, n):
+        B, c = self.B, self.ncam
+        return dict(nhwc=[f[c * B * pos:c * B * (pos + n)] for f in self.nhwc], l2i=self.l2i[B * pos:B * (pos + n)],
+                    tokens=self.tokens[B * pos:B * (pos + n)], hw=self.hw, pad_mult=self.pad_mult)
+
+    def frame(self, i):
+        return self._view(i % self.P, 1)
+
+    def window(self, start=0):
+        return self._view(start % self.P, self.P)
+
+    def next(self):
+        """iteration i trains frame i % P; its tensors are the slice of the look-ahead window it belongs to (if any)"""
+        pos = self.fifo.pop(0) if self.fifo else self.cur % self.P
+        self.cur += 1
+        return self._view(pos, 1)
+
+    def prefetch(self, skip=0):
+        """the P frames that follow the `skip` frames of a look-ahead still to be returned by next()"""
+        s0 = (self.cur + skip) % self.P          # [s0, s0 + P) lies inside the doubled storage
+        self.fifo.extend(range(s0, s0 + self.P))
+        w = self._view(s0, self.P)
+        return dict(feats_nhwc=w['nhwc'], lidar2img=w['l2i'], img_hw=w['hw'], tokens=w['tokens'], pad_mult=w['pad_mult'])
+
+
+def _train_setup(head, dev, rank, B, prefetch_depth=1):
     """A trainable copy of the head (tools/train.py's freeze list), its FusionTrainer and B synthetic GT sets."""
     from transcar_amd.trainer import FusionTrainer
     cfg = configs.head_cfg()
@@ -1127,7 +1173,7 @@ def _train_setup(head, dev, rank, B):
     was = torch.is_grad_enabled()
     torch.set_grad_enabled(True)
     try:
-        tr = FusionTrainer(thead)
+        tr = FusionTrainer(thead, prefetch_depth=prefetch_depth)
     finally:
         torch.set_grad_enabled(was)
     return thead, tr, gts, lbs
@@ -1140,20 +1186,25 @@ def train_bench(args, head, inp, dev, rank, world, affinity=None):
     assignment on the host as in the reference) + HIP backward + ONE all-reduce of
     the flat gradient bucket over RCCL + device-side clip + AdamW + weight re-pack."""
     B = args.batch
-    thead, tr, gts, lbs = _train_setup(head, dev, rank, B)
+    depth = 1 if (args.train_autograd or args.no_prefetch) else \
+        (args.prefetch_depth or max(1, auto_frames_per_launch(head, dev) // B))
+    thead, tr, gts, lbs = _train_setup(head, dev, rank, B, depth)
     torch.set_grad_enabled(True)
     last = {}
 
-    # the next iteration's frame is known one step ahead (a data loader's look-ahead; here the same synthetic
-    # frame): its FROZEN decoder forward is enqueued while the host solves this iteration's assignment
-    nxt = None if (args.train_autograd or args.no_prefetch) else dict(
-        feats_nhwc=inp['nhwc'], lidar2img=inp['l2i'], img_hw=inp['hw'], tokens=inp['tokens'], pad_mult=inp['pad_mult'])
+    # the next iterations' frames are known ahead (a data loader's look-ahead; here synthetic frames collated on the
+    # device): their FROZEN decoder forward is enqueued, as one batched launch sequence, while the host solves an
+    # iteration's assignment
+    loader = LookAheadFrames(head, dev, args.shapes, depth, B, seed=1 + rank) if depth > 1 else None
+    nxt = None if (args.train_autograd or args.no_prefetch) else (loader.prefetch if loader is not None else dict(
+        feats_nhwc=inp['nhwc'], lidar2img=inp['l2i'], img_hw=inp['hw'], tokens=inp['tokens'], pad_mult=inp['pad_mult']))
 
     def step():
+        f = loader.next() if loader is not None else inp
         if args.train_autograd:
-            last['losses'] = tr.step_nhwc(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'], inp['pad_mult'], gts, lbs)
+            last['losses'] = tr.step_nhwc(f['nhwc'], f['l2i'], f['hw'], f['tokens'], f['pad_mult'], gts, lbs)
         else:
-            last['losses'] = tr.step_fused_nhwc(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'], inp['pad_mult'],
+            last['losses'] = tr.step_fused_nhwc(f['nhwc'], f['l2i'], f['hw'], f['tokens'], f['pad_mult'],
                                                 gts, lbs, prefetch=nxt)
 
     census = rank_census(dev, world)
@@ -1170,6 +1221,7 @@ def train_bench(args, head, inp, dev, rank, world, affinity=None):
         'data': 'synthetic', 'timing': win,
         'config': {'workload': 'BASELINE.json configs[2]: %s FPN shapes, 900 queries, 255 radar points, '
                                '24 GT boxes, batch-per-GPU %d, DDP' % (args.shapes, B),
+                   'decoder_lookahead_frames': depth,
                    'trainable_parameters': tr.bucket.numel,
                    'grad_bucket_bytes': tr.bucket.numel * 4,
                    'parallelism': 'dp%d, one flat-bucket all-reduce per step (%s)'
@@ -1179,7 +1231,8 @@ def train_bench(args, head, inp, dev, rank, world, affinity=None):
     }
     # EVERY rank: the roofline's one full iteration carries the all-reduce of the loss normalisers (HEAD:889-902) --
     # run by rank 0 alone it waited for its peers for ever while they sat in the barrier below
-    roof = None if args.no_roofline else train_roofline(tr, thead, inp, gts, lbs, nxt, dev)
+    roof = None if args.no_roofline else train_roofline(tr, thead, loader.frame(0) if loader is not None else inp, gts, lbs,
+                                                        nxt, dev, loader.window() if loader is not None else None)
     if rank == 0:
         if roof is not None:
             line['roofline'] = roof
@@ -1189,7 +1242,7 @@ def train_bench(args, head, inp, dev, rank, world, affinity=None):
         torch.distributed.destroy_process_group()
 
 
-def train_roofline(tr, thead, inp, gts, lbs, nxt, dev):
+def train_roofline(tr, thead, inp, gts, lbs, nxt, dev, batch=None):
     """The training iteration's kernels timed live (HIP events around eager launches of the same C calls the timed
     loop makes, nothing else on the GPU) against the f32 MFMA peak.  Algorithmic flop of one frame (900 queries,
     T radar tokens): frozen decoder chain 1.431 GF per layer (the bench's inference figure) and the attention core;
@@ -1218,7 +1271,13 @@ def train_roofline(tr, thead, inp, gts, lbs, nxt, dev):
     tr.step_fused_nhwc(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'], inp['pad_mult'], gts, lbs, update=False)
     torch.cuda.synchronize()
     seed = 12345
-    dec_ms = ev_time(lambda: tr._decoder_forward(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'], inp['pad_mult'], seed, 0))
+    tr._pre = None                               # (the look-ahead of the iteration above is not consumed here)
+    if batch is not None:                        # the decoder as the iterations run it: P frames per launch sequence
+        Pn = int(batch['l2i'].shape[0]) // B
+        dec_ms = ev_time(lambda: tr._decoder_forward(batch['nhwc'], batch['l2i'], batch['hw'], batch['tokens'],
+                                                     batch['pad_mult'], seed, 1)) / Pn
+    else:
+        dec_ms = ev_time(lambda: tr._decoder_forward(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'], inp['pad_mult'], seed, 0))
     base = tr._decoder_forward(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'], inp['pad_mult'], seed, 0)
     aux = base['aux']
     hs_last, ref_last, last_box = aux['inter_states'][-1].contiguous(), aux['inter_references'][-1].contiguous(), aux['last_box']
@@ -1262,8 +1321,10 @@ def train_roofline(tr, thead, inp, gts, lbs, nxt, dev):
         tot_ms += ms
     out.update(alg_flop=tot_f, ms=tot_ms, achieved=tot_f / tot_ms / 1e9, frac=tot_f / tot_ms / 1e9 / F32_MFMA_PEAK_TFLOPS,
                kernel='the three device phases of an iteration (decoder forward, stack forward, stack backward)',
-               traffic=None, note='one frame per GPU (CFG:188): 4-row tiles, bound by the weight stream of a workgroup '
-                                  '(DESIGN.md section 5), not by the matrix pipe')
+               traffic=None, decoder_lookahead_frames=tr.prefetch_depth,
+               note='one frame per GPU (CFG:188): the trainable stack runs 4-row tiles, bound by the weight stream of a '
+                    'workgroup (DESIGN.md section 5), not by the matrix pipe; the frozen decoder runs for '
+                    '`decoder_lookahead_frames` frames per launch sequence (its ms is per frame)')
     return out
 
 
@@ -1332,21 +1393,21 @@ def train_side_run(head, inp, dev, args):
     """BASELINE.json configs[2] at one GPU inside the inference line: a short `--train` run --
     ms per iteration of the fused training path (frozen decoder forward in train mode, stack forward / backward as row
     chains, device loss, flat-bucket clip + AdamW), its launches per iteration and the roofline of its three phases."""
-    thead, tr, gts, lbs = _train_setup(head, dev, 0, 1)
-    frame = make_inputs(head, dev, args.shapes, 1, seed=3)
-    nxt = dict(feats_nhwc=frame['nhwc'], lidar2img=frame['l2i'], img_hw=frame['hw'], tokens=frame['tokens'],
-               pad_mult=frame['pad_mult'])
+    depth = max(1, auto_frames_per_launch(head, dev))
+    thead, tr, gts, lbs = _train_setup(head, dev, 0, 1, depth)
+    loader = LookAheadFrames(head, dev, args.shapes, depth, 1, seed=3)
+    nxt = loader.prefetch
     was = torch.is_grad_enabled()
     torch.set_grad_enabled(True)
     try:
         def step():
-            tr.step_fused_nhwc(frame['nhwc'], frame['l2i'], frame['hw'], frame['tokens'], frame['pad_mult'], gts, lbs,
-                               prefetch=nxt)
-        for _ in range(15):
+            f = loader.next()
+            tr.step_fused_nhwc(f['nhwc'], f['l2i'], f['hw'], f['tokens'], f['pad_mult'], gts, lbs, prefetch=nxt)
+        for _ in range(2 * depth):
             step()
         torch.cuda.synchronize()
-        t = _replay_rate(step, torch.cuda.synchronize, 50, min_s=0.8)
-        roof = train_roofline(tr, thead, frame, gts, lbs, nxt, dev)
+        t = _replay_rate(step, torch.cuda.synchronize, 6 * depth, min_s=0.8)
+        roof = train_roofline(tr, thead, loader.frame(0), gts, lbs, nxt, dev, loader.window())
     finally:
         torch.set_grad_enabled(was)
     out = {'workload': 'BASELINE.json configs[2] at one GPU: one frame per iteration (CFG:188), %s FPN shapes, 24 GT boxes'

@@ -162,6 +162,11 @@ typedef struct {
                                profiles/r4_split_mfma_probe.txt), activations of a linear step must stay below
                                4.19e6 in magnitude (an overflow shows as inf / NaN, never silently);
                                TC_MATRIX_F32 (1) = v_mfma_f32_16x16x4_f32, exact fp32 FMA chains */
+  unsigned long long dropout_seed_stride; /* decoder dropout with B > 1: 0 = one mask index space over the batch (seed
+                               = dropout_seed); != 0: sample b draws the masks it would draw LAUNCHED ALONE with the seed
+                               dropout_seed + b * stride (element indices relative to the sample) -- a batch of
+                               look-ahead frames through the frozen decoder is then bit-identical, frame by frame, to
+                               the frames launched one at a time (FusionTrainer(prefetch_depth=...)) */
 } tc_head_options;
 #define TC_MATRIX_AUTO 0
 #define TC_MATRIX_F32 1
@@ -583,6 +588,28 @@ int tc_detr_loss_fwd_bwd(const float* all_cls, const float* all_box, int num_out
                          const float* code_weights, float alpha, float gamma, float cls_loss_weight,
                          float bbox_loss_weight, float* losses, float* d_all_cls, float* d_all_box,
                          tc_stream_t stream);
+
+/* tc_lsa_assign (round 4): the Hungarian assignment ITSELF on the device -- what ASSIGN:117-125 does with a D2H copy
+ * and scipy.optimize.linear_sum_assignment on the host (0.30 ms of a 0.96 ms training iteration's critical path).
+ * The algorithm scipy implements (shortest augmenting paths, Jonker-Volgenant in Crouse's rectangular form: the
+ * ground-truth boxes are the rows), in float64 like scipy, one wavefront per (output, sample).
+ *   cost      [num_outputs, B, Q, Gmax] from tc_match_cost; gt_counts [B] (device); Q <= 1024, Gmax <= 128, Gmax <= Q
+ *   assigned  [num_outputs, B, Q] int: matched gt index or -1 (as HungarianAssigner3D's assigned_gt_inds - 1)
+ *   num_pos   [num_outputs, 2] float or NULL: += the number of matched boxes, in both columns (zero first) -- the
+ *             `avg_factors` of tc_detr_loss_fwd_bwd_counts (one rank), or the operand of the ranks' all-reduce
+ *   status    [1] int or NULL: += 1 for every (output, sample) with a non-finite cost (scipy raises there): that
+ *             sample stays unassigned
+ * The optimum is unique unless two assignments cost exactly the same; on an exact tie this kernel prefers the
+ * lowest unassigned query, scipy the one met last in its work list (same total cost). */
+int tc_lsa_assign(const float* cost, const int* gt_counts, int num_outputs, int B, int Q, int Gmax, int* assigned,
+                  float* num_pos, int* status, tc_stream_t stream);
+/* tc_detr_loss_fwd_bwd with avg_factors = raw counts: the normalisers are max(count, 1) */
+int tc_detr_loss_fwd_bwd_counts(const float* all_cls, const float* all_box, int num_outputs, int B, int Q,
+                                int num_classes, int code_size, const float* gt_norm, const int* gt_labels,
+                                int Gmax, const int* assigned, const float* avg_factors,
+                                const float* code_weights, float alpha, float gamma, float cls_loss_weight,
+                                float bbox_loss_weight, float* losses, float* d_all_cls, float* d_all_box,
+                                tc_stream_t stream);
 
 #ifdef __cplusplus
 }

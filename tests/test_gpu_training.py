@@ -399,10 +399,12 @@ def test_fused_training_batch_of_two_matches_autograd_path(A, golden_dir):
     assert float(d) < 2e-4, float(d)
 
 
+@pytest.mark.parametrize('device_assign', [True, False])
 @pytest.mark.parametrize('n_gt', [24, 0])
-def test_device_loss_matches_reference_loss_and_autograd(A, golden_dir, n_gt):
+def test_device_loss_matches_reference_loss_and_autograd(A, golden_dir, n_gt, device_assign):
     """tc_match_cost / tc_detr_loss_fwd_bwd against the reference's loss values (G7), its
-    Hungarian assignment, and torch autograd through Detr3DHead.loss for the gradients."""
+    Hungarian assignment, and torch autograd through Detr3DHead.loss for the gradients -- with the assignment solved
+    on the device (tc_lsa_assign, round 4) and on the host by scipy (the reference's route)."""
     from transcar_amd.device_loss import detr_loss_device
     g5 = np.load(os.path.join(golden_dir, 'g5_head_tiny.npz'))
     g7 = np.load(os.path.join(golden_dir, 'g7_loss.npz' if n_gt else 'g7_loss_empty.npz'))
@@ -413,7 +415,10 @@ def test_device_loss_matches_reference_loss_and_autograd(A, golden_dir, n_gt):
     gt, lab = gt.to(dev()), torch.from_numpy(labels[:n_gt]).to(dev())
     cls = torch.from_numpy(g5['all_cls_scores']).to(dev())
     box = torch.from_numpy(g5['all_bbox_preds']).to(dev())
-    losses, d_cls, d_box, assigned = detr_loss_device(h, cls, box, [gt], [lab])
+    losses, d_cls, d_box, assigned = detr_loss_device(h, cls, box, [gt], [lab], device_assign=device_assign)
+    if torch.is_tensor(assigned):
+        assert device_assign and int(h.last_assign_status.item()) == 0
+        assigned = assigned.cpu().numpy()
     for k, v in losses.items():
         ref = float(g7[k.replace('.', '_')])
         assert abs(float(v) - ref) <= 2e-5 * max(1.0, abs(ref)), (k, float(v), ref)
@@ -428,6 +433,58 @@ def test_device_loss_matches_reference_loss_and_autograd(A, golden_dir, n_gt):
         assert rel(d_box, bl.grad) < 2e-5
     else:
         assert float(d_box.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('Q,G,B', [(900, 24, 2), (900, 1, 1), (900, 128, 1), (37, 37, 3), (1024, 60, 1), (64, 5, 2)])
+def test_device_assignment_equals_scipy(A, Q, G, B):
+    """tc_lsa_assign against scipy.optimize.linear_sum_assignment (ASSIGN:117-125) on random cost matrices, structured
+    ones (every ground-truth box has a few cheap queries, as a trained head produces) and ragged batches (samples with
+    fewer boxes, one without any): the same assignment, query for query; `num_pos` = the matched boxes per output;
+    a NaN cost leaves that sample unassigned and raises `status` (scipy raises ValueError there)."""
+    import ctypes as C
+    from scipy.optimize import linear_sum_assignment
+    from transcar_amd import _lib as L
+    lib = L.lib()
+    rng = np.random.RandomState(Q * 131 + G)
+    Lyr = 3
+    cost = rng.rand(Lyr, B, Q, G).astype(np.float32) * 4.0
+    # structure: box g is close to queries around 7 g (+ noise): low costs there
+    for g in range(G):
+        cost[:, :, (7 * g) % Q, g] *= 0.05
+        cost[1, :, (7 * g + 3) % Q, g] *= 0.02
+    counts = np.full(B, G, dtype=np.int32)
+    if B > 1:
+        counts[1] = max(0, G // 3)
+    if B > 2:
+        counts[2] = 0
+    for b in range(B):
+        cost[:, b, :, counts[b]:] = 0.0                       # tc_match_cost writes 0 beyond a sample's count
+    c_d, n_d = torch.from_numpy(cost).to(dev()), torch.from_numpy(counts).to(dev())
+    asg = torch.full((Lyr, B, Q), -7, dtype=torch.int32, device=dev())
+    z = torch.zeros(2 * Lyr + 1, dtype=torch.float32, device=dev())
+    num_pos, status = z[:2 * Lyr].view(Lyr, 2), z[2 * Lyr:].view(torch.int32)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.check(lib.tc_lsa_assign(c_d.data_ptr(), n_d.data_ptr(), Lyr, B, Q, G, asg.data_ptr(), num_pos.data_ptr(),
+                              status.data_ptr(), st), 'tc_lsa_assign')
+    got = asg.cpu().numpy()
+    assert int(status.item()) == 0
+    for l in range(Lyr):
+        for b in range(B):
+            want = np.full(Q, -1, dtype=np.int32)
+            if counts[b]:
+                rows, cols = linear_sum_assignment(cost[l, b, :, :counts[b]])
+                want[rows] = cols
+            assert np.array_equal(got[l, b], want), (l, b, int((got[l, b] != want).sum()))
+    assert np.allclose(num_pos.cpu().numpy(), float(counts.sum()))
+    # a non-finite cost: that sample unassigned, status raised, the others untouched
+    cost[0, 0, 5, 0] = np.nan
+    c_d = torch.from_numpy(cost).to(dev())
+    z.zero_()
+    L.check(lib.tc_lsa_assign(c_d.data_ptr(), n_d.data_ptr(), Lyr, B, Q, G, asg.data_ptr(), num_pos.data_ptr(),
+                              status.data_ptr(), st), 'tc_lsa_assign')
+    got2 = asg.cpu().numpy()
+    assert int(status.item()) == 1 and (got2[0, 0] == -1).all()
+    assert np.array_equal(got2[1:], got[1:]) and np.array_equal(got2[0, 1:], got[0, 1:])
 
 
 def test_fused_step_with_device_loss_equals_torch_loss(A, golden_dir):
@@ -864,6 +921,104 @@ def test_decoder_prefetch_changes_nothing_but_the_schedule(A, golden_dir):
     # (AdamW normalises the step: the last-bit differences of the atomically summed gradients show up at ~1e-5)
     d = (res[True][1] - res[False][1]).abs().max() / res[False][1].abs().max()
     assert float(d) < 1e-4, float(d)
+
+
+def test_batched_decoder_lookahead_is_the_single_frame_decoder(A, golden_dir):
+    """FusionTrainer(prefetch_depth=P) (round 4): the FROZEN decoder of the next P frames runs as ONE
+    batched launch sequence at 16-row tiles, frame b with the dropout masks of seed + b * SEED_STRIDE
+    (tc_head_options.dropout_seed_stride) -- the seeds those iterations draw themselves.
+    (a) decoder states / references / last box of frame b of the batch are BIT-IDENTICAL to frame b run alone with its
+        own seed at the same tile height, dropout on (all five sites per layer incl. the attention probabilities);
+    (b) 2 P optimizer steps with the look-ahead and without it: every frame came from the look-ahead, same losses, same
+        parameters (up to the rounding of the backward's atomics, as in the depth-1 test);
+    (c) a look-ahead whose inputs were overwritten in place, or whose seeds no longer match the forward counter, is
+        dropped and nothing is drawn from the counter for it."""
+    from transcar_amd import ops
+    from transcar_amd.trainer import FusionTrainer
+    P = 3
+    feats, metas, gt, labels = frame_inputs(golden_dir)
+    l2i1 = ops.lidar2img_tensor(metas, dev())
+    img_hw = metas[0]['img_shape'][0][:2]
+    per_frame = [feats] + [[torch.from_numpy(x).to(dev()) for x in synth.make_feats('tiny', seed=9 + i, smooth=(4, 6))]
+                           for i in range(1, P)]
+    # the frames twice in a row: every window of P consecutive frames (cyclically) is one contiguous view
+    nhwc_b = [torch.cat([ops.to_nhwc(f[l]) for f in per_frame] * 2, 0).contiguous() for l in range(len(feats))]
+    l2i_b = torch.cat([l2i1] * (2 * P), 0).contiguous()
+
+    def make(depth):
+        h = train_head(golden_dir)
+        tok1, pad_mult = h.radar_tokens(metas, dev())
+        tok_b = torch.cat([tok1] * (2 * P), 0).contiguous()
+        tr = FusionTrainer(h, dropout=0.1, seed=4, lr=1e-3, prefetch_depth=depth, decoder_dropout=0.1)
+        tr.decoder_tile_rows = 16                                  # the same decoder arithmetic with and without look-ahead
+        ncam = nhwc_b[0].shape[0] // (2 * P)
+
+        def view(pos, n):
+            return dict(nhwc=[f[ncam * pos:ncam * (pos + n)] for f in nhwc_b], l2i=l2i_b[pos:pos + n], tokens=tok_b[pos:pos + n])
+
+        def window(start):                                         # the P frames from `start` on, as prefetch_decoder takes them
+            w = view(start % P, P)
+            return dict(feats_nhwc=w['nhwc'], lidar2img=w['l2i'], img_hw=img_hw, tokens=w['tokens'], pad_mult=pad_mult)
+        return h, tr, view, window, pad_mult
+    # (a)
+    h, tr, view, window, pad_mult = make(P)
+    assert tr.decoder_dropout > 0
+    seed0 = 0x1234567
+    w0 = window(0)
+    full = tr._decoder_forward(w0['feats_nhwc'], w0['lidar2img'], img_hw, w0['tokens'], pad_mult, seed0, 1)['aux']
+    torch.cuda.synchronize()
+    full = {k: v.clone() for k, v in full.items() if torch.is_tensor(v)}
+    frames = [view(i, 1) for i in range(P)]
+    for i, f in enumerate(frames):
+        one = tr._decoder_forward(f['nhwc'], f['l2i'], img_hw, f['tokens'], pad_mult,
+                                  (seed0 + i * tr.SEED_STRIDE) & 0xFFFFFFFFFFFFFFFF, 0)['aux']
+        torch.cuda.synchronize()
+        assert torch.equal(one['inter_states'][:, 0], full['inter_states'][:, i]), i
+        assert torch.equal(one['inter_references'][:, 0], full['inter_references'][:, i]), i
+        assert torch.equal(one['last_box'][0], full['last_box'][i]), i
+    other = tr._decoder_forward(frames[1]['nhwc'], frames[1]['l2i'], img_hw, frames[1]['tokens'], pad_mult, seed0, 0)['aux']
+    assert not torch.equal(other['inter_states'][:, 0], full['inter_states'][:, 1])      # (the seed matters: dropout is on)
+    # (b)
+    res = {}
+    for look in (False, 'again', True):                                # 'again': the run-to-run noise of the backward's atomics
+        h, tr, view, window, pad_mult = make(P)
+        hist = []
+        fifo = []                                # positions (in the doubled storage) of the frames of look-aheads under way
+        for it in range(2 * P + 1):
+            f = view(fifo.pop(0) if fifo else it % P, 1)           # iteration `it` trains frame it % P
+
+            def lookahead(skip=0, it=it):
+                # the loader's answer: the P frames that follow the `skip` pending ones, i.e. those of iterations
+                # it + 1 + skip ... it + skip + P -- one contiguous window of the doubled storage
+                s0 = (it + 1 + skip) % P
+                fifo.extend(range(s0, s0 + P))
+                return window(s0)
+            losses = tr.step_fused_nhwc(f['nhwc'], f['l2i'], img_hw, f['tokens'], pad_mult, [gt], [labels],
+                                        prefetch=lookahead if look is True else None)
+            hist.append({k: float(v) for k, v in losses.items()})
+        torch.cuda.synchronize()
+        res[look] = (hist, tr.bucket.params.clone(), getattr(tr, 'lookahead_hits', 0))
+    assert res[False][2] == 0 and res[True][2] == 2 * P              # every frame but the very first
+    for a_, b_ in zip(res[False][0], res[True][0]):
+        for k in a_:
+            assert abs(a_[k] - b_[k]) <= 2e-5 * max(1.0, abs(a_[k])), (k, a_[k], b_[k])
+    # AdamW normalises the step, so the last-bit differences of the atomically summed gradients grow over the seven
+    # steps: the look-ahead may differ from the plain run by no more than two plain runs differ from each other
+    scale = res[False][1].abs().max()
+    noise = float((res['again'][1] - res[False][1]).abs().max() / scale)
+    d = float((res[True][1] - res[False][1]).abs().max() / scale)
+    assert d <= 3.0 * noise + 1e-5, (d, noise)
+    # (c)
+    h, tr, view, window, pad_mult = make(P)
+    f = view(0, 1)
+    tr.step_fused_nhwc(f['nhwc'], f['l2i'], img_hw, f['tokens'], pad_mult, [gt], [labels], prefetch=lambda skip: window(1))
+    assert tr.lookahead_pending() == P
+    counter = h._train_forwards
+    nhwc_b[0].add_(0.0)                                               # the loader refills its static tensors in place
+    f = view(1, 1)
+    tr.step_fused_nhwc(f['nhwc'], f['l2i'], img_hw, f['tokens'], pad_mult, [gt], [labels], prefetch=None)
+    assert tr.lookahead_pending() == 0 and getattr(tr, 'lookahead_hits', 0) == 0
+    assert h._train_forwards == counter + 1                           # one seed per training forward, none for the dropped batch
 
 
 def test_backward_chain_guards_non_finite_loss_gradients(A, golden_dir):

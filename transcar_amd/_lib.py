@@ -116,7 +116,8 @@ class tc_head_options(C.Structure):
     _fields_ = [('chain_tile_rows', C.c_int), ('unfused', C.c_int),
                 ('last_level_cls_only', C.c_int), ('reuse_radar_kv', C.c_int),
                 ('decoder_dropout_p', C.c_float), ('radar_row_order', C.c_int),
-                ('dropout_seed', C.c_ulonglong), ('phase', C.c_int), ('matrix_path', C.c_int)]
+                ('dropout_seed', C.c_ulonglong), ('phase', C.c_int), ('matrix_path', C.c_int),
+                ('dropout_seed_stride', C.c_ulonglong)]
 
 
 TC_MATRIX_AUTO, TC_MATRIX_F32, TC_MATRIX_F16X2 = 0, 1, 2
@@ -210,6 +211,9 @@ SIGNATURES = {
                            _f, _f, _f, _vp, _vp]),
     'tc_detr_loss_fwd_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp,
                                   _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp]),
+    'tc_detr_loss_fwd_bwd_counts': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp,
+                                         _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp]),
+    'tc_lsa_assign': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'tc_sq_norm': (_i, [_vp, _sz, _vp, _vp]),
     'tc_adamw_step': (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _f,
                            _f, _vp, _vp]),

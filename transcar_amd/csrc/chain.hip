@@ -405,6 +405,7 @@ struct LinSpec {
   int sub_on;
   int drop_site;               // DROP instantiations: site + 1 of this step's output dropout (0: none)
   unsigned long long drop_seed; unsigned drop_thr; float drop_scale;
+  unsigned long long drop_stride; int drop_q;     // per-sample seeds (DropK::seed_stride / rows_per_sample; 0: off)
   const int* rowg;             // radar: LDS table tile position -> global row for the gdst stores (null: m0 + i)
   int gpre;                    // F_GPRE
   const float* cmask; float cscale;   // F_CMASK: y = cmask[row, col] > 0 ? y * cscale : 0 (cmask is [M, N])
@@ -543,8 +544,11 @@ __device__ __forceinline__ void lin_epilogue(const LinSpec& s, int tile, const A
       for (int g = 0; g < NG; ++g)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const unsigned idx = (unsigned)(s.m0 + 4 * g + i) * (unsigned)s.N + (unsigned)col;
-          y[g][i] = drop_keep(s.drop_seed, (unsigned)(s.drop_site - 1), idx, s.drop_thr) ? y[g][i] * s.drop_scale : 0.0f;
+          unsigned row = (unsigned)(s.m0 + 4 * g + i);
+          unsigned long long seed = s.drop_seed;
+          if (s.drop_q > 0) { const unsigned b = row / (unsigned)s.drop_q; row -= b * (unsigned)s.drop_q; seed += b * s.drop_stride; }
+          const unsigned idx = row * (unsigned)s.N + (unsigned)col;
+          y[g][i] = drop_keep(seed, (unsigned)(s.drop_site - 1), idx, s.drop_thr) ? y[g][i] * s.drop_scale : 0.0f;
         }
     }
   }
@@ -691,12 +695,15 @@ __device__ __forceinline__ void lin_epilogue16(const LinSpec& s, int tile, const
   }
   if (DROP) {
     if (s.drop_site != 0) {
+      unsigned row = (unsigned)(s.m0 + c);
+      unsigned long long seed = s.drop_seed;
+      if (s.drop_q > 0) { const unsigned b = row / (unsigned)s.drop_q; row -= b * (unsigned)s.drop_q; seed += b * s.drop_stride; }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const unsigned idx = (unsigned)(s.m0 + c) * (unsigned)s.N + (unsigned)(colb + 16 * j + i);
-          y[j][i] = drop_keep(s.drop_seed, (unsigned)(s.drop_site - 1), idx, s.drop_thr) ? y[j][i] * s.drop_scale : 0.0f;
+          const unsigned idx = row * (unsigned)s.N + (unsigned)(colb + 16 * j + i);
+          y[j][i] = drop_keep(seed, (unsigned)(s.drop_site - 1), idx, s.drop_thr) ? y[j][i] * s.drop_scale : 0.0f;
         }
     }
   }
@@ -1341,7 +1348,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
     s.woff = (r.flags & F_WAVE1) ? 1 : 0;
     s.dbg = k.dbg;
     s.sub_on = 0;
-    s.drop_site = 0; s.drop_seed = 0; s.drop_thr = 0; s.drop_scale = 1.0f;
+    s.drop_site = 0; s.drop_seed = 0; s.drop_thr = 0; s.drop_scale = 1.0f; s.drop_stride = 0; s.drop_q = 0;
     s.rowg = nullptr; s.gpre = 0; s.cmask = nullptr; s.cscale = 1.0f;
     return s;
   };
@@ -1366,7 +1373,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
     s.woff = e.woff;
     s.dbg = 0;
     s.sub_on = 0;
-    s.drop_site = 0; s.drop_seed = 0; s.drop_thr = 0; s.drop_scale = 1.0f;
+    s.drop_site = 0; s.drop_seed = 0; s.drop_thr = 0; s.drop_scale = 1.0f; s.drop_stride = 0; s.drop_q = 0;
     s.rowg = (prog_is_radar(PROG) && k.row_perm != nullptr) ? &S.rowg[0] : nullptr;
     s.gpre = (e.flags & F_GPRE) ? 1 : 0;
     if (DROP) {
@@ -1374,6 +1381,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
         s.drop_site = e.drop_site; s.drop_seed = k.rdrop.seed; s.drop_thr = k.rdrop.thr; s.drop_scale = k.rdrop.scale;
       } else {
         s.drop_site = e.drop_site; s.drop_seed = k.drop.seed; s.drop_thr = k.drop.thr; s.drop_scale = k.drop.scale;
+        s.drop_stride = k.drop.seed_stride; s.drop_q = (int)k.drop.rows_per_sample;
       }
     }
     return s;
@@ -2131,10 +2139,14 @@ int launch_rows(const ChainK& k, hipStream_t s, const char* what) {
 int launch(const ChainK& k, hipStream_t s, const char* what) {
   switch (k.program) {
     case PROG_DECODER:
-      if (k.drop.thr != 0) {            // train-mode dropout: its own instantiations, 4- and 8-row tiles
-        TC_REQUIRE((unsigned long long)k.M * 512ull < (1ull << 32), "decoder_chain: dropout index space");
-        return tile_rows(k) == 4 ? launch_r<4, PROG_DECODER, true>(k, s, what)
-                                 : launch_r<8, PROG_DECODER, true>(k, s, what);
+      if (k.drop.thr != 0) {            // train-mode dropout: its own instantiations -- 4- and 8-row tiles, and the
+        //                                  16-row tiles of the f16x2 path (several frames per launch: the trainer's
+        //                                  batched look-ahead of the frozen decoder, round 4)
+        TC_REQUIRE((unsigned long long)(k.drop.rows_per_sample ? k.drop.rows_per_sample : k.M) * 512ull < (1ull << 32),
+                   "decoder_chain: dropout index space");
+        const int rows = tile_rows(k);
+        if (rows == 16 && use_f16x2(k)) return launch_r<16, PROG_DECODER, true, 1>(k, s, what);
+        return rows == 4 ? launch_r<4, PROG_DECODER, true>(k, s, what) : launch_r<8, PROG_DECODER, true>(k, s, what);
       }
       return launch_rows<PROG_DECODER>(k, s, what);
     case PROG_RADAR: return launch_rows<PROG_RADAR>(k, s, what);

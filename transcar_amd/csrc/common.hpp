@@ -124,6 +124,12 @@ struct DropK {
   float scale;                 // 1 / (1 - p)
   unsigned site;
   unsigned tokens_ref;         // stride of the probability index (1500 reference tokens)
+  // Frozen decoder, several frames in one launch (tc_head_options.dropout_seed_stride): sample b draws its masks from
+  // seed + b * seed_stride with element indices relative to the sample -- the masks that frame would draw launched
+  // alone with that seed.  rows_per_sample = 0: one index space over the whole batch (every other caller).
+  unsigned long long seed_stride;
+  unsigned rows_per_sample;
+  unsigned pad_;
 };
 __host__ __device__ __forceinline__ bool drop_keep(unsigned long long seed, unsigned site, unsigned idx,
                                                    unsigned thr) {
@@ -136,6 +142,7 @@ __host__ __device__ __forceinline__ bool drop_keep(unsigned long long seed, unsi
 inline DropK make_drop(float p, unsigned long long seed, unsigned site, unsigned tokens_ref) {
   DropK d;
   d.seed = seed; d.site = site; d.tokens_ref = tokens_ref;
+  d.seed_stride = 0; d.rows_per_sample = 0; d.pad_ = 0;
   d.thr = p > 0.0f ? (unsigned)((double)p * 4294967296.0 + 0.5) : 0u;
   d.scale = p > 0.0f ? 1.0f / (1.0f - p) : 1.0f;
   return d;

@@ -203,7 +203,8 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
 
   // train-mode statistics of the frozen decoder: five dropout sites per layer (sites 16 + 8 l + 0..4)
   const bool ddrop = opt.decoder_dropout_p > 0.0f;
-  TC_REQUIRE(!ddrop || (unsigned long long)B * H * Q * Q < (1ull << 32), "decoder dropout: B*H*Q*Q exceeds 32 bits");
+  TC_REQUIRE(!ddrop || (unsigned long long)(opt.dropout_seed_stride ? 1 : B) * H * Q * Q < (1ull << 32),
+             "decoder dropout: B*H*Q*Q exceeds 32 bits");
   if (radar && ddrop && opt.phase != 1) TC_TRY(launch_radar_encode(re, s));     // no ride in the decoder launches then
   // layer 0 up to its attention output is a constant of the checkpoint (pack time) -- in eval
   // mode: with dropout on the attention probabilities it is not
@@ -220,7 +221,10 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
     const float* ref_in = l0c ? w->l0_init_reference
                               : lid == 0 ? h.init_ref : h.inter_refs + (size_t)(lid - 1) * rows * 3;
     DecoderChainArgs d;
-    if (ddrop) d.drop = make_drop(opt.decoder_dropout_p, opt.dropout_seed, 16u + 8u * (unsigned)lid, 0u);
+    if (ddrop) {
+      d.drop = make_drop(opt.decoder_dropout_p, opt.dropout_seed, 16u + 8u * (unsigned)lid, 0u);
+      if (opt.dropout_seed_stride != 0) { d.drop.seed_stride = opt.dropout_seed_stride; d.drop.rows_per_sample = (unsigned)Q; }
+    }
     if (!l0c) TC_TRY(launch_self_attn_core(h.qk, h.qk + C, 2 * C, h.vt, h.qpad, h.attn_o, C, B, Q, H, s,
                                            ddrop ? &d.drop : nullptr));
     d.attn_o = l0c ? w->l0_attn_out : h.attn_o;

@@ -101,7 +101,7 @@ struct DecoderChainArgs {
   // train-mode statistics of the frozen decoder (thr 0 = eval): drop.site is the site of THIS
   // layer's attention probabilities (16 + 8 * layer); the chain's four sites are drop.site + 1
   // (self-attention output), + 2 (cross-attention output, XFMR:378), + 3 (FFN hidden), + 4 (FFN output)
-  DropK drop = DropK{0, 0, 1.0f, 0, 0};
+  DropK drop = DropK{0, 0, 1.0f, 0, 0, 0, 0, 0};
 };
 int launch_decoder_chain(const DecoderChainArgs& a, hipStream_t s);
 
@@ -135,7 +135,7 @@ struct RadarChainArgs {
   // forward of a training iteration (tc_radar_train_fwd_fused): tape tensors of fusion layer 0 by TapeSlot,
   // layer r at + r * tape_stride floats; hit counts of layer r at hits + r * hits_stride; dropout seed / p
   float* const* tape = nullptr; size_t tape_stride = 0, hits_stride = 0;
-  DropK drop = DropK{0, 0, 1.0f, 0, 1500};
+  DropK drop = DropK{0, 0, 1.0f, 0, 1500, 0, 0, 0};
 };
 // Backward of the three fusion layers for the query rows as ONE launch of the row chain (chain.hip
 // PROG_RADAR_BWD): data gradients row-local, every dY a weight gradient needs stored (DySlot order), LayerNorm
@@ -191,7 +191,7 @@ struct RadarAttnArgs {
   float* attn_out;                     // [B*Q, C] (zero rows where no hit)
   int* hit_counts;                     // [B*Q]
   float qscale = 1.0f;                 // applied to qproj on load (1 when pre-scaled)
-  DropK drop = DropK{0, 0, 1.0f, 0, 1500};   // training: dropout on the attention probabilities (thr 0 = off)
+  DropK drop = DropK{0, 0, 1.0f, 0, 1500, 0, 0, 0};   // training: dropout on the attention probabilities (thr 0 = off)
 };
 int launch_radar_attn(const RadarAttnArgs& a, hipStream_t s);
 int launch_dropout(const float* x, const float* res, const int* gate, int rows, int cols, const DropK& d,

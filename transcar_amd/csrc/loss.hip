@@ -80,6 +80,7 @@ struct LossK {
   int Lyr, B, Q, ncls, code, Gmax;
   float alpha, gamma, wcls, wbox;
   float* losses; float* d_cls; float* d_box;
+  int avg_min1;                 // 1: `avg` holds raw counts (tc_lsa_assign's num_pos): the normaliser is max(count, 1)
 };
 
 // one thread per (l, b, q): focal loss over the classes + L1 over the box code of a
@@ -97,7 +98,8 @@ __global__ __launch_bounds__(256) void detr_loss_kernel(LossK p) {
     const size_t row = (size_t)l * rows_per_layer + r;
     const int b = r / p.Q;
     const int a = p.assigned[row];
-    const float inv = 1.0f / p.avg[2 * l], invb = 1.0f / p.avg[2 * l + 1];
+    const float inv = 1.0f / (p.avg_min1 ? fmaxf(p.avg[2 * l], 1.0f) : p.avg[2 * l]);
+    const float invb = 1.0f / (p.avg_min1 ? fmaxf(p.avg[2 * l + 1], 1.0f) : p.avg[2 * l + 1]);
     const int label = a >= 0 ? p.gt_labels[(size_t)b * p.Gmax + a] : p.ncls;
     const float* x = p.cls + row * p.ncls;
     float* dx = p.d_cls + row * p.ncls;
@@ -142,7 +144,8 @@ __global__ __launch_bounds__(256) void detr_loss_kernel(LossK p) {
   if (lane == 0) { red[0][wave] = lc; red[1][wave] = lb; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const float inv = 1.0f / p.avg[2 * l], invb = 1.0f / p.avg[2 * l + 1];
+    const float inv = 1.0f / (p.avg_min1 ? fmaxf(p.avg[2 * l], 1.0f) : p.avg[2 * l]);
+    const float invb = 1.0f / (p.avg_min1 ? fmaxf(p.avg[2 * l + 1], 1.0f) : p.avg[2 * l + 1]);
     unsafeAtomicAdd(p.losses + 2 * l + 0, (red[0][0] + red[0][1] + red[0][2] + red[0][3]) * p.wcls * inv);
     unsafeAtomicAdd(p.losses + 2 * l + 1, (red[1][0] + red[1][1] + red[1][2] + red[1][3]) * p.wbox * invb);
   }
@@ -153,6 +156,201 @@ int launch_detr_loss(const LossK& p, hipStream_t s) {
   if (rows == 0 || p.Lyr == 0) return 0;
   hipLaunchKernelGGL(detr_loss_kernel, dim3((rows + 255) / 256, p.Lyr), dim3(256), 0, s, p);
   return check_launch("detr_loss");
+}
+
+
+// ---- the Hungarian assignment itself, on the device (round 4) -------------------------------------------------
+// ASSIGN:117-125 moves the [Q, G] cost matrix to the host and calls scipy's linear_sum_assignment; with the
+// decoder hidden behind a look-ahead that round trip (D2H, three solves of 900 x 24, H2D: ~0.30 ms) was the largest
+// single piece of a 0.96 ms iteration's critical path.  Here: the same algorithm scipy implements (the shortest
+// augmenting path form of Jonker-Volgenant in Crouse's rectangular variant, scipy/optimize/rectangular_lsap: the G
+// ground-truth boxes are the rows, the Q queries the columns), in float64 like scipy, ONE WAVE per (decoder output,
+// sample): lane l owns columns l, l + 64, ...; a step of an augmenting path is a register update of the lane's
+// columns plus one wave-wide arg-min -- no barrier, no host.  The optimal assignment is unique unless two
+// candidate sets have exactly equal cost; on an exact tie between columns the lowest unassigned column wins here
+// (scipy: the one met last in its work list) -- same total cost, possibly another of the tied queries.
+// A non-finite cost (scipy raises ValueError) leaves the sample unassigned and sets *status.
+constexpr int LSA_COLS = 16;                       // columns per lane: Q <= 64 * LSA_COLS = 1024
+constexpr int LSA_GMAX = 128;                      // ground-truth boxes per sample
+struct LsaK {
+  const float* cost;                               // [P, Q, Gmax] (P = outputs x samples), 0 beyond a sample's count
+  const int* gt_counts;                            // [B]
+  int P, B, Q, Gmax;
+  int* assigned;                                   // [P, Q]: gt index or -1
+  float* num_pos;                                  // [outputs, 2] += matched boxes, both columns (zero first) or null
+  int* status;                                     // += 1 per sample with a non-finite cost, or null
+};
+
+__device__ __forceinline__ double wave_min_f64(double v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const double t = __shfl_xor(v, o, 64);
+    v = t < v ? t : v;
+  }
+  return v;
+}
+
+// LDS = true: the sample's costs are transposed into LDS first (a step then reads consecutive words); false (the
+// matrix does not fit: more than ~40 boxes at 900 queries): straight from global memory (L2), stride Gmax
+template <bool LDS>
+__global__ __launch_bounds__(64) void lsa_kernel(LsaK p) {
+  extern __shared__ __align__(16) float lsa_cost[];          // [G][Qpad] (transposed: a row = one ground-truth box)
+  __shared__ double u[LSA_GMAX];
+  __shared__ double spc_of_col4row[LSA_GMAX];
+  __shared__ int col4row[LSA_GMAX];
+  __shared__ int SR[LSA_GMAX];
+  const int prob = blockIdx.x, lane = threadIdx.x;
+  const int b = prob % p.B;
+  const int G = min(p.gt_counts[b], p.Gmax), Q = p.Q;
+  const int Qpad = (Q + 63) & ~63;
+  int* out = p.assigned + (size_t)prob * Q;
+  for (int j = lane; j < Q; j += 64) out[j] = -1;
+  if (G <= 0) return;
+  // the sample's costs, transposed into LDS (coalesced global reads: g fastest; 16 loads in flight per lane)
+  const float* cg = p.cost + (size_t)prob * Q * p.Gmax;
+  const int total = Q * p.Gmax;
+  int bad = 0;
+#pragma unroll 1
+  for (int base = 0; base < total; base += 64 * 16) {
+    float c[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int i = base + 64 * t + lane;
+      c[t] = i < total ? ldg1(cg + i) : 0.0f;
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int i = base + 64 * t + lane;
+      const int q = i / p.Gmax, g = i - q * p.Gmax;
+      if (i < total && g < G) {
+        bad |= !(fabsf(c[t]) <= 3.0e38f);
+        if (LDS) lsa_cost[g * Qpad + q] = c[t];
+      }
+    }
+  }
+  if (__any(bad)) {                                 // scipy: "matrix contains invalid numeric entries"
+    if (lane == 0 && p.status != nullptr) atomicAdd(p.status, 1);
+    return;
+  }
+  for (int i = lane; i < G; i += 64) { u[i] = 0.0; col4row[i] = -1; }
+  double v[LSA_COLS];
+  int row4col[LSA_COLS];
+#pragma unroll
+  for (int k = 0; k < LSA_COLS; ++k) { v[k] = 0.0; row4col[k] = -1; }
+  __syncthreads();                                  // (one wave: orders the LDS writes above)
+  const double INF = __longlong_as_double(0x7FF0000000000000ll);
+  for (int cur = 0; cur < G; ++cur) {
+    double spc[LSA_COLS];
+    int path[LSA_COLS];
+    unsigned sc = 0;                                // bit k: column lane + 64 k has been scanned (left `remaining`)
+#pragma unroll
+    for (int k = 0; k < LSA_COLS; ++k) { spc[k] = INF; path[k] = -1; }
+    for (int i = lane; i < G; i += 64) SR[i] = 0;
+    __syncthreads();
+    double minVal = 0.0;
+    int i = cur, sink = -1;
+    while (sink < 0) {
+      if (lane == 0) SR[i] = 1;
+      const double ui = u[i];
+      const float* crow = lsa_cost + i * Qpad;
+      float cij[LSA_COLS];
+#pragma unroll
+      for (int k = 0; k < LSA_COLS; ++k) {
+        const int j = lane + 64 * k;
+        cij[k] = j < Q ? (LDS ? crow[j] : ldg1(cg + (size_t)j * p.Gmax + i)) : 0.0f;
+      }
+      double best = INF; int bestk = -1, best_free = 0;
+#pragma unroll
+      for (int k = 0; k < LSA_COLS; ++k) {
+        const int j = lane + 64 * k;
+        if (j < Q && !((sc >> k) & 1u)) {
+          const double r = minVal + (double)cij[k] - ui - v[k];
+          if (r < spc[k]) { spc[k] = r; path[k] = i; }
+          const int fr = row4col[k] < 0;
+          // strictly lower, or equal and unassigned while the incumbent is assigned (scipy prefers a new sink)
+          if (spc[k] < best || (spc[k] == best && fr && !best_free)) { best = spc[k]; bestk = k; best_free = fr; }
+        }
+      }
+      const double lowest = wave_min_f64(best);
+      if (!(lowest < INF)) {                        // infeasible (cannot happen with finite costs)
+        if (lane == 0 && p.status != nullptr) atomicAdd(p.status, 1);
+        return;
+      }
+      // among the lanes that hold the minimum: an unassigned column first, then the lowest column index
+      const int mine = best == lowest && bestk >= 0;
+      const unsigned long long free_m = __ballot(mine && best_free), any_m = __ballot(mine);
+      const int win = __ffsll((long long)(free_m ? free_m : any_m)) - 1;
+      const int wk = __shfl(bestk, win, 64);
+      int r4c = -1;
+#pragma unroll
+      for (int k = 0; k < LSA_COLS; ++k) if (k == wk) r4c = row4col[k];
+      r4c = __shfl(r4c, win, 64);
+      minVal = lowest;
+      const int j = win + 64 * wk;
+      if (lane == win) sc |= 1u << wk;
+      if (r4c < 0) sink = j; else i = r4c;
+      __syncthreads();                              // SR[i] of lane 0 before the dual update reads it
+    }
+    // dual update (scipy: u[cur] += minVal; u[i] += minVal - spc[col4row[i]] for the other scanned rows;
+    // v[j] -= minVal - spc[j] for the scanned columns)
+#pragma unroll
+    for (int k = 0; k < LSA_COLS; ++k) {
+      if ((sc >> k) & 1u) {
+        v[k] -= minVal - spc[k];
+        if (row4col[k] >= 0) spc_of_col4row[row4col[k]] = spc[k];      // the row assigned to a scanned column
+      }
+    }
+    __syncthreads();
+    for (int r = lane; r < G; r += 64) {
+      if (r == cur) u[r] += minVal;
+      else if (SR[r]) u[r] += minVal - spc_of_col4row[r];
+    }
+    __syncthreads();
+    // augment along the path from the sink back to `cur`
+    int j = sink;
+    for (;;) {
+      const int ol = j & 63, ok = j >> 6;
+      int pi = -1;
+#pragma unroll
+      for (int k = 0; k < LSA_COLS; ++k) if (k == ok) pi = path[k];
+      pi = __shfl(pi, ol, 64);
+      if (lane == ol) {
+#pragma unroll
+        for (int k = 0; k < LSA_COLS; ++k) if (k == ok) row4col[k] = pi;
+      }
+      const int prev = col4row[pi];
+      __syncthreads();
+      if (lane == 0) col4row[pi] = j;
+      __syncthreads();
+      j = prev;
+      if (pi == cur) break;
+    }
+  }
+  __syncthreads();
+  for (int r = lane; r < G; r += 64) out[col4row[r]] = r;
+  if (lane < 2 && p.num_pos != nullptr) atomicAdd(p.num_pos + 2 * (prob / p.B) + lane, (float)G);
+}
+
+int launch_lsa(const float* cost, const int* gt_counts, int P, int B, int Q, int Gmax, int* assigned, float* num_pos,
+               int* status, hipStream_t s) {
+  TC_REQUIRE(P >= 1 && B >= 1 && P % B == 0, "lsa: P=%d B=%d", P, B);
+  TC_REQUIRE(Q >= 1 && Q <= 64 * LSA_COLS && Gmax >= 1 && Gmax <= LSA_GMAX && Gmax <= Q,
+             "lsa: Q=%d (<= %d) Gmax=%d (<= %d, <= Q)", Q, 64 * LSA_COLS, Gmax, LSA_GMAX);
+  const size_t lds = (size_t)Gmax * ((Q + 63) & ~63) * sizeof(float);
+  const bool in_lds = lds <= 150 * 1024;
+  static DeviceOnce once;
+  if (const int once_dev = once.need(); once_dev >= 0) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lsa_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) { set_error("lsa: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    once.done(once_dev);
+  }
+  LsaK p;
+  p.cost = cost; p.gt_counts = gt_counts; p.P = P; p.B = B; p.Q = Q; p.Gmax = Gmax; p.assigned = assigned;
+  p.num_pos = num_pos; p.status = status;
+  if (in_lds) hipLaunchKernelGGL(lsa_kernel<true>, dim3(P), dim3(64), lds, s, p);
+  else hipLaunchKernelGGL(lsa_kernel<false>, dim3(P), dim3(64), 0, s, p);
+  return check_launch("lsa");
 }
 
 }  // namespace tc
@@ -190,8 +388,32 @@ int tc_detr_loss_fwd_bwd(const float* all_cls, const float* all_box, int num_out
   p.avg = avg_factors; p.code_w = code_weights;
   p.Lyr = num_outputs; p.B = B; p.Q = Q; p.ncls = num_classes; p.code = code_size; p.Gmax = Gmax;
   p.alpha = alpha; p.gamma = gamma; p.wcls = cls_loss_weight; p.wbox = bbox_loss_weight;
-  p.losses = losses; p.d_cls = d_all_cls; p.d_box = d_all_box;
+  p.losses = losses; p.d_cls = d_all_cls; p.d_box = d_all_box; p.avg_min1 = 0;
   return launch_detr_loss(p, as_stream(stream));
+}
+
+// the same with `avg_factors` holding raw COUNTS of matched boxes (tc_lsa_assign's num_pos): the normalisers are
+// max(count, 1) (HEAD:889-902 on one rank), no host in between
+int tc_detr_loss_fwd_bwd_counts(const float* all_cls, const float* all_box, int num_outputs, int B, int Q,
+                         int num_classes, int code_size, const float* gt_norm, const int* gt_labels,
+                         int Gmax, const int* assigned, const float* avg_factors,
+                         const float* code_weights, float alpha, float gamma, float cls_loss_weight,
+                         float bbox_loss_weight, float* losses, float* d_all_cls, float* d_all_box,
+                         tc_stream_t stream) {
+  TC_REQUIRE(code_size >= 10, "detr_loss: code_size=%d (>= 10)", code_size);
+  LossK p;
+  p.cls = all_cls; p.box = all_box; p.gtn = gt_norm; p.gt_labels = gt_labels; p.assigned = assigned;
+  p.avg = avg_factors; p.code_w = code_weights;
+  p.Lyr = num_outputs; p.B = B; p.Q = Q; p.ncls = num_classes; p.code = code_size; p.Gmax = Gmax;
+  p.alpha = alpha; p.gamma = gamma; p.wcls = cls_loss_weight; p.wbox = bbox_loss_weight;
+  p.losses = losses; p.d_cls = d_all_cls; p.d_box = d_all_box; p.avg_min1 = 1;
+  return launch_detr_loss(p, as_stream(stream));
+}
+
+int tc_lsa_assign(const float* cost, const int* gt_counts, int num_outputs, int B, int Q, int Gmax, int* assigned,
+                  float* num_pos, int* status, tc_stream_t stream) {
+  TC_REQUIRE(cost != nullptr && gt_counts != nullptr && assigned != nullptr, "lsa_assign: null argument");
+  return launch_lsa(cost, gt_counts, num_outputs * B, B, Q, Gmax, assigned, num_pos, status, as_stream(stream));
 }
 
 }  // extern "C"

@@ -157,8 +157,10 @@ __global__ __launch_bounds__(SA_NW * 64) void self_attn_kernel(const float* __re
     qa[u] = ld4(qp); qb[u] = ld4(qp + 4);
     st[u].o0 = f32x4{0.f, 0.f, 0.f, 0.f}; st[u].o1 = f32x4{0.f, 0.f, 0.f, 0.f};
     st[u].negm = f32x4{0.f, 0.f, 0.f, 0.f}; st[u].l = 0.0f;
-    dbase[u] = DROP ? (((unsigned)b * gridDim.y + h) * Q + (unsigned)qrow) * Q + 4 * g : 0u;
+    // (a batch of frames with per-sample seeds: the index is the one sample b has when it is launched alone)
+    dbase[u] = DROP ? (((drop.rows_per_sample ? 0u : (unsigned)b) * gridDim.y + h) * Q + (unsigned)qrow) * Q + 4 * g : 0u;
   }
+  if (DROP) drop.seed += (unsigned long long)b * drop.seed_stride;
   // the wave's key tiles: wave, wave + NW, ... among the nfull whole tiles (two fragment buffers,
   // each loaded one tile ahead), then the ragged tile if it is this wave's turn
   const int nfull = Q >> 4;
@@ -237,12 +239,13 @@ int launch_self_attn_core(const float* q, const float* k, int ld, const float* v
   constexpr int QT = 2;
   dim3 grid((Q + 16 * QT - 1) / (16 * QT), H, B);
   if (drop != nullptr && drop->thr != 0) {
-    TC_REQUIRE((unsigned long long)B * H * Q * Q < (1ull << 32), "self_attn: dropout index space (B*H*Q*Q) exceeds 32 bits");
+    TC_REQUIRE((unsigned long long)(drop->rows_per_sample ? 1 : B) * H * Q * Q < (1ull << 32),
+               "self_attn: dropout index space (B*H*Q*Q) exceeds 32 bits");
     hipLaunchKernelGGL((self_attn_kernel<QT, true>), grid, dim3(SA_NW * 64), 0, s, q, k, ld, vt, ldt, out, ldo, Q,
                        H * 32, *drop);
   } else {
     hipLaunchKernelGGL((self_attn_kernel<QT, false>), grid, dim3(SA_NW * 64), 0, s, q, k, ld, vt, ldt, out, ldo, Q,
-                       H * 32, DropK{0, 0, 1.0f, 0, 0});
+                       H * 32, DropK{0, 0, 1.0f, 0, 0, 0, 0, 0});
   }
   return check_launch("self_attn");
 }

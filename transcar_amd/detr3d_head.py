@@ -51,7 +51,8 @@ MATRIX_PATHS = {None: L.TC_MATRIX_AUTO, 'auto': L.TC_MATRIX_AUTO, 'f32': L.TC_MA
 
 
 def head_options(tile_rows=None, unfused=None, last_level_cls_only=False,
-                 decoder_dropout_p=0.0, dropout_seed=0, radar_compact=None, phase=0, matrix_path=None):
+                 decoder_dropout_p=0.0, dropout_seed=0, radar_compact=None, phase=0, matrix_path=None,
+                 dropout_seed_stride=0):
     """tc_head_options for one forward.  unfused=None: the TRANSCAR_UNFUSED=1
     environment switch of the operator-by-operator cross-check path (a host-side
     knob: the library itself reads no environment)."""
@@ -67,6 +68,8 @@ def head_options(tile_rows=None, unfused=None, last_level_cls_only=False,
     o.phase = int(phase)          # 0: the whole forward; 1 / 2: before / after the radar tokens exist (forward_nhwc)
     # 16-row tiles: 'f16x2' (= automatic) two-plane f16 operands on the matrix cores, 'f32' the exact fp32 MFMA
     o.matrix_path = MATRIX_PATHS[matrix_path] if not isinstance(matrix_path, int) else int(matrix_path)
+    # decoder dropout of a batch of frames: sample b draws the masks of seed + b * stride, indices relative to the sample
+    o.dropout_seed_stride = int(dropout_seed_stride) & 0xFFFFFFFFFFFFFFFF
     return o
 
 
@@ -660,6 +663,15 @@ class Detr3DHead(BaseModule):
         return {'all_cls_scores': torch.stack(all_cls),
                 'all_bbox_preds': torch.stack(all_box),
                 'enc_cls_scores': None, 'enc_bbox_preds': None}
+
+    def peek_dropout_seed(self, ahead=1):
+        """The seed `next_dropout_seed` will return on its `ahead`-th next call (nothing is advanced): a look-ahead of
+        the frozen decoder draws the masks of the iterations that will consume it (FusionTrainer.prefetch_decoder)."""
+        import torch.distributed as dist
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        n = getattr(self, '_train_forwards', 0) + int(ahead)
+        return (int(getattr(self, 'dropout_seed', 0)) * 0x9E3779B1 + rank * 0xC2B2AE3D27D4EB4F
+                + n * 0x85EBCA77 + 1) & 0xFFFFFFFFFFFFFFFF
 
     def next_dropout_seed(self):
         """Seed of the counter-based dropout masks of ONE training forward: a function of

@@ -28,9 +28,16 @@ def gt_tensors(gt_bboxes_list, device):
     return out
 
 
-def detr_loss_device(head, all_cls, all_box, gt_bboxes_list, gt_labels_list, before_sync=None, defer_guard=False):
-    """-> (loss dict with the reference's keys, d_all_cls, d_all_box, assigned [Lyr,B,Q] numpy).
-    The gradients are those of sum(losses) (mmdet ``_parse_losses``)."""
+#: The Hungarian assignment on the device (tc_lsa_assign: the algorithm scipy's linear_sum_assignment implements, in
+#: float64, one wavefront per problem) instead of D2H + scipy + H2D: the iteration then has no host synchronisation
+#: at all.  False = the reference's route (ASSIGN:117-125), kept as the cross-check of the tests.
+DEVICE_ASSIGN = True
+
+
+def detr_loss_device(head, all_cls, all_box, gt_bboxes_list, gt_labels_list, before_sync=None, defer_guard=False,
+                     device_assign=None):
+    """-> (loss dict with the reference's keys, d_all_cls, d_all_box, assigned [Lyr,B,Q] (numpy; a device tensor with
+    device_assign)).  The gradients are those of sum(losses) (mmdet ``_parse_losses``)."""
     if head.assigner is None:
         raise L.TransCARHipError('loss needs train_cfg=dict(assigner=...) at construction')
     lib = L.lib()
@@ -73,6 +80,10 @@ def detr_loss_device(head, all_cls, all_box, gt_bboxes_list, gt_labels_list, bef
         float(getattr(a.cls_cost, 'eps', 1e-12)), cost.data_ptr(), _stream()), 'tc_match_cost')
     if before_sync is not None:        # work the device can do while the host waits and solves the assignment
         before_sync()
+    if device_assign is None:
+        device_assign = DEVICE_ASSIGN
+    if device_assign and Q <= 1024 and Gmax <= min(128, Q):
+        return _loss_with_device_assignment(head, lib, all_cls, all_box, cost, cache, defer_guard)
     cost_h = cost.cpu().numpy()                                   # the iteration's one sync
     assigned = np.full((Lyr, B, Q), -1, dtype=np.int32)
     num_pos = np.zeros(Lyr, dtype=np.float32)
@@ -125,6 +136,46 @@ def detr_loss_device(head, all_cls, all_box, gt_bboxes_list, gt_labels_list, bef
     d_box = torch.where(fin[:, 1].view(Lyr, 1, 1, 1), torch.nan_to_num(d_box, nan=0.0, posinf=0.0, neginf=0.0),
                         torch.zeros_like(d_box))
     return loss_dict(losses.masked_fill(torch.isnan(losses), 0.0)), d_cls, d_box, assigned
+
+
+def _loss_with_device_assignment(head, lib, all_cls, all_box, cost, cache, defer_guard):
+    """cost matrix -> tc_lsa_assign -> losses + gradients, nothing leaves the device (no host sync)."""
+    dev = all_cls.device
+    Lyr, B, Q, ncls = all_cls.shape
+    code = all_box.shape[-1]
+    _, counts, Gmax, lab, cnt, gtn = cache[:6]
+    # one fill: [matched boxes per level x 2 | loss accumulators per level x 2 | status]
+    z = torch.zeros(4 * Lyr + 1, dtype=torch.float32, device=dev)
+    num_pos, losses, status = z[:2 * Lyr].view(Lyr, 2), z[2 * Lyr:4 * Lyr].view(Lyr, 2), z[4 * Lyr:].view(torch.int32)
+    asg = torch.empty((Lyr, B, Q), dtype=torch.int32, device=dev)
+    L.check(lib.tc_lsa_assign(cost.data_ptr(), cnt.data_ptr(), Lyr, B, Q, Gmax, asg.data_ptr(), num_pos.data_ptr(),
+                              status.data_ptr(), _stream()), 'tc_lsa_assign')
+    head.last_assign_status = status              # > 0: a sample had a non-finite cost (scipy would have raised)
+    avg = num_pos
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        # normalisers, HEAD:885-902: mean over ranks of the number of positives, at least 1 -- on the device tensor
+        box_avg = num_pos[:, 1].clone()
+        dist.all_reduce(box_avg, op=dist.ReduceOp.SUM)
+        box_avg = box_avg / dist.get_world_size()
+        cls_avg = box_avg if head.sync_cls_avg_factor else num_pos[:, 0]
+        avg = torch.stack((cls_avg, box_avg), dim=1).contiguous()          # (the kernel clamps at 1)
+    d_cls = torch.empty_like(all_cls)
+    d_box = torch.empty_like(all_box)
+    lc, lb = head.loss_cls_cfg, head.loss_bbox_cfg
+    L.check(lib.tc_detr_loss_fwd_bwd_counts(
+        all_cls.data_ptr(), all_box.data_ptr(), Lyr, B, Q, ncls, code, gtn.data_ptr(), lab.data_ptr(),
+        Gmax, asg.data_ptr(), avg.data_ptr(), head.code_weights.data_ptr(),
+        float(lc.get('alpha', 0.25)), float(lc.get('gamma', 2.0)), float(lc.get('loss_weight', 1.0)),
+        float(lb.get('loss_weight', 1.0)), losses.data_ptr(), d_cls.data_ptr(), d_box.data_ptr(),
+        _stream()), 'tc_detr_loss_fwd_bwd_counts')
+    if defer_guard:
+        return None, d_cls, d_box, asg, losses
+    fin = torch.isfinite(losses)
+    d_cls = torch.where(fin[:, 0].view(Lyr, 1, 1, 1), torch.nan_to_num(d_cls, nan=0.0, posinf=0.0, neginf=0.0),
+                        torch.zeros_like(d_cls))
+    d_box = torch.where(fin[:, 1].view(Lyr, 1, 1, 1), torch.nan_to_num(d_box, nan=0.0, posinf=0.0, neginf=0.0),
+                        torch.zeros_like(d_box))
+    return loss_dict(losses.masked_fill(torch.isnan(losses), 0.0)), d_cls, d_box, asg
 
 
 def loss_dict(losses):

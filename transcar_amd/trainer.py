@@ -113,9 +113,13 @@ def grad_table(head):
 class FusionTrainer:
     """head: transcar_amd.Detr3DHead on the GPU, built with ``train_cfg``."""
 
+    #: coefficient of the forward counter in Detr3DHead.next_dropout_seed: consecutive training forwards draw
+    #: seeds this far apart, which is what lets ONE launch give every frame of a look-ahead batch its own masks
+    SEED_STRIDE = 0x85EBCA77
+
     def __init__(self, head, lr=1.5e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01,
                  max_norm=35.0, device_loss=True, dropout=0.1, seed=0, decoder_dropout=None,
-                 chain_forward=True, chain_backward=True):
+                 chain_forward=True, chain_backward=True, prefetch_depth=1):
         self.head = head.freeze_decoder()
         self.bucket = FlatBucket(head.trainable_parameters())
         head.refresh_weights()                      # parameter addresses moved into the bucket
@@ -145,6 +149,16 @@ class FusionTrainer:
         # False = tc_radar_train_bwd, one launch per operator
         self.chain_backward = bool(chain_backward)
         self._sq_clean = False
+        # Look-ahead of the FROZEN decoder (tools/train.py:245-252: nothing an iteration trains feeds it).  1 = the next
+        # frame's decoder forward runs on a side stream during this iteration (round 3: one frame, 4-row tiles, 0.44 ms
+        # of a 1.0 ms iteration at 19 % of the matrix peak).  P > 1 (round 4): the decoder forwards of the next P
+        # frames as ONE batched launch sequence (16-row tiles on the f16 matrix cores, the inference rate), every
+        # frame with the dropout masks of its own seed (tc_head_options.dropout_seed_stride); the iterations then
+        # consume the batch frame by frame.  The decoder's arithmetic is fixed by the depth, not by whether a frame
+        # was prefetched (`decoder_tile_rows`): with P > 1 a frame that missed the look-ahead runs the same 16-row
+        # kernels alone, so losses and parameters do not depend on the schedule.
+        self.prefetch_depth = max(1, int(prefetch_depth))
+        self.decoder_tile_rows = 16 if self.prefetch_depth > 1 else None
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -163,63 +177,119 @@ class FusionTrainer:
     # ~160 autograd nodes; torch autograd only differentiates the loss itself
     # ------------------------------------------------------------------
     def _decoder_forward(self, feats_nhwc, lidar2img, img_hw, tokens, pad_mult, seed, lane):
+        """The frozen decoder (train mode) on B >= 1 frames; frame b draws the masks of seed + b * SEED_STRIDE."""
         from .detr3d_head import head_options
         with torch.no_grad():
             return self.head.forward_nhwc(feats_nhwc, lidar2img, img_hw, tokens, pad_mult, aux='train',
                                           _allow_train=True, decoder_only=True, lane=lane,
-                                          options=head_options(decoder_dropout_p=self.decoder_dropout,
-                                                               dropout_seed=seed))
+                                          options=head_options(tile_rows=self.decoder_tile_rows,
+                                                               decoder_dropout_p=self.decoder_dropout,
+                                                               dropout_seed=seed, dropout_seed_stride=self.SEED_STRIDE))
 
     @staticmethod
     def _input_key(feats_nhwc, lidar2img, tokens, pad_mult):
-        return (tuple(int(f.data_ptr()) for f in feats_nhwc), int(lidar2img.data_ptr()), int(tokens.data_ptr()),
+        # address, shape AND version counter: a loader that refills the same static tensors in place with the next
+        # frame must not get the decoder states of the old contents (ADVICE r3; a view shares its base's counter)
+        return (tuple((int(f.data_ptr()), int(f._version), tuple(f.shape)) for f in feats_nhwc),
+                (int(lidar2img.data_ptr()), int(lidar2img._version)), (int(tokens.data_ptr()), int(tokens._version)),
                 int(pad_mult), tuple(tokens.shape))
 
-    def prefetch_decoder(self, feats_nhwc, lidar2img, img_hw, tokens, pad_mult):
-        """Enqueue the FROZEN decoder's forward of the NEXT iteration now, on a side stream: it depends on nothing
+    def prefetch_decoder(self, feats_nhwc, lidar2img, img_hw, tokens, pad_mult, skip=0):
+        """Enqueue the FROZEN decoder's forward of the NEXT iteration(s) now, on a side stream: it depends on nothing
         this iteration trains (tools/train.py:245-252 freezes it), so it runs while the host waits for the cost
         matrix and solves the Hungarian assignment (device idle otherwise: ~0.25 ms of a 1.5 ms iteration) and
-        beside the backward.  The inputs must stay untouched until that iteration; its dropout seed is drawn here
-        (same order of seeds as without prefetching).  step_fused_nhwc(prefetch=...) calls this at the right
-        moment."""
+        beside the backward.  The tensors hold the next P >= 1 frames (batch dimension P: a loader's look-ahead,
+        collated); the following P calls of step_fused_nhwc pick their frame up when they are handed the
+        corresponding slices (``feats[6 i : 6 i + 6]``, ``lidar2img[i : i + 1]``, ``tokens[i : i + 1]``), in order.
+        The inputs must stay untouched until then.  The dropout seeds are those the P iterations would draw
+        themselves: the forward counter is NOT advanced here but when a frame is consumed, and a look-ahead whose
+        seeds no longer match the counter (another training forward came in between) is dropped.
+        skip: frames of an earlier look-ahead still to be consumed before these (their iterations draw the seeds in
+        between).  step_fused_nhwc(prefetch=...) calls this at the right moment."""
         head = self.head
         if not head.training:
             head.train()
         cur = torch.cuda.current_stream()
         if getattr(self, '_pre_stream', None) is None:
             self._pre_stream = torch.cuda.Stream()
-        seed = head.next_dropout_seed()
-        lane = 1 - getattr(self, '_lane', 0)
+        P = int(lidar2img.shape[0])
+        ncam = feats_nhwc[0].shape[0] // P
+        counter0 = getattr(head, '_train_forwards', 0) + int(skip)
+        seed0 = head.peek_dropout_seed(1 + int(skip))          # the seed of the training forward that takes frame 0
+        pend = getattr(self, '_pre', None)
+        lane = 1 - (pend['lane'] if pend is not None else getattr(self, '_lane', 0))
         self._pre_stream.wait_stream(cur)                      # inputs written on the current stream are complete
         with torch.cuda.stream(self._pre_stream):
-            base = self._decoder_forward(feats_nhwc, lidar2img, img_hw, tokens, pad_mult, seed, lane)
+            base = self._decoder_forward(feats_nhwc, lidar2img, img_hw, tokens, pad_mult, seed0, lane)
             ev = torch.cuda.Event()
             ev.record(self._pre_stream)
         for t in base['aux'].values():
             if torch.is_tensor(t):
                 t.record_stream(cur)                           # allocated on the side stream, consumed on this one
-        self._pre = dict(key=self._input_key(feats_nhwc, lidar2img, tokens, pad_mult), seed=seed, base=base, ev=ev,
-                         lane=lane)
+        keys = [self._input_key([f[ncam * i:ncam * (i + 1)] for f in feats_nhwc], lidar2img[i:i + 1], tokens[i:i + 1],
+                                pad_mult) for i in range(P)]
+        new = dict(keys=keys, seed0=seed0, counter0=counter0, base=base, ev=ev, lane=lane, next=0, count=P)
+        if pend is not None and skip:
+            self._pre_next = new                               # behind the frames of the look-ahead in use
+        else:
+            self._pre, self._pre_next = new, None
+
+    def _take_prefetched(self, feats_nhwc, lidar2img, tokens, pad_mult):
+        """-> (aux of this frame, its dropout seed) from the pending look-ahead, or None."""
+        pre = getattr(self, '_pre', None)
+        if pre is None and getattr(self, '_pre_next', None) is not None:
+            pre = self._pre = self._pre_next
+            self._pre_next = None
+        if pre is None:
+            return None
+        head, i = self.head, pre['next']
+        ok = (i < pre['count'] and getattr(head, '_train_forwards', 0) == pre['counter0'] + i and
+              lidar2img.shape[0] == 1 and pre['keys'][i] == self._input_key(feats_nhwc, lidar2img, tokens, pad_mult))
+        if not ok:
+            self._pre = self._pre_next = None                  # stale: nothing was drawn from the seed counter for it
+            return None
+        if i == 0:
+            torch.cuda.current_stream().wait_event(pre['ev'])
+            self._lane = pre['lane']
+        seed = head.next_dropout_seed()
+        assert seed == (pre['seed0'] + i * self.SEED_STRIDE) & 0xFFFFFFFFFFFFFFFF
+        aux = pre['base']['aux']
+        out = dict(inter_states=aux['inter_states'][:, i:i + 1], inter_references=aux['inter_references'][:, i:i + 1],
+                   last_box=aux['last_box'][i:i + 1])
+        pre['next'] = i + 1
+        if pre['next'] >= pre['count']:
+            self._pre, self._pre_next = getattr(self, '_pre_next', None), None
+        self.lookahead_hits = getattr(self, 'lookahead_hits', 0) + 1
+        return out, seed
+
+    def lookahead_pending(self):
+        """Frames of look-ahead batches not consumed yet."""
+        n = 0
+        for pre in (getattr(self, '_pre', None), getattr(self, '_pre_next', None)):
+            if pre is not None:
+                n += pre['count'] - pre['next']
+        return n
 
     def step_fused_nhwc(self, feats_nhwc, lidar2img, img_hw, tokens, pad_mult, gt_bboxes_list,
                         gt_labels_list, lr=None, update=True, prefetch=None):
         """update=False stops after the backward: the gradients sit in the bucket.
-        prefetch: dict(feats_nhwc, lidar2img, img_hw, tokens, pad_mult) of the NEXT iteration's frame: its frozen
-        decoder forward is enqueued on a side stream once this iteration's cost matrix is on its way
-        (``prefetch_decoder``); the next call picks the result up when it is handed the same tensors."""
+        prefetch: dict(feats_nhwc, lidar2img, img_hw, tokens, pad_mult) of the NEXT iteration's frame -- or, with
+        ``prefetch_depth`` P > 1, of the next P frames (batch dimension P): their frozen decoder forward is enqueued
+        on a side stream once this iteration's cost matrix is on its way (``prefetch_decoder``), as ONE batched
+        launch sequence; the following calls pick their frame up when they are handed the same tensors (the
+        slices of the batch, in order).  A callable is called as ``prefetch(skip)`` (-> the dict) only when a look-ahead
+        is started: the frames that follow the `skip` frames of the look-ahead still in use (P > 1: the next batch is
+        started one iteration before the current one runs out)."""
         head, lib = self.head, L.lib()
         if not head.training:                      # (Module.train() walks ~380 submodules: 0.7 ms of host time per call)
             head.train()
-        pre, self._pre = getattr(self, '_pre', None), None
-        if pre is not None and pre['key'] == self._input_key(feats_nhwc, lidar2img, tokens, pad_mult):
-            torch.cuda.current_stream().wait_event(pre['ev'])
-            base, drop_seed, self._lane = pre['base'], pre['seed'], pre['lane']
-            head.last_dropout_seed = drop_seed
+        got = self._take_prefetched(feats_nhwc, lidar2img, tokens, pad_mult)
+        if got is not None:
+            aux, drop_seed = got
         else:
             drop_seed = head.next_dropout_seed()   # (seed, rank, forward counter): shared with forward_train_nhwc
-            base = self._decoder_forward(feats_nhwc, lidar2img, img_hw, tokens, pad_mult, drop_seed,
-                                         getattr(self, '_lane', 0))
-        aux = base['aux']
+            aux = self._decoder_forward(feats_nhwc, lidar2img, img_hw, tokens, pad_mult, drop_seed,
+                                        getattr(self, '_lane', 0))['aux']
         w = head.head_weights()
         B, T = lidar2img.shape[0], tokens.shape[1]
         hs_last = aux['inter_states'][-1].contiguous()
@@ -254,7 +324,16 @@ class FusionTrainer:
         raw_losses = None
         if self.device_loss:
             from .device_loss import detr_loss_device
-            hook = (lambda: self.prefetch_decoder(**prefetch)) if prefetch is not None else None
+            # (a callable is asked for the frames only when a look-ahead is really started: a loader hands over the
+            # window that FOLLOWS the frame this iteration trains on)
+            # a batched look-ahead (P > 1) is started ONE iteration before the frames in use run out: the batch is
+            # ~1.2 ms of device work beside a 1 ms iteration, and the iteration that takes its first frame would wait
+            # for all of it (measured: 1.70 instead of 0.96 ms once per batch)
+            pend = self.lookahead_pending()
+            start = prefetch is not None and getattr(self, '_pre_next', None) is None and \
+                pend <= (1 if self.prefetch_depth > 1 else 0)
+            hook = (lambda: self.prefetch_decoder(skip=pend, **(prefetch(pend) if callable(prefetch) else prefetch))) \
+                if start else None
             if self.chain_backward:      # the non-finite guard of the loss gradients happens inside the backward chain
                 losses, d_cls, d_box, _, raw_losses = detr_loss_device(
                     head, all_cls, all_box, gt_bboxes_list, gt_labels_list, before_sync=hook, defer_guard=True)
