@@ -311,6 +311,14 @@ int tc_decoder_layer_tail_fwd(const tc_decoder_layer* layer, const tc_linear* ne
  *   out [B*Q, ldo]. */
 int tc_sdpa_fwd(const float* q, const float* k, int ld, const float* vt, int ldt,
                 float* out, int ldo, int B, int Q, int num_heads, tc_stream_t stream);
+/* The same core on the f16 matrix cores with fp32 accuracy (round 4; what tc_head_forward runs in launches with
+ * 16-row tiles unless options.matrix_path = TC_MATRIX_F32): q | k rows [B*Q, 2C] token-major (q at columns 0..C-1,
+ * pre-scaled as above, k at C..2C-1), vt as above.  One conversion launch writes the operands as two f16 planes
+ * (hi, 2^11-scaled residual) into `workspace`, the attention launch computes every product from three
+ * v_mfma_f32_16x16x32_f16 with fp32 accumulation.  |q|, |k|, |v| must stay below 65 504. */
+size_t tc_sdpa_f16x2_workspace_bytes(int B, int Q, int num_heads);
+int tc_sdpa_fwd_f16x2(const float* qk, const float* vt, int ldt, float* out, int ldo, int B, int Q, int num_heads,
+                      void* workspace, size_t workspace_bytes, tc_stream_t stream);
 
 /* Distance-gated radar cross-attention, one fusion layer's attention step
  * (HEAD:549-581 / :619-653 / :675-711): three-circle gate around

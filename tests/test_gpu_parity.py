@@ -877,8 +877,9 @@ def test_missing_gpu_inputs_fail_loudly(T, head):
         head(feats, synth.make_img_metas(1, radar=synth.make_radar_frame()))
 
 
+@pytest.mark.parametrize('matrix', ['f32', 'f16x2'])
 @pytest.mark.parametrize('case', ['ramp_up', 'ramp_down', 'huge_negative_start', 'spikes', 'short_ragged'])
-def test_sdpa_lazy_recentring_extreme_scores(T, case):
+def test_sdpa_lazy_recentring_extreme_scores(T, case, matrix):
     """The attention core re-centres its running reference only when a score exceeds it by 2^8
     (self_attn.hip): score sequences built to stress that -- monotone ramps over the keys (every tile
     above / below the last), a first tile hundreds of octaves below the rest, isolated spikes, a key
@@ -904,7 +905,7 @@ def test_sdpa_lazy_recentring_extreme_scores(T, case):
     qpad = ((Q + 15) // 16) * 16
     vt = torch.zeros((B, C, qpad), dtype=torch.float32)
     vt[:, :, :Q] = torch.from_numpy(v).permute(0, 2, 1)
-    got = ops.sdpa(gpu(qs), gpu(k), gpu(vt)).cpu().double()
+    got = ops.sdpa(gpu(qs), gpu(k), gpu(vt), matrix_path=matrix).cpu().double()
     qd = torch.from_numpy(q).double().view(B, Q, H, D).permute(0, 2, 1, 3)
     kd = torch.from_numpy(k).double().view(B, Q, H, D).permute(0, 2, 1, 3)
     vd = torch.from_numpy(v).double().view(B, Q, H, D).permute(0, 2, 1, 3)

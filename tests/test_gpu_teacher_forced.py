@@ -119,7 +119,7 @@ def test_decoder_layers_teacher_forced_on_bench_inputs(rig, tile_rows, matrix):
         x_prev = qe[:, 256:][None] if lid == 0 else rig['hs'][lid - 1].permute(1, 0, 2)   # [1,Q,C]
         ref_prev = rig['init_ref'] if lid == 0 else rig['inter_refs'][lid - 1]
         q, k, vt = _qkv_from_oracle_state(sd, lid, x_prev, pos)
-        attn_o = ops.sdpa(gpu(q), gpu(k), gpu(vt))
+        attn_o = ops.sdpa(gpu(q), gpu(k), gpu(vt), matrix_path='f16x2' if matrix == 'f16x2' else 'f32')
         nxt = pv.layers[lid + 1].self_attn.in_proj if lid + 1 < L else None
         hs, ref_out, qk_next, vt_next = ops.decoder_layer_tail(
             pv.layers[lid], nxt, rig['nhwc'], attn_o, gpu(x_prev), gpu(qe), l2i, gpu(ref_prev), PCR, HW,
@@ -164,15 +164,17 @@ def test_decoder_layers_teacher_forced_on_bench_inputs(rig, tile_rows, matrix):
     print('\n'.join(['teacher-forced decoder layers on the bench workload:'] + report))
 
 
-def test_attention_core_teacher_forced(rig):
-    """tc_sdpa_fwd + out_proj residual on the oracle's layer-3 input vs torch MHA semantics."""
+@pytest.mark.parametrize('matrix', ['f32', 'f16x2'])
+def test_attention_core_teacher_forced(rig, matrix):
+    """tc_sdpa_fwd (fp32 MFMA) / tc_sdpa_fwd_f16x2 (two-plane f16 operands on the matrix cores, round 4) + out_proj
+    residual on the oracle's layer-3 input vs torch MHA semantics: the same tolerance for both."""
     ops = head_ops()
     sd = rig['sd']
     qe = sd['query_embedding.weight']
     pos = qe[:, :256][None]
     x_prev = rig['hs'][2].permute(1, 0, 2)
     q, k, vt = _qkv_from_oracle_state(sd, 3, x_prev, pos)
-    attn_o = ops.sdpa(gpu(q), gpu(k), gpu(vt)).cpu()
+    attn_o = ops.sdpa(gpu(q), gpu(k), gpu(vt), matrix_path=matrix).cpu()
     name = 'transformer.decoder.layers.3.attentions.0.attn'
     got = F.linear(attn_o, sd[name + '.out_proj.weight'], sd[name + '.out_proj.bias'])
     qk_in = (x_prev + pos).permute(1, 0, 2)

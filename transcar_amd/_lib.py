@@ -155,6 +155,8 @@ SIGNATURES = {
                                        _vp, _vp, _vp, _vp, _P(_f), _f, _f, _vp,
                                        _vp, _vp, _vp, _i, _i, _vp]),
     'tc_sdpa_fwd': (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    'tc_sdpa_f16x2_workspace_bytes': (_sz, [_i, _i, _i]),
+    'tc_sdpa_fwd_f16x2': (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     'tc_radar_xattn_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'tc_radar_gate_selfcheck': (_i, [_i, C.c_ulonglong, _vp, _vp]),
     'tc_radar_gated_xattn_fwd': (_i, [_P(tc_mha), _vp, _vp, _vp, _i, _vp, _vp,

@@ -225,6 +225,10 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
       d.drop = make_drop(opt.decoder_dropout_p, opt.dropout_seed, 16u + 8u * (unsigned)lid, 0u);
       if (opt.dropout_seed_stride != 0) { d.drop.seed_stride = opt.dropout_seed_stride; d.drop.rows_per_sample = (unsigned)Q; }
     }
+    // (the attention core stays on the fp32 MFMA: its two-plane f16 form, tc_sdpa_fwd_f16x2, is exact and tested but
+    // not faster at 900 queries -- 78 us + a 10 us conversion pass against 84 us per nine frames: with 203 VGPRs one
+    // workgroup per CU, and the kernel is bound by the latency of its dependent chain, not by the matrix pipe;
+    // tools/experiments/README.md)
     if (!l0c) TC_TRY(launch_self_attn_core(h.qk, h.qk + C, 2 * C, h.vt, h.qpad, h.attn_o, C, B, Q, H, s,
                                            ddrop ? &d.drop : nullptr));
     d.attn_o = l0c ? w->l0_attn_out : h.attn_o;
@@ -486,6 +490,13 @@ int tc_decoder_layer_tail_fwd(const tc_decoder_layer* layer, const tc_linear* ne
 int tc_sdpa_fwd(const float* q, const float* k, int ld, const float* vt, int ldt, float* out, int ldo,
                 int B, int Q, int num_heads, tc_stream_t stream) {
   return launch_self_attn_core(q, k, ld, vt, ldt, out, ldo, B, Q, num_heads, as_stream(stream));
+}
+
+size_t tc_sdpa_f16x2_workspace_bytes(int B, int Q, int num_heads) { return self_attn_h_ws_bytes(B, Q, num_heads); }
+
+int tc_sdpa_fwd_f16x2(const float* qk, const float* vt, int ldt, float* out, int ldo, int B, int Q, int num_heads,
+                      void* workspace, size_t workspace_bytes, tc_stream_t stream) {
+  return launch_self_attn_core_h(qk, vt, ldt, out, ldo, B, Q, num_heads, workspace, workspace_bytes, as_stream(stream));
 }
 
 size_t tc_radar_xattn_workspace_bytes(int B, int Q, int T, int C) {

@@ -200,14 +200,20 @@ def self_attn(mha, x, pos, num_heads=8):
     return out
 
 
-def sdpa(q, k, vt, num_heads=8):
-    """The self-attention core on projected operands (tc_sdpa_fwd):
+def sdpa(q, k, vt, num_heads=8, matrix_path='f32'):
+    """The self-attention core on projected operands (tc_sdpa_fwd; matrix_path='f16x2': tc_sdpa_fwd_f16x2, the
+    same on the f16 matrix cores with two-plane operands):
     q, k [B,Q,C] token-major (q pre-scaled by log2(e)/sqrt(head_dim)),
     vt [B,C,qpad] = V transposed, qpad = round_up(Q,16) -> [B,Q,C]."""
     B, Q, Cdim = q.shape
     qk = torch.cat((q, k), -1).contiguous()                 # the layout the chains produce
     _chk(qk, 'qk'); _chk(vt, 'vt')
     out = torch.empty((B, Q, Cdim), dtype=torch.float32, device=q.device)
+    if matrix_path == 'f16x2':
+        ws = torch.empty(L.lib().tc_sdpa_f16x2_workspace_bytes(B, Q, num_heads), dtype=torch.uint8, device=q.device)
+        L.check(L.lib().tc_sdpa_fwd_f16x2(qk.data_ptr(), _p(vt), vt.shape[-1], _p(out), Cdim, B, Q, num_heads,
+                                          ws.data_ptr(), ws.numel(), _stream()), 'tc_sdpa_fwd_f16x2')
+        return out
     L.check(L.lib().tc_sdpa_fwd(qk.data_ptr(), qk.data_ptr() + 4 * Cdim, 2 * Cdim, _p(vt),
                                 vt.shape[-1], _p(out), Cdim, B, Q, num_heads, _stream()),
             'tc_sdpa_fwd')
