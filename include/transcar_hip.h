@@ -383,6 +383,18 @@ int tc_box_decode_topk(const float* cls_scores /*[B,Q,num_classes]*/,
                        const float* post_center_range /*host[6]*/,
                        float* boxes, float* scores, int* labels, unsigned char* valid,
                        void* workspace, size_t workspace_bytes, tc_stream_t stream);
+/* The same selection, returned the way NMSFreeCoder.decode_single returns it (CODER:62-84): only the rows inside
+ * post_center_range (tested on the un-shifted centre) and, with use_threshold, with score > score_threshold --
+ * compacted in descending score order -- and their number.  The caller reads kept_count[b] (one small D2H for the
+ * batch) and takes the first kept_count[b] rows: no mask select, no gather.
+ *   kept_boxes [B,max_num,9], kept_scores [B,max_num], kept_labels [B,max_num] (64-bit: torch.long, CODER:54),
+ *   kept_count [B]; rows kept_count[b] .. max_num-1 are left unwritten.
+ *   z_shift 1: z -= h/2 (get_bboxes, HEAD:1018); 0: gravity-centre z as the coder itself returns it. */
+int tc_box_decode_kept(const float* cls_scores, const float* bbox_preds, int B, int Q, int num_classes,
+                       int code_size, int max_num, const float* post_center_range /*host[6]*/,
+                       float score_threshold, int use_threshold, int z_shift,
+                       float* kept_boxes, float* kept_scores, long long* kept_labels, int* kept_count,
+                       tc_stream_t stream);
 
 /* ---- the whole hot path: Detr3DHead.forward (HEAD:248-740), eval mode ----
  *   radar_tokens [B,T,36]: rows of the 36 hand-built features (HEAD:499-510),

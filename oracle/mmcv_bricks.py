@@ -6,7 +6,8 @@ The reference's ``mmdetection3d`` submodule is empty and un-pinned
 These classes restate the published semantics of the bricks configured at
 projects/configs/detr3d/detr3d_res101_gridmask.py:65-82 (SURVEY.md Appendix
 B): parity for this file is UNPINNED by the reference; it is cross-checked
-against stock ``torch.nn`` modules in tests/test_oracle_bricks.py.
+against stock ``torch.nn`` modules (``nn.TransformerDecoderLayer`` for the
+post-norm layer) in tests/test_oracle_bricks.py.
 
 Sub-module names (``attentions``, ``attn``, ``ffns``, ``layers``, ``norms``)
 follow mmcv so that state_dict keys equal those of a TransCAR checkpoint.
@@ -27,7 +28,10 @@ class Registry:
 
     def register_module(self, name=None, force=False, module=None):
         def _reg(cls):
-            self.module_dict[name or cls.__name__] = cls
+            key = name or cls.__name__
+            if not force and key in self.module_dict:       # mmcv: a second class under one name is an error
+                raise KeyError('%s is already registered in %s' % (key, self.name))
+            self.module_dict[key] = cls
             return cls
         if module is not None:
             return _reg(module)

@@ -869,6 +869,26 @@ def test_box_decode_ties_and_batches(T, case):
         if kk < 300:
             assert np.all(labels[b].cpu().numpy()[kk:] == -1) and not valid[b].cpu().numpy()[kk:].any()
             assert np.all(scores[b].cpu().numpy()[kk:] == 0)
+    # tc_box_decode_kept: what NMSFreeCoder.decode_single returns (CODER:62-84) -- the rows inside post_center_range
+    # (and above the threshold, strictly) compacted in score order, their number, int64 labels; bit-identical to a
+    # mask select over the fixed-size rows.  z_shift 0 = the coder's own gravity-centre z
+    for thr in (None, 0.0, float(np.median(scores.cpu().numpy()))):
+        for z_shift in (True, False):
+            kb, ks, kl, kc = ops.box_decode_kept(gpu(cls), gpu(box), pcr, 300, score_threshold=thr, z_shift=z_shift)
+            assert kl.dtype == torch.int64 and kc.dtype == torch.int32
+            for b in range(B):
+                m = valid[b].bool()
+                if thr:
+                    m = m & (scores[b] > thr)
+                n = int(kc[b])
+                assert n == int(m.sum())
+                want = boxes[b][m].clone()
+                if not z_shift:
+                    want[:, 2] = boxes[b][m][:, 2] + boxes[b][m][:, 5] * 0.5
+                    assert float((kb[b, :n] - want).abs().max() if n else 0.0) < 2e-6
+                else:
+                    assert torch.equal(kb[b, :n], want)
+                assert torch.equal(ks[b, :n], scores[b][m]) and torch.equal(kl[b, :n], labels[b][m].long())
 
 
 def test_missing_gpu_inputs_fail_loudly(T, head):

@@ -167,6 +167,7 @@ SIGNATURES = {
     'tc_box_decode_workspace_bytes': (_sz, [_i, _i, _i]),
     'tc_box_decode_topk': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _P(_f), _vp,
                                 _vp, _vp, _vp, _vp, _sz, _vp]),
+    'tc_box_decode_kept': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _P(_f), _f, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'tc_head_workspace_bytes': (_sz, [_P(tc_head_weights), _i, _i]),
     'tc_head_packed_bytes': (_sz, [_P(tc_head_weights)]),
     'tc_head_pack_weights': (_i, [_P(tc_head_weights), _vp, _sz,

@@ -22,7 +22,11 @@ constexpr int DEC_PASSES = 9;     // the bucket pass + up to eight byte passes (
 struct DecK {
   const float* cls; const float* box; int Q, ncls, code, K;
   float pcr[6];
-  float* boxes; float* scores; int* labels; unsigned char* valid;
+  float* boxes; float* scores; int* labels; unsigned char* valid;      // fixed-size rows + mask (may be null)
+  // round 4: the rows NMSFreeCoder keeps (inside post_center_range, above the score threshold), compacted in score
+  // order, and their number -- what decode_single returns (CODER:66-84) without a mask select on the host side
+  float* kboxes; float* kscores; long long* klabels; int* kcount;      // (may be null)
+  float thr; int use_thr; int z_shift;
 };
 
 #ifdef TC_CHAIN_STAMPS
@@ -36,6 +40,7 @@ struct DecLds {
   alignas(16) unsigned int hist[DEC_PASSES][256];
   alignas(16) unsigned long long sel[DEC_MAXK];      // survivors, any order; zero behind them
   unsigned int rank[DEC_MAXK];                       // survivor -> its place in descending order
+  unsigned long long keep[DEC_MAXK / 64];            // bit i: output row i is kept
   unsigned int count, ccount;
 };
 
@@ -67,6 +72,7 @@ __global__ __launch_bounds__(DEC_THREADS) void box_decode_kernel(DecK p) {
   for (int i = tid; i < DEC_PASSES * 256; i += DEC_THREADS) (&S.hist[0][0])[i] = 0u;
   for (int i = tid; i < DEC_MAXK; i += DEC_THREADS) { S.sel[i] = 0ull; S.rank[i] = 0u; }
   if (tid == 0) { S.count = 0u; S.ccount = 0u; }
+  if (tid < DEC_MAXK / 64) S.keep[tid] = 0ull;
   unsigned long long key[DEC_NK];
 #pragma unroll
   for (int j = 0; j < DEC_NK; ++j) {
@@ -221,32 +227,58 @@ __global__ __launch_bounds__(DEC_THREADS) void box_decode_kernel(DecK p) {
   __syncthreads();
   DEC_STAMP(13);
   // thread t decodes survivor t into output row rank[t]; rows K .. max_num - 1 (fewer candidates than max_num): zeros
-  for (int t = tid; t < p.K; t += DEC_THREADS) {
-    const int i = t < K ? (int)S.rank[t] : t;
-    float* ob = p.boxes + ((size_t)b * p.K + i) * 9;
-    if (t >= K) {
-      for (int j = 0; j < 9; ++j) ob[j] = 0.f;
-      p.scores[(size_t)b * p.K + i] = 0.f; p.labels[(size_t)b * p.K + i] = -1;
-      p.valid[(size_t)b * p.K + i] = 0;
-      continue;
+  // (max_num <= DEC_MAXK < DEC_THREADS: one survivor per thread at most)
+  {
+    const int t = tid;
+    const bool row = t < p.K, have = t < K;
+    const int i = have ? (int)S.rank[t] : t;
+    float o[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float score = 0.f;
+    int label = -1;
+    bool ok = false;
+    if (have) {
+      const unsigned long long k = S.sel[t];
+      const int idx = (int)(0xFFFFFFFFu - (unsigned int)(k & 0xFFFFFFFFull));
+      score = __uint_as_float((unsigned int)(k >> 32));
+      label = idx % p.ncls;
+      const float* nb = p.box + ((size_t)b * p.Q + idx / p.ncls) * p.code;
+      // UTIL:26-52
+      const float rot = atan2f(nb[6], nb[7]);
+      const float cx = nb[0], cy = nb[1], cz = nb[4];
+      const float w = expf(nb[2]), l = expf(nb[3]), h = expf(nb[5]);
+      ok = cx >= p.pcr[0] && cy >= p.pcr[1] && cz >= p.pcr[2] && cx <= p.pcr[3] && cy <= p.pcr[4] && cz <= p.pcr[5];
+      o[0] = cx; o[1] = cy; o[2] = p.z_shift ? cz - h * 0.5f : cz;   // HEAD:1018
+      o[3] = w; o[4] = l; o[5] = h; o[6] = rot;
+      o[7] = p.code > 8 ? nb[8] : 0.f; o[8] = p.code > 9 ? nb[9] : 0.f;
     }
-    const unsigned long long k = S.sel[t];
-    const int idx = (int)(0xFFFFFFFFu - (unsigned int)(k & 0xFFFFFFFFull));
-    const float score = __uint_as_float((unsigned int)(k >> 32));
-    const int label = idx % p.ncls, bi = idx / p.ncls;
-    const float* nb = p.box + ((size_t)b * p.Q + bi) * p.code;
-    // UTIL:26-52
-    const float rot = atan2f(nb[6], nb[7]);
-    const float cx = nb[0], cy = nb[1], cz = nb[4];
-    const float w = expf(nb[2]), l = expf(nb[3]), h = expf(nb[5]);
-    const bool ok = cx >= p.pcr[0] && cy >= p.pcr[1] && cz >= p.pcr[2] && cx <= p.pcr[3] &&
-                    cy <= p.pcr[4] && cz <= p.pcr[5];
-    ob[0] = cx; ob[1] = cy; ob[2] = cz - h * 0.5f;   // HEAD:1018
-    ob[3] = w; ob[4] = l; ob[5] = h; ob[6] = rot;
-    ob[7] = p.code > 8 ? nb[8] : 0.f; ob[8] = p.code > 9 ? nb[9] : 0.f;
-    p.scores[(size_t)b * p.K + i] = score;
-    p.labels[(size_t)b * p.K + i] = label;
-    p.valid[(size_t)b * p.K + i] = ok ? 1 : 0;
+    if (row && p.boxes != nullptr) {
+      float* ob = p.boxes + ((size_t)b * p.K + i) * 9;
+#pragma unroll
+      for (int j = 0; j < 9; ++j) ob[j] = o[j];
+      p.scores[(size_t)b * p.K + i] = score; p.labels[(size_t)b * p.K + i] = label;
+      p.valid[(size_t)b * p.K + i] = ok ? 1 : 0;
+    }
+    if (p.kboxes != nullptr) {                      // (uniform)
+      // CODER:62-76: the range mask is taken on the coder's own (un-shifted) centre, the threshold is strict
+      const bool kept = have && ok && (!p.use_thr || score > p.thr);
+      if (kept) atomicOr(&S.keep[i >> 6], 1ull << (i & 63));
+      __syncthreads();
+      int below_words = 0, total = 0;
+#pragma unroll
+      for (int wd = 0; wd < DEC_MAXK / 64; ++wd) {
+        const int c = __popcll(S.keep[wd]);
+        total += c;
+        if (wd < (i >> 6)) below_words += c;
+      }
+      if (kept) {
+        const int pos = below_words + __popcll(S.keep[i >> 6] & ((1ull << (i & 63)) - 1ull));
+        float* ob = p.kboxes + ((size_t)b * p.K + pos) * 9;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) ob[j] = o[j];
+        p.kscores[(size_t)b * p.K + pos] = score; p.klabels[(size_t)b * p.K + pos] = (long long)label;
+      }
+      if (tid == 0) p.kcount[b] = total;
+    }
   }
   DEC_STAMP(14);
 }
@@ -261,7 +293,7 @@ size_t box_decode_ws_bytes(int, int, int) { return 256; }
 
 int launch_box_decode(const float* cls, const float* box, int B, int Q, int ncls, int code,
                       int max_num, const float* pcr6_host, float* boxes, float* scores, int* labels,
-                      unsigned char* valid, void*, size_t, hipStream_t s) {
+                      unsigned char* valid, void*, size_t, hipStream_t s, const BoxDecodeKept* kept) {
   TC_REQUIRE(Q * ncls <= DEC_MAXN, "box_decode: Q*num_classes=%d > %d", Q * ncls, DEC_MAXN);
   TC_REQUIRE(max_num >= 1 && max_num <= DEC_MAXK, "box_decode: max_num=%d (1..%d)", max_num, DEC_MAXK);
   TC_REQUIRE(code >= 8, "box_decode: code_size=%d", code);
@@ -269,6 +301,14 @@ int launch_box_decode(const float* cls, const float* box, int B, int Q, int ncls
   p.cls = cls; p.box = box; p.Q = Q; p.ncls = ncls; p.code = code; p.K = max_num;
   for (int i = 0; i < 6; ++i) p.pcr[i] = pcr6_host[i];
   p.boxes = boxes; p.scores = scores; p.labels = labels; p.valid = valid;
+  TC_REQUIRE(boxes == nullptr || (scores != nullptr && labels != nullptr && valid != nullptr), "box_decode: fixed-size outputs come together");
+  p.kboxes = nullptr; p.kscores = nullptr; p.klabels = nullptr; p.kcount = nullptr; p.thr = 0.f; p.use_thr = 0; p.z_shift = 1;
+  if (kept != nullptr) {
+    TC_REQUIRE(kept->boxes && kept->scores && kept->labels && kept->count, "box_decode: kept outputs come together");
+    p.kboxes = kept->boxes; p.kscores = kept->scores; p.klabels = kept->labels; p.kcount = kept->count;
+    p.thr = kept->score_threshold; p.use_thr = kept->use_threshold; p.z_shift = kept->z_shift;
+  }
+  TC_REQUIRE(boxes != nullptr || kept != nullptr, "box_decode: no output");
   const size_t lds = (size_t)((Q * ncls + 1) & ~1) * 8;
   static DeviceOnce once;
   if (const int once_dev = once.need(); once_dev >= 0) {

@@ -631,6 +631,15 @@ int tc_box_decode_topk(const float* cls_scores, const float* bbox_preds, int B, 
                            workspace_bytes, as_stream(stream));
 }
 
+int tc_box_decode_kept(const float* cls_scores, const float* bbox_preds, int B, int Q, int num_classes, int code_size,
+                       int max_num, const float* post_center_range, float score_threshold, int use_threshold,
+                       int z_shift, float* kept_boxes, float* kept_scores, long long* kept_labels, int* kept_count,
+                       tc_stream_t stream) {
+  BoxDecodeKept k{kept_boxes, kept_scores, kept_labels, kept_count, score_threshold, use_threshold, z_shift};
+  return launch_box_decode(cls_scores, bbox_preds, B, Q, num_classes, code_size, max_num, post_center_range,
+                           nullptr, nullptr, nullptr, nullptr, nullptr, 0, as_stream(stream), &k);
+}
+
 size_t tc_head_packed_bytes(const tc_head_weights* w) {
   if (check_dims(w) != 0) return 0;
   tc_head_weights view = *w;

@@ -247,9 +247,16 @@ int launch_radar_ingest_batch(const double* raw, const double* times, const tc_r
                               float* tokens, int T, int* count, hipStream_t s);
 
 // ---- decode.hip ------------------------------------------------------------
+// the rows NMSFreeCoder keeps, compacted in score order (CODER:62-84): [B,max_num,9] / [B,max_num] / [B,max_num]
+// int64 (the reference's labels are torch.long) and count [B]; rows count[b] .. max_num-1 are not written
+struct BoxDecodeKept {
+  float* boxes; float* scores; long long* labels; int* count;
+  float score_threshold; int use_threshold;     // CODER:63-64, 73-74: strict `>`; off for None / 0
+  int z_shift;                                  // 1: z -= h / 2 (get_bboxes, HEAD:1018); 0: the coder's own output
+};
 int launch_box_decode(const float* cls, const float* box, int B, int Q, int ncls, int code,
                       int max_num, const float* pcr6_host, float* boxes, float* scores, int* labels,
-                      unsigned char* valid, void* ws, size_t ws_bytes, hipStream_t s);
+                      unsigned char* valid, void* ws, size_t ws_bytes, hipStream_t s, const BoxDecodeKept* kept = nullptr);
 size_t box_decode_ws_bytes(int B, int Q, int ncls);
 
 }  // namespace tc

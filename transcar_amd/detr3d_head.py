@@ -457,8 +457,9 @@ class Detr3DHead(BaseModule):
             options = head_options()
         ws = self._workspace[key]
         Q, ncls, code = self.num_query, self.cls_out_channels, self.code_size
-        cls = torch.empty((3, B, Q, ncls), dtype=torch.float32, device=dev)
-        box = torch.empty((3, B, Q, code), dtype=torch.float32, device=dev)
+        out = torch.empty(3 * B * Q * (ncls + code), dtype=torch.float32, device=dev)     # one allocation, two views
+        cls = out[:3 * B * Q * ncls].view(3, B, Q, ncls)
+        box = out[3 * B * Q * ncls:].view(3, B, Q, code)
         fv = ops.feats_view(feats_nhwc)
         aux_s, aux_t = None, None
         if aux == 'train':
@@ -533,7 +534,7 @@ class Detr3DHead(BaseModule):
                 'Detr3DHead.forward needs the feature maps on the MI355X '
                 '(got %s); transcar_amd has no CPU path' % dev)
         feats_nhwc = ops.to_nhwc_levels(mlvl_feats)       # one launch; channels_last levels zero-copy
-        l2i = ops.lidar2img_tensor(img_metas, dev)
+        l2i = ops.lidar2img_tensor(img_metas, dev, staged=True)    # pinned ring, one async H2D (none if unchanged)
         img_hw = img_metas[0]['img_shape'][0][:2]           # XFMR:403-404
         raws = []
         for m in img_metas:

@@ -1,7 +1,7 @@
 """NMSFreeCoder, mirror of
 projects/mmdet3d_plugin/core/bbox/coders/nms_free_coder.py (CODER:8-111).
-``decode`` runs tc_box_decode_topk on the GPU (top-k select + denormalise +
-centre-range mask in one kernel)."""
+``decode`` runs tc_box_decode_kept on the GPU (top-k select + denormalise +
+centre-range / threshold mask + compaction of the kept rows in one kernel)."""
 import torch
 
 from . import ops
@@ -28,29 +28,14 @@ class NMSFreeCoder:
             raise NotImplementedError(
                 'Need to reorganize output as a batch, only support '
                 'post_center_range is not None for now!')       # CODER:86-89
-        boxes, scores, labels, valid = ops.box_decode_topk(
-            cls_scores.contiguous(), bbox_preds.contiguous(),
-            self.post_center_range, self.max_num)
-        if not z_shift:          # CODER returns gravity-centre z; HEAD:1018 shifts
-            boxes = boxes.clone()
-            boxes[..., 2] = boxes[..., 2] + boxes[..., 5] * 0.5
-        # CODER:66-84.  One host sync for the whole batch (the kept rows' indices), then plain gathers: three
-        # boolean-mask selects per sample were three syncs and nine small launches each
-        m = valid.bool()
-        if self.score_threshold:
-            m = m & (scores > self.score_threshold)
-        kept = torch.nonzero(m)                                  # [n, 2] (sample, row), row-major: rows stay sorted
-        counts = torch.bincount(kept[:, 0], minlength=boxes.shape[0]).tolist() if boxes.shape[0] > 1 \
-            else [int(kept.shape[0])]
-        flat = kept[:, 0] * boxes.shape[1] + kept[:, 1]
-        b_all = boxes.reshape(-1, boxes.shape[-1]).index_select(0, flat)
-        s_all = scores.reshape(-1).index_select(0, flat)
-        l_all = labels.reshape(-1).index_select(0, flat).long()
-        out, o = [], 0
-        for n in counts:
-            out.append({'bboxes': b_all[o:o + n], 'scores': s_all[o:o + n], 'labels': l_all[o:o + n]})
-            o += n
-        return out
+        # CODER:62-84 on the device: the kernel writes the kept rows compacted in score order and counts them; the
+        # host reads the counts (the one sync of a decode: B ints) and slices -- no mask select, no gather
+        boxes, scores, labels, count = ops.box_decode_kept(
+            cls_scores.contiguous(), bbox_preds.contiguous(), self.post_center_range, self.max_num,
+            score_threshold=self.score_threshold, z_shift=z_shift)
+        counts = count.tolist()
+        return [{'bboxes': boxes[b, :n], 'scores': scores[b, :n], 'labels': labels[b, :n]}
+                for b, n in enumerate(counts)]
 
     def decode_single(self, cls_scores, bbox_preds):
         return self.decode_batch(cls_scores[None], bbox_preds[None], False)[0]

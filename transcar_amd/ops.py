@@ -463,7 +463,71 @@ def box_decode_topk(cls_scores, bbox_preds, post_center_range, max_num=300):
     return boxes, scores, labels, valid
 
 
-def lidar2img_tensor(img_metas, device):
-    """XFMR:382-386: stack img_metas[i]['lidar2img'] -> [B,N,4,4] fp32."""
-    l2i = np.asarray([m['lidar2img'] for m in img_metas])
-    return torch.from_numpy(l2i.astype(np.float32)).to(device).contiguous()
+def box_decode_kept(cls_scores, bbox_preds, post_center_range, max_num=300, score_threshold=None, z_shift=True):
+    """NMSFreeCoder.decode_single for a batch (tc_box_decode_kept): the kept rows (inside post_center_range, above
+    the score threshold) compacted in score order -> boxes [B,max_num,9], scores [B,max_num], labels [B,max_num]
+    (int64) and count [B] (int32, device); rows beyond count[b] are not written."""
+    _chk(cls_scores, 'cls_scores'); _chk(bbox_preds, 'bbox_preds')
+    B, Q, ncls = cls_scores.shape
+    dev = cls_scores.device
+    boxes = torch.empty((B, max_num, 9), dtype=torch.float32, device=dev)
+    scores = torch.empty((B, max_num), dtype=torch.float32, device=dev)
+    labels = torch.empty((B, max_num), dtype=torch.int64, device=dev)
+    count = torch.empty((B,), dtype=torch.int32, device=dev)
+    use_thr = bool(score_threshold)                   # CODER:73: `if self.score_threshold:` -- None and 0 are off
+    L.check(L.lib().tc_box_decode_kept(
+        _p(cls_scores), _p(bbox_preds), B, Q, ncls, bbox_preds.shape[-1], max_num, L.f6(post_center_range),
+        float(score_threshold) if use_thr else 0.0, int(use_thr), int(bool(z_shift)),
+        _p(boxes), _p(scores), _p(labels), _p(count), _stream()), 'tc_box_decode_kept')
+    return boxes, scores, labels, count
+
+
+class _Lidar2ImgStaging:
+    """Host -> device staging of the per-frame projection matrices (XFMR:382-386) for the plugin entry: a ring of
+    pinned [B,N,4,4] buffers (one asynchronous H2D on the caller's stream, no pageable bounce), and no copy at all
+    when the matrices are the ones staged last (a static rig replayed, benchmark loops).  The device tensors stay
+    inside the head (``Detr3DHead.forward``): nobody else can write to a cached one."""
+    RING = 8
+
+    def __init__(self):
+        self.slots = {}        # (device, shape) -> [pinned tensors, events, next]
+        self.last = {}         # device -> (host copy, device tensor, stream id, event)
+
+    def get(self, l2i, device):
+        key = str(device)
+        cur = torch.cuda.current_stream(device)
+        hit = self.last.get(key)
+        if hit is not None and hit[0].shape == l2i.shape and np.array_equal(hit[0], l2i):
+            if hit[2] != cur.cuda_stream:
+                cur.wait_event(hit[3])
+            return hit[1]
+        ring = self.slots.get((key, l2i.shape))
+        if ring is None:
+            ring = self.slots[(key, l2i.shape)] = [
+                [torch.empty(l2i.shape, dtype=torch.float32).pin_memory() for _ in range(self.RING)],
+                [None] * self.RING, 0]
+        i = ring[2]
+        ring[2] = (i + 1) % self.RING
+        if ring[1][i] is not None:
+            ring[1][i].synchronize()               # the copy that last read this pinned buffer (8 frames ago)
+        ring[0][i].numpy()[...] = l2i
+        out = torch.empty(l2i.shape, dtype=torch.float32, device=device)
+        out.copy_(ring[0][i], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        ring[1][i] = ev
+        self.last[key] = (l2i, out, cur.cuda_stream, ev)
+        return out
+
+
+_l2i_staging = _Lidar2ImgStaging()
+
+
+def lidar2img_tensor(img_metas, device, staged=False):
+    """XFMR:382-386: stack img_metas[i]['lidar2img'] -> [B,N,4,4] fp32 on `device`.
+    staged: through the head's pinned staging ring / last-matrices cache (the result must not be written to)."""
+    l2i = np.asarray([m['lidar2img'] for m in img_metas], dtype=np.float32)
+    device = torch.device(device)
+    if not staged or device.type != 'cuda':
+        return torch.from_numpy(l2i).to(device).contiguous()
+    return _l2i_staging.get(l2i, device)
