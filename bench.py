@@ -91,7 +91,7 @@ def parse(argv=None):
                          'side measurements (kernel traces of tools/profile_round.sh)')
     ap.add_argument('--no-live-pmc', action='store_true',
                     help='roofline.traffic: do not measure it in this run (two child passes of rocprofv3 --pmc, ~20 s '
-                         'each), take the committed profiles/r3_pmc.json figure')
+                         'each), take the figure of the latest committed profiles/r*_pmc.json')
     ap.add_argument('--no-roofline', action='store_true',
                     help='skip the per-kernel timing replays (the PMC passes of tools/profile_round.sh: '
                          'only the launches of real frames are to be counted)')
@@ -534,10 +534,13 @@ def roofline(head, inp, dev, matrix_path='auto'):
     pmc = {}
     try:
         # {kernel: {"<frames per launch>": {"traffic_bytes": ...}}}, written by tools/collect_profile.py
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r3_pmc.json')))
+        import glob
+        newest = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc.json')),
+                        key=lambda f: int(os.path.basename(f).split('_')[0][1:]))[-1]      # the latest round's passes
+        pmc = json.load(open(newest))
         ent = pmc.get(dom, {}).get(str(B))
         if ent:
-            traffic, src = ent['traffic_bytes'], 'profiles/r3_pmc.json'
+            traffic, src = ent['traffic_bytes'], 'profiles/' + os.path.basename(newest)
     except Exception:
         pass
     # algorithmic flop of the whole path per frame: 6 decoder chains (the last without the next

@@ -312,10 +312,13 @@ int tc_decoder_layer_tail_fwd(const tc_decoder_layer* layer, const tc_linear* ne
 int tc_sdpa_fwd(const float* q, const float* k, int ld, const float* vt, int ldt,
                 float* out, int ldo, int B, int Q, int num_heads, tc_stream_t stream);
 /* The same core on the f16 matrix cores with fp32 accuracy (round 4; what tc_head_forward runs in launches with
- * 16-row tiles unless options.matrix_path = TC_MATRIX_F32): q | k rows [B*Q, 2C] token-major (q at columns 0..C-1,
- * pre-scaled as above, k at C..2C-1), vt as above.  One conversion launch writes the operands as two f16 planes
- * (hi, 2^11-scaled residual) into `workspace`, the attention launch computes every product from three
- * v_mfma_f32_16x16x32_f16 with fp32 accumulation.  |q|, |k|, |v| must stay below 65 504. */
+ * 16-row tiles unless options.matrix_path = TC_MATRIX_F32 or train-mode dropout is on): q | k rows [B*Q, 2C]
+ * token-major (q at columns 0..C-1, pre-scaled as above, k at C..2C-1), vt as above.  Every operand is used as two
+ * f16 planes (hi = f16(x), lo = f16(x - hi); built in registers / LDS inside the kernel), every product is three
+ * v_mfma_f32_16x16x32_f16 with fp32 accumulation.  |q|, |k|, |v| must stay below 65 504; an element's low plane is
+ * exact to 2^-25 ABSOLUTE (f16 subnormals), i.e. the result is fp32-accurate for operands of magnitude >~ 2^-3 and
+ * absolutely accurate to ~1e-7 x |the other operand| below that.  `workspace` is unused (may be null): the query
+ * returns 0. */
 size_t tc_sdpa_f16x2_workspace_bytes(int B, int Q, int num_heads);
 int tc_sdpa_fwd_f16x2(const float* qk, const float* vt, int ldt, float* out, int ldo, int B, int Q, int num_heads,
                       void* workspace, size_t workspace_bytes, tc_stream_t stream);

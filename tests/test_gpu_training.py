@@ -1022,9 +1022,11 @@ def test_batched_decoder_lookahead_is_the_single_frame_decoder(A, golden_dir):
         torch.cuda.synchronize()
         res[look] = (hist, tr.bucket.params.clone(), getattr(tr, 'lookahead_hits', 0))
     assert res[False][2] == 0 and res[True][2] == 2 * P              # every frame but the very first
-    for a_, b_ in zip(res[False][0], res[True][0]):
+    # (the losses of later iterations carry the run-to-run noise of the earlier steps' atomically summed gradients:
+    # the yardstick is what two plain runs differ by at the same iteration)
+    for a_, b_, c_ in zip(res[False][0], res[True][0], res['again'][0]):
         for k in a_:
-            assert abs(a_[k] - b_[k]) <= 2e-5 * max(1.0, abs(a_[k])), (k, a_[k], b_[k])
+            assert abs(a_[k] - b_[k]) <= 2e-5 * max(1.0, abs(a_[k])) + 3.0 * abs(a_[k] - c_[k]), (k, a_[k], b_[k], c_[k])
     # AdamW normalises the step, so the last-bit differences of the atomically summed gradients grow over the seven
     # steps: the look-ahead may differ from the plain run by no more than two plain runs differ from each other
     scale = res[False][1].abs().max()

@@ -86,15 +86,17 @@ def label_chain(rows, num_layers=6):
 def prog_label(kernel_name):
     """Label from the template arguments (chain_kernel<rows, program>): works in any launch order."""
     import re
-    m = re.search(r'chain_dual_kernel<(\d+), (\d+), (\d+)>', kernel_name)
+    # round 4: a trailing template argument 1 = the two-plane f16 matrix path of the 16-row tiles (chain.hip MM)
+    m = re.search(r'chain_dual_kernel<(\d+), (\d+), (\d+)(?:, (\d+))?>', kernel_name)
     if m:
-        return 'chain_dual_kernel(decoder layer + radar encoder half %s, %s-row tiles)' % (
-            'A' if m.group(3) == '4' else 'B', m.group(1))
-    m = re.search(r'chain_kernel<(\d+), (\d+)(?:, (\w+))?>', kernel_name)
+        return 'chain_dual_kernel(decoder layer + radar encoder half %s, %s-row tiles%s)' % (
+            'A' if m.group(3) == '4' else 'B', m.group(1), ', f16x2' if m.group(4) == '1' else '')
+    m = re.search(r'chain_kernel<(\d+), (\d+)(?:, (\w+))?(?:, (\d+))?>', kernel_name)
     if m:
-        return 'chain_kernel(%s, %s-row tiles)' % ({'0': 'prologue', '1': 'decoder layer', '2': 'radar encoders',
-                                                    '3': 'radar fusion'}.get(m.group(2), 'program ' + m.group(2)),
-                                                   m.group(1))
+        return 'chain_kernel(%s, %s-row tiles%s)' % (
+            {'0': 'prologue', '1': 'decoder layer', '2': 'radar encoders', '3': 'radar fusion', '6': 'radar fusion (train)',
+             '7': 'radar encoders (train)', '8': 'radar backward'}.get(m.group(2), 'program ' + m.group(2)),
+            m.group(1), ', f16x2' if m.group(4) == '1' else '')
     if 'self_attn_kernel' in kernel_name:
         return 'self_attn_kernel'
     return short(kernel_name)
@@ -107,6 +109,16 @@ def main():
     os.makedirs(dst, exist_ok=True)
 
     lines = []
+    for extra, target in (('bench_driver.json', '_driver_cmd.json'), ('bench_vovnet.json', '_vovnet_bench.json'),
+                          ('bench_f32.json', '_f32_path_bench.json')):
+        p = os.path.join(src, extra)
+        if os.path.exists(p):
+            el = [ln.strip() for ln in open(p) if ln.strip().startswith('{')]
+            if el:
+                open(os.path.join(dst, name + target), 'w').write('\n'.join(el) + '\n')
+    fs = newest(os.path.join(src, 'prof_f32', '*', '*kernel_stats.csv'))
+    if fs:
+        open(os.path.join(dst, name + '_f32_path_kernel_stats.csv'), 'w').write(open(fs[0]).read())
     for f in ('bench.json', 'bench_pair1.json', 'bench_pair2.json', 'bench_pair4.json', 'bench_steps20.json'):
         p = os.path.join(src, f)
         if os.path.exists(p):
@@ -213,7 +225,7 @@ def main():
             for r in csv.DictReader(open(fs[0])):
                 if r['Counter_Name'] != ctr:
                     continue
-                a = acc[re.sub(r', \d+-row tiles', '', prog_label(r['Kernel_Name']))]
+                a = acc[re.sub(r', \d+-row tiles(, f16x2)?', '', prog_label(r['Kernel_Name']))]
                 a[0] += float(r['Counter_Value'])
                 a[1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
                 a[2] += 1

@@ -6,27 +6,28 @@
 # separate runs, kernel-trace only).  Copy what is to be judged into profiles/ with
 # tools/collect_profile.py <tag> <name>.
 set -u
-TAG=${1:-r3}
+TAG=${1:-r4}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 python -m pytest tests -x -q -m gpu > "$OUT/pytest_gpu.log" 2>&1
 echo "pytest rc=$?" >> "$OUT/pytest_gpu.log"
-python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"                                   # default: 9 frames per launch x 3 lanes, 200 steps
-python bench.py --pair 1 --no-cpu-baseline --no-batched > "$OUT/bench_pair1.json" 2>> "$OUT/bench.err"
-python bench.py --pair 2 --no-cpu-baseline --no-batched --no-handoff > "$OUT/bench_pair2.json" 2>> "$OUT/bench.err"
-python bench.py --pair 4 --no-cpu-baseline --no-batched --no-handoff > "$OUT/bench_pair4.json" 2>> "$OUT/bench.err"
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-batched > "$OUT/bench_steps20.json" 2>> "$OUT/bench.err"
+python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driver.json" 2> "$OUT/bench.err"      # the driver's command, everything in one line
+python bench.py --shapes vovnet --no-configs --no-batched --no-handoff > "$OUT/bench_vovnet.json" 2>> "$OUT/bench.err"   # configs[4] shapes as the headline
+python bench.py --matrix-path f32 --no-configs --no-batched --no-handoff --no-cpu-baseline > "$OUT/bench_f32.json" 2>> "$OUT/bench.err"   # the exact-f32 chains
+python bench.py > "$OUT/bench.json" 2>> "$OUT/bench.err"                                   # default: 9 frames per launch x 3 lanes, 200 steps
+python bench.py --pair 1 --no-cpu-baseline --no-batched --no-configs > "$OUT/bench_pair1.json" 2>> "$OUT/bench.err"
 python bench.py --train --steps 50 --warmup 5 > "$OUT/bench_train.json" 2>> "$OUT/bench.err"
 cd /tmp
 Q="--main-only --min-window-s 0.05 --warmup-s 0.05"   # the timed loop only, short windows: small traces
 # per-kernel durations, one launch sequence at a time (with frames in flight the kernels of different lanes share the GPU)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python3 "$REPO/bench.py" --lanes 1 --pair 9 --steps 54 --warmup 9 $Q > "$OUT/prof.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_pair1" -- python3 "$REPO/bench.py" --lanes 1 --pair 1 --steps 50 --warmup 5 $Q > "$OUT/prof_pair1.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_f32" -- python3 "$REPO/bench.py" --matrix-path f32 --lanes 1 --pair 9 --steps 54 --warmup 9 $Q > "$OUT/prof_f32.log" 2>&1
 # the default command (3 lanes): trace of the overlap
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_lanes" -- python3 "$REPO/bench.py" --pair 9 --steps 54 --warmup 9 $Q > "$OUT/prof_lanes.log" 2>&1
-for B in 9 8 4 2 1; do
+for B in 9 1; do
   for C in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
     rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_${C}_b$B" -- python3 "$REPO/bench.py" --batch $B --steps 5 --warmup 2 $Q --no-graph > "$OUT/pmc_${C}_b$B.log" 2>&1
   done

@@ -1,7 +1,7 @@
 #!/bin/bash
 # everything: the GPU suite, the driver's command (timed), the default bench, the training bench
 out=gpurun_out/${1:-r4n}; mkdir -p $out
-timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -6 > $out/pytest_gpu.txt; tail -3 $out/pytest_gpu.txt
+timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -12 > $out/pytest_gpu.txt; tail -3 $out/pytest_gpu.txt
 s=$(date +%s); timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_driver.json 2> $out/bench_driver.err; e=$(date +%s)
 echo "driver command wall: $((e - s)) s"
 python - <<PY

@@ -225,12 +225,17 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
       d.drop = make_drop(opt.decoder_dropout_p, opt.dropout_seed, 16u + 8u * (unsigned)lid, 0u);
       if (opt.dropout_seed_stride != 0) { d.drop.seed_stride = opt.dropout_seed_stride; d.drop.rows_per_sample = (unsigned)Q; }
     }
-    // (the attention core stays on the fp32 MFMA: its two-plane f16 form, tc_sdpa_fwd_f16x2, is exact and tested but
-    // not faster at 900 queries -- 78 us + a 10 us conversion pass against 84 us per nine frames: with 203 VGPRs one
-    // workgroup per CU, and the kernel is bound by the latency of its dependent chain, not by the matrix pipe;
-    // tools/experiments/README.md)
-    if (!l0c) TC_TRY(launch_self_attn_core(h.qk, h.qk + C, 2 * C, h.vt, h.qpad, h.attn_o, C, B, Q, H, s,
-                                           ddrop ? &d.drop : nullptr));
+    // the attention core follows the chains' rule (chain.hip tile_rows / use_f16x2): launches that run 16-row tiles on
+    // the f16 matrix cores take the staged two-plane core (self_attn.hip, round 4) -- 4- / 8-row launches (one or two
+    // frames: too few workgroups for a form without split keys), TC_MATRIX_F32 and train-mode dropout the fp32 core.  A
+    // frame's arithmetic is therefore fixed by (chain_tile_rows, matrix_path), not by how many frames share a launch
+    if (!l0c) {
+      const int trows = opt.chain_tile_rows ? opt.chain_tile_rows : (rows <= 1024 ? 4 : rows <= 2048 ? 8 : 16);
+      if (trows == 16 && opt.matrix_path != TC_MATRIX_F32 && !ddrop)
+        TC_TRY(launch_self_attn_core_x(h.qk, h.qk + C, 2 * C, h.vt, h.qpad, h.attn_o, C, B, Q, H, s));
+      else
+        TC_TRY(launch_self_attn_core(h.qk, h.qk + C, 2 * C, h.vt, h.qpad, h.attn_o, C, B, Q, H, s, ddrop ? &d.drop : nullptr));
+    }
     d.attn_o = l0c ? w->l0_attn_out : h.attn_o;
     d.attn_mod = l0c ? Q : 0; d.ref_mod = l0c ? Q : 0;
     if (lid == 0) { d.x_in = w->query_embedding + C; d.x_ld = 2 * C; d.x_mod = Q; }
@@ -492,11 +497,12 @@ int tc_sdpa_fwd(const float* q, const float* k, int ld, const float* vt, int ldt
   return launch_self_attn_core(q, k, ld, vt, ldt, out, ldo, B, Q, num_heads, as_stream(stream));
 }
 
-size_t tc_sdpa_f16x2_workspace_bytes(int B, int Q, int num_heads) { return self_attn_h_ws_bytes(B, Q, num_heads); }
+size_t tc_sdpa_f16x2_workspace_bytes(int, int, int) { return 0; }     // (the staged form needs none)
 
 int tc_sdpa_fwd_f16x2(const float* qk, const float* vt, int ldt, float* out, int ldo, int B, int Q, int num_heads,
                       void* workspace, size_t workspace_bytes, tc_stream_t stream) {
-  return launch_self_attn_core_h(qk, vt, ldt, out, ldo, B, Q, num_heads, workspace, workspace_bytes, as_stream(stream));
+  (void)workspace; (void)workspace_bytes;          // (an earlier form built f16 planes there; the staged form converts in LDS)
+  return launch_self_attn_core_x(qk, qk + num_heads * 32, 2 * num_heads * 32, vt, ldt, out, ldo, B, Q, num_heads, as_stream(stream));
 }
 
 size_t tc_radar_xattn_workspace_bytes(int B, int Q, int T, int C) {

@@ -178,11 +178,10 @@ int launch_gate_selfcheck(int n_radii, unsigned long long seed, unsigned long lo
 int launch_self_attn_core(const float* q, const float* k, int ld, const float* vt, int ldt,
                           float* out, int ldo, int B, int Q, int H, hipStream_t s,
                           const DropK* drop = nullptr);
-// the same on the f16 matrix cores (two-plane operands, fp32 accumulate): q | k rows [B*Q, 2 * 32 H] (q pre-scaled), planes
-// built in `ws` (self_attn_h_ws_bytes) by one conversion launch in front of it
-size_t self_attn_h_ws_bytes(int B, int Q, int H);
-int launch_self_attn_core_h(const float* qk, const float* vt, int ldt, float* out, int ldo, int B, int Q, int H,
-                            void* ws, size_t ws_bytes, hipStream_t s);
+// the same on the f16 matrix cores, fp32-accurate (round 4): two-plane f16 operands (hi, lo), fp32 accumulate; K / V^T are
+// split and staged through LDS inside the kernel, every wave walks all keys.  Same operands as launch_self_attn_core.
+int launch_self_attn_core_x(const float* q, const float* k, int ld, const float* vt, int ldt, float* out, int ldo,
+                            int B, int Q, int H, hipStream_t s);
 
 // ---- radar_attn.hip --------------------------------------------------------
 struct RadarAttnArgs {

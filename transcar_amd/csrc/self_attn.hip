@@ -240,244 +240,324 @@ __global__ __launch_bounds__(SA_NW * 64) void self_attn_kernel(const float* __re
 
 // ---- the same core on the f16 MATRIX CORES, fp32-accurate (round 4) ------------------------------------------
 // After the chains moved to the matrix cores this kernel was the largest share of a frame (5 x 84 us of 1 290 us per
-// nine frames), 58 % of its SIMD cycles f32 MFMAs on the vector pipe.  MEASURED RESULT (round 4): exact (every
-// attention test passes at the fp32 kernel's tolerances, 1e-6 from it) but NOT faster -- 78 us + a 10 us conversion
-// pass against 84 us per nine frames -- so tc_head_forward keeps the fp32 core; this one is the operator
-// tc_sdpa_fwd_f16x2.  Why: 203 VGPRs (two fragment buffers of 32 registers, 42 of running state for two query
-// sub-tiles, the P planes) = one workgroup per CU instead of two, and with the MFMA time gone (1.3 of 10 us per
-// workgroup) what is left is the latency of the dependent chain load -> QK -> exp -> split -> PV of a wave's 3.6 key
-// pairs; forcing 128 registers spills 140-720 bytes (190-380 us), one query sub-tile per workgroup 121 us, four 94 us.
-// Operands as two f16 planes (hi, 2^11-scaled lo:
-// chain.hip "16-row tiles on the f16 MATRIX CORES"), three v_mfma_f32_16x16x32_f16 per product:
-//   * Q | K and V^T arrive ALREADY SPLIT (attn_planes_kernel: one pass over the chain's fp32 outputs per layer; split
-//     inside this kernel every one of the 29 query-tile workgroups of a head would redo the same K / V conversion --
-//     ~140 VALU instructions per 32 keys, as much issue time as the f32 MFMAs they replace);
-//   * d = 32 is ONE MFMA's k: S^T of a 16-key tile = K_hi Q_hi + 2^-11 (K_lo Q_hi + K_hi Q_lo);
+// nine frames), 58 % of its SIMD cycles f32 MFMAs on the vector pipe.  Operands as two f16 planes (hi = f16(x),
+// lo = f16(x - hi)), three v_mfma_f32_16x16x32_f16 per product (hi hi + lo hi + hi lo):
+//   * d = 32 is ONE MFMA's k: S^T of a 16-key tile is three MFMAs into one accumulator;
 //   * the PV product sums over KEYS, 32 per MFMA: key tiles go in pairs, and the rows of the two K tiles are chosen so
 //     that a lane's eight scores (4 + 4) are the eight CONSECUTIVE keys 8g .. 8g + 7 of the pair (tile A holds keys
 //     8g' + i, tile B keys 8g' + 4 + i at row 4g' + i): the probabilities are the PV product's B operand as they
-//     stand -- split into planes in registers (8 values per lane) -- and V^T's operand is one 16-byte load per plane;
-//   * everything else (lazy re-centring, key pairs round-robin over the 8 waves, merge through LDS) as above.
+//     stand -- split into planes in registers (8 values per lane) -- and V^T's operand is one 16-byte read per plane.
+// FIRST FORM (measured, not kept: tools/experiments/README.md): the fp32 kernel's structure -- 8 waves split the keys,
+// planes built by a conversion pass -- 78 us + 10 us against 84 us per nine frames: 203 VGPRs, one workgroup per CU, and
+// a wave's 3.6 dependent key pairs + the merge are latency, not matrix time.  SECOND FORM (below, in tc_head_forward):
+// every wave walks all keys, K / V^T staged through LDS: 43 us.
 typedef _Float16 sa_f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 sa_f16x2 __attribute__((ext_vector_type(2)));
 #define MFMAH(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(sa_f16x8, (a)), __builtin_bit_cast(sa_f16x8, (b)), (c), 0, 0, 0)
-constexpr float SA_LO = 2048.0f, SA_ILO = 1.0f / 2048.0f;
-
 __device__ __forceinline__ unsigned sa_pk(float a, float b) {
   const sa_f16x2 v = {(_Float16)a, (_Float16)b};
   return __builtin_bit_cast(unsigned, v);
 }
-// fp32 -> (hi, lo) planes: Q | K rows [M, ncol] -> [M, ncol] halves each; V^T [B*C, ldt] -> [B*C, ldt2] (zero padded)
-__global__ __launch_bounds__(256) void attn_planes_kernel(const float* __restrict__ qk, size_t n_qk4,
-                                                          unsigned short* __restrict__ qk_h, unsigned short* __restrict__ qk_l,
-                                                          const float* __restrict__ vt, int rows_vt, int ldt, int Q, int ldt2,
-                                                          unsigned short* __restrict__ vt_h, unsigned short* __restrict__ vt_l) {
-  const size_t n_vt4 = (size_t)rows_vt * (ldt2 / 4);
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_qk4 + n_vt4; i += (size_t)gridDim.x * 256) {
-    float4 x;
-    unsigned short *dh, *dl;
-    if (i < n_qk4) {
-      x = ld4(qk + 4 * i); dh = qk_h + 4 * i; dl = qk_l + 4 * i;
-    } else {
-      const size_t j = i - n_qk4;
-      const size_t row = j / (ldt2 / 4);
-      const int c = 4 * (int)(j - row * (ldt2 / 4));
-      x = c + 3 < ldt ? ld4(vt + row * ldt + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c + 0 >= Q) x.x = 0.f;
-      if (c + 1 >= Q) x.y = 0.f;
-      if (c + 2 >= Q) x.z = 0.f;
-      if (c + 3 >= Q) x.w = 0.f;
-      dh = vt_h + row * ldt2 + c; dl = vt_l + row * ldt2 + c;
-    }
-    const unsigned h0 = sa_pk(x.x, x.y), h1 = sa_pk(x.z, x.w);
-    const sa_f16x2 a = __builtin_bit_cast(sa_f16x2, h0), b = __builtin_bit_cast(sa_f16x2, h1);
-    const unsigned l0 = sa_pk((x.x - (float)a[0]) * SA_LO, (x.y - (float)a[1]) * SA_LO);
-    const unsigned l1 = sa_pk((x.z - (float)b[0]) * SA_LO, (x.w - (float)b[1]) * SA_LO);
-    typedef unsigned sa_u2 __attribute__((ext_vector_type(2)));
-    *(TC_GLOBAL sa_u2*)(dh) = sa_u2{h0, h1};
-    *(TC_GLOBAL sa_u2*)(dl) = sa_u2{l0, l1};
-  }
-}
+// ---- round 4, second form: every wave walks ALL keys; K / V^T staged through LDS as MFMA fragments ------------
+// The split-key form above is bound by the latency of a wave's 3.6 dependent key pairs and by its merge.  Here a wave
+// owns QT 16-query sub-tiles for the whole key range (29 pairs of 32 keys: a real loop to pipeline, no merge, the
+// normaliser is two cross-lane adds at the end), and the NW = 4 waves of a workgroup share every K / V^T fragment:
+//   * the workgroup reads the chain's fp32 q | k rows and V^T ONCE per pair (one 32-byte task per thread: waves 0-1
+//     the 32 keys x 4 channel groups of K, waves 2-3 the 32 channels x 4 key groups of V^T), splits them into the two
+//     f16 planes in registers and writes them to LDS IN FRAGMENT ORDER ([pair][ka_h ka_l kb_h kb_l v0_h v0_l v1_h
+//     v1_l][lane] x 16 B): a wave's operand read is one conflict-free ds_read_b128 per fragment; no conversion pass,
+//     no plane buffers in HBM -- the kernel takes exactly what the fp32 core takes;
+//   * chunks of two pairs, double buffered (32 KB of LDS): the loads of chunk c + 1 are issued before chunk c is
+//     consumed, converted and stored after it, ONE barrier per chunk;
+//   * the block index is mapped so that the workgroups of one (batch, head) -- which read the same 230 KB of K / V^T
+//     -- run on ONE XCD (block i lands on XCD i % 8), and the workgroups that hold a sample's last, nearly empty
+//     query tile (Q = 900: 7 x 128 queries + 4) come last in the grid.
+// Per pair and sub-tile a SIMD issues ~90 VALU instructions (8 v_exp at quarter rate, the fp32 -> plane split of the
+// probabilities) beside 12 matrix-core MFMAs of 16 cycles: VALU bound, the matrix cores a third busy.
+#ifndef SX_NW_VALUE
+#define SX_NW_VALUE 4
+#endif
+#ifndef SX_QT_VALUE
+#define SX_QT_VALUE 2
+#endif
+constexpr int SX_NW = SX_NW_VALUE, SX_CP = 2;
+#ifndef SX_NPC
+#define SX_NPC 1
+#endif
+#ifndef SX_OCC
+#define SX_OCC 3
+#endif
 
-struct KVFragH { float4 ka_h, ka_l, kb_h, kb_l, v0_h, v0_l, v1_h, v1_l; };     // (8 halves each)
-struct KVPtrH { const unsigned short* ka; const unsigned short* kb; const unsigned short* v0; size_t klo, vlo, v1off; };
-__device__ __forceinline__ float4 ldh8(const unsigned short* p) { return ld4(reinterpret_cast<const float*>(p)); }
-__device__ __forceinline__ KVFragH load_kv_h(const KVPtrH& p) {
-  KVFragH f;
-  f.ka_h = ldh8(p.ka); f.ka_l = ldh8(p.ka + p.klo); f.kb_h = ldh8(p.kb); f.kb_l = ldh8(p.kb + p.klo);
-  f.v0_h = ldh8(p.v0); f.v0_l = ldh8(p.v0 + p.vlo); f.v1_h = ldh8(p.v0 + p.v1off); f.v1_l = ldh8(p.v0 + p.v1off + p.vlo);
-  return f;
-}
-struct SAStateH { f32x4 o0h, o0l, o1h, o1l, negm; float l; };
+// The staged form keeps the LOW planes UNSCALED (lo = f16(x - hi)): the matrix cores honour f16 subnormals
+// (measured: tools/r4_attn_time.py, error unchanged at 3e-7), so a lo plane's error is at most 2^-25 ABSOLUTE per element
+// -- below fp32's own rounding for operands of magnitude >= 0.5, and the scores / probabilities of this kernel are
+// O(0.1 .. 256) -- and all three products of a split product (hi hi + lo hi + hi lo) chain into ONE accumulator: no
+// 2^-11 recombination, no second accumulator set, no scale multiplies in the split.
+// running state of one 16-query sub-tile: O^T, the normaliser (an MFMA too with SX_L_MFMA: an all-ones A operand sums a
+// pair's probabilities over the keys) and the negated reference as the score products' C operand
+#ifndef SX_L_MFMA
+#define SX_L_MFMA 0
+#endif
+struct SXState { f32x4 o0, o1, lsum, negm; float l; };
 
-// One PAIR of 16-key tiles (32 keys) against one 16-query sub-tile.  nvalid < 32: the ragged last pair.
-__device__ __forceinline__ void sa_pair_h(const KVFragH& f, const float4& q_h, const float4& q_l, SAStateH& st, bool first,
-                                          int nvalid, int g) {
-  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  f32x4 al = MFMAH(f.ka_l, q_h, zero); al = MFMAH(f.ka_h, q_l, al);
-  f32x4 bl = MFMAH(f.kb_l, q_h, zero); bl = MFMAH(f.kb_h, q_l, bl);
-  const f32x4 ah = MFMAH(f.ka_h, q_h, st.negm), bh = MFMAH(f.kb_h, q_h, st.negm);
-  // s[i] = log2(e) * S^T[key0 + 8g + i][query r] + negm, i = 0..7
-  float s[8];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { s[i] = fmaf(al[i], SA_ILO, ah[i]); s[4 + i] = fmaf(bl[i], SA_ILO, bh[i]); }
-  float4 v0h = f.v0_h, v0l = f.v0_l, v1h = f.v1_h, v1l = f.v1_l;
-  if (nvalid < 32) {                                   // wave-uniform: keys >= nvalid are masked (their V planes are 0)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) if (8 * g + i >= nvalid) s[i] = -INFINITY;
-  }
-  const bool above = any_above(s[0], s[1], s[2], s[3], SA_TAU) || any_above(s[4], s[5], s[6], s[7], SA_TAU);
-  if (first || __builtin_amdgcn_ballot_w64(above) != 0) {
-    const float mx = max_lanes_16_32(fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7]))));
-    const float delta = first ? mx : fmaxf(mx, 0.0f);
-    const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s[i] -= delta;
-    st.l *= alpha;
-    st.o0h *= alpha; st.o0l *= alpha; st.o1h *= alpha; st.o1l *= alpha;
-    st.negm -= delta;
-  }
-  float p[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) p[i] = __builtin_amdgcn_exp2f(s[i]);
-  st.l += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
-  // P^T as two f16 planes: the lane's eight keys are the MFMA's eight k slots
-  unsigned ph[4], pl[4];
+// x (8 fp32) -> hi plane (round to nearest f16) and lo plane f16(x - hi): one v_cvt_pk per two elements + one
+// v_fma_mix{lo,hi}_f16 per element (the packed hi half is an operand as it stands)
+__device__ __forceinline__ void sx_split1(const float* x, float4& hi, float4& lo) {
+  unsigned hh[4], ll[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    ph[i] = sa_pk(p[2 * i], p[2 * i + 1]);
-    const sa_f16x2 hh = __builtin_bit_cast(sa_f16x2, ph[i]);
-    pl[i] = sa_pk((p[2 * i] - (float)hh[0]) * SA_LO, (p[2 * i + 1] - (float)hh[1]) * SA_LO);
+    hh[i] = sa_pk(x[2 * i], x[2 * i + 1]);
+    asm volatile("" : "+v"(hh[i]));      // opaque: the halves are read out of the PACKED register, not re-converted
+    const sa_f16x2 v = __builtin_bit_cast(sa_f16x2, hh[i]);
+    ll[i] = sa_pk(fmaf((float)v[0], -1.0f, x[2 * i]), fmaf((float)v[1], -1.0f, x[2 * i + 1]));
   }
-  const float4 p_h = make_float4(__uint_as_float(ph[0]), __uint_as_float(ph[1]), __uint_as_float(ph[2]), __uint_as_float(ph[3]));
-  const float4 p_l = make_float4(__uint_as_float(pl[0]), __uint_as_float(pl[1]), __uint_as_float(pl[2]), __uint_as_float(pl[3]));
-  // O^T[d][q] += V^T[d][key] P^T[key][q]
-  st.o0l = MFMAH(v0l, p_h, st.o0l); st.o0l = MFMAH(v0h, p_l, st.o0l); st.o0h = MFMAH(v0h, p_h, st.o0h);
-  st.o1l = MFMAH(v1l, p_h, st.o1l); st.o1l = MFMAH(v1h, p_l, st.o1l); st.o1h = MFMAH(v1h, p_h, st.o1h);
+  hi = make_float4(__uint_as_float(hh[0]), __uint_as_float(hh[1]), __uint_as_float(hh[2]), __uint_as_float(hh[3]));
+  lo = make_float4(__uint_as_float(ll[0]), __uint_as_float(ll[1]), __uint_as_float(ll[2]), __uint_as_float(ll[3]));
+}
+__device__ __forceinline__ void sx_split(const float4& x0, const float4& x1, float4& hi, float4& lo) {
+  const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+  sx_split1(x, hi, lo);
+}
+
+// One chunk of NP key pairs (32 keys each) against the wave's QT sub-tiles, as ONE straight-line block: all score
+// products first, ONE lazy re-centring test for the whole chunk (a chunk is re-centred as a unit: softmax is shift
+// invariant), then exponentials, plane split and the PV products.
+template <int QT, int NP>
+__device__ __forceinline__ void sx_chunk(const float4 (*fb)[8][64], int lane, int g, const float4* q_h, const float4* q_l,
+                                         SXState* st, bool first, int nvalid_last) {
+  float sc[NP][QT][8];
+#pragma unroll
+  for (int pp = 0; pp < NP; ++pp) {
+    const float4 ka_h = fb[pp][0][lane], ka_l = fb[pp][1][lane], kb_h = fb[pp][2][lane], kb_l = fb[pp][3][lane];
+    f32x4 sa[QT], sb[QT];
+#pragma unroll
+    for (int u = 0; u < QT; ++u) { sa[u] = MFMAH(ka_h, q_h[u], st[u].negm); sb[u] = MFMAH(kb_h, q_h[u], st[u].negm); }
+#pragma unroll
+    for (int u = 0; u < QT; ++u) { sa[u] = MFMAH(ka_l, q_h[u], sa[u]); sb[u] = MFMAH(kb_l, q_h[u], sb[u]); }
+#pragma unroll
+    for (int u = 0; u < QT; ++u) { sa[u] = MFMAH(ka_h, q_l[u], sa[u]); sb[u] = MFMAH(kb_h, q_l[u], sb[u]); }
+    // sc[i] = log2(e) * S^T[key0 + 8g + i][query r] + negm
+#pragma unroll
+    for (int u = 0; u < QT; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { sc[pp][u][i] = sa[u][i]; sc[pp][u][4 + i] = sb[u][i]; }
+  }
+  if (nvalid_last < 32) {                                // wave-uniform: the ragged last pair (its V planes are 0 there)
+#pragma unroll
+    for (int u = 0; u < QT; ++u)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) if (8 * g + i >= nvalid_last) sc[NP - 1][u][i] = -INFINITY;
+  }
+  // "does any score exceed tau?" on the integer unit, branch-free (any_above's trick: one max3 tree over all of them)
+  int top = __builtin_bit_cast(int, sc[0][0][0]);
+#pragma unroll
+  for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+    for (int u = 0; u < QT; ++u)
+#pragma unroll
+      for (int i = 0; i < 8; i += 2) top = max(max(top, __builtin_bit_cast(int, sc[pp][u][i])), __builtin_bit_cast(int, sc[pp][u][i + 1]));
+  const bool above = top > __builtin_bit_cast(int, SA_TAU);
+  if (first || __builtin_amdgcn_ballot_w64(above) != 0) {
+#pragma unroll
+    for (int u = 0; u < QT; ++u) {
+      float mx = sc[0][u][0];
+#pragma unroll
+      for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mx = fmaxf(mx, sc[pp][u][i]);
+      mx = max_lanes_16_32(mx);                           // finite: key 0 of every pair is a real key
+      const float delta = first ? mx : fmaxf(mx, 0.0f);
+      const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);   // first chunk: l = O = 0
+#pragma unroll
+      for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sc[pp][u][i] -= delta;
+      st[u].o0 *= alpha; st[u].o1 *= alpha; st[u].lsum *= alpha; st[u].l *= alpha;
+      st[u].negm -= delta;
+    }
+  }
+  const unsigned one2 = 0x3C003C00u;                       // (1.0h, 1.0h)
+  const float4 ones = make_float4(__uint_as_float(one2), __uint_as_float(one2), __uint_as_float(one2), __uint_as_float(one2));
+  (void)ones;
+#pragma unroll
+  for (int pp = 0; pp < NP; ++pp) {
+    const float4 v0h = fb[pp][4][lane], v0l = fb[pp][5][lane], v1h = fb[pp][6][lane], v1l = fb[pp][7][lane];
+#pragma unroll
+    for (int u = 0; u < QT; ++u) {
+      float p[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) p[i] = __builtin_amdgcn_exp2f(sc[pp][u][i]);
+      if (!SX_L_MFMA) st[u].l += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+      // P^T as two f16 planes: the lane's eight keys are the MFMA's eight k slots
+      float4 p_h, p_l;
+      sx_split1(p, p_h, p_l);
+      // O^T[d][q] += V^T[d][key] P^T[key][q];  l[q] += sum over the keys
+      st[u].o0 = MFMAH(v0h, p_h, st[u].o0); st[u].o1 = MFMAH(v1h, p_h, st[u].o1);
+      if (SX_L_MFMA) st[u].lsum = MFMAH(ones, p_h, st[u].lsum);
+      st[u].o0 = MFMAH(v0l, p_h, st[u].o0); st[u].o1 = MFMAH(v1l, p_h, st[u].o1);
+      st[u].o0 = MFMAH(v0h, p_l, st[u].o0); st[u].o1 = MFMAH(v1h, p_l, st[u].o1);
+      if (SX_L_MFMA) st[u].lsum = MFMAH(ones, p_l, st[u].lsum);
+    }
+  }
 }
 
 template <int QT>
-__global__ __launch_bounds__(SA_NW * 64) void self_attn_h_kernel(const unsigned short* __restrict__ qk_h, size_t qk_lo, int ld,
-                                                                 const unsigned short* __restrict__ vt_h, size_t vt_lo, int ldt2,
-                                                                 float* __restrict__ out, int ldo, int Q, int C) {
-  __shared__ float sm_m[SA_NW][QT][16];
-  __shared__ float sm_l[SA_NW][QT][64];
-  __shared__ float4 sm_o[SA_NW][QT][2][64];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+__global__ __launch_bounds__(SX_NW * 64) __attribute__((amdgpu_waves_per_eu(SX_OCC, SX_OCC))) void self_attn_x_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, int ld, const float* __restrict__ vt, int ldt,
+    float* __restrict__ out, int ldo, int Q, int C, int H, int BH) {
+  constexpr int QW = 16 * QT * SX_NW;                       // queries per workgroup
+  __shared__ float4 frag[2][SX_CP][8][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, g = lane >> 4;
-  const int q0 = blockIdx.x * 16 * QT, h = blockIdx.y, b = blockIdx.z;
+  // work item: (batch * head, query group)
+  const int Gf = Q / QW, nfull = BH * Gf;
+  int bh, qg;
+  {
+    const int idx = blockIdx.x;
+    if (idx >= nfull) { bh = idx - nfull; qg = Gf; }                      // the ragged query group of a (batch, head)
+    else if ((BH & 7) == 0) { const int slot = idx >> 3; bh = (slot / Gf) * 8 + (idx & 7); qg = slot % Gf; }
+    else { bh = idx / Gf; qg = idx % Gf; }
+  }
+  const int b = bh / H, h = bh - b * H;
   const size_t brow = (size_t)b * Q;
-  float4 q_h[QT], q_l[QT];
-  SAStateH st[QT];
+  const int q0 = qg * QW + wave * 16 * QT;
+  const bool active = q0 < Q;                                             // a wave without a real query only stages
+  // the thread's staging tasks of a pair: 256 tasks of 32 bytes (tasks 0..127: key t >> 2 of K, channel group t & 3;
+  // 128..255: channel (t - 128) >> 2 of V^T, key group t & 3), task t + i * threads for thread t
+  constexpr int NT = SX_NW * 64, TPT = NT >= 256 ? 1 : 256 / NT;
+  const bool stager = tid < 256;
+  bool is_k[TPT];
+  int gg[TPT], rowi[TPT], dfrag[TPT], dlane[TPT];
+  const float* src[TPT];
 #pragma unroll
-  for (int u = 0; u < QT; ++u) {
-    const int qrow = min(q0 + 16 * u + r, Q - 1);
-    const unsigned short* qp = qk_h + (brow + qrow) * ld + h * 32 + 8 * g;
-    q_h[u] = ldh8(qp); q_l[u] = ldh8(qp + qk_lo);
-    st[u].o0h = st[u].o0l = st[u].o1h = st[u].o1l = f32x4{0.f, 0.f, 0.f, 0.f};
-    st[u].negm = f32x4{0.f, 0.f, 0.f, 0.f}; st[u].l = 0.0f;
+  for (int tk = 0; tk < TPT; ++tk) {
+    const int t = tid + tk * NT;
+    is_k[tk] = __builtin_amdgcn_readfirstlane(t) < 128;                 // (wave-uniform: a wave's 64 tasks lie on one side)
+    const int tt = t & 127;
+    gg[tk] = tt & 3; rowi[tk] = tt >> 2;                                // K: key `rowi` of the pair; V^T: channel `rowi`
+    dfrag[tk] = is_k[tk] ? 2 * ((rowi[tk] >> 2) & 1) : 4 + 2 * (rowi[tk] >> 4);
+    dlane[tk] = is_k[tk] ? 16 * gg[tk] + 4 * (rowi[tk] >> 3) + (rowi[tk] & 3) : 16 * gg[tk] + (rowi[tk] & 15);
+    src[tk] = is_k[tk] ? k + brow * ld + h * 32 + 8 * gg[tk] : vt + ((size_t)b * C + h * 32 + rowi[tk]) * ldt + 8 * gg[tk];
   }
-  // the wave's key PAIRS: wave, wave + NW, ... among the nfull whole pairs, then the ragged pair if it is this wave's turn
-  const int nfull = Q >> 5;
-  const int n = wave < nfull ? (nfull - wave + SA_NW - 1) / SA_NW : 0;
-  const int ra = 8 * (r >> 2) + (r & 3);                // row r of tile A holds key ra of the pair, tile B key ra + 4
-  const unsigned short* kbase = qk_h + C + h * 32 + 8 * g;     // K columns of the (q | k) rows
-  KVPtrH p;
-  p.klo = qk_lo; p.vlo = vt_lo; p.v1off = (size_t)16 * ldt2;
-  p.ka = kbase + (brow + wave * 32 + ra) * ld;
-  p.kb = p.ka + (size_t)4 * ld;
-  p.v0 = vt_h + ((size_t)b * C + h * 32 + r) * ldt2 + wave * 32 + 8 * g;
-  const size_t kstep = (size_t)SA_NW * 32 * ld;
-  auto advance = [&]() { p.ka += kstep; p.kb += kstep; p.v0 += SA_NW * 32; };
-  auto pair = [&](const KVFragH& f, int i, int nvalid) {
-#pragma unroll
-    for (int u = 0; u < QT; ++u) sa_pair_h(f, q_h[u], q_l[u], st[u], i == 0, nvalid, g);
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto fetch = [&](int j, int tk, float4& x0, float4& x1) {
+    const int key0 = 32 * j;
+    if (is_k[tk]) {
+      const float* p = src[tk] + (size_t)min(key0 + rowi[tk], Q - 1) * ld;   // keys >= Q: any finite row (their scores are masked)
+      x0 = ld4(p); x1 = ld4(p + 4);
+    } else {
+      const int kk = key0 + 8 * gg[tk];
+      const float* p = src[tk] + key0;
+      x0 = kk + 3 < ldt ? ld4(p) : zero4;
+      x1 = kk + 7 < ldt ? ld4(p + 4) : zero4;
+      if (kk + 7 >= Q) {                                                  // keys >= Q weigh nothing
+        if (kk + 0 >= Q) x0.x = 0.f;
+        if (kk + 1 >= Q) x0.y = 0.f;
+        if (kk + 2 >= Q) x0.z = 0.f;
+        if (kk + 3 >= Q) x0.w = 0.f;
+        if (kk + 4 >= Q) x1.x = 0.f;
+        if (kk + 5 >= Q) x1.y = 0.f;
+        if (kk + 6 >= Q) x1.z = 0.f;
+        if (kk + 7 >= Q) x1.w = 0.f;
+      }
+    }
   };
-  KVFragH fa, fb;
-  if (n > 0) fa = load_kv_h(p);
-  int i = 0;
-  for (; i + 2 <= n; i += 2) {
-    advance();
-    fb = load_kv_h(p);
-    __builtin_amdgcn_sched_barrier(0);
-    pair(fa, i, 32);
-    advance();
-    if (i + 2 < n) fa = load_kv_h(p);
-    __builtin_amdgcn_sched_barrier(0);
-    pair(fb, i + 1, 32);
+  auto put = [&](int buf, int pp, int tk, const float4& x0, const float4& x1) {
+    float4 hi, lo;
+    sx_split(x0, x1, hi, lo);
+    frag[buf][pp][dfrag[tk]][dlane[tk]] = hi;
+    frag[buf][pp][dfrag[tk] + 1][dlane[tk]] = lo;
+  };
+  const int np = (Q + 31) >> 5, nchunk = (np + SX_CP - 1) / SX_CP;
+  float4 x[SX_CP][TPT][2];
+  if (stager) {
+#pragma unroll
+    for (int pp = 0; pp < SX_CP; ++pp)
+#pragma unroll
+      for (int tk = 0; tk < TPT; ++tk)
+        if (pp < np) fetch(pp, tk, x[pp][tk][0], x[pp][tk][1]);
   }
-  if (i < n) { pair(fa, i, 32); ++i; }
-  const int rag = Q & 31;
-  if (rag != 0 && wave == (nfull % SA_NW)) {            // this wave's next pair is the ragged one
-    KVPtrH pr = p;
-    const int k0 = nfull * 32;
-    pr.ka = kbase + (brow + min(k0 + ra, Q - 1)) * ld;
-    pr.kb = kbase + (brow + min(k0 + ra + 4, Q - 1)) * ld;
-    pr.v0 = vt_h + ((size_t)b * C + h * 32 + r) * ldt2 + k0 + 8 * g;          // ldt2 >= 32 * (nfull + 1), zero padded
-    const KVFragH fr = load_kv_h(pr);
-    pair(fr, i, rag);
-    ++i;
-  }
-  const bool idle = i == 0;
+  float4 q_h[QT], q_l[QT];
+  SXState st[QT];
 #pragma unroll
   for (int u = 0; u < QT; ++u) {
-    if (g == 0) sm_m[wave][u][r] = idle ? -INFINITY : -st[u].negm[0];
-    sm_l[wave][u][lane] = st[u].l;
-    sm_o[wave][u][0][lane] = make_float4(fmaf(st[u].o0l[0], SA_ILO, st[u].o0h[0]), fmaf(st[u].o0l[1], SA_ILO, st[u].o0h[1]),
-                                         fmaf(st[u].o0l[2], SA_ILO, st[u].o0h[2]), fmaf(st[u].o0l[3], SA_ILO, st[u].o0h[3]));
-    sm_o[wave][u][1][lane] = make_float4(fmaf(st[u].o1l[0], SA_ILO, st[u].o1h[0]), fmaf(st[u].o1l[1], SA_ILO, st[u].o1h[1]),
-                                         fmaf(st[u].o1l[2], SA_ILO, st[u].o1h[2]), fmaf(st[u].o1l[3], SA_ILO, st[u].o1h[3]));
+    const int qrow = min(q0 + 16 * u + r, Q - 1);                         // (rows past Q: a copy of the last query, not stored)
+    const float* qp = q + (brow + qrow) * ld + h * 32 + 8 * g;
+    sx_split(ld4(qp), ld4(qp + 4), q_h[u], q_l[u]);
+    st[u].o0 = st[u].o1 = st[u].lsum = st[u].negm = f32x4{0.f, 0.f, 0.f, 0.f};
+    st[u].l = 0.0f;
+  }
+  if (stager) {
+#pragma unroll
+    for (int pp = 0; pp < SX_CP; ++pp)
+#pragma unroll
+      for (int tk = 0; tk < TPT; ++tk)
+        if (pp < np) put(0, pp, tk, x[pp][tk][0], x[pp][tk][1]);
   }
   __syncthreads();
-  if (wave >= 2 * QT) return;
-  const int u = wave >> 1, half = wave & 1;
-  float mstar = sm_m[0][u][r];
+#pragma unroll 1
+  for (int c = 0; c < nchunk; ++c) {
+    const int buf = c & 1;
+#ifdef SX_NO_STAGE
+    const bool more = false;
+#else
+    const bool more = c + 1 < nchunk;
+#endif
+    if (more && stager) {
 #pragma unroll
-  for (int w = 1; w < SA_NW; ++w) mstar = fmaxf(mstar, sm_m[w][u][r]);
-  float l = 0.0f;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int pp = 0; pp < SX_CP; ++pp)
 #pragma unroll
-  for (int w = 0; w < SA_NW; ++w) {
-    const float sc = __builtin_amdgcn_exp2f(sm_m[w][u][r] - mstar);
-    l += sc * ((sm_l[w][u][r] + sm_l[w][u][r + 16]) + (sm_l[w][u][r + 32] + sm_l[w][u][r + 48]));
-    const float4 v = sm_o[w][u][half][lane];
-    acc.x += sc * v.x; acc.y += sc * v.y; acc.z += sc * v.z; acc.w += sc * v.w;
+        for (int tk = 0; tk < TPT; ++tk)
+          if ((c + 1) * SX_CP + pp < np) fetch((c + 1) * SX_CP + pp, tk, x[pp][tk][0], x[pp][tk][1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);                 // the next chunk's loads stay in front of this chunk's products
+#ifndef SX_NO_COMPUTE
+    if (active) {
+      const int left = np - c * SX_CP;                 // pairs in this chunk: SX_CP, or fewer in the last one
+      const int nvalid_last = min(32, Q - 32 * (c * SX_CP + min(left, SX_CP) - 1));
+      static_assert(SX_CP == 2, "the chunk dispatch below is written for two pairs");
+      if (SX_NPC == 2 && left >= 2) sx_chunk<QT, 2>(frag[buf], lane, g, q_h, q_l, st, c == 0, nvalid_last);
+      else {
+        sx_chunk<QT, 1>(frag[buf], lane, g, q_h, q_l, st, c == 0, left >= 2 ? 32 : nvalid_last);
+        if (left >= 2) sx_chunk<QT, 1>(frag[buf] + 1, lane, g, q_h, q_l, st, false, nvalid_last);
+      }
+    }
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    if (more && stager) {
+#pragma unroll
+      for (int pp = 0; pp < SX_CP; ++pp)
+#pragma unroll
+        for (int tk = 0; tk < TPT; ++tk)
+          if ((c + 1) * SX_CP + pp < np) put(buf ^ 1, pp, tk, x[pp][tk][0], x[pp][tk][1]);
+    }
+    __syncthreads();
   }
-  if (q0 + 16 * u + r < Q) {
-    const float inv = 1.0f / l;
-    float* op = out + (brow + q0 + 16 * u + r) * ldo + h * 32 + 16 * half + 4 * g;
-    st4(op, make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
+  if (!active) return;
+#pragma unroll
+  for (int u = 0; u < QT; ++u) {
+    const int qrow = q0 + 16 * u + r;
+    if (qrow < Q) {
+      float l = st[u].lsum[0];                         // SX_L_MFMA: every row of the ones-product holds the sum
+      if (!SX_L_MFMA) { l = st[u].l; l += __shfl_xor(l, 16); l += __shfl_xor(l, 32); }   // the lane's keys 8g .. 8g + 7 of every pair
+      const float inv = 1.0f / l;
+      float* op = out + (brow + qrow) * ldo + h * 32 + 4 * g;
+      st4(op, make_float4(st[u].o0[0] * inv, st[u].o0[1] * inv, st[u].o0[2] * inv, st[u].o0[3] * inv));
+      st4(op + 16, make_float4(st[u].o1[0] * inv, st[u].o1[1] * inv, st[u].o1[2] * inv, st[u].o1[3] * inv));
+    }
   }
 }
 
-size_t self_attn_h_ws_bytes(int B, int Q, int H) {
-  const size_t M = (size_t)B * Q, C = (size_t)H * 32, ldt2 = ((size_t)Q + 31) / 32 * 32;
-  return 2 * arena_slice(M * 2 * C, 2) + 2 * arena_slice((size_t)B * C * ldt2, 2);
-}
-
-// q | k rows [B*Q, 2C] (q pre-scaled), vt [B, C, ldt] fp32 -> planes in `ws` -> out [B*Q, C]
-int launch_self_attn_core_h(const float* qk, const float* vt, int ldt, float* out, int ldo, int B, int Q, int H,
-                            void* ws, size_t ws_bytes, hipStream_t s) {
+// q, k rows [B*Q, ld] (q pre-scaled), vt [B, C, ldt] fp32 -> out [B*Q, C]: the operands of launch_self_attn_core
+int launch_self_attn_core_x(const float* q, const float* k, int ld, const float* vt, int ldt, float* out, int ldo,
+                            int B, int Q, int H, hipStream_t s) {
   TC_REQUIRE(Q > 0 && B > 0 && H > 0, "self_attn(f16x2): empty problem");
   TC_REQUIRE((ldt & 3) == 0 && ldt >= ((Q + 15) / 16) * 16, "self_attn(f16x2): ldt=%d too small for Q=%d", ldt, Q);
-  TC_REQUIRE(ws != nullptr && ws_bytes >= self_attn_h_ws_bytes(B, Q, H), "self_attn(f16x2): workspace too small");
-  const int C = H * 32, ld = 2 * C, ldt2 = (Q + 31) / 32 * 32;
-  const size_t M = (size_t)B * Q;
-  Arena a(ws, ws_bytes);
-  unsigned short* qk_h = a.take<unsigned short>(M * ld);
-  unsigned short* qk_l = a.take<unsigned short>(M * ld);
-  unsigned short* vt_h = a.take<unsigned short>((size_t)B * C * ldt2);
-  unsigned short* vt_l = a.take<unsigned short>((size_t)B * C * ldt2);
-  const size_t n4 = M * ld / 4 + (size_t)B * C * (ldt2 / 4);
-  const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
-  hipLaunchKernelGGL(attn_planes_kernel, dim3(blocks), dim3(256), 0, s, qk, M * ld / 4, qk_h, qk_l, vt, B * C, ldt, Q, ldt2,
-                     vt_h, vt_l);
-  if (const int rc = check_launch("attn_planes"); rc != 0) return rc;
-  constexpr int QT = 2;
-  dim3 grid((Q + 16 * QT - 1) / (16 * QT), H, B);
-  hipLaunchKernelGGL((self_attn_h_kernel<QT>), grid, dim3(SA_NW * 64), 0, s, qk_h, (size_t)(qk_l - qk_h), ld, vt_h,
-                     (size_t)(vt_l - vt_h), ldt2, out, ldo, Q, C);
-  return check_launch("self_attn(f16x2)");
+  constexpr int QT = SX_QT_VALUE, QW = 16 * QT * SX_NW;
+  const int BH = B * H, Gf = Q / QW, G = (Q + QW - 1) / QW;
+  hipLaunchKernelGGL((self_attn_x_kernel<QT>), dim3(BH * Gf + (G > Gf ? BH : 0)), dim3(SX_NW * 64), 0, s, q, k, ld, vt, ldt,
+                     out, ldo, Q, H * 32, H, BH);
+  return check_launch("self_attn(f16x2, staged)");
 }
 
 int launch_self_attn_core(const float* q, const float* k, int ld, const float* vt, int ldt,
