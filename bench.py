@@ -460,8 +460,12 @@ def roofline(head, inp, dev, matrix_path='auto'):
     ao = torch.empty((M, Cd), device=dev)
 
     def run_attn():
-        L.check(lib.tc_sdpa_fwd(qk_in.data_ptr(), qk_in.data_ptr() + Cd * 4, 2 * Cd,
-                                vt_in.data_ptr(), qpad, ao.data_ptr(), Cd, B, Q, H, cur_stream()), 'sdpa')
+        if f16x2:       # what tc_head_forward launches beside 16-row f16x2 chains: the staged two-plane core (self_attn.hip)
+            L.check(lib.tc_sdpa_fwd_f16x2(qk_in.data_ptr(), vt_in.data_ptr(), qpad, ao.data_ptr(), Cd, B, Q, H, None, 0,
+                                          cur_stream()), 'sdpa_f16x2')
+        else:
+            L.check(lib.tc_sdpa_fwd(qk_in.data_ptr(), qk_in.data_ptr() + Cd * 4, 2 * Cd,
+                                    vt_in.data_ptr(), qpad, ao.data_ptr(), Cd, B, Q, H, cur_stream()), 'sdpa')
     attn_ms = time_events(run_attn)
     attn_flop = 4.0 * Q * Q * 32 * H * B
     # -- fused radar chain (three fusion layers in one launch) on this frame's decoder outputs
@@ -510,8 +514,11 @@ def roofline(head, inp, dev, matrix_path='auto'):
             weight_stream_gbs_per_cu=(-(-B * head.num_query // (16 if B * head.num_query > 2048 else 8 if B * head.num_query > 1024 else 4))
                                       * 795136 * 4 / 256.0) / chain_ms / 1e6),
         'self_attn_kernel': dict(
-            bound='mfma', achieved=attn_flop / attn_ms / 1e9, peak=F32_MFMA_PEAK_TFLOPS,
-            unit='TFLOP/s', ms=attn_ms, per_frame=6, alg_flop=attn_flop),
+            bound='mfma', achieved=attn_flop / attn_ms / 1e9, peak=chain_peak if f16x2 else F32_MFMA_PEAK_TFLOPS,
+            unit='TFLOP/s', ms=attn_ms, per_frame=6, alg_flop=attn_flop,
+            arithmetic='f16x2 split operands (self_attn_x_kernel), fp32 accumulate' if f16x2 else 'f32',
+            note='issue bound, not matrix bound: per 32 keys x 16 queries a SIMD issues 12 MFMAs beside ~60 VALU '
+                 'instructions (8 v_exp, the fp32 -> two-plane split of the probabilities)' if f16x2 else None),
         'chain_kernel(radar fusion)': dict(
             bound='mfma', achieved=radar_flop_exec / radar_ms / 1e9, peak=chain_peak,
             unit='TFLOP/s', ms=radar_ms, per_frame=1, alg_flop=radar_flop_exec, reference_flop=radar_flop,
@@ -553,7 +560,7 @@ def roofline(head, inp, dev, matrix_path='auto'):
                  + radar_flop_exec) / B
     r.update(path_flop_per_frame=path_flop)
     r.update(kernel=dom, traffic=traffic, traffic_source=src,
-             others={n: dict({kk: v[kk] for kk in ('bound', 'achieved', 'peak', 'unit', 'frac', 'ms', 'per_frame',
+             others={n: dict({kk: v[kk] for kk in ('bound', 'achieved', 'peak', 'unit', 'frac', 'ms', 'per_frame', 'arithmetic',
                                                   'frac_of_f32_mfma_peak') if kk in v},
                              traffic=(pmc.get(n, {}).get(str(B)) or {}).get('traffic_bytes'))
                      for n, v in kern.items() if n != dom})
@@ -565,7 +572,7 @@ def roofline(head, inp, dev, matrix_path='auto'):
 
 PMC_KERNELS = (('chain_kernel(decoder layer)', r'chain_kernel<\d+, 1, '),
                ('chain_kernel(radar fusion)', r'chain_kernel<\d+, 3, '),
-               ('self_attn_kernel', r'self_attn_kernel'))
+               ('self_attn_kernel', r'self_attn_(x_)?kernel'))
 
 
 def parse_counter_csv(path, ctr):
@@ -1577,11 +1584,11 @@ def main(argv=None):
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,
-        # the arithmetic the path computes in: fp32 everywhere; the linear steps of launches with 16-row tiles form each
+        # the arithmetic the path computes in: fp32 everywhere; the linear steps and the attention core of launches with 16-row tiles form each
         # fp32 product from two-plane f16 operands on the matrix cores (three MFMAs, fp32 accumulate) unless
         # --matrix-path f32 (`f32_path` carries that figure)
-        'dtype': ('f32 (linear steps of the batched launches: f16x2 split operands, %d v_mfma_f32_16x16x32_f16 products, fp32 '
-                  'accumulate; attention core and 4- / 8-row tiles: f32 MFMA)' % F16X2_PRODUCTS)
+        'dtype': ('f32 (linear steps and attention core of the batched launches: f16x2 split operands, %d '
+                  'v_mfma_f32_16x16x32_f16 products, fp32 accumulate; 4- / 8-row tiles: f32 MFMA)' % F16X2_PRODUCTS)
                  if (pipe is not None and pipe.tile_rows_of() == 16 and args.matrix_path != 'f32') else 'f32',
         'data': 'synthetic',
         'timing': win,

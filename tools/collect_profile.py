@@ -97,7 +97,7 @@ def prog_label(kernel_name):
             {'0': 'prologue', '1': 'decoder layer', '2': 'radar encoders', '3': 'radar fusion', '6': 'radar fusion (train)',
              '7': 'radar encoders (train)', '8': 'radar backward'}.get(m.group(2), 'program ' + m.group(2)),
             m.group(1), ', f16x2' if m.group(4) == '1' else '')
-    if 'self_attn_kernel' in kernel_name:
+    if 'self_attn_kernel' in kernel_name or 'self_attn_x_kernel' in kernel_name:     # (x: the staged f16x2 form, round 4)
         return 'self_attn_kernel'
     return short(kernel_name)
 
