@@ -164,13 +164,20 @@ int launch_detr_loss(const LossK& p, hipStream_t s) {
 // decoder hidden behind a look-ahead that round trip (D2H, three solves of 900 x 24, H2D: ~0.30 ms) was the largest
 // single piece of a 0.96 ms iteration's critical path.  Here: the same algorithm scipy implements (the shortest
 // augmenting path form of Jonker-Volgenant in Crouse's rectangular variant, scipy/optimize/rectangular_lsap: the G
-// ground-truth boxes are the rows, the Q queries the columns), in float64 like scipy, ONE WAVE per (decoder output,
-// sample): lane l owns columns l, l + 64, ...; a step of an augmenting path is a register update of the lane's
-// columns plus one wave-wide arg-min -- no barrier, no host.  The optimal assignment is unique unless two
-// candidate sets have exactly equal cost; on an exact tie between columns the lowest unassigned column wins here
-// (scipy: the one met last in its work list) -- same total cost, possibly another of the tied queries.
+// ground-truth boxes are the rows, the Q queries the columns), in float64 like scipy, one workgroup of LSA_NT = 256
+// threads per (decoder output, sample): thread t owns columns t, t + 256, ...; a step of an augmenting path is a
+// register update of the thread's columns plus a workgroup-wide arg-min (wave DPP, then the four waves' candidates
+// through LDS: two barriers per step).  First build: ONE wave, 16 columns per lane -- 143 us per iteration (a step =
+// 16 x ~10 float64 instructions per lane + the transposing load of the costs by 64 threads), the largest single item
+// on the iteration's critical path; four waves: see DESIGN.md section 5.
+// The optimal assignment is unique unless two candidate sets have exactly equal cost; on an exact tie between
+// columns an unassigned column wins, then the lowest (column mod 64), then the lowest column (scipy: the one met
+// last in its work list) -- same total cost, possibly another of the tied queries.  The order is a property of the
+// COLUMN, not of the thread that holds it: the one-wave build resolved ties the same way.
 // A non-finite cost (scipy raises ValueError) leaves the sample unassigned and sets *status.
-constexpr int LSA_COLS = 16;                       // columns per lane: Q <= 64 * LSA_COLS = 1024
+constexpr int LSA_NT = 256;                        // threads per problem
+constexpr int LSA_COLS = 4;                        // columns per thread: Q <= LSA_NT * LSA_COLS = 1024
+constexpr int LSA_QMAX = LSA_NT * LSA_COLS;
 constexpr int LSA_GMAX = 128;                      // ground-truth boxes per sample
 struct LsaK {
   const float* cost;                               // [P, Q, Gmax] (P = outputs x samples), 0 beyond a sample's count
@@ -189,38 +196,54 @@ __device__ __forceinline__ double wave_min_f64(double v) {
   }
   return v;
 }
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, o, 64));
+  return v;
+}
+// a column's place in the tie order: unassigned first, then column mod 64, then column / 64 (unique per column)
+__device__ __forceinline__ unsigned lsa_key(int j, bool is_free) { return (is_free ? 0u : 1u << 20) | ((unsigned)(j & 63) << 10) | (unsigned)(j >> 6); }
+__device__ __forceinline__ int lsa_key_col(unsigned key) { return (int)((key >> 10) & 63u) + 64 * (int)(key & 1023u); }
 
 // LDS = true: the sample's costs are transposed into LDS first (a step then reads consecutive words); false (the
 // matrix does not fit: more than ~40 boxes at 900 queries): straight from global memory (L2), stride Gmax
 template <bool LDS>
-__global__ __launch_bounds__(64) void lsa_kernel(LsaK p) {
+__global__ __launch_bounds__(LSA_NT) void lsa_kernel(LsaK p) {
   extern __shared__ __align__(16) float lsa_cost[];          // [G][Qpad] (transposed: a row = one ground-truth box)
   __shared__ double u[LSA_GMAX];
   __shared__ double spc_of_col4row[LSA_GMAX];
   __shared__ int col4row[LSA_GMAX];
   __shared__ int SR[LSA_GMAX];
-  const int prob = blockIdx.x, lane = threadIdx.x;
+  __shared__ int path_s[LSA_QMAX];                           // column -> the row it was reached from (this row's search)
+  __shared__ int row4col_s[LSA_QMAX];                        // column -> its row, or -1
+  __shared__ double red_val[LSA_NT / 64];
+  __shared__ unsigned red_key[LSA_NT / 64];
+  __shared__ int bad_s;
+  const int prob = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = prob % p.B;
   const int G = min(p.gt_counts[b], p.Gmax), Q = p.Q;
   const int Qpad = (Q + 63) & ~63;
   int* out = p.assigned + (size_t)prob * Q;
-  for (int j = lane; j < Q; j += 64) out[j] = -1;
-  if (G <= 0) return;
-  // the sample's costs, transposed into LDS (coalesced global reads: g fastest; 16 loads in flight per lane)
+  for (int j = tid; j < Q; j += LSA_NT) out[j] = -1;
+  if (G <= 0) return;                                         // (workgroup-uniform)
+  if (tid == 0) bad_s = 0;
+  for (int j = tid; j < LSA_QMAX; j += LSA_NT) row4col_s[j] = -1;
+  __syncthreads();
+  // the sample's costs, transposed into LDS (coalesced global reads: g fastest; 8 loads in flight per thread)
   const float* cg = p.cost + (size_t)prob * Q * p.Gmax;
   const int total = Q * p.Gmax;
   int bad = 0;
 #pragma unroll 1
-  for (int base = 0; base < total; base += 64 * 16) {
-    float c[16];
+  for (int base = 0; base < total; base += LSA_NT * 8) {
+    float c[8];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int i = base + 64 * t + lane;
+    for (int t = 0; t < 8; ++t) {
+      const int i = base + LSA_NT * t + tid;
       c[t] = i < total ? ldg1(cg + i) : 0.0f;
     }
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int i = base + 64 * t + lane;
+    for (int t = 0; t < 8; ++t) {
+      const int i = base + LSA_NT * t + tid;
       const int q = i / p.Gmax, g = i - q * p.Gmax;
       if (i < total && g < G) {
         bad |= !(fabsf(c[t]) <= 3.0e38f);
@@ -228,68 +251,67 @@ __global__ __launch_bounds__(64) void lsa_kernel(LsaK p) {
       }
     }
   }
-  if (__any(bad)) {                                 // scipy: "matrix contains invalid numeric entries"
-    if (lane == 0 && p.status != nullptr) atomicAdd(p.status, 1);
+  if (bad) bad_s = 1;
+  for (int i = tid; i < G; i += LSA_NT) { u[i] = 0.0; col4row[i] = -1; }
+  __syncthreads();
+  if (bad_s) {                                      // scipy: "matrix contains invalid numeric entries"
+    if (tid == 0 && p.status != nullptr) atomicAdd(p.status, 1);
     return;
   }
-  for (int i = lane; i < G; i += 64) { u[i] = 0.0; col4row[i] = -1; }
   double v[LSA_COLS];
   int row4col[LSA_COLS];
 #pragma unroll
   for (int k = 0; k < LSA_COLS; ++k) { v[k] = 0.0; row4col[k] = -1; }
-  __syncthreads();                                  // (one wave: orders the LDS writes above)
   const double INF = __longlong_as_double(0x7FF0000000000000ll);
   for (int cur = 0; cur < G; ++cur) {
     double spc[LSA_COLS];
-    int path[LSA_COLS];
-    unsigned sc = 0;                                // bit k: column lane + 64 k has been scanned (left `remaining`)
+    unsigned sc = 0;                                // bit k: column tid + LSA_NT k has been scanned (left `remaining`)
 #pragma unroll
-    for (int k = 0; k < LSA_COLS; ++k) { spc[k] = INF; path[k] = -1; }
-    for (int i = lane; i < G; i += 64) SR[i] = 0;
+    for (int k = 0; k < LSA_COLS; ++k) spc[k] = INF;
+    for (int i = tid; i < G; i += LSA_NT) SR[i] = 0;
     __syncthreads();
     double minVal = 0.0;
     int i = cur, sink = -1;
     while (sink < 0) {
-      if (lane == 0) SR[i] = 1;
+      if (tid == 0) SR[i] = 1;
       const double ui = u[i];
       const float* crow = lsa_cost + i * Qpad;
-      float cij[LSA_COLS];
+      double best = INF;
+      unsigned bkey = 0xFFFFFFFFu;
 #pragma unroll
       for (int k = 0; k < LSA_COLS; ++k) {
-        const int j = lane + 64 * k;
-        cij[k] = j < Q ? (LDS ? crow[j] : ldg1(cg + (size_t)j * p.Gmax + i)) : 0.0f;
-      }
-      double best = INF; int bestk = -1, best_free = 0;
-#pragma unroll
-      for (int k = 0; k < LSA_COLS; ++k) {
-        const int j = lane + 64 * k;
+        const int j = tid + LSA_NT * k;
         if (j < Q && !((sc >> k) & 1u)) {
-          const double r = minVal + (double)cij[k] - ui - v[k];
-          if (r < spc[k]) { spc[k] = r; path[k] = i; }
-          const int fr = row4col[k] < 0;
-          // strictly lower, or equal and unassigned while the incumbent is assigned (scipy prefers a new sink)
-          if (spc[k] < best || (spc[k] == best && fr && !best_free)) { best = spc[k]; bestk = k; best_free = fr; }
+          const float cij = LDS ? crow[j] : ldg1(cg + (size_t)j * p.Gmax + i);
+          const double r = minVal + (double)cij - ui - v[k];
+          if (r < spc[k]) { spc[k] = r; path_s[j] = i; }
+          const unsigned key = lsa_key(j, row4col[k] < 0);
+          if (spc[k] < best || (spc[k] == best && key < bkey)) { best = spc[k]; bkey = key; }
         }
       }
-      const double lowest = wave_min_f64(best);
-      if (!(lowest < INF)) {                        // infeasible (cannot happen with finite costs)
-        if (lane == 0 && p.status != nullptr) atomicAdd(p.status, 1);
+      // the workgroup's lowest (value, key): wave, then the waves' candidates through LDS
+      const double wlow = wave_min_f64(best);
+      const unsigned wkey = wave_min_u32(best == wlow ? bkey : 0xFFFFFFFFu);
+      if (lane == 0) { red_val[wave] = wlow; red_key[wave] = wkey; }
+      __syncthreads();
+      double lowest = red_val[0];
+      unsigned key = red_key[0];
+#pragma unroll
+      for (int w = 1; w < LSA_NT / 64; ++w) {
+        const double t = red_val[w];
+        const unsigned tk = red_key[w];
+        if (t < lowest || (t == lowest && tk < key)) { lowest = t; key = tk; }
+      }
+      if (!(lowest < INF)) {                        // infeasible (cannot happen with finite costs); uniform
+        if (tid == 0 && p.status != nullptr) atomicAdd(p.status, 1);
         return;
       }
-      // among the lanes that hold the minimum: an unassigned column first, then the lowest column index
-      const int mine = best == lowest && bestk >= 0;
-      const unsigned long long free_m = __ballot(mine && best_free), any_m = __ballot(mine);
-      const int win = __ffsll((long long)(free_m ? free_m : any_m)) - 1;
-      const int wk = __shfl(bestk, win, 64);
-      int r4c = -1;
-#pragma unroll
-      for (int k = 0; k < LSA_COLS; ++k) if (k == wk) r4c = row4col[k];
-      r4c = __shfl(r4c, win, 64);
       minVal = lowest;
-      const int j = win + 64 * wk;
-      if (lane == win) sc |= 1u << wk;
+      const int j = lsa_key_col(key);
+      if ((j & (LSA_NT - 1)) == tid) sc |= 1u << (j / LSA_NT);          // its owner takes it out of `remaining`
+      const int r4c = (key >> 20) ? row4col_s[j] : -1;                   // (the key says whether it is assigned)
       if (r4c < 0) sink = j; else i = r4c;
-      __syncthreads();                              // SR[i] of lane 0 before the dual update reads it
+      __syncthreads();                              // red_* are free again; SR / path_s of this step are visible
     }
     // dual update (scipy: u[cur] += minVal; u[i] += minVal - spc[col4row[i]] for the other scanned rows;
     // v[j] -= minVal - spc[j] for the scanned columns)
@@ -301,55 +323,49 @@ __global__ __launch_bounds__(64) void lsa_kernel(LsaK p) {
       }
     }
     __syncthreads();
-    for (int r = lane; r < G; r += 64) {
+    for (int r = tid; r < G; r += LSA_NT) {
       if (r == cur) u[r] += minVal;
       else if (SR[r]) u[r] += minVal - spc_of_col4row[r];
     }
-    __syncthreads();
-    // augment along the path from the sink back to `cur`
-    int j = sink;
-    for (;;) {
-      const int ol = j & 63, ok = j >> 6;
-      int pi = -1;
-#pragma unroll
-      for (int k = 0; k < LSA_COLS; ++k) if (k == ok) pi = path[k];
-      pi = __shfl(pi, ol, 64);
-      if (lane == ol) {
-#pragma unroll
-        for (int k = 0; k < LSA_COLS; ++k) if (k == ok) row4col[k] = pi;
+    // augment along the path from the sink back to `cur`: one thread walks it (at most G steps, usually one or two)
+    if (tid == 0) {
+      int j = sink;
+      for (;;) {
+        const int pi = path_s[j];
+        row4col_s[j] = pi;
+        const int prev = col4row[pi];
+        col4row[pi] = j;
+        j = prev;
+        if (pi == cur) break;
       }
-      const int prev = col4row[pi];
-      __syncthreads();
-      if (lane == 0) col4row[pi] = j;
-      __syncthreads();
-      j = prev;
-      if (pi == cur) break;
     }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < LSA_COLS; ++k) row4col[k] = row4col_s[tid + LSA_NT * k];
   }
-  __syncthreads();
-  for (int r = lane; r < G; r += 64) out[col4row[r]] = r;
-  if (lane < 2 && p.num_pos != nullptr) atomicAdd(p.num_pos + 2 * (prob / p.B) + lane, (float)G);
+  for (int r = tid; r < G; r += LSA_NT) out[col4row[r]] = r;
+  if (tid < 2 && p.num_pos != nullptr) atomicAdd(p.num_pos + 2 * (prob / p.B) + tid, (float)G);
 }
 
 int launch_lsa(const float* cost, const int* gt_counts, int P, int B, int Q, int Gmax, int* assigned, float* num_pos,
                int* status, hipStream_t s) {
   TC_REQUIRE(P >= 1 && B >= 1 && P % B == 0, "lsa: P=%d B=%d", P, B);
-  TC_REQUIRE(Q >= 1 && Q <= 64 * LSA_COLS && Gmax >= 1 && Gmax <= LSA_GMAX && Gmax <= Q,
-             "lsa: Q=%d (<= %d) Gmax=%d (<= %d, <= Q)", Q, 64 * LSA_COLS, Gmax, LSA_GMAX);
+  TC_REQUIRE(Q >= 1 && Q <= LSA_QMAX && Gmax >= 1 && Gmax <= LSA_GMAX && Gmax <= Q,
+             "lsa: Q=%d (<= %d) Gmax=%d (<= %d, <= Q)", Q, LSA_QMAX, Gmax, LSA_GMAX);
   const size_t lds = (size_t)Gmax * ((Q + 63) & ~63) * sizeof(float);
-  const bool in_lds = lds <= 150 * 1024;
+  const bool in_lds = lds <= 140 * 1024;        // (beside ~12 KB of static LDS)
   static DeviceOnce once;
   if (const int once_dev = once.need(); once_dev >= 0) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lsa_kernel<true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
     if (e != hipSuccess) { set_error("lsa: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     once.done(once_dev);
   }
   LsaK p;
   p.cost = cost; p.gt_counts = gt_counts; p.P = P; p.B = B; p.Q = Q; p.Gmax = Gmax; p.assigned = assigned;
   p.num_pos = num_pos; p.status = status;
-  if (in_lds) hipLaunchKernelGGL(lsa_kernel<true>, dim3(P), dim3(64), lds, s, p);
-  else hipLaunchKernelGGL(lsa_kernel<false>, dim3(P), dim3(64), 0, s, p);
+  if (in_lds) hipLaunchKernelGGL(lsa_kernel<true>, dim3(P), dim3(LSA_NT), lds, s, p);
+  else hipLaunchKernelGGL(lsa_kernel<false>, dim3(P), dim3(LSA_NT), 0, s, p);
   return check_launch("lsa");
 }
 
