@@ -1140,6 +1140,43 @@ def test_timed_geometry_is_frame_by_frame_the_single_frame_path(T, fpl):
             assert torch.equal(a_[0], b_[slot]), (lane, slot)
 
 
+def test_plugin_entry_stages_lidar2img_per_call(T, head):
+    """`Detr3DHead.forward` stages img_metas' projection matrices through a ring of eight pinned buffers and skips the
+    copy when they are the ones staged last (ops._Lidar2ImgStaging): 20 calls that alternate fresh rigs, a repeated
+    rig and a rig whose numpy arrays were modified IN PLACE since the last call all equal the device forward on a
+    freshly uploaded tensor, bit for bit -- also from a second stream."""
+    from transcar_amd import ops
+    feats = [gpu(f) for f in synth.make_feats('tiny', seed=1, smooth=SMOOTH)]
+    frame = synth.make_radar_frame(seed=2)
+    tok, pm = head.radar_tokens(synth.make_img_metas(1, synth.make_lidar2img(), radar=frame), dev())
+    nhwc = ops.to_nhwc_levels(feats)
+    rng = np.random.RandomState(3)
+    base = synth.make_lidar2img()
+    l2i = base.copy()
+    side = torch.cuda.Stream()
+    for it in range(20):
+        kind = it % 4
+        if kind == 0:
+            l2i = base * (1.0 + 0.01 * rng.standard_normal(base.shape))       # a new rig (new arrays)
+        elif kind == 2:
+            l2i[:, 0, 3] += 0.25                                                # the SAME arrays, modified in place
+        # kind 1, 3: unchanged since the last call (no copy)
+        metas = synth.make_img_metas(1, l2i, radar=frame)
+        if it >= 12:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                got = head(feats, metas)
+            torch.cuda.current_stream().wait_stream(side)
+        else:
+            got = head(feats, metas)
+        want = head.forward_nhwc(nhwc, ops.lidar2img_tensor(metas, dev()), configs.IMG_SHAPE[:2], tok, pm)
+        torch.cuda.synchronize()
+        for k in ('all_cls_scores', 'all_bbox_preds'):
+            assert torch.equal(got[k], want[k]), (it, k)
+    st = ops._l2i_staging
+    assert st.last[str(dev())][0].dtype == np.float32 and len(next(iter(st.slots.values()))[0]) == 8
+
+
 def test_ragged_radar_batch_through_the_plugin_entry(T, head):
     """One `head(mlvl_feats, img_metas)` call with three samples whose radar frames differ in size (255 points, a
     ragged handful, none at all): the batch ingest (tc_radar_build_tokens_batch, one launch) writes every sample's
