@@ -61,6 +61,33 @@ def main():
             print('  wave%d:' % w, ' '.join('%6d' % (row[j] - row[0]) for j in range(n)))
             print('     item0 [start, A read, setup, mfma+prefetch]:', ' '.join('%6d' % (row[j] - row[0]) for j in range(20, 24)),
                   ' item1:', ' '.join('%6d' % (row[j] - row[0]) for j in range(25, 29)))
+    if which == 'radar':
+        # the radar chain is the forward's last chain launch: its workgroups' spans, by tile position inside a sample
+        # (beyond one frame per launch the rows of a sample are ordered hits first: the gated part -- q projection,
+        # attention over the hit tokens, out_proj -- runs in the first tiles only)
+        wg = np.zeros((1024, 2), dtype=np.int64)
+        lib.tc_debug_wg_spans.restype = C.c_int
+        lib.tc_debug_wg_spans.argtypes = [C.c_void_p]
+        assert lib.tc_debug_wg_spans(wg.ctypes.data) == 0
+        rows = batch * head.num_query
+        R = 4 if rows <= 1024 else 8 if rows <= 2048 else 16
+        nb = min(-(-rows // R), 1024)
+        w = wg[:nb]
+        t0 = w[:, 0].min()
+        start, span = w[:, 0] - t0, w[:, 1] - w[:, 0]
+        print('radar chain: %d workgroups of %d rows; span min/median/max %d/%d/%d'
+              % (nb, R, span.min(), np.median(span), span.max()))
+        print('  span deciles:', ' '.join('%d' % x for x in np.percentile(span, [0, 10, 20, 30, 40, 50, 60, 70, 80, 90, 100])))
+        hist, edges = np.histogram(span, bins=12)
+        print('  span histogram (cycles: workgroups):', ', '.join('%d-%d: %d' % (edges[i], edges[i + 1], hist[i]) for i in range(len(hist))))
+        tiles_per_sample = -(-head.num_query // R)
+        pos = (np.arange(nb) * R % head.num_query) // R if rows % head.num_query == 0 else np.arange(nb) % tiles_per_sample
+        first = np.array([np.median(span[(np.arange(nb) * R // head.num_query == b) & ((np.arange(nb) * R % head.num_query) < 4 * R)])
+                          for b in range(batch)])
+        rest = np.array([np.median(span[(np.arange(nb) * R // head.num_query == b) & ((np.arange(nb) * R % head.num_query) >= 8 * R)])
+                         for b in range(batch)])
+        print('  median span of a sample\'s first 4 tiles (hit rows) %d, of its tiles from the 8th on (no hits) %d'
+              % (np.median(first), np.median(rest)))
     if which == 'decoder':
         wg = np.zeros((1024, 2), dtype=np.int64)
         lib.tc_debug_wg_spans.restype = C.c_int
