@@ -35,10 +35,12 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-enum Mode { M_F32 = 0, M_BF3_6 = 1, M_BF3_9 = 2, M_F16_3 = 3 };
+enum Mode { M_F32 = 0, M_BF3_6 = 1, M_BF3_9 = 2, M_F16_3 = 3, M_F16_I8 = 4 };
+// M_F16_I8: the weights' hi plane f16 + the residual as ONE BYTE per weight (round((w - hi) 2^S) + 128, S per matrix):
+// 3 bytes per weight instead of 4; the bytes become f16 integers in registers (v_perm + one packed add per two)
 __host__ __device__ constexpr int planes_of(int m) { return m == M_F32 ? 0 : (m == M_BF3_6 || m == M_BF3_9) ? 3 : 2; }
 // fragments (1 KiB per wave each) of a 64-column x 64-k item
-__host__ __device__ constexpr int frags_of(int m) { return m == M_F32 ? 16 : 8 * planes_of(m); }
+__host__ __device__ constexpr int frags_of(int m) { return m == M_F32 ? 16 : m == M_F16_I8 ? 12 : 8 * planes_of(m); }
 
 constexpr int LDA = 260;
 
@@ -71,17 +73,27 @@ __device__ __forceinline__ void split_bf3(const float4& a, const float4& b, uint
   p2 = make_uint4(q2[0], q2[1], q2[2], q2[3]);
   p3 = make_uint4(q3[0], q3[1], q3[2], q3[3]);
 }
-__device__ __forceinline__ void split_f16(const float4& a, const float4& b, uint4& p1, uint4& p2) {
+__device__ __forceinline__ void split_f16(const float4& a, const float4& b, uint4& p1, uint4& p2, float xs = 2048.0f) {
   const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
   uint32_t q1[4], q2[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     q1[i] = pk_f16(x[2 * i], x[2 * i + 1]);
-    const float r0 = (x[2 * i] - h_lo(q1[i])) * 2048.0f, r1 = (x[2 * i + 1] - h_hi(q1[i])) * 2048.0f;
+    const float r0 = (x[2 * i] - h_lo(q1[i])) * xs, r1 = (x[2 * i + 1] - h_hi(q1[i])) * xs;
     q2[i] = pk_f16(r0, r1);
   }
   p1 = make_uint4(q1[0], q1[1], q1[2], q1[3]);
   p2 = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+}
+
+// 8 bytes (u = residual + 128) -> the MFMA operand of 8 f16 integers u - 128: byte | 0x6400 is the f16 1024 + u
+__device__ __forceinline__ uint4 bytes_to_f16(uint32_t d0, uint32_t d1) {
+  const f16x2 off = {(_Float16)-1152.0f, (_Float16)-1152.0f};
+  auto cv = [&](uint32_t d, uint32_t sel) {
+    const uint32_t h = __builtin_amdgcn_perm(0x64646464u, d, sel);
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2, h) + off);
+  };
+  return make_uint4(cv(d0, 0x04010400u), cv(d0, 0x04030402u), cv(d1, 0x04010400u), cv(d1, 0x04030402u));
 }
 
 #define MFMA_BF(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
@@ -102,8 +114,37 @@ template <int MODE, int RG>
 struct Item {
   static constexpr int FR = frags_of(MODE);
   static __device__ __forceinline__ void run(f32x4 (&acc)[RG][4], f32x4 (&lo)[RG][4], uint4 (&w)[FR], const float* arow,
-                                             const char* next, unsigned lo_off) {
-    if constexpr (MODE == M_F32) {
+                                             const char* next, unsigned lo_off, float xs) {
+    if constexpr (MODE == M_F16_I8) {
+      // item: 8 hi fragments of 1 KiB, then 4 x 1 KiB of residual bytes (fragments 2 p and 2 p + 1 side by side, 8 B each
+      // per lane); w[0..7] the hi fragments, w[8 + p] the bytes of fragments 2 p, 2 p + 1
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        uint4 x[RG][2];
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg) {
+          const float4 a = *reinterpret_cast<const float4*>(arow + rg * 16 * LDA + 32 * kk);
+          const float4 b = *reinterpret_cast<const float4*>(arow + rg * 16 * LDA + 32 * kk + 4);
+          split_f16(a, b, x[rg][0], x[rg][1], xs);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int f = kk * 4 + j;
+          const uint4 wl4 = w[8 + (f >> 1)];
+          const uint4 wl = (f & 1) ? bytes_to_f16(wl4.z, wl4.w) : bytes_to_f16(wl4.x, wl4.y);
+#pragma unroll
+          for (int rg = 0; rg < RG; ++rg) {
+            lo[rg][j] = MFMA_H(wl, x[rg][0], lo[rg][j]);
+            lo[rg][j] = MFMA_H(w[f], x[rg][1], lo[rg][j]);
+            acc[rg][j] = MFMA_H(w[f], x[rg][0], acc[rg][j]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          w[f] = ldg16(next + lo_off + f * 1024);
+          if (f & 1) w[8 + (f >> 1)] = ldg16(next + lo_off + (8 + (f >> 1)) * 1024);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else if constexpr (MODE == M_F32) {
       float4 ar[RG][4];
 #pragma unroll
       for (int rg = 0; rg < RG; ++rg)
@@ -173,7 +214,7 @@ struct Item {
 template <int MODE, int RG>
 __global__ __launch_bounds__(256, RG == 1 ? 2 : 1) void loop_kernel(const char* __restrict__ W, const float* __restrict__ X,
                                                                     float* __restrict__ Y, int nitems, int nrep,
-                                                                    long long* __restrict__ cyc, int store, int M) {
+                                                                    long long* __restrict__ cyc, int store, int M, float xs) {
   extern __shared__ __align__(16) float lds[];          // [16 RG][LDA]
   constexpr int FR = frags_of(MODE);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -203,7 +244,7 @@ __global__ __launch_bounds__(256, RG == 1 ? 2 : 1) void loop_kernel(const char* 
 #pragma unroll 1
     for (int it = 0; it < nitems; ++it) {
       const int nx = it + 1 < nitems ? it + 1 : 0;
-      Item<MODE, RG>::run(acc, lo, w, arow0 + 64 * (it & 3), wbase + (size_t)nx * item_bytes, lo_off);
+      Item<MODE, RG>::run(acc, lo, w, arow0 + 64 * (it & 3), wbase + (size_t)nx * item_bytes, lo_off, xs);
       if (store && (it & 3) == 3) {
         // one 64-column tile of Y is complete (K = 256): item it belongs to tile (it >> 2), wave's columns
         const int tile = (it >> 2) * 4 + wave;
@@ -213,9 +254,9 @@ __global__ __launch_bounds__(256, RG == 1 ? 2 : 1) void loop_kernel(const char* 
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             f32x4 v = acc[rg][j];
-            if constexpr (MODE == M_F16_3) {
+            if constexpr (MODE == M_F16_3 || MODE == M_F16_I8) {
 #pragma unroll
-              for (int i = 0; i < 4; ++i) v[i] = v[i] + lo[rg][j][i] * (1.0f / 2048.0f);
+              for (int i = 0; i < 4; ++i) v[i] = v[i] + lo[rg][j][i] * (1.0f / xs);
             }
             const int row = m0 + 16 * rg + c;
             if (row < M && tile * 64 < 256)
@@ -249,8 +290,16 @@ static float h2f(uint16_t u) { _Float16 h; memcpy(&h, &u, 2); return (float)h; }
 
 // Wsrc(tile-of-64-columns t, k) -> packed item stream [wave][item][frag][lane][16 B]; item `it` of wave w is
 // column tile 4 (it / 4) + w, k block it % 4 (K = 256) -- `wrap` tiles repeat the 256-column matrix
+static float g_xs = 2048.0f;        // M_F16_I8: 2^S of the matrix (set by pack)
 static std::vector<char> pack(int mode, const std::vector<float>& W /*[256][256]*/, int nitems) {
   const int FR = frags_of(mode);
+  if (mode == M_F16_I8) {
+    float rmax = 0;
+    for (float x : W) rmax = std::max(rmax, fabsf(x - h2f(f2h(x))));
+    int S = 0;
+    while (ldexpf(rmax, S + 1) <= 127.0f) ++S;
+    g_xs = ldexpf(1.0f, S);
+  } else g_xs = 2048.0f;
   std::vector<char> out((size_t)4 * nitems * FR * 1024);
   for (int w = 0; w < 4; ++w)
     for (int it = 0; it < nitems; ++it) {
@@ -258,7 +307,19 @@ static std::vector<char> pack(int mode, const std::vector<float>& W /*[256][256]
       char* item = out.data() + ((size_t)w * nitems + it) * FR * 1024;
       for (int lane = 0; lane < 64; ++lane) {
         const int g = lane >> 4, c = lane & 15;
-        if (mode == M_F32) {
+        if (mode == M_F16_I8) {
+          for (int f = 0; f < 8; ++f) {
+            const int kk = f >> 2, j = f & 3;
+            uint16_t hi[8]; unsigned char by[8];
+            for (int e = 0; e < 8; ++e) {
+              const float x = W[(size_t)(64 * tile + 16 * j + c) * 256 + 64 * kb + 32 * kk + 8 * g + e];
+              hi[e] = f2h(x);
+              by[e] = (unsigned char)(lrintf((x - h2f(hi[e])) * g_xs) + 128);
+            }
+            memcpy(item + f * 1024 + lane * 16, hi, 16);
+            memcpy(item + (8 + (f >> 1)) * 1024 + lane * 16 + 8 * (f & 1), by, 8);
+          }
+        } else if (mode == M_F32) {
           for (int J = 0; J < 16; ++J) {
             float v[4];
             for (int j = 0; j < 4; ++j) v[j] = W[(size_t)(64 * tile + 16 * j + c) * 256 + 64 * kb + 16 * (J >> 2) + 4 * g + (J & 3)];
@@ -301,7 +362,7 @@ static void run_mode(const char* name, const std::vector<float>& X, const std::v
     CK(hipMemcpy(dX, X.data(), X.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemset(dY, 0, (size_t)M * 256 * 4));
     const int nb = (M + 16 * RG - 1) / (16 * RG);
-    hipLaunchKernelGGL((loop_kernel<MODE, RG>), dim3(nb), dim3(256), 16 * RG * LDA * 4, 0, dP, dX, dY, 4, 1, nullptr, 1, M);
+    hipLaunchKernelGGL((loop_kernel<MODE, RG>), dim3(nb), dim3(256), 16 * RG * LDA * 4, 0, dP, dX, dY, 4, 1, nullptr, 1, M, g_xs);
     CK(hipDeviceSynchronize());
     std::vector<float> Y((size_t)M * 256);
     CK(hipMemcpy(Y.data(), dY, Y.size() * 4, hipMemcpyDeviceToHost));
@@ -326,12 +387,12 @@ static void run_mode(const char* name, const std::vector<float>& X, const std::v
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int warm = 0; warm < 3; ++warm)
-      hipLaunchKernelGGL((loop_kernel<MODE, RG>), dim3(nb), dim3(256), 16 * RG * LDA * 4, 0, dP, dX, dY, nitems, nrep, dC, 0, Mr);
+      hipLaunchKernelGGL((loop_kernel<MODE, RG>), dim3(nb), dim3(256), 16 * RG * LDA * 4, 0, dP, dX, dY, nitems, nrep, dC, 0, Mr, g_xs);
     CK(hipDeviceSynchronize());
     const int NL = 10;
     CK(hipEventRecord(e0));
     for (int l = 0; l < NL; ++l)
-      hipLaunchKernelGGL((loop_kernel<MODE, RG>), dim3(nb), dim3(256), 16 * RG * LDA * 4, 0, dP, dX, dY, nitems, nrep, dC, 0, Mr);
+      hipLaunchKernelGGL((loop_kernel<MODE, RG>), dim3(nb), dim3(256), 16 * RG * LDA * 4, 0, dP, dX, dY, nitems, nrep, dC, 0, Mr, g_xs);
     CK(hipEventRecord(e1));
     CK(hipDeviceSynchronize());
     float ms = 0;
@@ -384,8 +445,10 @@ int main() {
   run_mode<M_BF3_6, 1>("bf16x3/6", X, W, Yref, yscale, M);
   run_mode<M_BF3_9, 1>("bf16x3/9", X, W, Yref, yscale, M);
   run_mode<M_F16_3, 1>("f16x2/3", X, W, Yref, yscale, M);
+  run_mode<M_F16_I8, 1>("f16+i8/3", X, W, Yref, yscale, M);
   run_mode<M_F32, 2>("f32", X, W, Yref, yscale, M);
   run_mode<M_BF3_6, 2>("bf16x3/6", X, W, Yref, yscale, M);
   run_mode<M_F16_3, 2>("f16x2/3", X, W, Yref, yscale, M);
+  run_mode<M_F16_I8, 2>("f16+i8/3", X, W, Yref, yscale, M);
   return 0;
 }
