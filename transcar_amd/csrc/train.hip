@@ -285,7 +285,10 @@ int launch_linear_bwd_weight_group(const WeightJob* jobs, int n, hipStream_t s) 
     BwdGemmK p;
     p.A = j.dy; p.relu = j.relu; p.gate = nullptr; p.Bm = j.x; p.cmask = nullptr; p.C = j.dw;
     p.colsum = j.db; p.ldA = j.N; p.ldB = j.ldx > 0 ? j.ldx : j.K; p.ldC = j.K; p.I = j.N; p.J = j.K; p.R = j.M;
-    p.rchunk = 128; p.accumulate = 1; p.alpha = 1.0f;
+#ifndef TC_WG_RCHUNK
+#define TC_WG_RCHUNK 256     // rows per workgroup: 128 -> 256 halved the float atomics into dW (0.845 -> 0.809 ms per iteration; 512: the same)
+#endif
+    p.rchunk = TC_WG_RCHUNK; p.accumulate = 1; p.alpha = 1.0f;
     const int v = bg_vec_ok(p, j.N) ? 1 : 0;
     WGroupItem& it = g[v].it[g[v].n++];
     it.p = p; it.gx = (j.K + 63) / 64; it.gy = (j.N + 63) / 64; it.gz = (j.M + p.rchunk - 1) / p.rchunk;
