@@ -366,27 +366,40 @@ def test_fused_training_path_gradients_match_reference(A, golden_dir, tag):
 
 
 def assert_same_gradients_up_to_one_relu_tie(h, tr, fused, auto, tol=1e-4):
-    """The two paths sum in different orders, so a LayerNorm output within an ulp of zero can land on either side of
-    the ReLU behind it.  That happens on the ResNet-101 frame since round 4 (row/channel 131 of final_cls2's second
-    LayerNorm; the decoder states moved by an ulp with the attention-maximum fix): ONE query row then contributes
-    differently, which is a rank-one term in every query-side weight gradient (every operator between the radar
-    attention and the losses is row-wise).  Allowed: at most one such row -- with the rank-one term removed the
-    query-side gradients agree to `tol`, and everything agrees to the fixture's 4e-3."""
+    """(flat gradient buffers of the trainer's bucket: see assert_grad_dicts_equal_up_to_one_relu_tie)"""
     d = float((auto - fused).abs().max() / fused.abs().max())
     if d < tol:
         return
     assert d < 4e-3, d
-    ties = 0
+    got, want = {}, {}
     for (n, p), off in zip(h.trainable_parameters(), tr.bucket.offsets):
-        if p.dim() != 2 or not n.startswith(('final_cls', 'final_reg', 'rf_linear', 'rf_multihead_attn')) \
-                or 'in_proj' in n:
+        got[n], want[n] = (b[off:off + p.numel()].view_as(p) for b in (auto, fused))
+    assert_grad_dicts_equal_up_to_one_relu_tie(got, want, tol, per_tensor=False)
+
+
+def assert_grad_dicts_equal_up_to_one_relu_tie(got, want, tol, per_tensor=True):
+    """Two paths that sum in different orders can put a LayerNorm output within an ulp of zero on different sides of
+    the ReLU behind it (final_cls*.3 -> LayerNorm -> ReLU on these fixtures).  ONE query row then contributes
+    differently, which is a rank-one term in every query-side weight gradient (every operator between the radar
+    attention and the losses is row-wise).  Allowed: every tensor within `tol` (relative to its own maximum when
+    `per_tensor`) -- or, if some are not, at most one such row: with the rank-one term removed the query-side weight
+    gradients agree to `tol`, and everything agrees to 4e-3."""
+    worst, ties = 0.0, 0
+    for n, w in want.items():
+        scale = max(float(w.abs().max()), 1e-6)
+        worst = max(worst, float((got[n] - w).abs().max()) / scale)
+    if per_tensor and worst <= tol:
+        return
+    for n, w in want.items():
+        scale = max(float(w.abs().max()), 1e-6)
+        d = float((got[n] - w).abs().max())
+        assert d <= 4e-3 * scale + 1e-7, (n, d, scale)
+        if w.dim() != 2 or not n.startswith(('final_cls', 'final_reg', 'rf_linear', 'rf_multihead_attn')) or 'in_proj' in n:
             continue
-        a, f = (b[off:off + p.numel()].view_as(p).double() for b in (auto, fused))
-        sv = torch.linalg.svdvals(a - f)
-        scale = float(f.abs().max())
+        sv = torch.linalg.svdvals((got[n] - w).double())
         assert float(sv[1]) < tol * scale, (n, [float(x) for x in sv[:3]], scale)
         ties += float(sv[0]) >= tol * scale
-    assert ties > 0, ('gradients differ by %g without a rank-one explanation' % d)
+    assert ties > 0, ('gradients differ by %g (relative) without a rank-one explanation' % worst)
 
 
 def test_fused_training_batch_of_two_matches_autograd_path(A, golden_dir):
@@ -834,10 +847,7 @@ def test_fused_training_with_many_radar_tokens(A, golden_dir, T_tok, n_per):
         assert all(torch.isfinite(v).all() for v in res[fused][1].values())
     for k, v in res[False][0].items():
         assert abs(res[True][0][k] - v) < 2e-4 * max(1.0, abs(v)), (k, res[True][0][k], v)
-    for n, want in res[False][1].items():
-        scale = float(want.abs().max())
-        d = float((res[True][1][n] - want).abs().max())
-        assert d <= 5e-4 * max(scale, 1e-6) + 1e-7, (n, d, scale)
+    assert_grad_dicts_equal_up_to_one_relu_tie(res[True][1], res[False][1], 5e-4)
     # the attention path carried gradient (the frame has radar returns inside the gates)
     assert float(res[True][1]['rf_multihead_attn.in_proj_weight'].abs().max()) > 0
 

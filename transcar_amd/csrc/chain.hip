@@ -699,12 +699,12 @@ __device__ __forceinline__ void lin_epilogue16(const LinSpec& s, int tile, const
       unsigned long long seed = s.drop_seed;
       if (s.drop_q > 0) { const unsigned b = row / (unsigned)s.drop_q; row -= b * (unsigned)s.drop_q; seed += b * s.drop_stride; }
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j) {
+        // the lane's four consecutive columns of sub-tile j: one hash (N and colb are multiples of 4)
+        const unsigned m = drop_keep4(seed, (unsigned)(s.drop_site - 1), row * (unsigned)s.N + (unsigned)(colb + 16 * j), s.drop_thr);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const unsigned idx = row * (unsigned)s.N + (unsigned)(colb + 16 * j + i);
-          y[j][i] = drop_keep(seed, (unsigned)(s.drop_site - 1), idx, s.drop_thr) ? y[j][i] * s.drop_scale : 0.0f;
-        }
+        for (int i = 0; i < 4; ++i) y[j][i] = ((m >> i) & 1u) ? y[j][i] * s.drop_scale : 0.0f;
+      }
     }
   }
   if (s.res != nullptr) {
@@ -1777,10 +1777,11 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
           float4 v = *reinterpret_cast<const float4*>(src + row * LD2 + 4 * lane);
           const unsigned idx = (unsigned)grow * 256u + 4u * (unsigned)lane;
           const float sc = k.rdrop.scale;
-          v.x = drop_keep(k.rdrop.seed, site, idx + 0u, k.rdrop.thr) ? v.x * sc : 0.0f;
-          v.y = drop_keep(k.rdrop.seed, site, idx + 1u, k.rdrop.thr) ? v.y * sc : 0.0f;
-          v.z = drop_keep(k.rdrop.seed, site, idx + 2u, k.rdrop.thr) ? v.z * sc : 0.0f;
-          v.w = drop_keep(k.rdrop.seed, site, idx + 3u, k.rdrop.thr) ? v.w * sc : 0.0f;
+          const unsigned dm = drop_keep4(k.rdrop.seed, site, idx, k.rdrop.thr);
+          v.x = (dm & 1u) ? v.x * sc : 0.0f;
+          v.y = (dm & 2u) ? v.y * sc : 0.0f;
+          v.z = (dm & 4u) ? v.z * sc : 0.0f;
+          v.w = (dm & 8u) ? v.w * sc : 0.0f;
           if (gated && S.gate[row] <= 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
           *reinterpret_cast<float4*>(dst + row * LD2 + 4 * lane) = v;
           if (r.gd != nullptr && m0 + row < M) st4(r.gd + (size_t)grow * 256 + 4 * lane, v);

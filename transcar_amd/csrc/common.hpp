@@ -114,10 +114,14 @@ __device__ __forceinline__ void stg1(float* p, float v) { *(TC_GLOBAL float*)(p)
 
 
 // ---- dropout (training): counter-based Bernoulli masks ----------------------
-// keep(seed, site, idx) = splitmix64(seed, site, idx) >> 32 >= thr, thr = round(p * 2^32): the
-// forward and the backward regenerate the same mask from (seed, site, element index) -- no mask
-// tensor is stored.  site = 4 * radar layer + {0: attention probabilities, 1: rf_dropout2,
-// 2: rf_dropout (FFN), 3: rf_dropout3}  (HEAD:129-171).
+// keep(seed, site, idx): ONE splitmix64 of (seed, site, idx / 4) decides the four elements 4 (idx / 4) .. + 3 from its
+// four 16-bit fields (field idx % 4 >= round(p * 2^16)): the forward and the backward regenerate the same mask from
+// (seed, site, element index) -- no mask tensor is stored.  Round 4: until then one hash per ELEMENT (>= thr =
+// round(p * 2^32)): three 64-bit multiplies per element were ~65 us of a 150 us train-mode attention core and of a
+// 170 us train-mode decoder chain (58 M probabilities / 19 M activations per nine frames); a lane that owns four
+// consecutive elements (the 16-row epilogues, the attention probabilities) now pays one (drop_keep4).
+// site = 4 * radar layer + {0: attention probabilities, 1: rf_dropout2, 2: rf_dropout (FFN), 3: rf_dropout3}
+// (HEAD:129-171); the frozen decoder's sites: 16 + 8 * layer + {0..4}.
 struct DropK {
   unsigned long long seed;
   unsigned thr;                // 0: dropout off
@@ -131,13 +135,39 @@ struct DropK {
   unsigned rows_per_sample;
   unsigned pad_;
 };
-__host__ __device__ __forceinline__ bool drop_keep(unsigned long long seed, unsigned site, unsigned idx,
-                                                   unsigned thr) {
-  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (((((unsigned long long)site) << 32) | idx) + 1ull);
+__host__ __device__ __forceinline__ unsigned long long drop_hash(unsigned long long seed, unsigned site, unsigned group) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (((((unsigned long long)site) << 32) | group) + 1ull);
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   z ^= z >> 31;
-  return (unsigned)(z >> 32) >= thr;
+  return z;
+}
+__host__ __device__ __forceinline__ unsigned drop_thr16(unsigned thr) { return (unsigned)(((unsigned long long)thr + 0x8000ull) >> 16); }
+__host__ __device__ __forceinline__ bool drop_keep(unsigned long long seed, unsigned site, unsigned idx,
+                                                   unsigned thr) {
+  const unsigned long long z = drop_hash(seed, site, idx >> 2);
+  return (unsigned)((z >> (16u * (idx & 3u))) & 0xFFFFull) >= drop_thr16(thr);
+}
+// the decisions of elements idx .. idx + 3 as bits 0..3: one hash when idx is a multiple of 4 (the callers' layouts
+// make it one), two otherwise
+__host__ __device__ __forceinline__ unsigned drop_keep4(unsigned long long seed, unsigned site, unsigned idx, unsigned thr) {
+  const unsigned t = drop_thr16(thr);
+  const unsigned long long z = drop_hash(seed, site, idx >> 2);
+  const unsigned a = idx & 3u;
+  unsigned m = 0;
+  if (a == 0u) {
+#pragma unroll
+    for (unsigned i = 0; i < 4u; ++i) m |= (unsigned)(((z >> (16u * i)) & 0xFFFFull) >= t) << i;
+    return m;
+  }
+  const unsigned long long z1 = drop_hash(seed, site, (idx >> 2) + 1u);
+#pragma unroll
+  for (unsigned i = 0; i < 4u; ++i) {
+    const unsigned e = a + i;
+    const unsigned long long zz = e < 4u ? z : z1;
+    m |= (unsigned)(((zz >> (16u * (e & 3u))) & 0xFFFFull) >= t) << i;
+  }
+  return m;
 }
 inline DropK make_drop(float p, unsigned long long seed, unsigned site, unsigned tokens_ref) {
   DropK d;

@@ -118,10 +118,11 @@ __device__ __forceinline__ void sa_tile(const KVFrag& f, const float4& qa, const
   st.l += (p0 + p1) + (p2 + p3);
   float d0 = p0, d1 = p1, d2 = p2, d3 = p3;
   if (DROP) {
-    d0 = drop_keep(drop.seed, drop.site, drop_base + 0, drop.thr) ? p0 * drop.scale : 0.0f;
-    d1 = drop_keep(drop.seed, drop.site, drop_base + 1, drop.thr) ? p1 * drop.scale : 0.0f;
-    d2 = drop_keep(drop.seed, drop.site, drop_base + 2, drop.thr) ? p2 * drop.scale : 0.0f;
-    d3 = drop_keep(drop.seed, drop.site, drop_base + 3, drop.thr) ? p3 * drop.scale : 0.0f;
+    const unsigned dm = drop_keep4(drop.seed, drop.site, drop_base, drop.thr);     // the lane's four consecutive keys
+    d0 = (dm & 1u) ? p0 * drop.scale : 0.0f;
+    d1 = (dm & 2u) ? p1 * drop.scale : 0.0f;
+    d2 = (dm & 4u) ? p2 * drop.scale : 0.0f;
+    d3 = (dm & 8u) ? p3 * drop.scale : 0.0f;
   }
   // O^T[d][q] += V^T[d][key] P^T[key][q]
   st.o0 = MFMA4(v0.x, d0, st.o0); st.o1 = MFMA4(v1.x, d0, st.o1);
