@@ -934,7 +934,7 @@ def test_decoder_prefetch_changes_nothing_but_the_schedule(A, golden_dir):
         frames.append(dict(feats_nhwc=nhwc, lidar2img=ops.lidar2img_tensor(metas, dev()),
                            img_hw=metas[0]['img_shape'][0][:2]))
     res = {}
-    for pre in (False, True):
+    for pre in (False, 'again', True):                 # 'again': the run-to-run noise of the backward's atomics
         h = train_head(golden_dir)
         tokens, pad_mult = h.radar_tokens(metas, dev())
         for fr in frames:
@@ -944,16 +944,19 @@ def test_decoder_prefetch_changes_nothing_but_the_schedule(A, golden_dir):
         for it in range(3):
             cur, nxt = frames[it % 2], frames[(it + 1) % 2]
             losses = tr.step_fused_nhwc(cur['feats_nhwc'], cur['lidar2img'], cur['img_hw'], cur['tokens'], cur['pad_mult'],
-                                        [gt], [labels], prefetch=nxt if pre else None)
+                                        [gt], [labels], prefetch=nxt if pre is True else None)
             hist.append({k: float(v) for k, v in losses.items()})
         torch.cuda.synchronize()
         res[pre] = (hist, tr.bucket.params.clone())
-    for a_, b_ in zip(res[False][0], res[True][0]):
+    # AdamW normalises the step, so the last-bit differences of the atomically summed gradients reach the parameters at
+    # ~1e-5 and the later losses with them: the yardstick is what two plain runs differ by at the same iteration
+    for a_, b_, c_ in zip(res[False][0], res[True][0], res['again'][0]):
         for k in a_:
-            assert abs(a_[k] - b_[k]) <= 2e-5 * max(1.0, abs(a_[k])), (k, a_[k], b_[k])
-    # (AdamW normalises the step: the last-bit differences of the atomically summed gradients show up at ~1e-5)
-    d = (res[True][1] - res[False][1]).abs().max() / res[False][1].abs().max()
-    assert float(d) < 1e-4, float(d)
+            assert abs(a_[k] - b_[k]) <= 2e-5 * max(1.0, abs(a_[k])) + 3.0 * abs(a_[k] - c_[k]), (k, a_[k], b_[k], c_[k])
+    scale = res[False][1].abs().max()
+    noise = float((res['again'][1] - res[False][1]).abs().max() / scale)
+    d = float((res[True][1] - res[False][1]).abs().max() / scale)
+    assert d <= 3.0 * noise + 1e-4, (d, noise)
 
 
 def test_batched_decoder_lookahead_is_the_single_frame_decoder(A, golden_dir):
@@ -1054,6 +1057,34 @@ def test_batched_decoder_lookahead_is_the_single_frame_decoder(A, golden_dir):
     tr.step_fused_nhwc(f['nhwc'], f['l2i'], img_hw, f['tokens'], pad_mult, [gt], [labels], prefetch=None)
     assert tr.lookahead_pending() == 0 and getattr(tr, 'lookahead_hits', 0) == 0
     assert h._train_forwards == counter + 1                           # one seed per training forward, none for the dropped batch
+
+
+def test_train_mode_decoder_on_the_matrix_cores_draws_the_fp32_kernels_masks(A, golden_dir):
+    """The frozen decoder in train mode at 16-row tiles: the two-plane f16 kernels (chains AND the staged attention core
+    with dropout on the probabilities, round 4) against the fp32 MFMA kernels with the same seed -- the masks are a
+    function of (seed, site, element index) only, so the two agree to fp32 rounding; without the seed they do not."""
+    from transcar_amd import ops
+    from transcar_amd.trainer import FusionTrainer
+    h = train_head(golden_dir)
+    feats, metas, gt, labels = frame_inputs(golden_dir, 'tiny')
+    nhwc = [ops.to_nhwc(f) for f in feats]
+    l2i = ops.lidar2img_tensor(metas, dev())
+    img_hw = metas[0]['img_shape'][0][:2]
+    tokens, pad_mult = h.radar_tokens(metas, dev())
+    tr = FusionTrainer(h, dropout=0.1, seed=4, decoder_dropout=0.1, prefetch_depth=9)
+    assert tr.decoder_tile_rows == 16
+    out = {}
+    for mp, seed in (('f16x2', 77), ('f32', 77), ('f16x2', 78)):
+        tr.decoder_matrix_path = mp
+        aux = tr._decoder_forward(nhwc, l2i, img_hw, tokens, pad_mult, seed, 0)['aux']
+        torch.cuda.synchronize()
+        out[(mp, seed)] = {k: v.clone() for k, v in aux.items() if torch.is_tensor(v)}
+    tr.decoder_matrix_path = None
+    a, b, c = out[('f16x2', 77)], out[('f32', 77)], out[('f16x2', 78)]
+    for k in ('inter_states', 'inter_references', 'last_box'):
+        assert torch.isfinite(a[k]).all()
+        assert float((a[k] - b[k]).abs().max()) < 5e-4, (k, float((a[k] - b[k]).abs().max()))
+    assert float((a['inter_states'] - c['inter_states']).abs().max()) > 1e-2      # another seed: other masks
 
 
 def test_backward_chain_guards_non_finite_loss_gradients(A, golden_dir):

@@ -227,12 +227,12 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
     }
     // the attention core follows the chains' rule (chain.hip tile_rows / use_f16x2): launches that run 16-row tiles on
     // the f16 matrix cores take the staged two-plane core (self_attn.hip, round 4) -- 4- / 8-row launches (one or two
-    // frames: too few workgroups for a form without split keys), TC_MATRIX_F32 and train-mode dropout the fp32 core.  A
+    // frames: too few workgroups for a form without split keys) and TC_MATRIX_F32 the fp32 core.  A
     // frame's arithmetic is therefore fixed by (chain_tile_rows, matrix_path), not by how many frames share a launch
     if (!l0c) {
       const int trows = opt.chain_tile_rows ? opt.chain_tile_rows : (rows <= 1024 ? 4 : rows <= 2048 ? 8 : 16);
-      if (trows == 16 && opt.matrix_path != TC_MATRIX_F32 && !ddrop)
-        TC_TRY(launch_self_attn_core_x(h.qk, h.qk + C, 2 * C, h.vt, h.qpad, h.attn_o, C, B, Q, H, s));
+      if (trows == 16 && opt.matrix_path != TC_MATRIX_F32)
+        TC_TRY(launch_self_attn_core_x(h.qk, h.qk + C, 2 * C, h.vt, h.qpad, h.attn_o, C, B, Q, H, s, ddrop ? &d.drop : nullptr));
       else
         TC_TRY(launch_self_attn_core(h.qk, h.qk + C, 2 * C, h.vt, h.qpad, h.attn_o, C, B, Q, H, s, ddrop ? &d.drop : nullptr));
     }

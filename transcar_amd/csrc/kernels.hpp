@@ -181,7 +181,7 @@ int launch_self_attn_core(const float* q, const float* k, int ld, const float* v
 // the same on the f16 matrix cores, fp32-accurate (round 4): two-plane f16 operands (hi, lo), fp32 accumulate; K / V^T are
 // split and staged through LDS inside the kernel, every wave walks all keys.  Same operands as launch_self_attn_core.
 int launch_self_attn_core_x(const float* q, const float* k, int ld, const float* vt, int ldt, float* out, int ldo,
-                            int B, int Q, int H, hipStream_t s);
+                            int B, int Q, int H, hipStream_t s, const DropK* drop = nullptr);
 
 // ---- radar_attn.hip --------------------------------------------------------
 struct RadarAttnArgs {

@@ -323,9 +323,14 @@ __device__ __forceinline__ void sx_split(const float4& x0, const float4& x1, flo
 // One chunk of NP key pairs (32 keys each) against the wave's QT sub-tiles, as ONE straight-line block: all score
 // products first, ONE lazy re-centring test for the whole chunk (a chunk is re-centred as a unit: softmax is shift
 // invariant), then exponentials, plane split and the PV products.
-template <int QT, int NP>
+// DROP (train-mode statistics of the frozen decoder: the trainer's batched look-ahead): the mask of self_attn_kernel --
+// drop_keep(seed, site, ((b * H + h) * Q + query) * Q + key) on the normalised probability, the normaliser does not see
+// it -- on the lane's eight consecutive keys: two hashes (drop_keep4).  dbase[u]: the index of (query r of sub-tile u,
+// key 8 g) at pair 0; key0 = the first key of the chunk's first pair.
+template <int QT, int NP, bool DROP = false>
 __device__ __forceinline__ void sx_chunk(const float4 (*fb)[8][64], int lane, int g, const float4* q_h, const float4* q_l,
-                                         SXState* st, bool first, int nvalid_last) {
+                                         SXState* st, bool first, int nvalid_last, const DropK* drop = nullptr,
+                                         const unsigned* dbase = nullptr, unsigned key0 = 0u) {
   float sc[NP][QT][8];
 #pragma unroll
   for (int pp = 0; pp < NP; ++pp) {
@@ -389,6 +394,15 @@ __device__ __forceinline__ void sx_chunk(const float4 (*fb)[8][64], int lane, in
 #pragma unroll
       for (int i = 0; i < 8; ++i) p[i] = __builtin_amdgcn_exp2f(sc[pp][u][i]);
       if (!SX_L_MFMA) st[u].l += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+      if constexpr (DROP) {
+        const unsigned idx = dbase[u] + key0 + 32u * (unsigned)pp;
+        const unsigned m0 = drop_keep4(drop->seed, drop->site, idx, drop->thr), m1 = drop_keep4(drop->seed, drop->site, idx + 4u, drop->thr);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          p[i] = ((m0 >> i) & 1u) ? p[i] * drop->scale : 0.0f;
+          p[4 + i] = ((m1 >> i) & 1u) ? p[4 + i] * drop->scale : 0.0f;
+        }
+      }
       // P^T as two f16 planes: the lane's eight keys are the MFMA's eight k slots
       float4 p_h, p_l;
       sx_split1(p, p_h, p_l);
@@ -402,10 +416,10 @@ __device__ __forceinline__ void sx_chunk(const float4 (*fb)[8][64], int lane, in
   }
 }
 
-template <int QT>
+template <int QT, bool DROP = false>
 __global__ __launch_bounds__(SX_NW * 64) __attribute__((amdgpu_waves_per_eu(SX_OCC, SX_OCC))) void self_attn_x_kernel(
     const float* __restrict__ q, const float* __restrict__ k, int ld, const float* __restrict__ vt, int ldt,
-    float* __restrict__ out, int ldo, int Q, int C, int H, int BH) {
+    float* __restrict__ out, int ldo, int Q, int C, int H, int BH, DropK drop) {
   constexpr int QW = 16 * QT * SX_NW;                       // queries per workgroup
   __shared__ float4 frag[2][SX_CP][8][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -480,9 +494,13 @@ __global__ __launch_bounds__(SX_NW * 64) __attribute__((amdgpu_waves_per_eu(SX_O
   }
   float4 q_h[QT], q_l[QT];
   SXState st[QT];
+  unsigned dbase[QT];
+  if (DROP) drop.seed += (unsigned long long)b * drop.seed_stride;
 #pragma unroll
   for (int u = 0; u < QT; ++u) {
     const int qrow = min(q0 + 16 * u + r, Q - 1);                         // (rows past Q: a copy of the last query, not stored)
+    // (a batch of frames with per-sample seeds: the index is the one sample b has when it is launched alone)
+    dbase[u] = DROP ? (((drop.rows_per_sample ? 0u : (unsigned)b) * (unsigned)H + (unsigned)h) * (unsigned)Q + (unsigned)qrow) * (unsigned)Q + 8u * (unsigned)g : 0u;
     const float* qp = q + (brow + qrow) * ld + h * 32 + 8 * g;
     sx_split(ld4(qp), ld4(qp + 4), q_h[u], q_l[u]);
     st[u].o0 = st[u].o1 = st[u].lsum = st[u].negm = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -517,10 +535,11 @@ __global__ __launch_bounds__(SX_NW * 64) __attribute__((amdgpu_waves_per_eu(SX_O
       const int left = np - c * SX_CP;                 // pairs in this chunk: SX_CP, or fewer in the last one
       const int nvalid_last = min(32, Q - 32 * (c * SX_CP + min(left, SX_CP) - 1));
       static_assert(SX_CP == 2, "the chunk dispatch below is written for two pairs");
-      if (SX_NPC == 2 && left >= 2) sx_chunk<QT, 2>(frag[buf], lane, g, q_h, q_l, st, c == 0, nvalid_last);
+      const unsigned key0 = 32u * (unsigned)(c * SX_CP);
+      if (SX_NPC == 2 && left >= 2) sx_chunk<QT, 2, DROP>(frag[buf], lane, g, q_h, q_l, st, c == 0, nvalid_last, &drop, dbase, key0);
       else {
-        sx_chunk<QT, 1>(frag[buf], lane, g, q_h, q_l, st, c == 0, left >= 2 ? 32 : nvalid_last);
-        if (left >= 2) sx_chunk<QT, 1>(frag[buf] + 1, lane, g, q_h, q_l, st, false, nvalid_last);
+        sx_chunk<QT, 1, DROP>(frag[buf], lane, g, q_h, q_l, st, c == 0, left >= 2 ? 32 : nvalid_last, &drop, dbase, key0);
+        if (left >= 2) sx_chunk<QT, 1, DROP>(frag[buf] + 1, lane, g, q_h, q_l, st, false, nvalid_last, &drop, dbase, key0 + 32u);
       }
     }
 #endif
@@ -551,13 +570,20 @@ __global__ __launch_bounds__(SX_NW * 64) __attribute__((amdgpu_waves_per_eu(SX_O
 
 // q, k rows [B*Q, ld] (q pre-scaled), vt [B, C, ldt] fp32 -> out [B*Q, C]: the operands of launch_self_attn_core
 int launch_self_attn_core_x(const float* q, const float* k, int ld, const float* vt, int ldt, float* out, int ldo,
-                            int B, int Q, int H, hipStream_t s) {
+                            int B, int Q, int H, hipStream_t s, const DropK* drop) {
   TC_REQUIRE(Q > 0 && B > 0 && H > 0, "self_attn(f16x2): empty problem");
   TC_REQUIRE((ldt & 3) == 0 && ldt >= ((Q + 15) / 16) * 16, "self_attn(f16x2): ldt=%d too small for Q=%d", ldt, Q);
   constexpr int QT = SX_QT_VALUE, QW = 16 * QT * SX_NW;
   const int BH = B * H, Gf = Q / QW, G = (Q + QW - 1) / QW;
-  hipLaunchKernelGGL((self_attn_x_kernel<QT>), dim3(BH * Gf + (G > Gf ? BH : 0)), dim3(SX_NW * 64), 0, s, q, k, ld, vt, ldt,
-                     out, ldo, Q, H * 32, H, BH);
+  const dim3 grid(BH * Gf + (G > Gf ? BH : 0));
+  if (drop != nullptr && drop->thr != 0) {
+    TC_REQUIRE((unsigned long long)(drop->rows_per_sample ? 1 : B) * H * Q * Q < (1ull << 32),
+               "self_attn(f16x2): dropout index space (B*H*Q*Q) exceeds 32 bits");
+    hipLaunchKernelGGL((self_attn_x_kernel<QT, true>), grid, dim3(SX_NW * 64), 0, s, q, k, ld, vt, ldt, out, ldo, Q, H * 32, H, BH, *drop);
+  } else {
+    hipLaunchKernelGGL((self_attn_x_kernel<QT, false>), grid, dim3(SX_NW * 64), 0, s, q, k, ld, vt, ldt, out, ldo, Q, H * 32, H, BH,
+                       DropK{0, 0, 1.0f, 0, 0, 0, 0, 0});
+  }
   return check_launch("self_attn(f16x2, staged)");
 }
 

@@ -183,6 +183,7 @@ class FusionTrainer:
             return self.head.forward_nhwc(feats_nhwc, lidar2img, img_hw, tokens, pad_mult, aux='train',
                                           _allow_train=True, decoder_only=True, lane=lane,
                                           options=head_options(tile_rows=self.decoder_tile_rows,
+                                                               matrix_path=getattr(self, 'decoder_matrix_path', None),
                                                                decoder_dropout_p=self.decoder_dropout,
                                                                dropout_seed=seed, dropout_seed_stride=self.SEED_STRIDE))
 
