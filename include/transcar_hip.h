@@ -312,7 +312,7 @@ int tc_decoder_layer_tail_fwd(const tc_decoder_layer* layer, const tc_linear* ne
 int tc_sdpa_fwd(const float* q, const float* k, int ld, const float* vt, int ldt,
                 float* out, int ldo, int B, int Q, int num_heads, tc_stream_t stream);
 /* The same core on the f16 matrix cores with fp32 accuracy (round 4; what tc_head_forward runs in launches with
- * 16-row tiles unless options.matrix_path = TC_MATRIX_F32 or train-mode dropout is on): q | k rows [B*Q, 2C]
+ * 16-row tiles unless options.matrix_path = TC_MATRIX_F32, with the train-mode dropout on the probabilities too): q | k rows [B*Q, 2C]
  * token-major (q at columns 0..C-1, pre-scaled as above, k at C..2C-1), vt as above.  Every operand is used as two
  * f16 planes (hi = f16(x), lo = f16(x - hi); built in registers / LDS inside the kernel), every product is three
  * v_mfma_f32_16x16x32_f16 with fp32 accumulation.  |q|, |k|, |v| must stay below 65 504; an element's low plane is
