@@ -574,6 +574,21 @@ int tc_radar_train_bwd_fused(const tc_head_weights* w, const tc_head_weights* gr
                              void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes,
                              float dropout_p, unsigned long long dropout_seed, const float* layer_losses,
                              float* layer_losses_clean, tc_stream_t stream);
+/* The same with `flags`: bit 0 = the workspace already holds the transposed packed weights of the CURRENT parameters
+ * (tc_radar_train_repack packed them in the launch that re-packed the forward's copy): the backward's own pack launch
+ * is skipped. */
+int tc_radar_train_bwd_fused_ex(const tc_head_weights* w, const tc_head_weights* grads, const float* hs_last,
+                                const float* last_box, const float* radar_tokens, int B, int T, int pad_mult,
+                                const float* all_bbox_preds, const float* d_all_cls, const float* d_all_box,
+                                void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes,
+                                float dropout_p, unsigned long long dropout_seed, const float* layer_losses,
+                                float* layer_losses_clean, int flags, tc_stream_t stream);
+/* One launch for BOTH weight layouts a fused training iteration needs from the current parameters: the 4x4x1 packed
+ * copy of the trainable weights inside `packed_view` (tc_head_repack_trainable_ex(w, view, 1)) and the transposed
+ * packed weights of the three fusion layers inside the backward's workspace (tc_radar_train_bwd_workspace_bytes(w, B,
+ * T)); call it once after the optimizer step, then tc_radar_train_fwd_fused and tc_radar_train_bwd_fused_ex(flags 1). */
+int tc_radar_train_repack(const tc_head_weights* w, tc_head_weights* packed_view, void* bwd_workspace,
+                          size_t bwd_workspace_bytes, int B, int T, tc_stream_t stream);
 /* layer_losses: optional device [num_radar_layers, 2] = (loss_cls, loss_bbox) of each level as tc_detr_loss_fwd_bwd
  * wrote them: a level whose loss is not finite sends no gradient down and non-finite gradient elements count
  * as 0 (HEAD:915-916 zeroes a NaN loss) -- the guard of transcar_amd/device_loss.py inside the

@@ -743,6 +743,31 @@ int tc_head_repack_trainable_ex(const tc_head_weights* w, tc_head_weights* packe
   return launch_pack_group(jobs, nj, as_stream(stream));
 }
 
+// train_stack.hip: the pack jobs of the backward's transposed weights (into its workspace)
+extern "C" int radar_train_transposed_jobs(const tc_head_weights* w, int B, int T, void* workspace, size_t workspace_bytes,
+                                           tc::PackJob* jobs, int cap);
+
+int tc_radar_train_repack(const tc_head_weights* w, tc_head_weights* packed_view, void* bwd_workspace,
+                          size_t bwd_workspace_bytes, int B, int T, tc_stream_t stream) {
+  TC_TRY(check_dims(w));
+  TC_REQUIRE(packed_view != nullptr && packed_view->l0_attn_out != nullptr,
+             "radar_train_repack: packed_view was not produced by tc_head_pack_weights");
+  tc_head_weights scratch = *packed_view;
+  PackItem items[MAX_PACK_ITEMS];
+  const int n = collect_pack_items(w, &scratch, items);
+  const int first = 1 + 10 * w->num_layers;
+  PackJob jobs[MAX_PACK_ITEMS + 10 * TC_MAX_RADAR_LAYERS];
+  int nj = 0;
+  for (int i = first; i < n; ++i) {
+    TC_REQUIRE(items[i].src != nullptr, "radar_train_repack: weight %d is null", i);
+    if (items[i].narrow) continue;
+    jobs[nj++] = PackJob{items[i].src, const_cast<float*>(*items[i].slot), nullptr, items[i].N, items[i].K};
+  }
+  const int nt = radar_train_transposed_jobs(w, B, T, bwd_workspace, bwd_workspace_bytes, jobs + nj, 10 * TC_MAX_RADAR_LAYERS);
+  if (nt < 0) return -1;
+  return launch_pack_group(jobs, nj + nt, as_stream(stream));
+}
+
 int tc_head_repack_trainable(const tc_head_weights* w, tc_head_weights* packed_view,
                              tc_stream_t stream) {
   return tc_head_repack_trainable_ex(w, packed_view, 3, stream);

@@ -73,9 +73,10 @@ __global__ __launch_bounds__(256) void pack_linear_kernel(const float* __restric
 
 // Several weights in ONE launch (the trainable part after an optimizer step: 28 matrices, one launch instead of
 // 28): the items travel in the kernel-argument segment, a block finds its item from the block offsets.
-constexpr int PACK_GROUP_MAX = 48;
+constexpr int PACK_GROUP_MAX = 60;        // 60 x 64 B of items + the count fit the 4 KiB kernel-argument segment
 struct PackGroupItem { const float* W; float* P; float* P16; float* PH; int N, K, ntile, nkq, first_block, transpose, ldw; };
 struct PackGroupK { PackGroupItem it[PACK_GROUP_MAX]; int n; };
+static_assert(sizeof(PackGroupK) <= 4096, "the grouped pack's items travel as kernel arguments");
 constexpr int PACK_EPT = 8;               // elements per thread
 __global__ __launch_bounds__(256) void pack_group_kernel(PackGroupK g) {
   int i = 0;

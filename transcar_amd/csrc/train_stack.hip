@@ -467,17 +467,56 @@ size_t bwd_ws_layout(const tc_head_weights* w, int B, int T, void* base, size_t 
 }
 }  // namespace
 
+// the transposed packed weights of the three fusion layers (what the backward row chain multiplies by): pack jobs
+static int transposed_jobs(const tc_head_weights* w, const BwdWs& ws, PackJob* jobs) {
+  const int C = w->embed_dims, F = w->ffn_dims, code = w->code_size, ncls = w->num_classes;
+  int n = 0;
+  auto add = [&](const float* W, float* P, int N_out, int K_in) {
+    PackJob j;
+    j.W = W; j.P = P; j.P16 = nullptr; j.N = N_out; j.K = K_in; j.transpose = 1; j.ldw = N_out;
+    jobs[n++] = j;
+  };
+  for (int r = 0; r < TC_MAX_RADAR_LAYERS; ++r) {
+    const tc_radar_layer& rl = w->radar[r];
+    const tc_radar_layer& lt = ws.wT[r];
+    // forward W is [N_fwd][K_fwd] (row stride K_fwd); the chain computes dx[K_fwd] = dy[N_fwd] W, i.e. a linear
+    // step with N_out = K_fwd outputs and K_in = N_fwd inputs whose weight (n, k) = W[k][n]: ldw = K_fwd = N_out
+    add(rl.attn.in_proj.w, const_cast<float*>(lt.attn.in_proj.w), C, C);          // Wq: rows 0..C-1 of in_proj
+    add(rl.attn.out_proj.w, const_cast<float*>(lt.attn.out_proj.w), C, C);
+    add(rl.linear1.w, const_cast<float*>(lt.linear1.w), C, F);                    // linear1: [F][C]
+    add(rl.linear2.w, const_cast<float*>(lt.linear2.w), F, C);                    // linear2: [C][F]
+    add(rl.final_cls.l0.w, const_cast<float*>(lt.final_cls.l0.w), C, C);
+    add(rl.final_cls.l3.w, const_cast<float*>(lt.final_cls.l3.w), C, C);
+    add(rl.final_cls.l6.w, const_cast<float*>(lt.final_cls.l6.w), C, ncls);       // [ncls][C]
+    add(rl.final_reg.l0.w, const_cast<float*>(lt.final_reg.l0.w), C, C);
+    add(rl.final_reg.l2.w, const_cast<float*>(lt.final_reg.l2.w), C, C);
+    add(rl.final_reg.l4.w, const_cast<float*>(lt.final_reg.l4.w), C, code);       // [code][C]
+  }
+  return n;
+}
+// (head.hip: tc_radar_train_repack appends these to the forward's re-pack jobs -- ONE launch for both layouts)
+int radar_train_transposed_jobs(const tc_head_weights* w, int B, int T, void* workspace, size_t workspace_bytes,
+                                PackJob* jobs, int cap) {
+  if (check(w, B, T) != 0) return -1;
+  BwdWs ws;
+  if (workspace == nullptr || bwd_ws_layout(w, B, T, workspace, workspace_bytes, &ws) > workspace_bytes || cap < 10 * TC_MAX_RADAR_LAYERS) {
+    set_error("radar_train_repack: backward workspace too small");
+    return -1;
+  }
+  return transposed_jobs(w, ws, jobs);
+}
+
 size_t tc_radar_train_bwd_workspace_bytes(const tc_head_weights* w, int B, int T) {
   if (check(w, B, T) != 0) return 0;
   return bwd_ws_layout(w, B, T, nullptr, ~size_t(0), nullptr);
 }
 
-int tc_radar_train_bwd_fused(const tc_head_weights* w, const tc_head_weights* grads, const float* hs_last,
-                             const float* last_box, const float* radar_tokens, int B, int T, int pad_mult,
-                             const float* all_bbox_preds, const float* d_all_cls, const float* d_all_box,
-                             void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes,
-                             float dropout_p, unsigned long long dropout_seed, const float* layer_losses,
-                             float* layer_losses_clean, tc_stream_t stream) {
+int tc_radar_train_bwd_fused_ex(const tc_head_weights* w, const tc_head_weights* grads, const float* hs_last,
+                                const float* last_box, const float* radar_tokens, int B, int T, int pad_mult,
+                                const float* all_bbox_preds, const float* d_all_cls, const float* d_all_box,
+                                void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes,
+                                float dropout_p, unsigned long long dropout_seed, const float* layer_losses,
+                                float* layer_losses_clean, int flags, tc_stream_t stream) {
   TS_TRY(check(w, B, T));
   TC_REQUIRE(grads != nullptr && workspace != nullptr, "radar_train_bwd_fused: null argument");
   TC_REQUIRE(dropout_p >= 0.0f && dropout_p < 1.0f, "radar_train_bwd_fused: dropout_p=%g", (double)dropout_p);
@@ -491,31 +530,11 @@ int tc_radar_train_bwd_fused(const tc_head_weights* w, const tc_head_weights* gr
   const int Q = w->num_query, C = w->embed_dims, F = w->ffn_dims, code = w->code_size;
   const int ncls = w->num_classes, RI = w->radar_in_dims;
   const int rows = B * Q, rt = B * T;
-  // 1. the transposed packed weights of the three layers: one launch
-  {
+  // 1. the transposed packed weights of the three layers: one launch -- unless the caller packed them together with the
+  //    forward's copy (tc_radar_train_repack, flags bit 0: the parameters have not changed in between)
+  if (!(flags & 1)) {
     PackJob jobs[10 * TC_MAX_RADAR_LAYERS];
-    int n = 0;
-    auto add = [&](const float* W, float* P, int N_out, int K_in) {      // pack (W^T): W is [K_in... no: W is [N_fwd = K_in][K_fwd = N_out]
-      PackJob j;
-      j.W = W; j.P = P; j.P16 = nullptr; j.N = N_out; j.K = K_in; j.transpose = 1; j.ldw = N_out;
-      jobs[n++] = j;
-    };
-    for (int r = 0; r < TC_MAX_RADAR_LAYERS; ++r) {
-      const tc_radar_layer& rl = w->radar[r];
-      const tc_radar_layer& lt = ws.wT[r];
-      // forward W is [N_fwd][K_fwd] (row stride K_fwd); the chain computes dx[K_fwd] = dy[N_fwd] W, i.e. a linear
-      // step with N_out = K_fwd outputs and K_in = N_fwd inputs whose weight (n, k) = W[k][n]: ldw = K_fwd = N_out
-      add(rl.attn.in_proj.w, const_cast<float*>(lt.attn.in_proj.w), C, C);          // Wq: rows 0..C-1 of in_proj
-      add(rl.attn.out_proj.w, const_cast<float*>(lt.attn.out_proj.w), C, C);
-      add(rl.linear1.w, const_cast<float*>(lt.linear1.w), C, F);                    // linear1: [F][C]
-      add(rl.linear2.w, const_cast<float*>(lt.linear2.w), F, C);                    // linear2: [C][F]
-      add(rl.final_cls.l0.w, const_cast<float*>(lt.final_cls.l0.w), C, C);
-      add(rl.final_cls.l3.w, const_cast<float*>(lt.final_cls.l3.w), C, C);
-      add(rl.final_cls.l6.w, const_cast<float*>(lt.final_cls.l6.w), C, ncls);       // [ncls][C]
-      add(rl.final_reg.l0.w, const_cast<float*>(lt.final_reg.l0.w), C, C);
-      add(rl.final_reg.l2.w, const_cast<float*>(lt.final_reg.l2.w), C, C);
-      add(rl.final_reg.l4.w, const_cast<float*>(lt.final_reg.l4.w), C, code);       // [code][C]
-    }
+    const int n = transposed_jobs(w, ws, jobs);
     TS_TRY(launch_pack_group(jobs, n, s));
   }
   // 2. accumulators
@@ -592,6 +611,17 @@ int tc_radar_train_bwd_fused(const tc_head_weights* w, const tc_head_weights* gr
   // radar_position_encoder.0 (Linear(3, C)): X = the tokens' first three columns (xyz), read in place
   job(radar_tokens, du0, gpe.l0, rt, 3, C, nullptr, RI);
   return launch_linear_bwd_weight_group(jobs, n, s);
+}
+
+int tc_radar_train_bwd_fused(const tc_head_weights* w, const tc_head_weights* grads, const float* hs_last,
+                             const float* last_box, const float* radar_tokens, int B, int T, int pad_mult,
+                             const float* all_bbox_preds, const float* d_all_cls, const float* d_all_box,
+                             void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes,
+                             float dropout_p, unsigned long long dropout_seed, const float* layer_losses,
+                             float* layer_losses_clean, tc_stream_t stream) {
+  return tc_radar_train_bwd_fused_ex(w, grads, hs_last, last_box, radar_tokens, B, T, pad_mult, all_bbox_preds, d_all_cls,
+                                     d_all_box, tape, tape_bytes, workspace, workspace_bytes, dropout_p, dropout_seed,
+                                     layer_losses, layer_losses_clean, 0, stream);
 }
 
 // The multipliers (0 or 1 / (1 - p)) of elements 0..n-1 of a dropout site, for tests and for

@@ -307,11 +307,20 @@ class FusionTrainer:
         Q = head.num_query
         all_cls = torch.empty((3, B, Q, head.cls_out_channels), dtype=torch.float32, device=tokens.device)
         all_box = torch.empty((3, B, Q, head.code_size), dtype=torch.float32, device=tokens.device)
+        self._wT_ready = False
         if self.chain_forward:
-            # the packed (4x4x1) copy of the trainable weights for the CURRENT parameters: one launch
+            # the packed (4x4x1) copy of the trainable weights for the CURRENT parameters -- and, when the backward is
+            # the fused one too, its transposed packed weights in the same launch (the parameters do not change
+            # between this forward and its backward): one launch instead of two
             pv = head._packed_view
-            L.check(lib.tc_head_repack_trainable_ex(C.byref(w), C.byref(pv), 1, self._stream()),
-                    'tc_head_repack_trainable_ex')
+            if self.chain_backward:
+                bws = self._backward_workspace(lib, w, key, B, T, tokens.device)
+                L.check(lib.tc_radar_train_repack(C.byref(w), C.byref(pv), bws.data_ptr(), bws.numel(), B, T,
+                                                  self._stream()), 'tc_radar_train_repack')
+                self._wT_ready = True
+            else:
+                L.check(lib.tc_head_repack_trainable_ex(C.byref(w), C.byref(pv), 1, self._stream()),
+                        'tc_head_repack_trainable_ex')
             head._packed_dirty = True                  # the 16x16x4 copy (inference at >= 3 frames) is stale
             L.check(lib.tc_radar_train_fwd_fused(
                 C.byref(pv), hs_last.data_ptr(), ref_last.data_ptr(), last_box.data_ptr(), tokens.data_ptr(),
@@ -357,19 +366,15 @@ class FusionTrainer:
             self._gtab, self._gtab_key = grad_table(head), gkey
         g = self._gtab
         if self.chain_backward:
-            if getattr(self, '_bws_key', None) != key:
-                nb = lib.tc_radar_train_bwd_workspace_bytes(C.byref(w), B, T)
-                if nb == 0:
-                    raise L.TransCARHipError(lib.tc_last_error().decode())
-                self._bws = torch.empty(nb, dtype=torch.uint8, device=tokens.device)
-                self._bws_key = key
+            bws = self._backward_workspace(lib, w, key, B, T, tokens.device)
             clean = torch.empty_like(raw_losses) if raw_losses is not None else None
-            L.check(lib.tc_radar_train_bwd_fused(
+            L.check(lib.tc_radar_train_bwd_fused_ex(
                 C.byref(w), C.byref(g), hs_last.data_ptr(), last_box.data_ptr(), tokens.data_ptr(), B, T,
                 int(pad_mult), all_box.data_ptr(), d_cls.data_ptr(), d_box.data_ptr(), tape.data_ptr(),
-                tape.numel(), self._bws.data_ptr(), self._bws.numel(), self.dropout, drop_seed,
+                tape.numel(), bws.data_ptr(), bws.numel(), self.dropout, drop_seed,
                 raw_losses.data_ptr() if raw_losses is not None else None,
-                clean.data_ptr() if clean is not None else None, self._stream()), 'tc_radar_train_bwd_fused')
+                clean.data_ptr() if clean is not None else None, 1 if self._wT_ready else 0, self._stream()),
+                'tc_radar_train_bwd_fused_ex')
             if clean is not None:
                 from .device_loss import loss_dict
                 losses = loss_dict(clean)
@@ -386,6 +391,15 @@ class FusionTrainer:
         if update:
             self._optimizer_step(lr)
         return {k: v.detach() for k, v in losses.items()}
+
+    def _backward_workspace(self, lib, w, key, B, T, device):
+        if getattr(self, '_bws_key', None) != key:
+            nb = lib.tc_radar_train_bwd_workspace_bytes(C.byref(w), B, T)
+            if nb == 0:
+                raise L.TransCARHipError(lib.tc_last_error().decode())
+            self._bws = torch.empty(nb, dtype=torch.uint8, device=device)
+            self._bws_key = key
+        return self._bws
 
     def _optimizer_step(self, lr=None):
         world = self.bucket.all_reduce()
