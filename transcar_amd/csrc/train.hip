@@ -248,7 +248,16 @@ int launch_linear_bwd_data(const float* dy, const float* relu_out, const int* ro
   const int mt = (M + 63) / 64;
   const bool vec = bg_vec_ok(p, N);         // A = dY[m][n]: contiguous along the reduction index n
   const bool wide = mt * ((K + 63) / 64) >= 200;          // enough 64-wide tiles to fill the chip
-  const dim3 grid(wide ? (K + 63) / 64 : (K + 31) / 32, mt, 1);
+  // A few dozen workgroups that each walk a long reduction (the token side of the fused backward: 256 rows, dK|dV ->
+  // dmem over n = 512: 32 workgroups x 16 k-steps = 14 us of latency): when the result is ADDED to dx anyway, split
+  // the reduction over gz workgroups that add their parts with float atomics (round 4: 3 x 14 -> 3 x 6 us)
+  int gz = 1;
+  if (accumulate && !wide && mt * ((K + 31) / 32) <= 64 && N >= 256) {
+    gz = N >= 512 ? 4 : 2;
+    p.rchunk = (((N + gz - 1) / gz + BG_RK - 1) / BG_RK) * BG_RK;
+    gz = (N + p.rchunk - 1) / p.rchunk;
+  }
+  const dim3 grid(wide ? (K + 63) / 64 : (K + 31) / 32, mt, gz);
   if (wide && vec) hipLaunchKernelGGL((bwd_gemm_kernel<BWD_DATA, 64, true>), grid, dim3(256), 0, s, p);
   else if (wide) hipLaunchKernelGGL((bwd_gemm_kernel<BWD_DATA, 64, false>), grid, dim3(256), 0, s, p);
   else if (vec) hipLaunchKernelGGL((bwd_gemm_kernel<BWD_DATA, 32, true>), grid, dim3(256), 0, s, p);
