@@ -386,6 +386,7 @@ def cur_stream():
 
 
 F16_MFMA_PEAK_TFLOPS = 2516.6  # dense f16 / bf16 matrix peak: 1024 flop / clk / SIMD x 1024 SIMDs x 2.4 GHz
+L1_PATH_GBS_PER_CU = 64 * 2.4            # bytes per clock of a CU's vector-memory (L1) path x the clock in GHz
 F16X2_PRODUCTS = 3             # v_mfma_f32_16x16x32_f16 per 32 k of one fp32-accurate product (chain.hip linear_step16h)
 MATRIX_PATH_CODE = {'auto': 0, 'f32': 1, 'f16x2': 2}
 
@@ -512,7 +513,11 @@ def roofline(head, inp, dev, matrix_path='auto'):
             # every workgroup streams the layer's packed weights (3.18 MB) through its CU's vector-memory path: what
             # binds the f16x2 item loop (DESIGN.md section 5 "Round 4"; ~57 B / clk / CU measured by split_mfma_probe)
             weight_stream_gbs_per_cu=(-(-B * head.num_query // (16 if B * head.num_query > 2048 else 8 if B * head.num_query > 1024 else 4))
-                                      * 795136 * 4 / 256.0) / chain_ms / 1e6),
+                                      * 795136 * 4 / 256.0) / chain_ms / 1e6,
+            # ... against what a CU's vector-memory path delivers (64 B / clk at 2.4 GHz): the resource the kernel's item
+            # loops run against (inside them ~57 of 64 B / clk, tools/split_mfma_probe.hip; averaged over the whole
+            # kernel -- sampling, LayerNorms, epilogues included -- the figure below)
+            weight_stream_peak_gbs_per_cu=L1_PATH_GBS_PER_CU),
         'self_attn_kernel': dict(
             bound='mfma', achieved=attn_flop / attn_ms / 1e9, peak=chain_peak if f16x2 else F32_MFMA_PEAK_TFLOPS,
             unit='TFLOP/s', ms=attn_ms, per_frame=6, alg_flop=attn_flop,
