@@ -404,8 +404,7 @@ class Detr3DHead(BaseModule):
             tokens = torch.empty((B, T, radar.NUM_FEATURES), dtype=torch.float32, device=device)
 
             def fill():
-                for b, r in enumerate(raws):
-                    stage.put(b, r)
+                stage.put_all(raws)              # host pack of every sample, then three H2D copies for the batch
                 stage.build(tokens)
                 if T < radar.NUM_RADAR_TOKENS and max(n_raw) > T - 1:
                     ops.radar_check_fits(stage.count, T)     # an explicit T: the kept points must fit (one D2H sync)

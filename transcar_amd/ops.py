@@ -415,6 +415,28 @@ class RadarRawStage:
         self._copied[slot] = ev
         return n
 
+    def put_all(self, frames):
+        """Stage samples 0 .. len(frames)-1 at once: every sample packed on the host first, then THREE H2D copies for
+        the whole batch (the slabs are contiguous) instead of three per sample -- nine frames per call were 27 copies,
+        ~0.15 ms of host time the device spent waiting behind decoder layers 0-3 (round 4)."""
+        n = len(frames)
+        if n > self.P:
+            raise L.TransCARHipError('%d radar frames, the stage holds %d' % (n, self.P))
+        for ev in self._copied:
+            if ev is not None:
+                ev.synchronize()                    # the previous copies out of the pinned mirrors have run
+        for slot, frame in enumerate(frames):
+            self._pack(slot, frame)
+        if n and max(self.n_raw[:n]):
+            # whole slots (contiguous slabs: one plain copy each; rows behind a sample's count are never read)
+            self.raw[:n].copy_(self.h_raw[:n], non_blocking=True)
+            self.times[:n].copy_(self.h_times[:n], non_blocking=True)
+        self.desc[:n].copy_(self.h_desc[:n], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._copied = [ev] * n + self._copied[n:]
+        return self.n_raw[:n]
+
     def build(self, tokens, n=None):
         """One launch: the first n (default all) samples' raw rows -> tokens[:n] ([n,T,36], contiguous)."""
         from . import radar as R
