@@ -239,7 +239,7 @@ def lib():
                 'CPU fallback; run __graft_entry__.build() or '
                 '`make -C transcar_amd/csrc`.' % LIB_PATH)
         dll = C.CDLL(LIB_PATH)
-        if hasattr(dll, 'tc_debug_chain_stamps') and os.environ.get('TRANSCAR_ALLOW_STAMPS') != '1':
+        if (hasattr(dll, 'tc_debug_chain_stamps') or hasattr(dll, 'tc_debug_diag_build')) and os.environ.get('TRANSCAR_ALLOW_STAMPS') != '1':
             raise TransCARHipError(
                 '%s is the STAMPS debug build (timing switches with wrong results); set '
                 'TRANSCAR_ALLOW_STAMPS=1 to use it for tools/chain_stamps.py' % LIB_PATH)

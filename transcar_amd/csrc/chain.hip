@@ -57,6 +57,11 @@ __device__ long long g_cam_stamps[4][8];      // camera sampling of workgroup 10
   } while (0)
 #endif
 #include "rowdev.hpp"
+#ifdef TC_CHAIN_DUMP
+// diagnostic build only (make DUMP=1): the LDS destination of every step of the radar program, [step][row][256] floats
+__device__ float* g_chain_dump;
+__device__ long long g_chain_dump_floats;
+#endif
 
 namespace tc {
 
@@ -875,20 +880,20 @@ __device__ __forceinline__ void split_h(const float4& a, const float4& b, float4
   p2 = make_float4(__uint_as_float(q2[0]), __uint_as_float(q2[1]), __uint_as_float(q2[2]), __uint_as_float(q2[3]));
 }
 
-// One HALF item (64 columns x 32 k): 8 fragments of 1 KiB -- (sub-tile j, plane p) at wb.b[2 j + p] --, 12 MFMAs;
-// fragments refilled in place from the next half item right behind their MFMAs (as ItemSteps16).
+// One HALF item (64 columns x 32 k): 8 fragments of 1 KiB -- (sub-tile j, plane p) at wb.b[2 j + p] --, 12 MFMAs.
 // TWO register buffers of one half item each (b[0..7], b[8..15]): while half item i issues its MFMAs from one, the
 // fragments of half item i + 1 are loaded into the other -- group by group behind the MFMAs of the same group, so
 // that a register is overwritten a whole half item (12 MFMAs of this wave) after its last read.
-// Round 3's f32 loop refills a fragment IN PLACE, right behind its MFMAs ("the matrix pipe reads its operands at
-// issue": true for v_mfma_f32_16x16x4_f32, which runs on the vector pipe).  With the matrix-core MFMAs that is NOT
-// safe at two workgroups per CU: the first build of this loop (in place) returned wrong sub-tiles in a few row tiles
-// of every launch, differently from run to run -- only with two workgroups per CU (an 84 KB LDS request that keeps
-// them apart: exact), never with this second buffer, never with the stream drained once per half item; refilling
-// one group late (3 MFMAs between read and overwrite) was not enough (tools/r4_diag2.py, profiles/r4_f16x2_hazard.txt).
-// Reading of it: with the SIMD's matrix core shared by two waves an issued MFMA can wait its turn while the wave
-// goes on to issue the load, and the hardware orders VMEM returns only against the issuing wave's vmcnt, not against
-// operand reads still to come.
+// Round 3's f32 loop refills a fragment IN PLACE, right behind its MFMAs.  The first build of this loop did the same and
+// the radar program returned a few wrong rows per launch at two workgroups per CU.  Round 5 found out why
+// (profiles/r5_refill_hazard.txt): the in-place refill itself is EXACT (tools/refill_hazard_probe.hip), but while a wave
+// has loads landing in registers its matrix-core MFMAs have just read, a NEIGHBOURING wave on the SIMD gets 0 in lanes
+// 48..63 of the low result of `v_pk_mul_f32 ... op_sel:[0,1]` -- the form hipcc's SLP vectoriser gave the radar attention's
+// pv * v products (tools/pk_hazard_probe.hip reproduces it outside the library).  The library avoids both sides: no such
+// instruction is formed (-fno-slp-vectorize, tools/isa_lint.py in the test suite), and the fragments of half item i + 1
+// go to the OTHER buffer, a whole half item (12 MFMAs of this wave) away from the registers' last read -- beside this loop
+// the probe's victims saw nothing in 2.5e9 executions.
+#ifndef TC_H16_INPLACE
 template <int J, int BUF>
 struct ItemSteps16H {
   static __device__ __forceinline__ void run(Acc16H& acc, WBuf& wb, const float4& x1, const float4& x2, const float* np,
@@ -990,6 +995,93 @@ __device__ __forceinline__ bool linear_step16h(const LinSpec& s, WBuf& w0, bool 
   }
   return next_first != nullptr;
 }
+
+#else
+// DIAGNOSTIC BUILD ONLY (make INPLACE=1 -> build/hip_inplace/, never the product): round 4's first form of this loop,
+// the fragments refilled in place right behind their MFMAs ("variant A" of profiles/r4_f16x2_hazard.txt), kept to
+// chase the flaky rows it produced in the radar program (tools/r5_hazard_hunt.py, profiles/r5_refill_hazard.txt).
+
+template <int J>
+struct ItemSteps16HA {
+  static __device__ __forceinline__ void run(Acc16H& acc, WBuf& wb, const float4& x1, const float4& x2, const float* np,
+                                             unsigned lo) {
+    constexpr int C0 = 2 * J;
+    acc.lo[J] = MFMA16H(wb.b[C0 + 1], x1, acc.lo[J]);
+    acc.lo[J] = MFMA16H(wb.b[C0], x2, acc.lo[J]);
+    acc.hi[J] = MFMA16H(wb.b[C0], x1, acc.hi[J]);
+    __builtin_amdgcn_sched_barrier(0);
+    wb.b[C0] = ld4(np + (size_t)(lo + (2 * J) * 256u));
+    wb.b[C0 + 1] = ld4(np + (size_t)(lo + (2 * J + 1) * 256u));
+    __builtin_amdgcn_sched_barrier(0);
+    ItemSteps16HA<J + 1>::run(acc, wb, x1, x2, np, lo);
+  }
+};
+template <>
+struct ItemSteps16HA<4> {
+  static __device__ __forceinline__ void run(Acc16H&, WBuf&, const float4&, const float4&, const float*, unsigned) {}
+};
+
+template <bool DROP, typename SpecFn>
+__device__ __forceinline__ bool linear_step16h(const LinSpec& s, WBuf& w0, bool preloaded, const float* next_first,
+                                               SpecFn make_spec, int step_idx) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) - s.woff) & (CH_NW - 1);
+  const int ntiles = (s.N + 63) >> 6;
+  const int kpad = (s.K + 63) & ~63;
+  const int nhalf = kpad / 32;
+  const int my_tiles = wave < ntiles ? (ntiles - wave + CH_NW - 1) / CH_NW : 0;
+  const int nitems = my_tiles * nhalf;
+  const float* arow = s.src + (lane & 15) * s.src_ld + 8 * (lane >> 4);
+  const float* wbase = s.W + (size_t)wave * 64 * kpad;
+  const unsigned lo = 4u * lane;
+  const size_t tile_stride = (size_t)CH_NW * 64 * kpad;
+  Acc16H acc;
+  float bvl = 0.f;
+  if (!preloaded) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w0.b[i] = ld4(wbase + (size_t)(lo + i * 256u));
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  int tt = 0, kh = 0;
+  const float* wcur = wbase;
+#pragma unroll 1
+  for (int it = 0; it < nitems; ++it) {
+    const float* np = wcur;
+    int nt = tt, nk = kh;
+    if (++nk == nhalf) { nk = 0; ++nt; np = wbase + (size_t)nt * tile_stride; }
+    else np += 8 * 256;
+    const bool last = it + 1 >= nitems;
+    const float* nload = last ? (next_first != nullptr ? next_first : wbase) : np;
+    if (kh == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { acc.hi[j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc.lo[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      const float* bsrc = s.bias != nullptr ? s.bias : s.W;
+      bvl = ldg1(bsrc + min((wave + tt * CH_NW) * 64 + lane, s.N - 1));
+    }
+    float4 x1, x2;
+    split_h(*reinterpret_cast<const float4*>(arow + kh * 32), *reinterpret_cast<const float4*>(arow + kh * 32 + 4), x1, x2);
+    ItemSteps16HA<0>::run(acc, w0, x1, x2, nload, lo);
+    if (kh == nhalf - 1) {
+      int tile = wave + tt * CH_NW;
+      int sidx = step_idx;
+      asm volatile("" : "+s"(tile), "+s"(sidx));
+      Acc16 y;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          y.v[j][i] = fmaf(acc.lo[j][i], 1.0f / (H_LO_SCALE * H_ACT_SCALE), acc.hi[j][i] * (1.0f / H_ACT_SCALE));
+      const LinSpec e = make_spec(sidx);
+      lin_epilogue16<DROP>(e, tile, y, lane, bvl);
+    }
+    wcur = np; tt = nt; kh = nk;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  return next_first != nullptr;
+}
+
+#endif  // TC_H16_INPLACE
 
 // y[R, N] = epilogue(src[R, K] W^T): called by all CH_NT threads, no internal barrier.
 //
@@ -1395,6 +1487,27 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
     return __builtin_amdgcn_readfirstlane(any) > 0;
   };
 
+#ifdef TC_CHAIN_DUMP
+  // called by every thread after a step (radar program only): waits for the step's writers, copies the first 256
+  // columns of its LDS destination to g_chain_dump[step][row], waits again
+  auto dump_step = [&](int step, int dst_id) {
+    if constexpr (PROG == PROG_RADAR) {
+      __syncthreads();
+      float* out = g_chain_dump;
+      const float* src = buf_ptr(S, dst_id);
+      if (out != nullptr && src != nullptr && dst_id != B_L && (long long)(step + 1) * M * 256 <= g_chain_dump_floats) {
+        const int ld = buf_ld(dst_id);
+        for (int row = wave; row < R; row += CH_NW)
+          if (m0 + row < M)
+            st4(out + ((size_t)step * M + S.rowg[row]) * 256 + 4 * lane, *reinterpret_cast<const float4*>(src + row * ld + 4 * lane));
+      }
+      __syncthreads();
+    }
+  };
+#define DUMP_STEP(step, dst) dump_step((step), (dst))
+#else
+#define DUMP_STEP(step, dst) do {} while (0)
+#endif
   int idx = (CHAIN_DBG(k.dbg) & 16) ? total : early_n;          // the leading loads are already in LDS
 #ifdef TC_CHAIN_STAMPS
   for (int j = 0; j < 2 * early_n; ++j) STEP_STAMP();
@@ -1442,6 +1555,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
         STEP_STAMP();
         if (r.sync && !(CHAIN_DBG(k.dbg) & 2)) __syncthreads();
         STEP_STAMP();
+        DUMP_STEP(idx, r.dst);
         if (++idx >= total) break;
       }
       continue;
@@ -1891,6 +2005,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
     STEP_STAMP();
     if (r.sync) __syncthreads();
     STEP_STAMP();
+    DUMP_STEP(idx, r.dst);
     ++idx;
   }
   WG_STAMP(1);
@@ -2185,6 +2300,25 @@ extern "C" int tc_debug_cam_stamps(long long* host_out) {
 extern "C" int tc_debug_chain_sub(int step, long long* host_out) {
   if (host_out == nullptr) return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_sub_step), &step, sizeof(int));
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_chain_sub), sizeof(long long) * CH_NW * 64);
+}
+#endif
+
+#ifdef TC_CHAIN_DUMP
+extern "C" int tc_debug_set_chain_dump(void* buf, long long floats) {
+  float* p = static_cast<float*>(buf);
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_chain_dump), &p, sizeof(p));
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_chain_dump_floats), &floats, sizeof(floats));
+  return (int)e;
+}
+#endif
+#ifdef TC_DIAG_BUILD
+// marks a diagnostic build (make INPLACE=1 / DUMP=1): transcar_amd/_lib.py refuses it without TRANSCAR_ALLOW_STAMPS=1
+extern "C" int tc_debug_diag_build() {
+#ifdef TC_H16_INPLACE
+  return 1;
+#else
+  return 2;
+#endif
 }
 #endif
 

@@ -187,6 +187,8 @@ class Detr3DHead(BaseModule):
         #: 'device' (default): raw radar sweeps in img_metas are turned into tokens by tc_radar_build_tokens_batch;
         #: 'host': the reference's numpy route (transcar_amd/radar.py)
         self.radar_ingest = 'device'
+        #: tc_head_options of ``forward`` (``head_options(...)``; None = defaults: automatic tile height and matrix path)
+        self.forward_options = None
         self._radar_stage = {}
         self._ingest_streams = {}       # device -> side stream of the two-phase forward (forward_nhwc(fill_tokens=))
         #: bumped whenever a device buffer a captured hipGraph may point at (packed weights,
@@ -550,7 +552,7 @@ class Detr3DHead(BaseModule):
                                            pad_mult)
         # raw sweeps: the decoder layers that do not read the tokens are enqueued BEFORE the host packs the frame
         return self.forward_nhwc(feats_nhwc, l2i, img_hw, tokens, pad_mult,
-                                 aux=aux, fill_tokens=fill)
+                                 aux=aux, fill_tokens=fill, options=self.forward_options)
 
     # ------------------------------------------------------------------
     # training forward: frozen decoder (fused HIP chains, no graph) + the
