@@ -71,7 +71,7 @@ def parse(argv=None):
                          'of K steps ends with one partial launch of K %% P frames.  Other settings are measured '
                          'beside the headline (`frames_per_launch_sweep`), the like-for-like latency '
                          '`latency_ms_per_frame` always at 1')
-    ap.add_argument('--tile-rows', type=int, default=0, choices=[0, 4, 8, 16],
+    ap.add_argument('--tile-rows', type=int, default=0, choices=[0, 4, 8, 16, 32],
                     help='row-tile height of the fused chains in the frame pipeline (0 = automatic)')
     ap.add_argument('--matrix-path', default='auto', choices=['auto', 'f32', 'f16x2'],
                     help='tc_head_options.matrix_path of the 16-row tiles: f16x2 (= auto) two-plane f16 operands on the '
@@ -400,7 +400,7 @@ def matrix_peak(f16x2):
     return F32_MFMA_PEAK_TFLOPS, 'dense f32 MFMA peak (v_mfma_f32_16x16x4_f32 = the fp32 vector rate)'
 
 
-def roofline(head, inp, dev, matrix_path='auto'):
+def roofline(head, inp, dev, matrix_path='auto', tile_rows=0):
     """Live timing of the kernels of the path.  The dominant one (largest share
     of a frame: the fused decoder row chain, 6 launches per frame) is reported
     against its roofline; the others ride along under "others".  The chain kernels of a launch with 16-row tiles
@@ -414,6 +414,7 @@ def roofline(head, inp, dev, matrix_path='auto'):
     M = B * Q
     H, code, NL = 8, head.code_size, 24
     qpad = ((Q + 15) // 16) * 16
+    tile_rows = tile_rows or getattr(roofline, 'tile_rows', 0)       # (tools/chain_stamps.py sets the attribute)
     o = head.forward_nhwc(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'], inp['pad_mult'], aux=True)
     ref = o['aux']['inter_references'][2].contiguous()
     hs2 = o['aux']['inter_states'][2].contiguous()
@@ -434,7 +435,7 @@ def roofline(head, inp, dev, matrix_path='auto'):
             C.byref(pv.layers[3]), C.byref(pv.layers[4].self_attn.in_proj), C.byref(fv), B, Q, 6,
             code, attn_o.data_ptr(), hs2.data_ptr(), qe.data_ptr(), inp['l2i'].data_ptr(),
             ref.data_ptr(), pc, float(inp['hw'][0]), float(inp['hw'][1]), hs_out.data_ptr(),
-            ref_out.data_ptr(), qk.data_ptr(), vt.data_ptr(), qpad, mp_code << 8, cur_stream()), 'decoder_layer_tail')
+            ref_out.data_ptr(), qk.data_ptr(), vt.data_ptr(), qpad, (mp_code << 8) | int(tile_rows), cur_stream()), 'decoder_layer_tail')
     if getattr(roofline, 'chain_only', False):        # tools/chain_stamps.py: one launch, no timing
         run_chain()
         return None
@@ -478,7 +479,7 @@ def roofline(head, inp, dev, matrix_path='auto'):
     rws = torch.empty(lib.tc_head_workspace_bytes(C.byref(pv), B, T_tok), dtype=torch.uint8, device=dev)
     rcls = torch.empty((3, B, Q, head.cls_out_channels), device=dev)
     rbox = torch.empty((3, B, Q, code), device=dev)
-    ropt = head_options(matrix_path=matrix_path)
+    ropt = head_options(matrix_path=matrix_path, tile_rows=tile_rows or None)
 
     def run_radar():
         L.check(lib.tc_radar_fusion_fwd(
@@ -494,7 +495,7 @@ def roofline(head, inp, dev, matrix_path='auto'):
     # rows are ordered hits first per sample beyond one frame per launch, so a sample's n hit rows occupy
     # ceil(n / R) tiles (+ 1 where a tile straddles two samples)
     hits_l = o['aux']['radar_hit_counts'].cpu().numpy() > 0                         # [3, B, Q]
-    R_tile = 4 if M <= 1024 else 8 if M <= 2048 else 16
+    R_tile = tile_rows or (4 if M <= 1024 else 8 if M <= 2048 else 32 if (M > 4096 and matrix_path != 'f32') else 16)
     gated_rows = 0
     for l in range(3):
         if M > 1024:                                                                # compacted (automatic rule)
@@ -512,8 +513,8 @@ def roofline(head, inp, dev, matrix_path='auto'):
             arithmetic='f16x2 split operands, fp32 accumulate' if f16x2 else 'f32',
             # every workgroup streams the layer's packed weights (3.18 MB) through its CU's vector-memory path: what
             # binds the f16x2 item loop (DESIGN.md section 5 "Round 4"; ~57 B / clk / CU measured by split_mfma_probe)
-            weight_stream_gbs_per_cu=(-(-B * head.num_query // (16 if B * head.num_query > 2048 else 8 if B * head.num_query > 1024 else 4))
-                                      * 795136 * 4 / 256.0) / chain_ms / 1e6,
+            weight_stream_gbs_per_cu=(-(-B * head.num_query // R_tile) * 795136 * 4 / 256.0) / chain_ms / 1e6,
+            tile_rows=R_tile, workgroups=-(-B * head.num_query // R_tile),
             # ... against what a CU's vector-memory path delivers (64 B / clk at 2.4 GHz): the resource the kernel's item
             # loops run against (inside them ~57 of 64 B / clk, tools/split_mfma_probe.hip; averaged over the whole
             # kernel -- sampling, LayerNorms, epilogues included -- the figure below)
@@ -803,7 +804,7 @@ def sweep_side_run(head, dev, args, skip, streams=None):
         # ended in a flush of a partly filled lane and the sweep showed 8 below 4)
         rounds = max(2, -(-max(20, args.steps) // (fpl * pipe.lanes)))
         t = _replay_rate(step, sync, rounds * fpl * pipe.lanes, min_s=0.6)
-        r = roofline(head, lanes[0], dev, args.matrix_path)
+        r = roofline(head, lanes[0], dev, args.matrix_path, tile_rows=args.tile_rows)
         allk = dict(r['others'])
         allk[r['kernel']] = r
         out[str(fpl)] = {'frames_per_launch': fpl, 'frames_in_flight': fpl * pipe.lanes,
@@ -1398,7 +1399,7 @@ def vovnet_side_run(head, dev, args, fpl, streams=None):
     from transcar_amd.pipeline import FramePipeline
     rate, pipe, lanes = _pipeline_rate(head, dev, args, 'vovnet', fpl, head_options(matrix_path=args.matrix_path), streams,
                                        seed0=61)
-    r = roofline(head, lanes[0], dev, args.matrix_path)
+    r = roofline(head, lanes[0], dev, args.matrix_path, tile_rows=args.tile_rows)
     one = make_inputs(head, dev, 'vovnet', 1, seed=67, host_feats=False)
     pipe1 = FramePipeline(head, [one], streams=streams)
     lat = single_lane(pipe1, args)
@@ -1593,8 +1594,9 @@ def main(argv=None):
         # fp32 product from two-plane f16 operands on the matrix cores (three MFMAs, fp32 accumulate) unless
         # --matrix-path f32 (`f32_path` carries that figure)
         'dtype': ('f32 (linear steps and attention core of the batched launches: f16x2 split operands, %d '
-                  'v_mfma_f32_16x16x32_f16 products, fp32 accumulate; 4- / 8-row tiles: f32 MFMA)' % F16X2_PRODUCTS)
-                 if (pipe is not None and pipe.tile_rows_of() == 16 and args.matrix_path != 'f32') else 'f32',
+                  'v_mfma_f32_16x16x32_f16 products, fp32 accumulate; activations of the 32-row tiles held as two f16 planes; '
+                  '4- / 8-row tiles: f32 MFMA)' % F16X2_PRODUCTS)
+                 if (pipe is not None and pipe.tile_rows_of() >= 16 and args.matrix_path != 'f32') else 'f32',
         'data': 'synthetic',
         'timing': win,
         'per_rank': per_rank_summary(own, args.steps, args.batch),
@@ -1628,7 +1630,7 @@ def main(argv=None):
             line['latency_ms_per_frame'] = line['single_lane']['ms_per_frame_synced']
         if not args.no_roofline:
             # the dominant kernel as the timed region launches it (frames_per_launch frames per launch)
-            line['roofline'] = roofline(head, pipe.inputs[0] if pipe is not None else inp, dev, args.matrix_path)
+            line['roofline'] = roofline(head, pipe.inputs[0] if pipe is not None else inp, dev, args.matrix_path, tile_rows=args.tile_rows)
             line['roofline']['frames_per_launch'] = 1 if pipe is None else pipe.frames_per_launch
             # every kernel of the path together, at the measured whole-job rate -- against the f32 MFMA peak (the
             # attention core and the small tiles compute on it; > 1 would only say that the f16x2 chains beat it)

@@ -969,7 +969,7 @@ def test_sdpa_lazy_recentring_extreme_scores(T, case, matrix):
     np.testing.assert_allclose(got.numpy(), want.numpy(), atol=2e-5, rtol=1e-4)
 
 
-@pytest.mark.parametrize('tile_rows', [0, 16])
+@pytest.mark.parametrize('tile_rows', [0, 16, 32])
 def test_radar_row_order_is_invisible_in_the_outputs(T, head, tile_rows):
     """tc_head_options.radar_row_order: with the queries that have a radar return inside their first gate
     processed first (row tiles without any skip the q projection / gated attention / out_proj), scores,
@@ -1026,7 +1026,7 @@ def test_pipelines_can_share_streams(T, head):
         FramePipeline(head, lanes, streams=a.streams[:1])
 
 
-@pytest.mark.parametrize('tile_rows,matrix', [(8, None), (16, 'f16x2'), (16, 'f32')])
+@pytest.mark.parametrize('tile_rows,matrix', [(8, None), (16, 'f16x2'), (16, 'f32'), (32, 'f16x2')])
 def test_a_frame_in_a_batch_equals_the_frame_alone(T, head, tile_rows, matrix):
     """Size independence of the whole path at a fixed tile height: every kernel is row-local except the
     per-(sample, head) attention, so frame b of a three-frame launch (tiles straddle the sample boundaries,
@@ -1097,7 +1097,8 @@ def test_f16x2_chains_are_exact_and_repeatable_at_two_workgroups_per_cu(T, head)
     assert all(torch.equal(outs[0][0], x[0]) and torch.equal(outs[0][1], x[1]) for x in outs[1:])
 
 
-def test_full_size_launch_of_eight_frames_is_frame_by_frame_the_single_frame_path(T):
+@pytest.mark.parametrize('tile_rows', [16, 32])
+def test_full_size_launch_of_eight_frames_is_frame_by_frame_the_single_frame_path(T, tile_rows):
     """The bench's own configuration (ResNet-101 FPN shapes, iid-noise maps, 8 frames per launch, 16-row tiles
     on the 16x16x4 MFMA, two workgroups per CU, radar rows compacted): frames 0, 3 and 7 of the launch are
     bit-identical to the same frames launched alone at the same tile height, and the decoded boxes with them --
@@ -1109,7 +1110,7 @@ def test_full_size_launch_of_eight_frames_is_frame_by_frame_the_single_frame_pat
     head, _ = bench.build_head(dev())
     B = 8
     inp = bench.make_inputs(head, dev(), 'res101', B, seed=71, host_feats=False)
-    opt = head_options(tile_rows=16)
+    opt = head_options(tile_rows=tile_rows)
     full = head.forward_nhwc(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'], inp['pad_mult'], options=opt)
     torch.cuda.synchronize()
     cls, box = full['all_cls_scores'].clone(), full['all_bbox_preds'].clone()
@@ -1131,10 +1132,10 @@ def test_full_size_launch_of_eight_frames_is_frame_by_frame_the_single_frame_pat
 @pytest.mark.parametrize('fpl', ['resident', 10])
 def test_timed_geometry_is_frame_by_frame_the_single_frame_path(T, fpl):
     """EXACTLY what `python bench.py --steps 20` launches: ResNet-101 FPN shapes, iid-noise maps,
-    the default options (automatic tile height, radar rows compacted), three lanes in flight, frames per launch =
-    the most whose 16-row tiles are resident at once (9 = 507 workgroups), a window of 20 submits = 9 + 9 + a
-    PARTIAL launch of 2 (at the full launch's 16-row tiles: FramePipeline.tile_rows_of) -- and, second case, 10 frames per launch = 563 workgroups on 512 slots (a
-    second scheduling round; the driver's round-2 geometry).  Every one of the 20 frames, and its decoded boxes,
+    the default options (automatic tile height: 32 rows since round 5, radar rows compacted), three lanes in flight,
+    frames per launch = the most whose tiles are resident at once (9 = 254 workgroups of 32 rows, one per CU), a window of
+    20 submits = 9 + 9 + a PARTIAL launch of 2 (at the full launch's tile height: FramePipeline.tile_rows_of) -- and, second
+    case, 10 frames per launch = 282 workgroups on 256 slots (a second scheduling round; the driver's round-2 geometry).  Every one of the 20 frames, and its decoded boxes,
     is bit-identical to the same frame launched alone at the same tile height."""
     import bench
     bench._imports()
@@ -1160,7 +1161,7 @@ def test_timed_geometry_is_frame_by_frame_the_single_frame_path(T, fpl):
         partial = lane == part_lane
         outs, dec = pipe.last_flush[2] if partial else pipe.outputs[lane]
         opt = head_options(tile_rows=pipe.tile_rows_of(n_part if partial else P))       # what that launch used
-        assert opt.chain_tile_rows == 16
+        assert opt.chain_tile_rows == 32                 # more than 4096 rows per full launch: one 32-row workgroup per CU
         inp = lanes[lane]
         one = head.forward_nhwc([f[6 * slot:6 * slot + 6] for f in inp['nhwc']], inp['l2i'][slot:slot + 1], inp['hw'],
                                 inp['tokens'][slot:slot + 1], inp['pad_mult'], options=opt)

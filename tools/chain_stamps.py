@@ -36,8 +36,12 @@ def main():
     lib.tc_debug_chain_sub.restype = C.c_int
     lib.tc_debug_chain_sub.argtypes = [C.c_int, C.c_void_p]
     lib.tc_debug_chain_sub(sub, None)
+    rows_env = int(os.environ.get('STAMPS_ROWS', '0'))       # 0: automatic; 32: the 8-wave tiles
+    from transcar_amd.detr3d_head import head_options
+    NWV = 8 if rows_env == 32 else 4
+    bench.roofline.tile_rows = rows_env
     for _ in range(3):
-        head.forward_nhwc(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'], inp['pad_mult'])
+        head.forward_nhwc(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'], inp['pad_mult'], options=head_options(tile_rows=rows_env or None))
     if which == 'decoder':
         # the forward's LAST chain launch is the radar chain; run one decoder tail on top
         bench.roofline_chain_once(head, inp, dev)
@@ -45,11 +49,11 @@ def main():
     else:
         names = RAD * 3
     torch.cuda.synchronize()
-    buf = np.zeros((4, 64), dtype=np.int64)
+    buf = np.zeros((8, 64), dtype=np.int64)
     assert lib.tc_debug_chain_stamps(buf.ctypes.data) == 0
     t = buf - buf[:, :1]                                   # s_memtime ticks (= core cycles here)
     if sub >= 0:
-        sb = np.zeros((4, 64), dtype=np.int64)
+        sb = np.zeros((8, 64), dtype=np.int64)
         assert lib.tc_debug_chain_sub(0, sb.ctypes.data) == 0
         print('sub-step stamps of table step %d (%s): 0 dispatch, 1 spec built, 2 first load issued, 3.. after item i' % (sub, names[sub]))
         st = sb[0, 40:47]
@@ -70,7 +74,7 @@ def main():
         lib.tc_debug_wg_spans.argtypes = [C.c_void_p]
         assert lib.tc_debug_wg_spans(wg.ctypes.data) == 0
         rows = batch * head.num_query
-        R = 4 if rows <= 1024 else 8 if rows <= 2048 else 16
+        R = rows_env or (4 if rows <= 1024 else 8 if rows <= 2048 else 16)
         nb = min(-(-rows // R), 1024)
         w = wg[:nb]
         t0 = w[:, 0].min()
@@ -112,14 +116,14 @@ def main():
               'taps issued (last visible camera), accumulated, row done, rows done, pair counter added')
         for w in range(4):
             print('  wave%d:' % w, ' '.join('%6d' % (cb[w, j] - cb[w, 0]) for j in (5, 1, 2, 3, 4, 6, 7)))
-    print('%-14s %s' % ('step', '   '.join('wave%d work / wait' % w for w in range(4))))
+    print('%-14s %s' % ('step', '   '.join('wave%d work / wait' % w for w in range(NWV))))
     n = min(len(names), 31)
     for i in range(n):
         cols = []
-        for w in range(4):
+        for w in range(NWV):
             work = t[w, 1 + 2 * i] - t[w, 2 * i]
             wait = t[w, 2 + 2 * i] - t[w, 1 + 2 * i]
-            cols.append('%7d /%6d' % (work, wait))
+            cols.append('%6d /%5d' % (work, wait))
         print('%-14s %s' % (names[i], '   '.join(cols)))
     print('total cycles (wave 0): %d = %.1f us at 2.4 GHz' % (t[0, 2 * n], t[0, 2 * n] / 2400.0))
 

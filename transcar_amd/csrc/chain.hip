@@ -67,8 +67,10 @@ namespace tc {
 
 namespace {
 
-constexpr int CH_NW = 4;
+constexpr int CH_NW = 4;              // waves of a workgroup with 4- / 8- / 16-row tiles ...
 constexpr int CH_NT = CH_NW * 64;
+constexpr int CH_NW_MAX = 8;          // ... and with 32-row tiles (round 5: one workgroup of 8 waves per CU)
+constexpr int nw_of(int R) { return R == 32 ? 8 : 4; }
 constexpr int LD5 = 516;   // 512 + 4 floats
 constexpr int LD2 = 260;   // 256 + 4
 constexpr int LDL = 36;
@@ -101,9 +103,10 @@ struct PreRec { const float* first; int nidx; int pad; };
 // arguments -> LDS records) every launch began with ~9400 cycles of dependent loads, 4 us
 // of a 56 us decoder layer; read per step with scalar loads straight from the
 // kernel-argument segment, every step paid 400-800 cycles of scalar-cache misses (+6 us).
-struct StepAll { StepRes r; EpiRec e; PreRec p[CH_NW]; };
-static_assert(sizeof(StepAll) % 16 == 0, "records are copied 16 bytes at a time");
-template <int N> struct Recs { StepAll s[N]; };
+template <int NW> struct StepAllT { StepRes r; EpiRec e; PreRec p[NW]; };
+using StepAll = StepAllT<CH_NW>;
+static_assert(sizeof(StepAllT<CH_NW>) % 16 == 0 && sizeof(StepAllT<CH_NW_MAX>) % 16 == 0, "records are copied 16 bytes at a time");
+template <int N, int NW = CH_NW> struct Recs { StepAllT<NW> s[N]; };
 
 // Activations of the R rows: FOUR [R][256 + 4] units (round 1 had seven: 120 KB at R = 16, one
 // workgroup per CU).  Unit 0 (B_X) is the residual stream; units 1-3 are temporaries placed by the
@@ -118,7 +121,7 @@ constexpr int HM_WORDS = 8;
 static_assert(HM_WORDS * 8 <= LDL * 4 && (LDL * 4) % 8 == 0, "hit masks live in a row of the logit buffer");
 template <int R, int NREC>
 struct ChainLds {
-  StepAll recs[NREC];
+  StepAllT<nw_of(R)> recs[NREC];
   float unit[4][R][LD2];
   float l[R][LDL];
   float box[R][12];
@@ -414,6 +417,7 @@ struct LinSpec {
   const int* rowg;             // radar: LDS table tile position -> global row for the gdst stores (null: m0 + i)
   int gpre;                    // F_GPRE
   const float* cmask; float cscale;   // F_CMASK: y = cmask[row, col] > 0 ? y * cscale : 0 (cmask is [M, N])
+  int dst_pl, res_pl;          // 32-row kernels: the LDS destination / residual holds planes (act_ld4 / act_st4)
 };
 
 // One work item = (64-column output tile, 64-deep k block): 16 x 16-byte weight
@@ -425,7 +429,7 @@ constexpr int KB = 64;
 struct WBuf { float4 b[16]; };
 
 #ifdef TC_CHAIN_STAMPS
-__device__ long long g_chain_sub[CH_NW][64];
+__device__ long long g_chain_sub[CH_NW_MAX][64];
 __device__ int g_sub_step;      // table index of the linear step to dissect
 #define SUB_STAMP(slot)                                                                       \
   do {                                                                                        \
@@ -663,37 +667,44 @@ struct ItemSteps16<16> {
 // v_mfma per sub-tile, D = fma(bias, 1, acc) + 0 + 0 + 0, the same single rounding as the scalar add it replaces
 // (16 crossbar moves per tile otherwise, or 16 live registers).  N is a multiple of 4 wherever a step has an LDS destination or a residual
 // (256 / 512 / 24 / 64 / 128); the 3-column head of the prologue only stores to global memory, element by element.
-template <bool DROP>
-__device__ __forceinline__ void lin_epilogue16(const LinSpec& s, int tile, const Acc16& acc, int lane, float bvl) {
+template <bool PL> __device__ __forceinline__ float4 act_ld4(const float* row, int col);      // (defined with the f16 planes below)
+template <bool PL> __device__ __forceinline__ void act_st4(float* row, int col, const float4& v);
+// NJ: sub-tiles of 16 columns in the wave's tile (4: the 64-column tiles of the 16-row kernels; 2: the 32-column tiles
+// of the 32-row kernels); colbase: the tile's first column; bvl: the bias of column colbase + lane (lanes >= 16 NJ: unused).
+// The rows are s.src / dst / res / gate / rowg / m0 + 0 .. 15: the 32-row kernels pass a view of their second row group.
+template <bool DROP, int NJ = 4, bool PL = false>
+__device__ __forceinline__ void lin_epilogue16(const LinSpec& s, int colbase, const f32x4 (&accv)[NJ], int lane, float bvl) {
   const int c = lane & 15, g = lane >> 4;
-  const int colb = tile * 64 + 4 * g;            // + 16 j
-  float y[4][4];
-  f32x4 ab[4] = {acc.v[0], acc.v[1], acc.v[2], acc.v[3]};
+  const int colb = colbase + 4 * g;              // + 16 j
+  float y[NJ][4];
+  f32x4 ab[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) ab[j] = accv[j];
   if (s.bias != nullptr) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ab[j] = MFMA16(bvl, g == j ? 1.0f : 0.0f, ab[j]);
+    for (int j = 0; j < NJ; ++j) ab[j] = MFMA16(bvl, g == j ? 1.0f : 0.0f, ab[j]);
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const float sc = (colb + 16 * j < s.scale_cols) ? s.scale : 1.0f;     // scale_cols is 0 or 256
 #pragma unroll
     for (int i = 0; i < 4; ++i) y[j][i] = ab[j][i] * sc;
   }
   if (s.act == 1) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int i = 0; i < 4; ++i) y[j][i] = fmaxf(y[j][i], 0.0f);
   } else if (s.act == 2) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int i = 0; i < 4; ++i) y[j][i] = sigmoidf_(y[j][i]);
   }
   if (s.gate != nullptr) {
     if (s.gate[c] == 0) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i) y[j][i] = 0.0f;
     }
@@ -704,7 +715,7 @@ __device__ __forceinline__ void lin_epilogue16(const LinSpec& s, int tile, const
       unsigned long long seed = s.drop_seed;
       if (s.drop_q > 0) { const unsigned b = row / (unsigned)s.drop_q; row -= b * (unsigned)s.drop_q; seed += b * s.drop_stride; }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         // the lane's four consecutive columns of sub-tile j: one hash (N and colb are multiples of 4)
         const unsigned m = drop_keep4(seed, (unsigned)(s.drop_site - 1), row * (unsigned)s.N + (unsigned)(colb + 16 * j), s.drop_thr);
 #pragma unroll
@@ -713,21 +724,25 @@ __device__ __forceinline__ void lin_epilogue16(const LinSpec& s, int tile, const
     }
   }
   if (s.res != nullptr) {
-    float4 rr[4];
+    float4 rr[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      rr[j] = colb + 16 * j < s.N ? *reinterpret_cast<const float4*>(s.res + c * s.res_ld + colb + 16 * j)
-                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < NJ; ++j)
+      rr[j] = colb + 16 * j >= s.N ? make_float4(0.f, 0.f, 0.f, 0.f)
+              : (PL && s.res_pl) ? act_ld4<PL>(s.res + c * s.res_ld, colb + 16 * j)
+                                 : *reinterpret_cast<const float4*>(s.res + c * s.res_ld + colb + 16 * j);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { y[j][0] += rr[j].x; y[j][1] += rr[j].y; y[j][2] += rr[j].z; y[j][3] += rr[j].w; }
+    for (int j = 0; j < NJ; ++j) { y[j][0] += rr[j].x; y[j][1] += rr[j].y; y[j][2] += rr[j].z; y[j][3] += rr[j].w; }
   }
   const bool vec = (s.N & 3) == 0;               // wave-uniform
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const int col = colb + 16 * j;
     if (col >= s.N) break;                       // columns only grow with j
     const float4 y4 = make_float4(y[j][0], y[j][1], y[j][2], y[j][3]);
-    if (s.dst != nullptr) *reinterpret_cast<float4*>(s.dst + c * s.dst_ld + col) = y4;      // (N % 4 == 0 here)
+    if (s.dst != nullptr) {                                                                // (N % 4 == 0 here)
+      if (PL && s.dst_pl) act_st4<PL>(s.dst + c * s.dst_ld, col, y4);
+      else *reinterpret_cast<float4*>(s.dst + c * s.dst_ld + col) = y4;
+    }
     if (s.gdst != nullptr && s.m0 + c < s.M) {
       const int grow = s.rowg != nullptr ? s.rowg[c] : s.m0 + c;
       float* gp = s.gdst + (size_t)grow * s.gdst_ld + col;
@@ -829,7 +844,7 @@ __device__ __forceinline__ bool linear_step16(const LinSpec& s, WBuf& w0, bool p
       asm volatile("" : "+s"(tile), "+s"(sidx));         // see linear_step: the epilogue rebuilds its view
       if (!(CHAIN_DBG(s.dbg) & 1)) {
         const LinSpec e = make_spec(sidx);
-        lin_epilogue16<DROP>(e, tile, acc, lane, bvl);
+        lin_epilogue16<DROP>(e, tile * 64, acc.v, lane, bvl);
       }
     }
     wcur = np; tt = nt; kb = nk;
@@ -878,6 +893,46 @@ __device__ __forceinline__ void split_h(const float4& a, const float4& b, float4
   }
   p1 = make_float4(__uint_as_float(q1[0]), __uint_as_float(q1[1]), __uint_as_float(q1[2]), __uint_as_float(q1[3]));
   p2 = make_float4(__uint_as_float(q2[0]), __uint_as_float(q2[1]), __uint_as_float(q2[2]), __uint_as_float(q2[3]));
+}
+
+// ---- the 32-row kernels keep their activations in LDS AS PLANES (round 5) -------------------------------------------
+// With 8 waves per workgroup every wave would split all 32 rows of an item for itself (176 vector instructions per 24
+// MFMAs: measured, the item loop then is VALU bound and SLOWER than two 16-row workgroups).  So the split happens where a
+// value is WRITTEN, once: the four activation units (X, U1..U3, A) of a 32-row workgroup hold, per row and per 8
+// consecutive columns, 16 bytes of hi plane and 16 bytes of lo plane -- the 32 bytes the 8 floats would take, and exactly
+// the two operand fragments a lane of v_mfma_f32_16x16x32_f16 needs (two ds_read_b128, no arithmetic in the item loop).
+// Every other reader (LayerNorm, residual adds, the narrow heads, the attention's query) reconstructs
+// x = 64 hi + lo / 32 (one rounding; the pair carries s x to 2^-24 relative, so a store / load round trip moves a value
+// by at most one unit in its last place).  The logits / box / centre side buffers stay fp32.
+template <bool PL>
+__device__ __forceinline__ float4 act_ld4(const float* row, int col) {       // col % 4 == 0; `row`: start of the LDS row
+  if constexpr (!PL) {
+    return *reinterpret_cast<const float4*>(row + col);
+  } else {
+    const char* p = reinterpret_cast<const char*>(row) + (col >> 3) * 32 + (col & 7) * 2;
+    const uint2 h = *reinterpret_cast<const uint2*>(p), l = *reinterpret_cast<const uint2*>(p + 16);
+    const f16x2 h0 = __builtin_bit_cast(f16x2, h.x), h1 = __builtin_bit_cast(f16x2, h.y);
+    const f16x2 l0 = __builtin_bit_cast(f16x2, l.x), l1 = __builtin_bit_cast(f16x2, l.y);
+    constexpr float UH = 1.0f / H_ACT_SCALE, UL = 1.0f / (H_ACT_SCALE * H_LO_SCALE);
+    return make_float4(fmaf((float)l0[0], UL, (float)h0[0] * UH), fmaf((float)l0[1], UL, (float)h0[1] * UH),
+                       fmaf((float)l1[0], UL, (float)h1[0] * UH), fmaf((float)l1[1], UL, (float)h1[1] * UH));
+  }
+}
+template <bool PL>
+__device__ __forceinline__ void act_st4(float* row, int col, const float4& v) {
+  if constexpr (!PL) {
+    *reinterpret_cast<float4*>(row + col) = v;
+  } else {
+    const float t0 = v.x * H_ACT_SCALE, t1 = v.y * H_ACT_SCALE, t2 = v.z * H_ACT_SCALE, t3 = v.w * H_ACT_SCALE;
+    uint2 h, l;
+    h.x = pk_h2(t0, t1); h.y = pk_h2(t2, t3);
+    const f16x2 h0 = __builtin_bit_cast(f16x2, h.x), h1 = __builtin_bit_cast(f16x2, h.y);
+    l.x = pk_h2((t0 - (float)h0[0]) * H_LO_SCALE, (t1 - (float)h0[1]) * H_LO_SCALE);
+    l.y = pk_h2((t2 - (float)h1[0]) * H_LO_SCALE, (t3 - (float)h1[1]) * H_LO_SCALE);
+    char* p = reinterpret_cast<char*>(row) + (col >> 3) * 32 + (col & 7) * 2;
+    *reinterpret_cast<uint2*>(p) = h;
+    *reinterpret_cast<uint2*>(p + 16) = l;
+  }
 }
 
 // One HALF item (64 columns x 32 k): 8 fragments of 1 KiB -- (sub-tile j, plane p) at wb.b[2 j + p] --, 12 MFMAs.
@@ -986,7 +1041,7 @@ __device__ __forceinline__ bool linear_step16h(const LinSpec& s, WBuf& w0, bool 
             for (int i = 0; i < 4; ++i)
               y.v[j][i] = fmaf(acc.lo[j][i], 1.0f / (H_LO_SCALE * H_ACT_SCALE), acc.hi[j][i] * (1.0f / H_ACT_SCALE));
           const LinSpec e = make_spec(sidx);
-          lin_epilogue16<DROP>(e, tile, y, lane, bvl);
+          lin_epilogue16<DROP>(e, tile * 64, y.v, lane, bvl);
         }
       }
       wcur = np; tt = nt; kh = nk;
@@ -1073,7 +1128,7 @@ __device__ __forceinline__ bool linear_step16h(const LinSpec& s, WBuf& w0, bool 
         for (int i = 0; i < 4; ++i)
           y.v[j][i] = fmaf(acc.lo[j][i], 1.0f / (H_LO_SCALE * H_ACT_SCALE), acc.hi[j][i] * (1.0f / H_ACT_SCALE));
       const LinSpec e = make_spec(sidx);
-      lin_epilogue16<DROP>(e, tile, y, lane, bvl);
+      lin_epilogue16<DROP>(e, tile * 64, y.v, lane, bvl);
     }
     wcur = np; tt = nt; kh = nk;
     __builtin_amdgcn_sched_barrier(0);
@@ -1082,6 +1137,143 @@ __device__ __forceinline__ bool linear_step16h(const LinSpec& s, WBuf& w0, bool 
 }
 
 #endif  // TC_H16_INPLACE
+
+// ---- 32-row tiles on the f16 matrix cores (round 5) --------------------------------------------------------
+// What bounds the 16-row f16 loop is the weight stream: every 16-row workgroup pulls the layer's 3.18 MB of planes through
+// its CU's vector-memory path (two workgroups per CU: ~60 GB/s per CU, 64 B/clk at best), and the matrix cores idle 85 %
+// of the time.  Here ONE workgroup of EIGHT waves owns 32 rows, one per CU (140-152 KB of LDS): a wave owns 32-COLUMN
+// tiles (two of the 16-column sub-tiles of the same packed PH copy: fragments [kk][2 half .. + 1][p] of every 64-deep
+// item, still 1 KiB per wave-instruction) and BOTH 16-row groups, so a fetched fragment feeds 6 MFMAs instead of 3 and
+// the CU streams the layer's weights once per 32 rows -- while the row-local steps (LayerNorm, camera sampling, gate,
+// attention) still see 4 rows per wave on 8 waves, as in two 16-row workgroups.  Same products in the same k order as
+// linear_step16h: bit-identical results.  Item = 32 columns x 64 k = 8 fragments ((kk, jj, p) at b[8 BUF + 4 kk + 2 jj + p]),
+// 24 MFMAs; two item buffers, the fragments of item i + 1 go to the other buffer group by group (see above: never in place).
+struct Acc32H { f32x4 hi[2][2]; f32x4 lo[2][2]; };     // [row group][sub-tile jj]
+
+template <int BUF>
+__device__ __forceinline__ void item32h(Acc32H& acc, WBuf& wb, const float* arow0, const float* arow1, int koff,
+                                        const float* np, unsigned lo) {
+  constexpr int C = 8 * BUF, N = 8 * (1 - BUF);
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    // the operand fragments of the two row groups: the 16 bytes of hi plane and the 16 bytes of lo plane of the lane's 8 k
+    float4 x1[2], x2[2];
+    x1[0] = *reinterpret_cast<const float4*>(arow0 + koff + 32 * kk); x2[0] = *reinterpret_cast<const float4*>(arow0 + koff + 32 * kk + 4);
+    x1[1] = *reinterpret_cast<const float4*>(arow1 + koff + 32 * kk); x2[1] = *reinterpret_cast<const float4*>(arow1 + koff + 32 * kk + 4);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int f = 4 * kk + 2 * jj;
+#pragma unroll
+      for (int rg = 0; rg < 2; ++rg) {
+        acc.lo[rg][jj] = MFMA16H(wb.b[C + f + 1], x1[rg], acc.lo[rg][jj]);
+        acc.lo[rg][jj] = MFMA16H(wb.b[C + f], x2[rg], acc.lo[rg][jj]);
+        acc.hi[rg][jj] = MFMA16H(wb.b[C + f], x1[rg], acc.hi[rg][jj]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // the wave's fragments of the next item: (kk, jj, p) at 8 kk + 2 jj + p fragments behind np (np carries the half)
+      wb.b[N + f] = ld4(np + (size_t)(lo + (8 * kk + 2 * jj) * 256u));
+      wb.b[N + f + 1] = ld4(np + (size_t)(lo + (8 * kk + 2 * jj + 1) * 256u));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+// linear_step for R = 32 (8 waves; same contract as linear_step16h: w0 may arrive preloaded with the step's first item in
+// b[0..7], the last item of an even count fetches `next_first`; an odd count -- the radar encoders' two K = 64 steps --
+// ends on buffer 1 and hands nothing over)
+template <bool DROP, typename SpecFn>
+__device__ __forceinline__ bool linear_step32h(const LinSpec& s, WBuf& w0, bool preloaded, const float* next_first,
+                                               SpecFn make_spec, int step_idx) {
+  constexpr int NW = 8;
+  const int lane = threadIdx.x & 63;
+  const int wave = (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) - s.woff) & (NW - 1);
+  const int ntiles = (s.N + 31) >> 5;                  // 32-column tiles
+  const int kpad = (s.K + 63) & ~63;
+  const int nkb = kpad / KB;
+  const int my_tiles = wave < ntiles ? (ntiles - wave + NW - 1) / NW : 0;
+  const int nitems = my_tiles * nkb;
+  // lane 16g + c reads rows c and 16 + c, the 8 consecutive k of group g in every 32-wide half of the item
+  const float* arow0 = s.src + (lane & 15) * s.src_ld + 8 * (lane >> 4);
+  const float* arow1 = arow0 + 16 * s.src_ld;
+  const float* wbase = s.W + (size_t)(wave >> 1) * 64 * kpad + (size_t)(wave & 1) * 4 * 256;   // wave-uniform; the lane adds lo
+  const unsigned lo = 4u * lane;
+  const size_t tile_stride = (size_t)(NW / 2) * 64 * kpad;
+  Acc32H acc;
+  float bvl = 0.f;
+  SUB_STAMP(1);
+  if (CHAIN_DBG(s.dbg) & 32) return false;
+  if (!preloaded) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      w0.b[i] = ld4(wbase + (size_t)(lo + i * 256u));
+      w0.b[4 + i] = ld4(wbase + (size_t)(lo + (8 + i) * 256u));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  SUB_STAMP(2);
+  __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): see linear_step16
+  int tt = 0, kb = 0;
+  const float* wcur = wbase;
+  // one item: accumulators / bias at the start of a tile, the MFMAs from buffer BUF, the epilogue at the end of a tile
+  auto run = [&](auto buf, const float* np_last) {
+    constexpr int BUF = decltype(buf)::value;
+    const float* np = wcur;
+    int nt = tt, nk = kb;
+    if (++nk == nkb) { nk = 0; ++nt; np = wbase + (size_t)nt * tile_stride; }
+    else np += 16 * 256;
+    const float* nload = np_last != nullptr ? np_last : np;
+    if (kb == 0) {
+#pragma unroll
+      for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) { acc.hi[rg][jj] = f32x4{0.f, 0.f, 0.f, 0.f}; acc.lo[rg][jj] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      const float* bsrc = s.bias != nullptr ? s.bias : s.W;
+      bvl = ldg1(bsrc + min((wave + tt * NW) * 32 + lane, s.N - 1));
+    }
+    item32h<BUF>(acc, w0, arow0, arow1, kb * KB, nload, lo);
+    if (kb == nkb - 1) {
+      int tile = wave + tt * NW;
+      int sidx = step_idx;
+      asm volatile("" : "+s"(tile), "+s"(sidx));         // see linear_step: the epilogue rebuilds its view
+      if (!(CHAIN_DBG(s.dbg) & 1)) {
+        LinSpec e = make_spec(sidx);
+#pragma unroll
+        for (int rg = 0; rg < 2; ++rg) {
+          f32x4 y[2];
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              y[jj][i] = fmaf(acc.lo[rg][jj][i], 1.0f / (H_LO_SCALE * H_ACT_SCALE), acc.hi[rg][jj][i] * (1.0f / H_ACT_SCALE));
+          lin_epilogue16<DROP, 2, true>(e, tile * 32, y, lane, bvl);
+          // the second row group: the same view 16 rows down
+          if (e.dst != nullptr) e.dst += 16 * e.dst_ld;
+          if (e.res != nullptr) e.res += 16 * e.res_ld;
+          if (e.gate != nullptr) e.gate += 16;
+          if (e.rowg != nullptr) e.rowg += 16;
+          e.m0 += 16;
+        }
+      }
+    }
+    wcur = np; tt = nt; kb = nk;
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  const float* fallback = wbase;
+  int it = 0;
+#pragma unroll 1
+  for (; it + 1 < nitems; it += 2) {
+    run(B0{}, nullptr);
+    const bool last = it + 2 >= nitems;
+    run(B1{}, last ? (next_first != nullptr ? next_first : fallback) : nullptr);
+  }
+  if (it < nitems) {               // odd item count: the step ends on buffer 1, nothing is handed over
+    run(B0{}, fallback);
+    return false;
+  }
+  return next_first != nullptr;
+}
 
 // y[R, N] = epilogue(src[R, K] W^T): called by all CH_NT threads, no internal barrier.
 //
@@ -1100,6 +1292,7 @@ __device__ __forceinline__ bool linear_step(const LinSpec& s, WBuf& w0, bool pre
                                             const float* next_first, SpecFn make_spec, int step_idx) {
   // 16-row tiles: ONE weight buffer refilled in place, 16x16x4 f32 MFMAs (linear_step16) or the two-plane f16
   // form on the matrix cores (linear_step16h, MM = 1)
+  if constexpr (R == 32) return linear_step32h<DROP>(s, w0, preloaded, next_first, make_spec, step_idx);
   if constexpr (R == 16 && MM == 1) return linear_step16h<DROP>(s, w0, preloaded, next_first, make_spec, step_idx);
   if constexpr (R == 16) return linear_step16<DROP, SRC2>(s, w0, preloaded, next_first, make_spec, step_idx);
   constexpr int NG = R / 4;
@@ -1214,7 +1407,7 @@ __device__ __forceinline__ int buf_ld(int id) { return id == B_A ? LD5 : id == B
 
 #ifdef TC_CHAIN_STAMPS
 // debug build only (make STAMPS=1): s_memtime after every step of workgroup 100
-__device__ long long g_chain_stamps[CH_NW][64];
+__device__ long long g_chain_stamps[CH_NW_MAX][64];
 #define STEP_STAMP()                                                                          \
   do {                                                                                        \
     if (blockIdx.x == 100 && lane == 0 && stamp_i < 64)                                       \
@@ -1268,8 +1461,10 @@ __device__ long long g_wg_span[1024][2];
 // private segment under the combined pressure of the camera-sampling and radar-attention
 // bodies; the specialised kernels are smaller and were 3.5 % faster per frame.)
 template <int R, int PROG, bool DROP = false, int MM = 0>
-__device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __restrict__ recs, const int block) {
-  static_assert(MM == 0 || (R == 16 && PROG != PROG_PROLOGUE), "the f16 two-plane path exists for 16-row tiles");
+__device__ __forceinline__ void chain_body(const ChainDev& k, const StepAllT<nw_of(R)>* __restrict__ recs, const int block) {
+  constexpr int NW = nw_of(R), NT = NW * 64;        // waves / threads of the workgroup
+  constexpr bool PL = R == 32;                      // the activation units hold planes (act_ld4 / act_st4)
+  static_assert((MM == 0 && R <= 16) || (MM == 1 && R >= 16 && PROG != PROG_PROLOGUE), "the f16 two-plane path exists for 16- and 32-row tiles (and is the only one at 32)");
   extern __shared__ __align__(16) unsigned char smem_raw[];
   using Lds = ChainLds<R, rec_cap(PROG)>;
   Lds& S = *reinterpret_cast<Lds*>(smem_raw);
@@ -1279,12 +1474,12 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
   // The records, kernel-argument segment -> registers (-> LDS below): issued before anything
   // depends on a kernel argument -- the first touch of the segment costs ~2600 cycles, and
   // this way the copy and the scalar loads of the arguments share that one latency.
-  constexpr int REC16 = rec_cap(PROG) * (int)(sizeof(StepAll) / 16);
-  constexpr int REC_TRIPS = (REC16 + CH_NT - 1) / CH_NT;
+  constexpr int REC16 = rec_cap(PROG) * (int)(sizeof(StepAllT<NW>) / 16);
+  constexpr int REC_TRIPS = (REC16 + NT - 1) / NT;
   int4 rec_v[REC_TRIPS];
 #pragma unroll
   for (int t = 0; t < REC_TRIPS; ++t) {
-    const int i = min((int)threadIdx.x + t * CH_NT, REC16 - 1);   // unconditional: stays in registers
+    const int i = min((int)threadIdx.x + t * NT, REC16 - 1);   // unconditional: stays in registers
     rec_v[t] = reinterpret_cast<const int4*>(recs)[i];
   }
   const int M = k.M;
@@ -1294,7 +1489,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
   const int total = k.total;
   // The leading global-to-LDS loads of a program (a decoder layer starts with three) go out
   // together: one memory latency, one barrier.
-  constexpr int EARLY_MAX = 3, EARLY_RW = (R + CH_NW - 1) / CH_NW;
+  constexpr int EARLY_MAX = 3, EARLY_RW = (R + NW - 1) / NW;
   const int early_n = k.early_n;
   {
     float4 early_v[EARLY_MAX][EARLY_RW];
@@ -1305,7 +1500,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
         const int ld = recs[j].r.gld, mod = recs[j].r.gmod;
 #pragma unroll
         for (int ri = 0; ri < EARLY_RW; ++ri) {
-          int grow = min(m0 + wave + ri * CH_NW, M - 1);
+          int grow = min(m0 + wave + ri * NW, M - 1);
           if (mod > 0) grow = grow % mod;
           early_v[j][ri] = ld4(gsrc + (size_t)grow * ld + 4 * lane);
         }
@@ -1318,15 +1513,15 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
         float* dst = reinterpret_cast<float*>(smem_raw) + recs[j].e.dst_off;
 #pragma unroll
         for (int ri = 0; ri < EARLY_RW; ++ri) {
-          const int row = wave + ri * CH_NW;
-          if (row < R) *reinterpret_cast<float4*>(dst + row * LD2 + 4 * lane) = early_v[j][ri];
+          const int row = wave + ri * NW;
+          if (row < R) act_st4<PL>(dst + row * LD2, 4 * lane, early_v[j][ri]);
         }
       }
     }
   }
 #pragma unroll
   for (int t = 0; t < REC_TRIPS; ++t) {
-    const int i = threadIdx.x + t * CH_NT;
+    const int i = threadIdx.x + t * NT;
     if (i < REC16) reinterpret_cast<int4*>(&S.recs[0])[i] = rec_v[t];
   }
   START_STAMP(43);
@@ -1338,9 +1533,9 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
       return k.row_perm != nullptr ? k.row_perm[pos] : pos;
     };
     if (threadIdx.x < R) S.rowg[threadIdx.x] = row_of(threadIdx.x);
-    for (int row = wave; row < R; row += CH_NW) {
+    for (int row = wave; row < R; row += NW) {
       const int grow = row_of(row);
-      *reinterpret_cast<float4*>(&S.unit[0][row][4 * lane]) = ld4(k.g[G_QF] + (size_t)grow * 256 + 4 * lane);
+      act_st4<PL>(&S.unit[0][row][0], 4 * lane, ld4(k.g[G_QF] + (size_t)grow * 256 + 4 * lane));
     }
     {
       // one (row, column) per thread: columns 0..code-1 the previous box, 12..14 the gate centre
@@ -1364,7 +1559,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
   }
   if constexpr (PROG == PROG_RADAR_BWD) {
     // nothing comes down to the top layer: the carried gradients (layer input in unit X, box in the row records) start at zero
-    for (int i = threadIdx.x; i < R * LD2; i += CH_NT) (&S.unit[0][0][0])[i] = 0.0f;
+    for (int i = threadIdx.x; i < R * LD2; i += NT) (&S.unit[0][0][0])[i] = 0.0f;
     if (threadIdx.x < R * 12) (&S.box[0][0])[threadIdx.x] = 0.0f;
     if (threadIdx.x < R) S.gate[threadIdx.x] = 0;
   }
@@ -1381,7 +1576,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
   // wave, the rows' independent reduction chains interleave, stores last (row by row the 16-row tiles
   // paid four gamma / beta round trips and four serial reduction chains per LayerNorm).
   auto do_ln = [&](const StepRes& r) {
-    constexpr int NR = R / CH_NW;
+    constexpr int NR = R / NW;
     const float* a = buf_ptr(S, r.src); const int lda = buf_ld(r.src);
     const float* c = buf_ptr(S, r.src2); const int ldc = buf_ld(r.src2);
     const bool xp = (r.flags & F_LN_XP) != 0;          // `res` names an OUTPUT then: result + query_pos
@@ -1393,20 +1588,20 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
     float4 v[NR], pos4[NR];
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-      const int row = wave + CH_NW * i;
+      const int row = wave + NW * i;
       pos4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (xp) {                                        // in flight under the reductions
         int prow = min(m0 + row, M - 1);
         if (k.g_mod[G_POS] > 0) prow = prow % k.g_mod[G_POS];
         pos4[i] = ld4(k.g[G_POS] + (size_t)prow * k.g_ld[G_POS] + 4 * lane);
       }
-      v[i] = *reinterpret_cast<const float4*>(a + row * lda + 4 * lane);
+      v[i] = act_ld4<PL>(a + row * lda, 4 * lane);
     }
     if (c != nullptr) {
       const float4 g2 = ld4(r.p2 + 4 * lane), b2 = ld4(r.p3 + 4 * lane);
       float4 cv[NR];
 #pragma unroll
-      for (int i = 0; i < NR; ++i) cv[i] = *reinterpret_cast<const float4*>(c + (wave + CH_NW * i) * ldc + 4 * lane);
+      for (int i = 0; i < NR; ++i) cv[i] = act_ld4<PL>(c + (wave + NW * i) * ldc, 4 * lane);
       ln_rows<NR>(cv, g2, b2);
 #pragma unroll
       for (int i = 0; i < NR; ++i) v[i] = add4(v[i], relu4(cv[i]));
@@ -1414,14 +1609,14 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
     ln_rows<NR>(v, gg, bb);
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-      const int row = wave + CH_NW * i;
+      const int row = wave + NW * i;
       if (r.flags & F_LN_RELU) v[i] = relu4(v[i]);
       if constexpr (PROG == PROG_RADAR_ENC_TRAIN) {      // tape: pos = relu(LN(u2)) before the feature sum
         if (r.gt != nullptr && m0 + row < M) st4(r.gt + (size_t)(m0 + row) * 256 + 4 * lane, v[i]);
       }
-      if (dd != nullptr) v[i] = add4(v[i], *reinterpret_cast<const float4*>(dd + row * LD2 + 4 * lane));
-      *reinterpret_cast<float4*>(dst + row * LD2 + 4 * lane) = v[i];
-      if (xp) *reinterpret_cast<float4*>(dst2 + row * LD2 + 4 * lane) = add4(v[i], pos4[i]);
+      if (dd != nullptr) v[i] = add4(v[i], act_ld4<PL>(dd + row * LD2, 4 * lane));
+      act_st4<PL>(dst + row * LD2, 4 * lane, v[i]);
+      if (xp) act_st4<PL>(dst2 + row * LD2, 4 * lane, add4(v[i], pos4[i]));
       if (gdst != nullptr && m0 + row < M) st4(gdst + (size_t)(m0 + row) * 256 + 4 * lane, v[i]);
     }
   };
@@ -1442,6 +1637,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
     s.sub_on = 0;
     s.drop_site = 0; s.drop_seed = 0; s.drop_thr = 0; s.drop_scale = 1.0f; s.drop_stride = 0; s.drop_q = 0;
     s.rowg = nullptr; s.gpre = 0; s.cmask = nullptr; s.cscale = 1.0f;
+    s.dst_pl = 0; s.res_pl = 0;
     return s;
   };
   // ... and the part its epilogue needs, rebuilt per tile from the 64-byte LDS record
@@ -1468,6 +1664,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
     s.drop_site = 0; s.drop_seed = 0; s.drop_thr = 0; s.drop_scale = 1.0f; s.drop_stride = 0; s.drop_q = 0;
     s.rowg = (prog_is_radar(PROG) && k.row_perm != nullptr) ? &S.rowg[0] : nullptr;
     s.gpre = (e.flags & F_GPRE) ? 1 : 0;
+    s.dst_pl = PL && e.dst_ld != LDL; s.res_pl = PL && e.res_ld != LDL;      // (the logit buffer stays fp32)
     if (DROP) {
       if constexpr (PROG == PROG_RADAR_TRAIN) {      // radar dropout sites 4 r + {1, 2, 3} (HEAD:581-585)
         s.drop_site = e.drop_site; s.drop_seed = k.rdrop.seed; s.drop_thr = k.rdrop.thr; s.drop_scale = k.rdrop.scale;
@@ -1497,7 +1694,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
       const float* src = buf_ptr(S, dst_id);
       if (out != nullptr && src != nullptr && dst_id != B_L && (long long)(step + 1) * M * 256 <= g_chain_dump_floats) {
         const int ld = buf_ld(dst_id);
-        for (int row = wave; row < R; row += CH_NW)
+        for (int row = wave; row < R; row += NW)
           if (m0 + row < M)
             st4(out + ((size_t)step * M + S.rowg[row]) * 256 + 4 * lane, *reinterpret_cast<const float4*>(src + row * ld + 4 * lane));
       }
@@ -1533,7 +1730,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
           if (r.res != B_NONE && r.dst != B_NONE) {
             const float* rs = buf_ptr(S, r.res); const int rld = buf_ld(r.res);
             float* dd = buf_ptr(S, r.dst);
-            for (int row = wave; row < R; row += CH_NW)
+            for (int row = wave; row < R; row += NW)
               *reinterpret_cast<float4*>(dd + row * LD2 + 4 * lane) = *reinterpret_cast<const float4*>(rs + row * rld + 4 * lane);
           }
         } else if (kd == K_LINEAR) {
@@ -1542,7 +1739,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
           s.sub_on = (r.si == g_sub_step && r.rep == 0);
           SUB_STAMP(0);
 #endif
-          if (((wave - s.woff) & (CH_NW - 1)) < ((s.N + 63) >> 6)) {   // else: no column tile here, w0 keeps waiting
+          if (((wave - s.woff) & (NW - 1)) < (R == 32 ? (s.N + 31) >> 5 : (s.N + 63) >> 6)) {   // else: no column tile here, w0 keeps waiting
             const PreRec pr = load_uniform<PreRec>(S.recs[idx].p[wave]);
             const bool have = linear_step<R, DROP, PROG == PROG_PROLOGUE, MM>(s, w0, pre_idx == idx, pr.first, epi_spec, idx);
             pre_idx = have ? pr.nidx : -1;
@@ -1566,7 +1763,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
       case K_LOAD: { if constexpr (PROG == PROG_DECODER || PROG == PROG_PROLOGUE || PROG == PROG_RADAR_ENC_B) {
         // this and the directly following K_LOAD steps (the decoder starts with three) go
         // out together: one memory latency instead of three, one barrier
-        constexpr int MAXL = 3, RW = (R + CH_NW - 1) / CH_NW;
+        constexpr int MAXL = 3, RW = (R + NW - 1) / NW;
         int n = 1;
         while (n < MAXL && idx + n < total && ufirst(S.recs[idx + n].r.kind) == K_LOAD) ++n;
         float4 v[MAXL][RW];
@@ -1582,7 +1779,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
             any_sync |= rj.sync;
 #pragma unroll
             for (int ri = 0; ri < RW; ++ri) {
-              int grow = min(m0 + wave + ri * CH_NW, M - 1);
+              int grow = min(m0 + wave + ri * NW, M - 1);
               if (mod > 0) grow = grow % mod;
               v[j][ri] = ld4(gsrc + (size_t)grow * ld + 4 * lane);
             }
@@ -1593,8 +1790,8 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
           if (j < n) {
 #pragma unroll
             for (int ri = 0; ri < RW; ++ri) {
-              const int row = wave + ri * CH_NW;
-              if (row < R) *reinterpret_cast<float4*>(dsts[j] + row * LD2 + 4 * lane) = v[j][ri];
+              const int row = wave + ri * NW;
+              if (row < R) act_st4<PL>(dsts[j] + row * LD2, 4 * lane, v[j][ri]);
             }
           }
         }
@@ -1605,17 +1802,28 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
       }
       } break;
       case K_TOKENS: { if constexpr (prog_is_enc_full(PROG) || PROG == PROG_RADAR_ENC_A) {   // radar token tile, zero padded to 64 columns
-        for (int i = threadIdx.x; i < R * 64; i += CH_NT) {
+        if constexpr (PL) {           // four columns per thread (the tile is the A operand of feat.0: planes)
+          for (int i = threadIdx.x; i < R * 16; i += NT) {
+            const int row = i >> 4, c4 = 4 * (i & 15);
+            const int grow = min(m0 + row, M - 1);
+            const float* tk = k.tokens + (size_t)grow * k.RI;
+            act_st4<PL>(&S.unit[1][0][0] + row * LD5, c4,
+                        make_float4(c4 < k.RI ? tk[c4] : 0.0f, c4 + 1 < k.RI ? tk[c4 + 1] : 0.0f, c4 + 2 < k.RI ? tk[c4 + 2] : 0.0f,
+                                    c4 + 3 < k.RI ? tk[c4 + 3] : 0.0f));
+          }
+        } else {
+        for (int i = threadIdx.x; i < R * 64; i += NT) {
           const int row = i >> 6, c = i & 63;
           const int grow = min(m0 + row, M - 1);
           (&S.unit[1][0][0])[row * LD5 + c] = c < k.RI ? k.tokens[(size_t)grow * k.RI + c] : 0.0f;
+        }
         }
       } break;
       } break;
       case K_POSENC: { if constexpr (PROG == PROG_DECODER || prog_is_enc_full(PROG) || PROG == PROG_RADAR_ENC_A) {   // Linear(3,256) + LN + ReLU of inverse_sigmoid(ref) or of raw token xyz
         float* dst = buf_ptr(S, r.dst);
         const bool skip0 = (r.flags & F_NOT_W0) != 0;      // wave 0 is busy with the narrow linear step before
-        const int row_first = skip0 ? wave - 1 : wave, row_step = skip0 ? CH_NW - 1 : CH_NW;
+        const int row_first = skip0 ? wave - 1 : wave, row_step = skip0 ? NW - 1 : NW;
         // decoder: lane i fetches and inverts the reference point of row i -- one round trip and one
         // inverse_sigmoid per ROW of the tile (before: per row of the loop below, evaluated by all 64 lanes)
         float q0 = 0.f, q1 = 0.f, q2 = 0.f;
@@ -1628,20 +1836,24 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
         }
         for (int row = row_first; row < R && row >= 0; row += row_step) {
           float p0, p1, p2;
-          if (r.src == B_A) { const float* tk = &S.unit[1][0][0] + row * LD5; p0 = tk[0]; p1 = tk[1]; p2 = tk[2]; }
+          if (r.src == B_A) {
+            if constexpr (PL) {          // (the token tile holds planes: the raw xyz come from the tokens themselves)
+              const float* tk = k.tokens + (size_t)min(m0 + row, M - 1) * k.RI; p0 = tk[0]; p1 = tk[1]; p2 = tk[2];
+            } else { const float* tk = &S.unit[1][0][0] + row * LD5; p0 = tk[0]; p1 = tk[1]; p2 = tk[2]; }
+          }
           else { p0 = lane_f(q0, row); p1 = lane_f(q1, row); p2 = lane_f(q2, row); }
           if constexpr (PROG == PROG_RADAR_ENC_TRAIN) {
             // tape: the pre-LayerNorm values u0 (r.gt) and u1 = relu(LN(u0)) (r.gd)
             float4 pre;
             const float4 u1 = posenc_l0_row(p0, p1, p2, uptr(r.p0), uptr(r.p1), uptr(r.p2), uptr(r.p3), lane, &pre);
-            *reinterpret_cast<float4*>(dst + row * LD2 + 4 * lane) = u1;
+            act_st4<PL>(dst + row * LD2, 4 * lane, u1);
             if (m0 + row < M) {
               st4(r.gt + (size_t)(m0 + row) * 256 + 4 * lane, pre);
               st4(r.gd + (size_t)(m0 + row) * 256 + 4 * lane, u1);
             }
           } else {
-            *reinterpret_cast<float4*>(dst + row * LD2 + 4 * lane) =
-                posenc_l0_row(p0, p1, p2, uptr(r.p0), uptr(r.p1), uptr(r.p2), uptr(r.p3), lane);
+            act_st4<PL>(dst + row * LD2, 4 * lane,
+                        posenc_l0_row(p0, p1, p2, uptr(r.p0), uptr(r.p1), uptr(r.p2), uptr(r.p3), lane));
           }
         }
       } break;
@@ -1658,20 +1870,20 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
         unsigned long long vm;
         {
           const int i = lane >> 4, c = lane & 15;
-          const int prow = wave + CH_NW * min(i, R / CH_NW - 1);
+          const int prow = wave + NW * min(i, R / NW - 1);
           const int grow = min(m0 + prow, M - 1);
-          const bool act = i < R / CH_NW && c < k.cam.num_cams;
+          const bool act = i < R / NW && c < k.cam.num_cams;
           vm = __ballot(cam_project_lane(k.cam, k.ref_mod > 0 ? grow % k.ref_mod : grow, grow / k.Q,
                                          min(c, k.cam.num_cams - 1), act, pu, pv));
         }
 #pragma unroll 1
-        for (int i = 0; i < R / CH_NW; ++i) {
-          const int row = wave + CH_NW * i;
+        for (int i = 0; i < R / NW; ++i) {
+          const int row = wave + NW * i;
           const int grow = min(m0 + row, M - 1);
           const unsigned long long vmask = (vm >> (16 * i)) & 0xFFFFull;
           const float4 o = cam_sample_core<4>(k.cam, grow / k.Q, &S.l[row][0], lane, vmask, pu, pv,
                                               [](int, int, int, const float* ptr) { return ld4(ptr); }, 16 * i);
-          *reinterpret_cast<float4*>(buf_ptr(S, r.dst) + row * LD2 + 4 * lane) = o;
+          act_st4<PL>(buf_ptr(S, r.dst) + row * LD2, 4 * lane, o);
           if (m0 + row < M) pairs += __popcll(vmask);
         }
         CAM_STAMP(6);
@@ -1706,15 +1918,17 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
         // a fixed order.  W is read in the nn.Linear layout [N][256] (not packed): lane 16g + c's float4 at
         // W[c][16 kg + 4g ..] IS the B operand of the k group's four MFMAs.  Same code at every tile height
         // (rows >= R repeat row R - 1, never stored).
+        // 32-row tiles (8 waves): waves 0-3 the first 16 rows, waves 4-7 the second (rgw), the k groups over kq
         const int N = r.N;                                // <= 12 (launchers check code / num_classes)
         const int c = lane & 15, g = lane >> 4;
+        const int rgw = wave >> 2, kq = wave & 3;
         const float* Wn = uptr(r.p0) + (size_t)min(c, N - 1) * 256 + 4 * g;
-        const float* src = buf_ptr(S, r.src) + min(c, R - 1) * buf_ld(r.src) + 4 * g;
+        const float* src = buf_ptr(S, r.src) + min(16 * rgw + c, R - 1) * buf_ld(r.src);
         float4 av[4], bw[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          bw[q] = ld4(Wn + 16 * (4 * wave + q));
-          av[q] = *reinterpret_cast<const float4*>(src + 16 * (4 * wave + q));
+          bw[q] = ld4(Wn + 16 * (4 * kq + q));
+          av[q] = act_ld4<PL>(src, 4 * g + 16 * (4 * kq + q));
         }
         const float bias = r.p1 != nullptr ? ldg1(uptr(r.p1) + min(c, N - 1)) : 0.0f;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -1727,14 +1941,14 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
 #pragma unroll
         for (int i = 0; i < 4; ++i) part[(wave * 16 + 4 * g + i) * 16 + c] = acc[i];
         __syncthreads();
-        if (wave == 0 && c < N) {
+        if (kq == 0 && c < N) {
           float y[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const int row = 4 * g + i;
-            float v = part[row * 16 + c];
+            const int prow = 4 * g + i;                   // row of the group's partial tiles
+            float v = part[(wave * 16 + prow) * 16 + c];
 #pragma unroll
-            for (int w = 1; w < CH_NW; ++w) v += part[(w * 16 + row) * 16 + c];
+            for (int w = 1; w < 4; ++w) v += part[((wave + w) * 16 + prow) * 16 + c];
             y[i] = v + bias;
           }
           // (the LDS and the global stores in ONE predicated loop body trip a hipcc back-end error:
@@ -1744,12 +1958,12 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
             const int dld = buf_ld(r.dst);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-              if (4 * g + i < R) dd[(4 * g + i) * dld] = y[i];
+              if (16 * rgw + 4 * g + i < R) dd[(16 * rgw + 4 * g + i) * dld] = y[i];
           }
           if (r.gd != nullptr) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              const int row = 4 * g + i;
+              const int row = 16 * rgw + 4 * g + i;
               if (row < R && m0 + row < M) {
                 int grow = m0 + row;
                 if constexpr (prog_is_radar(PROG)) grow = S.rowg[row];
@@ -1785,7 +1999,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
         }
         __syncthreads();
 #pragma unroll 1
-        for (int row = wave; row < R; row += CH_NW) {
+        for (int row = wave; row < R; row += NW) {
           const int grow = S.rowg[row];
           const int b = grow / k.Q;
           int count = 0;
@@ -1816,10 +2030,10 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
       case K_RADAR_ATTN: { if constexpr (prog_is_radar(PROG)) {   // distance-gated attention (HEAD:549-579)
         if (PROG == PROG_RADAR && (r.flags & F_IFHIT) && !tile_has_hit()) break;      // its output only feeds the (skipped) out_proj
 #pragma unroll 1
-        for (int row = wave; row < R; row += CH_NW) {
+        for (int row = wave; row < R; row += NW) {
           const int grow = S.rowg[row];
           const int b = grow / k.Q;
-          float4 q4 = *reinterpret_cast<const float4*>(buf_ptr(S, r.src) + row * LD2 + 4 * lane);
+          float4 q4 = act_ld4<PL>(buf_ptr(S, r.src) + row * LD2, 4 * lane);
           const float* kv = (rep == 0 ? k.g[G_KV0] : rep == 1 ? k.g[G_KV1] : k.g[G_KV2]);
           int count = 0;
           const GateGeom gg(S.cen[row][0], S.cen[row][1], GateGeom::Pre{S.box[row][10], S.box[row][11], S.cen[row][3]});
@@ -1838,7 +2052,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
             o = radar_attn_row_g(gg, q4, k.tokens + (size_t)b * k.T * k.RI, k.RI, kv + (size_t)b * k.T * 512, 512,
                                  k.T, k.pad_mult, lane, count, DropK(), 0, hm);
           }
-          *reinterpret_cast<float4*>(buf_ptr(S, r.dst) + row * LD2 + 4 * lane) = o;
+          act_st4<PL>(buf_ptr(S, r.dst) + row * LD2, 4 * lane, o);
           if (lane == 0) S.gate[row] = count;        // the same count as K_RADAR_GATE's (same predicate)
         }
       } break;
@@ -1851,7 +2065,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
         float* dst = buf_ptr(S, r.dst);
         const float* src = uptr(r.p0);
         const bool carry = (r.flags & F_CARRY) != 0;
-        for (int i = threadIdx.x; i < R * 64; i += CH_NT) {
+        for (int i = threadIdx.x; i < R * 64; i += NT) {
           const int row = i >> 6, c = i & 63;
           const int grow = min(m0 + row, M - 1);
           float v = c < N ? ldg1(src + (size_t)grow * N + c) : 0.0f;
@@ -1886,7 +2100,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
         float* dst = buf_ptr(S, r.dst);
         const unsigned site = 4u * (unsigned)(k.nlayers - 1 - rep) + (unsigned)r.K;
         const bool gated = (r.flags & F_GATE) != 0;
-        for (int row = wave; row < R; row += CH_NW) {
+        for (int row = wave; row < R; row += NW) {
           const int grow = min(m0 + row, M - 1);
           float4 v = *reinterpret_cast<const float4*>(src + row * LD2 + 4 * lane);
           const unsigned idx = (unsigned)grow * 256u + 4u * (unsigned)lane;
@@ -1912,7 +2126,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
         const bool relu = (r.flags & F_LN_RELU) != 0;
         const float4 g = ld4(uptr(r.p0) + 4 * lane);
         float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int row = wave; row < R; row += CH_NW) {
+        for (int row = wave; row < R; row += NW) {
           const int grow = min(m0 + row, M - 1);
           const size_t o = (size_t)grow * 256 + 4 * lane;
           float4 z = ld4(uptr(r.p1) + o);
@@ -1945,7 +2159,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
           *reinterpret_cast<float4*>(dzb + row * LD2 + 4 * lane) = dz;
           if (r.gd != nullptr && m0 + row < M) st4(r.gd + o, dz);
         }
-        // the waves' partial sums: [CH_NW][256] floats fit one unit at every tile height (R >= 4)
+        // the waves' partial sums: [NW][256] floats fit one unit at every tile height (R >= 4)
 #pragma unroll 1
         for (int part = 0; part < 2; ++part) {
           __syncthreads();                       // (part 0: dy / the scratch unit's previous contents are done with)
@@ -1955,7 +2169,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
           if (gdst != nullptr) {
             float t = scratch[threadIdx.x];
 #pragma unroll
-            for (int w = 1; w < CH_NW; ++w) t += scratch[w * 256 + threadIdx.x];
+            for (int w = 1; w < NW; ++w) t += scratch[w * 256 + threadIdx.x];
             unsafeAtomicAdd(gdst + threadIdx.x, t);
           }
         }
@@ -1967,7 +2181,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
         float* dqb = buf_ptr(S, r.dst);
         DropK dk = k.rdrop;
         dk.site = 4u * (unsigned)layer;
-        for (int row = wave; row < R; row += CH_NW) {
+        for (int row = wave; row < R; row += NW) {
           const int grow = min(m0 + row, M - 1);
           const int b = grow / k.Q;
           float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -2012,7 +2226,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAll* __r
 }
 
 template <int R, int PROG, bool DROP = false, int MM = 0>
-__global__ __launch_bounds__(CH_NT, 2) void chain_kernel(ChainDev k, Recs<rec_cap(PROG)> recs) {
+__global__ __launch_bounds__(nw_of(R) * 64, 2) void chain_kernel(ChainDev k, Recs<rec_cap(PROG), nw_of(R)> recs) {
   chain_body<R, PROG, DROP, MM>(k, recs.s, blockIdx.x);
 }
 
@@ -2021,9 +2235,10 @@ __global__ __launch_bounds__(CH_NT, 2) void chain_kernel(ChainDev k, Recs<rec_ca
 // encoders this way: as a branch of the hipGraph on a side stream, the fork and the join
 // each left a ~10 us hole in the replayed frame (profiles: rocprofv3 kernel trace).
 template <int RA, int RB, int PROGB, int MM = 0>
-__global__ __launch_bounds__(CH_NT, 2) void chain_dual_kernel(ChainDev ka, ChainDev kb, int na,
-                                                           Recs<rec_cap(PROG_DECODER)> ra,
-                                                           Recs<rec_cap(PROGB)> rb) {
+__global__ __launch_bounds__(nw_of(RA) * 64, 2) void chain_dual_kernel(ChainDev ka, ChainDev kb, int na,
+                                                           Recs<rec_cap(PROG_DECODER), nw_of(RA)> ra,
+                                                           Recs<rec_cap(PROGB), nw_of(RB)> rb) {
+  static_assert(nw_of(RA) == nw_of(RB), "both programs of a launch run with the same workgroup size");
   if ((int)blockIdx.x < na) chain_body<RA, PROG_DECODER, false, MM>(ka, ra.s, blockIdx.x);
   else chain_body<RB, PROGB, false, MM>(kb, rb.s, (int)blockIdx.x - na);
 }
@@ -2048,12 +2263,13 @@ constexpr size_t chain_lds_bytes() { return sizeof(ChainLds<R, rec_cap(PROG)>); 
 inline int buf_ld_h(int id) { return id == B_A ? LD5 : id == B_L ? LDL : LD2; }
 
 template <int R, int PROG, int MM = 0>
-void resolve_program(ChainK& k, StepAll* out) {
+void resolve_program(ChainK& k, StepAllT<nw_of(R)>* out) {
+  constexpr int NW = nw_of(R);
   const StepDesc* table = prog_table(PROG);
   constexpr int nsteps = table_steps(PROG);
   const int nrep = (prog_is_radar(PROG) || PROG == PROG_RADAR_BWD) ? k.nlayers : 1;
   const int total = nsteps * nrep;
-  memset(out, 0, sizeof(StepAll) * rec_cap(PROG));
+  memset(out, 0, sizeof(StepAllT<NW>) * rec_cap(PROG));
   for (int idx = 0; idx < total; ++idx) {
     const int rep = idx / nsteps, si = idx - rep * nsteps;
     const int layer = PROG == PROG_RADAR_BWD ? k.nlayers - 1 - rep : rep;          // the backward walks the layers down
@@ -2113,7 +2329,7 @@ void resolve_program(ChainK& k, StepAll* out) {
       r.N = d.N == N_LOGITS ? k.nlogits : d.N == N_CODE ? k.code : d.N == N_CLS ? k.ncls : d.N;
       const int woff = (d.flags & F_WOFF) ? 512 : 0;
       r.p0 = pr.w + (size_t)woff * ((r.K + 63) & ~63);   // packed: a 64-row tile = 64 * kpad floats
-      if (R == 16) r.p0 += (MM == 1 ? 2 : 1) * k.w16_delta;   // the 16x16x4 copy / the two-plane f16 copy behind it (pack.hip); launch_r checks delta != 0
+      if (R >= 16) r.p0 += (MM == 1 ? 2 : 1) * k.w16_delta;   // the 16x16x4 copy / the two-plane f16 copy behind it (pack.hip); launch_r checks delta != 0
       r.p1 = pr.b ? pr.b + woff : nullptr;
       if (PROG == PROG_RADAR_BWD) r.p1 = nullptr;         // dx = dy W: no bias
       if (d.gsel == G_CLS) r.gd += (size_t)rep * k.M * k.ncls;
@@ -2155,17 +2371,26 @@ void resolve_program(ChainK& k, StepAll* out) {
   // per (step, wave): the next linear step inside the same run of light steps where the
   // wave owns a column tile, and that step's first weight item
   for (int idx = 0; idx < total; ++idx) {
-    for (int w = 0; w < CH_NW; ++w) {
+    for (int w = 0; w < NW; ++w) {
       PreRec& pr = out[idx].p[w];
       pr.first = nullptr; pr.nidx = -1;
       for (int j = idx + 1; j < total; ++j) {
         const StepRes& n = out[j].r;
         if (n.kind == K_LN || n.kind == K_NOP) continue;
         if (n.kind != K_LINEAR) break;
-        const int vw = (w - ((n.flags & F_WAVE1) ? 1 : 0)) & (CH_NW - 1);
-        if (vw >= ((n.N + 63) >> 6)) continue;
-        pr.nidx = j;
-        pr.first = n.p0 + (size_t)vw * 64 * ((n.K + 63) & ~63);
+        const int vw = (w - ((n.flags & F_WAVE1) ? 1 : 0)) & (NW - 1);
+        const size_t kpad = (size_t)((n.K + 63) & ~63);
+        if (R == 32) {
+          // 32-row tiles: a wave owns 32-COLUMN tiles (linear_step32h): tile vw = half (vw & 1) of the 64-column tile
+          // vw >> 1 of the packed planes -- fragments [kk][2 half .. 2 half + 1][p] of every 64-deep item
+          if (vw >= ((n.N + 31) >> 5)) continue;
+          pr.nidx = j;
+          pr.first = n.p0 + (size_t)(vw >> 1) * 64 * kpad + (size_t)(vw & 1) * 4 * 256;
+        } else {
+          if (vw >= ((n.N + 63) >> 6)) continue;
+          pr.nidx = j;
+          pr.first = n.p0 + (size_t)vw * 64 * kpad;
+        }
         break;
       }
     }
@@ -2187,14 +2412,14 @@ int launch_dual_r(const ChainK& ka_, const ChainK& kb_, hipStream_t s, const cha
     once.done(once_dev);
   }
   ChainK ka = ka_, kb = kb_;
-  TC_REQUIRE((RA != 16 || ka.w16_delta != 0) && (RB != 16 || kb.w16_delta != 0),
-             "%s: 16-row tiles need weights from a tc_head_pack_weights view (packed16_delta is 0)", what);
-  Recs<rec_cap(PROG_DECODER)> ra;
-  Recs<rec_cap(PROGB)> rb;
+  TC_REQUIRE((RA < 16 || ka.w16_delta != 0) && (RB < 16 || kb.w16_delta != 0),
+             "%s: 16- / 32-row tiles need weights from a tc_head_pack_weights view (packed16_delta is 0)", what);
+  Recs<rec_cap(PROG_DECODER), nw_of(RA)> ra;
+  Recs<rec_cap(PROGB), nw_of(RB)> rb;
   resolve_program<RA, PROG_DECODER, MM>(ka, ra.s);
   resolve_program<RB, PROGB, MM>(kb, rb.s);
   const int na = (ka.M + RA - 1) / RA, nb = (kb.M + RB - 1) / RB;
-  hipLaunchKernelGGL((chain_dual_kernel<RA, RB, PROGB, MM>), dim3(na + nb), dim3(CH_NT), lds, s,
+  hipLaunchKernelGGL((chain_dual_kernel<RA, RB, PROGB, MM>), dim3(na + nb), dim3(nw_of(RA) * 64), lds, s,
                      static_cast<const ChainDev&>(ka), static_cast<const ChainDev&>(kb), na, ra, rb);
   return check_launch(what);
 }
@@ -2210,12 +2435,12 @@ int launch_r(const ChainK& k_, hipStream_t s, const char* what) {
     once.done(once_dev);
   }
   ChainK k = k_;
-  TC_REQUIRE(R != 16 || k.w16_delta != 0,
-             "%s: 16-row tiles need weights from a tc_head_pack_weights view (packed16_delta is 0)", what);
-  Recs<rec_cap(PROG)> recs;
+  TC_REQUIRE(R < 16 || k.w16_delta != 0,
+             "%s: 16- / 32-row tiles need weights from a tc_head_pack_weights view (packed16_delta is 0)", what);
+  Recs<rec_cap(PROG), nw_of(R)> recs;
   resolve_program<R, PROG, MM>(k, recs.s);
   constexpr size_t lds = chain_lds_bytes<R, PROG>();
-  hipLaunchKernelGGL((chain_kernel<R, PROG, DROP, MM>), dim3((k.M + R - 1) / R), dim3(CH_NT), lds, s,
+  hipLaunchKernelGGL((chain_kernel<R, PROG, DROP, MM>), dim3((k.M + R - 1) / R), dim3(nw_of(R) * 64), lds, s,
                      static_cast<const ChainDev&>(k), recs);
   return check_launch(what);
 }
@@ -2235,7 +2460,14 @@ void init_k(ChainK& k) {
 // they lost to 8 rows everywhere).  4 frames per launch x 3 lanes: 4214 (8 rows) -> 4597 frames/s.
 // The height is a per-call argument (tc_head_options.chain_tile_rows / tile_rows of
 // tc_decoder_layer_tail_fwd): no process-global state.
-int tile_rows(const ChainK& k) { return k.tile_rows ? k.tile_rows : (k.M <= 1024 ? 4 : k.M <= 2048 ? 8 : 16); }
+// Round 5: 32 rows (one workgroup of 8 waves per CU, activations as planes) once the 16-row tiles would need two
+// workgroups per CU (more than 4096 rows: five frames or more) and the matrix path is not pinned to f32: the CU then pulls
+// a layer's weights through its L2 port once per 32 rows without relying on two workgroups sharing the L1 in lockstep
+// (nine frames: decoder chain 110 -> 102 us, radar chain 233 -> 214 us; profiles/r5_*).
+int tile_rows(const ChainK& k) {
+  if (k.tile_rows) return k.tile_rows;
+  return k.M <= 1024 ? 4 : k.M <= 2048 ? 8 : (k.M > 4096 && k.matrix_path != TC_MATRIX_F32) ? 32 : 16;
+}
 
 // The matrix path of the 16-row tiles (tc_head_options.matrix_path): automatic = the two-plane f16 form on the
 // matrix cores (measured: DESIGN.md section 5 "Round 4"); TC_MATRIX_F32 keeps the exact fp32 FMA chains of
@@ -2248,6 +2480,10 @@ int launch_rows(const ChainK& k, hipStream_t s, const char* what) {
   const int rows = tile_rows(k);
   if (rows == 4) return launch_r<4, PROG>(k, s, what);
   if (rows == 8) return launch_r<8, PROG>(k, s, what);
+  if (rows == 32) {
+    TC_REQUIRE(use_f16x2(k), "%s: 32-row tiles exist on the f16x2 matrix path only", what);
+    return launch_r<32, PROG, false, 1>(k, s, what);
+  }
   if (use_f16x2(k)) return launch_r<16, PROG, false, 1>(k, s, what);
   return launch_r<16, PROG>(k, s, what);
 }
@@ -2261,6 +2497,10 @@ int launch(const ChainK& k, hipStream_t s, const char* what) {
         TC_REQUIRE((unsigned long long)(k.drop.rows_per_sample ? k.drop.rows_per_sample : k.M) * 512ull < (1ull << 32),
                    "decoder_chain: dropout index space");
         const int rows = tile_rows(k);
+        if (rows == 32) {
+          TC_REQUIRE(use_f16x2(k), "%s: 32-row tiles exist on the f16x2 matrix path only", what);
+          return launch_r<32, PROG_DECODER, true, 1>(k, s, what);
+        }
         if (rows == 16 && use_f16x2(k)) return launch_r<16, PROG_DECODER, true, 1>(k, s, what);
         return rows == 4 ? launch_r<4, PROG_DECODER, true>(k, s, what) : launch_r<8, PROG_DECODER, true>(k, s, what);
       }
@@ -2289,7 +2529,7 @@ int launch(const ChainK& k, hipStream_t s, const char* what) {
 
 #ifdef TC_CHAIN_STAMPS
 extern "C" int tc_debug_chain_stamps(long long* host_out) {
-  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_chain_stamps), sizeof(long long) * CH_NW * 64);
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_chain_stamps), sizeof(long long) * CH_NW_MAX * 64);
 }
 extern "C" int tc_debug_wg_spans(long long* host_out) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wg_span), sizeof(long long) * 1024 * 2);
@@ -2299,7 +2539,7 @@ extern "C" int tc_debug_cam_stamps(long long* host_out) {
 }
 extern "C" int tc_debug_chain_sub(int step, long long* host_out) {
   if (host_out == nullptr) return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_sub_step), &step, sizeof(int));
-  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_chain_sub), sizeof(long long) * CH_NW * 64);
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_chain_sub), sizeof(long long) * CH_NW_MAX * 64);
 }
 #endif
 
@@ -2367,8 +2607,8 @@ static int make_decoder_k(const DecoderChainArgs& a, ChainK& k) {
   k.ref_in = a.ref_in; k.ref_mod = a.ref_mod; k.ref_out = a.ref_out; k.box_m = a.box_m;
   fill_camk(a.cam, k.cam);
   k.pair_counter = a.cam.pair_counter;
-  TC_REQUIRE(a.tile_rows == 0 || a.tile_rows == 4 || a.tile_rows == 8 || a.tile_rows == 16,
-             "decoder_chain: tile_rows=%d (0 = automatic, 4, 8 or 16)", a.tile_rows);
+  TC_REQUIRE(a.tile_rows == 0 || a.tile_rows == 4 || a.tile_rows == 8 || a.tile_rows == 16 || a.tile_rows == 32,
+             "decoder_chain: tile_rows=%d (0 = automatic, 4, 8, 16 or 32)", a.tile_rows);
   k.tile_rows = a.tile_rows;
   k.matrix_path = a.matrix_path;
   k.drop = a.drop;
@@ -2433,6 +2673,10 @@ int launch_decoder_chain_with_encoders(const DecoderChainArgs& d, const RadarEnc
   // and 225 + T/4 workgroups fit the chip at two per CU
   if (rows == 4) return TC_DUAL(4, 4, 0);
   if (rows == 8) return TC_DUAL(8, 8, 0);
+  if (rows == 32) {
+    TC_REQUIRE(use_f16x2(kd), "%s: 32-row tiles exist on the f16x2 matrix path only", what);
+    return TC_DUAL(32, 32, 1);
+  }
   if (use_f16x2(kd)) return TC_DUAL(16, 16, 1);
   return TC_DUAL(16, 16, 0);
 #undef TC_DUAL
@@ -2467,15 +2711,15 @@ int launch_radar_chain(const RadarChainArgs& a, hipStream_t s) {
   TC_REQUIRE(a.cen_from_box || a.ref_last != nullptr, "radar_chain: ref_last is null");
   for (int i = 0; i < 6; ++i) k.cam.pc[i] = a.pc[i];
   k.all_box = a.all_box; k.hits = a.hits;
-  TC_REQUIRE(a.tile_rows == 0 || a.tile_rows == 4 || a.tile_rows == 8 || a.tile_rows == 16,
-             "radar_chain: tile_rows=%d (0 = automatic, 4, 8 or 16)", a.tile_rows);
+  TC_REQUIRE(a.tile_rows == 0 || a.tile_rows == 4 || a.tile_rows == 8 || a.tile_rows == 16 || a.tile_rows == 32,
+             "radar_chain: tile_rows=%d (0 = automatic, 4, 8, 16 or 32)", a.tile_rows);
   k.tile_rows = a.tile_rows; k.last_cls_only = a.last_cls_only; k.matrix_path = a.matrix_path;
   if (a.tape != nullptr) {                    // forward of a training iteration: tape + dropout
     TC_REQUIRE(a.row_perm == nullptr && !a.last_cls_only, "radar_chain: the training forward takes the rows in their own order");
     k.program = PROG_RADAR_TRAIN;
     for (int i = 0; i < T_COUNT; ++i) k.tape[i] = a.tape[i];
     k.tape_stride = a.tape_stride; k.hits_stride = a.hits_stride; k.rdrop = a.drop;
-    if (k.tile_rows == 16 || (k.tile_rows == 0 && a.M > 2048)) k.tile_rows = 8;
+    if (k.tile_rows >= 16 || (k.tile_rows == 0 && a.M > 2048)) k.tile_rows = 8;
   }
   return launch(k, s, "chain(radar)");
 }

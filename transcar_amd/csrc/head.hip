@@ -230,8 +230,8 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
     // frames: too few workgroups for a form without split keys) and TC_MATRIX_F32 the fp32 core.  A
     // frame's arithmetic is therefore fixed by (chain_tile_rows, matrix_path), not by how many frames share a launch
     if (!l0c) {
-      const int trows = opt.chain_tile_rows ? opt.chain_tile_rows : (rows <= 1024 ? 4 : rows <= 2048 ? 8 : 16);
-      if (trows == 16 && opt.matrix_path != TC_MATRIX_F32)
+      const int trows = opt.chain_tile_rows ? opt.chain_tile_rows : (rows <= 1024 ? 4 : rows <= 2048 ? 8 : 16);   // (32 counts as 16 here)
+      if (trows >= 16 && opt.matrix_path != TC_MATRIX_F32)
         TC_TRY(launch_self_attn_core_x(h.qk, h.qk + C, 2 * C, h.vt, h.qpad, h.attn_o, C, B, Q, H, s, ddrop ? &d.drop : nullptr));
       else
         TC_TRY(launch_self_attn_core(h.qk, h.qk + C, 2 * C, h.vt, h.qpad, h.attn_o, C, B, Q, H, s, ddrop ? &d.drop : nullptr));
@@ -548,8 +548,10 @@ static int read_options(const tc_head_options* options, tc_head_options& opt) {
   TC_REQUIRE(opt.radar_row_order >= 0 && opt.radar_row_order <= 2, "options.radar_row_order=%d (0 automatic, 1 own order, 2 hits first)",
              opt.radar_row_order);
   TC_REQUIRE(opt.chain_tile_rows == 0 || opt.chain_tile_rows == 4 || opt.chain_tile_rows == 8 ||
-                 opt.chain_tile_rows == 16,
-             "options.chain_tile_rows=%d (0 = automatic, 4, 8 or 16)", opt.chain_tile_rows);
+                 opt.chain_tile_rows == 16 || opt.chain_tile_rows == 32,
+             "options.chain_tile_rows=%d (0 = automatic, 4, 8, 16 or 32)", opt.chain_tile_rows);
+  TC_REQUIRE(opt.chain_tile_rows != 32 || opt.matrix_path != TC_MATRIX_F32,
+             "options.chain_tile_rows=32 exists on the f16x2 matrix path only (matrix_path = f32 was asked for)");
   TC_REQUIRE(opt.decoder_dropout_p >= 0.0f && opt.decoder_dropout_p < 1.0f, "options.decoder_dropout_p=%g",
              (double)opt.decoder_dropout_p);
   TC_REQUIRE(opt.phase >= 0 && opt.phase <= 2, "options.phase=%d (0 whole forward, 1 before the radar tokens, 2 the rest)",

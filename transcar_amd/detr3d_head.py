@@ -39,8 +39,8 @@ def _env_tile_rows():
     """TRANSCAR_CHAIN_ROWS (host-side tuning knob, read once at import, validated)."""
     import os
     v = os.environ.get('TRANSCAR_CHAIN_ROWS', '0')
-    if v not in ('0', '4', '8', '16'):
-        raise ValueError('TRANSCAR_CHAIN_ROWS=%r (0 = automatic, 4, 8 or 16)' % v)
+    if v not in ('0', '4', '8', '16', '32'):
+        raise ValueError('TRANSCAR_CHAIN_ROWS=%r (0 = automatic, 4, 8, 16 or 32)' % v)
     return int(v)
 
 

@@ -108,9 +108,12 @@ class FramePipeline:
         self._next = 0
         self._capture()
 
-    @staticmethod
-    def _auto_tile_rows(rows):
-        """the library's automatic rule (chain.hip tile_rows()): 4 up to 1024 rows per launch, 8 up to 2048, 16 beyond"""
+    def _auto_tile_rows(self, rows):
+        """the library's automatic rule (chain.hip tile_rows()): 4 up to 1024 rows per launch, 8 up to 2048, 16 up to
+        4096, 32 beyond (16 when the matrix path is pinned to f32)"""
+        from . import _lib as L
+        if rows > 4096 and int(self.options.matrix_path) != L.TC_MATRIX_F32:
+            return 32
         return 4 if rows <= 1024 else 8 if rows <= 2048 else 16
 
     def tile_rows_of(self, n=None):
