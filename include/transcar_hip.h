@@ -34,7 +34,7 @@ extern "C" {
 #define TC_MAX_LEVELS 4
 #define TC_MAX_LAYERS 8
 #define TC_MAX_RADAR_LAYERS 3
-#define TC_ABI_VERSION 9
+#define TC_ABI_VERSION 10
 
 typedef void* tc_stream_t;
 
@@ -126,7 +126,9 @@ typedef struct {
 /* per-call options of tc_head_forward (NULL = all defaults = the reference's eval forward) */
 typedef struct {
   int chain_tile_rows;      /* rows of a workgroup's tile in the fused row chains: 0 = automatic
-                               (4 up to 1024 rows per launch, 8 up to 2048, 16 beyond), 4, 8 or 16 */
+                               (4 up to 1024 rows per launch, 8 up to 2048, 16 up to 4096, 32 beyond -- 16 when
+                               matrix_path is TC_MATRIX_F32), 4, 8, 16 or 32 (32: f16x2 matrix path only; one
+                               workgroup of 8 waves per CU, activations held in LDS as two f16 planes) */
   int unfused;              /* 1: operator-by-operator launch sequence (~160 launches), the
                                in-tree cross-check of the fused chains */
   int last_level_cls_only;  /* 1 (inference opt-in): final_cls / final_cls2 are not evaluated --
@@ -167,6 +169,12 @@ typedef struct {
                                dropout_seed + b * stride (element indices relative to the sample) -- a batch of
                                look-ahead frames through the frozen decoder is then bit-identical, frame by frame, to
                                the frames launched one at a time (FusionTrainer(prefetch_depth=...)) */
+  int* range_status;        /* ABI 10, device pointer or NULL: a sticky word the kernels of the f16x2 matrix path OR 1
+                               into when a linear step produces a non-finite value -- which is what an operand beyond
+                               the f16 planes' range (|activation| >= 65504 * 2^6 = 4.19e6, |weight| >= 65504) turns
+                               into: inf / NaN in the affected rows, never a wrong finite number.  The caller clears
+                               it; Detr3DHead reads it where it already reads results back (get_bboxes) and, on
+                               TC_MATRIX_AUTO, runs its next forwards on TC_MATRIX_F32 */
 } tc_head_options;
 #define TC_MATRIX_AUTO 0
 #define TC_MATRIX_F32 1

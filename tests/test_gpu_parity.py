@@ -1221,6 +1221,56 @@ def test_soak_of_the_timed_geometry_is_bit_identical_launch_to_launch(T, tile_ro
     assert time.time() - t0 < 60.0
 
 
+@pytest.mark.parametrize('case', ['weight', 'activation'])
+def test_f16_range_guard_flags_an_overflow_and_falls_back_to_f32(T, sd_np, case):
+    """an operand beyond the f16 planes' range on the DEFAULT (f16x2) path of a batched launch --
+    a weight of 1e5 (> 65504) or feature maps of ~1e9 (a sampled activation > 65504 * 2^6 = 4.19e6) -- turns into
+    inf / NaN in the outputs (never a wrong finite number), tc_head_options.range_status says so, get_bboxes reads the
+    word with its counts and the head runs its next automatic forwards on the exact-fp32 kernels, whose results are
+    finite and bit-identical to a head that was on the f32 path all along."""
+    import warnings
+    from transcar_amd.detr3d_head import head_options
+    sdm = {k: v.copy() for k, v in sd_np.items()}
+    scale = 1.0
+    if case == 'weight':
+        sdm['transformer.decoder.layers.3.ffns.0.layers.0.0.weight'][5, 7] = 1.0e5
+    else:
+        scale = 1.0e9
+
+    def make():
+        h = T.build_head(configs.head_cfg())
+        h.load_state_dict({k: torch.from_numpy(v) for k, v in sdm.items()}, strict=True)
+        return h.to(dev()).eval()
+    h = make()
+    feats = [gpu(np.concatenate([synth.make_feats('tiny', seed=s_, smooth=SMOOTH)[l] for s_ in (1, 11, 12)], 0) * scale)
+             for l in range(4)]
+    frames = [synth.make_radar_frame(seed=2 + i) for i in range(3)]
+    metas = synth.make_img_metas(3, synth.make_lidar2img(), radar=frames)
+    assert h.last_range_status == 0 and not h.matrix_fallback
+    outs = h(feats, metas)                                  # three frames: 16-row tiles on the f16 matrix cores
+    assert not torch.isfinite(outs['all_cls_scores']).all(), 'the overflow must be visible in the values too'
+    with pytest.warns(UserWarning, match='f16x2'):
+        h.get_bboxes(outs, metas)                           # ... and in the status word, read with the decode's counts
+    assert h.matrix_fallback and h.last_range_status == 0  # (cleared)
+    again = h(feats, metas)                                 # automatic -> f32 now
+    ref = make()
+    ref.forward_options = head_options(matrix_path='f32')
+    want = ref(feats, metas)
+    assert torch.isfinite(again['all_cls_scores']).all() and torch.isfinite(again['all_bbox_preds']).all()
+    assert torch.equal(again['all_cls_scores'], want['all_cls_scores']) and torch.equal(again['all_bbox_preds'], want['all_bbox_preds'])
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        h.get_bboxes(again, metas)                          # nothing to report
+    assert ref.last_range_status == 0                       # the f32 path never sets it
+    # an explicit f16x2 request is honoured (and flags again): only `auto` falls back
+    h.forward_options = head_options(matrix_path='f16x2', tile_rows=16)
+    h(feats, metas)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter('always')
+        assert h.last_range_status == 1
+    assert len(rec) == 0                                    # (the fallback was announced once)
+
+
 def test_plugin_entry_stages_lidar2img_per_call(T, head):
     """`Detr3DHead.forward` stages img_metas' projection matrices through a ring of eight pinned buffers and skips the
     copy when they are the ones staged last (ops._Lidar2ImgStaging): 20 calls that alternate fresh rigs, a repeated

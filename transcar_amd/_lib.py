@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get('TRANSCAR_HIP_LIB') or os.path.join(_HERE, 'lib', 'lib
 TC_MAX_LEVELS = 4
 TC_MAX_LAYERS = 8
 TC_MAX_RADAR_LAYERS = 3
-TC_ABI_VERSION = 9
+TC_ABI_VERSION = 10
 
 c_fp = C.c_void_p      # device pointers travel as integers
 
@@ -117,7 +117,7 @@ class tc_head_options(C.Structure):
                 ('last_level_cls_only', C.c_int), ('reuse_radar_kv', C.c_int),
                 ('decoder_dropout_p', C.c_float), ('radar_row_order', C.c_int),
                 ('dropout_seed', C.c_ulonglong), ('phase', C.c_int), ('matrix_path', C.c_int),
-                ('dropout_seed_stride', C.c_ulonglong)]
+                ('dropout_seed_stride', C.c_ulonglong), ('range_status', c_fp)]
 
 
 TC_MATRIX_AUTO, TC_MATRIX_F32, TC_MATRIX_F16X2 = 0, 1, 2

@@ -360,6 +360,7 @@ struct ChainDev {
   // backward (PROG_RADAR_BWD), by fusion layer
   const float* bwd_cxy[TC_MAX_RADAR_LAYERS]; int bwd_ldc[TC_MAX_RADAR_LAYERS];   // gate centre of the layer's forward
   const float* bwd_box[TC_MAX_RADAR_LAYERS];                                      // ... and its box (previous level)
+  int* range_status;           // f16x2 kernels (MM = 1): tc_head_options.range_status or null
   const float* loss_vals;      // [layers, 2] (cls, bbox) losses of the iteration or null: a layer whose loss is not
                                // finite sends no gradient down (HEAD:915-916 zeroes such a loss), non-finite elements are 0
   float* loss_out;             // or null: loss_vals with NaN -> 0 for the iteration's loss dict (workgroup 0 writes it)
@@ -418,6 +419,7 @@ struct LinSpec {
   int gpre;                    // F_GPRE
   const float* cmask; float cscale;   // F_CMASK: y = cmask[row, col] > 0 ? y * cscale : 0 (cmask is [M, N])
   int dst_pl, res_pl;          // 32-row kernels: the LDS destination / residual holds planes (act_ld4 / act_st4)
+  int* range_flag;             // f16x2 kernels: sticky device word, OR-ed with 1 when the step produces a non-finite value
 };
 
 // One work item = (64-column output tile, 64-deep k block): 16 x 16-byte weight
@@ -515,7 +517,7 @@ __device__ __forceinline__ void lin_epilogue(const LinSpec& s, int tile, const A
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) y[g][i] = fmaxf(y[g][i], 0.0f);
+      for (int i = 0; i < 4; ++i) y[g][i] = relu_(y[g][i]);
   } else if (s.act == 2) {
 #pragma unroll
     for (int g = 0; g < NG; ++g)
@@ -690,11 +692,21 @@ __device__ __forceinline__ void lin_epilogue16(const LinSpec& s, int colbase, co
 #pragma unroll
     for (int i = 0; i < 4; ++i) y[j][i] = ab[j][i] * sc;
   }
+  if (s.range_flag != nullptr) {
+    // the f16 planes overflow at |activation| >= 4.19e6 / |weight| >= 65504: the product then is inf or NaN, never a wrong
+    // finite number -- one sticky word says so (tc_head_options.range_status)
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bad |= !(fabsf(y[j][i]) <= 3.0e38f);
+    if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(s.range_flag, 1);
+  }
   if (s.act == 1) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) y[j][i] = fmaxf(y[j][i], 0.0f);
+      for (int i = 0; i < 4; ++i) y[j][i] = relu_(y[j][i]);
   } else if (s.act == 2) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
@@ -1637,7 +1649,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAllT<nw_
     s.sub_on = 0;
     s.drop_site = 0; s.drop_seed = 0; s.drop_thr = 0; s.drop_scale = 1.0f; s.drop_stride = 0; s.drop_q = 0;
     s.rowg = nullptr; s.gpre = 0; s.cmask = nullptr; s.cscale = 1.0f;
-    s.dst_pl = 0; s.res_pl = 0;
+    s.dst_pl = 0; s.res_pl = 0; s.range_flag = nullptr;
     return s;
   };
   // ... and the part its epilogue needs, rebuilt per tile from the 64-byte LDS record
@@ -1665,6 +1677,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAllT<nw_
     s.rowg = (prog_is_radar(PROG) && k.row_perm != nullptr) ? &S.rowg[0] : nullptr;
     s.gpre = (e.flags & F_GPRE) ? 1 : 0;
     s.dst_pl = PL && e.dst_ld != LDL; s.res_pl = PL && e.res_ld != LDL;      // (the logit buffer stays fp32)
+    s.range_flag = MM == 1 ? k.range_status : nullptr;
     if (DROP) {
       if constexpr (PROG == PROG_RADAR_TRAIN) {      // radar dropout sites 4 r + {1, 2, 3} (HEAD:581-585)
         s.drop_site = e.drop_site; s.drop_seed = k.rdrop.seed; s.drop_thr = k.rdrop.thr; s.drop_scale = k.rdrop.scale;
@@ -2612,6 +2625,7 @@ static int make_decoder_k(const DecoderChainArgs& a, ChainK& k) {
   k.tile_rows = a.tile_rows;
   k.matrix_path = a.matrix_path;
   k.drop = a.drop;
+  k.range_status = a.range_status;
   return 0;
 }
 
@@ -2633,7 +2647,7 @@ static int make_radar_enc_k(const RadarEncodeArgs& a, ChainK& k, int part = 0) {
     for (int i = 0; i < T_COUNT; ++i) k.tape[i] = a.tape[i];
   }
   k.M = a.M; k.Q = 1; k.RI = a.RI; k.tokens = a.tokens; k.has_next = 1;
-  k.w16_delta = a.w16_delta; k.matrix_path = a.matrix_path;
+  k.w16_delta = a.w16_delta; k.matrix_path = a.matrix_path; k.range_status = a.range_status;
   TC_REQUIRE(part == 0 || a.radar_feat != nullptr, "radar_encode: split programs need the radar_feat buffer");
   k.g[G_RFEAT] = a.radar_feat; k.g_ld[G_RFEAT] = 256;
   k.pairs[0] = a.rpe.l0; k.pairs[1] = tc_linear{a.rpe.n1.g, a.rpe.n1.b}; k.pairs[2] = a.rpe.l3;
@@ -2714,6 +2728,7 @@ int launch_radar_chain(const RadarChainArgs& a, hipStream_t s) {
   TC_REQUIRE(a.tile_rows == 0 || a.tile_rows == 4 || a.tile_rows == 8 || a.tile_rows == 16 || a.tile_rows == 32,
              "radar_chain: tile_rows=%d (0 = automatic, 4, 8, 16 or 32)", a.tile_rows);
   k.tile_rows = a.tile_rows; k.last_cls_only = a.last_cls_only; k.matrix_path = a.matrix_path;
+  k.range_status = a.range_status;
   if (a.tape != nullptr) {                    // forward of a training iteration: tape + dropout
     TC_REQUIRE(a.row_perm == nullptr && !a.last_cls_only, "radar_chain: the training forward takes the rows in their own order");
     k.program = PROG_RADAR_TRAIN;

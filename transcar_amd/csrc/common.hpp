@@ -79,6 +79,8 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// torch.relu keeps a NaN (fmaxf would return 0 -- and hide, behind every ReLU, what an overflow of the f16 planes did)
+__device__ __forceinline__ float relu_(float x) { return x < 0.0f ? 0.0f : x; }
 
 // XFMR:17-32
 __device__ __forceinline__ float inverse_sigmoidf_(float x) {

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(NW * 64) void gemm16_kernel(GemmK p) {
   for (int i = 0; i < 4; ++i) {
     const int row = m0 + 4 * g + i;
     float y = (s[i] + bv) * sc;
-    if (p.act == 1) y = fmaxf(y, 0.0f);
+    if (p.act == 1) y = relu_(y);
     else if (p.act == 2) y = sigmoidf_(y);
     if (row < p.M) {
       if (p.rowgate != nullptr && p.rowgate[row] == 0) y = 0.0f;

@@ -198,7 +198,7 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
       re.kv[r] = h.kv3[r];
     }
     re.radar_feat = h.radar_feat;
-    re.w16_delta = w->packed16_delta; re.matrix_path = opt.matrix_path;
+    re.w16_delta = w->packed16_delta; re.matrix_path = opt.matrix_path; re.range_status = opt.range_status;
   }
 
   // train-mode statistics of the frozen decoder: five dropout sites per layer (sites 16 + 8 l + 0..4)
@@ -253,6 +253,7 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
     d.cam.img_h = img_h; d.cam.img_w = img_w; d.cam.out = nullptr; d.cam.vis = nullptr;
     d.cam.pair_counter = pairs;
     d.code = code; d.M = rows; d.tile_rows = opt.chain_tile_rows; d.matrix_path = opt.matrix_path;
+    d.range_status = opt.range_status;
     // the radar encoders ride in two launches, half each (all in layer 0 when there is only one layer)
     if (radar && !ddrop && lid == enc_first) TC_TRY(launch_decoder_chain_with_encoders(d, re, L > 1 ? 1 : 0, s));
     else if (radar && !ddrop && L > 1 && lid == enc_first + 1) TC_TRY(launch_decoder_chain_with_encoders(d, re, 2, s));
@@ -281,6 +282,7 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
   for (int i = 0; i < 6; ++i) rc.pc[i] = w->pc_range[i];
   rc.all_cls = all_cls_scores; rc.all_box = all_bbox_preds; rc.hits = h.hits;
   rc.tile_rows = opt.chain_tile_rows; rc.last_cls_only = opt.last_level_cls_only; rc.matrix_path = opt.matrix_path;
+  rc.range_status = opt.range_status;
   if (opt.radar_row_order == 2 || (opt.radar_row_order == 0 && rows > 1024)) {
     // queries with a radar return inside their first gate go first: the other tiles skip the gated part
     TC_TRY(launch_radar_compact(rc.ref_last, rc.box_m, code, 0, w->pc_range, radar_tokens, w->radar_in_dims, B, Q, T,
@@ -607,6 +609,7 @@ int tc_radar_fusion_fwd(const tc_head_weights* packed_view, const float* hs_last
   rc.all_cls = all_cls_scores + (size_t)first_layer * rows * ncls;
   rc.all_box = all_bbox_preds + (size_t)first_layer * rows * code;
   rc.hits = h.hits; rc.tile_rows = opt.chain_tile_rows; rc.last_cls_only = opt.last_level_cls_only; rc.matrix_path = opt.matrix_path;
+  rc.range_status = opt.range_status;
   rc.cen_from_box = first_layer > 0;
   if (opt.radar_row_order == 2 || (opt.radar_row_order == 0 && rows > 1024)) {
     TC_TRY(launch_radar_compact(ref_last, prev_box, code, rc.cen_from_box, w->pc_range, radar_tokens, w->radar_in_dims,

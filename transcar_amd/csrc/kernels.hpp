@@ -102,6 +102,7 @@ struct DecoderChainArgs {
   // layer's attention probabilities (16 + 8 * layer); the chain's four sites are drop.site + 1
   // (self-attention output), + 2 (cross-attention output, XFMR:378), + 3 (FFN hidden), + 4 (FFN output)
   DropK drop = DropK{0, 0, 1.0f, 0, 0, 0, 0, 0};
+  int* range_status = nullptr;               // f16x2 kernels: sticky non-finite flag (tc_head_options.range_status)
 };
 int launch_decoder_chain(const DecoderChainArgs& a, hipStream_t s);
 
@@ -113,6 +114,7 @@ struct RadarEncodeArgs {
   size_t w16_delta = 0;
   float* const* tape = nullptr;              // training forward: tape tensors by TapeSlot (chain.hip TSel order)
   int matrix_path = 0;                       // as DecoderChainArgs (the stand-alone encoder program runs 16-row tiles)
+  int* range_status = nullptr;               // f16x2 kernels: sticky non-finite flag (tc_head_options.range_status)
 };
 int launch_radar_encode(const RadarEncodeArgs& a, hipStream_t s);
 // a decoder layer and the radar encoders as ONE launch (no side stream / graph branch)
@@ -136,6 +138,7 @@ struct RadarChainArgs {
   // layer r at + r * tape_stride floats; hit counts of layer r at hits + r * hits_stride; dropout seed / p
   float* const* tape = nullptr; size_t tape_stride = 0, hits_stride = 0;
   DropK drop = DropK{0, 0, 1.0f, 0, 1500, 0, 0, 0};
+  int* range_status = nullptr;               // f16x2 kernels: sticky non-finite flag (tc_head_options.range_status)
 };
 // Backward of the three fusion layers for the query rows as ONE launch of the row chain (chain.hip
 // PROG_RADAR_BWD): data gradients row-local, every dY a weight gradient needs stored (DySlot order), LayerNorm

@@ -8,7 +8,7 @@
 namespace tc {
 
 __device__ __forceinline__ float4 relu4(float4 v) {
-  return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+  return make_float4(relu_(v.x), relu_(v.y), relu_(v.z), relu_(v.w));
 }
 __device__ __forceinline__ float4 add4(float4 a, float4 b) {
   return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);

@@ -189,6 +189,12 @@ class Detr3DHead(BaseModule):
         self.radar_ingest = 'device'
         #: tc_head_options of ``forward`` (``head_options(...)``; None = defaults: automatic tile height and matrix path)
         self.forward_options = None
+        #: f16-range guard (tc_head_options.range_status): word 0 of ``_status_buf`` is OR-ed with 1 by the f16x2 kernels
+        #: when a linear step produces a non-finite value (an operand beyond the f16 planes' range turns into inf / NaN,
+        #: never into a wrong finite number); get_bboxes reads it with the decode's counts and, on the automatic matrix
+        #: path, switches this head to the exact-fp32 kernels (``matrix_fallback``) from the next forward on
+        self._status_buf = None
+        self.matrix_fallback = False
         self._radar_stage = {}
         self._ingest_streams = {}       # device -> side stream of the two-phase forward (forward_nhwc(fill_tokens=))
         #: bumped whenever a device buffer a captured hipGraph may point at (packed weights,
@@ -456,6 +462,16 @@ class Detr3DHead(BaseModule):
                                                device=dev)
         if options is None:
             options = head_options()
+        if not options.range_status or (self.matrix_fallback and options.matrix_path == L.TC_MATRIX_AUTO):
+            own = L.tc_head_options()                  # (the caller's struct stays as it is)
+            C.memmove(C.byref(own), C.byref(options), C.sizeof(own))
+            if not own.range_status:
+                own.range_status = self.status_buffer(dev).data_ptr()
+            if self.matrix_fallback and own.matrix_path == L.TC_MATRIX_AUTO:
+                own.matrix_path = L.TC_MATRIX_F32
+                if own.chain_tile_rows == 32:
+                    own.chain_tile_rows = 16
+            options = own
         ws = self._workspace[key]
         Q, ncls, code = self.num_query, self.cls_out_channels, self.code_size
         out = torch.empty(3 * B * Q * (ncls + code), dtype=torch.float32, device=dev)     # one allocation, two views
@@ -757,9 +773,40 @@ class Detr3DHead(BaseModule):
         return [(n, p) for n, p in self.named_parameters()
                 if p.requires_grad and not n.startswith(unused)]
 
+    def status_buffer(self, device):
+        """int32 [1 + 255] on the device: word 0 the f16-range status, the rest scratch for the decode's counts."""
+        if self._status_buf is None or self._status_buf.device != torch.device(device):
+            self._status_buf = torch.zeros(256, dtype=torch.int32, device=device)
+        return self._status_buf
+
+    @property
+    def last_range_status(self):
+        """0: every forward since the last read stayed inside the f16 planes' range (or ran on the f32 path); 1: a linear
+        step of the f16x2 path produced inf / NaN.  Reading it synchronises and clears the word."""
+        if self._status_buf is None:
+            return 0
+        v = int(self._status_buf[0])
+        if v:
+            self._range_overflow()
+        return v
+
+    def _range_overflow(self):
+        import warnings
+        self._status_buf[:1].zero_()
+        if not self.matrix_fallback:
+            self.matrix_fallback = True
+            warnings.warn('transcar_amd: a linear step of the f16x2 matrix path produced a non-finite value (an activation '
+                          'beyond 4.19e6 or a weight beyond 65504 in magnitude, or non-finite inputs); the affected rows '
+                          'are inf / NaN.  Forwards with matrix_path = auto run on the exact-fp32 kernels from now on '
+                          '(head.matrix_fallback = False to go back).')
+
     def get_bboxes(self, preds_dicts, img_metas, rescale=False):
         """HEAD:1003-1023."""
-        preds = self.bbox_coder.decode(preds_dicts, z_shift=True)
+        sb = self._status_buf if (self._status_buf is not None and
+                                  self._status_buf.device == preds_dicts['all_cls_scores'].device) else None
+        preds = self.bbox_coder.decode(preds_dicts, z_shift=True, status_buf=sb)
+        if getattr(self.bbox_coder, 'last_status', None):
+            self._range_overflow()
         ret_list = []
         for i, p in enumerate(preds):
             bboxes = p['bboxes']

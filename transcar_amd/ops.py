@@ -485,7 +485,8 @@ def box_decode_topk(cls_scores, bbox_preds, post_center_range, max_num=300):
     return boxes, scores, labels, valid
 
 
-def box_decode_kept(cls_scores, bbox_preds, post_center_range, max_num=300, score_threshold=None, z_shift=True):
+def box_decode_kept(cls_scores, bbox_preds, post_center_range, max_num=300, score_threshold=None, z_shift=True,
+                    count_out=None):
     """NMSFreeCoder.decode_single for a batch (tc_box_decode_kept): the kept rows (inside post_center_range, above
     the score threshold) compacted in score order -> boxes [B,max_num,9], scores [B,max_num], labels [B,max_num]
     (int64) and count [B] (int32, device); rows beyond count[b] are not written."""
@@ -495,7 +496,9 @@ def box_decode_kept(cls_scores, bbox_preds, post_center_range, max_num=300, scor
     boxes = torch.empty((B, max_num, 9), dtype=torch.float32, device=dev)
     scores = torch.empty((B, max_num), dtype=torch.float32, device=dev)
     labels = torch.empty((B, max_num), dtype=torch.int64, device=dev)
-    count = torch.empty((B,), dtype=torch.int32, device=dev)
+    # count_out: an int32 device tensor of B elements to write the counts to (Detr3DHead.get_bboxes: the words behind
+    # the head's range status, so that ONE small D2H reads both)
+    count = count_out if count_out is not None else torch.empty((B,), dtype=torch.int32, device=dev)
     use_thr = bool(score_threshold)                   # CODER:73: `if self.score_threshold:` -- None and 0 are off
     L.check(L.lib().tc_box_decode_kept(
         _p(cls_scores), _p(bbox_preds), B, Q, ncls, bbox_preds.shape[-1], max_num, L.f6(post_center_range),
