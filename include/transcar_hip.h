@@ -649,6 +649,13 @@ int tc_detr_loss_fwd_bwd(const float* all_cls, const float* all_box, int num_out
  * lowest unassigned query, scipy the one met last in its work list (same total cost). */
 int tc_lsa_assign(const float* cost, const int* gt_counts, int num_outputs, int B, int Q, int Gmax, int* assigned,
                   float* num_pos, int* status, tc_stream_t stream);
+/* ABI 10: ... and poison_losses [num_outputs, 2] (the zeroed loss accumulators tc_detr_loss_fwd_bwd* adds to) or NULL:
+ * NaN goes into the pair of an output one of whose samples could not be assigned, so that the non-finite-loss guard of
+ * the backward zeroes that output's gradients instead of training every query of the sample towards "background".
+ * The reference stops there (scipy raises ValueError, ASSIGN:117-125); FusionTrainer raises too, one iteration late
+ * (the status word travels back without a synchronisation). */
+int tc_lsa_assign_ex(const float* cost, const int* gt_counts, int num_outputs, int B, int Q, int Gmax, int* assigned,
+                     float* num_pos, int* status, float* poison_losses, tc_stream_t stream);
 /* tc_detr_loss_fwd_bwd with avg_factors = raw counts: the normalisers are max(count, 1) */
 int tc_detr_loss_fwd_bwd_counts(const float* all_cls, const float* all_box, int num_outputs, int B, int Q,
                                 int num_classes, int code_size, const float* gt_norm, const int* gt_labels,

@@ -221,6 +221,7 @@ SIGNATURES = {
     'tc_detr_loss_fwd_bwd_counts': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp,
                                          _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp]),
     'tc_lsa_assign': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'tc_lsa_assign_ex': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'tc_sq_norm': (_i, [_vp, _sz, _vp, _vp]),
     'tc_adamw_step': (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _f,
                            _f, _vp, _vp]),

@@ -190,6 +190,8 @@ struct LsaK {
   int* assigned;                                   // [P, Q]: gt index or -1
   float* num_pos;                                  // [outputs, 2] += matched boxes, both columns (zero first) or null
   int* status;                                     // += 1 per sample with a non-finite cost, or null
+  float* poison;                                   // [outputs, 2] loss accumulators or null: NaN into the output's pair
+                                                   // when a sample of it cannot be assigned (scipy would have raised)
 };
 
 __device__ __forceinline__ double wave_min_f64(double v) {
@@ -260,6 +262,7 @@ __global__ __launch_bounds__(LSA_NT) void lsa_kernel(LsaK p) {
   __syncthreads();
   if (bad_s) {                                      // scipy: "matrix contains invalid numeric entries"
     if (tid == 0 && p.status != nullptr) atomicAdd(p.status, 1);
+    if (tid < 2 && p.poison != nullptr) p.poison[2 * (prob / p.B) + tid] = __int_as_float(0x7fc00000);
     return;
   }
   double v[LSA_COLS];
@@ -308,6 +311,7 @@ __global__ __launch_bounds__(LSA_NT) void lsa_kernel(LsaK p) {
       }
       if (!(lowest < INF)) {                        // infeasible (cannot happen with finite costs); uniform
         if (tid == 0 && p.status != nullptr) atomicAdd(p.status, 1);
+        if (tid < 2 && p.poison != nullptr) p.poison[2 * (prob / p.B) + tid] = __int_as_float(0x7fc00000);
         return;
       }
       minVal = lowest;
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(LSA_NT) void lsa_kernel(LsaK p) {
 }
 
 int launch_lsa(const float* cost, const int* gt_counts, int P, int B, int Q, int Gmax, int* assigned, float* num_pos,
-               int* status, hipStream_t s) {
+               int* status, float* poison, hipStream_t s) {
   TC_REQUIRE(P >= 1 && B >= 1 && P % B == 0, "lsa: P=%d B=%d", P, B);
   TC_REQUIRE(Q >= 1 && Q <= LSA_QMAX && Gmax >= 1 && Gmax <= LSA_GMAX && Gmax <= Q,
              "lsa: Q=%d (<= %d) Gmax=%d (<= %d, <= Q)", Q, LSA_QMAX, Gmax, LSA_GMAX);
@@ -367,7 +371,7 @@ int launch_lsa(const float* cost, const int* gt_counts, int P, int B, int Q, int
   }
   LsaK p;
   p.cost = cost; p.gt_counts = gt_counts; p.P = P; p.B = B; p.Q = Q; p.Gmax = Gmax; p.assigned = assigned;
-  p.num_pos = num_pos; p.status = status;
+  p.num_pos = num_pos; p.status = status; p.poison = poison;
   if (in_lds) hipLaunchKernelGGL(lsa_kernel<true>, dim3(P), dim3(LSA_NT), lds, s, p);
   else hipLaunchKernelGGL(lsa_kernel<false>, dim3(P), dim3(LSA_NT), 0, s, p);
   return check_launch("lsa");
@@ -433,7 +437,13 @@ int tc_detr_loss_fwd_bwd_counts(const float* all_cls, const float* all_box, int 
 int tc_lsa_assign(const float* cost, const int* gt_counts, int num_outputs, int B, int Q, int Gmax, int* assigned,
                   float* num_pos, int* status, tc_stream_t stream) {
   TC_REQUIRE(cost != nullptr && gt_counts != nullptr && assigned != nullptr, "lsa_assign: null argument");
-  return launch_lsa(cost, gt_counts, num_outputs * B, B, Q, Gmax, assigned, num_pos, status, as_stream(stream));
+  return launch_lsa(cost, gt_counts, num_outputs * B, B, Q, Gmax, assigned, num_pos, status, nullptr, as_stream(stream));
+}
+
+int tc_lsa_assign_ex(const float* cost, const int* gt_counts, int num_outputs, int B, int Q, int Gmax, int* assigned,
+                     float* num_pos, int* status, float* poison_losses, tc_stream_t stream) {
+  TC_REQUIRE(cost != nullptr && gt_counts != nullptr && assigned != nullptr, "lsa_assign: null argument");
+  return launch_lsa(cost, gt_counts, num_outputs * B, B, Q, Gmax, assigned, num_pos, status, poison_losses, as_stream(stream));
 }
 
 }  // extern "C"

@@ -148,9 +148,13 @@ def _loss_with_device_assignment(head, lib, all_cls, all_box, cost, cache, defer
     z = torch.zeros(4 * Lyr + 1, dtype=torch.float32, device=dev)
     num_pos, losses, status = z[:2 * Lyr].view(Lyr, 2), z[2 * Lyr:4 * Lyr].view(Lyr, 2), z[4 * Lyr:].view(torch.int32)
     asg = torch.empty((Lyr, B, Q), dtype=torch.int32, device=dev)
-    L.check(lib.tc_lsa_assign(cost.data_ptr(), cnt.data_ptr(), Lyr, B, Q, Gmax, asg.data_ptr(), num_pos.data_ptr(),
-                              status.data_ptr(), _stream()), 'tc_lsa_assign')
-    head.last_assign_status = status              # > 0: a sample had a non-finite cost (scipy would have raised)
+    L.check(lib.tc_lsa_assign_ex(cost.data_ptr(), cnt.data_ptr(), Lyr, B, Q, Gmax, asg.data_ptr(), num_pos.data_ptr(),
+                                 status.data_ptr(), losses.data_ptr(), _stream()), 'tc_lsa_assign_ex')
+    # > 0: a sample had a non-finite cost.  scipy raises there (ASSIGN:117-125) and the reference stops; here the
+    # output's losses are poisoned (NaN: the backward's guard then sends no gradient down) and the word travels to
+    # the host without a synchronisation -- FusionTrainer raises at its next step (check_assign_status)
+    head.last_assign_status = status
+    post_assign_status(head, status)
     avg = num_pos
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         # normalisers, HEAD:885-902: mean over ranks of the number of positives, at least 1 -- on the device tensor
@@ -176,6 +180,36 @@ def _loss_with_device_assignment(head, lib, all_cls, all_box, cost, cache, defer
     d_box = torch.where(fin[:, 1].view(Lyr, 1, 1, 1), torch.nan_to_num(d_box, nan=0.0, posinf=0.0, neginf=0.0),
                         torch.zeros_like(d_box))
     return loss_dict(losses.masked_fill(torch.isnan(losses), 0.0)), d_cls, d_box, asg
+
+
+def post_assign_status(head, status):
+    """Asynchronous D2H of the assignment's status word into pinned memory + an event: read by check_assign_status."""
+    ring = getattr(head, '_assign_pending', None)
+    if ring is None:
+        ring = head._assign_pending = []
+    host = torch.empty(1, dtype=torch.int32).pin_memory()
+    host.copy_(status, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    ring.append((host, ev))
+
+
+def check_assign_status(head, wait=False):
+    """Raises ValueError (as scipy.optimize.linear_sum_assignment does inside the reference's assigner, ASSIGN:117-125)
+    when an iteration whose status word has arrived -- every pending one with wait=True -- met a cost matrix with
+    non-finite entries.  No synchronisation unless wait."""
+    ring = getattr(head, '_assign_pending', None)
+    while ring:
+        host, ev = ring[0]
+        if wait:
+            ev.synchronize()
+        elif not ev.query():
+            return
+        ring.pop(0)
+        if int(host[0]) != 0:
+            ring.clear()
+            raise ValueError('matrix contains invalid numeric entries (cost matrix of the Hungarian assignment; '
+                             '%d sample(s): their outputs sent no gradient)' % int(host[0]))
 
 
 def loss_dict(losses):

@@ -284,6 +284,9 @@ class FusionTrainer:
         head, lib = self.head, L.lib()
         if not head.training:                      # (Module.train() walks ~380 submodules: 0.7 ms of host time per call)
             head.train()
+        if self.device_loss:
+            from .device_loss import check_assign_status
+            check_assign_status(head)              # a non-finite cost matrix of an earlier iteration: ValueError, as scipy
         got = self._take_prefetched(feats_nhwc, lidar2img, tokens, pad_mult)
         if got is not None:
             aux, drop_seed = got
