@@ -1235,7 +1235,21 @@ def train_bench(args, head, inp, dev, rank, world, affinity=None):
     census = rank_census(dev, world)
     med, win = timed_windows(step, torch.cuda.synchronize, args, dev, world)
     own = D.gather_floats(win['own_window_ms_median'], dev if world > 1 else None)
+    # what the gradient exchange costs the compute stream: between the end of the backward and the optimizer's first
+    # kernel (events of 20 extra iterations, outside the timed windows).  One rank: no collective, the figure is the
+    # events' own distance; more ranks: the all-reduce's exposed part (it starts asynchronously behind the backward and
+    # runs beside the look-ahead decoder; FusionTrainer.step_fused_nhwc)
+    exposed = None
+    if not args.train_autograd:
+        tr.exchange_events = []
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+        gaps = sorted(a.elapsed_time(b) for a, b in tr.exchange_events)
+        tr.exchange_events = None
+        exposed = {'median': gaps[len(gaps) // 2], 'max': gaps[-1], 'iterations': len(gaps)}
     line = {
+        'exposed_collective_ms': exposed,
         'per_rank': per_rank_summary(own, args.steps, B), 'cpu_affinity': affinity,
         'metric': 'training frames/sec: fusion head iteration (frozen DETR3D decoder fwd + radar '
                   'stack fwd/bwd + loss + grad all-reduce + AdamW), FPN features resident in HBM',

@@ -42,14 +42,22 @@ def main():
     gts, lbs = [gt.to(dev)], [torch.from_numpy(labels).to(dev)]
     tr = FusionTrainer(head, dropout=0.1, seed=5, lr=1e-3)
     losses = []
+    calls = []                                           # every collective of the iterations: (elements, async?)
+    real_all_reduce = dist.all_reduce
+
+    def counting_all_reduce(t, *a, **kw):
+        calls.append((int(t.numel()), bool(kw.get('async_op', False))))
+        return real_all_reduce(t, *a, **kw)
+    dist.all_reduce = counting_all_reduce
     for it in range(3):
         cur, nxt = frames[it % 2], frames[(it + 1) % 2]
         out = tr.step_fused_nhwc(cur['feats_nhwc'], cur['lidar2img'], cur['img_hw'], cur['tokens'], cur['pad_mult'],
                                  gts, lbs, prefetch=nxt)
         losses.append(float(sum(out.values())))
     torch.cuda.synchronize()
+    dist.all_reduce = real_all_reduce
     p = tr.bucket.params.double()
-    mine = dict(rank=rank, sum=float(p.sum()), abs=float(p.abs().sum()), first=p[:8].tolist(), losses=losses,
+    mine = dict(rank=rank, sum=float(p.sum()), abs=float(p.abs().sum()), first=p[:8].tolist(), losses=losses, calls=calls,
                 finite=bool(torch.isfinite(p).all()), seed=int(tr.last_dropout_seed))
     parts = [None] * world
     dist.all_gather_object(parts, mine)

@@ -47,6 +47,12 @@ def test_two_ranks_on_one_gpu_end_with_the_same_parameters():
     assert a['sum'] == b['sum'] and a['abs'] == b['abs'] and a['first'] == b['first']
     # different frames and different dropout streams (the rank is part of the seed): different local losses
     assert a['losses'] != b['losses'] and a['seed'] != b['seed']
+    # exactly TWO collectives per iteration (DESIGN section 7 = north_star): the loss normalisers (a few floats,
+    # HEAD:885-902) and the flat gradient bucket, started asynchronously behind the backward
+    for part in (a, b):
+        assert len(part['calls']) == 2 * 3, part['calls']
+        for small, big in zip(part['calls'][0::2], part['calls'][1::2]):
+            assert small[0] <= 8 and big[0] > 2_000_000 and big[1] is True, (small, big)
 
 
 def test_training_bench_with_two_ranks_finishes_and_reports_its_roofline():
@@ -70,4 +76,5 @@ def test_training_bench_with_two_ranks_finishes_and_reports_its_roofline():
     assert len(lines) == 1, out[-1000:]
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['rccl_ranks'] == 2
+    assert d['exposed_collective_ms']['iterations'] == 20 and 0.0 <= d['exposed_collective_ms']['median'] < 50.0
     assert d['roofline'] and d['roofline']['parts'] and len(d['per_rank']['frames_per_s']) == 2

@@ -187,9 +187,16 @@ def post_assign_status(head, status):
     ring = getattr(head, '_assign_pending', None)
     if ring is None:
         ring = head._assign_pending = []
-    host = torch.empty(1, dtype=torch.int32).pin_memory()
+        head._assign_slots = torch.zeros(64, dtype=torch.int32).pin_memory()      # one pinned allocation, 64 words in turn
+        head._assign_events = [torch.cuda.Event() for _ in range(64)]
+        head._assign_next = 0
+    if len(ring) >= 64:                               # nobody looked for 64 iterations: look now
+        check_assign_status(head, wait=True)
+    i = head._assign_next
+    head._assign_next = (i + 1) % 64
+    host = head._assign_slots[i:i + 1]
     host.copy_(status, non_blocking=True)
-    ev = torch.cuda.Event()
+    ev = head._assign_events[i]
     ev.record()
     ring.append((host, ev))
 

@@ -61,10 +61,23 @@ class FlatBucket:
 
     def all_reduce(self):
         """SUM over ranks, one collective for the whole bucket."""
+        return self.all_reduce_end(self.all_reduce_begin())
+
+    def all_reduce_begin(self):
+        """Start the bucket's ONE all-reduce (SUM) without waiting for it: ordered behind everything already enqueued on
+        the current stream (the backward's weight-gradient kernel), it runs on the backend's communication stream
+        (RCCL) beside whatever other streams have in flight -- the look-ahead of the frozen decoder.  -> handle."""
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM)
-            return dist.get_world_size()
-        return 1
+            return dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, async_op=True), dist.get_world_size()
+        return None, 1
+
+    @staticmethod
+    def all_reduce_end(pending):
+        """The current stream (not the host, on RCCL) waits for the exchange; -> world size."""
+        work, world = pending
+        if work is not None:
+            work.wait()
+        return world
 
 
 def cosine_lr(base_lr, cur_iter, cur_epoch, max_epochs, warmup_iters=4000, warmup_ratio=1.0 / 3,
@@ -392,7 +405,15 @@ class FusionTrainer:
             self._last = dict(w=w, g=g, hs_last=hs_last, last_box=last_box, tokens=tokens, B=B, T=T, pad_mult=int(pad_mult),
                               all_box=all_box, d_cls=d_cls, d_box=d_box, tape=tape, seed=drop_seed)
         if update:
-            self._optimizer_step(lr)
+            # the gradient exchange starts the moment the backward is enqueued; the optimizer waits on its handle
+            # (tools/train.py:253-260: DDP's buckets overlap the same way).  `exchange_events` (bench.py --train):
+            # how long the compute stream stood still between the backward's end and the optimizer's first kernel
+            pending = self.bucket.all_reduce_begin()
+            ev = None
+            if getattr(self, 'exchange_events', None) is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            self._optimizer_step(lr, pending=pending, mark=ev)
         return {k: v.detach() for k, v in losses.items()}
 
     def _backward_workspace(self, lib, w, key, B, T, device):
@@ -404,8 +425,11 @@ class FusionTrainer:
             self._bws_key = key
         return self._bws
 
-    def _optimizer_step(self, lr=None):
-        world = self.bucket.all_reduce()
+    def _optimizer_step(self, lr=None, pending=None, mark=None):
+        world = self.bucket.all_reduce_end(pending) if pending is not None else self.bucket.all_reduce()
+        if mark is not None:
+            mark[1].record()
+            self.exchange_events.append(mark)
         b, lib = self.bucket, L.lib()
         self.iter += 1
         if not self._sq_clean:                 # (zeroed with the gradients in the fused iteration)
