@@ -510,6 +510,7 @@ def roofline(head, inp, dev, matrix_path='auto', tile_rows=0):
         'chain_kernel(decoder layer)': dict(
             bound='mfma', achieved=chain_flop / chain_ms / 1e9, peak=chain_peak, peak_definition=chain_peak_def,
             unit='TFLOP/s', ms=chain_ms, per_frame=6, alg_flop=chain_flop,
+            launches_per_frame='6 = 4 plain launches + 2 that carry the radar encoders (chain_dual_kernel: others)',
             arithmetic='f16x2 split operands, fp32 accumulate' if f16x2 else 'f32',
             # every workgroup streams the layer's packed weights (3.18 MB) through its CU's vector-memory path: what
             # binds the f16x2 item loop (DESIGN.md section 5 "Round 4"; ~57 B / clk / CU measured by split_mfma_probe)
@@ -573,7 +574,34 @@ def roofline(head, inp, dev, matrix_path='auto', tile_rows=0):
     for n, v in kern.items():                       # (the radar chain's executed / reference flop ride along)
         if n != dom and 'reference_flop' in v:
             r['others'][n].update(alg_flop=v['alg_flop'], reference_flop=v['reference_flop'], note=v['note'])
+    # the two decoder launches of a frame that carry the radar encoders (chain_dual_kernel) have no entry point of their
+    # own to time here: their durations come from the committed kernel trace of the same command (profiles/)
+    r['others'].update(dual_kernels_from_profile(B, chain_flop, chain_peak))
     return r
+
+
+def dual_kernels_from_profile(B, chain_flop, chain_peak):
+    import csv
+    import glob
+    import re
+    out = {}
+    try:
+        cands = [f for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*_kernel_stats.csv'))
+                 if re.match(r'^r\d+_kernel_stats\.csv$', os.path.basename(f))]
+        newest = sorted(cands, key=lambda f: int(os.path.basename(f).split('_')[0][1:]))[-1]
+        for row in csv.DictReader(open(newest)):
+            m = re.search(r'chain_dual_kernel<(\d+), \d+, (\d+), (\d+)>', row['Name'])
+            if m and int(row['Calls']) >= 10:
+                ms = float(row['AverageNs']) * 1e-6
+                part = {'4': 'A (encoders + K|V of fusion layer 1)', '5': 'B (K|V of fusion layers 2, 3)', '2': 'whole'}.get(m.group(2), m.group(2))
+                out['chain_dual_kernel(decoder layer + radar encoders %s)' % part] = dict(
+                    bound='mfma', unit='TFLOP/s', ms=ms, per_frame=1, tile_rows=int(m.group(1)), peak=chain_peak,
+                    achieved=chain_flop / ms / 1e9, frac=chain_flop / ms / 1e9 / chain_peak,
+                    note='duration from %s (nine frames per launch, one lane); flop = the decoder layer\'s only'
+                         % ('profiles/' + os.path.basename(newest)))
+    except Exception:
+        pass
+    return out
 
 
 PMC_KERNELS = (('chain_kernel(decoder layer)', r'chain_kernel<\d+, 1, '),

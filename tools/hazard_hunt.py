@@ -8,7 +8,7 @@ phase, every repetition verified), so the cause sits in the radar program.  This
   make -C transcar_amd/csrc INPLACE=1 DUMP=1     -> build/hip_inplace_dump/...inplace_dump.so          (stage `dump`)
   make -C transcar_amd/csrc DUMP=1               -> build/hip_dump/libtranscar_hip_dump.so             (production loop + dump)
 
-  TRANSCAR_ALLOW_STAMPS=1 TRANSCAR_HIP_LIB=<lib> python tools/r5_hazard_hunt.py final|dump [runs]
+  TRANSCAR_ALLOW_STAMPS=1 TRANSCAR_HIP_LIB=<lib> python tools/hazard_hunt.py final|dump [runs]
 
 `final`: rows whose class logits / boxes differ from the f32 path's by more than 1e-3, per run and layer.
 `dump` : the LDS destination of every step of the radar program is copied out ([step][row][256]); run-to-run

@@ -1066,7 +1066,7 @@ __device__ __forceinline__ bool linear_step16h(const LinSpec& s, WBuf& w0, bool 
 #else
 // DIAGNOSTIC BUILD ONLY (make INPLACE=1 -> build/hip_inplace/, never the product): round 4's first form of this loop,
 // the fragments refilled in place right behind their MFMAs ("variant A" of profiles/r4_f16x2_hazard.txt), kept to
-// chase the flaky rows it produced in the radar program (tools/r5_hazard_hunt.py, profiles/r5_refill_hazard.txt).
+// chase the flaky rows it produced in the radar program (tools/hazard_hunt.py, profiles/r5_refill_hazard.txt).
 
 template <int J>
 struct ItemSteps16HA {

@@ -515,16 +515,25 @@ class _Lidar2ImgStaging:
     RING = 8
 
     def __init__(self):
+        import threading
         self.slots = {}        # (device, shape) -> [pinned tensors, events, next]
         self.last = {}         # device -> (host copy, device tensor, stream id, event)
+        self.lock = threading.Lock()      # forwards from several host threads (one per stream) share this object
 
     def get(self, l2i, device):
+        with self.lock:
+            return self._get(l2i, device)
+
+    def _get(self, l2i, device):
         key = str(device)
         cur = torch.cuda.current_stream(device)
         hit = self.last.get(key)
         if hit is not None and hit[0].shape == l2i.shape and np.array_equal(hit[0], l2i):
             if hit[2] != cur.cuda_stream:
                 cur.wait_event(hit[3])
+                # a consumer on ANOTHER stream: the caching allocator must not hand the tensor's memory out again (it
+                # is replaced on the next miss) before that stream's work has finished with it
+                hit[1].record_stream(cur)
             return hit[1]
         ring = self.slots.get((key, l2i.shape))
         if ring is None:

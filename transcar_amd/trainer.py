@@ -189,8 +189,11 @@ class FusionTrainer:
     # fast path: the trainable stack as two C calls (tc_radar_train_fwd / _bwd) instead of
     # ~160 autograd nodes; torch autograd only differentiates the loss itself
     # ------------------------------------------------------------------
-    def _decoder_forward(self, feats_nhwc, lidar2img, img_hw, tokens, pad_mult, seed, lane):
-        """The frozen decoder (train mode) on B >= 1 frames; frame b draws the masks of seed + b * SEED_STRIDE."""
+    def _decoder_forward(self, feats_nhwc, lidar2img, img_hw, tokens, pad_mult, seed, lane, lookahead=False):
+        """The frozen decoder (train mode) on B >= 1 frames.  lookahead: the frames are consumed one per iteration, frame
+        b draws the masks of seed + b * SEED_STRIDE (the seed of the iteration that will take it).  An ordinary batch
+        (B > 1 frames of ONE iteration) draws from one index space with the iteration's seed: with the stride, sample 1
+        of iteration n would repeat the masks of sample 0 of iteration n + 1."""
         from .detr3d_head import head_options
         with torch.no_grad():
             return self.head.forward_nhwc(feats_nhwc, lidar2img, img_hw, tokens, pad_mult, aux='train',
@@ -198,15 +201,25 @@ class FusionTrainer:
                                           options=head_options(tile_rows=self.decoder_tile_rows,
                                                                matrix_path=getattr(self, 'decoder_matrix_path', None),
                                                                decoder_dropout_p=self.decoder_dropout,
-                                                               dropout_seed=seed, dropout_seed_stride=self.SEED_STRIDE))
+                                                               dropout_seed=seed,
+                                                               dropout_seed_stride=self.SEED_STRIDE if lookahead else 0))
 
-    @staticmethod
-    def _input_key(feats_nhwc, lidar2img, tokens, pad_mult):
-        # address, shape AND version counter: a loader that refills the same static tensors in place with the next
-        # frame must not get the decoder states of the old contents (a view shares its base's counter)
-        return (tuple((int(f.data_ptr()), int(f._version), tuple(f.shape)) for f in feats_nhwc),
+    def _input_key(self, feats_nhwc, lidar2img, tokens, pad_mult):
+        # address, shape, the tensors' version counters AND this trainer's look-ahead generation.  The version counter
+        # sees torch's in-place operators only: a loader that refills the same static tensors through this package's
+        # raw-pointer kernels (ops.to_nhwc into a preallocated buffer, RadarRawStage.build, FramePipeline write hooks,
+        # any ctypes tc_* call) must call ``invalidate_lookahead()`` -- it bumps the generation, and a pending
+        # look-ahead of the old contents is dropped instead of handing their decoder states to the new frame
+        return (int(getattr(self, '_generation', 0)),
+                tuple((int(f.data_ptr()), int(f._version), tuple(f.shape)) for f in feats_nhwc),
                 (int(lidar2img.data_ptr()), int(lidar2img._version)), (int(tokens.data_ptr()), int(tokens._version)),
                 int(pad_mult), tuple(tokens.shape))
+
+    def invalidate_lookahead(self):
+        """The tensors handed to ``prefetch_decoder`` / ``step_fused_nhwc(prefetch=...)`` were rewritten in place by
+        something torch's version counters do not see: pending look-ahead frames are stale."""
+        self._generation = int(getattr(self, '_generation', 0)) + 1
+        self._pre = self._pre_next = None
 
     def prefetch_decoder(self, feats_nhwc, lidar2img, img_hw, tokens, pad_mult, skip=0):
         """Enqueue the FROZEN decoder's forward of the NEXT iteration(s) now, on a side stream: it depends on nothing
@@ -234,7 +247,7 @@ class FusionTrainer:
         lane = 1 - (pend['lane'] if pend is not None else getattr(self, '_lane', 0))
         self._pre_stream.wait_stream(cur)                      # inputs written on the current stream are complete
         with torch.cuda.stream(self._pre_stream):
-            base = self._decoder_forward(feats_nhwc, lidar2img, img_hw, tokens, pad_mult, seed0, lane)
+            base = self._decoder_forward(feats_nhwc, lidar2img, img_hw, tokens, pad_mult, seed0, lane, lookahead=True)
             ev = torch.cuda.Event()
             ev.record(self._pre_stream)
         for t in base['aux'].values():
