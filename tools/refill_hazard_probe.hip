@@ -299,6 +299,13 @@ int main(int argc, char** argv) {
     unsigned long long nb = 0;
     for (unsigned b : bad) nb += b;
     printf("variants A and J alone (256 workgroups, one per CU): %llu wrong elements\n", nb);
+    // ... and what ONE workgroup per CU streams at (no second workgroup to share the L1 with: every byte crosses the CU's
+    // L2 port): 32 KiB per half item and workgroup
+    std::vector<long long> cyc(256);
+    CK(hipMemcpy(cyc.data(), d.cyc, 256 * 8, hipMemcpyDeviceToHost));
+    std::sort(cyc.begin(), cyc.end());
+    const double per_half = (double)cyc[128] / (8.0 * nrep);
+    printf("one workgroup per CU (J): %.0f cycles per half item = %.1f B/clk per CU through the L2 port\n", per_half, 32768.0 / per_half);
   }
   const int delays[] = {0, 1, 4, 16, 64};
   const int nd = (int)(sizeof(delays) / sizeof(int));
