@@ -59,10 +59,12 @@ def main():
         st = sb[0, 40:47]
         print('kernel start (cycles since entry): early loads issued %d, resolve done %d, early stores %d, barrier %d, prefetch records %d, ready %d'
               % tuple(int(x - st[0]) for x in st[1:]))
-        for w in range(4):
+        for w in range(NWV):
             row = sb[w]
             n = int((row[:20] > 0).sum())
-            print('  wave%d:' % w, ' '.join('%6d' % (row[j] - row[0]) for j in range(n)))
+            print('  wave%d:' % w, ' '.join('%d:%d' % (j, row[j] - row[0]) for j in range(20) if row[j] > 0))
+            if NWV == 8:
+                continue
             print('     item0 [start, A read, setup, mfma+prefetch]:', ' '.join('%6d' % (row[j] - row[0]) for j in range(20, 24)),
                   ' item1:', ' '.join('%6d' % (row[j] - row[0]) for j in range(25, 29)))
     if which == 'radar':

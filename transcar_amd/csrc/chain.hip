@@ -674,104 +674,115 @@ template <bool PL> __device__ __forceinline__ void act_st4(float* row, int col, 
 // NJ: sub-tiles of 16 columns in the wave's tile (4: the 64-column tiles of the 16-row kernels; 2: the 32-column tiles
 // of the 32-row kernels); colbase: the tile's first column; bvl: the bias of column colbase + lane (lanes >= 16 NJ: unused).
 // The rows are s.src / dst / res / gate / rowg / m0 + 0 .. 15: the 32-row kernels pass a view of their second row group.
-template <bool DROP, int NJ = 4, bool PL = false>
-__device__ __forceinline__ void lin_epilogue16(const LinSpec& s, int colbase, const f32x4 (&accv)[NJ], int lane, float bvl) {
+// NRG (32-row kernels: 2): the accumulators of NRG row groups of 16 rows go through the phases TOGETHER -- accv[NJ rg + jj]
+// is sub-tile jj of rows 16 rg .. 16 rg + 15 -- so that every LDS read of the tile is in flight before the first
+// LDS store (one call per row group serialised them: the compiler cannot tell the stores from the next group's reads).
+template <bool DROP, int NJ = 4, bool PL = false, int NRG = 1>
+__device__ __forceinline__ void lin_epilogue16(const LinSpec& s, int colbase, const f32x4 (&accv)[NJ * NRG], int lane, float bvl) {
+  constexpr int V = NJ * NRG;
   const int c = lane & 15, g = lane >> 4;
-  const int colb = colbase + 4 * g;              // + 16 j
-  float y[NJ][4];
-  f32x4 ab[NJ];
+  const int colb = colbase + 4 * g;              // + 16 jj
+  float y[V][4];
+  f32x4 ab[V];
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) ab[j] = accv[j];
+  for (int v = 0; v < V; ++v) ab[v] = accv[v];
   if (s.bias != nullptr) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) ab[j] = MFMA16(bvl, g == j ? 1.0f : 0.0f, ab[j]);
+    for (int v = 0; v < V; ++v) ab[v] = MFMA16(bvl, g == (v % NJ) ? 1.0f : 0.0f, ab[v]);
   }
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const float sc = (colb + 16 * j < s.scale_cols) ? s.scale : 1.0f;     // scale_cols is 0 or 256
+  for (int v = 0; v < V; ++v) {
+    const float sc = (colb + 16 * (v % NJ) < s.scale_cols) ? s.scale : 1.0f;     // scale_cols is 0 or 256
 #pragma unroll
-    for (int i = 0; i < 4; ++i) y[j][i] = ab[j][i] * sc;
+    for (int i = 0; i < 4; ++i) y[v][i] = ab[v][i] * sc;
   }
   if (s.range_flag != nullptr) {
-    // the f16 planes overflow at |activation| >= 4.19e6 / |weight| >= 65504: the product then is inf or NaN, never a wrong
-    // finite number -- one sticky word says so (tc_head_options.range_status)
+    // the f16 planes overflow at |activation| >= 4.19e6 / |weight| >= 65504: the product then is inf or NaN -- one sticky
+    // word says so (tc_head_options.range_status)
     bool bad = false;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+    for (int v = 0; v < V; ++v)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) bad |= !(fabsf(y[j][i]) <= 3.0e38f);
+      for (int i = 0; i < 4; ++i) bad |= !(fabsf(y[v][i]) <= 3.0e38f);
     if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(s.range_flag, 1);
   }
   if (s.act == 1) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+    for (int v = 0; v < V; ++v)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) y[j][i] = relu_(y[j][i]);
+      for (int i = 0; i < 4; ++i) y[v][i] = relu_(y[v][i]);
   } else if (s.act == 2) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+    for (int v = 0; v < V; ++v)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) y[j][i] = sigmoidf_(y[j][i]);
+      for (int i = 0; i < 4; ++i) y[v][i] = sigmoidf_(y[v][i]);
   }
   if (s.gate != nullptr) {
-    if (s.gate[c] == 0) {
 #pragma unroll
-      for (int j = 0; j < NJ; ++j)
+    for (int rg = 0; rg < NRG; ++rg)
+      if (s.gate[16 * rg + c] == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) y[j][i] = 0.0f;
-    }
+        for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) y[NJ * rg + jj][i] = 0.0f;
+      }
   }
   if (DROP) {
     if (s.drop_site != 0) {
-      unsigned row = (unsigned)(s.m0 + c);
-      unsigned long long seed = s.drop_seed;
-      if (s.drop_q > 0) { const unsigned b = row / (unsigned)s.drop_q; row -= b * (unsigned)s.drop_q; seed += b * s.drop_stride; }
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        // the lane's four consecutive columns of sub-tile j: one hash (N and colb are multiples of 4)
-        const unsigned m = drop_keep4(seed, (unsigned)(s.drop_site - 1), row * (unsigned)s.N + (unsigned)(colb + 16 * j), s.drop_thr);
+      for (int rg = 0; rg < NRG; ++rg) {
+        unsigned row = (unsigned)(s.m0 + 16 * rg + c);
+        unsigned long long seed = s.drop_seed;
+        if (s.drop_q > 0) { const unsigned b = row / (unsigned)s.drop_q; row -= b * (unsigned)s.drop_q; seed += b * s.drop_stride; }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) y[j][i] = ((m >> i) & 1u) ? y[j][i] * s.drop_scale : 0.0f;
+        for (int jj = 0; jj < NJ; ++jj) {
+          // the lane's four consecutive columns of sub-tile jj: one hash (N and colb are multiples of 4)
+          const unsigned m = drop_keep4(seed, (unsigned)(s.drop_site - 1), row * (unsigned)s.N + (unsigned)(colb + 16 * jj), s.drop_thr);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) y[NJ * rg + jj][i] = ((m >> i) & 1u) ? y[NJ * rg + jj][i] * s.drop_scale : 0.0f;
+        }
       }
     }
   }
   if (s.res != nullptr) {
-    float4 rr[NJ];
+    float4 rr[V];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
-      rr[j] = colb + 16 * j >= s.N ? make_float4(0.f, 0.f, 0.f, 0.f)
-              : (PL && s.res_pl) ? act_ld4<PL>(s.res + c * s.res_ld, colb + 16 * j)
-                                 : *reinterpret_cast<const float4*>(s.res + c * s.res_ld + colb + 16 * j);
+    for (int v = 0; v < V; ++v) {
+      const int col = colb + 16 * (v % NJ), row = 16 * (v / NJ) + c;
+      rr[v] = col >= s.N ? make_float4(0.f, 0.f, 0.f, 0.f)
+              : (PL && s.res_pl) ? act_ld4<PL>(s.res + row * s.res_ld, col)
+                                 : *reinterpret_cast<const float4*>(s.res + row * s.res_ld + col);
+    }
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) { y[j][0] += rr[j].x; y[j][1] += rr[j].y; y[j][2] += rr[j].z; y[j][3] += rr[j].w; }
+    for (int v = 0; v < V; ++v) { y[v][0] += rr[v].x; y[v][1] += rr[v].y; y[v][2] += rr[v].z; y[v][3] += rr[v].w; }
   }
   const bool vec = (s.N & 3) == 0;               // wave-uniform
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int col = colb + 16 * j;
-    if (col >= s.N) break;                       // columns only grow with j
-    const float4 y4 = make_float4(y[j][0], y[j][1], y[j][2], y[j][3]);
+  for (int v = 0; v < V; ++v) {
+    const int col = colb + 16 * (v % NJ), rloc = 16 * (v / NJ) + c;
+    if (col >= s.N) continue;
+    const float4 y4 = make_float4(y[v][0], y[v][1], y[v][2], y[v][3]);
     if (s.dst != nullptr) {                                                                // (N % 4 == 0 here)
-      if (PL && s.dst_pl) act_st4<PL>(s.dst + c * s.dst_ld, col, y4);
-      else *reinterpret_cast<float4*>(s.dst + c * s.dst_ld + col) = y4;
+      if (PL && s.dst_pl) act_st4<PL>(s.dst + rloc * s.dst_ld, col, y4);
+      else *reinterpret_cast<float4*>(s.dst + rloc * s.dst_ld + col) = y4;
     }
-    if (s.gdst != nullptr && s.m0 + c < s.M) {
-      const int grow = s.rowg != nullptr ? s.rowg[c] : s.m0 + c;
+    if (s.gdst != nullptr && s.m0 + rloc < s.M) {
+      const int grow = s.rowg != nullptr ? s.rowg[rloc] : s.m0 + rloc;
       float* gp = s.gdst + (size_t)grow * s.gdst_ld + col;
       if (vec && (s.gdst_ld & 3) == 0) st4(gp, y4);
       else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) if (col + i < s.N) stg1(gp + i, y[j][i]);
+        for (int i = 0; i < 4; ++i) if (col + i < s.N) stg1(gp + i, y[v][i]);
       }
     }
-    if (s.gt != nullptr && s.m0 + c < s.M) {
+    if (s.gt != nullptr && s.m0 + rloc < s.M) {
       // the transposed V of the next layer's attention, [b][column][query]: the 16 lanes of a group write 16
       // consecutive queries of one column
-      const int row = s.m0 + c;
+      const int row = s.m0 + rloc;
       const int bb = row / s.gt_rpb, q = row - bb * s.gt_rpb;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        if (col + i < s.N) stg1(s.gt + ((size_t)bb * s.N + col + i) * s.gt_ld + q, y[j][i]);
+        if (col + i < s.N) stg1(s.gt + ((size_t)bb * s.N + col + i) * s.gt_ld + q, y[v][i]);
     }
   }
   // Global stores read their data registers late and gfx9 tracks that with vmcnt, which retires in
@@ -1166,20 +1177,25 @@ template <int BUF>
 __device__ __forceinline__ void item32h(Acc32H& acc, WBuf& wb, const float* arow0, const float* arow1, int koff,
                                         const float* np, unsigned lo) {
   constexpr int C = 8 * BUF, N = 8 * (1 - BUF);
+  // the operand fragments of the two row groups: the 16 bytes of hi plane and the 16 bytes of lo plane of the lane's 8 k,
+  // BOTH 32-k halves of the item up front (eight ds_read_b128: the second half's latency runs under the first half's MFMAs)
+  float4 x1[2][2], x2[2][2];
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) {
-    // the operand fragments of the two row groups: the 16 bytes of hi plane and the 16 bytes of lo plane of the lane's 8 k
-    float4 x1[2], x2[2];
-    x1[0] = *reinterpret_cast<const float4*>(arow0 + koff + 32 * kk); x2[0] = *reinterpret_cast<const float4*>(arow0 + koff + 32 * kk + 4);
-    x1[1] = *reinterpret_cast<const float4*>(arow1 + koff + 32 * kk); x2[1] = *reinterpret_cast<const float4*>(arow1 + koff + 32 * kk + 4);
+    x1[kk][0] = *reinterpret_cast<const float4*>(arow0 + koff + 32 * kk); x2[kk][0] = *reinterpret_cast<const float4*>(arow0 + koff + 32 * kk + 4);
+    x1[kk][1] = *reinterpret_cast<const float4*>(arow1 + koff + 32 * kk); x2[kk][1] = *reinterpret_cast<const float4*>(arow1 + koff + 32 * kk + 4);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       const int f = 4 * kk + 2 * jj;
 #pragma unroll
       for (int rg = 0; rg < 2; ++rg) {
-        acc.lo[rg][jj] = MFMA16H(wb.b[C + f + 1], x1[rg], acc.lo[rg][jj]);
-        acc.lo[rg][jj] = MFMA16H(wb.b[C + f], x2[rg], acc.lo[rg][jj]);
-        acc.hi[rg][jj] = MFMA16H(wb.b[C + f], x1[rg], acc.hi[rg][jj]);
+        acc.lo[rg][jj] = MFMA16H(wb.b[C + f + 1], x1[kk][rg], acc.lo[rg][jj]);
+        acc.lo[rg][jj] = MFMA16H(wb.b[C + f], x2[kk][rg], acc.lo[rg][jj]);
+        acc.hi[rg][jj] = MFMA16H(wb.b[C + f], x1[kk][rg], acc.hi[rg][jj]);
       }
       __builtin_amdgcn_sched_barrier(0);
       // the wave's fragments of the next item: (kk, jj, p) at 8 kk + 2 jj + p fragments behind np (np carries the half)
@@ -1243,30 +1259,25 @@ __device__ __forceinline__ bool linear_step32h(const LinSpec& s, WBuf& w0, bool 
       bvl = ldg1(bsrc + min((wave + tt * NW) * 32 + lane, s.N - 1));
     }
     item32h<BUF>(acc, w0, arow0, arow1, kb * KB, nload, lo);
+    SUB_STAMP(3 + tt * nkb + kb);
     if (kb == nkb - 1) {
       int tile = wave + tt * NW;
       int sidx = step_idx;
       asm volatile("" : "+s"(tile), "+s"(sidx));         // see linear_step: the epilogue rebuilds its view
       if (!(CHAIN_DBG(s.dbg) & 1)) {
-        LinSpec e = make_spec(sidx);
+        const LinSpec e = make_spec(sidx);
+        f32x4 y[4];                                  // [2 rg + jj]
 #pragma unroll
-        for (int rg = 0; rg < 2; ++rg) {
-          f32x4 y[2];
+        for (int rg = 0; rg < 2; ++rg)
 #pragma unroll
           for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-              y[jj][i] = fmaf(acc.lo[rg][jj][i], 1.0f / (H_LO_SCALE * H_ACT_SCALE), acc.hi[rg][jj][i] * (1.0f / H_ACT_SCALE));
-          lin_epilogue16<DROP, 2, true>(e, tile * 32, y, lane, bvl);
-          // the second row group: the same view 16 rows down
-          if (e.dst != nullptr) e.dst += 16 * e.dst_ld;
-          if (e.res != nullptr) e.res += 16 * e.res_ld;
-          if (e.gate != nullptr) e.gate += 16;
-          if (e.rowg != nullptr) e.rowg += 16;
-          e.m0 += 16;
-        }
+              y[2 * rg + jj][i] = fmaf(acc.lo[rg][jj][i], 1.0f / (H_LO_SCALE * H_ACT_SCALE), acc.hi[rg][jj][i] * (1.0f / H_ACT_SCALE));
+        lin_epilogue16<DROP, 2, true, 2>(e, tile * 32, y, lane, bvl);
       }
     }
+    if (nk == 0) SUB_STAMP(16 + tt);               // (behind the tile's epilogue)
     wcur = np; tt = nt; kb = nk;
     __builtin_amdgcn_sched_barrier(0);
   };
