@@ -677,8 +677,12 @@ template <bool PL> __device__ __forceinline__ void act_st4(float* row, int col, 
 // NRG (32-row kernels: 2): the accumulators of NRG row groups of 16 rows go through the phases TOGETHER -- accv[NJ rg + jj]
 // is sub-tile jj of rows 16 rg .. 16 rg + 15 -- so that every LDS read of the tile is in flight before the first
 // LDS store (one call per row group serialised them: the compiler cannot tell the stores from the next group's reads).
+// bias4 (32-row kernels): the lane's own four bias values per sub-tile, loaded as float4 at the start of the tile -- added
+// here with one rounding each, exactly what the rank-1 MFMA of the 16-row kernels does with `bvl` (which those keep:
+// one register instead of 4 NJ across their item loop).
 template <bool DROP, int NJ = 4, bool PL = false, int NRG = 1>
-__device__ __forceinline__ void lin_epilogue16(const LinSpec& s, int colbase, const f32x4 (&accv)[NJ * NRG], int lane, float bvl) {
+__device__ __forceinline__ void lin_epilogue16(const LinSpec& s, int colbase, const f32x4 (&accv)[NJ * NRG], int lane, float bvl,
+                                               const float4* bias4 = nullptr) {
   constexpr int V = NJ * NRG;
   const int c = lane & 15, g = lane >> 4;
   const int colb = colbase + 4 * g;              // + 16 jj
@@ -687,8 +691,16 @@ __device__ __forceinline__ void lin_epilogue16(const LinSpec& s, int colbase, co
 #pragma unroll
   for (int v = 0; v < V; ++v) ab[v] = accv[v];
   if (s.bias != nullptr) {
+    if (bias4 != nullptr) {
 #pragma unroll
-    for (int v = 0; v < V; ++v) ab[v] = MFMA16(bvl, g == (v % NJ) ? 1.0f : 0.0f, ab[v]);
+      for (int v = 0; v < V; ++v) {
+        const float4 b4 = bias4[v % NJ];
+        ab[v][0] += b4.x; ab[v][1] += b4.y; ab[v][2] += b4.z; ab[v][3] += b4.w;
+      }
+    } else {
+#pragma unroll
+      for (int v = 0; v < V; ++v) ab[v] = MFMA16(bvl, g == (v % NJ) ? 1.0f : 0.0f, ab[v]);
+    }
   }
 #pragma unroll
   for (int v = 0; v < V; ++v) {
@@ -1227,7 +1239,7 @@ __device__ __forceinline__ bool linear_step32h(const LinSpec& s, WBuf& w0, bool 
   const unsigned lo = 4u * lane;
   const size_t tile_stride = (size_t)(NW / 2) * 64 * kpad;
   Acc32H acc;
-  float bvl = 0.f;
+  float4 bias4[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
   SUB_STAMP(1);
   if (CHAIN_DBG(s.dbg) & 32) return false;
   if (!preloaded) {
@@ -1255,8 +1267,12 @@ __device__ __forceinline__ bool linear_step32h(const LinSpec& s, WBuf& w0, bool 
       for (int rg = 0; rg < 2; ++rg)
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) { acc.hi[rg][jj] = f32x4{0.f, 0.f, 0.f, 0.f}; acc.lo[rg][jj] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      // the lane's four consecutive bias values of either sub-tile, in flight under the MFMAs; an unconditional load
+      // (see linear_step; columns beyond N are never stored: any valid address will do)
       const float* bsrc = s.bias != nullptr ? s.bias : s.W;
-      bvl = ldg1(bsrc + min((wave + tt * NW) * 32 + lane, s.N - 1));
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+        bias4[jj] = ld4(bsrc + min((wave + tt * NW) * 32 + 16 * jj + 4 * (lane >> 4), max(s.N - 4, 0)));
     }
     item32h<BUF>(acc, w0, arow0, arow1, kb * KB, nload, lo);
     SUB_STAMP(3 + tt * nkb + kb);
@@ -1274,7 +1290,7 @@ __device__ __forceinline__ bool linear_step32h(const LinSpec& s, WBuf& w0, bool 
 #pragma unroll
             for (int i = 0; i < 4; ++i)
               y[2 * rg + jj][i] = fmaf(acc.lo[rg][jj][i], 1.0f / (H_LO_SCALE * H_ACT_SCALE), acc.hi[rg][jj][i] * (1.0f / H_ACT_SCALE));
-        lin_epilogue16<DROP, 2, true, 2>(e, tile * 32, y, lane, bvl);
+        lin_epilogue16<DROP, 2, true, 2>(e, tile * 32, y, lane, 0.0f, bias4);
       }
     }
     if (nk == 0) SUB_STAMP(16 + tt);               // (behind the tile's epilogue)
