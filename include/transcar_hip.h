@@ -172,8 +172,10 @@ typedef struct {
   int* range_status;        /* ABI 10, device pointer or NULL: a sticky word the kernels of the f16x2 matrix path OR 1
                                into when a linear step produces a non-finite value -- which is what an operand beyond
                                the f16 planes' range (|activation| >= 65504 * 2^6 = 4.19e6, |weight| >= 65504) turns
-                               into: inf / NaN in the affected rows, never a wrong finite number.  The caller clears
-                               it; Detr3DHead reads it where it already reads results back (get_bboxes) and, on
+                               into: inf / NaN in the step's result of the affected rows.  Later steps may turn those
+                               into finite-looking outputs again (a sigmoid, the clamp of a reference point, a
+                               row gate of 0): the FLAG is the signal, not the outputs.  The caller clears it;
+                               Detr3DHead reads it where it already reads results back (get_bboxes) and, on
                                TC_MATRIX_AUTO, runs its next forwards on TC_MATRIX_F32 */
 } tc_head_options;
 #define TC_MATRIX_AUTO 0

@@ -6,7 +6,7 @@
 # separate runs, kernel-trace only).  Copy what is to be judged into profiles/ with
 # tools/collect_profile.py <tag> <name>.
 set -u
-TAG=${1:-r4}
+TAG=${1:-r5}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
