@@ -630,6 +630,102 @@ def parse_counter_csv(path, ctr):
     return {name: (v / n, n, dur / n) for name, (v, n, dur) in acc.items() if n}
 
 
+def _pmc_tools():
+    """(rocprofv3, python) for a --pmc child pass, or None: rocprofv3 missing, this process itself profiled, or the
+    interpreter not a real ELF binary (under --pmc the profiler's preloaded library has initialised the GPU before the
+    program starts, so a shim script that re-execs would be an exec from a GPU-initialised process, which this pool
+    forbids -- ADVICE r3: no PATH lookup of "python3")."""
+    import shutil
+    if any(k.startswith('ROCPROF') or k.startswith('ROCP_') for k in os.environ):
+        return None
+    exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(exe):
+        return None
+    py = os.path.realpath(sys.executable or '')
+    try:
+        with open(py, 'rb') as f:
+            if f.read(4) != b'\x7fELF':
+                return None
+    except OSError:
+        return None
+    return exe, py
+
+
+def _pmc_pass(exe, py, tmp, ctr, bench_args, timeout_s):
+    """One `rocprofv3 --kernel-trace --pmc <ctr> -- python3 bench.py <bench_args>` child (kernel trace only, the program
+    itself behind `--`: the GPU box's rules) -> path of its counter csv, or None."""
+    import glob
+    import signal
+    import subprocess
+    out = os.path.join(tmp, ctr)
+    cmd = [exe, '--kernel-trace', '--pmc', ctr, '--output-format', 'csv', '-d', out, '--', py,
+           os.path.join(ROOT, 'bench.py')] + list(bench_args)
+    env = dict(os.environ, TMPDIR='/tmp')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    # its own session: on a timeout the WHOLE group goes (rocprofv3 and the profiled bench.py behind it), or the
+    # grandchild would keep running on the GPU beside the side measurements that follow (ADVICE r3)
+    proc = subprocess.Popen(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                            start_new_session=True)
+    try:
+        rc = proc.wait(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        proc.wait()
+        return None
+    files = glob.glob(os.path.join(out, '**', '*counter_collection.csv'), recursive=True)
+    return files[0] if rc == 0 and files else None
+
+
+def iteration_traffic_from_csvs(fetch_csv, write_csv):
+    """HBM-side bytes per TRAINING ITERATION from the two counter csv files of a `bench.py --train` child: every
+    dispatch of the process counted, (2 FETCH_SIZE + WRITE_SIZE) * 1024 summed, divided by the iterations the child ran
+    (= launches of adamw_kernel: exactly one per iteration) -> dict or None."""
+    import csv
+    tot, iters = {}, {}
+    for ctr, path in (('FETCH_SIZE', fetch_csv), ('WRITE_SIZE', write_csv)):
+        t, n = 0.0, 0
+        for row in csv.DictReader(open(path)):
+            if row.get('Counter_Name') != ctr:
+                continue
+            t += float(row['Counter_Value'])
+            n += 'adamw_kernel' in row['Kernel_Name']
+        tot[ctr], iters[ctr] = t, n
+    if not iters['FETCH_SIZE'] or not iters['WRITE_SIZE']:
+        return None
+    fetch, write = tot['FETCH_SIZE'] / iters['FETCH_SIZE'], tot['WRITE_SIZE'] / iters['WRITE_SIZE']
+    return dict(traffic_bytes=int((2 * fetch + write) * 1024), fetch_kb=round(fetch, 1), write_kb=round(write, 1),
+                iterations=iters['FETCH_SIZE'])
+
+
+def live_train_traffic(extra_args=(), timeout_s=120):
+    """`train.roofline.traffic` (VERDICT r4 item 9): two --pmc child passes of `bench.py --train` (FETCH_SIZE, WRITE_SIZE;
+    all kernels of an iteration incl. its share of the look-ahead decoder) -> iteration_traffic_from_csvs, or None."""
+    import shutil
+    import tempfile
+    tools = _pmc_tools()
+    if tools is None:
+        return None
+    tmp = tempfile.mkdtemp(prefix='tc_pmc_train_', dir='/tmp')
+    try:
+        paths = []
+        for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+            pth = _pmc_pass(tools[0], tools[1], tmp, ctr, ['--train', '--steps', '9', '--warmup', '2', '--no-roofline',
+                                                          '--min-window-s', '0.02', '--warmup-s', '0.02'] + list(extra_args),
+                            timeout_s)
+            if pth is None:
+                return None
+            paths.append(pth)
+        return iteration_traffic_from_csvs(*paths)
+    except (OSError, ValueError, KeyError):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def live_traffic(frames_per_launch, timeout_s=75, extra_args=()):
     """HBM-side bytes per launch of the path's kernels, MEASURED in this run (the figure used to
     come from a committed profile): child passes `rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES --
@@ -637,54 +733,23 @@ def live_traffic(frames_per_launch, timeout_s=75, extra_args=()):
     behind `--`: the GPU box's rules), the counters averaged per launch and corrected as MI355X_MICROARCH.md's HBM
     section prescribes for gfx950: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  {} when rocprofv3 is missing, this
     process is itself being profiled, or a pass fails -- the caller keeps the committed figure then."""
-    import glob
     import shutil
-    import signal
     import subprocess
     import tempfile
-    if any(k.startswith('ROCPROF') or k.startswith('ROCP_') for k in os.environ):
+    tools = _pmc_tools()
+    if tools is None:
         return {}
-    exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
-    if not os.path.exists(exe):
-        return {}
-    # the profiled program must be a real interpreter binary: under --pmc the profiler's preloaded library has
-    # initialised the GPU before the program starts, so a shim script that re-execs (pyenv and the like) would be an
-    # exec from a GPU-initialised process, which this pool forbids (ADVICE r3) -- no PATH lookup of "python3"
-    py = os.path.realpath(sys.executable or '')
-    try:
-        with open(py, 'rb') as f:
-            if f.read(4) != b'\x7fELF':
-                return {}
-    except OSError:
-        return {}
+    exe, py = tools
     got = {}
     tmp = tempfile.mkdtemp(prefix='tc_pmc_', dir='/tmp')
     try:
         for ctr in ('FETCH_SIZE', 'WRITE_SIZE', 'SQ_VALU_MFMA_BUSY_CYCLES'):
-            out = os.path.join(tmp, ctr)
-            cmd = [exe, '--kernel-trace', '--pmc', ctr, '--output-format', 'csv', '-d', out, '--', py,
-                   os.path.join(ROOT, 'bench.py'), '--batch', str(frames_per_launch), '--steps', '3', '--warmup', '1',
-                   '--main-only', '--no-graph', '--min-window-s', '0.02', '--warmup-s', '0.02'] + list(extra_args)
-            env = dict(os.environ, TMPDIR='/tmp')
-            for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
-                env.pop(k, None)
-            # its own session: on a timeout the WHOLE group goes (rocprofv3 and the profiled bench.py behind it), or the
-            # grandchild would keep running on the GPU beside the side measurements that follow (ADVICE r3)
-            proc = subprocess.Popen(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
-                                    start_new_session=True)
-            try:
-                rc = proc.wait(timeout=timeout_s)
-            except subprocess.TimeoutExpired:
-                try:
-                    os.killpg(proc.pid, signal.SIGKILL)
-                except OSError:
-                    pass
-                proc.wait()
+            csv_path = _pmc_pass(exe, py, tmp, ctr, ['--batch', str(frames_per_launch), '--steps', '3', '--warmup', '1',
+                                                     '--main-only', '--no-graph', '--min-window-s', '0.02',
+                                                     '--warmup-s', '0.02'] + list(extra_args), timeout_s)
+            if csv_path is None:
                 return {}
-            files = glob.glob(os.path.join(out, '**', '*counter_collection.csv'), recursive=True)
-            if rc != 0 or not files:
-                return {}
-            for name, (v, n, dur) in parse_counter_csv(files[0], ctr).items():
+            for name, (v, n, dur) in parse_counter_csv(csv_path, ctr).items():
                 got.setdefault(name, {})[ctr] = v
                 got[name]['launches'] = n
                 if ctr == 'SQ_VALU_MFMA_BUSY_CYCLES':
@@ -1108,7 +1173,36 @@ def cpu_baseline(sd, inp, seconds):
                one_thread=one, all_physical_cores=dict(every or one, note='bounded probe: 1 warm-up + 2 frames'),
                probes={str(n): r for n, r in probes.items()})
     out.update(info)
+    out['box_to_box'] = cpu_baseline_spread(best['ms_per_frame'])
     return out
+
+
+def cpu_baseline_spread(this_ms=None):
+    """the CPU figure moves between boxes of the pool (and with the thread count the 2-frame probes
+    pick).  The spread of `cpu_baseline.ms_per_frame` over the committed bench lines of all rounds (profiles/r*_bench.json,
+    r*_driver_cmd.json: each a run on another box) and this run."""
+    import glob
+    vals = []
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench.json')) +
+                    glob.glob(os.path.join(ROOT, 'profiles', 'r*_driver_cmd.json'))):
+        try:
+            with open(f) as fh:
+                for ln in fh:
+                    ln = ln.strip()
+                    if ln.startswith('{'):
+                        cb = json.loads(ln).get('cpu_baseline') or {}
+                        if cb.get('ms_per_frame'):
+                            vals.append((float(cb['ms_per_frame']), int(cb.get('cores', 0)), os.path.basename(f)))
+                        break
+        except (OSError, ValueError):
+            continue
+    ms = [v[0] for v in vals] + ([float(this_ms)] if this_ms else [])
+    if not ms:
+        return None
+    return dict(runs=len(ms), min_ms_per_frame=min(ms), max_ms_per_frame=max(ms), median_ms_per_frame=float(np.median(ms)),
+                threads_chosen=sorted({v[1] for v in vals}),
+                note='cpu_baseline.ms_per_frame of the committed bench lines of every round (one box each) and of this run: '
+                     'the baseline is a reported figure with this spread, not a constant')
 
 
 def rank_census(dev, world):
@@ -1302,6 +1396,14 @@ def train_bench(args, head, inp, dev, rank, world, affinity=None):
                                                         nxt, dev, loader.window() if loader is not None else None)
     if rank == 0:
         if roof is not None:
+            # HBM-side bytes per iteration, measured by two --pmc child passes of this command (world size 1 only: the
+            # children run beside nothing then)
+            if world == 1 and not args.no_live_pmc and not args.train_autograd:
+                tt = live_train_traffic(extra_args=('--shapes', args.shapes) + (('--no-prefetch',) if args.no_prefetch else ()))
+                if tt is not None:
+                    roof['traffic'], roof['traffic_source'] = tt['traffic_bytes'], 'this run'
+                    roof['traffic_detail'] = dict(tt, unit='bytes per iteration = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 summed '
+                                                           'over every dispatch / iterations (adamw_kernel launches)')
             line['roofline'] = roof
         print(json.dumps(line), flush=True)
     D.barrier()

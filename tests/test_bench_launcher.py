@@ -174,3 +174,20 @@ def test_pmc_counter_csv_is_reduced_per_kernel(tmp_path):
     assert v == 200.0 and n == 2 and abs(dur - 1.5e-6) < 1e-12
     assert got['chain_kernel(radar fusion)'][0] == 50.0 and got['self_attn_kernel'][1] == 1
     assert bench.parse_counter_csv(str(f), 'WRITE_SIZE') == {'chain_kernel(decoder layer)': (7.0, 1, 1e-8)}
+
+
+def test_training_iteration_traffic_is_summed_over_all_dispatches(tmp_path):
+    """`bench.py --train` -> roofline.traffic: every dispatch of the child's counter csv counts, the number of
+    iterations is the number of adamw_kernel launches (one per iteration), bytes = (2 FETCH + WRITE) * 1024."""
+    import bench
+    hdr = 'Kernel_Name,Counter_Name,Counter_Value,Start_Timestamp,End_Timestamp\n'
+    names = ['void tc::chain_kernel<4, 6, true>(...)', 'void tc::bwd_weight_group_kernel(...)', 'void tc::adamw_kernel(...)']
+    fetch, write = tmp_path / 'f.csv', tmp_path / 'w.csv'
+    fetch.write_text(hdr + ''.join('"%s",FETCH_SIZE,%s,0,1\n' % (n, v) for _ in range(3) for n, v in zip(names, (100., 40., 10.))))
+    write.write_text(hdr + ''.join('"%s",WRITE_SIZE,%s,0,1\n' % (n, v) for _ in range(3) for n, v in zip(names, (20., 30., 10.))) +
+                     '"x",FETCH_SIZE,999,0,1\n')
+    got = bench.iteration_traffic_from_csvs(str(fetch), str(write))
+    assert got['iterations'] == 3 and got['fetch_kb'] == 150.0 and got['write_kb'] == 60.0
+    assert got['traffic_bytes'] == (2 * 150 + 60) * 1024
+    write.write_text(hdr)
+    assert bench.iteration_traffic_from_csvs(str(fetch), str(write)) is None
