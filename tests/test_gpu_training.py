@@ -985,7 +985,8 @@ def test_decoder_prefetch_changes_nothing_but_the_schedule(A, golden_dir):
     assert_params_equal_up_to_adam_noise(res[False][1], res[True][1], res['again'][1], lr=1e-5, steps=3, slack=1e-5)
 
 
-def test_batched_decoder_lookahead_is_the_single_frame_decoder(A, golden_dir):
+@pytest.mark.parametrize('rows', [16, 32])
+def test_batched_decoder_lookahead_is_the_single_frame_decoder(A, golden_dir, rows):
     """FusionTrainer(prefetch_depth=P) (round 4): the FROZEN decoder of the next P frames runs as ONE
     batched launch sequence at 16-row tiles, frame b with the dropout masks of seed + b * SEED_STRIDE
     (tc_head_options.dropout_seed_stride) -- the seeds those iterations draw themselves.
@@ -1012,7 +1013,7 @@ def test_batched_decoder_lookahead_is_the_single_frame_decoder(A, golden_dir):
         tok1, pad_mult = h.radar_tokens(metas, dev())
         tok_b = torch.cat([tok1] * (2 * P), 0).contiguous()
         tr = FusionTrainer(h, dropout=0.1, seed=4, lr=1e-5, prefetch_depth=depth, decoder_dropout=0.1)
-        tr.decoder_tile_rows = 16                                  # the same decoder arithmetic with and without look-ahead
+        tr.decoder_tile_rows = rows                                # the same decoder arithmetic with and without look-ahead
         ncam = nhwc_b[0].shape[0] // (2 * P)
 
         def view(pos, n):
@@ -1027,7 +1028,7 @@ def test_batched_decoder_lookahead_is_the_single_frame_decoder(A, golden_dir):
     assert tr.decoder_dropout > 0
     seed0 = 0x1234567
     w0 = window(0)
-    full = tr._decoder_forward(w0['feats_nhwc'], w0['lidar2img'], img_hw, w0['tokens'], pad_mult, seed0, 1)['aux']
+    full = tr._decoder_forward(w0['feats_nhwc'], w0['lidar2img'], img_hw, w0['tokens'], pad_mult, seed0, 1, lookahead=True)['aux']
     torch.cuda.synchronize()
     full = {k: v.clone() for k, v in full.items() if torch.is_tensor(v)}
     frames = [view(i, 1) for i in range(P)]
@@ -1082,8 +1083,10 @@ def test_batched_decoder_lookahead_is_the_single_frame_decoder(A, golden_dir):
     assert h._train_forwards == counter + 1                           # one seed per training forward, none for the dropped batch
 
 
-def test_train_mode_decoder_on_the_matrix_cores_draws_the_fp32_kernels_masks(A, golden_dir):
-    """The frozen decoder in train mode at 16-row tiles: the two-plane f16 kernels (chains AND the staged attention core
+@pytest.mark.parametrize('rows', [16, 32])
+def test_train_mode_decoder_on_the_matrix_cores_draws_the_fp32_kernels_masks(A, golden_dir, rows):
+    """The frozen decoder in train mode at 16- and 32-row tiles (32: what a nine-frame look-ahead runs since round 5;
+    the f32 side of the comparison stays at 16 rows, the f32 MFMA kernels' largest tile): the two-plane f16 kernels (chains AND the staged attention core
     with dropout on the probabilities, round 4) against the fp32 MFMA kernels with the same seed -- the masks are a
     function of (seed, site, element index) only, so the two agree to fp32 rounding; without the seed they do not."""
     from transcar_amd import ops
@@ -1095,10 +1098,11 @@ def test_train_mode_decoder_on_the_matrix_cores_draws_the_fp32_kernels_masks(A, 
     img_hw = metas[0]['img_shape'][0][:2]
     tokens, pad_mult = h.radar_tokens(metas, dev())
     tr = FusionTrainer(h, dropout=0.1, seed=4, decoder_dropout=0.1, prefetch_depth=9)
-    assert tr.decoder_tile_rows == 16
+    assert tr.decoder_tile_rows == 32                          # 9 x 900 rows > 4 096
     out = {}
     for mp, seed in (('f16x2', 77), ('f32', 77), ('f16x2', 78)):
         tr.decoder_matrix_path = mp
+        tr.decoder_tile_rows = rows if mp == 'f16x2' else 16
         aux = tr._decoder_forward(nhwc, l2i, img_hw, tokens, pad_mult, seed, 0)['aux']
         torch.cuda.synchronize()
         out[(mp, seed)] = {k: v.clone() for k, v in aux.items() if torch.is_tensor(v)}

@@ -43,6 +43,12 @@
 //    runs at full rate: tools/icache_probe.hip); the step table exists to keep
 //    ONE code image for all four programs.
 #include <stdlib.h>
+#ifndef TC_PRIO
+#define TC_PRIO 0
+#endif
+#ifndef TC_PRIO_MASK
+#define TC_PRIO_MASK 4
+#endif
 #include <string.h>
 
 #include <type_traits>
@@ -970,6 +976,161 @@ __device__ __forceinline__ void act_st4(float* row, int col, const float4& v) {
   }
 }
 
+// The epilogue of a 32 x 32 tile of the 32-row kernels (both row groups, both 16-column sub-tiles: v = 2 rg + jj is rows
+// 16 rg + c, columns colbase + 16 jj + 4 g ..).  Same arithmetic, in the same order, as lin_epilogue16 behind the
+// hi / lo recombination -- but carried out on t = s x (s = H_ACT_SCALE, a power of two: every step commutes with it
+// bit for bit), which is what the planes store: the un-scaling of the accumulators, of a residual read from planes and
+// the re-scaling in front of the split cancel (3 multiplies per element less).  The tile lies inside N (the caller
+// sends ragged tiles -- the 24 attention logits -- through lin_epilogue16): no per-lane column tests, so all four
+// residual reads are in flight together, ahead of the arithmetic, and nothing between them and the stores branches on
+// a lane.
+struct Acc32H;
+template <bool DROP>
+__device__ __forceinline__ void lin_epilogue32(const LinSpec& s, int colbase, const f32x4 (&thi)[4], const f32x4 (&tlo)[4], int lane,
+                                               const float4 (&bias4)[2]) {
+  const int c = lane & 15, g = lane >> 4;
+  const int colb = colbase + 4 * g;
+  constexpr float US = 1.0f / H_ACT_SCALE;
+  // residual: raw reads first
+  uint2 rh[4], rl[4];
+  float4 rf[4];
+  const bool res_planes = s.res != nullptr && s.res_pl, res_f32 = s.res != nullptr && !s.res_pl;
+  if (res_planes) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int col = colb + 16 * (v & 1), row = 16 * (v >> 1) + c;
+      const char* p = reinterpret_cast<const char*>(s.res + row * s.res_ld) + (col >> 3) * 32 + (col & 7) * 2;
+      rh[v] = *reinterpret_cast<const uint2*>(p); rl[v] = *reinterpret_cast<const uint2*>(p + 16);
+    }
+  } else if (res_f32) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+      rf[v] = *reinterpret_cast<const float4*>(s.res + (16 * (v >> 1) + c) * s.res_ld + colb + 16 * (v & 1));
+  }
+  float t[4][4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[v][i] = fmaf(tlo[v][i], 1.0f / H_LO_SCALE, thi[v][i]);
+  if (s.bias != nullptr) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const float4 b4 = bias4[v & 1];
+      t[v][0] = fmaf(b4.x, H_ACT_SCALE, t[v][0]); t[v][1] = fmaf(b4.y, H_ACT_SCALE, t[v][1]);
+      t[v][2] = fmaf(b4.z, H_ACT_SCALE, t[v][2]); t[v][3] = fmaf(b4.w, H_ACT_SCALE, t[v][3]);
+    }
+  }
+  if (colbase < s.scale_cols) {                    // scale_cols is 0 or 256, colbase a multiple of 32: wave-uniform
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) t[v][i] *= s.scale;
+  }
+  if (s.range_flag != nullptr) {
+    bool bad = false;
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bad |= !(fabsf(t[v][i]) <= 3.0e38f * H_ACT_SCALE);
+    if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(s.range_flag, 1);
+  }
+  if (s.act == 1) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) t[v][i] = relu_(t[v][i]);
+  } else if (s.act == 2) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) t[v][i] = sigmoidf_(t[v][i] * US) * H_ACT_SCALE;
+  }
+  if (s.gate != nullptr) {
+#pragma unroll
+    for (int rg = 0; rg < 2; ++rg)
+      if (s.gate[16 * rg + c] == 0) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) t[2 * rg + jj][i] = 0.0f;
+      }
+  }
+  if (DROP) {
+    if (s.drop_site != 0) {
+#pragma unroll
+      for (int rg = 0; rg < 2; ++rg) {
+        unsigned row = (unsigned)(s.m0 + 16 * rg + c);
+        unsigned long long seed = s.drop_seed;
+        if (s.drop_q > 0) { const unsigned b = row / (unsigned)s.drop_q; row -= b * (unsigned)s.drop_q; seed += b * s.drop_stride; }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const unsigned m = drop_keep4(seed, (unsigned)(s.drop_site - 1), row * (unsigned)s.N + (unsigned)(colb + 16 * jj), s.drop_thr);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) t[2 * rg + jj][i] = ((m >> i) & 1u) ? t[2 * rg + jj][i] * s.drop_scale : 0.0f;
+        }
+      }
+    }
+  }
+  if (res_planes) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const f16x2 h0 = __builtin_bit_cast(f16x2, rh[v].x), h1 = __builtin_bit_cast(f16x2, rh[v].y);
+      const f16x2 l0 = __builtin_bit_cast(f16x2, rl[v].x), l1 = __builtin_bit_cast(f16x2, rl[v].y);
+      t[v][0] += fmaf((float)l0[0], 1.0f / H_LO_SCALE, (float)h0[0]); t[v][1] += fmaf((float)l0[1], 1.0f / H_LO_SCALE, (float)h0[1]);
+      t[v][2] += fmaf((float)l1[0], 1.0f / H_LO_SCALE, (float)h1[0]); t[v][3] += fmaf((float)l1[1], 1.0f / H_LO_SCALE, (float)h1[1]);
+    }
+  } else if (res_f32) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      t[v][0] = fmaf(rf[v].x, H_ACT_SCALE, t[v][0]); t[v][1] = fmaf(rf[v].y, H_ACT_SCALE, t[v][1]);
+      t[v][2] = fmaf(rf[v].z, H_ACT_SCALE, t[v][2]); t[v][3] = fmaf(rf[v].w, H_ACT_SCALE, t[v][3]);
+    }
+  }
+  if (s.dst != nullptr) {
+    if (s.dst_pl) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int col = colb + 16 * (v & 1), rloc = 16 * (v >> 1) + c;
+        uint2 h, l;
+        h.x = pk_h2(t[v][0], t[v][1]); h.y = pk_h2(t[v][2], t[v][3]);
+        const f16x2 h0 = __builtin_bit_cast(f16x2, h.x), h1 = __builtin_bit_cast(f16x2, h.y);
+        l.x = pk_h2((t[v][0] - (float)h0[0]) * H_LO_SCALE, (t[v][1] - (float)h0[1]) * H_LO_SCALE);
+        l.y = pk_h2((t[v][2] - (float)h1[0]) * H_LO_SCALE, (t[v][3] - (float)h1[1]) * H_LO_SCALE);
+        char* p = reinterpret_cast<char*>(s.dst + rloc * s.dst_ld) + (col >> 3) * 32 + (col & 7) * 2;
+        *reinterpret_cast<uint2*>(p) = h;
+        *reinterpret_cast<uint2*>(p + 16) = l;
+      }
+    } else {
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        *reinterpret_cast<float4*>(s.dst + (16 * (v >> 1) + c) * s.dst_ld + colb + 16 * (v & 1)) =
+            make_float4(t[v][0] * US, t[v][1] * US, t[v][2] * US, t[v][3] * US);
+    }
+  }
+  if (s.gdst != nullptr || s.gt != nullptr) {
+    const bool vec = (s.gdst_ld & 3) == 0;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int col = colb + 16 * (v & 1), rloc = 16 * (v >> 1) + c;
+      if (s.m0 + rloc >= s.M) continue;
+      const float4 y4 = make_float4(t[v][0] * US, t[v][1] * US, t[v][2] * US, t[v][3] * US);
+      if (s.gdst != nullptr) {
+        const int grow = s.rowg != nullptr ? s.rowg[rloc] : s.m0 + rloc;
+        float* gp = s.gdst + (size_t)grow * s.gdst_ld + col;
+        if (vec) st4(gp, y4);
+        else { stg1(gp, y4.x); stg1(gp + 1, y4.y); stg1(gp + 2, y4.z); stg1(gp + 3, y4.w); }
+      }
+      if (s.gt != nullptr) {
+        const int row = s.m0 + rloc;
+        const int bb = row / s.gt_rpb, q = row - bb * s.gt_rpb;
+        float* tp = s.gt + ((size_t)bb * s.N + col) * s.gt_ld + q;
+        stg1(tp, y4.x); stg1(tp + s.gt_ld, y4.y); stg1(tp + 2 * (size_t)s.gt_ld, y4.z); stg1(tp + 3 * (size_t)s.gt_ld, y4.w);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see lin_epilogue16
+  }
+}
+
 // One HALF item (64 columns x 32 k): 8 fragments of 1 KiB -- (sub-tile j, plane p) at wb.b[2 j + p] --, 12 MFMAs.
 // TWO register buffers of one half item each (b[0..7], b[8..15]): while half item i issues its MFMAs from one, the
 // fragments of half item i + 1 are loaded into the other -- group by group behind the MFMAs of the same group, so
@@ -1239,6 +1400,15 @@ __device__ __forceinline__ bool linear_step32h(const LinSpec& s, WBuf& w0, bool 
   const unsigned lo = 4u * lane;
   const size_t tile_stride = (size_t)(NW / 2) * 64 * kpad;
   Acc32H acc;
+#if TC_PRIO >= 4
+  // experiment: the SIMD partners (waves w and w + 4) out of phase -- the second one starts its items TC_PRIO x 64 cycles late
+  if ((__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & TC_PRIO_MASK) != 0) __builtin_amdgcn_s_sleep(TC_PRIO);
+#endif
+#if TC_PRIO == 1
+  const bool prio_hi = (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 4) == 0;
+#elif TC_PRIO == 3
+  const bool prio_hi = (((__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >> 2) ^ step_idx) & 1) == 0;
+#endif
   float4 bias4[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
   SUB_STAMP(1);
   if (CHAIN_DBG(s.dbg) & 32) return false;
@@ -1274,23 +1444,35 @@ __device__ __forceinline__ bool linear_step32h(const LinSpec& s, WBuf& w0, bool 
       for (int jj = 0; jj < 2; ++jj)
         bias4[jj] = ld4(bsrc + min((wave + tt * NW) * 32 + 16 * jj + 4 * (lane >> 4), max(s.N - 4, 0)));
     }
+#if TC_PRIO == 1 || TC_PRIO == 3
+    if (prio_hi) __builtin_amdgcn_s_setprio(3);
+#endif
     item32h<BUF>(acc, w0, arow0, arow1, kb * KB, nload, lo);
     SUB_STAMP(3 + tt * nkb + kb);
+#if TC_PRIO == 1 || TC_PRIO == 3
+    if (kb == nkb - 1) __builtin_amdgcn_s_setprio(0);
+#endif
     if (kb == nkb - 1) {
       int tile = wave + tt * NW;
       int sidx = step_idx;
       asm volatile("" : "+s"(tile), "+s"(sidx));         // see linear_step: the epilogue rebuilds its view
       if (!(CHAIN_DBG(s.dbg) & 1)) {
         const LinSpec e = make_spec(sidx);
-        f32x4 y[4];                                  // [2 rg + jj]
+        if (tile * 32 + 32 <= e.N) {                 // (wave-uniform)
+          const f32x4 thi[4] = {acc.hi[0][0], acc.hi[0][1], acc.hi[1][0], acc.hi[1][1]};
+          const f32x4 tlo[4] = {acc.lo[0][0], acc.lo[0][1], acc.lo[1][0], acc.lo[1][1]};
+          lin_epilogue32<DROP>(e, tile * 32, thi, tlo, lane, bias4);
+        } else {
+          f32x4 y[4];                                  // [2 rg + jj]
 #pragma unroll
-        for (int rg = 0; rg < 2; ++rg)
+          for (int rg = 0; rg < 2; ++rg)
 #pragma unroll
-          for (int jj = 0; jj < 2; ++jj)
+            for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-              y[2 * rg + jj][i] = fmaf(acc.lo[rg][jj][i], 1.0f / (H_LO_SCALE * H_ACT_SCALE), acc.hi[rg][jj][i] * (1.0f / H_ACT_SCALE));
-        lin_epilogue16<DROP, 2, true, 2>(e, tile * 32, y, lane, 0.0f, bias4);
+              for (int i = 0; i < 4; ++i)
+                y[2 * rg + jj][i] = fmaf(acc.lo[rg][jj][i], 1.0f / (H_LO_SCALE * H_ACT_SCALE), acc.hi[rg][jj][i] * (1.0f / H_ACT_SCALE));
+          lin_epilogue16<DROP, 2, true, 2>(e, tile * 32, y, lane, 0.0f, bias4);
+        }
       }
     }
     if (nk == 0) SUB_STAMP(16 + tt);               // (behind the tile's epilogue)
@@ -1502,6 +1684,9 @@ __device__ long long g_wg_span[1024][2];
 template <int R, int PROG, bool DROP = false, int MM = 0>
 __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAllT<nw_of(R)>* __restrict__ recs, const int block) {
   constexpr int NW = nw_of(R), NT = NW * 64;        // waves / threads of the workgroup
+#if TC_PRIO == 2
+  if constexpr (R == 32) { if ((__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & TC_PRIO_MASK) == 0) __builtin_amdgcn_s_setprio(3); }
+#endif
   constexpr bool PL = R == 32;                      // the activation units hold planes (act_ld4 / act_st4)
   static_assert((MM == 0 && R <= 16) || (MM == 1 && R >= 16 && PROG != PROG_PROLOGUE), "the f16 two-plane path exists for 16- and 32-row tiles (and is the only one at 32)");
   extern __shared__ __align__(16) unsigned char smem_raw[];

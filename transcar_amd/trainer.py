@@ -168,10 +168,12 @@ class FusionTrainer:
         # frames as ONE batched launch sequence (16-row tiles on the f16 matrix cores, the inference rate), every
         # frame with the dropout masks of its own seed (tc_head_options.dropout_seed_stride); the iterations then
         # consume the batch frame by frame.  The decoder's arithmetic is fixed by the depth, not by whether a frame
-        # was prefetched (`decoder_tile_rows`): with P > 1 a frame that missed the look-ahead runs the same 16-row
+        # was prefetched (`decoder_tile_rows`): with P > 1 a frame that missed the look-ahead runs the same 16- / 32-row
         # kernels alone, so losses and parameters do not depend on the schedule.
+        # Round 5: a look-ahead of more than 4 096 rows (nine frames: 8 100) runs the 32-row tiles, like inference.
         self.prefetch_depth = max(1, int(prefetch_depth))
-        self.decoder_tile_rows = 16 if self.prefetch_depth > 1 else None
+        rows = self.prefetch_depth * int(head.num_query)
+        self.decoder_tile_rows = (32 if rows > 4096 else 16) if self.prefetch_depth > 1 else None
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
