@@ -1812,7 +1812,7 @@ def main(argv=None):
                 line['frames_per_launch_sweep'] = sweep_side_run(head, dev, args, pipe.frames_per_launch,
                                                                  streams=pipe.streams)
             if pipe is not None and not args.main_only and args.batch == 1:
-                if args.matrix_path != 'f32' and pipe.tile_rows_of() == 16:
+                if args.matrix_path != 'f32' and pipe.tile_rows_of() >= 16:
                     line['f32_path'] = f32_path_side_run(head, dev, args, pipe.frames_per_launch, streams=pipe.streams)
                 if args.shapes == 'res101' and not args.no_configs:
                     # configs[4] (VoVNet FPN shapes) and configs[2] (a training iteration) at one GPU, in the same line

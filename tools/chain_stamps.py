@@ -28,7 +28,7 @@ def main():
     torch.set_grad_enabled(False)
     head, _ = bench.build_head(dev)
     batch = int(os.environ.get('STAMPS_BATCH', '1'))        # 4: the 16-row tiles
-    inp = bench.make_inputs(head, dev, 'res101', batch, seed=1)
+    inp = bench.make_inputs(head, dev, os.environ.get('STAMPS_SHAPES', 'res101'), batch, seed=1)   # 'tiny': every tap an L2 hit
     lib = L.lib()
     lib.tc_debug_chain_stamps.restype = C.c_int
     lib.tc_debug_chain_stamps.argtypes = [C.c_void_p]
@@ -117,7 +117,7 @@ def main():
         print('camera sampling (cycles relative to the entry of cam_sample_row): step entry, projected + ballot, '
               'taps issued (last visible camera), accumulated, row done, rows done, pair counter added')
         for w in range(4):
-            print('  wave%d:' % w, ' '.join('%6d' % (cb[w, j] - cb[w, 0]) for j in (5, 1, 2, 3, 4, 6, 7)))
+            print('  wave%d:' % w, ' '.join('%6d' % (cb[w, j] - cb[w, 5]) for j in (5, 0, 1, 2, 3, 4, 6, 7)), ' (relative to the step entry; row stamps: the wave\'s LAST row)')
     print('%-14s %s' % ('step', '   '.join('wave%d work / wait' % w for w in range(NWV))))
     n = min(len(names), 31)
     for i in range(n):
