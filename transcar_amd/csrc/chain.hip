@@ -1684,6 +1684,16 @@ __device__ long long g_wg_span[1024][2];
 template <int R, int PROG, bool DROP = false, int MM = 0>
 __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAllT<nw_of(R)>* __restrict__ recs, const int block) {
   constexpr int NW = nw_of(R), NT = NW * 64;        // waves / threads of the workgroup
+#if defined(TC_STAGGER)
+  // experiment: every second workgroup of a 32-row decoder launch starts TC_STAGGER x 4096 cycles late (the camera
+  // sampling windows of the two halves of the chip then do not coincide)
+  if constexpr (R == 32 && PROG == PROG_DECODER) {
+    if (blockIdx.x & 1) {
+#pragma unroll 1
+      for (int i = 0; i < TC_STAGGER; ++i) __builtin_amdgcn_s_sleep(64);
+    }
+  }
+#endif
 #if TC_PRIO == 2
   if constexpr (R == 32) { if ((__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & TC_PRIO_MASK) == 0) __builtin_amdgcn_s_setprio(3); }
 #endif
