@@ -109,6 +109,9 @@ def parse(argv=None):
                     help='with --train: frames of look-ahead whose FROZEN decoder forward runs as one batched launch '
                          'sequence (FusionTrainer(prefetch_depth=...)); 0 = the frames whose 16-row tiles are resident at '
                          'once (9 for 900 queries), 1 = round 3\'s one-frame look-ahead')
+    ap.add_argument('--deterministic', action='store_true',
+                    help='--train: FusionTrainer(deterministic=True) -- the backward accumulates order-free '
+                         '(tc_radar_train_bwd_fused_det: bit-identical gradients run to run); the default keeps the float atomics')
     ap.add_argument('--no-prefetch', action='store_true',
                     help='with --train: do not enqueue the next iteration\'s frozen decoder forward while the host '
                          'solves the assignment')
@@ -1314,7 +1317,7 @@ class LookAheadFrames:
         return dict(feats_nhwc=w['nhwc'], lidar2img=w['l2i'], img_hw=w['hw'], tokens=w['tokens'], pad_mult=w['pad_mult'])
 
 
-def _train_setup(head, dev, rank, B, prefetch_depth=1):
+def _train_setup(head, dev, rank, B, prefetch_depth=1, deterministic=False):
     """A trainable copy of the head (tools/train.py's freeze list), its FusionTrainer and B synthetic GT sets."""
     from transcar_amd.trainer import FusionTrainer
     cfg = configs.head_cfg()
@@ -1332,7 +1335,7 @@ def _train_setup(head, dev, rank, B, prefetch_depth=1):
     was = torch.is_grad_enabled()
     torch.set_grad_enabled(True)
     try:
-        tr = FusionTrainer(thead, prefetch_depth=prefetch_depth)
+        tr = FusionTrainer(thead, prefetch_depth=prefetch_depth, deterministic=deterministic)
     finally:
         torch.set_grad_enabled(was)
     return thead, tr, gts, lbs
@@ -1347,7 +1350,7 @@ def train_bench(args, head, inp, dev, rank, world, affinity=None):
     B = args.batch
     depth = 1 if (args.train_autograd or args.no_prefetch) else \
         (args.prefetch_depth or max(1, auto_frames_per_launch(head, dev) // B))
-    thead, tr, gts, lbs = _train_setup(head, dev, rank, B, depth)
+    thead, tr, gts, lbs = _train_setup(head, dev, rank, B, depth, deterministic=args.deterministic)
     torch.set_grad_enabled(True)
     last = {}
 
@@ -1384,6 +1387,7 @@ def train_bench(args, head, inp, dev, rank, world, affinity=None):
         exposed = {'median': gaps[len(gaps) // 2], 'max': gaps[-1], 'iterations': len(gaps)}
     line = {
         'exposed_collective_ms': exposed,
+        'deterministic': bool(args.deterministic),
         'per_rank': per_rank_summary(own, args.steps, B), 'cpu_affinity': affinity,
         'metric': 'training frames/sec: fusion head iteration (frozen DETR3D decoder fwd + radar '
                   'stack fwd/bwd + loss + grad all-reduce + AdamW), FPN features resident in HBM',
@@ -1411,7 +1415,8 @@ def train_bench(args, head, inp, dev, rank, world, affinity=None):
             # HBM-side bytes per iteration, measured by two --pmc child passes of this command (world size 1 only: the
             # children run beside nothing then)
             if world == 1 and not args.no_live_pmc and not args.train_autograd:
-                tt = live_train_traffic(extra_args=('--shapes', args.shapes) + (('--no-prefetch',) if args.no_prefetch else ()))
+                tt = live_train_traffic(extra_args=('--shapes', args.shapes) + (('--no-prefetch',) if args.no_prefetch else ()) +
+                                        (('--deterministic',) if args.deterministic else ()))
                 if tt is not None:
                     roof['traffic'], roof['traffic_source'] = tt['traffic_bytes'], 'this run'
                     roof['traffic_detail'] = dict(tt, unit='bytes per iteration = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 summed '

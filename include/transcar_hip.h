@@ -34,7 +34,7 @@ extern "C" {
 #define TC_MAX_LEVELS 4
 #define TC_MAX_LAYERS 8
 #define TC_MAX_RADAR_LAYERS 3
-#define TC_ABI_VERSION 10
+#define TC_ABI_VERSION 11
 
 typedef void* tc_stream_t;
 
@@ -593,6 +593,24 @@ int tc_radar_train_bwd_fused_ex(const tc_head_weights* w, const tc_head_weights*
                                 void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes,
                                 float dropout_p, unsigned long long dropout_seed, const float* layer_losses,
                                 float* layer_losses_clean, int flags, tc_stream_t stream);
+/* ABI 11: the same backward with ORDER-FREE accumulation -- what torch calls a deterministic algorithm.  The backward adds
+ * partial sums from many workgroups into one element in five places (weight-gradient row chunks, bias column sums,
+ * LayerNorm parameter gradients of the row chain and of the token side, dK | dV of the attention backward); with float
+ * atomics the rounding depends on the arrival order and two runs differ in the last bits.  Here every such add is an
+ * INTEGER atomic on a 64-bit fixed-point shadow of its target (units of 2^-40: exact for |v| >= 2^-16, 9e-13 absolute
+ * below; |v| < 8.4e6), the token side's split reductions run unsplit, and two small launches add the shadows back:
+ * bit-identical gradients from identical inputs, on any schedule.  (tools/train.py:238-260 trains with torch's float
+ * atomics, i.e. without this guarantee; FusionTrainer(deterministic=True) and the tests that compare runs use it.)
+ * grad_base / grad_elems: the span that holds EVERY tensor of `grads` (the flat bucket); shadow: at least grad_elems +
+ * 3 * B * T * 2 * embed_dims + 8 64-bit words; the first grad_elems + 3 B T 2 embed_dims must be zero on entry -- the
+ * call leaves them zero -- the last 8 are scratch. */
+int tc_radar_train_bwd_fused_det(const tc_head_weights* w, const tc_head_weights* grads, const float* hs_last,
+                                 const float* last_box, const float* radar_tokens, int B, int T, int pad_mult,
+                                 const float* all_bbox_preds, const float* d_all_cls, const float* d_all_box,
+                                 void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes,
+                                 float dropout_p, unsigned long long dropout_seed, const float* layer_losses,
+                                 float* layer_losses_clean, int flags, float* grad_base, size_t grad_elems,
+                                 long long* shadow, size_t shadow_elems, tc_stream_t stream);
 /* One launch for BOTH weight layouts a fused training iteration needs from the current parameters: the 4x4x1 packed
  * copy of the trainable weights inside `packed_view` (tc_head_repack_trainable_ex(w, view, 1)) and the transposed
  * packed weights of the three fusion layers inside the backward's workspace (tc_radar_train_bwd_workspace_bytes(w, B,

@@ -985,6 +985,64 @@ def test_decoder_prefetch_changes_nothing_but_the_schedule(A, golden_dir):
     assert_params_equal_up_to_adam_noise(res[False][1], res[True][1], res['again'][1], lr=1e-5, steps=3, slack=1e-5)
 
 
+def test_deterministic_backward_is_bit_identical_on_any_schedule(A, golden_dir):
+    """FusionTrainer(deterministic=True) (round 5; tc_radar_train_bwd_fused_det): every partial sum the
+    backward adds with a float atomic -- weight-gradient row chunks, bias column sums, LayerNorm parameter gradients of
+    the row chain and the token side, dK | dV of the attention backward -- goes through an integer atomic on a fixed-point
+    shadow, so the sums do not depend on the order the workgroups arrive in.
+    (a) one backward, twice from the same state: gradients torch.equal (the float-atomic mode is compared with the same
+        code and is allowed to differ -- and must agree with the deterministic gradients to 2e-6 of their scale);
+    (b) three optimizer steps with dropout, with and without the decoder look-ahead on its side stream, and a repeat:
+        losses and parameters torch.equal -- the `==` the schedule test of the atomic mode cannot ask for."""
+    from transcar_amd import ops
+    from transcar_amd.trainer import FusionTrainer
+    feats, metas, gt, labels = frame_inputs(golden_dir)
+    frames = []
+    for i in range(2):
+        f = feats if i == 0 else [torch.from_numpy(x).to(dev()) for x in synth.make_feats('tiny', seed=9, smooth=(4, 6))]
+        frames.append(dict(feats_nhwc=[ops.to_nhwc(x) for x in f], lidar2img=ops.lidar2img_tensor(metas, dev()),
+                           img_hw=metas[0]['img_shape'][0][:2]))
+    # (a)
+    grads = {}
+    for mode in ('det', 'det2', 'atomic'):
+        h = train_head(golden_dir)
+        tokens, pad_mult = h.radar_tokens(metas, dev())
+        tr = FusionTrainer(h, dropout=0.1, seed=2, lr=1e-5, deterministic=mode != 'atomic')
+        fr = frames[0]
+        tr.step_fused_nhwc(fr['feats_nhwc'], fr['lidar2img'], fr['img_hw'], tokens, pad_mult, [gt], [labels], update=False)
+        torch.cuda.synchronize()
+        grads[mode] = tr.bucket.grads.clone()
+        if mode != 'atomic':
+            assert int(tr._shadow[:-8].abs().max()) == 0        # the call leaves its shadow zero (the last 8 words: scratch)
+    assert float(grads['det'].abs().max()) > 0
+    assert torch.equal(grads['det'], grads['det2'])
+    scale = float(grads['det'].abs().max())
+    assert float((grads['det'] - grads['atomic']).abs().max()) <= 2e-6 * scale
+    # (b)
+    res = {}
+    for pre in (False, 'again', True):
+        h = train_head(golden_dir)
+        tokens, pad_mult = h.radar_tokens(metas, dev())
+        for fr in frames:
+            fr.update(tokens=tokens, pad_mult=pad_mult)
+        tr = FusionTrainer(h, dropout=0.1, seed=2, lr=1e-3, deterministic=True)
+        hist = []
+        for it in range(3):
+            cur, nxt = frames[it % 2], frames[(it + 1) % 2]
+            losses = tr.step_fused_nhwc(cur['feats_nhwc'], cur['lidar2img'], cur['img_hw'], cur['tokens'], cur['pad_mult'],
+                                        [gt], [labels], prefetch=nxt if pre is True else None)
+            hist.append(losses)
+        torch.cuda.synchronize()
+        res[pre] = (hist, tr.bucket.params.clone())
+    for other in ('again', True):
+        assert torch.equal(res[False][1], res[other][1]), other
+        for a_, b_ in zip(res[False][0], res[other][0]):
+            for k in a_:
+                # the loss VALUES still meet in float atomics of the loss kernel (they are reported, nothing is derived
+                # from them): equal to rounding
+                assert abs(float(a_[k]) - float(b_[k])) <= 2e-6 * max(1.0, abs(float(a_[k]))), (other, k)
+
+
 @pytest.mark.parametrize('rows', [16, 32])
 def test_batched_decoder_lookahead_is_the_single_frame_decoder(A, golden_dir, rows):
     """FusionTrainer(prefetch_depth=P) (round 4): the FROZEN decoder of the next P frames runs as ONE

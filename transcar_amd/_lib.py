@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get('TRANSCAR_HIP_LIB') or os.path.join(_HERE, 'lib', 'lib
 TC_MAX_LEVELS = 4
 TC_MAX_LAYERS = 8
 TC_MAX_RADAR_LAYERS = 3
-TC_ABI_VERSION = 10
+TC_ABI_VERSION = 11
 
 c_fp = C.c_void_p      # device pointers travel as integers
 
@@ -211,6 +211,9 @@ SIGNATURES = {
     'tc_radar_train_bwd_fused_ex': (_i, [_P(tc_head_weights), _P(tc_head_weights), _vp,
                                          _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp, _sz,
                                          _f, C.c_ulonglong, _vp, _vp, _i, _vp]),
+    'tc_radar_train_bwd_fused_det': (_i, [_P(tc_head_weights), _P(tc_head_weights), _vp,
+                                          _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp, _sz,
+                                          _f, C.c_ulonglong, _vp, _vp, _i, _vp, _sz, _vp, _sz, _vp]),
     'tc_radar_train_repack': (_i, [_P(tc_head_weights), _P(tc_head_weights), _vp, _sz, _i, _i, _vp]),
     'tc_dropout_mask': (_i, [_f, C.c_ulonglong, _i, _sz, _vp, _vp]),
     'tc_normalize_bbox': (_i, [_vp, _i, _vp, _vp]),

@@ -370,6 +370,9 @@ struct ChainDev {
   const float* loss_vals;      // [layers, 2] (cls, bbox) losses of the iteration or null: a layer whose loss is not
                                // finite sends no gradient down (HEAD:915-916 zeroes such a loss), non-finite elements are 0
   float* loss_out;             // or null: loss_vals with NaN -> 0 for the iteration's loss dict (workgroup 0 writes it)
+  const DetAcc* detp;          // backward: deterministic accumulation of dgamma / dbeta / dK | dV (common.hpp) -- a
+                               // DEVICE copy of the ranges, or null (by value its 12 scalars cost the backward
+                               // chain 29 more spilled SGPRs: +7 us per launch in the default mode)
 };
 // ... plus what only the host-side resolver needs
 struct ChainK : ChainDev {
@@ -2406,7 +2409,8 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAllT<nw_
             float t = scratch[threadIdx.x];
 #pragma unroll
             for (int w = 1; w < NW; ++w) t += scratch[w * 256 + threadIdx.x];
-            unsafeAtomicAdd(gdst + threadIdx.x, t);
+            if (k.detp != nullptr) acc_add(*k.detp, gdst + threadIdx.x, t);
+            else unsafeAtomicAdd(gdst + threadIdx.x, t);
           }
         }
       } break;
@@ -2431,7 +2435,8 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAllT<nw_
             dq = radar_attn_bwd_row(cxy[0], cxy[1], bx[3], bx[6], bx[7], k.rmin[layer], k.rmax[layer], q4,
                                     k.tokens + (size_t)b * k.T * k.RI, k.RI, uptr(r.p2) + (size_t)b * k.T * 512,
                                     const_cast<float*>(uptr(r.p3)) + (size_t)b * k.T * 512, 512, k.T, k.pad_mult, dO, o4,
-                                    dk, grow, lane);
+                                    dk, grow, lane,
+                                    k.detp != nullptr ? det_shadow_of(*k.detp, uptr(r.p3) + (size_t)b * k.T * 512) : nullptr);
             dq.x *= k.qscale; dq.y *= k.qscale; dq.z *= k.qscale; dq.w *= k.qscale;
           }
           *reinterpret_cast<float4*>(dqb + row * LD2 + 4 * lane) = dq;
@@ -2998,6 +3003,7 @@ int launch_radar_chain_bwd(const RadarBwdChainArgs& a, hipStream_t s) {
   k.hits = const_cast<int*>(a.hits);
   k.qscale = a.qscale; k.tokens = a.tokens; k.RI = a.RI; k.T = a.T; k.pad_mult = a.pad_mult;
   k.rdrop = a.drop;
+  k.detp = a.det_device;
   k.tile_rows = a.tile_rows == 8 || (a.tile_rows == 0 && a.M > 1024) ? 8 : 4;
   return launch(k, s, "chain(radar backward)");
 }

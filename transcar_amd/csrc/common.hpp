@@ -115,6 +115,40 @@ __device__ __forceinline__ float ldg1(const float* p) { return *(const TC_GLOBAL
 __device__ __forceinline__ void stg1(float* p, float v) { *(TC_GLOBAL float*)(p) = v; }
 
 
+// Deterministic accumulation (round 5, tc_radar_train_bwd_fused_det).  A value that would be added with a FLOAT atomic --
+// whose sum depends on the order the adds arrive in -- is rounded to a 64-bit fixed-point number (units of 2^-40; exact for
+// |v| >= 2^-16, an absolute 9e-13 below) and added with an INTEGER atomic into a shadow of its target: integer sums are
+// exact, so the result does not depend on the order.  det_flush adds the shadows back into the targets (and zeroes them).
+// Two address ranges: the flat gradient bucket, and the backward workspace's dK | dV accumulators.  shadow[r] == nullptr:
+// off (plain float atomics).  |v| must stay below 2^23 (8.4e6); a non-finite v contributes nothing a float would keep.
+struct DetAcc {
+  const float* lo[2]; const float* hi[2]; long long* shadow[2];
+};
+constexpr float DET_SCALE = 1099511627776.0f;        // 2^40
+// the shadow word of *p, or nullptr (p outside both ranges / mode off): resolved ONCE per target tensor where the target
+// is known at launch (the GEMMs' C and column sums, LayerNorm parameter gradients, a sample's dK | dV) -- a range test
+// per atomic cost the float-atomic default 2 % of an iteration
+__host__ __device__ __forceinline__ long long* det_shadow_of(const DetAcc& d, const float* p) {
+  for (int r = 0; r < 2; ++r)
+    if (d.shadow[r] != nullptr && p >= d.lo[r] && p < d.hi[r]) return d.shadow[r] + (p - d.lo[r]);
+  return nullptr;
+}
+// *p += v: through the shadow word sp (of p) when there is one (wave-uniform test), a float atomic otherwise
+__device__ __forceinline__ void acc_add_at(long long* sp, float* p, float v) {
+  if (sp != nullptr) atomicAdd(reinterpret_cast<unsigned long long*>(sp), (unsigned long long)__float2ll_rn(v * DET_SCALE));
+  else unsafeAtomicAdd(p, v);
+}
+__device__ __forceinline__ void acc_add(const DetAcc& d, float* p, float v) {
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+    if (d.shadow[r] != nullptr && p >= d.lo[r] && p < d.hi[r]) {
+      atomicAdd(reinterpret_cast<unsigned long long*>(d.shadow[r] + (p - d.lo[r])),
+                (unsigned long long)__float2ll_rn(v * DET_SCALE));
+      return;
+    }
+  unsafeAtomicAdd(p, v);
+}
+
 // ---- dropout (training): counter-based Bernoulli masks ----------------------
 // keep(seed, site, idx): ONE splitmix64 of (seed, site, idx / 4) decides the four elements 4 (idx / 4) .. + 3 from its
 // four 16-bit fields (field idx % 4 >= round(p * 2^16)): the forward and the backward regenerate the same mask from

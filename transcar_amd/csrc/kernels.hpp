@@ -160,6 +160,7 @@ struct RadarBwdChainArgs {
   float qscale;
   DropK drop;
   int tile_rows = 0;
+  const DetAcc* det_device = nullptr;          // deterministic mode: a device copy of the thread's DetAcc (launch_det_store)
 };
 int launch_radar_chain_bwd(const RadarBwdChainArgs& a, hipStream_t s);
 // order of the tape pointer arrays above (= chain.hip TSel)
@@ -215,6 +216,21 @@ int launch_linear_bwd_weight(const float* x, const float* dy, const float* relu_
 struct WeightJob { const float* x; const float* dy; float* dw; float* db; int M, K, N; const float* relu = nullptr; /* dy is zeroed where relu <= 0 */
                    int ldx = 0; /* row stride of x (0: K) -- the first K columns of a wider matrix */ };
 int launch_linear_bwd_weight_group(const WeightJob* jobs, int n, hipStream_t s);
+// Deterministic accumulation (common.hpp DetAcc): the launchers of the backward (bwd GEMMs, LayerNorm backward, the
+// backward row chain) hand the calling thread's current DetAcc to their kernels.  tc_radar_train_bwd_fused_det sets it
+// for the duration of ITS call (DetScope) -- per call, per thread: not a process-wide switch.
+DetAcc& current_det();
+struct DetScope {
+  DetAcc saved;
+  explicit DetScope(const DetAcc& d) : saved(current_det()) { current_det() = d; }
+  ~DetScope() { current_det() = saved; }
+  DetScope(const DetScope&) = delete;
+  DetScope& operator=(const DetScope&) = delete;
+};
+// targets[i] += shadow[i] * 2^-40; shadow[i] = 0, for range r of d (one launch)
+int launch_det_flush(const DetAcc& d, int range, hipStream_t s);
+// *dst (device memory) = d, stream-ordered: the backward row chain reads the ranges from there
+int launch_det_store(const DetAcc& d, DetAcc* dst, hipStream_t s);
 int launch_ln256_bwd(const float* a, const float* b, const float* gamma, const float* dy,
                      const float* relu_out, float* dz, float* dgamma, float* dbeta, int M,
                      hipStream_t s);

@@ -412,7 +412,8 @@ __device__ __forceinline__ float head_sum8(float s) {      // 8 lanes = one 32-c
 __device__ __forceinline__ float4 radar_attn_bwd_row(float cx, float cy, float b3, float b6, float b7, float rmin,
                                                      float rmax, float4 q4, const float* rxy, int ld_xy,
                                                      const float* kv, float* dkv, int ldkv, int T, int pad_mult,
-                                                     float4 dO, float4 o4, const DropK& drop, int row, int lane) {
+                                                     float4 dO, float4 o4, const DropK& drop, int row, int lane,
+                                                     long long* sdkv = nullptr) {      // the shadow of dkv (DetAcc) or null
   // gate geometry: identical to radar_attn_row (HEAD:553-567)
   const float len = expf(b3);
   const float rs = -b6, rc = -b7;
@@ -463,10 +464,19 @@ __device__ __forceinline__ float4 radar_attn_bwd_row(float cx, float cy, float b
           const float pk = pj * keep;
           dq.x += ds * k4.x; dq.y += ds * k4.y; dq.z += ds * k4.z; dq.w += ds * k4.w;
           float* dk = dkv + (size_t)tok * ldkv + 4 * lane;
-          unsafeAtomicAdd(dk + 0, ds * q4.x); unsafeAtomicAdd(dk + 1, ds * q4.y);
-          unsafeAtomicAdd(dk + 2, ds * q4.z); unsafeAtomicAdd(dk + 3, ds * q4.w);
-          unsafeAtomicAdd(dk + 256, pk * dO.x); unsafeAtomicAdd(dk + 257, pk * dO.y);
-          unsafeAtomicAdd(dk + 258, pk * dO.z); unsafeAtomicAdd(dk + 259, pk * dO.w);
+          if (sdkv != nullptr) {       // deterministic mode (wave-uniform): integer atomics on the shadow of dkv
+            unsigned long long* sk = reinterpret_cast<unsigned long long*>(sdkv + (size_t)tok * ldkv + 4 * lane);
+            auto fx = [](float v) { return (unsigned long long)__float2ll_rn(v * DET_SCALE); };
+            atomicAdd(sk + 0, fx(ds * q4.x)); atomicAdd(sk + 1, fx(ds * q4.y));
+            atomicAdd(sk + 2, fx(ds * q4.z)); atomicAdd(sk + 3, fx(ds * q4.w));
+            atomicAdd(sk + 256, fx(pk * dO.x)); atomicAdd(sk + 257, fx(pk * dO.y));
+            atomicAdd(sk + 258, fx(pk * dO.z)); atomicAdd(sk + 259, fx(pk * dO.w));
+          } else {
+            unsafeAtomicAdd(dk + 0, ds * q4.x); unsafeAtomicAdd(dk + 1, ds * q4.y);
+            unsafeAtomicAdd(dk + 2, ds * q4.z); unsafeAtomicAdd(dk + 3, ds * q4.w);
+            unsafeAtomicAdd(dk + 256, pk * dO.x); unsafeAtomicAdd(dk + 257, pk * dO.y);
+            unsafeAtomicAdd(dk + 258, pk * dO.z); unsafeAtomicAdd(dk + 259, pk * dO.w);
+          }
         }
       }
     }

@@ -59,7 +59,8 @@ __device__ __forceinline__ float bg_load_a(const BwdGemmK& p, int gi, int gr, in
 // contiguous index and base address a multiple of 4 floats -- checked by the launchers); the scalar
 // variant (one predicated 4-byte load per element) remains for the 10- / 24-wide heads.
 template <int MODE, int BN, bool VEC>
-__device__ __forceinline__ void bwd_gemm_body(const BwdGemmK& p, const int bx, const int by, const int bz, const int gz) {
+__device__ __forceinline__ void bwd_gemm_body(const BwdGemmK& p, const int bx, const int by, const int bz, const int gz,
+                                              const DetAcc& det) {      // det: deterministic accumulation of the atomic stores, or all null
   constexpr int NT = BN / 16;
   constexpr int AE = 64 * BG_RK / 256;      // A elements per thread and step (8)
   constexpr int BE = BN * BG_RK / 256;      // B elements per thread and step (8 or 4)
@@ -186,28 +187,46 @@ __device__ __forceinline__ void bwd_gemm_body(const BwdGemmK& p, const int bx, c
     __syncthreads();
   }
   const bool atomic = MODE == BWD_WEIGHT || gz > 1;
+  long long* const sC = atomic ? det_shadow_of(det, p.C) : nullptr;      // (C lies inside one range or outside both)
+  if (sC != nullptr) {           // deterministic mode (wave-uniform): integer atomics on the shadow of C
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int col = j0 + 16 * t + (lane & 15);
+    for (int t = 0; t < NT; ++t) {
+      const int col = j0 + 16 * t + (lane & 15);
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int row = i0 + 16 * wave + 4 * (lane >> 4) + reg;
-      if (row < p.I && col < p.J) {
-        float v = acc[t][reg] * p.alpha;
-        float* c = p.C + (size_t)row * p.ldC + col;
-        if (p.cmask != nullptr && p.cmask[(size_t)row * p.ldC + col] <= 0.f) v = 0.f;
-        if (atomic) unsafeAtomicAdd(c, v);
-        else if (p.accumulate) *c += v;
-        else *c = v;
+      for (int reg = 0; reg < 4; ++reg) {
+        const int row = i0 + 16 * wave + 4 * (lane >> 4) + reg;
+        if (row < p.I && col < p.J) {
+          float v = acc[t][reg] * p.alpha;
+          if (p.cmask != nullptr && p.cmask[(size_t)row * p.ldC + col] <= 0.f) v = 0.f;
+          atomicAdd(reinterpret_cast<unsigned long long*>(sC + ((size_t)row * p.ldC + col)),
+                    (unsigned long long)__float2ll_rn(v * DET_SCALE));
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int col = j0 + 16 * t + (lane & 15);
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int row = i0 + 16 * wave + 4 * (lane >> 4) + reg;
+        if (row < p.I && col < p.J) {
+          float v = acc[t][reg] * p.alpha;
+          float* c = p.C + (size_t)row * p.ldC + col;
+          if (p.cmask != nullptr && p.cmask[(size_t)row * p.ldC + col] <= 0.f) v = 0.f;
+          if (atomic) unsafeAtomicAdd(c, v);
+          else if (p.accumulate) *c += v;
+          else *c = v;
+        }
       }
     }
   }
-  if (do_colsum && tid < 64 && i0 + tid < p.I) unsafeAtomicAdd(p.colsum + i0 + tid, csum);
+  if (do_colsum && tid < 64 && i0 + tid < p.I) acc_add_at(det_shadow_of(det, p.colsum + i0 + tid), p.colsum + i0 + tid, csum);
 }
 
 template <int MODE, int BN, bool VEC>
-__global__ __launch_bounds__(256) void bwd_gemm_kernel(BwdGemmK p) {
-  bwd_gemm_body<MODE, BN, VEC>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z);
+__global__ __launch_bounds__(256) void bwd_gemm_kernel(BwdGemmK p, DetAcc det) {
+  bwd_gemm_body<MODE, BN, VEC>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z, det);
 }
 
 // Every weight gradient of an iteration in ONE launch (two: the 16-byte-load variant and the scalar one for the
@@ -216,7 +235,7 @@ __global__ __launch_bounds__(256) void bwd_gemm_kernel(BwdGemmK p) {
 // for a 900 x 256 x 256 product.)
 constexpr int WGROUP_MAX = 48;
 struct WGroupItem { BwdGemmK p; int first_block, gx, gy, gz; };
-struct WGroupK { WGroupItem it[WGROUP_MAX]; int n; };
+struct WGroupK { WGroupItem it[WGROUP_MAX]; int n; DetAcc det; };
 template <bool VEC>
 __global__ __launch_bounds__(256) void bwd_weight_group_kernel(WGroupK g) {
   int i = 0;
@@ -228,7 +247,7 @@ __global__ __launch_bounds__(256) void bwd_weight_group_kernel(WGroupK g) {
   const int bx = b % it.gx; b /= it.gx;
   const int by = b % it.gy;
   const int bz = b / it.gy;
-  bwd_gemm_body<BWD_WEIGHT, 64, VEC>(it.p, bx, by, bz, it.gz);
+  bwd_gemm_body<BWD_WEIGHT, 64, VEC>(it.p, bx, by, bz, it.gz, g.det);
 }
 
 static bool bg_vec_ok(const BwdGemmK& p, int contiguous_a_extent) {
@@ -242,6 +261,7 @@ int launch_linear_bwd_data(const float* dy, const float* relu_out, const int* ro
                            int N, float alpha, int accumulate, hipStream_t s) {
   TC_REQUIRE(M > 0 && K > 0 && N > 0, "linear_bwd_data: M=%d K=%d N=%d", M, K, N);
   BwdGemmK p;
+  const DetAcc det = current_det();
   p.A = dy; p.relu = relu_out; p.gate = row_gate; p.Bm = w; p.cmask = in_relu_mask; p.C = dx;
   p.colsum = nullptr; p.ldA = N; p.ldB = K; p.ldC = K; p.I = M; p.J = K; p.R = N;
   p.rchunk = ((N + BG_RK - 1) / BG_RK) * BG_RK; p.accumulate = accumulate; p.alpha = alpha;
@@ -252,16 +272,17 @@ int launch_linear_bwd_data(const float* dy, const float* relu_out, const int* ro
   // dmem over n = 512: 32 workgroups x 16 k-steps = 14 us of latency): when the result is ADDED to dx anyway, split
   // the reduction over gz workgroups that add their parts with float atomics (round 4: 3 x 14 -> 3 x 6 us)
   int gz = 1;
-  if (accumulate && !wide && mt * ((K + 31) / 32) <= 64 && N >= 256) {
+  // (deterministic mode: no split -- a single writer per element adds in place)
+  if (accumulate && !wide && mt * ((K + 31) / 32) <= 64 && N >= 256 && det.shadow[0] == nullptr && det.shadow[1] == nullptr) {
     gz = N >= 512 ? 4 : 2;
     p.rchunk = (((N + gz - 1) / gz + BG_RK - 1) / BG_RK) * BG_RK;
     gz = (N + p.rchunk - 1) / p.rchunk;
   }
   const dim3 grid(wide ? (K + 63) / 64 : (K + 31) / 32, mt, gz);
-  if (wide && vec) hipLaunchKernelGGL((bwd_gemm_kernel<BWD_DATA, 64, true>), grid, dim3(256), 0, s, p);
-  else if (wide) hipLaunchKernelGGL((bwd_gemm_kernel<BWD_DATA, 64, false>), grid, dim3(256), 0, s, p);
-  else if (vec) hipLaunchKernelGGL((bwd_gemm_kernel<BWD_DATA, 32, true>), grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((bwd_gemm_kernel<BWD_DATA, 32, false>), grid, dim3(256), 0, s, p);
+  if (wide && vec) hipLaunchKernelGGL((bwd_gemm_kernel<BWD_DATA, 64, true>), grid, dim3(256), 0, s, p, det);
+  else if (wide) hipLaunchKernelGGL((bwd_gemm_kernel<BWD_DATA, 64, false>), grid, dim3(256), 0, s, p, det);
+  else if (vec) hipLaunchKernelGGL((bwd_gemm_kernel<BWD_DATA, 32, true>), grid, dim3(256), 0, s, p, det);
+  else hipLaunchKernelGGL((bwd_gemm_kernel<BWD_DATA, 32, false>), grid, dim3(256), 0, s, p, det);
   return check_launch("linear_bwd_data");
 }
 
@@ -270,15 +291,16 @@ int launch_linear_bwd_weight(const float* x, const float* dy, const float* relu_
                              float alpha, hipStream_t s) {
   TC_REQUIRE(M > 0 && K > 0 && N > 0, "linear_bwd_weight: M=%d K=%d N=%d", M, K, N);
   BwdGemmK p;
+  const DetAcc det = current_det();
   p.A = dy; p.relu = relu_out; p.gate = row_gate; p.Bm = x; p.cmask = nullptr; p.C = dw;
   p.colsum = db; p.ldA = N; p.ldB = K; p.ldC = K; p.I = N; p.J = K; p.R = M;
   p.rchunk = 64; p.accumulate = 1; p.alpha = alpha;
   TC_REQUIRE(dw != nullptr, "linear_bwd_weight: dw is NULL");
   const dim3 grid((K + 63) / 64, (N + 63) / 64, (M + p.rchunk - 1) / p.rchunk);
   if (bg_vec_ok(p, N))                      // A = dY[m][n]: contiguous along the output row index n
-    hipLaunchKernelGGL((bwd_gemm_kernel<BWD_WEIGHT, 64, true>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((bwd_gemm_kernel<BWD_WEIGHT, 64, true>), grid, dim3(256), 0, s, p, det);
   else
-    hipLaunchKernelGGL((bwd_gemm_kernel<BWD_WEIGHT, 64, false>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((bwd_gemm_kernel<BWD_WEIGHT, 64, false>), grid, dim3(256), 0, s, p, det);
   return check_launch("linear_bwd_weight");
 }
 
@@ -287,6 +309,7 @@ int launch_linear_bwd_weight_group(const WeightJob* jobs, int n, hipStream_t s) 
   WGroupK g[2];                      // [1]: 16-byte operand loads, [0]: scalar
   int blocks[2] = {0, 0};
   g[0].n = g[1].n = 0;
+  g[0].det = g[1].det = current_det();
   for (int i = 0; i < n; ++i) {
     const WeightJob& j = jobs[i];
     TC_REQUIRE(j.M > 0 && j.K > 0 && j.N > 0 && j.dw != nullptr && j.x != nullptr && j.dy != nullptr,
@@ -309,10 +332,40 @@ int launch_linear_bwd_weight_group(const WeightJob* jobs, int n, hipStream_t s) 
   return check_launch("linear_bwd_weight_group");
 }
 
+// ---- deterministic accumulation: the calling thread's scope and the flush ---------------------------------------
+DetAcc& current_det() {
+  static thread_local DetAcc d = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+  return d;
+}
+__global__ __launch_bounds__(256) void det_flush_kernel(float* dst, long long* shadow, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const long long v = shadow[i];
+    if (v != 0) {
+      dst[i] += (float)((double)v * (1.0 / (double)DET_SCALE));
+      shadow[i] = 0;
+    }
+  }
+}
+__global__ void det_store_kernel(DetAcc d, DetAcc* dst) { *dst = d; }
+int launch_det_store(const DetAcc& d, DetAcc* dst, hipStream_t s) {
+  hipLaunchKernelGGL(det_store_kernel, dim3(1), dim3(1), 0, s, d, dst);
+  return check_launch("det_store");
+}
+int launch_det_flush(const DetAcc& d, int range, hipStream_t s) {
+  TC_REQUIRE(range >= 0 && range < 2, "det_flush: range %d", range);
+  if (d.shadow[range] == nullptr) return 0;
+  const size_t n = (size_t)(d.hi[range] - d.lo[range]);
+  if (n == 0) return 0;
+  const int grid = (int)std::min<size_t>((n + 255) / 256, 2048);
+  hipLaunchKernelGGL(det_flush_kernel, dim3(grid), dim3(256), 0, s, const_cast<float*>(d.lo[range]), d.shadow[range], n);
+  return check_launch("det_flush");
+}
+
 // ---- LayerNorm(a (+b)) (+ReLU) backward, C = 256 ---------------------------
 struct LnBwdK {
   const float* a; const float* b; const float* gamma; const float* dy; const float* relu_out;
   float* dz; float* dgamma; float* dbeta; int M;
+  DetAcc det;
 };
 
 __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdK p) {
@@ -358,13 +411,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdK p) {
     }
     if (p.dgamma != nullptr) {
       float* dg = p.dgamma + 4 * lane;
-      unsafeAtomicAdd(dg, tg.x); unsafeAtomicAdd(dg + 1, tg.y);
-      unsafeAtomicAdd(dg + 2, tg.z); unsafeAtomicAdd(dg + 3, tg.w);
+      long long* sp = det_shadow_of(p.det, dg);
+      acc_add_at(sp, dg, tg.x); acc_add_at(sp ? sp + 1 : sp, dg + 1, tg.y);
+      acc_add_at(sp ? sp + 2 : sp, dg + 2, tg.z); acc_add_at(sp ? sp + 3 : sp, dg + 3, tg.w);
     }
     if (p.dbeta != nullptr) {
       float* dbp = p.dbeta + 4 * lane;
-      unsafeAtomicAdd(dbp, tb.x); unsafeAtomicAdd(dbp + 1, tb.y);
-      unsafeAtomicAdd(dbp + 2, tb.z); unsafeAtomicAdd(dbp + 3, tb.w);
+      long long* sp = det_shadow_of(p.det, dbp);
+      acc_add_at(sp, dbp, tb.x); acc_add_at(sp ? sp + 1 : sp, dbp + 1, tb.y);
+      acc_add_at(sp ? sp + 2 : sp, dbp + 2, tb.z); acc_add_at(sp ? sp + 3 : sp, dbp + 3, tb.w);
     }
   }
 }
@@ -374,6 +429,7 @@ int launch_ln256_bwd(const float* a, const float* b, const float* gamma, const f
                      hipStream_t s) {
   TC_REQUIRE(M > 0, "layernorm_bwd: M=%d", M);
   LnBwdK p;
+  p.det = current_det();
   p.a = a; p.b = b; p.gamma = gamma; p.dy = dy; p.relu_out = relu_out; p.dz = dz;
   p.dgamma = dgamma; p.dbeta = dbeta; p.M = M;
   const int grid = min((M + 3) / 4, 64);   // few workgroups: dgamma/dbeta meet in 512 atomics each
@@ -389,6 +445,7 @@ struct RadBwdK {
   float rmin, rmax, qscale;
   float* dq; float* dkv;
   DropK drop;                  // dropout on the attention probabilities (thr 0 = off)
+  DetAcc det;
 };
 
 __global__ __launch_bounds__(256) void radar_attn_bwd_kernel(RadBwdK p) {
@@ -404,7 +461,8 @@ __global__ __launch_bounds__(256) void radar_attn_bwd_kernel(RadBwdK p) {
   const float4 o4 = ld4(p.attn_out + (size_t)row * 256 + 4 * lane);
   const float4 dq = radar_attn_bwd_row(cx, cy, bx[3], bx[6], bx[7], p.rmin, p.rmax, q4,
                                        p.rxy + (size_t)b * p.T * p.ld_xy, p.ld_xy, p.kv + (size_t)b * p.T * p.ldkv,
-                                       p.dkv + (size_t)b * p.T * p.ldkv, p.ldkv, p.T, p.pad_mult, dO, o4, p.drop, row, lane);
+                                       p.dkv + (size_t)b * p.T * p.ldkv, p.ldkv, p.T, p.pad_mult, dO, o4, p.drop, row, lane,
+                                       det_shadow_of(p.det, p.dkv + (size_t)b * p.T * p.ldkv));
   st4(p.dq + (size_t)row * 256 + 4 * lane,
       make_float4(dq.x * p.qscale, dq.y * p.qscale, dq.z * p.qscale, dq.w * p.qscale));
 }
@@ -418,7 +476,7 @@ int launch_radar_attn_bwd(const RadarAttnArgs& a, float qscale, const float* d_a
   p.attn_out = a.attn_out; p.d_attn = d_attn;
   p.ldq = a.ldq; p.ldkv = a.ldkv; p.code = a.code; p.ld_xy = a.ld_xy; p.ld_c = a.ld_c;
   p.B = a.B; p.Q = a.Q; p.T = a.T; p.pad_mult = a.pad_mult; p.rmin = a.rmin; p.rmax = a.rmax;
-  p.qscale = qscale; p.dq = dq; p.dkv = dkv; p.drop = a.drop;
+  p.qscale = qscale; p.dq = dq; p.dkv = dkv; p.drop = a.drop; p.det = current_det();
   const int rows = a.B * a.Q;
   hipLaunchKernelGGL(radar_attn_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, p);
   return check_launch("radar_attn_bwd");

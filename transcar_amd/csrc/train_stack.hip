@@ -561,7 +561,18 @@ int tc_radar_train_bwd_fused_ex(const tc_head_weights* w, const tc_head_weights*
   a.nlayers = TC_MAX_RADAR_LAYERS; a.Q = Q; a.M = rows; a.code = code; a.ncls = ncls;
   a.qscale = 1.0f / sqrtf((float)(C / w->num_heads));
   a.drop = make_drop(dropout_p, dropout_seed, 0u, (unsigned)w->num_radar_tokens_ref);
+  {
+    // deterministic mode: the chain reads the ranges from a device copy behind the shadows (tc_radar_train_bwd_fused_det)
+    const DetAcc& d = current_det();
+    if (d.shadow[0] != nullptr && d.shadow[1] != nullptr) {
+      DetAcc* dev = reinterpret_cast<DetAcc*>(d.shadow[1] + (d.hi[1] - d.lo[1]));
+      TS_TRY(launch_det_store(d, dev, s));
+      a.det_device = dev;
+    }
+  }
   TS_TRY(launch_radar_chain_bwd(a, s));
+  // (deterministic mode: the chain's dK | dV sums sit in their shadow; the token side reads dK | dV next)
+  TS_TRY(launch_det_flush(current_det(), 1, s));
   // 4. the token side: dmem = sum_r dkv_r Wkv_r, then the encoders (data gradients only; weights below)
   for (int r = 0; r < TC_MAX_RADAR_LAYERS; ++r)
     TS_TRY(launch_linear_bwd_data(ws.dkv[r], nullptr, nullptr, w->radar[r].attn.in_proj.w + (size_t)C * C, nullptr, ws.dmem,
@@ -610,7 +621,42 @@ int tc_radar_train_bwd_fused_ex(const tc_head_weights* w, const tc_head_weights*
   job(t.u1, du, gpe.l3, rt, C, C);
   // radar_position_encoder.0 (Linear(3, C)): X = the tokens' first three columns (xyz), read in place
   job(radar_tokens, du0, gpe.l0, rt, 3, C, nullptr, RI);
-  return launch_linear_bwd_weight_group(jobs, n, s);
+  TS_TRY(launch_linear_bwd_weight_group(jobs, n, s));
+  return launch_det_flush(current_det(), 0, s);      // (deterministic mode: the bucket's sums back into the gradients)
+}
+
+// The same backward with ORDER-FREE accumulation: every float atomic of the backward -- the weight
+// gradients' row chunks, the bias column sums, the LayerNorm parameter gradients of the row chain and of the token side,
+// the attention backward's dK | dV -- becomes an integer atomic on a 2^-40 fixed-point shadow (common.hpp DetAcc), the
+// split reductions of the token side run unsplit, and two flush launches add the shadows back.  Two calls on the same
+// inputs give bit-identical gradients.  grad_base / grad_elems: the span that holds every tensor of `grads` (the flat
+// bucket); shadow: grad_elems + 3 * B * T * 2 * embed_dims + 8 64-bit words, the first grad_elems + 3 B T 2 C of them ZERO on
+// entry (the call leaves them zero; the last 8 are scratch).
+int tc_radar_train_bwd_fused_det(const tc_head_weights* w, const tc_head_weights* grads, const float* hs_last,
+                                 const float* last_box, const float* radar_tokens, int B, int T, int pad_mult,
+                                 const float* all_bbox_preds, const float* d_all_cls, const float* d_all_box,
+                                 void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes,
+                                 float dropout_p, unsigned long long dropout_seed, const float* layer_losses,
+                                 float* layer_losses_clean, int flags, float* grad_base, size_t grad_elems,
+                                 long long* shadow, size_t shadow_elems, tc_stream_t stream) {
+  TS_TRY(check(w, B, T));
+  TC_REQUIRE(grad_base != nullptr && shadow != nullptr && workspace != nullptr, "radar_train_bwd_fused_det: null argument");
+  BwdWs ws;
+  TC_REQUIRE(bwd_ws_layout(w, B, T, workspace, workspace_bytes, &ws) <= workspace_bytes,
+             "radar_train_bwd_fused_det: workspace too small");
+  const size_t dkv_elems = (size_t)TC_MAX_RADAR_LAYERS * B * T * 2 * w->embed_dims;
+  constexpr size_t kTail = (sizeof(DetAcc) + 7) / 8;          // a device copy of the ranges behind the shadows
+  TC_REQUIRE(shadow_elems >= grad_elems + dkv_elems + kTail, "radar_train_bwd_fused_det: shadow holds %zu words, %zu needed",
+             shadow_elems, grad_elems + dkv_elems + kTail);
+  TC_REQUIRE(ws.dkv[TC_MAX_RADAR_LAYERS - 1] + (size_t)B * T * 2 * w->embed_dims == ws.dkv[0] + dkv_elems,
+             "radar_train_bwd_fused_det: the dK | dV accumulators are not contiguous");
+  DetAcc d;
+  d.lo[0] = grad_base; d.hi[0] = grad_base + grad_elems; d.shadow[0] = shadow;
+  d.lo[1] = ws.dkv[0]; d.hi[1] = ws.dkv[0] + dkv_elems; d.shadow[1] = shadow + grad_elems;
+  DetScope scope(d);
+  return tc_radar_train_bwd_fused_ex(w, grads, hs_last, last_box, radar_tokens, B, T, pad_mult, all_bbox_preds, d_all_cls,
+                                     d_all_box, tape, tape_bytes, workspace, workspace_bytes, dropout_p, dropout_seed,
+                                     layer_losses, layer_losses_clean, flags, stream);
 }
 
 int tc_radar_train_bwd_fused(const tc_head_weights* w, const tc_head_weights* grads, const float* hs_last,

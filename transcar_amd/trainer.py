@@ -132,8 +132,14 @@ class FusionTrainer:
 
     def __init__(self, head, lr=1.5e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01,
                  max_norm=35.0, device_loss=True, dropout=0.1, seed=0, decoder_dropout=None,
-                 chain_forward=True, chain_backward=True, prefetch_depth=1):
+                 chain_forward=True, chain_backward=True, prefetch_depth=1, deterministic=False):
         self.head = head.freeze_decoder()
+        # deterministic=True (round 5): the fused backward accumulates order-free
+        # (tc_radar_train_bwd_fused_det: integer atomics on a fixed-point shadow of the gradient bucket and of dK | dV) --
+        # two runs from the same state give bit-identical gradients and parameters, on any schedule.  The default keeps
+        # the float atomics (what torch's own backward does in the reference): bench.py --train reports both.
+        self.deterministic = bool(deterministic)
+        self._shadow = None
         self.bucket = FlatBucket(head.trainable_parameters())
         head.refresh_weights()                      # parameter addresses moved into the bucket
         self.m = torch.zeros_like(self.bucket.params)
@@ -399,13 +405,20 @@ class FusionTrainer:
         if self.chain_backward:
             bws = self._backward_workspace(lib, w, key, B, T, tokens.device)
             clean = torch.empty_like(raw_losses) if raw_losses is not None else None
-            L.check(lib.tc_radar_train_bwd_fused_ex(
-                C.byref(w), C.byref(g), hs_last.data_ptr(), last_box.data_ptr(), tokens.data_ptr(), B, T,
-                int(pad_mult), all_box.data_ptr(), d_cls.data_ptr(), d_box.data_ptr(), tape.data_ptr(),
-                tape.numel(), bws.data_ptr(), bws.numel(), self.dropout, drop_seed,
-                raw_losses.data_ptr() if raw_losses is not None else None,
-                clean.data_ptr() if clean is not None else None, 1 if self._wT_ready else 0, self._stream()),
-                'tc_radar_train_bwd_fused_ex')
+            common = (C.byref(w), C.byref(g), hs_last.data_ptr(), last_box.data_ptr(), tokens.data_ptr(), B, T,
+                      int(pad_mult), all_box.data_ptr(), d_cls.data_ptr(), d_box.data_ptr(), tape.data_ptr(),
+                      tape.numel(), bws.data_ptr(), bws.numel(), self.dropout, drop_seed,
+                      raw_losses.data_ptr() if raw_losses is not None else None,
+                      clean.data_ptr() if clean is not None else None, 1 if self._wT_ready else 0)
+            if self.deterministic:
+                need = self.bucket.numel + 3 * B * T * 2 * head.embed_dims + 8
+                if self._shadow is None or self._shadow.numel() < need or self._shadow.device != tokens.device:
+                    self._shadow = torch.zeros(need, dtype=torch.int64, device=tokens.device)   # the call leaves it zero
+                L.check(lib.tc_radar_train_bwd_fused_det(*common, self.bucket.grads.data_ptr(), self.bucket.numel,
+                                                         self._shadow.data_ptr(), self._shadow.numel(), self._stream()),
+                        'tc_radar_train_bwd_fused_det')
+            else:
+                L.check(lib.tc_radar_train_bwd_fused_ex(*common, self._stream()), 'tc_radar_train_bwd_fused_ex')
             if clean is not None:
                 from .device_loss import loss_dict
                 losses = loss_dict(clean)
