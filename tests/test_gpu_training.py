@@ -1066,11 +1066,12 @@ def test_batched_decoder_lookahead_is_the_single_frame_decoder(A, golden_dir, ro
     nhwc_b = [torch.cat([ops.to_nhwc(f[l]) for f in per_frame] * 2, 0).contiguous() for l in range(len(feats))]
     l2i_b = torch.cat([l2i1] * (2 * P), 0).contiguous()
 
-    def make(depth):
+    def make(depth, deterministic=False):
         h = train_head(golden_dir)
         tok1, pad_mult = h.radar_tokens(metas, dev())
         tok_b = torch.cat([tok1] * (2 * P), 0).contiguous()
-        tr = FusionTrainer(h, dropout=0.1, seed=4, lr=1e-5, prefetch_depth=depth, decoder_dropout=0.1)
+        tr = FusionTrainer(h, dropout=0.1, seed=4, lr=1e-5, prefetch_depth=depth, decoder_dropout=0.1,
+                           deterministic=deterministic)
         tr.decoder_tile_rows = rows                                # the same decoder arithmetic with and without look-ahead
         ncam = nhwc_b[0].shape[0] // (2 * P)
 
@@ -1101,8 +1102,10 @@ def test_batched_decoder_lookahead_is_the_single_frame_decoder(A, golden_dir, ro
     assert not torch.equal(other['inter_states'][:, 0], full['inter_states'][:, 1])      # (the seed matters: dropout is on)
     # (b)
     res = {}
-    for look in (False, 'again', True):                                # 'again': the run-to-run noise of the backward's atomics
-        h, tr, view, window, pad_mult = make(P)
+    # ('again': the run-to-run noise of the backward's float atomics; 'det' / 'det-look': the same two schedules with the
+    # order-free backward -- VERDICT r4 item 4: `==` instead of a yardstick)
+    for look in (False, 'again', True, 'det', 'det-look'):
+        h, tr, view, window, pad_mult = make(P, deterministic=str(look).startswith('det'))
         hist = []
         fifo = []                                # positions (in the doubled storage) of the frames of look-aheads under way
         for it in range(2 * P + 1):
@@ -1115,11 +1118,13 @@ def test_batched_decoder_lookahead_is_the_single_frame_decoder(A, golden_dir, ro
                 fifo.extend(range(s0, s0 + P))
                 return window(s0)
             losses = tr.step_fused_nhwc(f['nhwc'], f['l2i'], img_hw, f['tokens'], pad_mult, [gt], [labels],
-                                        prefetch=lookahead if look is True else None)
+                                        prefetch=lookahead if look in (True, 'det-look') else None)
             hist.append({k: float(v) for k, v in losses.items()})
         torch.cuda.synchronize()
         res[look] = (hist, tr.bucket.params.clone(), getattr(tr, 'lookahead_hits', 0))
     assert res[False][2] == 0 and res[True][2] == 2 * P              # every frame but the very first
+    assert res['det'][2] == 0 and res['det-look'][2] == 2 * P
+    assert torch.equal(res['det'][1], res['det-look'][1])            # seven optimizer steps, look-ahead or not: the same bits
     # (the losses of later iterations carry the run-to-run noise of the earlier steps' atomically summed gradients:
     # the yardstick is what two plain runs differ by at the same iteration)
     for a_, b_, c_ in zip(res[False][0], res[True][0], res['again'][0]):

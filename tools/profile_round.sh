@@ -19,6 +19,7 @@ python bench.py --matrix-path f32 --no-configs --no-batched --no-handoff --no-cp
 python bench.py > "$OUT/bench.json" 2>> "$OUT/bench.err"                                   # default: 9 frames per launch x 3 lanes, 200 steps
 python bench.py --pair 1 --no-cpu-baseline --no-batched --no-configs > "$OUT/bench_pair1.json" 2>> "$OUT/bench.err"
 python bench.py --train --steps 50 --warmup 5 > "$OUT/bench_train.json" 2>> "$OUT/bench.err"
+python bench.py --train --deterministic --steps 50 --warmup 5 --no-live-pmc > "$OUT/bench_train_det.json" 2>> "$OUT/bench.err"   # order-free backward
 cd /tmp
 Q="--main-only --min-window-s 0.05 --warmup-s 0.05"   # the timed loop only, short windows: small traces
 # per-kernel durations, one launch sequence at a time (with frames in flight the kernels of different lanes share the GPU)
