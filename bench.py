@@ -433,11 +433,15 @@ def roofline(head, inp, dev, matrix_path='auto', tile_rows=0):
     vt = torch.zeros((B, Cd, qpad), device=dev)
     qe = head.query_embedding.weight
 
-    def run_chain():
+    # the inputs of decoder layer l as the forward hands them over: the states and reference points layer l - 1 wrote
+    hs_of = [o['aux']['inter_states'][l].contiguous() for l in range(5)]
+    ref_of = [o['aux']['inter_references'][l].contiguous() for l in range(5)]
+
+    def run_chain(layer=3):
         L.check(lib.tc_decoder_layer_tail_fwd(
-            C.byref(pv.layers[3]), C.byref(pv.layers[4].self_attn.in_proj), C.byref(fv), B, Q, 6,
-            code, attn_o.data_ptr(), hs2.data_ptr(), qe.data_ptr(), inp['l2i'].data_ptr(),
-            ref.data_ptr(), pc, float(inp['hw'][0]), float(inp['hw'][1]), hs_out.data_ptr(),
+            C.byref(pv.layers[layer]), C.byref(pv.layers[layer + 1].self_attn.in_proj), C.byref(fv), B, Q, 6,
+            code, attn_o.data_ptr(), hs_of[layer - 1].data_ptr(), qe.data_ptr(), inp['l2i'].data_ptr(),
+            ref_of[layer - 1].data_ptr(), pc, float(inp['hw'][0]), float(inp['hw'][1]), hs_out.data_ptr(),
             ref_out.data_ptr(), qk.data_ptr(), vt.data_ptr(), qpad, (mp_code << 8) | int(tile_rows), cur_stream()), 'decoder_layer_tail')
     if getattr(roofline, 'chain_only', False):        # tools/chain_stamps.py: one launch, no timing
         run_chain()
@@ -476,9 +480,15 @@ def roofline(head, inp, dev, matrix_path='auto', tile_rows=0):
     # The decoder chain AS A FRAME LAUNCHES IT: behind an attention core (which has swept the L2s in between), not back
     # to back with itself -- the pair replayed, the attention core's own time taken off.  This is the duration the
     # rocprofv3 summary of the frame sequence shows (profiles/r5_kernel_stats.csv: 99.8 us against 90.6 back to back).
+    # ... and as ANOTHER layer every launch (layers 1..4 in turn, each with its own weights, states and reference points),
+    # as consecutive layers of a frame do: the 3.18 MB of packed planes and the camera taps of the moved reference points
+    # then come from the Infinity Cache / HBM, not from L2s the previous replay of the same launch warmed.
+    turn = [0]
+
     def run_pair():
         run_attn()
-        run_chain()
+        run_chain(1 + turn[0] % 4)
+        turn[0] += 1
     chain_ms = max(time_events(run_pair) - attn_ms, chain_b2b_ms)
     # -- fused radar chain (three fusion layers in one launch) on this frame's decoder outputs
     from transcar_amd.detr3d_head import head_options
@@ -521,9 +531,9 @@ def roofline(head, inp, dev, matrix_path='auto', tile_rows=0):
             bound='mfma', achieved=chain_flop / chain_ms / 1e9, peak=chain_peak, peak_definition=chain_peak_def,
             unit='TFLOP/s', ms=chain_ms, per_frame=6, alg_flop=chain_flop,
             ms_back_to_back=chain_b2b_ms,
-            timing='HIP events over a 50-fold graph replay of [attention core, decoder chain] minus the attention core\'s own '
-                   '50-fold replay: the chain as a frame launches it (back to back with itself -- warm L2s, the same camera '
-                   'taps every launch -- it takes ms_back_to_back)',
+            timing='HIP events over a 50-fold graph replay of [attention core, decoder chain of layer 1 + i % 4] minus the '
+                   'attention core\'s own 50-fold replay: the chain as a frame launches it -- behind an attention core, another '
+                   'layer\'s weights every launch (back to back with itself, warm L2s, it takes ms_back_to_back)',
             launches_per_frame='6 = 4 plain launches + 2 that carry the radar encoders (chain_dual_kernel: others)',
             arithmetic='f16x2 split operands, fp32 accumulate' if f16x2 else 'f32',
             # every workgroup streams the layer's packed weights (3.18 MB) through its CU's vector-memory path: what
