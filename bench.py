@@ -363,7 +363,13 @@ def time_events(fn, iters=50, warm=3):
     """Average device time of fn() in ms: `iters` launches are captured into one
     hipGraph (no host launch gaps) and the replay is bracketed by HIP events on
     the stream the kernels run on."""
-    s = torch.cuda.Stream()
+    # ONE side stream for every replay of the process: a process has four hardware queues and streams are dealt onto
+    # them in creation order -- a fresh stream per call shifted which queue the head's ingest stream and the trainer's
+    # look-ahead stream landed on, i.e. the drop-in and training side measurements moved by 5 % with the NUMBER of replays
+    # the roofline happened to make before them
+    s = getattr(time_events, 'stream', None)
+    if s is None:
+        s = time_events.stream = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
         for _ in range(warm):
