@@ -405,13 +405,25 @@ __device__ __forceinline__ void sx_chunk(const float4 (*fb)[8][64], int lane, in
       }
       // P^T as two f16 planes: the lane's eight keys are the MFMA's eight k slots
       float4 p_h, p_l;
+#ifdef SX_NO_PLO      // experiment (upper bound of VERDICT r4 item 8's "hi plane only for small probabilities"): no lo plane of P at all
+      {
+        unsigned hh[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hh[i] = sa_pk(p[2 * i], p[2 * i + 1]);
+        p_h = make_float4(__uint_as_float(hh[0]), __uint_as_float(hh[1]), __uint_as_float(hh[2]), __uint_as_float(hh[3]));
+        p_l = p_h;
+      }
+#else
       sx_split1(p, p_h, p_l);
+#endif
       // O^T[d][q] += V^T[d][key] P^T[key][q];  l[q] += sum over the keys
       st[u].o0 = MFMAH(v0h, p_h, st[u].o0); st[u].o1 = MFMAH(v1h, p_h, st[u].o1);
       if (SX_L_MFMA) st[u].lsum = MFMAH(ones, p_h, st[u].lsum);
       st[u].o0 = MFMAH(v0l, p_h, st[u].o0); st[u].o1 = MFMAH(v1l, p_h, st[u].o1);
+#ifndef SX_NO_PLO
       st[u].o0 = MFMAH(v0h, p_l, st[u].o0); st[u].o1 = MFMAH(v1h, p_l, st[u].o1);
       if (SX_L_MFMA) st[u].lsum = MFMAH(ones, p_l, st[u].lsum);
+#endif
     }
   }
 }
