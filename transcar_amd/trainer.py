@@ -139,6 +139,9 @@ class FusionTrainer:
         # two runs from the same state give bit-identical gradients and parameters, on any schedule.  The default keeps
         # the float atomics (what torch's own backward does in the reference): bench.py --train reports both.
         self.deterministic = bool(deterministic)
+        if self.deterministic and not chain_backward:
+            raise ValueError('FusionTrainer(deterministic=True) needs the fused backward (chain_backward=True): the '
+                             'per-operator backward (tc_radar_train_bwd) accumulates with float atomics')
         self._shadow = None
         self.bucket = FlatBucket(head.trainable_parameters())
         head.refresh_weights()                      # parameter addresses moved into the bucket
