@@ -191,3 +191,14 @@ def test_training_iteration_traffic_is_summed_over_all_dispatches(tmp_path):
     assert got['traffic_bytes'] == (2 * 150 + 60) * 1024
     write.write_text(hdr)
     assert bench.iteration_traffic_from_csvs(str(fetch), str(write)) is None
+
+
+def test_cpu_baseline_spread_reads_the_committed_lines():
+    """cpu_baseline.box_to_box: min / max / median of cpu_baseline.ms_per_frame over the committed
+    bench lines of every round plus the current run's figure."""
+    import bench
+    got = bench.cpu_baseline_spread(1000.0)
+    assert got['runs'] >= 2 and got['max_ms_per_frame'] == 1000.0
+    assert 100.0 < got['min_ms_per_frame'] <= got['median_ms_per_frame'] <= got['max_ms_per_frame']
+    base = bench.cpu_baseline_spread()
+    assert base['runs'] == got['runs'] - 1 and base['max_ms_per_frame'] < 1000.0
