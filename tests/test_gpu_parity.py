@@ -1221,8 +1221,9 @@ def test_soak_of_the_timed_geometry_is_bit_identical_launch_to_launch(T, tile_ro
     assert time.time() - t0 < 60.0
 
 
+@pytest.mark.parametrize('rows', [0, 32])
 @pytest.mark.parametrize('case', ['weight', 'activation'])
-def test_f16_range_guard_flags_an_overflow_and_falls_back_to_f32(T, sd_np, case):
+def test_f16_range_guard_flags_an_overflow_and_falls_back_to_f32(T, sd_np, case, rows):
     """an operand beyond the f16 planes' range on the DEFAULT (f16x2) path of a batched launch --
     a weight of 1e5 (> 65504) or feature maps of ~1e9 (a sampled activation > 65504 * 2^6 = 4.19e6) -- turns into
     inf / NaN in the outputs (never a wrong finite number), tc_head_options.range_status says so, get_bboxes reads the
@@ -1242,6 +1243,8 @@ def test_f16_range_guard_flags_an_overflow_and_falls_back_to_f32(T, sd_np, case)
         h.load_state_dict({k: torch.from_numpy(v) for k, v in sdm.items()}, strict=True)
         return h.to(dev()).eval()
     h = make()
+    if rows:                 # the 32-row tiles' epilogue (lin_epilogue32) carries its own copy of the test; on the fall-back the
+        h.forward_options = head_options(tile_rows=rows)       # head lowers a forced 32 to the f32 kernels' 16 rows
     feats = [gpu(np.concatenate([synth.make_feats('tiny', seed=s_, smooth=SMOOTH)[l] for s_ in (1, 11, 12)], 0) * scale)
              for l in range(4)]
     frames = [synth.make_radar_frame(seed=2 + i) for i in range(3)]
