@@ -1401,9 +1401,30 @@ def train_bench(args, head, inp, dev, rank, world, affinity=None):
         gaps = sorted(a.elapsed_time(b) for a, b in tr.exchange_events)
         tr.exchange_events = None
         exposed = {'median': gaps[len(gaps) // 2], 'max': gaps[-1], 'iterations': len(gaps)}
+    # the cost of the order-free backward beside the default ("report the cost in bench.py --train"):
+    # the SAME trainer flipped to deterministic=True for three windows of the same length (one rank, fused path only)
+    det_cost = None
+    if world == 1 and not args.train_autograd and not args.deterministic and not args.main_only:
+        tr.deterministic = True
+        try:
+            for _ in range(max(3, args.warmup)):
+                step()
+            torch.cuda.synchronize()
+            wins = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                torch.cuda.synchronize()
+                wins.append((time.perf_counter() - t0) / args.steps * 1e3)
+            det_cost = {'ms_per_step': float(np.median(wins)), 'relative_to_default': float(np.median(wins)) / (med / args.steps * 1e3),
+                        'what': 'FusionTrainer(deterministic=True): tc_radar_train_bwd_fused_det, bit-identical gradients run to run'}
+        finally:
+            tr.deterministic = False
     line = {
         'exposed_collective_ms': exposed,
         'deterministic': bool(args.deterministic),
+        'deterministic_cost': det_cost,
         'per_rank': per_rank_summary(own, args.steps, B), 'cpu_affinity': affinity,
         'metric': 'training frames/sec: fusion head iteration (frozen DETR3D decoder fwd + radar '
                   'stack fwd/bwd + loss + grad all-reduce + AdamW), FPN features resident in HBM',
