@@ -744,7 +744,7 @@ def live_train_traffic(extra_args=(), timeout_s=120):
     try:
         paths = []
         for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
-            pth = _pmc_pass(tools[0], tools[1], tmp, ctr, ['--train', '--steps', '9', '--warmup', '2', '--no-roofline',
+            pth = _pmc_pass(tools[0], tools[1], tmp, ctr, ['--train', '--steps', '9', '--warmup', '2', '--no-roofline', '--main-only',
                                                           '--min-window-s', '0.02', '--warmup-s', '0.02'] + list(extra_args),
                             timeout_s)
             if pth is None:
