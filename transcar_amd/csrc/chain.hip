@@ -2115,6 +2115,93 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAllT<nw_
           vm = __ballot(cam_project_lane(k.cam, k.ref_mod > 0 ? grow % k.ref_mod : grow, grow / k.Q,
                                          min(c, k.cam.num_cams - 1), act, pu, pv));
         }
+#ifdef TC_SAMPLE_PIPE
+        if constexpr (R == 32) {
+          // The wave's (row, visible camera) pairs as ONE software pipeline: while the taps of a pair are summed, half by
+          // half (levels 0-1, levels 2-3: two buffers of eight 1 KiB rows), the freed half is refilled with the NEXT
+          // pair's taps -- of the same row or the next -- whose geometry was computed under the loads.  The rows' tap
+          // round trips (HBM / Infinity Cache: the maps do not fit the L2s) overlap instead of queueing up behind each
+          // other.  Same products, same order of sums per camera and per row as cam_sample_core: bit-identical.
+          unsigned long long rest = vm;
+          for (int i = 0; i < R / NW; ++i) {            // rows no camera sees: zeros
+            const int row = wave + NW * i;
+            if (((vm >> (16 * i)) & 0xFFFFull) == 0) act_st4<PL>(buf_ptr(S, r.dst) + row * LD2, 4 * lane, make_float4(0.f, 0.f, 0.f, 0.f));
+            if (m0 + row < M) pairs += __popcll((vm >> (16 * i)) & 0xFFFFull);
+          }
+          if (rest != 0) {
+            auto pop = [&](int& pi, int& pc) {
+              const int bit = __ffsll((long long)rest) - 1;
+              rest &= rest - 1;
+              pi = bit >> 4; pc = bit & 15;
+            };
+            auto geom = [&](int pi, int pc, float& w_lane, int& pix_lane) {
+              const int grow = min(m0 + wave + NW * pi, M - 1);
+              cam_tap_lane<4>(k.cam, grow / k.Q, pc, lane_f(pu, 16 * pi + pc), lane_f(pv, 16 * pi + pc), lane, w_lane, pix_lane);
+            };
+            auto sig = [&](int pi) {
+              const float* lg = &S.l[wave + NW * pi][0];
+              return sigmoidf_(lg[min(lane, k.cam.num_cams * 4 - 1)]);
+            };
+            float4 tap[2][2][4];                        // [half][level within the half][tap]
+            auto issue = [&](int half, int pix_lane) {
+#pragma unroll
+              for (int l = 0; l < 2; ++l)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                  tap[half][l][t] = ld4(cam_tap_ptr(k.cam, 2 * half + l, __builtin_amdgcn_readlane(pix_lane, 4 * (2 * half + l) + t), lane));
+            };
+            auto consume = [&](int half, float w_lane, float sg_lane, int pc, float4& camacc) {
+#pragma unroll
+              for (int l = 0; l < 2; ++l) {
+                const int lv = 2 * half + l;
+                const float w0 = lane_f(w_lane, 4 * lv + 0), w1 = lane_f(w_lane, 4 * lv + 1);
+                const float w2 = lane_f(w_lane, 4 * lv + 2), w3 = lane_f(w_lane, 4 * lv + 3);
+                const float4 (&tp)[4] = tap[half][l];
+                float4 sm;
+                sm.x = tp[0].x * w0 + tp[1].x * w1 + tp[2].x * w2 + tp[3].x * w3;
+                sm.y = tp[0].y * w0 + tp[1].y * w1 + tp[2].y * w2 + tp[3].y * w3;
+                sm.z = tp[0].z * w0 + tp[1].z * w1 + tp[2].z * w2 + tp[3].z * w3;
+                sm.w = tp[0].w * w0 + tp[1].w * w1 + tp[2].w * w2 + tp[3].w * w3;
+                if (sm.x != sm.x) sm.x = 0.f;
+                if (sm.y != sm.y) sm.y = 0.f;
+                if (sm.z != sm.z) sm.z = 0.f;
+                if (sm.w != sm.w) sm.w = 0.f;
+                const float a = lane_f(sg_lane, pc * 4 + lv);
+                camacc.x += sm.x * a; camacc.y += sm.y * a; camacc.z += sm.z * a; camacc.w += sm.w * a;
+              }
+            };
+            int ci, cc;
+            pop(ci, cc);
+            float cw; int cp;
+            geom(ci, cc, cw, cp);
+            float csg = sig(ci);
+            issue(0, cp); issue(1, cp);
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+            for (;;) {
+              const bool more = rest != 0;              // wave-uniform
+              int ni = ci, nc = cc;
+              if (more) pop(ni, nc);
+              float nw; int np;
+              geom(ni, nc, nw, np);                     // (the last pair again when nothing follows: harmless re-reads, no branch around loads)
+              const float nsg = ni != ci ? sig(ni) : csg;
+              float4 camacc = make_float4(0.f, 0.f, 0.f, 0.f);
+              consume(0, cw, csg, cc, camacc);
+              issue(0, np);
+              consume(1, cw, csg, cc, camacc);
+              issue(1, np);
+              acc.x += camacc.x; acc.y += camacc.y; acc.z += camacc.z; acc.w += camacc.w;
+              if (!more || ni != ci) {
+                act_st4<PL>(buf_ptr(S, r.dst) + (wave + NW * ci) * LD2, 4 * lane, acc);
+                acc = make_float4(0.f, 0.f, 0.f, 0.f);
+              }
+              if (!more) break;
+              ci = ni; cc = nc; cw = nw; cp = np; csg = nsg;
+            }
+          }
+        } else
+#endif
+        {
 #pragma unroll 1
         for (int i = 0; i < R / NW; ++i) {
           const int row = wave + NW * i;
@@ -2124,6 +2211,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAllT<nw_
                                               [](int, int, int, const float* ptr) { return ld4(ptr); }, 16 * i);
           act_st4<PL>(buf_ptr(S, r.dst) + row * LD2, 4 * lane, o);
           if (m0 + row < M) pairs += __popcll(vmask);
+        }
         }
         CAM_STAMP(6);
         if (k.pair_counter != nullptr && lane == 0 && pairs > 0)
