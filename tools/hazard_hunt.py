@@ -2,7 +2,9 @@
 
 tools/refill_hazard_probe.hip shows the refill itself is exact outside chain.hip (512 workgroups, partners out of
 phase, every repetition verified), so the cause sits in the radar program.  This script runs the radar part
-(tc_radar_fusion_fwd, 8 frames = 450 workgroups of 16 rows, two per CU) on a DIAGNOSTIC build:
+(tc_radar_fusion_fwd, 8 frames = 450 workgroups of 16 rows, two per CU) on a DIAGNOSTIC build.  The in-place loop
+and its INPLACE make target left the product source in round 6: `git apply tools/experiments/r5_chain_experiments.patch`
+brings them back (with the other rejected round-5 experiments), then:
 
   make -C transcar_amd/csrc INPLACE=1            -> build/hip_inplace/libtranscar_hip_inplace.so       (stage `final`)
   make -C transcar_amd/csrc INPLACE=1 DUMP=1     -> build/hip_inplace_dump/...inplace_dump.so          (stage `dump`)

@@ -43,12 +43,6 @@
 //    runs at full rate: tools/icache_probe.hip); the step table exists to keep
 //    ONE code image for all four programs.
 #include <stdlib.h>
-#ifndef TC_PRIO
-#define TC_PRIO 0
-#endif
-#ifndef TC_PRIO_MASK
-#define TC_PRIO_MASK 4
-#endif
 #include <string.h>
 
 #include <type_traits>
@@ -1148,7 +1142,6 @@ __device__ __forceinline__ void lin_epilogue32(const LinSpec& s, int colbase, co
 // instruction is formed (-fno-slp-vectorize, tools/isa_lint.py in the test suite), and the fragments of half item i + 1
 // go to the OTHER buffer, a whole half item (12 MFMAs of this wave) away from the registers' last read -- beside this loop
 // the probe's victims saw nothing in 2.5e9 executions.
-#ifndef TC_H16_INPLACE
 template <int J, int BUF>
 struct ItemSteps16H {
   static __device__ __forceinline__ void run(Acc16H& acc, WBuf& wb, const float4& x1, const float4& x2, const float* np,
@@ -1251,92 +1244,6 @@ __device__ __forceinline__ bool linear_step16h(const LinSpec& s, WBuf& w0, bool 
   return next_first != nullptr;
 }
 
-#else
-// DIAGNOSTIC BUILD ONLY (make INPLACE=1 -> build/hip_inplace/, never the product): round 4's first form of this loop,
-// the fragments refilled in place right behind their MFMAs ("variant A" of profiles/r4_f16x2_hazard.txt), kept to
-// chase the flaky rows it produced in the radar program (tools/hazard_hunt.py, profiles/r5_refill_hazard.txt).
-
-template <int J>
-struct ItemSteps16HA {
-  static __device__ __forceinline__ void run(Acc16H& acc, WBuf& wb, const float4& x1, const float4& x2, const float* np,
-                                             unsigned lo) {
-    constexpr int C0 = 2 * J;
-    acc.lo[J] = MFMA16H(wb.b[C0 + 1], x1, acc.lo[J]);
-    acc.lo[J] = MFMA16H(wb.b[C0], x2, acc.lo[J]);
-    acc.hi[J] = MFMA16H(wb.b[C0], x1, acc.hi[J]);
-    __builtin_amdgcn_sched_barrier(0);
-    wb.b[C0] = ld4(np + (size_t)(lo + (2 * J) * 256u));
-    wb.b[C0 + 1] = ld4(np + (size_t)(lo + (2 * J + 1) * 256u));
-    __builtin_amdgcn_sched_barrier(0);
-    ItemSteps16HA<J + 1>::run(acc, wb, x1, x2, np, lo);
-  }
-};
-template <>
-struct ItemSteps16HA<4> {
-  static __device__ __forceinline__ void run(Acc16H&, WBuf&, const float4&, const float4&, const float*, unsigned) {}
-};
-
-template <bool DROP, typename SpecFn>
-__device__ __forceinline__ bool linear_step16h(const LinSpec& s, WBuf& w0, bool preloaded, const float* next_first,
-                                               SpecFn make_spec, int step_idx) {
-  const int lane = threadIdx.x & 63;
-  const int wave = (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) - s.woff) & (CH_NW - 1);
-  const int ntiles = (s.N + 63) >> 6;
-  const int kpad = (s.K + 63) & ~63;
-  const int nhalf = kpad / 32;
-  const int my_tiles = wave < ntiles ? (ntiles - wave + CH_NW - 1) / CH_NW : 0;
-  const int nitems = my_tiles * nhalf;
-  const float* arow = s.src + (lane & 15) * s.src_ld + 8 * (lane >> 4);
-  const float* wbase = s.W + (size_t)wave * 64 * kpad;
-  const unsigned lo = 4u * lane;
-  const size_t tile_stride = (size_t)CH_NW * 64 * kpad;
-  Acc16H acc;
-  float bvl = 0.f;
-  if (!preloaded) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) w0.b[i] = ld4(wbase + (size_t)(lo + i * 256u));
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-  int tt = 0, kh = 0;
-  const float* wcur = wbase;
-#pragma unroll 1
-  for (int it = 0; it < nitems; ++it) {
-    const float* np = wcur;
-    int nt = tt, nk = kh;
-    if (++nk == nhalf) { nk = 0; ++nt; np = wbase + (size_t)nt * tile_stride; }
-    else np += 8 * 256;
-    const bool last = it + 1 >= nitems;
-    const float* nload = last ? (next_first != nullptr ? next_first : wbase) : np;
-    if (kh == 0) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { acc.hi[j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc.lo[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-      const float* bsrc = s.bias != nullptr ? s.bias : s.W;
-      bvl = ldg1(bsrc + min((wave + tt * CH_NW) * 64 + lane, s.N - 1));
-    }
-    float4 x1, x2;
-    split_h(*reinterpret_cast<const float4*>(arow + kh * 32), *reinterpret_cast<const float4*>(arow + kh * 32 + 4), x1, x2);
-    ItemSteps16HA<0>::run(acc, w0, x1, x2, nload, lo);
-    if (kh == nhalf - 1) {
-      int tile = wave + tt * CH_NW;
-      int sidx = step_idx;
-      asm volatile("" : "+s"(tile), "+s"(sidx));
-      Acc16 y;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          y.v[j][i] = fmaf(acc.lo[j][i], 1.0f / (H_LO_SCALE * H_ACT_SCALE), acc.hi[j][i] * (1.0f / H_ACT_SCALE));
-      const LinSpec e = make_spec(sidx);
-      lin_epilogue16<DROP>(e, tile * 64, y.v, lane, bvl);
-    }
-    wcur = np; tt = nt; kh = nk;
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  return next_first != nullptr;
-}
-
-#endif  // TC_H16_INPLACE
 
 // ---- 32-row tiles on the f16 matrix cores (round 5) --------------------------------------------------------
 // What bounds the 16-row f16 loop is the weight stream: every 16-row workgroup pulls the layer's 3.18 MB of planes through
@@ -1404,15 +1311,6 @@ __device__ __forceinline__ bool linear_step32h(const LinSpec& s, WBuf& w0, bool 
   const unsigned lo = 4u * lane;
   const size_t tile_stride = (size_t)(NW / 2) * 64 * kpad;
   Acc32H acc;
-#if TC_PRIO >= 4
-  // experiment: the SIMD partners (waves w and w + 4) out of phase -- the second one starts its items TC_PRIO x 64 cycles late
-  if ((__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & TC_PRIO_MASK) != 0) __builtin_amdgcn_s_sleep(TC_PRIO);
-#endif
-#if TC_PRIO == 1
-  const bool prio_hi = (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 4) == 0;
-#elif TC_PRIO == 3
-  const bool prio_hi = (((__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >> 2) ^ step_idx) & 1) == 0;
-#endif
   float4 bias4[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
   SUB_STAMP(1);
   if (CHAIN_DBG(s.dbg) & 32) return false;
@@ -1448,14 +1346,8 @@ __device__ __forceinline__ bool linear_step32h(const LinSpec& s, WBuf& w0, bool 
       for (int jj = 0; jj < 2; ++jj)
         bias4[jj] = ld4(bsrc + min((wave + tt * NW) * 32 + 16 * jj + 4 * (lane >> 4), max(s.N - 4, 0)));
     }
-#if TC_PRIO == 1 || TC_PRIO == 3
-    if (prio_hi) __builtin_amdgcn_s_setprio(3);
-#endif
     item32h<BUF>(acc, w0, arow0, arow1, kb * KB, nload, lo);
     SUB_STAMP(3 + tt * nkb + kb);
-#if TC_PRIO == 1 || TC_PRIO == 3
-    if (kb == nkb - 1) __builtin_amdgcn_s_setprio(0);
-#endif
     if (kb == nkb - 1) {
       int tile = wave + tt * NW;
       int sidx = step_idx;
@@ -1688,19 +1580,6 @@ __device__ long long g_wg_span[1024][2];
 template <int R, int PROG, bool DROP = false, int MM = 0>
 __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAllT<nw_of(R)>* __restrict__ recs, const int block) {
   constexpr int NW = nw_of(R), NT = NW * 64;        // waves / threads of the workgroup
-#if defined(TC_STAGGER)
-  // experiment: every second workgroup of a 32-row decoder launch starts TC_STAGGER x 4096 cycles late (the camera
-  // sampling windows of the two halves of the chip then do not coincide)
-  if constexpr (R == 32 && PROG == PROG_DECODER) {
-    if (blockIdx.x & 1) {
-#pragma unroll 1
-      for (int i = 0; i < TC_STAGGER; ++i) __builtin_amdgcn_s_sleep(64);
-    }
-  }
-#endif
-#if TC_PRIO == 2
-  if constexpr (R == 32) { if ((__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & TC_PRIO_MASK) == 0) __builtin_amdgcn_s_setprio(3); }
-#endif
   constexpr bool PL = R == 32;                      // the activation units hold planes (act_ld4 / act_st4)
   static_assert((MM == 0 && R <= 16) || (MM == 1 && R >= 16 && PROG != PROG_PROLOGUE), "the f16 two-plane path exists for 16- and 32-row tiles (and is the only one at 32)");
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -2115,93 +1994,6 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAllT<nw_
           vm = __ballot(cam_project_lane(k.cam, k.ref_mod > 0 ? grow % k.ref_mod : grow, grow / k.Q,
                                          min(c, k.cam.num_cams - 1), act, pu, pv));
         }
-#ifdef TC_SAMPLE_PIPE
-        if constexpr (R == 32) {
-          // The wave's (row, visible camera) pairs as ONE software pipeline: while the taps of a pair are summed, half by
-          // half (levels 0-1, levels 2-3: two buffers of eight 1 KiB rows), the freed half is refilled with the NEXT
-          // pair's taps -- of the same row or the next -- whose geometry was computed under the loads.  The rows' tap
-          // round trips (HBM / Infinity Cache: the maps do not fit the L2s) overlap instead of queueing up behind each
-          // other.  Same products, same order of sums per camera and per row as cam_sample_core: bit-identical.
-          unsigned long long rest = vm;
-          for (int i = 0; i < R / NW; ++i) {            // rows no camera sees: zeros
-            const int row = wave + NW * i;
-            if (((vm >> (16 * i)) & 0xFFFFull) == 0) act_st4<PL>(buf_ptr(S, r.dst) + row * LD2, 4 * lane, make_float4(0.f, 0.f, 0.f, 0.f));
-            if (m0 + row < M) pairs += __popcll((vm >> (16 * i)) & 0xFFFFull);
-          }
-          if (rest != 0) {
-            auto pop = [&](int& pi, int& pc) {
-              const int bit = __ffsll((long long)rest) - 1;
-              rest &= rest - 1;
-              pi = bit >> 4; pc = bit & 15;
-            };
-            auto geom = [&](int pi, int pc, float& w_lane, int& pix_lane) {
-              const int grow = min(m0 + wave + NW * pi, M - 1);
-              cam_tap_lane<4>(k.cam, grow / k.Q, pc, lane_f(pu, 16 * pi + pc), lane_f(pv, 16 * pi + pc), lane, w_lane, pix_lane);
-            };
-            auto sig = [&](int pi) {
-              const float* lg = &S.l[wave + NW * pi][0];
-              return sigmoidf_(lg[min(lane, k.cam.num_cams * 4 - 1)]);
-            };
-            float4 tap[2][2][4];                        // [half][level within the half][tap]
-            auto issue = [&](int half, int pix_lane) {
-#pragma unroll
-              for (int l = 0; l < 2; ++l)
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                  tap[half][l][t] = ld4(cam_tap_ptr(k.cam, 2 * half + l, __builtin_amdgcn_readlane(pix_lane, 4 * (2 * half + l) + t), lane));
-            };
-            auto consume = [&](int half, float w_lane, float sg_lane, int pc, float4& camacc) {
-#pragma unroll
-              for (int l = 0; l < 2; ++l) {
-                const int lv = 2 * half + l;
-                const float w0 = lane_f(w_lane, 4 * lv + 0), w1 = lane_f(w_lane, 4 * lv + 1);
-                const float w2 = lane_f(w_lane, 4 * lv + 2), w3 = lane_f(w_lane, 4 * lv + 3);
-                const float4 (&tp)[4] = tap[half][l];
-                float4 sm;
-                sm.x = tp[0].x * w0 + tp[1].x * w1 + tp[2].x * w2 + tp[3].x * w3;
-                sm.y = tp[0].y * w0 + tp[1].y * w1 + tp[2].y * w2 + tp[3].y * w3;
-                sm.z = tp[0].z * w0 + tp[1].z * w1 + tp[2].z * w2 + tp[3].z * w3;
-                sm.w = tp[0].w * w0 + tp[1].w * w1 + tp[2].w * w2 + tp[3].w * w3;
-                if (sm.x != sm.x) sm.x = 0.f;
-                if (sm.y != sm.y) sm.y = 0.f;
-                if (sm.z != sm.z) sm.z = 0.f;
-                if (sm.w != sm.w) sm.w = 0.f;
-                const float a = lane_f(sg_lane, pc * 4 + lv);
-                camacc.x += sm.x * a; camacc.y += sm.y * a; camacc.z += sm.z * a; camacc.w += sm.w * a;
-              }
-            };
-            int ci, cc;
-            pop(ci, cc);
-            float cw; int cp;
-            geom(ci, cc, cw, cp);
-            float csg = sig(ci);
-            issue(0, cp); issue(1, cp);
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 1
-            for (;;) {
-              const bool more = rest != 0;              // wave-uniform
-              int ni = ci, nc = cc;
-              if (more) pop(ni, nc);
-              float nw; int np;
-              geom(ni, nc, nw, np);                     // (the last pair again when nothing follows: harmless re-reads, no branch around loads)
-              const float nsg = ni != ci ? sig(ni) : csg;
-              float4 camacc = make_float4(0.f, 0.f, 0.f, 0.f);
-              consume(0, cw, csg, cc, camacc);
-              issue(0, np);
-              consume(1, cw, csg, cc, camacc);
-              issue(1, np);
-              acc.x += camacc.x; acc.y += camacc.y; acc.z += camacc.z; acc.w += camacc.w;
-              if (!more || ni != ci) {
-                act_st4<PL>(buf_ptr(S, r.dst) + (wave + NW * ci) * LD2, 4 * lane, acc);
-                acc = make_float4(0.f, 0.f, 0.f, 0.f);
-              }
-              if (!more) break;
-              ci = ni; cc = nc; cw = nw; cp = np; csg = nsg;
-            }
-          }
-        } else
-#endif
-        {
 #pragma unroll 1
         for (int i = 0; i < R / NW; ++i) {
           const int row = wave + NW * i;
@@ -2211,7 +2003,6 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAllT<nw_
                                               [](int, int, int, const float* ptr) { return ld4(ptr); }, 16 * i);
           act_st4<PL>(buf_ptr(S, r.dst) + row * LD2, 4 * lane, o);
           if (m0 + row < M) pairs += __popcll(vmask);
-        }
         }
         CAM_STAMP(6);
         if (k.pair_counter != nullptr && lane == 0 && pairs > 0)
@@ -2881,14 +2672,8 @@ extern "C" int tc_debug_set_chain_dump(void* buf, long long floats) {
 }
 #endif
 #ifdef TC_DIAG_BUILD
-// marks a diagnostic build (make INPLACE=1 / DUMP=1): transcar_amd/_lib.py refuses it without TRANSCAR_ALLOW_STAMPS=1
-extern "C" int tc_debug_diag_build() {
-#ifdef TC_H16_INPLACE
-  return 1;
-#else
-  return 2;
-#endif
-}
+// marks a diagnostic build (make DUMP=1): transcar_amd/_lib.py refuses it without TRANSCAR_ALLOW_STAMPS=1
+extern "C" int tc_debug_diag_build() { return 2; }
 #endif
 
 void fill_camk(const CamSampleArgs& a, CamK& p);   // cam_sample.hip
