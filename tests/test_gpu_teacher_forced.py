@@ -96,11 +96,12 @@ def _qkv_from_oracle_state(sd, lid, x, pos):
     return q.float(), k.float(), vt.float()
 
 
-@pytest.mark.parametrize('tile_rows,matrix', [(0, None), (8, None), (16, 'f16x2'), (16, 'f32')])
+@pytest.mark.parametrize('tile_rows,matrix', [(0, None), (8, None), (16, 'f16x2'), (16, 'f32'), (32, 'f16x2')])
 def test_decoder_layers_teacher_forced_on_bench_inputs(rig, tile_rows, matrix):
     """Every tile height of the row chain (0 = the automatic choice, 4-row tiles at one frame; 8; 16 on BOTH
     matrix paths: the two-plane f16 operands on the matrix cores -- round 4, the default -- and the
-    v_mfma_f32_16x16x4 path on the second weight copy; the tolerances are the same for all):
+    v_mfma_f32_16x16x4 path on the second weight copy; 32 rows with the activations as f16 planes in LDS -- round 5's
+    headline tile height, here since round 6; the tolerances are the same for all):
     HIP layer l (attention core + fused row chain) on the oracle's layer-(l-1) state and
     reference points, l = 0..5, iid-noise ResNet-101 maps, full-scale refinement MLPs -- measured
     against the fp64 evaluation of the reference formula on the same inputs, next to the fp32
@@ -191,9 +192,9 @@ def _hit_aware(got, want, got_hits, want_hits, tol, what):
     return agree
 
 
-@pytest.mark.parametrize('tile_rows,matrix', [(0, None), (16, 'f16x2'), (16, 'f32')])
+@pytest.mark.parametrize('tile_rows,matrix', [(0, None), (16, 'f16x2'), (16, 'f32'), (32, 'f16x2')])
 def test_radar_layers_teacher_forced_on_bench_inputs(rig, tile_rows, matrix):
-    """(4-row tiles and the 16-row tiles on both matrix paths: two-plane f16 and the f32 16x16x4.)  The fused radar chain, ONE fusion layer at a time: layer r is fed the oracle's query
+    """(4-row tiles, the 16-row tiles on both matrix paths: two-plane f16 and the f32 16x16x4, and the 32-row tiles.)  The fused radar chain, ONE fusion layer at a time: layer r is fed the oracle's query
     features and box of layer r-1 (hs[5] / the decoder's last box for r = 0) and must reproduce the
     oracle's class scores, boxes and hit counts of layer r; then all three layers in one launch from
     the oracle's hs[5] (the launch tc_head_forward makes)."""
