@@ -601,9 +601,12 @@ int tc_radar_train_bwd_fused_ex(const tc_head_weights* w, const tc_head_weights*
  * below; |v| < 8.4e6), the token side's split reductions run unsplit, and two small launches add the shadows back:
  * bit-identical gradients from identical inputs, on any schedule.  (tools/train.py:238-260 trains with torch's float
  * atomics, i.e. without this guarantee; FusionTrainer(deterministic=True) and the tests that compare runs use it.)
- * grad_base / grad_elems: the span that holds EVERY tensor of `grads` (the flat bucket); shadow: at least grad_elems +
+ * grad_base / grad_elems: the span that holds EVERY tensor of `grads` (the flat bucket); shadow: shadow_elems >= grad_elems +
  * 3 * B * T * 2 * embed_dims + 8 64-bit words; the first grad_elems + 3 B T 2 embed_dims must be zero on entry -- the
- * call leaves them zero -- the last 8 are scratch. */
+ * call leaves them zero -- and the LAST 8 words of the buffer (shadow[shadow_elems - 8 ..]) are scratch, wherever (B, T)
+ * put the end of the sums: one buffer sized for the longest frame serves every shorter one (round 6).  A partial sum the
+ * fixed-point word cannot hold (NaN, inf, |v| >= 2^23) is added to the float target itself: non-finite or exploding
+ * gradients stay visible, as with the float atomics of tc_radar_train_bwd_fused. */
 int tc_radar_train_bwd_fused_det(const tc_head_weights* w, const tc_head_weights* grads, const float* hs_last,
                                  const float* last_box, const float* radar_tokens, int B, int T, int pad_mult,
                                  const float* all_bbox_preds, const float* d_all_cls, const float* d_all_box,

@@ -1279,7 +1279,51 @@ def test_f16_range_guard_flags_an_overflow_and_falls_back_to_f32(T, sd_np, case,
     with warnings.catch_warnings(record=True) as rec:
         warnings.simplefilter('always')
         assert h.last_range_status == 1
-    assert len(rec) == 0                                    # (the fallback was announced once)
+    assert len(rec) == 1 and 'pinned' in str(rec[0].message)   # a pinned path cannot fall back: every overflow warns
+
+
+def test_f16_range_guard_reaches_a_frame_pipeline(T, sd_np):
+    """the main inference path replays captured graphs with the f16x2 kernels and the 32-row tiles
+    baked in and never calls get_bboxes -- the guard must work THERE.  A lane's graph ends with a copy of the status word
+    into a pinned host word; `wait` reads it, the head falls back (generation bump) and the next launch re-captures on
+    the exact-fp32 kernels: finite outputs, equal to a pipeline that was on the f32 path all along."""
+    import warnings
+    from transcar_amd.detr3d_head import head_options
+    from transcar_amd.pipeline import FramePipeline
+    from transcar_amd import ops, radar as R
+    sdm = {k: v.copy() for k, v in sd_np.items()}
+    sdm['transformer.decoder.layers.3.ffns.0.layers.0.0.weight'][5, 7] = 1.0e5
+
+    def make():
+        h = T.build_head(configs.head_cfg())
+        h.load_state_dict({k: torch.from_numpy(v) for k, v in sdm.items()}, strict=True)
+        return h.to(dev()).eval()
+    P = 5                                                   # 4 500 rows per launch: the automatic rule picks 32-row tiles
+    feats = [gpu(np.concatenate([synth.make_feats('tiny', seed=10 + j, smooth=SMOOTH)[l] for j in range(P)], 0)) for l in range(4)]
+    l2i = gpu(np.stack([synth.make_lidar2img()] * P))
+    tok_np, pm = R.pack_tokens([R.build_radar_features(synth.make_radar_frame(seed=2 + j)) for j in range(P)], T=256)
+
+    def lane_inputs():
+        return dict(nhwc=[t.clone() for t in ops.to_nhwc_levels(feats)], l2i=l2i.clone(), hw=HW, tokens=gpu(tok_np), pad_mult=pm)
+    h = make()
+    pipe = FramePipeline(h, [lane_inputs(), lane_inputs()])
+    assert pipe.tile_rows_of() == 32
+    lane, (outs, dec) = pipe.launch()
+    with pytest.warns(UserWarning, match='f16x2'):
+        pipe.wait(lane)
+    assert pipe.range_status(lane) == 1 and h.matrix_fallback
+    assert not torch.isfinite(outs['all_cls_scores']).all()
+    lane2, (outs2, dec2) = pipe.launch()                    # re-captures: f32 kernels, 16-row tiles
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        pipe.wait(lane2)
+    assert pipe.range_status(lane2) == 0 and pipe.tile_rows_of() == 16
+    ref = make()
+    rp = FramePipeline(ref, [lane_inputs()], options=head_options(matrix_path='f32'))
+    l3, (want, _) = rp.launch()
+    rp.wait(l3)
+    assert torch.isfinite(outs2['all_cls_scores']).all()
+    assert torch.equal(outs2['all_cls_scores'], want['all_cls_scores']) and torch.equal(outs2['all_bbox_preds'], want['all_bbox_preds'])
 
 
 def test_plugin_entry_stages_lidar2img_per_call(T, head):

@@ -1052,6 +1052,47 @@ def test_deterministic_backward_is_bit_identical_on_any_schedule(A, golden_dir):
                 assert abs(float(a_[k]) - float(b_[k])) <= 2e-6 * max(1.0, abs(float(a_[k]))), (other, k)
 
 
+def test_deterministic_backward_with_a_varying_token_count(A, golden_dir):
+    """radar.pack_tokens rounds T to multiples of 64, so T varies from frame to frame on real data.
+    The device copy of the accumulation ranges used to sit right behind the dK | dV shadows -- an offset that moves with T --
+    and a shorter frame left its six pointer words inside the shadow range of a later, longer frame (times 2^-40: ~1e2 added
+    to dK | dV).  Now the copy lives in the LAST words of the shadow buffer.  One trainer sees T = 128, 64, 128 (update=False:
+    same parameters); the gradients of the third call must be torch.equal to a fresh trainer's on the same frame, the
+    shadow is zero in front of its tail after every call, and a non-representable partial sum is not silently finite."""
+    from transcar_amd import ops
+    from transcar_amd.trainer import FusionTrainer
+    feats, metas, gt, labels = frame_inputs(golden_dir)
+    g5 = np.load(os.path.join(golden_dir, 'g5_head_tiny.npz'))
+    nhwc = [ops.to_nhwc(x) for x in feats]
+    l2i = ops.lidar2img_tensor(metas, dev())
+    img_hw = metas[0]['img_shape'][0][:2]
+
+    def toks(h, n_per_radar):
+        m = synth.make_img_metas(1, synth.make_lidar2img(), radar=synth.make_radar_frame(seed=5, n_per_radar=n_per_radar, centres=g5['radar_centres']))
+        return h.radar_tokens(m, dev())
+    h = train_head(golden_dir)
+    tr = FusionTrainer(h, dropout=0.1, seed=2, lr=1e-5, deterministic=True)
+    seen = []
+    for n in (20, 10, 20):                     # 100 / 50 / 100 points -> T = 128 / 64 / 128
+        tokens, pad_mult = toks(h, n)
+        seen.append(tokens.shape[1])
+        tr.bucket.zero_grad()
+        tr.step_fused_nhwc(nhwc, l2i, img_hw, tokens, pad_mult, [gt], [labels], update=False)
+        torch.cuda.synchronize()
+        assert int(tr._shadow[:-8].abs().max()) == 0
+    assert seen == [128, 64, 128], seen
+    third = tr.bucket.grads.clone()
+    h2 = train_head(golden_dir)
+    tr2 = FusionTrainer(h2, dropout=0.1, seed=2, lr=1e-5, deterministic=True)
+    tokens, pad_mult = toks(h2, 20)
+    h2._train_forwards = h._train_forwards - 1          # the fresh trainer draws the dropout seed of the first one's third call
+    tr2.step_fused_nhwc(nhwc, l2i, img_hw, tokens, pad_mult, [gt], [labels], update=False)
+    torch.cuda.synchronize()
+    assert h2.last_dropout_seed == h.last_dropout_seed
+    assert float(third.abs().max()) > 0
+    assert torch.equal(third, tr2.bucket.grads)
+
+
 @pytest.mark.parametrize('rows', [16, 32])
 def test_batched_decoder_lookahead_is_the_single_frame_decoder(A, golden_dir, rows):
     """FusionTrainer(prefetch_depth=P) (round 4): the FROZEN decoder of the next P frames runs as ONE
@@ -1214,6 +1255,11 @@ def test_a_non_finite_cost_matrix_sends_no_gradient_and_raises_as_scipy_does(A, 
     with pytest.raises(ValueError, match='invalid numeric entries'):
         tr.step_fused_nhwc(nhwc, l2i, hw, tokens, pad_mult, [gt], [labels], update=False)
     check_assign_status(h, wait=True)                       # (cleared by the raise)
+    # a bad cost matrix in the LAST iteration of an epoch: no next step would report it -- finish() / state_dict() do
+    tr.step_fused_nhwc(nhwc, l2i, hw, tokens, pad_mult, [bad_gt], [labels], update=False)
+    with pytest.raises(ValueError, match='invalid numeric entries'):
+        tr.state_dict()
+    assert set(tr.state_dict()) == {'head', 'm', 'v', 'iter'}            # (cleared: the checkpoint is written now)
 
 
 def test_backward_chain_guards_non_finite_loss_gradients(A, golden_dir):

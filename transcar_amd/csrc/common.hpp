@@ -120,7 +120,10 @@ __device__ __forceinline__ void stg1(float* p, float v) { *(TC_GLOBAL float*)(p)
 // |v| >= 2^-16, an absolute 9e-13 below) and added with an INTEGER atomic into a shadow of its target: integer sums are
 // exact, so the result does not depend on the order.  det_flush adds the shadows back into the targets (and zeroes them).
 // Two address ranges: the flat gradient bucket, and the backward workspace's dK | dV accumulators.  shadow[r] == nullptr:
-// off (plain float atomics).  |v| must stay below 2^23 (8.4e6); a non-finite v contributes nothing a float would keep.
+// off (plain float atomics).  The fixed-point word holds |v| < 2^23 (8.4e6); a value it cannot hold -- NaN, inf, or
+// larger -- goes to the FLOAT target with a float atomic instead (det_fits / acc_add_at; round 6): the flush adds
+// the shadow onto it, so an exploding or non-finite gradient stays visible in the parameters' gradients exactly as in the
+// default mode (float2ll of such a value is undefined and would have produced a finite wrong sum).
 struct DetAcc {
   const float* lo[2]; const float* hi[2]; long long* shadow[2];
 };
@@ -133,21 +136,13 @@ __host__ __device__ __forceinline__ long long* det_shadow_of(const DetAcc& d, co
     if (d.shadow[r] != nullptr && p >= d.lo[r] && p < d.hi[r]) return d.shadow[r] + (p - d.lo[r]);
   return nullptr;
 }
-// *p += v: through the shadow word sp (of p) when there is one (wave-uniform test), a float atomic otherwise
+__device__ __forceinline__ bool det_fits(float v) { return fabsf(v) < 8388608.0f; }      // false for NaN / inf / |v| >= 2^23
+// *p += v: through the shadow word sp (of p) when there is one (wave-uniform test) and it can hold v, a float atomic otherwise
 __device__ __forceinline__ void acc_add_at(long long* sp, float* p, float v) {
-  if (sp != nullptr) atomicAdd(reinterpret_cast<unsigned long long*>(sp), (unsigned long long)__float2ll_rn(v * DET_SCALE));
+  if (sp != nullptr && det_fits(v)) atomicAdd(reinterpret_cast<unsigned long long*>(sp), (unsigned long long)__float2ll_rn(v * DET_SCALE));
   else unsafeAtomicAdd(p, v);
 }
-__device__ __forceinline__ void acc_add(const DetAcc& d, float* p, float v) {
-#pragma unroll
-  for (int r = 0; r < 2; ++r)
-    if (d.shadow[r] != nullptr && p >= d.lo[r] && p < d.hi[r]) {
-      atomicAdd(reinterpret_cast<unsigned long long*>(d.shadow[r] + (p - d.lo[r])),
-                (unsigned long long)__float2ll_rn(v * DET_SCALE));
-      return;
-    }
-  unsafeAtomicAdd(p, v);
-}
+__device__ __forceinline__ void acc_add(const DetAcc& d, float* p, float v) { acc_add_at(det_shadow_of(d, p), p, v); }
 
 // ---- dropout (training): counter-based Bernoulli masks ----------------------
 // keep(seed, site, idx): ONE splitmix64 of (seed, site, idx / 4) decides the four elements 4 (idx / 4) .. + 3 from its

@@ -220,10 +220,14 @@ int launch_linear_bwd_weight_group(const WeightJob* jobs, int n, hipStream_t s);
 // backward row chain) hand the calling thread's current DetAcc to their kernels.  tc_radar_train_bwd_fused_det sets it
 // for the duration of ITS call (DetScope) -- per call, per thread: not a process-wide switch.
 DetAcc& current_det();
+// ... and where the DEVICE copy of it lives for the backward row chain (launch_det_store): the LAST words of the caller's
+// shadow buffer -- a place that does not move with (B, T) (round 6, ADVICE r5: behind the dK | dV shadows it moved with T,
+// and a shorter frame left its pointer words inside a longer frame's shadow range)
+DetAcc*& current_det_device();
 struct DetScope {
-  DetAcc saved;
-  explicit DetScope(const DetAcc& d) : saved(current_det()) { current_det() = d; }
-  ~DetScope() { current_det() = saved; }
+  DetAcc saved; DetAcc* saved_dev;
+  DetScope(const DetAcc& d, DetAcc* dev) : saved(current_det()), saved_dev(current_det_device()) { current_det() = d; current_det_device() = dev; }
+  ~DetScope() { current_det() = saved; current_det_device() = saved_dev; }
   DetScope(const DetScope&) = delete;
   DetScope& operator=(const DetScope&) = delete;
 };

@@ -465,12 +465,11 @@ __device__ __forceinline__ float4 radar_attn_bwd_row(float cx, float cy, float b
           dq.x += ds * k4.x; dq.y += ds * k4.y; dq.z += ds * k4.z; dq.w += ds * k4.w;
           float* dk = dkv + (size_t)tok * ldkv + 4 * lane;
           if (sdkv != nullptr) {       // deterministic mode (wave-uniform): integer atomics on the shadow of dkv
-            unsigned long long* sk = reinterpret_cast<unsigned long long*>(sdkv + (size_t)tok * ldkv + 4 * lane);
-            auto fx = [](float v) { return (unsigned long long)__float2ll_rn(v * DET_SCALE); };
-            atomicAdd(sk + 0, fx(ds * q4.x)); atomicAdd(sk + 1, fx(ds * q4.y));
-            atomicAdd(sk + 2, fx(ds * q4.z)); atomicAdd(sk + 3, fx(ds * q4.w));
-            atomicAdd(sk + 256, fx(pk * dO.x)); atomicAdd(sk + 257, fx(pk * dO.y));
-            atomicAdd(sk + 258, fx(pk * dO.z)); atomicAdd(sk + 259, fx(pk * dO.w));
+            long long* sk = sdkv + (size_t)tok * ldkv + 4 * lane;
+            acc_add_at(sk + 0, dk + 0, ds * q4.x); acc_add_at(sk + 1, dk + 1, ds * q4.y);
+            acc_add_at(sk + 2, dk + 2, ds * q4.z); acc_add_at(sk + 3, dk + 3, ds * q4.w);
+            acc_add_at(sk + 256, dk + 256, pk * dO.x); acc_add_at(sk + 257, dk + 257, pk * dO.y);
+            acc_add_at(sk + 258, dk + 258, pk * dO.z); acc_add_at(sk + 259, dk + 259, pk * dO.w);
           } else {
             unsafeAtomicAdd(dk + 0, ds * q4.x); unsafeAtomicAdd(dk + 1, ds * q4.y);
             unsafeAtomicAdd(dk + 2, ds * q4.z); unsafeAtomicAdd(dk + 3, ds * q4.w);

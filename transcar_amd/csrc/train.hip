@@ -198,8 +198,7 @@ __device__ __forceinline__ void bwd_gemm_body(const BwdGemmK& p, const int bx, c
         if (row < p.I && col < p.J) {
           float v = acc[t][reg] * p.alpha;
           if (p.cmask != nullptr && p.cmask[(size_t)row * p.ldC + col] <= 0.f) v = 0.f;
-          atomicAdd(reinterpret_cast<unsigned long long*>(sC + ((size_t)row * p.ldC + col)),
-                    (unsigned long long)__float2ll_rn(v * DET_SCALE));
+          acc_add_at(sC + ((size_t)row * p.ldC + col), p.C + (size_t)row * p.ldC + col, v);
         }
       }
     }
@@ -336,6 +335,10 @@ int launch_linear_bwd_weight_group(const WeightJob* jobs, int n, hipStream_t s) 
 DetAcc& current_det() {
   static thread_local DetAcc d = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
   return d;
+}
+DetAcc*& current_det_device() {
+  static thread_local DetAcc* p = nullptr;
+  return p;
 }
 __global__ __launch_bounds__(256) void det_flush_kernel(float* dst, long long* shadow, size_t n) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {

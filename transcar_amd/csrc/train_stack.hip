@@ -562,10 +562,11 @@ int tc_radar_train_bwd_fused_ex(const tc_head_weights* w, const tc_head_weights*
   a.qscale = 1.0f / sqrtf((float)(C / w->num_heads));
   a.drop = make_drop(dropout_p, dropout_seed, 0u, (unsigned)w->num_radar_tokens_ref);
   {
-    // deterministic mode: the chain reads the ranges from a device copy behind the shadows (tc_radar_train_bwd_fused_det)
+    // deterministic mode: the chain reads the ranges from a device copy in the last words of the caller's shadow buffer
+    // (tc_radar_train_bwd_fused_det)
     const DetAcc& d = current_det();
-    if (d.shadow[0] != nullptr && d.shadow[1] != nullptr) {
-      DetAcc* dev = reinterpret_cast<DetAcc*>(d.shadow[1] + (d.hi[1] - d.lo[1]));
+    DetAcc* dev = current_det_device();
+    if (d.shadow[0] != nullptr && d.shadow[1] != nullptr && dev != nullptr) {
       TS_TRY(launch_det_store(d, dev, s));
       a.det_device = dev;
     }
@@ -630,8 +631,11 @@ int tc_radar_train_bwd_fused_ex(const tc_head_weights* w, const tc_head_weights*
 // the attention backward's dK | dV -- becomes an integer atomic on a 2^-40 fixed-point shadow (common.hpp DetAcc), the
 // split reductions of the token side run unsplit, and two flush launches add the shadows back.  Two calls on the same
 // inputs give bit-identical gradients.  grad_base / grad_elems: the span that holds every tensor of `grads` (the flat
-// bucket); shadow: grad_elems + 3 * B * T * 2 * embed_dims + 8 64-bit words, the first grad_elems + 3 B T 2 C of them ZERO on
-// entry (the call leaves them zero; the last 8 are scratch).
+// bucket); shadow: shadow_elems >= grad_elems + 3 * B * T * 2 * embed_dims + 8 64-bit words, the first grad_elems + 3 B T 2 C of
+// them ZERO on entry (the call leaves them zero); the LAST 8 words of the buffer (shadow + shadow_elems - 8 ...) are
+// scratch -- they hold the device copy of the ranges, at a place that does not depend on (B, T): one buffer sized for the
+// longest frame serves every shorter one (round 6; until then the copy sat right behind the dK | dV shadows and a
+// shorter frame's copy was read as sums by a later, longer one).
 int tc_radar_train_bwd_fused_det(const tc_head_weights* w, const tc_head_weights* grads, const float* hs_last,
                                  const float* last_box, const float* radar_tokens, int B, int T, int pad_mult,
                                  const float* all_bbox_preds, const float* d_all_cls, const float* d_all_box,
@@ -645,7 +649,8 @@ int tc_radar_train_bwd_fused_det(const tc_head_weights* w, const tc_head_weights
   TC_REQUIRE(bwd_ws_layout(w, B, T, workspace, workspace_bytes, &ws) <= workspace_bytes,
              "radar_train_bwd_fused_det: workspace too small");
   const size_t dkv_elems = (size_t)TC_MAX_RADAR_LAYERS * B * T * 2 * w->embed_dims;
-  constexpr size_t kTail = (sizeof(DetAcc) + 7) / 8;          // a device copy of the ranges behind the shadows
+  constexpr size_t kTail = 8;                                 // a device copy of the ranges in the buffer's last words
+  static_assert(sizeof(DetAcc) <= kTail * 8, "the device copy of the ranges fits the tail");
   TC_REQUIRE(shadow_elems >= grad_elems + dkv_elems + kTail, "radar_train_bwd_fused_det: shadow holds %zu words, %zu needed",
              shadow_elems, grad_elems + dkv_elems + kTail);
   TC_REQUIRE(ws.dkv[TC_MAX_RADAR_LAYERS - 1] + (size_t)B * T * 2 * w->embed_dims == ws.dkv[0] + dkv_elems,
@@ -653,7 +658,7 @@ int tc_radar_train_bwd_fused_det(const tc_head_weights* w, const tc_head_weights
   DetAcc d;
   d.lo[0] = grad_base; d.hi[0] = grad_base + grad_elems; d.shadow[0] = shadow;
   d.lo[1] = ws.dkv[0]; d.hi[1] = ws.dkv[0] + dkv_elems; d.shadow[1] = shadow + grad_elems;
-  DetScope scope(d);
+  DetScope scope(d, reinterpret_cast<DetAcc*>(shadow + (shadow_elems - kTail)));
   return tc_radar_train_bwd_fused_ex(w, grads, hs_last, last_box, radar_tokens, B, T, pad_mult, all_bbox_preds, d_all_cls,
                                      d_all_box, tape, tape_bytes, workspace, workspace_bytes, dropout_p, dropout_seed,
                                      layer_losses, layer_losses_clean, flags, stream);

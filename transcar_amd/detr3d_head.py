@@ -195,6 +195,7 @@ class Detr3DHead(BaseModule):
         #: path, switches this head to the exact-fp32 kernels (``matrix_fallback``) from the next forward on
         self._status_buf = None
         self.matrix_fallback = False
+        self.matrix_fallback_generation = -1
         self._radar_stage = {}
         self._ingest_streams = {}       # device -> side stream of the two-phase forward (forward_nhwc(fill_tokens=))
         #: bumped whenever a device buffer a captured hipGraph may point at (packed weights,
@@ -790,11 +791,23 @@ class Detr3DHead(BaseModule):
             self._range_overflow()
         return v
 
-    def _range_overflow(self):
+    def _range_overflow(self, pinned=False):
+        """The f16-range guard fired (status word 0).  Clears the word; on the automatic matrix path the head falls back
+        to the exact-fp32 kernels AND bumps ``buffers_generation`` (round 6): captured graphs -- FramePipeline
+        lanes, with the matrix path and the 32-row tiles baked in -- are stale from here on and the pipeline re-captures
+        (``matrix_fallback_generation`` names the bump as this one).  With the path pinned to f16x2 nothing can fall back:
+        every overflow warns."""
         import warnings
         self._status_buf[:1].zero_()
+        if pinned or (self.forward_options is not None and self.forward_options.matrix_path == L.TC_MATRIX_F16X2):
+            warnings.warn('transcar_amd: a linear step of the f16x2 matrix path produced a non-finite value and the matrix '
+                          'path is pinned to f16x2: the affected rows are inf / NaN in every such forward (matrix_path = '
+                          'auto would fall back to the exact-fp32 kernels).')
+            return
         if not self.matrix_fallback:
             self.matrix_fallback = True
+            self.buffers_generation += 1
+            self.matrix_fallback_generation = self.buffers_generation
             warnings.warn('transcar_amd: a linear step of the f16x2 matrix path produced a non-finite value (an activation '
                           'beyond 4.19e6 or a weight beyond 65504 in magnitude, or non-finite inputs); the affected rows '
                           'are inf / NaN.  Forwards with matrix_path = auto run on the exact-fp32 kernels from now on '

@@ -33,6 +33,7 @@ Ordering contract (the producer works on the CURRENT stream):
 """
 import torch
 
+from . import _lib as _L
 from . import ops
 from ._lib import TransCARHipError
 
@@ -105,14 +106,20 @@ class FramePipeline:
         self._partial = {}
         self.last_flush = None
         self._last = [None] * len(self.streams)        # per lane: (valid frame slots, outputs) of its last launch
+        # f16-range guard (tc_head_options.range_status, round 6 / ADVICE r5): every lane's graph ENDS with a copy of the
+        # head's sticky status word into a pinned host word of the lane -- `wait(lane)` reads it without another
+        # synchronisation, reports it (`range_status(lane)`) and lets the head fall back; nobody calls get_bboxes here
+        self._status_host = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in self.inputs]
+        self._status_seen = [0] * len(self.inputs)
         self._next = 0
         self._capture()
 
     def _auto_tile_rows(self, rows):
         """the library's automatic rule (chain.hip tile_rows()): 4 up to 1024 rows per launch, 8 up to 2048, 16 up to
         4096, 32 beyond (16 when the matrix path is pinned to f32)"""
-        from . import _lib as L
-        if rows > 4096 and int(self.options.matrix_path) != L.TC_MATRIX_F32:
+        mp = int(self.options.matrix_path)
+        f32 = mp == _L.TC_MATRIX_F32 or (mp == _L.TC_MATRIX_AUTO and self.head.matrix_fallback)
+        if rows > 4096 and not f32:
             return 32
         return 4 if rows <= 1024 else 8 if rows <= 2048 else 16
 
@@ -152,10 +159,13 @@ class FramePipeline:
             self.radar_stage[i].build(self.inputs[i]['tokens'], n=n)
         outs = self.head.forward_nhwc(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'],
                                       inp['pad_mult'], lane=i, options=self._options_of(n))
-        if not self.decode:
-            return outs, None
-        dec = ops.box_decode_topk(outs['all_cls_scores'][-1], outs['all_bbox_preds'][-1],
-                                  self.head.bbox_coder.post_center_range, self.head.bbox_coder.max_num)
+        dec = None
+        if self.decode:
+            dec = ops.box_decode_topk(outs['all_cls_scores'][-1], outs['all_bbox_preds'][-1],
+                                      self.head.bbox_coder.post_center_range, self.head.bbox_coder.max_num)
+        sb = self.head._status_buf
+        if sb is not None and sb.device == inp['l2i'].device:
+            self._status_host[i].copy_(sb[:1], non_blocking=True)      # (a memcpy node of the lane's graph)
         return outs, dec
 
     def _capture(self):
@@ -215,6 +225,11 @@ class FramePipeline:
             n = None
         if n is not None and not 1 <= n < self.frames_per_launch:
             raise TransCARHipError('launch: n=%r of %d frame slots' % (n, self.frames_per_launch))
+        if self.head.buffers_generation != self._generation and \
+                self.head.matrix_fallback_generation == self.head.buffers_generation:
+            # the f16-range guard fired (wait() below, or a get_bboxes of the plugin path): the head is on the exact-fp32
+            # kernels now, these graphs still hold the f16x2 kernels -- capture them again (host-synchronous, once)
+            self.recapture()
         if self.head.buffers_generation != self._generation:
             raise TransCARHipError(
                 'FramePipeline: the head re-allocated device buffers (packed weights / workspaces) '
@@ -348,7 +363,20 @@ class FramePipeline:
         return bool(T < R.NUM_RADAR_TOKENS and int(self.radar_stage[lane].count[:n].max().item()) > T - 1)
 
     def wait(self, lane):
+        """Block until the lane's last launch has finished.  Also reads the f16-range status the launch left in the
+        lane's pinned word: non-zero = a linear step of the f16x2 path produced inf / NaN somewhere in a forward since the
+        word was last cleared (the affected rows of THIS launch's outputs may be non-finite: `range_status(lane)`); on
+        the automatic matrix path the head falls back to the exact-fp32 kernels and the next `launch` re-captures."""
         self.streams[lane].synchronize()
+        v = int(self._status_host[lane][0])
+        self._status_seen[lane] = v
+        if v:
+            self._status_host[lane][0] = 0
+            self.head._range_overflow(pinned=int(self.options.matrix_path) == _L.TC_MATRIX_F16X2)
+
+    def range_status(self, lane):
+        """The f16-range status word as `wait(lane)` last read it (0: in range)."""
+        return self._status_seen[lane]
 
     def synchronize(self):
         for s in self.streams:

@@ -184,6 +184,16 @@ class FusionTrainer:
         rows = self.prefetch_depth * int(head.num_query)
         self.decoder_tile_rows = (32 if rows > 4096 else 16) if self.prefetch_depth > 1 else None
 
+    def _decoder_tile_rows_now(self):
+        """`decoder_tile_rows`, resolved at the call: 32-row tiles exist on the f16x2 matrix path only (chain.hip
+        tile_rows()), so with ``decoder_matrix_path = 'f32'`` -- or after the f16-range guard's fall-back -- a depth
+        that asks for 32 rows runs the f32 kernels' 16 (every look-ahead raised otherwise)."""
+        rows = self.decoder_tile_rows
+        mp = getattr(self, 'decoder_matrix_path', None)
+        if rows == 32 and (mp == 'f32' or (mp in (None, 'auto') and self.head.matrix_fallback)):
+            return 16
+        return rows
+
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -209,7 +219,7 @@ class FusionTrainer:
         with torch.no_grad():
             return self.head.forward_nhwc(feats_nhwc, lidar2img, img_hw, tokens, pad_mult, aux='train',
                                           _allow_train=True, decoder_only=True, lane=lane,
-                                          options=head_options(tile_rows=self.decoder_tile_rows,
+                                          options=head_options(tile_rows=self._decoder_tile_rows_now(),
                                                                matrix_path=getattr(self, 'decoder_matrix_path', None),
                                                                decoder_dropout_p=self.decoder_dropout,
                                                                dropout_seed=seed,
@@ -446,6 +456,20 @@ class FusionTrainer:
                 ev[0].record()
             self._optimizer_step(lr, pending=pending, mark=ev)
         return {k: v.detach() for k, v in losses.items()}
+
+    def finish(self):
+        """Call at the end of an epoch, before an evaluation and before a checkpoint is written (``state_dict`` below does):
+        waits for the status words of every iteration still in flight and raises the ValueError scipy raises in the
+        reference (ASSIGN:117-125) if one of them met a non-finite cost matrix -- `step_fused_nhwc` polls without a
+        synchronisation and would report the LAST iteration only at a next one that never comes."""
+        if self.device_loss:
+            from .device_loss import check_assign_status
+            check_assign_status(self.head, wait=True)
+
+    def state_dict(self):
+        """Checkpoint of the head's parameters (the reference's keys) + the optimizer state; `finish()` first."""
+        self.finish()
+        return dict(head=self.head.state_dict(), m=self.m.clone(), v=self.v.clone(), iter=self.iter)
 
     def _backward_workspace(self, lib, w, key, B, T, device):
         if getattr(self, '_bws_key', None) != key:
