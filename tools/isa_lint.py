@@ -7,7 +7,13 @@ lanes 48..63 of the low result while ANOTHER wave on the same SIMD had vector-me
 its matrix-core MFMAs had just read.  The library is built with -fno-slp-vectorize (no v_pk_*_f32 is formed at
 all) and this lint fails the CPU test suite if a packed f32 op with a non-zero op_sel entry ever comes back.
 
-    python tools/isa_lint.py [path/to/libtranscar_hip.so]      (exit code 1 on a finding)
+Rule PK-MFMA (round 6): every packed-f32 op inside a symbol that also issues MFMAs is REPORTED
+(`lint_text(...)[1]['pk_mfma']`: [(symbol, packed ops, MFMAs)]) -- beside MFMAs a packed f32 op costs +22-26 cycles over the
+two scalar ops it replaces (MI355X_MICROARCH.md).  Round 5's library held 16 / 40 `v_pk_mul_f32 ... op_sel_hi:[1,0]` in the
+two attention cores (hipcc legalises `acc *= alpha` on an ext_vector_type that way, with or without the SLP
+vectoriser); they are scalar multiplies now (self_attn.hip scale_f4) and the CPU suite asserts the list stays empty.
+
+    python tools/isa_lint.py [path/to/libtranscar_hip.so]      (exit code 1 on a finding of either rule)
 """
 import os
 import re
@@ -60,7 +66,8 @@ def lint_text(text):
     """Findings in a disassembly / assembly listing: [(symbol, line, instruction)]."""
     findings = []
     sym = None
-    stats = {'pk_f32': 0, 'mfma': 0, 'kernels': 0}
+    stats = {'pk_f32': 0, 'mfma': 0, 'kernels': 0, 'pk_mfma': []}
+    per = {}                                  # symbol -> [packed f32 ops, MFMAs]
     for ln, line in enumerate(text.split('\n')):
         m = re.match(r'^[0-9a-f]* ?<([^>]+)>:$', line) or re.match(r'^(_Z\w+):', line)
         if m:
@@ -69,13 +76,16 @@ def lint_text(text):
             continue
         if 'v_mfma_' in line:
             stats['mfma'] += 1
+            per.setdefault(sym, [0, 0])[1] += 1
         pk = PK_F32.search(line)
         if not pk:
             continue
         stats['pk_f32'] += 1
+        per.setdefault(sym, [0, 0])[0] += 1
         sel = OP_SEL.search(pk.group(2))
         if sel and '1' in sel.group(1):
             findings.append((sym, ln + 1, line.strip()))
+    stats['pk_mfma'] = [(s_, n[0], n[1]) for s_, n in per.items() if n[0] and n[1]]      # rule PK-MFMA
     return findings, stats
 
 
@@ -87,7 +97,9 @@ def main():
         lib, stats['kernels'], stats['mfma'], stats['pk_f32'], len(findings)))
     for sym, ln, ins in findings[:40]:
         print('  PK-OPSEL  %s  line %d: %s' % ((sym or '?')[:80], ln, ins))
-    return 1 if findings else 0
+    for sym, npk, nm in stats['pk_mfma']:
+        print('  PK-MFMA   %s: %d packed f32 ops beside %d MFMAs' % ((sym or '?')[:80], npk, nm))
+    return 1 if findings or stats['pk_mfma'] else 0
 
 
 if __name__ == '__main__':
