@@ -1523,12 +1523,17 @@ __device__ __forceinline__ float* buf_ptr(ChainLds<R, NREC>& S, int id) {
 __device__ __forceinline__ int buf_ld(int id) { return id == B_A ? LD5 : id == B_L ? LDL : LD2; }
 
 #ifdef TC_CHAIN_STAMPS
-// debug build only (make STAMPS=1): s_memtime after every step of workgroup 100
+// debug build only (make STAMPS=1): s_memtime after every step of workgroup 100 -- and of a second workgroup
+// (g_stamp_block2, tc_debug_stamp_block2: block 100's partner on its CU in the stagger experiment below)
 __device__ long long g_chain_stamps[CH_NW_MAX][64];
+__device__ long long g_chain_stamps2[CH_NW_MAX][64];
+__device__ int g_stamp_block2 = -1;
 #define STEP_STAMP()                                                                          \
   do {                                                                                        \
     if (blockIdx.x == 100 && lane == 0 && stamp_i < 64)                                       \
       g_chain_stamps[wave][stamp_i] = __builtin_amdgcn_s_memtime();                           \
+    if ((int)blockIdx.x == g_stamp_block2 && lane == 0 && stamp_i < 64)                       \
+      g_chain_stamps2[wave][stamp_i] = __builtin_amdgcn_s_memtime();                          \
     ++stamp_i;                                                                                \
   } while (0)
 #else
@@ -1568,6 +1573,14 @@ __device__ long long g_wg_span[1024][2];
   do {                                                                                        \
     if (threadIdx.x == 0 && blockIdx.x < 1024) g_wg_span[blockIdx.x][(which)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
+// ROUND 6 EXPERIMENT (tools/stagger_probe.py): two 16-row workgroups share a CU; the SECOND arrival
+// on a CU starts TRANSCAR_CHAIN_DBG bits 8..15 x 4096 cycles late, so that its row-local phases (epilogues, LayerNorm,
+// sampling: VALU / LDS / latency) run beside the first one's item loops (matrix cores) and vice versa.  With more
+// workgroups than slots (18 / 27 frames per launch) a later workgroup takes the slot -- and the phase -- of the one
+// that ended: the offset persists over the launch.  Arrival number per CU: key = XCC id + the SE / SH / CU fields of
+// HW_ID; g_wg_cu[block] = {key, ticket} for the write-up.  The launcher zeroes the tickets (tc_debug_stagger_reset).
+__device__ unsigned g_cu_ticket[2048];
+__device__ int g_wg_cu[2048][2];
 #else
 #define START_STAMP(slot) do {} while (0)
 #define WG_STAMP(which) do {} while (0)
@@ -1603,6 +1616,26 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAllT<nw_
   if (CHAIN_DBG(k.dbg) & 64) return;
   START_STAMP(40);
   WG_STAMP(0);
+#ifdef TC_CHAIN_STAMPS
+  if constexpr (R == 16 && PROG == PROG_DECODER) {
+    const int stg = (k.dbg >> 8) & 0xFF;
+    if (stg > 0 || (k.dbg & (1 << 16))) {         // (bit 16: draw and record the tickets without a delay)
+      const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);         // HW_REG_HW_ID
+      const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);        // HW_REG_XCC_ID
+      const unsigned key = ((xcc & 7u) << 8) | ((hw >> 8) & 0xFFu);
+      unsigned tk = 0;
+      if (threadIdx.x == 0) {
+        tk = atomicAdd(&g_cu_ticket[key], 1u);
+        if (blockIdx.x < 2048) { g_wg_cu[blockIdx.x][0] = (int)key; g_wg_cu[blockIdx.x][1] = (int)tk; }
+      }
+      tk = (unsigned)__builtin_amdgcn_readfirstlane((int)tk);       // wave 0 only: the others meet it at the first barrier
+      if (wave == 0 && tk == 1u) {
+#pragma unroll 1
+        for (int i = 0; i < stg; ++i) __builtin_amdgcn_s_sleep(64);
+      }
+    }
+  }
+#endif
   const int total = k.total;
   // The leading global-to-LDS loads of a program (a decoder layer starts with three) go out
   // together: one memory latency, one barrier.
@@ -2565,11 +2598,14 @@ int launch_r(const ChainK& k_, hipStream_t s, const char* what) {
   return check_launch(what);
 }
 
+#ifdef TC_CHAIN_STAMPS
+static int g_dbg_override = -1;     // tc_debug_set_chain_dbg: TRANSCAR_CHAIN_DBG at run time (tools/stagger_probe.py)
+#endif
 void init_k(ChainK& k) {
   memset(&k, 0, sizeof(k));
 #ifdef TC_CHAIN_STAMPS
   static const int dbg = [] { const char* e = getenv("TRANSCAR_CHAIN_DBG"); return e ? atoi(e) : 0; }();
-  k.dbg = dbg;
+  k.dbg = g_dbg_override >= 0 ? g_dbg_override : dbg;
 #endif
 }
 
@@ -2650,6 +2686,21 @@ int launch(const ChainK& k, hipStream_t s, const char* what) {
 #ifdef TC_CHAIN_STAMPS
 extern "C" int tc_debug_chain_stamps(long long* host_out) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_chain_stamps), sizeof(long long) * CH_NW_MAX * 64);
+}
+extern "C" int tc_debug_chain_stamps2(int block2, long long* host_out) {
+  if (host_out == nullptr) return (int)hipMemcpyToSymbol(HIP_SYMBOL(tc::g_stamp_block2), &block2, sizeof(int));
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(tc::g_chain_stamps2), sizeof(long long) * tc::CH_NW_MAX * 64);
+}
+extern "C" int tc_debug_set_chain_dbg(int v) { tc::g_dbg_override = v; return 0; }
+// zero the per-CU arrival tickets (stream-ordered) / read {cu key, ticket} of every workgroup of the last launch
+extern "C" int tc_debug_stagger_reset(void* stream) {
+  void* p = nullptr;
+  hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(tc::g_cu_ticket));
+  if (e == hipSuccess) e = hipMemsetAsync(p, 0, sizeof(unsigned) * 2048, static_cast<hipStream_t>(stream));
+  return (int)e;
+}
+extern "C" int tc_debug_wg_cu(int* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(tc::g_wg_cu), sizeof(int) * 2048 * 2);
 }
 extern "C" int tc_debug_wg_spans(long long* host_out) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wg_span), sizeof(long long) * 1024 * 2);
