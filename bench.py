@@ -86,6 +86,10 @@ def parse(argv=None):
     ap.add_argument('--no-radar-compact', action='store_true',
                     help='tc_head_options.radar_row_order = 1: the radar chain keeps the queries in their own order '
                          '(default: beyond one frame per launch, queries with a radar hit go first)')
+    ap.add_argument('--pregather', action='store_true',
+                    help='tc_head_options.cam_pregather = 1 (round 6, opt-in): extra workgroups of the attention-core launch in '
+                         'front of a decoder chain gather its camera taps (bit-identical outputs; default: the chain gathers '
+                         'itself -- with three launch sequences in flight the pre-gather costs 2.8 %%)')
     ap.add_argument('--main-only', action='store_true',
                     help='only the main timed loop: no single-lane, roofline, delivery, hand-off, batched or CPU '
                          'side measurements (kernel traces of tools/profile_round.sh)')
@@ -1754,7 +1758,8 @@ def main(argv=None):
         pipe = FramePipeline(head, lanes, options=head_options(tile_rows=args.tile_rows or None,
                                                               last_level_cls_only=args.last_cls_only,
                                                               radar_compact=False if args.no_radar_compact else None,
-                                                              matrix_path=args.matrix_path))
+                                                              matrix_path=args.matrix_path,
+                                                              cam_pregather=bool(args.pregather)))
 
     def step():
         if pipe is None:

@@ -34,7 +34,7 @@ extern "C" {
 #define TC_MAX_LEVELS 4
 #define TC_MAX_LAYERS 8
 #define TC_MAX_RADAR_LAYERS 3
-#define TC_ABI_VERSION 11
+#define TC_ABI_VERSION 12
 
 typedef void* tc_stream_t;
 
@@ -177,6 +177,20 @@ typedef struct {
                                row gate of 0): the FLAG is the signal, not the outputs.  The caller clears it;
                                Detr3DHead reads it where it already reads results back (get_bboxes) and, on
                                TC_MATRIX_AUTO, runs its next forwards on TC_MATRIX_F32 */
+  int cam_pregather;        /* ABI 12 (round 6), opt-in.  feature_sampling (XFMR:381-422) of decoder layer l needs only the
+                               layer's reference points, which are final when layer l - 1 ends -- and the attention core of
+                               layer l runs in between.  1: launches that take the f16x2 attention core (16- / 32-row
+                               tiles) carry the gather as extra workgroups of that launch (projection, the 16 taps of every
+                               visible (query, camera) pair, the four bilinear level values: 4 KiB per pair into
+                               cam_pregather_ws) and the chain's sampling step only weighs and sums them (XFMR:367-373):
+                               the same products in the same order, bit-identical outputs.  Measured (DESIGN.md section
+                               5, round 6): decoder chain 100 -> 89.5 us per nine frames, attention-core launch 42 -> 50.4
+                               us; one launch sequence at a time 1 % faster, three in flight 2.8 % SLOWER (the launch
+                               moves 170 MB more) -- hence 0 = the chain gathers itself (default; layer 0 and the 4- /
+                               8-row launches always do) */
+  void* cam_pregather_ws;   /* cam_pregather = 1: device scratch of tc_cam_pregather_workspace_bytes(w, B) bytes, owned by
+                               the caller for the duration of the call (one per stream in flight) */
+  size_t cam_pregather_bytes;
 } tc_head_options;
 #define TC_MATRIX_AUTO 0
 #define TC_MATRIX_F32 1
@@ -415,6 +429,8 @@ int tc_box_decode_kept(const float* cls_scores, const float* bbox_preds, int B, 
  *   pad_mult     see tc_radar_gated_xattn_fwd
  *   all_cls_scores / all_bbox_preds [3,B,Q,10] */
 size_t tc_head_workspace_bytes(const tc_head_weights* w, int B, int T);
+/* scratch of tc_head_options.cam_pregather = 1 (ABI 12): B * Q * (num_cams * num_levels * C floats + one int) */
+size_t tc_cam_pregather_workspace_bytes(const tc_head_weights* w, int B);
 /* One-time re-layout of the nn.Linear weights into MFMA fragment order for the
  * fused row-chain kernels (1 KiB-coalesced weight streaming): call once per
  * checkpoint load / after an optimizer step changes the weights.  `packed` is a

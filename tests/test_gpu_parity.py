@@ -1183,6 +1183,44 @@ def test_timed_geometry_is_frame_by_frame_the_single_frame_path(T, fpl):
             assert torch.equal(a_[0], b_[slot]), (lane, slot)
 
 
+@pytest.mark.parametrize('case', ['res101-32', 'res101-16', 'tiny-16-ragged'])
+def test_cam_pregather_is_bit_identical_to_the_in_chain_gather(T, case):
+    """Round 6 (tc_head_options.cam_pregather, ABI 12, opt-in): on the f16x2 path the camera taps of decoder
+    layers 1..5 are gathered and bilinearly reduced by extra workgroups of the attention-core launch IN FRONT of the
+    layer's chain (rowdev.hpp cam_pregather_rows), and the chain's sampling step only weighs and sums the stored level
+    values (XFMR:367-373).  Same projection, same taps, same products in the same order: every output of the head --
+    class scores, boxes, decoder states, reference points, hit counts, the visible-pair count -- is torch.equal to
+    the forward whose chains gather for themselves (cam_pregather = 0: the default, every launch until round 5), on the bench's
+    iid-noise ResNet-101 maps at both tile heights and on tiny maps with a ragged last tile (777 queries)."""
+    import bench
+    bench._imports()
+    from transcar_amd.detr3d_head import head_options
+    shapes, rows = case.split('-')[0], int(case.split('-')[1])
+    if case.endswith('ragged'):
+        sd_np = synth.make_state_dict(seed=5, num_query=777)
+        head = T.build_head(configs.head_cfg(num_query=777))
+        head.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
+        head = head.to(dev()).eval()
+        B = 3
+    else:
+        head, _ = bench.build_head(dev())
+        B = 9 if rows == 32 else 5
+    inp = bench.make_inputs(head, dev(), shapes, B, seed=31, host_feats=False)
+    outs = {}
+    for mode in ('pre', 'direct', 'pre2'):
+        o = head.forward_nhwc(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'], inp['pad_mult'], aux=True,
+                              options=head_options(tile_rows=rows, matrix_path='f16x2', cam_pregather=mode != 'direct'))
+        torch.cuda.synchronize()
+        outs[mode] = o
+    assert torch.isfinite(outs['direct']['all_cls_scores']).all()
+    for other in ('pre', 'pre2'):
+        for k in ('all_cls_scores', 'all_bbox_preds'):
+            assert torch.equal(outs[other][k], outs['direct'][k]), (other, k)
+        for k in ('inter_states', 'inter_references', 'radar_hit_counts', 'last_box'):
+            assert torch.equal(outs[other]['aux'][k], outs['direct']['aux'][k]), (other, k)
+        assert int(outs[other]['aux']['sample_pairs']) == int(outs['direct']['aux']['sample_pairs']) > 0
+
+
 @pytest.mark.parametrize('tile_rows', [16, 32])
 def test_soak_of_the_timed_geometry_is_bit_identical_launch_to_launch(T, tile_rows):
     """>= 2 000 replays of bench.py's nine-frame launch (ResNet-101 FPN shapes, iid-noise maps,

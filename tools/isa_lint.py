@@ -11,7 +11,9 @@ Rule PK-MFMA (round 6): every packed-f32 op inside a symbol t
 (`lint_text(...)[1]['pk_mfma']`: [(symbol, packed ops, MFMAs)]) -- beside MFMAs a packed f32 op costs +22-26 cycles over the
 two scalar ops it replaces (MI355X_MICROARCH.md).  Round 5's library held 16 / 40 `v_pk_mul_f32 ... op_sel_hi:[1,0]` in the
 two attention cores (hipcc legalises `acc *= alpha` on an ext_vector_type that way, with or without the SLP
-vectoriser); they are scalar multiplies now (self_attn.hip scale_f4) and the CPU suite asserts the list stays empty.
+vectoriser); the library is now compiled with the packed-f32 ops switched off (`-target-feature -packed-fp32-ops`,
+transcar_amd/csrc/Makefile; scalarising them in the source cost the core 29 registers and 11 % -- profiles/r6_attention_pk.txt)
+and the CPU suite asserts the list stays empty.
 
     python tools/isa_lint.py [path/to/libtranscar_hip.so]      (exit code 1 on a finding of either rule)
 """

@@ -116,7 +116,7 @@ def main():
     B = 18
     best_d = min(results[B], key=lambda x: x[1])[0] or 16
     st = make(B, 1)
-    for d in (0, best_d):
+    for d in sorted({0, best_d, 16, 32}):
         lib.tc_debug_set_chain_dbg((d << 8) | (1 << 16))        # (bit 16: draw the per-CU tickets also at delay 0)
         lib.tc_debug_chain_stamps2(-1, None)
         chain(st)

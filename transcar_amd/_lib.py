@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get('TRANSCAR_HIP_LIB') or os.path.join(_HERE, 'lib', 'lib
 TC_MAX_LEVELS = 4
 TC_MAX_LAYERS = 8
 TC_MAX_RADAR_LAYERS = 3
-TC_ABI_VERSION = 11
+TC_ABI_VERSION = 12
 
 c_fp = C.c_void_p      # device pointers travel as integers
 
@@ -117,7 +117,8 @@ class tc_head_options(C.Structure):
                 ('last_level_cls_only', C.c_int), ('reuse_radar_kv', C.c_int),
                 ('decoder_dropout_p', C.c_float), ('radar_row_order', C.c_int),
                 ('dropout_seed', C.c_ulonglong), ('phase', C.c_int), ('matrix_path', C.c_int),
-                ('dropout_seed_stride', C.c_ulonglong), ('range_status', c_fp)]
+                ('dropout_seed_stride', C.c_ulonglong), ('range_status', c_fp), ('cam_pregather', C.c_int),
+                ('cam_pregather_ws', c_fp), ('cam_pregather_bytes', C.c_size_t)]
 
 
 TC_MATRIX_AUTO, TC_MATRIX_F32, TC_MATRIX_F16X2 = 0, 1, 2
@@ -169,6 +170,7 @@ SIGNATURES = {
                                 _vp, _vp, _vp, _vp, _sz, _vp]),
     'tc_box_decode_kept': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _P(_f), _f, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'tc_head_workspace_bytes': (_sz, [_P(tc_head_weights), _i, _i]),
+    'tc_cam_pregather_workspace_bytes': (_sz, [_P(tc_head_weights), _i]),
     'tc_head_packed_bytes': (_sz, [_P(tc_head_weights)]),
     'tc_head_pack_weights': (_i, [_P(tc_head_weights), _vp, _sz,
                                   _P(tc_head_weights), _vp]),

@@ -347,6 +347,7 @@ struct ChainDev {
   // decoder
   const float* ref_in; int ref_mod; float* ref_out; float* box_m;
   CamK cam; unsigned long long* pair_counter;
+  const float* pre; const int* premask;     // round 6: the sampling step's pre-gathered level values / visibility masks, or null
   // radar
   const float* tokens; int RI, T, pad_mult;
   const float* ref_last; const float* box_in;
@@ -1590,7 +1591,10 @@ __device__ int g_wg_cu[2048][2];
 // uses.  (One code image for all four programs made the R = 4 kernel spill 9 dwords to a
 // private segment under the combined pressure of the camera-sampling and radar-attention
 // bodies; the specialised kernels are smaller and were 3.5 % faster per frame.)
-template <int R, int PROG, bool DROP = false, int MM = 0>
+// PRE (round 6; decoder program on the f16x2 path only): the sampling step reads the level values the pre-gather workgroups
+// of the attention-core launch stored -- its own instantiations, so that the kernels that gather for themselves keep
+// their code and registers exactly (with both paths in one kernel the direct-gather launches lost 2 us to 12 more spills)
+template <int R, int PROG, bool DROP = false, int MM = 0, bool PRE = false>
 __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAllT<nw_of(R)>* __restrict__ recs, const int block) {
   constexpr int NW = nw_of(R), NT = NW * 64;        // waves / threads of the workgroup
   constexpr bool PL = R == 32;                      // the activation units hold planes (act_ld4 / act_st4)
@@ -2013,6 +2017,65 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAllT<nw_
         if (CHAIN_DBG(k.dbg) & 8) break;
         int pairs = 0;
         CAM_STAMP(5);
+        if constexpr (PRE) {
+          // Round 6: the taps were gathered and bilinearly reduced by the pre-gather workgroups of the attention-core
+          // launch in front of this one (rowdev.hpp cam_pregather_rows: same projection, same tap geometry, same
+          // cam_level_value).  What is left: a row's visibility mask, 4 KiB contiguous per visible (row, camera) pair,
+          // sigmoid(attention_weights) . level value, summed in cam_sample_core's order -- bit-identical.  The FIRST
+          // visible camera of all the wave's rows is fetched in one round trip (1.03 visible cameras per row on the
+          // bench's rig); further cameras of a row follow one pair at a time.
+          constexpr int NR = R / NW;
+          const int NC = k.cam.num_cams;
+          int mk = 0;
+          if (lane < NR) mk = k.premask[min(m0 + wave + NW * lane, M - 1)];
+          float4 v[NR][4];
+          int vmask[NR], cam0[NR];
+          const float* rowp[NR];
+#pragma unroll
+          for (int i = 0; i < NR; ++i) {
+            vmask[i] = __builtin_amdgcn_readlane(mk, i);
+            cam0[i] = vmask[i] ? __ffs(vmask[i]) - 1 : 0;
+            const int grow = min(m0 + wave + NW * i, M - 1);
+            rowp[i] = k.pre + ((size_t)grow * NC) * (4 * 256) + 4 * lane;
+#pragma unroll
+            for (int l = 0; l < 4; ++l) v[i][l] = ld4(rowp[i] + ((size_t)cam0[i] * 4 + l) * 256);   // (no visible camera: read, never used)
+          }
+#pragma unroll
+          for (int i = 0; i < NR; ++i) {
+            const int row = wave + NW * i;
+            const float sg_lane = sigmoidf_(S.l[row][min(lane, NC * 4 - 1)]);
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            int rest = vmask[i];
+            if (rest) {                                  // (wave-uniform)
+              float4 camacc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+              for (int l = 0; l < 4; ++l) {
+                const float a = lane_f(sg_lane, cam0[i] * 4 + l);
+                camacc.x += v[i][l].x * a; camacc.y += v[i][l].y * a; camacc.z += v[i][l].z * a; camacc.w += v[i][l].w * a;
+              }
+              acc.x += camacc.x; acc.y += camacc.y; acc.z += camacc.z; acc.w += camacc.w;
+              rest &= rest - 1;
+#pragma unroll 1
+              while (rest) {
+                const int cam = __ffs(rest) - 1;
+                rest &= rest - 1;
+                float4 u[4];
+#pragma unroll
+                for (int l = 0; l < 4; ++l) u[l] = ld4(rowp[i] + ((size_t)cam * 4 + l) * 256);
+                float4 ca = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int l = 0; l < 4; ++l) {
+                  const float a = lane_f(sg_lane, cam * 4 + l);
+                  ca.x += u[l].x * a; ca.y += u[l].y * a; ca.z += u[l].z * a; ca.w += u[l].w * a;
+                }
+                acc.x += ca.x; acc.y += ca.y; acc.z += ca.z; acc.w += ca.w;
+              }
+            }
+            act_st4<PL>(buf_ptr(S, r.dst) + row * LD2, 4 * lane, acc);
+            if (m0 + row < M) pairs += __popc(vmask[i]);
+          }
+        } else {
+        // (launchers: PRE instantiations exist where k.pre is set -- decoder program, f16x2 path)
         // The projections of ALL the wave's rows first, 16 lanes per row (lane 16 i + c: row wave + 4 i, camera c):
         // one round trip for the reference points and one for the lidar2img rows per WAVE instead of per row
         // (stamps: 3 300 of a row's 7 700 cycles were its projection -- two dependent global loads and a
@@ -2036,6 +2099,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAllT<nw_
                                               [](int, int, int, const float* ptr) { return ld4(ptr); }, 16 * i);
           act_st4<PL>(buf_ptr(S, r.dst) + row * LD2, 4 * lane, o);
           if (m0 + row < M) pairs += __popcll(vmask);
+        }
         }
         CAM_STAMP(6);
         if (k.pair_counter != nullptr && lane == 0 && pairs > 0)
@@ -2378,21 +2442,21 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAllT<nw_
   WG_STAMP(1);
 }
 
-template <int R, int PROG, bool DROP = false, int MM = 0>
+template <int R, int PROG, bool DROP = false, int MM = 0, bool PRE = false>
 __global__ __launch_bounds__(nw_of(R) * 64, 2) void chain_kernel(ChainDev k, Recs<rec_cap(PROG), nw_of(R)> recs) {
-  chain_body<R, PROG, DROP, MM>(k, recs.s, blockIdx.x);
+  chain_body<R, PROG, DROP, MM, PRE>(k, recs.s, blockIdx.x);
 }
 
 // Two programs in one launch: workgroups [0, na) run the decoder layer `ka` on RA-row
 // tiles, the rest the radar encoders `kb` on RB-row tiles.  Decoder layer 0 carries the
 // encoders this way: as a branch of the hipGraph on a side stream, the fork and the join
 // each left a ~10 us hole in the replayed frame (profiles: rocprofv3 kernel trace).
-template <int RA, int RB, int PROGB, int MM = 0>
+template <int RA, int RB, int PROGB, int MM = 0, bool PRE = false>
 __global__ __launch_bounds__(nw_of(RA) * 64, 2) void chain_dual_kernel(ChainDev ka, ChainDev kb, int na,
                                                            Recs<rec_cap(PROG_DECODER), nw_of(RA)> ra,
                                                            Recs<rec_cap(PROGB), nw_of(RB)> rb) {
   static_assert(nw_of(RA) == nw_of(RB), "both programs of a launch run with the same workgroup size");
-  if ((int)blockIdx.x < na) chain_body<RA, PROG_DECODER, false, MM>(ka, ra.s, blockIdx.x);
+  if ((int)blockIdx.x < na) chain_body<RA, PROG_DECODER, false, MM, PRE>(ka, ra.s, blockIdx.x);
   else chain_body<RB, PROGB, false, MM>(kb, rb.s, (int)blockIdx.x - na);
 }
 
@@ -2554,12 +2618,12 @@ void resolve_program(ChainK& k, StepAllT<nw_of(R)>* out) {
   k.early_n = early;
 }
 
-template <int RA, int RB, int PROGB, int MM = 0>
+template <int RA, int RB, int PROGB, int MM = 0, bool PRE = false>
 int launch_dual_r(const ChainK& ka_, const ChainK& kb_, hipStream_t s, const char* what) {
   constexpr size_t lds = chain_lds_bytes<RA, PROG_DECODER>() > chain_lds_bytes<RB, PROGB>() ? chain_lds_bytes<RA, PROG_DECODER>() : chain_lds_bytes<RB, PROGB>();
   static DeviceOnce once;
   if (const int once_dev = once.need(); once_dev >= 0) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_dual_kernel<RA, RB, PROGB, MM>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_dual_kernel<RA, RB, PROGB, MM, PRE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("chain: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     once.done(once_dev);
@@ -2572,16 +2636,16 @@ int launch_dual_r(const ChainK& ka_, const ChainK& kb_, hipStream_t s, const cha
   resolve_program<RA, PROG_DECODER, MM>(ka, ra.s);
   resolve_program<RB, PROGB, MM>(kb, rb.s);
   const int na = (ka.M + RA - 1) / RA, nb = (kb.M + RB - 1) / RB;
-  hipLaunchKernelGGL((chain_dual_kernel<RA, RB, PROGB, MM>), dim3(na + nb), dim3(nw_of(RA) * 64), lds, s,
+  hipLaunchKernelGGL((chain_dual_kernel<RA, RB, PROGB, MM, PRE>), dim3(na + nb), dim3(nw_of(RA) * 64), lds, s,
                      static_cast<const ChainDev&>(ka), static_cast<const ChainDev&>(kb), na, ra, rb);
   return check_launch(what);
 }
 
-template <int R, int PROG, bool DROP = false, int MM = 0>
+template <int R, int PROG, bool DROP = false, int MM = 0, bool PRE = false>
 int launch_r(const ChainK& k_, hipStream_t s, const char* what) {
   static DeviceOnce once;
   if (const int once_dev = once.need(); once_dev >= 0) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<R, PROG, DROP, MM>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<R, PROG, DROP, MM, PRE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)chain_lds_bytes<R, PROG>());
     if (e != hipSuccess) { set_error("chain: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
@@ -2593,7 +2657,7 @@ int launch_r(const ChainK& k_, hipStream_t s, const char* what) {
   Recs<rec_cap(PROG), nw_of(R)> recs;
   resolve_program<R, PROG, MM>(k, recs.s);
   constexpr size_t lds = chain_lds_bytes<R, PROG>();
-  hipLaunchKernelGGL((chain_kernel<R, PROG, DROP, MM>), dim3((k.M + R - 1) / R), dim3(nw_of(R) * 64), lds, s,
+  hipLaunchKernelGGL((chain_kernel<R, PROG, DROP, MM, PRE>), dim3((k.M + R - 1) / R), dim3(nw_of(R) * 64), lds, s,
                      static_cast<const ChainDev&>(k), recs);
   return check_launch(what);
 }
@@ -2638,8 +2702,10 @@ int launch_rows(const ChainK& k, hipStream_t s, const char* what) {
   if (rows == 8) return launch_r<8, PROG>(k, s, what);
   if (rows == 32) {
     TC_REQUIRE(use_f16x2(k), "%s: 32-row tiles exist on the f16x2 matrix path only", what);
+    if constexpr (PROG == PROG_DECODER) { if (k.pre != nullptr) return launch_r<32, PROG, false, 1, true>(k, s, what); }
     return launch_r<32, PROG, false, 1>(k, s, what);
   }
+  if constexpr (PROG == PROG_DECODER) { if (k.pre != nullptr && use_f16x2(k)) return launch_r<16, PROG, false, 1, true>(k, s, what); }
   if (use_f16x2(k)) return launch_r<16, PROG, false, 1>(k, s, what);
   return launch_r<16, PROG>(k, s, what);
 }
@@ -2772,6 +2838,8 @@ static int make_decoder_k(const DecoderChainArgs& a, ChainK& k) {
   k.ref_in = a.ref_in; k.ref_mod = a.ref_mod; k.ref_out = a.ref_out; k.box_m = a.box_m;
   fill_camk(a.cam, k.cam);
   k.pair_counter = a.cam.pair_counter;
+  TC_REQUIRE((a.pre == nullptr) == (a.premask == nullptr), "decoder_chain: pre-gathered values and masks come together");
+  k.pre = a.pre; k.premask = a.premask;
   TC_REQUIRE(a.tile_rows == 0 || a.tile_rows == 4 || a.tile_rows == 8 || a.tile_rows == 16 || a.tile_rows == 32,
              "decoder_chain: tile_rows=%d (0 = automatic, 4, 8, 16 or 32)", a.tile_rows);
   k.tile_rows = a.tile_rows;
@@ -2830,10 +2898,10 @@ int launch_decoder_chain_with_encoders(const DecoderChainArgs& d, const RadarEnc
   TC_REQUIRE(kd.drop.thr == 0, "decoder dropout: launch the encoders on their own (launch_radar_encode)");
   const int rows = tile_rows(kd);
   const char* what = "chain(decoder + radar_encode)";
-#define TC_DUAL(RA, RB, MM)                                                           \
-  (part == 1 ? launch_dual_r<RA, RB, PROG_RADAR_ENC_A, MM>(kd, ke, s, what)           \
-   : part == 2 ? launch_dual_r<RA, RB, PROG_RADAR_ENC_B, MM>(kd, ke, s, what)         \
-               : launch_dual_r<RA, RB, PROG_RADAR_ENC, MM>(kd, ke, s, what))
+#define TC_DUAL(RA, RB, MM, ...)                                                              \
+  (part == 1 ? launch_dual_r<RA, RB, PROG_RADAR_ENC_A, MM, ##__VA_ARGS__>(kd, ke, s, what)       \
+   : part == 2 ? launch_dual_r<RA, RB, PROG_RADAR_ENC_B, MM, ##__VA_ARGS__>(kd, ke, s, what)     \
+               : launch_dual_r<RA, RB, PROG_RADAR_ENC, MM, ##__VA_ARGS__>(kd, ke, s, what))
   // 4-row decoder tiles run two workgroups per CU (256 VGPRs): the encoder rows then use 4-row
   // tiles too -- a 16-row body in the same kernel would spill ~100 registers at that budget,
   // and 225 + T/4 workgroups fit the chip at two per CU
@@ -2841,8 +2909,10 @@ int launch_decoder_chain_with_encoders(const DecoderChainArgs& d, const RadarEnc
   if (rows == 8) return TC_DUAL(8, 8, 0);
   if (rows == 32) {
     TC_REQUIRE(use_f16x2(kd), "%s: 32-row tiles exist on the f16x2 matrix path only", what);
+    if (kd.pre != nullptr) return TC_DUAL(32, 32, 1, true);
     return TC_DUAL(32, 32, 1);
   }
+  if (use_f16x2(kd) && kd.pre != nullptr) return TC_DUAL(16, 16, 1, true);
   if (use_f16x2(kd)) return TC_DUAL(16, 16, 1);
   return TC_DUAL(16, 16, 0);
 #undef TC_DUAL

@@ -225,17 +225,6 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
       d.drop = make_drop(opt.decoder_dropout_p, opt.dropout_seed, 16u + 8u * (unsigned)lid, 0u);
       if (opt.dropout_seed_stride != 0) { d.drop.seed_stride = opt.dropout_seed_stride; d.drop.rows_per_sample = (unsigned)Q; }
     }
-    // the attention core follows the chains' rule (chain.hip tile_rows / use_f16x2): launches that run 16-row tiles on
-    // the f16 matrix cores take the staged two-plane core (self_attn.hip, round 4) -- 4- / 8-row launches (one or two
-    // frames: too few workgroups for a form without split keys) and TC_MATRIX_F32 the fp32 core.  A
-    // frame's arithmetic is therefore fixed by (chain_tile_rows, matrix_path), not by how many frames share a launch
-    if (!l0c) {
-      const int trows = opt.chain_tile_rows ? opt.chain_tile_rows : (rows <= 1024 ? 4 : rows <= 2048 ? 8 : 16);   // (32 counts as 16 here)
-      if (trows >= 16 && opt.matrix_path != TC_MATRIX_F32)
-        TC_TRY(launch_self_attn_core_x(h.qk, h.qk + C, 2 * C, h.vt, h.qpad, h.attn_o, C, B, Q, H, s, ddrop ? &d.drop : nullptr));
-      else
-        TC_TRY(launch_self_attn_core(h.qk, h.qk + C, 2 * C, h.vt, h.qpad, h.attn_o, C, B, Q, H, s, ddrop ? &d.drop : nullptr));
-    }
     d.attn_o = l0c ? w->l0_attn_out : h.attn_o;
     d.attn_mod = l0c ? Q : 0; d.ref_mod = l0c ? Q : 0;
     if (lid == 0) { d.x_in = w->query_embedding + C; d.x_ld = 2 * C; d.x_mod = Q; }
@@ -254,6 +243,30 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
     d.cam.pair_counter = pairs;
     d.code = code; d.M = rows; d.tile_rows = opt.chain_tile_rows; d.matrix_path = opt.matrix_path;
     d.range_status = opt.range_status;
+    // the attention core follows the chains' rule (chain.hip tile_rows / use_f16x2): launches that run 16-row tiles on
+    // the f16 matrix cores take the staged two-plane core (self_attn.hip, round 4) -- 4- / 8-row launches (one or two
+    // frames: too few workgroups for a form without split keys) and TC_MATRIX_F32 the fp32 core.  A
+    // frame's arithmetic is therefore fixed by (chain_tile_rows, matrix_path), not by how many frames share a launch.
+    // Round 6 (opt-in, tc_head_options.cam_pregather): the staged core's launch also carries the camera gather of THIS
+    // layer's chain (pre-gather workgroups: the layer's reference points are final since the previous chain).
+    if (!l0c) {
+      const int trows = opt.chain_tile_rows ? opt.chain_tile_rows : (rows <= 1024 ? 4 : rows <= 2048 ? 8 : 16);   // (32 counts as 16 here)
+      if (trows >= 16 && opt.matrix_path != TC_MATRIX_F32) {
+        PreGatherArgs pga;
+        const bool pre = !ddrop && opt.cam_pregather == 1;
+        if (pre) {
+          // scratch: [rows][num_cams][levels][C] level values (only the visible pairs' 4 KiB are ever touched), [rows] masks
+          float* pbuf = static_cast<float*>(opt.cam_pregather_ws);
+          int* pmask = reinterpret_cast<int*>(pbuf + (size_t)rows * w->num_cams * w->num_levels * C);
+          pga.cam = d.cam; pga.M = rows; pga.ref_mod = d.ref_mod; pga.out = pbuf; pga.mask = pmask;
+          d.pre = pbuf; d.premask = pmask;
+        }
+        TC_TRY(launch_self_attn_core_x(h.qk, h.qk + C, 2 * C, h.vt, h.qpad, h.attn_o, C, B, Q, H, s, ddrop ? &d.drop : nullptr,
+                                       pre ? &pga : nullptr));
+      } else {
+        TC_TRY(launch_self_attn_core(h.qk, h.qk + C, 2 * C, h.vt, h.qpad, h.attn_o, C, B, Q, H, s, ddrop ? &d.drop : nullptr));
+      }
+    }
     // the radar encoders ride in two launches, half each (all in layer 0 when there is only one layer)
     if (radar && !ddrop && lid == enc_first) TC_TRY(launch_decoder_chain_with_encoders(d, re, L > 1 ? 1 : 0, s));
     else if (radar && !ddrop && L > 1 && lid == enc_first + 1) TC_TRY(launch_decoder_chain_with_encoders(d, re, 2, s));
@@ -561,6 +574,8 @@ static int read_options(const tc_head_options* options, tc_head_options& opt) {
   TC_REQUIRE(opt.phase == 0 || !opt.unfused, "options.phase=%d needs the fused path", opt.phase);
   TC_REQUIRE(opt.matrix_path >= TC_MATRIX_AUTO && opt.matrix_path <= TC_MATRIX_F16X2,
              "options.matrix_path=%d (0 automatic, 1 fp32 MFMA, 2 two-plane f16 MFMA)", opt.matrix_path);
+  TC_REQUIRE(opt.cam_pregather == 0 || opt.cam_pregather == 1, "options.cam_pregather=%d (0 off, 1 on)", opt.cam_pregather);
+  TC_REQUIRE(opt.cam_pregather == 0 || opt.cam_pregather_ws != nullptr, "options.cam_pregather needs cam_pregather_ws");
   return 0;
 }
 
@@ -778,6 +793,12 @@ int tc_head_repack_trainable(const tc_head_weights* w, tc_head_weights* packed_v
   return tc_head_repack_trainable_ex(w, packed_view, 3, stream);
 }
 
+size_t tc_cam_pregather_workspace_bytes(const tc_head_weights* w, int B) {
+  if (check_dims(w) != 0 || B < 1) return 0;
+  const size_t rows = (size_t)B * w->num_query;
+  return rows * ((size_t)w->num_cams * w->num_levels * w->embed_dims * sizeof(float) + sizeof(int));
+}
+
 size_t tc_head_workspace_bytes(const tc_head_weights* w, int B, int T) {
   if (check_dims(w) != 0) return 0;
   return head_ws_layout(w, B, T, nullptr, ~size_t(0), nullptr);
@@ -799,6 +820,8 @@ int tc_head_forward(const tc_head_weights* w, const tc_head_weights* packed_view
   HeadWs h;
   const size_t need = head_ws_layout(w, B, T, workspace, workspace_bytes, &h);
   TC_REQUIRE(need <= workspace_bytes, "workspace too small: need %zu, have %zu", need, workspace_bytes);
+  TC_REQUIRE(opt.cam_pregather == 0 || opt.cam_pregather_bytes >= tc_cam_pregather_workspace_bytes(w, B),
+             "options.cam_pregather_ws holds %zu bytes, %zu needed", opt.cam_pregather_bytes, tc_cam_pregather_workspace_bytes(w, B));
   hipStream_t s = as_stream(stream);
   const int Q = w->num_query, C = w->embed_dims, F = w->ffn_dims, L = w->num_layers, H = w->num_heads;
   const int code = w->code_size, ncls = w->num_classes;

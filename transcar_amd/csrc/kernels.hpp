@@ -103,6 +103,9 @@ struct DecoderChainArgs {
   // (self-attention output), + 2 (cross-attention output, XFMR:378), + 3 (FFN hidden), + 4 (FFN output)
   DropK drop = DropK{0, 0, 1.0f, 0, 0, 0, 0, 0};
   int* range_status = nullptr;               // f16x2 kernels: sticky non-finite flag (tc_head_options.range_status)
+  // round 6: the sampling step reads what the pre-gather workgroups of the attention-core launch in front stored
+  // (PreGatherArgs::out / mask of the SAME reference points) instead of gathering itself; null: gathers itself
+  const float* pre = nullptr; const int* premask = nullptr;
 };
 int launch_decoder_chain(const DecoderChainArgs& a, hipStream_t s);
 
@@ -184,8 +187,15 @@ int launch_self_attn_core(const float* q, const float* k, int ld, const float* v
                           const DropK* drop = nullptr);
 // the same on the f16 matrix cores, fp32-accurate (round 4): two-plane f16 operands (hi, lo), fp32 accumulate; K / V^T are
 // split and staged through LDS inside the kernel, every wave walks all keys.  Same operands as launch_self_attn_core.
+// pregather (round 6; may be null): extra workgroups of the same launch gather the camera taps of the decoder chain that
+// FOLLOWS (rowdev.hpp cam_pregather_rows): `cam` as for the chain (ref = that layer's reference points), out
+// [M][num_cams][num_levels][256] floats, mask [M] ints.  Eval launches only (drop == null / thr 0).
+struct PreGatherArgs {
+  CamSampleArgs cam; int M, ref_mod; float* out; int* mask;
+};
 int launch_self_attn_core_x(const float* q, const float* k, int ld, const float* vt, int ldt, float* out, int ldo,
-                            int B, int Q, int H, hipStream_t s, const DropK* drop = nullptr);
+                            int B, int Q, int H, hipStream_t s, const DropK* drop = nullptr,
+                            const PreGatherArgs* pregather = nullptr);
 
 // ---- radar_attn.hip --------------------------------------------------------
 struct RadarAttnArgs {

@@ -140,6 +140,22 @@ __device__ __forceinline__ float lane_f(float v, int j) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
 }
 
+// The bilinear value of one level of one (query, camera) pair: the four taps times their weights, NaN -> 0 on the
+// sampled value (XFMR:367).  ONE definition for the in-chain sampling (cam_sample_core) and for the pre-gather
+// workgroups of the attention-core launch (cam_pregather_rows, round 6): same expression, same contraction, same bits.
+__device__ __forceinline__ float4 cam_level_value(const float4 (&tap)[4], const float (&wgt)[4]) {
+  float4 s;
+  s.x = tap[0].x * wgt[0] + tap[1].x * wgt[1] + tap[2].x * wgt[2] + tap[3].x * wgt[3];
+  s.y = tap[0].y * wgt[0] + tap[1].y * wgt[1] + tap[2].y * wgt[2] + tap[3].y * wgt[3];
+  s.z = tap[0].z * wgt[0] + tap[1].z * wgt[1] + tap[2].z * wgt[2] + tap[3].z * wgt[3];
+  s.w = tap[0].w * wgt[0] + tap[1].w * wgt[1] + tap[2].w * wgt[2] + tap[3].w * wgt[3];
+  if (s.x != s.x) s.x = 0.f;
+  if (s.y != s.y) s.y = 0.f;
+  if (s.z != s.z) s.z = 0.f;
+  if (s.w != s.w) s.w = 0.f;
+  return s;
+}
+
 // Weighted sum over the visible cameras (XFMR:365-373).  u, v: lane c holds camera c's
 // coordinates; lg: the query's num_cams*L attention logits (any address space);
 // fetch(c, l, t, ptr): this lane's 4 channels of tap t of level l of the c-th visible camera.
@@ -176,16 +192,7 @@ __device__ __forceinline__ float4 cam_sample_core(const CamK& p, int b, const fl
     float4 camacc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int l = 0; l < L; ++l) {
-      float4 s;
-      s.x = tap[l][0].x * wgt[l][0] + tap[l][1].x * wgt[l][1] + tap[l][2].x * wgt[l][2] + tap[l][3].x * wgt[l][3];
-      s.y = tap[l][0].y * wgt[l][0] + tap[l][1].y * wgt[l][1] + tap[l][2].y * wgt[l][2] + tap[l][3].y * wgt[l][3];
-      s.z = tap[l][0].z * wgt[l][0] + tap[l][1].z * wgt[l][1] + tap[l][2].z * wgt[l][2] + tap[l][3].z * wgt[l][3];
-      s.w = tap[l][0].w * wgt[l][0] + tap[l][1].w * wgt[l][1] + tap[l][2].w * wgt[l][2] + tap[l][3].w * wgt[l][3];
-      // XFMR:367 -- NaN -> 0 on the sampled value
-      if (s.x != s.x) s.x = 0.f;
-      if (s.y != s.y) s.y = 0.f;
-      if (s.z != s.z) s.z = 0.f;
-      if (s.w != s.w) s.w = 0.f;
+      const float4 s = cam_level_value(tap[l], wgt[l]);
       const float a = lane_f(sg_lane, cam * L + l);   // XFMR:370, mask == 1 here
       camacc.x += s.x * a; camacc.y += s.y * a; camacc.z += s.z * a; camacc.w += s.w * a;
     }
@@ -194,6 +201,73 @@ __device__ __forceinline__ float4 cam_sample_core(const CamK& p, int b, const fl
     ++c;
   }
   return acc;
+}
+
+// ---- round 6: the camera gather off the decoder chain's critical path ------------------------------
+// The reference points of decoder layer l are final when chain l - 1 ends, and the attention core of layer l runs in
+// between: extra workgroups of THAT launch (self_attn.hip) project every row, fetch the 16 taps of every visible
+// (row, camera) pair and store the four bilinear level values (cam_level_value: 4 x 1 KiB per pair) plus the row's
+// visibility mask.  The chain's sampling step then reads 4 KiB contiguous per pair and only weighs and sums
+// (sigmoid(attention_weights) . mask, XFMR:367-373) -- the same products in the same order: bit-identical outputs.
+//   out  [M][num_cams][L][256] floats (only visible pairs are written / read), mask [M] ints (bit c: camera c visible)
+struct PreGatherK {
+  CamK cam;                   // data / H / W / l2i / ref (this layer's reference points) / pc / img size
+  int M, ref_mod;             // rows; reference rows taken modulo ref_mod when > 0
+  float* out; int* mask;
+  int nblocks;                // workgroups of the launch that run this role (0: none)
+};
+// the rows r0 .. r0 + nrows - 1 (nrows a multiple of 4) of one WAVE
+template <int L>
+__device__ __forceinline__ void cam_pregather_rows(const PreGatherK& g, int r0, int nrows, int lane) {
+  const CamK& p = g.cam;
+#pragma unroll 1
+  for (int base = 0; base < nrows; base += 4) {
+    // lane 16 i + c: row r0 + base + i, camera c -- the projections of four rows in one round trip
+    float pu, pv;
+    unsigned long long vm;
+    {
+      const int i = lane >> 4, c = lane & 15;
+      const int row = r0 + base + i;
+      const int grow = min(row, g.M - 1);
+      const bool act = row < g.M && c < p.num_cams;
+      vm = __ballot(cam_project_lane(p, g.ref_mod > 0 ? grow % g.ref_mod : grow, grow / p.Q, min(c, p.num_cams - 1), act, pu, pv));
+    }
+    if (lane < 4 && r0 + base + lane < g.M) g.mask[r0 + base + lane] = (int)((vm >> (16 * lane)) & 0xFFFFull);
+    unsigned long long rest = vm;
+#pragma unroll 1
+    while (rest) {
+      const int bit = __ffsll((long long)rest) - 1;
+      rest &= rest - 1;
+      const int cam = bit & 15;
+      const int grow = r0 + base + (bit >> 4);
+      float w_lane;
+      int pix_lane;
+      cam_tap_lane<L>(p, grow / p.Q, cam, lane_f(pu, bit), lane_f(pv, bit), lane, w_lane, pix_lane);
+      // two levels (eight taps: 8 KiB per wave in flight) at a time: 32 tap registers instead of 64 -- the role must fit
+      // the attention core's 128-register budget (four waves per SIMD: at 156 registers the core itself lost a quarter of
+      // its occupancy and 5 us per launch, measured)
+      float* o = g.out + (((size_t)grow * p.num_cams + cam) * L) * 256 + 4 * lane;
+#pragma unroll
+      for (int l0 = 0; l0 < L; l0 += 2) {
+        float4 tap[2][4];
+        float wgt[2][4];
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            wgt[l][t] = lane_f(w_lane, 4 * (l0 + l) + t);
+            tap[l][t] = ld4(cam_tap_ptr(p, l0 + l, __builtin_amdgcn_readlane(pix_lane, 4 * (l0 + l) + t), lane));
+          }
+        }
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+          const float4 s = cam_level_value(tap[l], wgt[l]);
+          st4(o + (l0 + l) * 256, s);
+        }
+        __builtin_amdgcn_sched_barrier(0);          // (the second half's taps are not hoisted above the first half's sums)
+      }
+    }
+  }
 }
 
 template <int L>
