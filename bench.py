@@ -1399,12 +1399,21 @@ def train_bench(args, head, inp, dev, rank, world, affinity=None):
     exposed = None
     if not args.train_autograd:
         tr.exchange_events = []
+        tr.exchange_chunk_events = []
         for _ in range(20):
             step()
         torch.cuda.synchronize()
         gaps = sorted(a.elapsed_time(b) for a, b in tr.exchange_events)
         tr.exchange_events = None
         exposed = {'median': gaps[len(gaps) // 2], 'max': gaps[-1], 'iterations': len(gaps)}
+        if tr.exchange_chunk_events:
+            # the exchange in chunks (more than one rank): the compute stream's wait for each chunk's all-reduce, in the
+            # order it waits (fusion layer 3, 2, 1, radar encoders) -- chunk k travels while chunk k + 1 is computed, so
+            # only the last one should show
+            per = list(zip(*[[evs[i].elapsed_time(evs[i + 1]) for i in range(len(evs) - 1)] for evs in tr.exchange_chunk_events]))
+            exposed['per_chunk_median'] = [sorted(c)[len(c) // 2] for c in per]
+            exposed['chunk_bytes'] = [4 * (b - a) for a, b in tr.bucket.chunk_ranges]
+        tr.exchange_chunk_events = None
     # the cost of the order-free backward beside the default ("report the cost in bench.py --train"):
     # the SAME trainer flipped to deterministic=True for three windows of the same length (one rank, fused path only)
     det_cost = None

@@ -602,13 +602,22 @@ int tc_radar_train_bwd_fused(const tc_head_weights* w, const tc_head_weights* gr
                              float* layer_losses_clean, tc_stream_t stream);
 /* The same with `flags`: bit 0 = the workspace already holds the transposed packed weights of the CURRENT parameters
  * (tc_radar_train_repack packed them in the launch that re-packed the forward's copy): the backward's own pack launch
- * is skipped. */
+ * is skipped.  Bit 1 (ABI 12) = the weight gradients dW = dY^T X are NOT formed by this call: the caller launches them
+ * chunk by chunk with tc_radar_train_bwd_weights (below) and starts the gradient exchange of a chunk behind its launch. */
 int tc_radar_train_bwd_fused_ex(const tc_head_weights* w, const tc_head_weights* grads, const float* hs_last,
                                 const float* last_box, const float* radar_tokens, int B, int T, int pad_mult,
                                 const float* all_bbox_preds, const float* d_all_cls, const float* d_all_box,
                                 void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes,
                                 float dropout_p, unsigned long long dropout_seed, const float* layer_losses,
                                 float* layer_losses_clean, int flags, tc_stream_t stream);
+/* ABI 12 (round 6): the weight gradients of one chunk after tc_radar_train_bwd_fused_ex(flags bit 1) on the same stream,
+ * same tape / workspace: group 0 .. TC_MAX_RADAR_LAYERS - 1 = fusion layers from the TOP one down (the order a layer-wise
+ * backward finishes them, the order DDP's buckets fill in the reference: tools/train.py:253-260), TC_MAX_RADAR_LAYERS =
+ * the radar encoders.  Every group is one grouped launch (two with the 10-wide heads); together they add exactly what the
+ * single grouped launch of tc_radar_train_bwd_fused_ex adds. */
+int tc_radar_train_bwd_weights(const tc_head_weights* w, const tc_head_weights* grads, const float* hs_last,
+                               const float* radar_tokens, int B, int T, void* tape, size_t tape_bytes, void* workspace,
+                               size_t workspace_bytes, int group, tc_stream_t stream);
 /* ABI 11: the same backward with ORDER-FREE accumulation -- what torch calls a deterministic algorithm.  The backward adds
  * partial sums from many workgroups into one element in five places (weight-gradient row chunks, bias column sums,
  * LayerNorm parameter gradients of the row chain and of the token side, dK | dV of the attention backward); with float

@@ -45,8 +45,11 @@ def main():
     calls = []                                           # every collective of the iterations: (elements, async?)
     real_all_reduce = dist.all_reduce
 
+    tr.chunk_events = []                                 # (chunk, event behind its weight-gradient launch)
+
     def counting_all_reduce(t, *a, **kw):
-        calls.append((int(t.numel()), bool(kw.get('async_op', False))))
+        # ... and how many weight-gradient chunk launches had been ENQUEUED when the collective was issued
+        calls.append((int(t.numel()), bool(kw.get('async_op', False)), len(tr.chunk_events)))
         return real_all_reduce(t, *a, **kw)
     dist.all_reduce = counting_all_reduce
     for it in range(3):
@@ -56,9 +59,13 @@ def main():
         losses.append(float(sum(out.values())))
     torch.cuda.synchronize()
     dist.all_reduce = real_all_reduce
+    # device order of the chunk launches of the last iteration: each ends after the one before
+    last = [ev for _, ev in tr.chunk_events[-4:]]
+    chunk_order_ok = all(last[i].elapsed_time(last[i + 1]) > 0.0 for i in range(3)) if len(last) == 4 else False
     p = tr.bucket.params.double()
     mine = dict(rank=rank, sum=float(p.sum()), abs=float(p.abs().sum()), first=p[:8].tolist(), losses=losses, calls=calls,
-                finite=bool(torch.isfinite(p).all()), seed=int(tr.last_dropout_seed))
+                finite=bool(torch.isfinite(p).all()), seed=int(tr.last_dropout_seed),
+                chunks=[b - a for a, b in tr.bucket.chunk_ranges], chunk_order_ok=chunk_order_ok)
     parts = [None] * world
     dist.all_gather_object(parts, mine)
     if rank == 0:

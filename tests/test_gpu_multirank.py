@@ -47,12 +47,19 @@ def test_two_ranks_on_one_gpu_end_with_the_same_parameters():
     assert a['sum'] == b['sum'] and a['abs'] == b['abs'] and a['first'] == b['first']
     # different frames and different dropout streams (the rank is part of the seed): different local losses
     assert a['losses'] != b['losses'] and a['seed'] != b['seed']
-    # exactly TWO collectives per iteration (DESIGN section 7 = north_star): the loss normalisers (a few floats,
-    # HEAD:885-902) and the flat gradient bucket, started asynchronously behind the backward
+    # Round 6: 1 + 4 collectives per iteration -- the loss normalisers (a few floats, HEAD:885-902) and
+    # the gradient bucket in its four exchange chunks (fusion layer 3, 2, 1, radar encoders: together the whole bucket),
+    # each started asynchronously right behind the launch that finished its weight gradients: when chunk g's collective
+    # was issued, exactly g + 1 chunk launches of the iteration had been enqueued -- i.e. it is on its way before the
+    # later weight-gradient launches (and the last one in particular) have even started
     for part in (a, b):
-        assert len(part['calls']) == 2 * 3, part['calls']
-        for small, big in zip(part['calls'][0::2], part['calls'][1::2]):
-            assert small[0] <= 8 and big[0] > 2_000_000 and big[1] is True, (small, big)
+        assert len(part['calls']) == 5 * 3, part['calls']
+        assert len(part['chunks']) == 4 and sum(part['chunks']) > 2_000_000 and part['chunk_order_ok']
+        for it in range(3):
+            small, chunks = part['calls'][5 * it], part['calls'][5 * it + 1:5 * it + 5]
+            assert small[0] <= 8
+            assert [c[0] for c in chunks] == part['chunks'] and all(c[1] is True for c in chunks), chunks
+            assert [c[2] for c in chunks] == [4 * it + g + 1 for g in range(4)], chunks
 
 
 def test_training_bench_with_two_ranks_finishes_and_reports_its_roofline():

@@ -1262,6 +1262,58 @@ def test_a_non_finite_cost_matrix_sends_no_gradient_and_raises_as_scipy_does(A, 
     assert set(tr.state_dict()) == {'head', 'm', 'v', 'iter'}            # (cleared: the checkpoint is written now)
 
 
+@pytest.mark.parametrize('tag', ['tiny', 'res101'])
+def test_weight_gradients_in_exchange_chunks_equal_the_grouped_launch(A, golden_dir, tag):
+    """Round 6: tc_radar_train_bwd_fused_ex(flags bit 1) + tc_radar_train_bwd_weights(group 0..3) --
+    fusion layer 3, 2, 1, radar encoders, one launch each, what a multi-rank iteration runs so that a chunk's all-reduce
+    travels under the next chunk's launch -- add exactly the gradients of the single grouped launch (up to the float
+    atomics' order); every chunk writes ONLY its own range of the bucket (the exchange of chunk g may start behind launch
+    g); the chunk ranges tile the bucket in exchange order."""
+    import ctypes as C
+    from transcar_amd import _lib as L, ops
+    from transcar_amd.trainer import FusionTrainer, exchange_chunk_of
+    h = train_head(golden_dir)
+    feats, metas, gt, labels = frame_inputs(golden_dir, tag)
+    nhwc = [ops.to_nhwc(f) for f in feats]
+    l2i = ops.lidar2img_tensor(metas, dev())
+    tokens, pad_mult = h.radar_tokens(metas, dev())
+    tr = FusionTrainer(h, dropout=0.1, seed=4)
+    tr.keep_last = True
+    tr.step_fused_nhwc(nhwc, l2i, metas[0]['img_shape'][0][:2], tokens, pad_mult, [gt], [labels], update=False)
+    torch.cuda.synchronize()
+    want = tr.bucket.grads.clone()
+    assert float(want.abs().max()) > 0
+    k, lib = tr._last, L.lib()
+    rngs = tr.bucket.chunk_ranges
+    assert len(rngs) == 4 and rngs[0][0] == 0 and rngs[-1][1] == tr.bucket.numel and all(a[1] == b[0] for a, b in zip(rngs, rngs[1:]))
+    for n, off in zip(tr.bucket.names, tr.bucket.offsets):
+        a, b = rngs[exchange_chunk_of(n)]
+        assert a <= off < b, n
+    tr.bucket.zero_grad()
+    L.check(lib.tc_radar_train_bwd_fused_ex(
+        C.byref(k['w']), C.byref(k['g']), k['hs_last'].data_ptr(), k['last_box'].data_ptr(), k['tokens'].data_ptr(),
+        k['B'], k['T'], k['pad_mult'], k['all_box'].data_ptr(), k['d_cls'].data_ptr(), k['d_box'].data_ptr(),
+        k['tape'].data_ptr(), k['tape'].numel(), tr._bws.data_ptr(), tr._bws.numel(), tr.dropout, k['seed'], None, None,
+        2, tr._stream()), 'bwd (weights deferred)')
+    torch.cuda.synchronize()
+    before = tr.bucket.grads.clone()              # LayerNorm / bias-free parts the chain itself adds; no weight gradient yet
+    for gi, (a, b) in enumerate(rngs):
+        L.check(lib.tc_radar_train_bwd_weights(
+            C.byref(k['w']), C.byref(k['g']), k['hs_last'].data_ptr(), k['tokens'].data_ptr(), k['B'], k['T'],
+            k['tape'].data_ptr(), k['tape'].numel(), tr._bws.data_ptr(), tr._bws.numel(), gi, tr._stream()), 'weights %d' % gi)
+        torch.cuda.synchronize()
+        now = tr.bucket.grads.clone()
+        changed = (now != before).nonzero().flatten()
+        assert changed.numel() > 0 and int(changed.min()) >= a and int(changed.max()) < b, (gi, a, b, int(changed.min()), int(changed.max()))
+        before = now
+    scale = float(want.abs().max())
+    assert float((before - want).abs().max()) <= 2e-6 * scale
+    with pytest.raises(L.TransCARHipError):
+        L.check(lib.tc_radar_train_bwd_weights(
+            C.byref(k['w']), C.byref(k['g']), k['hs_last'].data_ptr(), k['tokens'].data_ptr(), k['B'], k['T'],
+            k['tape'].data_ptr(), k['tape'].numel(), tr._bws.data_ptr(), tr._bws.numel(), 4, tr._stream()), 'weights 4')
+
+
 def test_backward_chain_guards_non_finite_loss_gradients(A, golden_dir):
     """HEAD:915-916 zeroes a non-finite loss; its gradient must not reach the bucket either.  With the fused
     backward that guard lives INSIDE the backward chain (tc_radar_train_bwd_fused(layer_losses=...)): a level whose

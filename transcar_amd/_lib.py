@@ -216,6 +216,8 @@ SIGNATURES = {
     'tc_radar_train_bwd_fused_det': (_i, [_P(tc_head_weights), _P(tc_head_weights), _vp,
                                           _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp, _sz,
                                           _f, C.c_ulonglong, _vp, _vp, _i, _vp, _sz, _vp, _sz, _vp]),
+    'tc_radar_train_bwd_weights': (_i, [_P(tc_head_weights), _P(tc_head_weights), _vp, _vp, _i, _i, _vp, _sz, _vp, _sz,
+                                        _i, _vp]),
     'tc_radar_train_repack': (_i, [_P(tc_head_weights), _P(tc_head_weights), _vp, _sz, _i, _i, _vp]),
     'tc_dropout_mask': (_i, [_f, C.c_ulonglong, _i, _sz, _vp, _vp]),
     'tc_normalize_bbox': (_i, [_vp, _i, _vp, _vp]),

@@ -511,6 +511,56 @@ size_t tc_radar_train_bwd_workspace_bytes(const tc_head_weights* w, int B, int T
   return bwd_ws_layout(w, B, T, nullptr, ~size_t(0), nullptr);
 }
 
+// The weight gradients dW = dY^T X (+ bias column sums) of the trainable stack from the tape and the dY tensors the backward
+// chain / the token side stored.  group -1: all 38 in one grouped launch; 0 .. TC_MAX_RADAR_LAYERS - 1: the jobs of fusion
+// layer (TC_MAX_RADAR_LAYERS - 1 - group) -- the top layer first, the order in which a layer-wise backward would finish
+// them --; TC_MAX_RADAR_LAYERS: the token side (radar encoders).
+static int weight_gradients(const tc_head_weights* w, const tc_head_weights* grads, const float* hs_last,
+                            const float* radar_tokens, int B, int T, const Tape& t, const BwdWs& ws, int group, hipStream_t s) {
+  const int Q = w->num_query, C = w->embed_dims, F = w->ffn_dims, code = w->code_size;
+  const int ncls = w->num_classes, RI = w->radar_in_dims;
+  const int rows = B * Q, rt = B * T;
+  const tc_pos_encoder& gpe = grads->radar_position_encoder;
+  float* du = t.dkv;                 // [rt, C] scratch of the tape (the token side's LayerNorm backward wrote it)
+  float* du0 = ws.du0;               // [rt, C]
+  WeightJob jobs[11 * TC_MAX_RADAR_LAYERS + 5];
+  int n = 0;
+  auto job = [&](const float* x, const float* dy, const tc_linear& g, int M, int K, int N, const float* relu = nullptr,
+                 int ldx = 0) {
+    WeightJob j;
+    j.x = x; j.dy = dy; j.dw = const_cast<float*>(g.w); j.db = const_cast<float*>(g.b); j.M = M; j.K = K; j.N = N; j.relu = relu;
+    j.ldx = ldx;
+    jobs[n++] = j;
+  };
+  for (int r = 0; r < TC_MAX_RADAR_LAYERS; ++r) {
+    if (group >= 0 && r != TC_MAX_RADAR_LAYERS - 1 - group) continue;
+    const tc_radar_layer& gl = grads->radar[r];
+    const LayerTape& l = t.L[r];
+    const size_t off = (size_t)r * ws.dy_stride;
+    const float* qin = r == 0 ? hs_last : t.L[r - 1].x3;
+    job(qin, ws.dy[DY_DQP] + off, tc_linear{gl.attn.in_proj.w, gl.attn.in_proj.b}, rows, C, C);
+    job(t.mem, ws.dkv[r], tc_linear{gl.attn.in_proj.w + (size_t)C * C, gl.attn.in_proj.b + C}, rt, C, 2 * C);
+    job(l.ao, ws.dy[DY_DPROJ] + off, gl.attn.out_proj, rows, C, C);
+    job(l.x2, ws.dy[DY_DH] + off, gl.linear1, rows, C, F);
+    job(l.h, ws.dy[DY_DFF] + off, gl.linear2, rows, F, C);
+    job(l.x3, ws.dy[DY_DC0] + off, gl.final_cls.l0, rows, C, C);
+    job(l.c1, ws.dy[DY_DC2] + off, gl.final_cls.l3, rows, C, C);
+    job(l.c3, ws.dy[DY_DCLS] + off, gl.final_cls.l6, rows, C, ncls);        // (the guarded copy the chain stored)
+    job(l.x3, ws.dy[DY_DT0] + off, gl.final_reg.l0, rows, C, C);
+    job(l.t0, ws.dy[DY_DT1] + off, gl.final_reg.l2, rows, C, C);
+    job(l.t1, ws.dy[DY_DBOX] + off, gl.final_reg.l4, rows, C, code);
+  }
+  if (group < 0 || group == TC_MAX_RADAR_LAYERS) {
+    job(t.f1, ws.dmem, grads->radar_feat4, rt, 128, C, t.f2);
+    job(t.f0, t.dt128, grads->radar_feat2, rt, 64, 128);
+    job(radar_tokens, t.dt64, grads->radar_feat0, rt, RI, 64);
+    job(t.u1, du, gpe.l3, rt, C, C);
+    // radar_position_encoder.0 (Linear(3, C)): X = the tokens' first three columns (xyz), read in place
+    job(radar_tokens, du0, gpe.l0, rt, 3, C, nullptr, RI);
+  }
+  return launch_linear_bwd_weight_group(jobs, n, s);
+}
+
 int tc_radar_train_bwd_fused_ex(const tc_head_weights* w, const tc_head_weights* grads, const float* hs_last,
                                 const float* last_box, const float* radar_tokens, int B, int T, int pad_mult,
                                 const float* all_bbox_preds, const float* d_all_cls, const float* d_all_box,
@@ -589,40 +639,14 @@ int tc_radar_train_bwd_fused_ex(const tc_head_weights* w, const tc_head_weights*
   TS_TRY(launch_linear_bwd_data(du, nullptr, nullptr, pe.l3.w, nullptr, du2, rt, C, C, 1.0f, 0, s));
   float* du0 = ws.du0;               // [rt, C]
   TS_TRY(ln_bwd(t.u0, nullptr, pe.n1, gpe.n1, du2, t.u1, du0, rt, s));
-  // 5. every weight gradient: one grouped launch (two with the scalar variant for the 10-wide heads)
-  WeightJob jobs[11 * TC_MAX_RADAR_LAYERS + 5];
-  int n = 0;
-  auto job = [&](const float* x, const float* dy, const tc_linear& g, int M, int K, int N, const float* relu = nullptr,
-                 int ldx = 0) {
-    WeightJob j;
-    j.x = x; j.dy = dy; j.dw = const_cast<float*>(g.w); j.db = const_cast<float*>(g.b); j.M = M; j.K = K; j.N = N; j.relu = relu;
-    j.ldx = ldx;
-    jobs[n++] = j;
-  };
-  for (int r = 0; r < TC_MAX_RADAR_LAYERS; ++r) {
-    const tc_radar_layer& gl = grads->radar[r];
-    const LayerTape& l = t.L[r];
-    const size_t off = (size_t)r * ws.dy_stride;
-    const float* qin = r == 0 ? hs_last : t.L[r - 1].x3;
-    job(qin, ws.dy[DY_DQP] + off, tc_linear{gl.attn.in_proj.w, gl.attn.in_proj.b}, rows, C, C);
-    job(t.mem, ws.dkv[r], tc_linear{gl.attn.in_proj.w + (size_t)C * C, gl.attn.in_proj.b + C}, rt, C, 2 * C);
-    job(l.ao, ws.dy[DY_DPROJ] + off, gl.attn.out_proj, rows, C, C);
-    job(l.x2, ws.dy[DY_DH] + off, gl.linear1, rows, C, F);
-    job(l.h, ws.dy[DY_DFF] + off, gl.linear2, rows, F, C);
-    job(l.x3, ws.dy[DY_DC0] + off, gl.final_cls.l0, rows, C, C);
-    job(l.c1, ws.dy[DY_DC2] + off, gl.final_cls.l3, rows, C, C);
-    job(l.c3, ws.dy[DY_DCLS] + off, gl.final_cls.l6, rows, C, ncls);        // (the guarded copy the chain stored)
-    job(l.x3, ws.dy[DY_DT0] + off, gl.final_reg.l0, rows, C, C);
-    job(l.t0, ws.dy[DY_DT1] + off, gl.final_reg.l2, rows, C, C);
-    job(l.t1, ws.dy[DY_DBOX] + off, gl.final_reg.l4, rows, C, code);
+  // 5. every weight gradient: one grouped launch (two with the scalar variant for the 10-wide heads) -- or, flags bit 1,
+  //    left to tc_radar_train_bwd_weights: one launch per fusion layer (top layer first) + one for the token side, so that
+  //    the caller can start the gradient exchange of a chunk while the next one is computed (round 6)
+  if (flags & 2) {
+    TC_REQUIRE(current_det().shadow[0] == nullptr, "radar_train_bwd_fused: chunked weight gradients run with float atomics only");
+    return 0;
   }
-  job(t.f1, ws.dmem, grads->radar_feat4, rt, 128, C, t.f2);
-  job(t.f0, t.dt128, grads->radar_feat2, rt, 64, 128);
-  job(radar_tokens, t.dt64, grads->radar_feat0, rt, RI, 64);
-  job(t.u1, du, gpe.l3, rt, C, C);
-  // radar_position_encoder.0 (Linear(3, C)): X = the tokens' first three columns (xyz), read in place
-  job(radar_tokens, du0, gpe.l0, rt, 3, C, nullptr, RI);
-  TS_TRY(launch_linear_bwd_weight_group(jobs, n, s));
+  TS_TRY(weight_gradients(w, grads, hs_last, radar_tokens, B, T, t, ws, -1, s));
   return launch_det_flush(current_det(), 0, s);      // (deterministic mode: the bucket's sums back into the gradients)
 }
 
@@ -673,6 +697,23 @@ int tc_radar_train_bwd_fused(const tc_head_weights* w, const tc_head_weights* gr
   return tc_radar_train_bwd_fused_ex(w, grads, hs_last, last_box, radar_tokens, B, T, pad_mult, all_bbox_preds, d_all_cls,
                                      d_all_box, tape, tape_bytes, workspace, workspace_bytes, dropout_p, dropout_seed,
                                      layer_losses, layer_losses_clean, 0, stream);
+}
+
+// Round 6: the weight gradients of ONE chunk (tc_radar_train_bwd_fused_ex with flags bit 1 left them out): group 0 ..
+// TC_MAX_RADAR_LAYERS - 1 = fusion layers top-down, TC_MAX_RADAR_LAYERS = the radar encoders.  Same tape / workspace as
+// the backward call it follows on the same stream.
+int tc_radar_train_bwd_weights(const tc_head_weights* w, const tc_head_weights* grads, const float* hs_last,
+                               const float* radar_tokens, int B, int T, void* tape, size_t tape_bytes, void* workspace,
+                               size_t workspace_bytes, int group, tc_stream_t stream) {
+  TS_TRY(check(w, B, T));
+  TC_REQUIRE(grads != nullptr && workspace != nullptr && tape != nullptr, "radar_train_bwd_weights: null argument");
+  TC_REQUIRE(group >= 0 && group <= TC_MAX_RADAR_LAYERS, "radar_train_bwd_weights: group=%d (0..%d)", group, TC_MAX_RADAR_LAYERS);
+  Tape t;
+  TC_REQUIRE(tape_layout(w, B, T, tape, tape_bytes, &t) <= tape_bytes, "radar_train_bwd_weights: tape too small");
+  BwdWs ws;
+  TC_REQUIRE(bwd_ws_layout(w, B, T, workspace, workspace_bytes, &ws) <= workspace_bytes,
+             "radar_train_bwd_weights: workspace too small");
+  return weight_gradients(w, grads, hs_last, radar_tokens, B, T, t, ws, group, as_stream(stream));
 }
 
 // The multipliers (0 or 1 / (1 - p)) of elements 0..n-1 of a dropout site, for tests and for

@@ -24,14 +24,39 @@ import torch.distributed as dist
 from . import _lib as L
 
 
-class FlatBucket:
-    """Flat parameter / gradient storage for [(name, parameter)]."""
+def exchange_chunk_of(name):
+    """Chunk of the gradient exchange a trainable parameter of the fusion stack belongs to, in the order the backward
+    finishes the weight gradients (tc_radar_train_bwd_weights): 0 / 1 / 2 = fusion layer 3 / 2 / 1 (HEAD:129-171: the
+    modules with suffix `3` / `_3`, `2` / `_2`, none), 3 = the radar encoders and anything else."""
+    head = name.split('.')[0]
+    stems = ('final_cls', 'final_reg', 'rf_multihead_attn', 'rf_linear1', 'rf_linear2', 'rf_norm1', 'rf_norm2', 'rf_norm3')
+    for stem in stems:
+        if head.startswith(stem):
+            tail = head[len(stem):]
+            if tail in ('3', '_3'):
+                return 0
+            if tail in ('2', '_2'):
+                return 1
+            if tail == '':
+                return 2
+    return 3
 
-    def __init__(self, named_params):
+
+class FlatBucket:
+    """Flat parameter / gradient storage for [(name, parameter)].
+
+    chunk_of (round 6): name -> chunk index.  The parameters of a chunk are stored contiguously, chunk 0 first
+    (``chunk_ranges``: [(begin, end)] element ranges): the gradient exchange can then travel chunk by chunk while the
+    backward is still producing the next one (``all_reduce_chunk_begin``).  ``names`` / ``items`` / ``offsets`` stay in
+    the order of ``named_params``."""
+
+    def __init__(self, named_params, chunk_of=None):
         self.names = [n for n, _ in named_params]
         self.items = [p for _, p in named_params]
         if not self.items:
             raise ValueError('no trainable parameters')
+        chunks = [int(chunk_of(n)) if chunk_of is not None else 0 for n in self.names]
+        order = sorted(range(len(self.items)), key=lambda i: (chunks[i], i))
         dev = self.items[0].device
         n = sum(p.numel() for p in self.items)
         self.params = torch.empty(n, dtype=torch.float32, device=dev)
@@ -40,15 +65,22 @@ class FlatBucket:
         self._store = torch.zeros(n + L.TC_SQ_NORM_PARTIALS, dtype=torch.float32, device=dev)
         self.grads = self._store[:n]
         self.sq = self._store[n:]
-        self.offsets = []
+        self.offsets = [0] * len(self.items)
+        self.chunk_ranges = []
         off = 0
-        for p in self.items:
+        for i in order:
+            p = self.items[i]
             k = p.numel()
             self.params[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.params[off:off + k].view(p.shape)
             p.grad = self.grads[off:off + k].view(p.shape)
-            self.offsets.append(off)
+            self.offsets[i] = off
+            if not self.chunk_ranges or chunks[i] != self._last_chunk:
+                self.chunk_ranges.append([off, off])
+                self._last_chunk = chunks[i]
             off += k
+            self.chunk_ranges[-1][1] = off
+        self.chunk_ranges = [tuple(r) for r in self.chunk_ranges]
         self.numel = n
 
     def zero_grad(self, check_views=True):
@@ -71,12 +103,24 @@ class FlatBucket:
             return dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, async_op=True), dist.get_world_size()
         return None, 1
 
+    def all_reduce_chunk_begin(self, i):
+        """Start the all-reduce (SUM) of chunk i alone -- ordered behind what is enqueued on the current stream (the launch
+        that produced the chunk's last gradients), beside whatever the compute stream does next (the next chunk's weight
+        gradients).  -> (handle or None, world size), for ``all_reduce_end``."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            a, b = self.chunk_ranges[i]
+            return dist.all_reduce(self.grads[a:b], op=dist.ReduceOp.SUM, async_op=True), dist.get_world_size()
+        return None, 1
+
     @staticmethod
     def all_reduce_end(pending):
-        """The current stream (not the host, on RCCL) waits for the exchange; -> world size."""
-        work, world = pending
-        if work is not None:
-            work.wait()
+        """The current stream (not the host, on RCCL) waits for the exchange -- one handle or a list of chunk handles, in
+        the order they were started; -> world size."""
+        world = 1
+        for work, w in (pending if isinstance(pending, list) else [pending]):
+            if work is not None:
+                work.wait()
+            world = w
         return world
 
 
@@ -143,7 +187,14 @@ class FusionTrainer:
             raise ValueError('FusionTrainer(deterministic=True) needs the fused backward (chain_backward=True): the '
                              'per-operator backward (tc_radar_train_bwd) accumulates with float atomics')
         self._shadow = None
-        self.bucket = FlatBucket(head.trainable_parameters())
+        # Round 6: the bucket is laid out in EXCHANGE CHUNKS -- fusion layer 3, 2, 1, radar encoders,
+        # the order in which the backward finishes their weight gradients -- and with more than one rank an iteration
+        # launches the weight gradients chunk by chunk (tc_radar_train_bwd_weights) with one asynchronous all-reduce
+        # behind each: chunk k travels while chunk k + 1 is computed (`chunked_exchange`; tools/train.py:253-260: DDP's
+        # buckets).  One rank, or deterministic=True (the order-free backward flushes its shadow once, behind ONE grouped
+        # launch): the single grouped launch and the single all-reduce of round 5.
+        self.chunked_exchange = True
+        self.bucket = FlatBucket(head.trainable_parameters(), chunk_of=exchange_chunk_of)
         head.refresh_weights()                      # parameter addresses moved into the bucket
         self.m = torch.zeros_like(self.bucket.params)
         self.v = torch.zeros_like(self.bucket.params)
@@ -422,7 +473,10 @@ class FusionTrainer:
                       int(pad_mult), all_box.data_ptr(), d_cls.data_ptr(), d_box.data_ptr(), tape.data_ptr(),
                       tape.numel(), bws.data_ptr(), bws.numel(), self.dropout, drop_seed,
                       raw_losses.data_ptr() if raw_losses is not None else None,
-                      clean.data_ptr() if clean is not None else None, 1 if self._wT_ready else 0)
+                      clean.data_ptr() if clean is not None else None)
+            chunked = self._exchange_in_chunks(update)
+            flags = (1 if self._wT_ready else 0) | (2 if chunked else 0)
+            common = common + (flags,)
             if self.deterministic:
                 need = self.bucket.numel + 3 * B * T * 2 * head.embed_dims + 8
                 if self._shadow is None or self._shadow.numel() < need or self._shadow.device != tokens.device:
@@ -432,6 +486,19 @@ class FusionTrainer:
                         'tc_radar_train_bwd_fused_det')
             else:
                 L.check(lib.tc_radar_train_bwd_fused_ex(*common, self._stream()), 'tc_radar_train_bwd_fused_ex')
+                if chunked:
+                    # the weight gradients chunk by chunk, each chunk's all-reduce started behind its launch: it travels
+                    # (RCCL's stream) while the compute stream forms the next chunk
+                    chunk_pending = []
+                    for gi in range(len(self.bucket.chunk_ranges)):
+                        L.check(lib.tc_radar_train_bwd_weights(
+                            C.byref(w), C.byref(g), hs_last.data_ptr(), tokens.data_ptr(), B, T, tape.data_ptr(),
+                            tape.numel(), bws.data_ptr(), bws.numel(), gi, self._stream()), 'tc_radar_train_bwd_weights')
+                        if getattr(self, 'chunk_events', None) is not None:
+                            ev = torch.cuda.Event(enable_timing=True)
+                            ev.record()
+                            self.chunk_events.append((gi, ev))
+                        chunk_pending.append(self.bucket.all_reduce_chunk_begin(gi))
             if clean is not None:
                 from .device_loss import loss_dict
                 losses = loss_dict(clean)
@@ -449,7 +516,7 @@ class FusionTrainer:
             # the gradient exchange starts the moment the backward is enqueued; the optimizer waits on its handle
             # (tools/train.py:253-260: DDP's buckets overlap the same way).  `exchange_events` (bench.py --train):
             # how long the compute stream stood still between the backward's end and the optimizer's first kernel
-            pending = self.bucket.all_reduce_begin()
+            pending = chunk_pending if (self.chain_backward and chunked) else self.bucket.all_reduce_begin()
             ev = None
             if getattr(self, 'exchange_events', None) is not None:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -471,6 +538,13 @@ class FusionTrainer:
         self.finish()
         return dict(head=self.head.state_dict(), m=self.m.clone(), v=self.v.clone(), iter=self.iter)
 
+    def _exchange_in_chunks(self, update=True):
+        """Chunked weight-gradient launches + one all-reduce per chunk: only where there is an exchange to hide (more than
+        one rank), on the fused float-atomic backward, and only with the four chunks the C entry knows."""
+        return bool(update and self.chunked_exchange and self.chain_backward and not self.deterministic
+                    and len(self.bucket.chunk_ranges) == 4
+                    and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
     def _backward_workspace(self, lib, w, key, B, T, device):
         if getattr(self, '_bws_key', None) != key:
             nb = lib.tc_radar_train_bwd_workspace_bytes(C.byref(w), B, T)
@@ -481,7 +555,20 @@ class FusionTrainer:
         return self._bws
 
     def _optimizer_step(self, lr=None, pending=None, mark=None):
-        world = self.bucket.all_reduce_end(pending) if pending is not None else self.bucket.all_reduce()
+        if mark is not None and isinstance(pending, list):
+            # (bench.py --train: how long the compute stream waits for EACH chunk's all-reduce, in the order it waits)
+            evs, world = [mark[0]], 1
+            for work, wld in pending:
+                if work is not None:
+                    work.wait()
+                world = wld
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                evs.append(e)
+            if getattr(self, 'exchange_chunk_events', None) is not None:
+                self.exchange_chunk_events.append(evs)
+        else:
+            world = self.bucket.all_reduce_end(pending) if pending is not None else self.bucket.all_reduce()
         if mark is not None:
             mark[1].record()
             self.exchange_events.append(mark)
