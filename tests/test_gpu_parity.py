@@ -1364,6 +1364,81 @@ def test_f16_range_guard_reaches_a_frame_pipeline(T, sd_np):
     assert torch.equal(outs2['all_cls_scores'], want['all_cls_scores']) and torch.equal(outs2['all_bbox_preds'], want['all_bbox_preds'])
 
 
+@pytest.mark.parametrize('layout', ['channels_last', 'nchw'])
+def test_plugin_entry_graphs_are_bit_identical_to_the_eager_entry(T, sd_np, layout):
+    """Round 6: `head(mlvl_feats, img_metas)` + `get_bboxes` replay two captured hipGraphs once a call
+    signature (feature-map addresses, shapes, options) is seen for the second time (transcar_amd/plugin_graph.py).
+    Five calls on the same feature tensors with DIFFERENT frames' radar sweeps / lidar2img and maps refilled in place:
+    call 1 is eager, call 2 captures, calls 3-5 replay -- every call's outputs and decoded boxes are torch.equal to a
+    head whose graphs are switched off; results handed out earlier are not overwritten by later calls; new feature
+    tensors (other addresses) take the eager path again; an in-place weight update is picked up by the next replay."""
+    def make():
+        h = T.build_head(configs.head_cfg())
+        h.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
+        return h.to(dev()).eval()
+    hg, he = make(), make()
+    he.plugin_graphs = False
+    B = 2
+    shapes = configs.LEVEL_SHAPES['tiny']
+
+    def fresh(seed):
+        g = torch.Generator(device=dev())
+        g.manual_seed(seed)
+        fs = [torch.randn((B, 6, 256, h_, w_), device=dev(), generator=g) for (h_, w_) in shapes]
+        if layout == 'channels_last':
+            fs = [f.view(B * 6, 256, *f.shape[-2:]).to(memory_format=torch.channels_last).view(B, 6, 256, *f.shape[-2:]) for f in fs]
+        return fs
+    feats = fresh(5)
+    kept = []
+    # (the very first forward of a head packs its weights and allocates its workspace: the buffer generation -- part of a
+    # call's signature -- settles with it)
+    hg(fresh(3), [synth.make_img_metas(1, radar=synth.make_radar_frame(seed=39, n_per_radar=30 + b))[0] for b in range(B)])
+    base = dict(hg._plugin_graphs.stats)
+    for it in range(5):
+        for f in feats:                                  # the backbone writes the next frames into the same tensors
+            f.mul_(0.9).add_(0.01 * (it + 1))
+        l2i = synth.make_lidar2img()
+        l2i = [m.copy() for m in l2i]
+        l2i[0][0, 3] += 0.05 * it                         # another rig every call
+        metas = [synth.make_img_metas(1, np.stack(l2i), radar=synth.make_radar_frame(seed=40 + 2 * it + b, n_per_radar=30 + b))[0]
+                 for b in range(B)]
+        og = hg(feats, metas)
+        bg = hg.get_bboxes(og, metas)
+        oe = he(feats, metas)
+        be = he.get_bboxes(oe, metas)
+        torch.cuda.synchronize()
+        for k in ('all_cls_scores', 'all_bbox_preds'):
+            assert torch.equal(og[k], oe[k]), (it, k)
+        for sg, se in zip(bg, be):
+            for x, y in zip(sg, se):
+                assert x.shape == y.shape and torch.equal(x, y), it
+        kept.append((og['all_cls_scores'], oe['all_cls_scores'].clone(), bg[0][0], be[0][0].clone()))
+    st = {k: v - base[k] for k, v in hg._plugin_graphs.stats.items()}
+    assert st['captures'] == 1 and st['replays'] == 4 and st['eager'] == 1, st
+    for a_, b_, c_, d_ in kept:                          # what a call handed out still holds that call's values
+        assert torch.equal(a_, b_) and torch.equal(c_, d_)
+    # other tensors: eager again (first sighting of the new signature) ...
+    feats2 = fresh(6)
+    o2 = hg(feats2, metas)
+    assert hg._plugin_graphs.stats['eager'] - base['eager'] == 2 and '_decoded' not in o2
+    assert torch.equal(o2['all_cls_scores'], he(feats2, metas)['all_cls_scores'])
+    # ... and an in-place change of a trainable weight reaches the next replay (re-pack in front of it)
+    with torch.no_grad():
+        for h in (hg, he):
+            h.final_cls3[0].weight.mul_(1.5)
+            h.mark_trainable_dirty()
+    og, oe = hg(feats, metas), he(feats, metas)
+    assert hg._plugin_graphs.stats['replays'] - base['replays'] == 5
+    assert torch.equal(og['all_cls_scores'], oe['all_cls_scores']) and not torch.equal(og['all_cls_scores'][2], kept[-1][0][2])
+    # a dict that is not the entry's latest is decoded again, correctly
+    first = hg(feats, metas)
+    second = hg(feats, metas)
+    b1, b2 = hg.get_bboxes(first, metas), hg.get_bboxes(second, metas)
+    for sg, se in zip(b1, b2):
+        for x, y in zip(sg, se):
+            assert torch.equal(x, y)
+
+
 def test_plugin_entry_stages_lidar2img_per_call(T, head):
     """`Detr3DHead.forward` stages img_metas' projection matrices through a ring of eight pinned buffers and skips the
     copy when they are the ones staged last (ops._Lidar2ImgStaging): 20 calls that alternate fresh rigs, a repeated

@@ -200,6 +200,9 @@ class Detr3DHead(BaseModule):
         self._status_buf = None
         self.matrix_fallback = False
         self.matrix_fallback_generation = -1
+        #: the plugin entry as cached hipGraphs (transcar_amd/plugin_graph.py); ``plugin_graphs = False``: always eager
+        self._plugin_graphs = None
+        self.plugin_graphs = True
         self._radar_stage = {}
         self._ingest_streams = {}       # device -> side stream of the two-phase forward (forward_nhwc(fill_tokens=))
         #: bumped whenever a device buffer a captured hipGraph may point at (packed weights,
@@ -428,7 +431,7 @@ class Detr3DHead(BaseModule):
 
     def forward_nhwc(self, feats_nhwc, lidar2img, img_hw, tokens, pad_mult,
                      aux=False, _allow_train=False, lane=0, decoder_only=False,
-                     options=None, fill_tokens=None):
+                     options=None, fill_tokens=None, _out=None):
         """The device-side forward: everything already on the GPU.
         feats_nhwc: list of [B*N,H,W,C]; lidar2img [B,N,4,4]; tokens [B,T,36].
         Only enqueues work on the current stream (graph-capturable).
@@ -490,7 +493,10 @@ class Detr3DHead(BaseModule):
             options = own
         ws = self._workspace[key]
         Q, ncls, code = self.num_query, self.cls_out_channels, self.code_size
-        out = torch.empty(3 * B * Q * (ncls + code), dtype=torch.float32, device=dev)     # one allocation, two views
+        # one allocation, two views (_out: a static buffer of a captured graph, transcar_amd/plugin_graph.py)
+        out = _out if _out is not None else torch.empty(3 * B * Q * (ncls + code), dtype=torch.float32, device=dev)
+        if out.numel() != 3 * B * Q * (ncls + code) or out.dtype != torch.float32 or not out.is_contiguous():
+            raise L.TransCARHipError('forward_nhwc: _out must be a contiguous fp32 buffer of %d elements' % (3 * B * Q * (ncls + code)))
         cls = out[:3 * B * Q * ncls].view(3, B, Q, ncls)
         box = out[3 * B * Q * ncls:].view(3, B, Q, code)
         fv = ops.feats_view(feats_nhwc)
@@ -566,6 +572,20 @@ class Detr3DHead(BaseModule):
             raise L.TransCARHipError(
                 'Detr3DHead.forward needs the feature maps on the MI355X '
                 '(got %s); transcar_amd has no CPU path' % dev)
+        for m in img_metas:
+            if 'radar' not in m:
+                raise KeyError(
+                    "img_metas[i]['radar'] is required: raw sweeps "
+                    '(transcar_amd/radar.py) or an [n,36] feature array')
+        # round 6: a call signature seen before (same feature-map addresses, shapes, options) replays two captured
+        # graphs instead of ~20 eager launches (transcar_amd/plugin_graph.py); anything else takes the eager path below
+        if self._plugin_graphs is None:
+            from .plugin_graph import PluginGraphs
+            self._plugin_graphs = PluginGraphs(self)
+        if self._plugin_graphs.eligible(mlvl_feats, img_metas, aux):
+            outs = self._plugin_graphs.forward(mlvl_feats, img_metas)
+            if outs is not None:
+                return outs
         feats_nhwc = ops.to_nhwc_levels(mlvl_feats)       # one launch; channels_last levels zero-copy
         l2i = ops.lidar2img_tensor(img_metas, dev, staged=True)    # pinned ring, one async H2D (none if unchanged)
         img_hw = img_metas[0]['img_shape'][0][:2]           # XFMR:403-404
@@ -830,11 +850,20 @@ class Detr3DHead(BaseModule):
 
     def get_bboxes(self, preds_dicts, img_metas, rescale=False):
         """HEAD:1003-1023."""
-        sb = self._status_buf if (self._status_buf is not None and
-                                  self._status_buf.device == preds_dicts['all_cls_scores'].device) else None
-        preds = self.bbox_coder.decode(preds_dicts, z_shift=True, status_buf=sb)
-        if getattr(self.bbox_coder, 'last_status', None):
-            self._range_overflow()
+        done = None
+        if self._plugin_graphs is not None:
+            from .plugin_graph import PluginGraphs
+            done = PluginGraphs.decoded(preds_dicts)          # the graph of this forward already decoded (same kernel)
+        if done is not None:
+            preds, status = done
+            if status:
+                self._range_overflow()
+        else:
+            sb = self._status_buf if (self._status_buf is not None and
+                                      self._status_buf.device == preds_dicts['all_cls_scores'].device) else None
+            preds = self.bbox_coder.decode(preds_dicts, z_shift=True, status_buf=sb)
+            if getattr(self.bbox_coder, 'last_status', None):
+                self._range_overflow()
         ret_list = []
         for i, p in enumerate(preds):
             bboxes = p['bboxes']

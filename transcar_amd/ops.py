@@ -437,6 +437,23 @@ class RadarRawStage:
         self._copied = [ev] * n + self._copied[n:]
         return self.n_raw[:n]
 
+    def pack_host(self, frames):
+        """Host part of ``put_all`` alone: pack samples 0 .. len(frames)-1 into the pinned mirrors (the caller has made
+        sure the copies that last read them are done).  With ``copy_to_device`` as nodes of a captured graph
+        (transcar_amd/plugin_graph.py) the H2D copies read whatever the mirrors hold at replay time."""
+        if len(frames) > self.P:
+            raise L.TransCARHipError('%d radar frames, the stage holds %d' % (len(frames), self.P))
+        for slot, frame in enumerate(frames):
+            self._pack(slot, frame)
+        return self.n_raw[:len(frames)]
+
+    def copy_to_device(self, n=None):
+        """The three H2D copies of the first n (default all) samples, whole slots, on the current stream (capturable)."""
+        n = self.P if n is None else int(n)
+        self.raw[:n].copy_(self.h_raw[:n], non_blocking=True)
+        self.times[:n].copy_(self.h_times[:n], non_blocking=True)
+        self.desc[:n].copy_(self.h_desc[:n], non_blocking=True)
+
     def build(self, tokens, n=None):
         """One launch: the first n (default all) samples' raw rows -> tokens[:n] ([n,T,36], contiguous)."""
         from . import radar as R
@@ -486,16 +503,22 @@ def box_decode_topk(cls_scores, bbox_preds, post_center_range, max_num=300):
 
 
 def box_decode_kept(cls_scores, bbox_preds, post_center_range, max_num=300, score_threshold=None, z_shift=True,
-                    count_out=None):
+                    count_out=None, out=None):
     """NMSFreeCoder.decode_single for a batch (tc_box_decode_kept): the kept rows (inside post_center_range, above
     the score threshold) compacted in score order -> boxes [B,max_num,9], scores [B,max_num], labels [B,max_num]
     (int64) and count [B] (int32, device); rows beyond count[b] are not written."""
     _chk(cls_scores, 'cls_scores'); _chk(bbox_preds, 'bbox_preds')
     B, Q, ncls = cls_scores.shape
     dev = cls_scores.device
-    boxes = torch.empty((B, max_num, 9), dtype=torch.float32, device=dev)
-    scores = torch.empty((B, max_num), dtype=torch.float32, device=dev)
-    labels = torch.empty((B, max_num), dtype=torch.int64, device=dev)
+    if out is not None:                 # (boxes [B,max_num,9] f32, scores [B,max_num] f32, labels [B,max_num] i64): static buffers of a graph
+        boxes, scores, labels = out
+        if tuple(boxes.shape) != (B, max_num, 9) or tuple(scores.shape) != (B, max_num) or tuple(labels.shape) != (B, max_num) \
+                or labels.dtype != torch.int64 or not (boxes.is_contiguous() and scores.is_contiguous() and labels.is_contiguous()):
+            raise L.TransCARHipError('box_decode_kept: out tensors of the wrong shape / dtype')
+    else:
+        boxes = torch.empty((B, max_num, 9), dtype=torch.float32, device=dev)
+        scores = torch.empty((B, max_num), dtype=torch.float32, device=dev)
+        labels = torch.empty((B, max_num), dtype=torch.int64, device=dev)
     # count_out: an int32 device tensor of B elements to write the counts to (Detr3DHead.get_bboxes: the words behind
     # the head's range status, so that ONE small D2H reads both)
     count = count_out if count_out is not None else torch.empty((B,), dtype=torch.int32, device=dev)
