@@ -250,6 +250,21 @@ def main():
     p1 = newest(os.path.join(src, 'prof_pair1', '*', '*kernel_stats.csv'))
     if p1:
         open(os.path.join(dst, name + '_pair1_kernel_stats.csv'), 'w').write(open(p1[0]).read())
+    # round 6: the opt-in camera pre-gather (bench line + the kernel stats of one launch sequence at a time), the plugin
+    # entry's breakdown, the pair-exchange probe
+    pg = newest(os.path.join(src, 'prof_pregather', '*', '*kernel_stats.csv'))
+    if pg:
+        open(os.path.join(dst, name + '_pregather_kernel_stats.csv'), 'w').write(open(pg[0]).read())
+    for f, target in (('bench_pregather.json', '_pregather_bench.json'), ('dropin_breakdown.txt', '_dropin_breakdown.txt'),
+                      ('pair_exchange_probe.txt', '_pair_exchange_probe.txt'), ('bench_train_det.json', '_train_det_bench.json')):
+        pth = os.path.join(src, f)
+        if os.path.exists(pth):
+            txt = open(pth).read()
+            if f.endswith('.json'):
+                txt = '\n'.join(ln.strip() for ln in txt.splitlines() if ln.strip().startswith('{')) + '\n'
+            else:
+                txt = '\n'.join(ln for ln in txt.splitlines() if 'amdgpu.ids' not in ln) + '\n'
+            open(os.path.join(dst, name + target), 'w').write(txt)
     print(open(os.path.join(dst, name + '_frame_trace.txt')).read())
     print(json.dumps(res, indent=1))
 
