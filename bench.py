@@ -90,6 +90,9 @@ def parse(argv=None):
                     help='tc_head_options.cam_pregather = 1 (round 6, opt-in): extra workgroups of the attention-core launch in '
                          'front of a decoder chain gather its camera taps (bit-identical outputs; default: the chain gathers '
                          'itself -- with three launch sequences in flight the pre-gather costs 2.8 %%)')
+    ap.add_argument('--weight-prefetch', action='store_true',
+                    help='tc_head_options.weight_prefetch = 1 (round 6, opt-in): the attention-core launches pull the next decoder '
+                         "chain's weights into the L2s (+2.8 %% with one lane, -0.7 %% with three)")
     ap.add_argument('--main-only', action='store_true',
                     help='only the main timed loop: no single-lane, roofline, delivery, hand-off, batched or CPU '
                          'side measurements (kernel traces of tools/profile_round.sh)')
@@ -489,7 +492,7 @@ def roofline(head, inp, dev, matrix_path='auto', tile_rows=0):
     attn_flop = 4.0 * Q * Q * 32 * H * B
     # The decoder chain AS A FRAME LAUNCHES IT: behind an attention core (which has swept the L2s in between), not back
     # to back with itself -- the pair replayed, the attention core's own time taken off.  This is the duration the
-    # rocprofv3 summary of the frame sequence shows (profiles/r5_kernel_stats.csv: 99.8 us against 90.6 back to back).
+    # rocprofv3 summary of the frame sequence shows (profiles/r5_kernel_stats.csv: 99.8 us against 90.6 back to back; r6: the same).
     # ... and as ANOTHER layer every launch (layers 1..4 in turn, each with its own weights, states and reference points),
     # as consecutive layers of a frame do: the 3.18 MB of packed planes and the camera taps of the moved reference points
     # then come from the Infinity Cache / HBM, not from L2s the previous replay of the same launch warmed.
@@ -625,7 +628,7 @@ def dual_kernels_from_profile(B, chain_flop, chain_peak):
                  if re.match(r'^r\d+_kernel_stats\.csv$', os.path.basename(f))]
         newest = sorted(cands, key=lambda f: int(os.path.basename(f).split('_')[0][1:]))[-1]
         for row in csv.DictReader(open(newest)):
-            m = re.search(r'chain_dual_kernel<(\d+), \d+, (\d+), (\d+)>', row['Name'])
+            m = re.search(r'chain_dual_kernel<(\d+), \d+, (\d+), (\d+)(?:, (?:true|false))?>', row['Name'])
             if m and int(row['Calls']) >= 10:
                 ms = float(row['AverageNs']) * 1e-6
                 part = {'4': 'A (encoders + K|V of fusion layer 1)', '5': 'B (K|V of fusion layers 2, 3)', '2': 'whole'}.get(m.group(2), m.group(2))
@@ -1768,7 +1771,8 @@ def main(argv=None):
                                                               last_level_cls_only=args.last_cls_only,
                                                               radar_compact=False if args.no_radar_compact else None,
                                                               matrix_path=args.matrix_path,
-                                                              cam_pregather=bool(args.pregather)))
+                                                              cam_pregather=bool(args.pregather),
+                                                              weight_prefetch=bool(args.weight_prefetch)))
 
     def step():
         if pipe is None:

@@ -87,16 +87,17 @@ def prog_label(kernel_name):
     """Label from the template arguments (chain_kernel<rows, program>): works in any launch order."""
     import re
     # round 4: a trailing template argument 1 = the two-plane f16 matrix path of the 16-row tiles (chain.hip MM)
-    m = re.search(r'chain_dual_kernel<(\d+), (\d+), (\d+)(?:, (\d+))?>', kernel_name)
+    # round 6: a fifth / fifth template argument `true` = the PRE instantiation (the sampling step reads pre-gathered values)
+    m = re.search(r'chain_dual_kernel<(\d+), (\d+), (\d+)(?:, (\d+))?(?:, (true|false))?>', kernel_name)
     if m:
-        return 'chain_dual_kernel(decoder layer + radar encoder half %s, %s-row tiles%s)' % (
-            'A' if m.group(3) == '4' else 'B', m.group(1), ', f16x2' if m.group(4) == '1' else '')
-    m = re.search(r'chain_kernel<(\d+), (\d+)(?:, (\w+))?(?:, (\d+))?>', kernel_name)
+        return 'chain_dual_kernel(decoder layer + radar encoder half %s, %s-row tiles%s%s)' % (
+            'A' if m.group(3) == '4' else 'B', m.group(1), ', f16x2' if m.group(4) == '1' else '', ', pre-gathered' if m.group(5) == 'true' else '')
+    m = re.search(r'chain_kernel<(\d+), (\d+)(?:, (\w+))?(?:, (\d+))?(?:, (true|false))?>', kernel_name)
     if m:
-        return 'chain_kernel(%s, %s-row tiles%s)' % (
+        return 'chain_kernel(%s, %s-row tiles%s%s)' % (
             {'0': 'prologue', '1': 'decoder layer', '2': 'radar encoders', '3': 'radar fusion', '6': 'radar fusion (train)',
              '7': 'radar encoders (train)', '8': 'radar backward'}.get(m.group(2), 'program ' + m.group(2)),
-            m.group(1), ', f16x2' if m.group(4) == '1' else '')
+            m.group(1), ', f16x2' if m.group(4) == '1' else '', ', pre-gathered' if m.group(5) == 'true' else '')
     if 'self_attn_kernel' in kernel_name or 'self_attn_x_kernel' in kernel_name:     # (x: the staged f16x2 form, round 4)
         return 'self_attn_kernel'
     return short(kernel_name)

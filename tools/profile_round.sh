@@ -43,7 +43,7 @@ python tools/dropin_breakdown.py > "$OUT/dropin_breakdown.txt" 2>&1
 [ -x tools/pair_exchange_probe ] && timeout 120 tools/pair_exchange_probe > "$OUT/pair_exchange_probe.txt" 2>&1
 # keep the merge-back small (gpurun copies back at most 64 MiB): stats / trace / counter csv only
 find "$OUT" -type f ! -name '*kernel_stats.csv' ! -name '*kernel_trace.csv' ! -name '*counter_collection.csv' \
-     ! -name '*.json' ! -name '*.log' ! -name '*.err' -delete 2>/dev/null
+     ! -name '*.json' ! -name '*.log' ! -name '*.err' ! -name '*.txt' -delete 2>/dev/null
 find "$OUT" -name '*kernel_trace.csv' -size +12M -delete 2>/dev/null
 # the counter csv of a PMC pass carries every dispatch of the process: keep the kernels of the path
 for f in $(find "$OUT" -name '*counter_collection.csv'); do
