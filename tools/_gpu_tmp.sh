@@ -1,9 +1,7 @@
-mkdir -p gpurun_out/r6k
-python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "plugin or pregather or pipeline or frames_in_flight or range_guard" > gpurun_out/r6k/pytest.log 2>&1; tail -4 gpurun_out/r6k/pytest.log
-python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r6k/bench_driver.json 2> gpurun_out/r6k/bench.err
-python -c "
-import json
-d=json.loads(open('gpurun_out/r6k/bench_driver.json').read().strip().splitlines()[-1])
-print(d['value'], d['ms_per_step']); print(json.dumps(d.get('dropin_forward'))[200:1500]); print(d.get('single_lane'), d.get('latency_ms_per_frame'))
-"
-python tools/dropin_breakdown.py > gpurun_out/r6k/dropin_breakdown.txt 2>&1; sed -n 2,8p gpurun_out/r6k/dropin_breakdown.txt; tail -1 gpurun_out/r6k/dropin_breakdown.txt
+mkdir -p gpurun_out/r6l
+Q="--main-only --no-cpu-baseline"
+for cfg in "--lanes 3" "--tile-rows 16 --lanes 3" "--tile-rows 16 --lanes 4" "--tile-rows 16 --lanes 6" "--lanes 4" "--lanes 6" "--tile-rows 16 --lanes 6 --pair 5" "--tile-rows 16 --lanes 8 --pair 4"; do
+  python bench.py --steps 216 --warmup 18 $Q $cfg 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('216 [$cfg]', round(d['value'],1))"
+  GPU_MAX_HW_QUEUES=8 python bench.py --steps 216 --warmup 18 $Q $cfg 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('216 [$cfg] 8 hw queues', round(d['value'],1))"
+done > gpurun_out/r6l/lanes16.txt 2>&1
+cat gpurun_out/r6l/lanes16.txt
