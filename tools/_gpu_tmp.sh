@@ -1,7 +1,10 @@
-mkdir -p gpurun_out/r6l
+mkdir -p gpurun_out/r6n
 Q="--main-only --no-cpu-baseline"
-for cfg in "--lanes 3" "--tile-rows 16 --lanes 3" "--tile-rows 16 --lanes 4" "--tile-rows 16 --lanes 6" "--lanes 4" "--lanes 6" "--tile-rows 16 --lanes 6 --pair 5" "--tile-rows 16 --lanes 8 --pair 4"; do
-  python bench.py --steps 216 --warmup 18 $Q $cfg 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('216 [$cfg]', round(d['value'],1))"
-  GPU_MAX_HW_QUEUES=8 python bench.py --steps 216 --warmup 18 $Q $cfg 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('216 [$cfg] 8 hw queues', round(d['value'],1))"
-done > gpurun_out/r6l/lanes16.txt 2>&1
-cat gpurun_out/r6l/lanes16.txt
+for i in 1 2 3; do
+for lib in "" "build/hip_nt2/libtranscar_hip_nt2.so" "build/hip_nt3/libtranscar_hip_nt3.so"; do
+  TRANSCAR_HIP_LIB=$lib python bench.py --gpus 1 --steps 20 --warmup 5 $Q 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('driver [$lib]', round(d['value'],1))"
+  TRANSCAR_HIP_LIB=$lib python bench.py --steps 216 --warmup 18 $Q 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('216   [$lib]', round(d['value'],1))"
+  TRANSCAR_HIP_LIB=$lib python bench.py --lanes 1 --steps 54 --warmup 9 $Q 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('1lane [$lib]', round(d['value'],1))"
+done; done > gpurun_out/r6n/ab_nt23.txt 2>&1
+cat gpurun_out/r6n/ab_nt23.txt
+python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "timed_geometry or pregather or plugin or cam_sample or end_to_end" 2>&1 | tail -3

@@ -57,6 +57,17 @@ __device__ long long g_cam_stamps[4][8];      // camera sampling of workgroup 10
   } while (0)
 #endif
 #include "rowdev.hpp"
+// Round 6: the camera taps are loaded with the NON-TEMPORAL hint (rowdev.hpp cam_tap_ld).  A tap row is read once; with
+// plain loads the 134 MB a nine-frame layer gathers went through the L2s as ordinary lines and pushed out what IS
+// reused -- the layer's packed weights (3.2 MB per XCD, streamed by 32 workgroups each) and, a launch later, the next
+// kernels' operands.  Same loads, same values (bit-identical outputs); measured on one box, alternating runs
+// (profiles/r6_taps_nt_ab.txt): driver command 9 408 -> 9 638 frames/s (+2.4 %), 216-step windows 10 296 -> 10 409 (+1.1 %),
+// one launch sequence at a time 8 081 -> 8 465 (+4.7 %).
+// The same hint on the other read-once streams of a chain -- the attention output, the layer input, the radar chain's
+// query rows (TC_ONCE_LD): another +1.0 % (driver command 9 595 -> 9 693) / +1.6 % (216-step windows 10 300 -> 10 468).  The
+// hint on the write-once STORES (hs, q | k, the attention output) costs 1-1.5 % instead: they stay plain
+// (profiles/r6_taps_nt_ab.txt; tools/experiments/README.md).
+#define TC_ONCE_LD(p) ldg4_stream(p)
 #ifdef TC_CHAIN_DUMP
 // diagnostic build only (make DUMP=1): the LDS destination of every step of the radar program, [step][row][256] floats
 __device__ float* g_chain_dump;
@@ -1656,7 +1667,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAllT<nw_
         for (int ri = 0; ri < EARLY_RW; ++ri) {
           int grow = min(m0 + wave + ri * NW, M - 1);
           if (mod > 0) grow = grow % mod;
-          early_v[j][ri] = ld4(gsrc + (size_t)grow * ld + 4 * lane);
+          early_v[j][ri] = TC_ONCE_LD(gsrc + (size_t)grow * ld + 4 * lane);
         }
       }
     }
@@ -1689,7 +1700,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAllT<nw_
     if (threadIdx.x < R) S.rowg[threadIdx.x] = row_of(threadIdx.x);
     for (int row = wave; row < R; row += NW) {
       const int grow = row_of(row);
-      act_st4<PL>(&S.unit[0][row][0], 4 * lane, ld4(k.g[G_QF] + (size_t)grow * 256 + 4 * lane));
+      act_st4<PL>(&S.unit[0][row][0], 4 * lane, TC_ONCE_LD(k.g[G_QF] + (size_t)grow * 256 + 4 * lane));
     }
     {
       // one (row, column) per thread: columns 0..code-1 the previous box, 12..14 the gate centre
@@ -1936,7 +1947,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAllT<nw_
             for (int ri = 0; ri < RW; ++ri) {
               int grow = min(m0 + wave + ri * NW, M - 1);
               if (mod > 0) grow = grow % mod;
-              v[j][ri] = ld4(gsrc + (size_t)grow * ld + 4 * lane);
+              v[j][ri] = TC_ONCE_LD(gsrc + (size_t)grow * ld + 4 * lane);
             }
           }
         }
@@ -2038,7 +2049,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAllT<nw_
             const int grow = min(m0 + wave + NW * i, M - 1);
             rowp[i] = k.pre + ((size_t)grow * NC) * (4 * 256) + 4 * lane;
 #pragma unroll
-            for (int l = 0; l < 4; ++l) v[i][l] = ld4(rowp[i] + ((size_t)cam0[i] * 4 + l) * 256);   // (no visible camera: read, never used)
+            for (int l = 0; l < 4; ++l) v[i][l] = cam_tap_ld(rowp[i] + ((size_t)cam0[i] * 4 + l) * 256);   // (no visible camera: read, never used; read once: non-temporal)
           }
 #pragma unroll
           for (int i = 0; i < NR; ++i) {
@@ -2061,7 +2072,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAllT<nw_
                 rest &= rest - 1;
                 float4 u[4];
 #pragma unroll
-                for (int l = 0; l < 4; ++l) u[l] = ld4(rowp[i] + ((size_t)cam * 4 + l) * 256);
+                for (int l = 0; l < 4; ++l) u[l] = cam_tap_ld(rowp[i] + ((size_t)cam * 4 + l) * 256);
                 float4 ca = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int l = 0; l < 4; ++l) {
@@ -2096,7 +2107,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAllT<nw_
           const int grow = min(m0 + row, M - 1);
           const unsigned long long vmask = (vm >> (16 * i)) & 0xFFFFull;
           const float4 o = cam_sample_core<4>(k.cam, grow / k.Q, &S.l[row][0], lane, vmask, pu, pv,
-                                              [](int, int, int, const float* ptr) { return ld4(ptr); }, 16 * i);
+                                              [](int, int, int, const float* ptr) { return cam_tap_ld(ptr); }, 16 * i);
           act_st4<PL>(buf_ptr(S, r.dst) + row * LD2, 4 * lane, o);
           if (m0 + row < M) pairs += __popcll(vmask);
         }
