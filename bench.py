@@ -90,9 +90,6 @@ def parse(argv=None):
                     help='tc_head_options.cam_pregather = 1 (round 6, opt-in): extra workgroups of the attention-core launch in '
                          'front of a decoder chain gather its camera taps (bit-identical outputs; default: the chain gathers '
                          'itself -- with three launch sequences in flight the pre-gather costs 2.8 %%)')
-    ap.add_argument('--weight-prefetch', action='store_true',
-                    help='tc_head_options.weight_prefetch = 1 (round 6, opt-in): the attention-core launches pull the next decoder '
-                         "chain's weights into the L2s (+2.8 %% with one lane, -0.7 %% with three)")
     ap.add_argument('--main-only', action='store_true',
                     help='only the main timed loop: no single-lane, roofline, delivery, hand-off, batched or CPU '
                          'side measurements (kernel traces of tools/profile_round.sh)')
@@ -1771,8 +1768,7 @@ def main(argv=None):
                                                               last_level_cls_only=args.last_cls_only,
                                                               radar_compact=False if args.no_radar_compact else None,
                                                               matrix_path=args.matrix_path,
-                                                              cam_pregather=bool(args.pregather),
-                                                              weight_prefetch=bool(args.weight_prefetch)))
+                                                              cam_pregather=bool(args.pregather)))
 
     def step():
         if pipe is None:

@@ -191,12 +191,6 @@ typedef struct {
   void* cam_pregather_ws;   /* cam_pregather = 1: device scratch of tc_cam_pregather_workspace_bytes(w, B) bytes, owned by
                                the caller for the duration of the call (one per stream in flight) */
   size_t cam_pregather_bytes;
-  int weight_prefetch;      /* ABI 12 (round 6), opt-in: 1 = an f16x2 attention-core launch ends by pulling the packed weights
-                               of the decoder chain that follows (3.2 MB per layer) into the L2 of every XCD -- the chain's
-                               first touch of a weight line is then an L2 hit instead of an Infinity-Cache fill.  Outputs
-                               unchanged (a cache hint).  One launch sequence at a time: +2.8 % frames/s; three in flight:
-                               -0.7 % (the lines do not survive the other lanes' kernels) -- 0 (default) = off; the plugin
-                               entry's graphs and one-lane pipelines switch it on */
 } tc_head_options;
 #define TC_MATRIX_AUTO 0
 #define TC_MATRIX_F32 1

@@ -118,7 +118,7 @@ class tc_head_options(C.Structure):
                 ('decoder_dropout_p', C.c_float), ('radar_row_order', C.c_int),
                 ('dropout_seed', C.c_ulonglong), ('phase', C.c_int), ('matrix_path', C.c_int),
                 ('dropout_seed_stride', C.c_ulonglong), ('range_status', c_fp), ('cam_pregather', C.c_int),
-                ('cam_pregather_ws', c_fp), ('cam_pregather_bytes', C.c_size_t), ('weight_prefetch', C.c_int)]
+                ('cam_pregather_ws', c_fp), ('cam_pregather_bytes', C.c_size_t)]
 
 
 TC_MATRIX_AUTO, TC_MATRIX_F32, TC_MATRIX_F16X2 = 0, 1, 2

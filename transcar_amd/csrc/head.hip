@@ -261,15 +261,8 @@ static int head_forward_fused(const tc_head_weights* w, const tc_feats_nhwc* fea
           pga.cam = d.cam; pga.M = rows; pga.ref_mod = d.ref_mod; pga.out = pbuf; pga.mask = pmask;
           d.pre = pbuf; d.premask = pmask;
         }
-        // (tc_head_options.weight_prefetch: the packed f16 planes this layer's chain will stream -- out_proj .. reg.l2 and the
-        // next layer's in_proj, contiguous in tc_head_pack_weights' order -- for the attention launch to pull into the L2s)
-        const tc_decoder_layer& ly = w->layers[lid];
-        const float* wb = ly.self_attn.out_proj.w + 2 * w->packed16_delta;
-        const float* we = (lid + 1 < L ? w->layers[lid + 1].self_attn.in_proj.w + packed_floats(3 * C, C)
-                                       : ly.reg.l2.w + packed_floats(C, C)) + 2 * w->packed16_delta;
         TC_TRY(launch_self_attn_core_x(h.qk, h.qk + C, 2 * C, h.vt, h.qpad, h.attn_o, C, B, Q, H, s, ddrop ? &d.drop : nullptr,
-                                       pre ? &pga : nullptr,
-                                       opt.weight_prefetch == 1 && !ddrop && w->packed16_delta != 0 && we > wb ? wb : nullptr, (size_t)(we - wb)));
+                                       pre ? &pga : nullptr));
       } else {
         TC_TRY(launch_self_attn_core(h.qk, h.qk + C, 2 * C, h.vt, h.qpad, h.attn_o, C, B, Q, H, s, ddrop ? &d.drop : nullptr));
       }
@@ -583,7 +576,6 @@ static int read_options(const tc_head_options* options, tc_head_options& opt) {
              "options.matrix_path=%d (0 automatic, 1 fp32 MFMA, 2 two-plane f16 MFMA)", opt.matrix_path);
   TC_REQUIRE(opt.cam_pregather == 0 || opt.cam_pregather == 1, "options.cam_pregather=%d (0 off, 1 on)", opt.cam_pregather);
   TC_REQUIRE(opt.cam_pregather == 0 || opt.cam_pregather_ws != nullptr, "options.cam_pregather needs cam_pregather_ws");
-  TC_REQUIRE(opt.weight_prefetch == 0 || opt.weight_prefetch == 1, "options.weight_prefetch=%d (0 off, 1 on)", opt.weight_prefetch);
   return 0;
 }
 

@@ -195,8 +195,7 @@ struct PreGatherArgs {
 };
 int launch_self_attn_core_x(const float* q, const float* k, int ld, const float* vt, int ldt, float* out, int ldo,
                             int B, int Q, int H, hipStream_t s, const DropK* drop = nullptr,
-                            const PreGatherArgs* pregather = nullptr,
-                            const float* warm_base = nullptr, size_t warm_floats = 0);   // (tc_head_options.weight_prefetch: weights to pull into the L2s)
+                            const PreGatherArgs* pregather = nullptr);
 
 // ---- radar_attn.hip --------------------------------------------------------
 struct RadarAttnArgs {

@@ -433,18 +433,10 @@ __device__ __forceinline__ void sx_chunk(const float4 (*fb)[8][64], int lane, in
   }
 }
 
-// Round 6 (tc_head_options.weight_prefetch, opt-in): the attention-core launch ends by pulling the packed weights of the
-// decoder chain that follows into the L2 of every XCD (workgroups are dealt round-robin over the eight XCDs: block b warms
-// slice b / 8 of the range for XCD b % 8), so that the chain's first touch of a weight line is an L2 hit instead of an
-// Infinity-Cache fill.  Measured: one launch sequence at a time +2.8 % frames/s (8 060 -> 8 290), three in flight -0.7 %
-// (10 278 -> 10 204: the lines do not survive the other lanes' kernels and the fills are extra traffic) -- hence opt-in:
-// the plugin entry and one-lane pipelines switch it on.
-struct WarmK { const float* base; unsigned floats; };
-
 template <int QT, bool DROP = false>
 __global__ __launch_bounds__(SX_NW * 64) __attribute__((amdgpu_waves_per_eu(SX_OCC, SX_OCC))) void self_attn_x_kernel(
     const float* __restrict__ q, const float* __restrict__ k, int ld, const float* __restrict__ vt, int ldt,
-    float* __restrict__ out, int ldo, int Q, int C, int H, int BH, DropK drop, PreGatherK pg, WarmK warm) {
+    float* __restrict__ out, int ldo, int Q, int C, int H, int BH, DropK drop, PreGatherK pg) {
   constexpr int QW = 16 * QT * SX_NW;                       // queries per workgroup
   __shared__ float4 frag[2][SX_CP][8][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -538,7 +530,11 @@ __global__ __launch_bounds__(SX_NW * 64) __attribute__((amdgpu_waves_per_eu(SX_O
     // (a batch of frames with per-sample seeds: the index is the one sample b has when it is launched alone)
     dbase[u] = DROP ? (((drop.rows_per_sample ? 0u : (unsigned)b) * (unsigned)H + (unsigned)h) * (unsigned)Q + (unsigned)qrow) * (unsigned)Q + 8u * (unsigned)g : 0u;
     const float* qp = q + (brow + qrow) * ld + h * 32 + 8 * g;
+#ifdef SX_Q_NT
+    sx_split(ldg4_stream(qp), ldg4_stream(qp + 4), q_h[u], q_l[u]);      // (round-6 experiment: a query row is read by one workgroup only)
+#else
     sx_split(ld4(qp), ld4(qp + 4), q_h[u], q_l[u]);
+#endif
     st[u].o0 = st[u].o1 = st[u].lsum = st[u].negm = f32x4{0.f, 0.f, 0.f, 0.f};
     st[u].l = 0.0f;
   }
@@ -589,22 +585,6 @@ __global__ __launch_bounds__(SX_NW * 64) __attribute__((amdgpu_waves_per_eu(SX_O
     }
     __syncthreads();
   }
-  if constexpr (!DROP) {
-    if (warm.floats != 0) {
-      const int nattn = (int)gridDim.x - pg.nblocks;
-      const unsigned per_xcd = (unsigned)(nattn + 7) >> 3;                       // blocks of this launch per XCD
-      const unsigned slice4 = ((warm.floats >> 2) + per_xcd - 1) / per_xcd;      // float4s per block
-      const unsigned first = ((unsigned)blockIdx.x >> 3) * slice4, total4 = warm.floats >> 2;
-      float4 keep = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (unsigned i = tid; i < slice4; i += SX_NW * 64) {
-        if (first + i < total4) {
-          const float4 v = ld4(warm.base + 4 * (size_t)(first + i));
-          keep.x += v.x;                                                         // (the load must not be dead)
-        }
-      }
-      asm volatile("" :: "v"(keep.x));
-    }
-  }
   if (!active) return;
 #pragma unroll
   for (int u = 0; u < QT; ++u) {
@@ -624,8 +604,7 @@ __global__ __launch_bounds__(SX_NW * 64) __attribute__((amdgpu_waves_per_eu(SX_O
 void fill_camk(const CamSampleArgs& a, CamK& p);   // cam_sample.hip
 
 int launch_self_attn_core_x(const float* q, const float* k, int ld, const float* vt, int ldt, float* out, int ldo,
-                            int B, int Q, int H, hipStream_t s, const DropK* drop, const PreGatherArgs* pregather,
-                            const float* warm_base, size_t warm_floats) {
+                            int B, int Q, int H, hipStream_t s, const DropK* drop, const PreGatherArgs* pregather) {
   TC_REQUIRE(Q > 0 && B > 0 && H > 0, "self_attn(f16x2): empty problem");
   TC_REQUIRE((ldt & 3) == 0 && ldt >= ((Q + 15) / 16) * 16, "self_attn(f16x2): ldt=%d too small for Q=%d", ldt, Q);
   constexpr int QT = SX_QT_VALUE, QW = 16 * QT * SX_NW;
@@ -633,12 +612,11 @@ int launch_self_attn_core_x(const float* q, const float* k, int ld, const float*
   const int nattn = BH * Gf + (G > Gf ? BH : 0);
   PreGatherK pg;
   memset(&pg, 0, sizeof(pg));
-  WarmK warm{warm_base, (unsigned)(warm_base != nullptr ? warm_floats : 0)};
   if (drop != nullptr && drop->thr != 0) {
     TC_REQUIRE(pregather == nullptr, "self_attn(f16x2): the pre-gather rides in eval launches only");
     TC_REQUIRE((unsigned long long)(drop->rows_per_sample ? 1 : B) * H * Q * Q < (1ull << 32),
                "self_attn(f16x2): dropout index space (B*H*Q*Q) exceeds 32 bits");
-    hipLaunchKernelGGL((self_attn_x_kernel<QT, true>), dim3(nattn), dim3(SX_NW * 64), 0, s, q, k, ld, vt, ldt, out, ldo, Q, H * 32, H, BH, *drop, pg, WarmK{nullptr, 0});
+    hipLaunchKernelGGL((self_attn_x_kernel<QT, true>), dim3(nattn), dim3(SX_NW * 64), 0, s, q, k, ld, vt, ldt, out, ldo, Q, H * 32, H, BH, *drop, pg);
   } else {
     if (pregather != nullptr) {
       const PreGatherArgs& a = *pregather;
@@ -653,7 +631,7 @@ int launch_self_attn_core_x(const float* q, const float* k, int ld, const float*
       pg.nblocks = (a.M + SX_PG_ROWS - 1) / SX_PG_ROWS;
     }
     hipLaunchKernelGGL((self_attn_x_kernel<QT, false>), dim3(nattn + pg.nblocks), dim3(SX_NW * 64), 0, s, q, k, ld, vt, ldt, out, ldo, Q, H * 32, H, BH,
-                       DropK{0, 0, 1.0f, 0, 0, 0, 0, 0}, pg, warm);
+                       DropK{0, 0, 1.0f, 0, 0, 0, 0, 0}, pg);
   }
   return check_launch("self_attn(f16x2, staged)");
 }

@@ -52,7 +52,7 @@ MATRIX_PATHS = {None: L.TC_MATRIX_AUTO, 'auto': L.TC_MATRIX_AUTO, 'f32': L.TC_MA
 
 def head_options(tile_rows=None, unfused=None, last_level_cls_only=False,
                  decoder_dropout_p=0.0, dropout_seed=0, radar_compact=None, phase=0, matrix_path=None,
-                 dropout_seed_stride=0, cam_pregather=None, weight_prefetch=False):
+                 dropout_seed_stride=0, cam_pregather=None):
     """tc_head_options for one forward.  unfused=None: the TRANSCAR_UNFUSED=1
     environment switch of the operator-by-operator cross-check path (a host-side
     knob: the library itself reads no environment)."""
@@ -74,9 +74,6 @@ def head_options(tile_rows=None, unfused=None, last_level_cls_only=False,
     # its chain (f16x2 launches); forward_nhwc supplies the scratch.  Bit-identical outputs; 1 % faster with one launch
     # sequence at a time, 2.8 % slower with three in flight: off by default
     o.cam_pregather = 1 if cam_pregather else 0
-    # opt-in (ABI 12): the attention-core launches pull the next chain's weights into the L2s (a cache hint: outputs
-    # unchanged); +2.8 % with one launch sequence at a time, -0.7 % with three in flight
-    o.weight_prefetch = 1 if weight_prefetch else 0
     return o
 
 

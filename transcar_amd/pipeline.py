@@ -91,9 +91,9 @@ class FramePipeline:
             [torch.cuda.Stream() for _ in self.inputs]
         self.done = [torch.cuda.Event() for _ in self.inputs]
         # one lane = one launch sequence at a time: the attention launches have the chip to themselves, which is where the
-        # L2 weight prefetch (+2.8 %) and the camera pre-gather (+1 %) pay (round 6; with more lanes they cost 0.7 / 2.8 %)
+        # camera pre-gather pays (+1.3 %, round 6; with three lanes it costs 2.8 %)
         solo = len(self.inputs) == 1
-        self.options = options if options is not None else head_options(tile_rows=tile_rows, weight_prefetch=solo, cam_pregather=solo)
+        self.options = options if options is not None else head_options(tile_rows=tile_rows, cam_pregather=solo)
         # radar_raw_capacity = N: every lane also owns a raw-radar stage (ops.RadarRawStage: device slabs for
         # N raw points per frame slot + descriptors) and its graph STARTS with the device-side radar ingest
         # (tc_radar_build_tokens_batch, HEAD:301-536) writing the lane's static `tokens`; the producer hands

@@ -101,9 +101,8 @@ class PluginGraphs:
         if src is not None:
             C.memmove(C.byref(o), C.byref(src), C.sizeof(o))
         o.phase = phase
-        # the plugin entry runs ONE launch sequence at a time: the two round-6 opt-ins that pay exactly there (and cost
-        # with several sequences in flight) are on -- outputs bit-identical either way
-        o.weight_prefetch = 1
+        # the plugin entry runs ONE launch sequence at a time: the round-6 opt-in that pays exactly there (and costs with
+        # several sequences in flight) is on -- outputs bit-identical either way
         o.cam_pregather = 1
         return o
 
