@@ -42,7 +42,17 @@ def main():
     bench.roofline.tile_rows = rows_env
     for _ in range(3):
         head.forward_nhwc(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'], inp['pad_mult'], options=head_options(tile_rows=rows_env or None))
-    if which == 'decoder':
+    if which == 'decoder' and os.environ.get('STAMPS_COLD') == '1':
+        # IN SEQUENCE (round 6): a forward that stops after decoder layer 3 (tc_head_options.phase = 1) -- the stamped
+        # launch is that layer as a frame runs it, its weights last touched a sequence ago; in between, other data of
+        # the size of a whole sequence's taps is streamed through the caches
+        junk = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device=dev)
+        for _ in range(2):
+            junk.add_(1.0)
+            head.forward_nhwc(inp['nhwc'], inp['l2i'], inp['hw'], inp['tokens'], inp['pad_mult'],
+                              options=head_options(tile_rows=rows_env or None, phase=1))
+        names = DEC
+    elif which == 'decoder':
         # the forward's LAST chain launch is the radar chain; run one decoder tail on top
         bench.roofline_chain_once(head, inp, dev)
         names = DEC
