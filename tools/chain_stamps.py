@@ -2,6 +2,8 @@
 """Per-step cycle counts of the fused row chains (debug build with s_memtime
 stamps):   make -C transcar_amd/csrc STAMPS=1
            TRANSCAR_ALLOW_STAMPS=1 TRANSCAR_HIP_LIB=build/hip_stamps/libtranscar_hip_stamps.so python tools/chain_stamps.py [decoder|radar]
+STAMPS_COLD=1 (round 6, decoder only): the stamped launch is decoder layer 3 IN A SEQUENCE (a forward that stops behind it,
+other data streamed in between) instead of the layer repeated on top of a forward: profiles/r6_chain_stamps_cold.txt.
 Prints, for workgroup 100 and each of its 4 waves, the cycles (100 MHz s_memtime
 ticks x 24 = 2.4 GHz core cycles) each step took and the wait at its barrier."""
 import ctypes as C
