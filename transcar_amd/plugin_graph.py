@@ -70,8 +70,9 @@ class PluginGraphs:
         ob = bytes(o) if o is not None else b''
         fk = tuple((f.data_ptr(), tuple(f.shape), tuple(f.stride())) for f in mlvl_feats)
         hw = tuple(img_metas[0]['img_shape'][0][:2])
+        ncam = len(img_metas[0]['lidar2img'])
         return (len(img_metas), str(mlvl_feats[0].device), fk, T, cap, hw, ob, h.buffers_generation, bool(h.matrix_fallback),
-                torch.cuda.current_stream().cuda_stream)
+                torch.cuda.current_stream().cuda_stream, ncam)
 
     # ------------------------------------------------------------------
     def forward(self, mlvl_feats, img_metas):
@@ -116,7 +117,9 @@ class PluginGraphs:
         e.key, e.B, e.T, e.hw = key, B, T, hw
         e.serial = 0
         e.done = None
-        e.feats = list(mlvl_feats)                  # (keeps the caller's storage alive while the graphs point at it)
+        # (the caller's tensors are NOT kept alive: a replay happens only when a call hands over tensors at exactly these
+        # addresses, i.e. while they exist; holding references would keep the backbone's blocks out of the caching
+        # allocator's hands and change the very addresses the key relies on)
         l2i_np = np.asarray([m['lidar2img'] for m in img_metas], dtype=np.float32)           # [B, N, 4, 4] (XFMR:382-386)
         e.l2i_host = torch.zeros(l2i_np.shape, dtype=torch.float32).pin_memory()
         e.stage = ops.RadarRawStage(B, cap, dev)
