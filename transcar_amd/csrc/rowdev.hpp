@@ -26,10 +26,86 @@ __device__ __forceinline__ float4 ln_row(float4 v, const float* g, const float* 
                      d.z * rstd * gg.z + bb.z, d.w * rstd * gg.w + bb.w);
 }
 
+// Wave64 sums of FOUR rows at once (round 6).  In: each lane's partial sum of rows a, b, c, d.  Out (in `a`): the wave
+// total of row j in every lane whose bank (lane >> 2) & 3 is j.  Same reduction TREE as four wave_sum()s -- pairs at
+// distance 1, 2, quad + quad, 8 + 8, row + row, half + half; IEEE addition commutes, so which of a pair's two lanes does the
+// add does not matter -- hence the same bits; but from the third stage on ONE register carries two, then four rows
+// (DPP bank masks merge them), and the two cross-row stages are gfx950's half-wave / row swaps instead of row_bcast (which
+// would broadcast lane 15 / 31, i.e. one bank): 20 vector instructions instead of 4 x 12.  A LayerNorm step of the 16- and
+// 32-row chains is VALU-bound -- two waves per SIMD, 4 cycles per wave64 instruction: ~460 instructions for a wave's
+// four rows were the step's 5.3 K cycles (profiles/r6_ln_valu.txt: the same with its parameter loads removed, the same
+// when repeated through warm code) -- and a quarter of those were the eight separate reductions and the four copies of
+// 1 / sqrt(var + eps), all lanes computing one number.
+// (hazards: VALU write -> DPP read of that register, and -> v_permlane read: 2 wait states; hipcc pads nothing inside an
+// asm string)
+__device__ __forceinline__ float wave_sum4_packed(float a, float b, float c, float d) {
+  float t;
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      // quad + quad: a | b share %0 (even | odd banks), c | d share %2
+      "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %2, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+      // 8 + 8 (row_ror:8 keeps a lane's bank parity; row_mirror would not): banks 0..3 of %0 = a, b, c, d
+      "s_nop 0\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      // row + row, half + half
+      "v_mov_b32 %4, %0\n\t"
+      "s_nop 1\n\t"
+      "v_permlane16_swap_b32 %4, %0\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32 %0, %0, %4\n\t"
+      "v_mov_b32 %4, %0\n\t"
+      "s_nop 1\n\t"
+      "v_permlane32_swap_b32 %4, %0\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32 %0, %0, %4\n\t"
+      "s_nop 1"
+      : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&v"(t));
+  return a;
+}
+__device__ __forceinline__ float packed_row(float v, int j) {        // row j's value of a wave_sum4_packed() register
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 4 * j));
+}
+
 // The same for NR rows at once (gamma / beta already in registers): the rows' reduction chains are
 // independent and interleave.  Same operations per row as ln_row: bit-identical results.
 template <int NR>
 __device__ __forceinline__ void ln_rows(float4 (&v)[NR], const float4 gg, const float4 bb) {
+#ifndef TC_LN_UNPACKED
+  if constexpr (NR == 4) {
+    // four rows: the packed reductions, and 1 / sqrt(var + eps) ONCE, on the register that carries the four variances
+    const float sp = wave_sum4_packed(v[0].x + v[0].y + v[0].z + v[0].w, v[1].x + v[1].y + v[1].z + v[1].w,
+                                      v[2].x + v[2].y + v[2].z + v[2].w, v[3].x + v[3].y + v[3].z + v[3].w);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float mean = packed_row(sp, i) * (1.0f / 256.0f);
+      v[i] = make_float4(v[i].x - mean, v[i].y - mean, v[i].z - mean, v[i].w - mean);
+    }
+    float qq[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qq[i] = v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+    const float qp = wave_sum4_packed(qq[0], qq[1], qq[2], qq[3]);
+    const float rp = 1.0f / sqrtf(qp * (1.0f / 256.0f) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float rstd = packed_row(rp, i);
+      v[i] = make_float4(v[i].x * rstd * gg.x + bb.x, v[i].y * rstd * gg.y + bb.y,
+                         v[i].z * rstd * gg.z + bb.z, v[i].w * rstd * gg.w + bb.w);
+    }
+    return;
+  }
+#endif
   float s[NR];
 #pragma unroll
   for (int i = 0; i < NR; ++i) s[i] = wave_sum(v[i].x + v[i].y + v[i].z + v[i].w);
