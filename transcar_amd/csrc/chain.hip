@@ -2013,15 +2013,52 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAllT<nw_
           q0 = inverse_sigmoidf_(k.ref_in[(size_t)grow * 3 + 0]);
           q1 = inverse_sigmoidf_(k.ref_in[(size_t)grow * 3 + 1]);
           q2 = inverse_sigmoidf_(k.ref_in[(size_t)grow * 3 + 2]);
+          if constexpr (PROG == PROG_DECODER) {
+            // kept for the layer's last step (K_REFUPD adds the regression deltas to exactly these values): the centre
+            // records are free in the decoder program -- one global round trip and three logs less at the end of every tile
+            if (wave == (skip0 ? 1 : 0) && lane < R) { S.cen[lane][0] = q0; S.cen[lane][1] = q1; S.cen[lane][2] = q2; }
+          }
         }
-        for (int row = row_first; row < R && row >= 0; row += row_step) {
-          float p0, p1, p2;
+        auto xyz = [&](int row, float& p0, float& p1, float& p2) {
           if (r.src == B_A) {
             if constexpr (PL) {          // (the token tile holds planes: the raw xyz come from the tokens themselves)
               const float* tk = k.tokens + (size_t)min(m0 + row, M - 1) * k.RI; p0 = tk[0]; p1 = tk[1]; p2 = tk[2];
             } else { const float* tk = &S.unit[1][0][0] + row * LD5; p0 = tk[0]; p1 = tk[1]; p2 = tk[2]; }
           }
           else { p0 = lane_f(q0, row); p1 = lane_f(q1, row); p2 = lane_f(q2, row); }
+        };
+        int row = row_first;
+        if constexpr (PROG != PROG_RADAR_ENC_TRAIN) {
+          // Round 6: a wave's rows four at a time -- W0 / b0 / gamma / beta fetched once, the LayerNorms through the packed
+          // reductions (rowdev.hpp ln_rows<4>).  Same expressions per row as posenc_l0_row: bit-identical.  (Row by row
+          // this step was 10.5 K cycles of a 32-row decoder layer for the seven waves that share it: VALU-bound.)
+          if (row >= 0 && row + 3 * row_step < R) {
+            const float* w0 = uptr(r.p0); const float* b0 = uptr(r.p1);
+            float wc[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int c = 4 * lane + i;
+              wc[i][0] = ldg1(w0 + c * 3 + 0); wc[i][1] = ldg1(w0 + c * 3 + 1); wc[i][2] = ldg1(w0 + c * 3 + 2); wc[i][3] = ldg1(b0 + c);
+            }
+            const float4 gg = ld4(uptr(r.p2) + 4 * lane), bb = ld4(uptr(r.p3) + 4 * lane);
+            for (; row + 3 * row_step < R; row += 4 * row_step) {
+              float4 v4[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                float p0, p1, p2;
+                xyz(row + j * row_step, p0, p1, p2);
+                v4[j] = make_float4(wc[0][0] * p0 + wc[0][1] * p1 + wc[0][2] * p2 + wc[0][3], wc[1][0] * p0 + wc[1][1] * p1 + wc[1][2] * p2 + wc[1][3],
+                                    wc[2][0] * p0 + wc[2][1] * p1 + wc[2][2] * p2 + wc[2][3], wc[3][0] * p0 + wc[3][1] * p1 + wc[3][2] * p2 + wc[3][3]);
+              }
+              ln_rows<4>(v4, gg, bb);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) act_st4<PL>(dst + (row + j * row_step) * LD2, 4 * lane, relu4(v4[j]));
+            }
+          }
+        }
+        for (; row < R && row >= 0; row += row_step) {
+          float p0, p1, p2;
+          xyz(row, p0, p1, p2);
           if constexpr (PROG == PROG_RADAR_ENC_TRAIN) {
             // tape: the pre-LayerNorm values u0 (r.gt) and u1 = relu(LN(u0)) (r.gd)
             float4 pre;
@@ -2140,8 +2177,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAllT<nw_
           float val = S.l[row][j];
           const int c = j == 0 ? 0 : j == 1 ? 1 : j == 4 ? 2 : -1;      // box columns cx, cy, cz <- reference x, y, z
           if (c >= 0) {
-            const float rr = k.ref_in[(size_t)(k.ref_mod > 0 ? grow % k.ref_mod : grow) * 3 + c];
-            const float n = sigmoidf_(val + inverse_sigmoidf_(rr));
+            const float n = sigmoidf_(val + S.cen[row][c]);      // inverse_sigmoid(reference), computed by K_POSENC
             k.ref_out[(size_t)grow * 3 + c] = n;
             const float* pc = k.cam.pc;
             val = n * (pc[3 + c] - pc[c]) + pc[c];
