@@ -182,7 +182,9 @@ enum Flags : short {
   F_CMASK = 1024,     // linear (backward): zero the outputs where the tape tensor `gt` [M, N] is <= 0 (ReLU')
   F_CMASK_SCALE = 2048,  // ... and multiply the kept ones by the dropout scale (the tape tensor is a dropped-out ReLU)
   F_CARRY = 4096,     // K_LOADG: the layer's first step (box gradient carry, hit counts of the layer)
-  F_NOT_LAYER0 = 8192 // the step does not exist for fusion layer 1 (nothing below it is trainable)
+  F_NOT_LAYER0 = 8192, // the step does not exist for fusion layer 1 (nothing below it is trainable)
+  F_PRESYNC = 16384   // K_NARROW: the barrier in front of the step is the step's own, BEHIND its weight loads (the step before
+                      // ends without one): the loads' round trip runs under the wait for the slowest wave
 };
 // global tensors, indices into ChainK::g
 enum GSel : short {
@@ -213,8 +215,8 @@ constexpr StepDesc PROG_DECODER_T[] = {
     {K_LINEAR, 13, -1, 256, 256, B_X, B_NONE, B_U2, B_NONE, 1, 0, G_NONE, G_NONE, 0},     // reg.0
     {K_LINEAR, 16, -1, 256, 512, B_U1, B_NONE, B_NONE, B_NONE, 0, F_SCALEQ | F_SKIP_NONEXT, G_QK, G_NONE, 0},
     {K_LINEAR, 16, -1, 256, 256, B_X, B_NONE, B_NONE, B_NONE, 0, F_WOFF | F_SKIP_NONEXT, G_NONE, G_VT, 1},
-    {K_LINEAR, 14, -1, 256, 256, B_U2, B_NONE, B_U3, B_NONE, 1, 0, G_NONE, G_NONE, 1},    // reg.2
-    {K_NARROW, 15, -1, 256, N_CODE, B_U3, B_U1, B_L, B_NONE, 0, 0, G_NONE, G_NONE, 1},    // reg.4 (partial sums: U1)
+    {K_LINEAR, 14, -1, 256, 256, B_U2, B_NONE, B_U3, B_NONE, 1, 0, G_NONE, G_NONE, 0},    // reg.2
+    {K_NARROW, 15, -1, 256, N_CODE, B_U3, B_U1, B_L, B_NONE, 0, F_PRESYNC, G_NONE, G_NONE, 1},    // reg.4 (partial sums: U1)
     {K_REFUPD, 0, 0, 0, 0, B_L, B_NONE, B_NONE, B_NONE, 0, 0, G_NONE, G_NONE, 0},
     {K_END, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
 // prologue pairs: 0 reference_points 16 layer-0 in_proj
@@ -279,10 +281,10 @@ constexpr StepDesc PROG_RADAR_LAYER_T[] = {
     {K_LN, 7, -1, 0, 0, B_U1, B_NONE, B_U1, B_NONE, 0, F_LN_RELU, G_NONE, G_NONE, 0},        // in place
     {K_LINEAR, 12, -1, 256, 256, B_U2, B_NONE, B_U3, B_NONE, 1, 0, G_NONE, G_NONE, 1},       // final_reg.2
     {K_LINEAR, 8, -1, 256, 256, B_U1, B_NONE, B_U2, B_NONE, 0, 0, G_NONE, G_NONE, 1},        // final_cls.3
-    {K_LN, 9, -1, 0, 0, B_U2, B_NONE, B_U2, B_NONE, 0, F_LN_RELU, G_NONE, G_NONE, 1},        // in place
+    {K_LN, 9, -1, 0, 0, B_U2, B_NONE, B_U2, B_NONE, 0, F_LN_RELU, G_NONE, G_NONE, 0},        // in place
     // the two 10-column heads: one MFMA sub-tile each, k split over the four waves (K_NARROW)
-    {K_NARROW, 13, -1, 256, N_CODE, B_U3, B_U1, B_L, B_NONE, 0, 0, G_NONE, G_NONE, 1},       // final_reg.4 (partial sums: U1)
-    {K_NARROW, 10, -1, 256, N_CLS, B_U2, B_U1, B_NONE, B_NONE, 0, 0, G_CLS, G_NONE, 1},      // final_cls.6
+    {K_NARROW, 13, -1, 256, N_CODE, B_U3, B_U1, B_L, B_NONE, 0, F_PRESYNC, G_NONE, G_NONE, 0},       // final_reg.4 (partial sums: U1)
+    {K_NARROW, 10, -1, 256, N_CLS, B_U2, B_U1, B_NONE, B_NONE, 0, F_PRESYNC, G_CLS, G_NONE, 1},      // final_cls.6
     {K_BOXADD, 0, 0, 0, 0, B_L, B_NONE, B_NONE, B_NONE, 0, 0, G_NONE, G_NONE, 1},
     {K_END, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
 
@@ -2202,11 +2204,11 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAllT<nw_
         const float* src = buf_ptr(S, r.src) + min(16 * rgw + c, R - 1) * buf_ld(r.src);
         float4 av[4], bw[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          bw[q] = ld4(Wn + 16 * (4 * kq + q));
-          av[q] = act_ld4<PL>(src, 4 * g + 16 * (4 * kq + q));
-        }
+        for (int q = 0; q < 4; ++q) bw[q] = ld4(Wn + 16 * (4 * kq + q));
         const float bias = r.p1 != nullptr ? ldg1(uptr(r.p1) + min(c, N - 1)) : 0.0f;
+        if (r.flags & F_PRESYNC) __syncthreads();         // (the source tile is complete behind this barrier)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) av[q] = act_ld4<PL>(src, 4 * g + 16 * (4 * kq + q));
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
