@@ -932,17 +932,38 @@ __device__ __forceinline__ unsigned pk_h2(float a, float b) {
   const f16x2 v = {(_Float16)a, (_Float16)b};
   return __builtin_bit_cast(unsigned, v);
 }
+// Two scaled values t = s x -> their halves of the two planes: hi = f16(t), lo = f16((t - hi) 2^11).  Round 6: written so
+// that hipcc emits FIVE vector instructions per pair instead of ten -- v_cvt_pk_f16_f32; t - hi as v_fma_mix_f32 reading
+// the half straight out of the packed register (the multiplier -1 made opaque: a literal is canonicalised to
+// v_cvt_f32_f16 + v_sub_f32, and without the opaque `hi` the halves are converted a second time, one by one); the scaling and
+// the conversion of lo as v_fma_mixlo / mixhi_f16 (r 2^11 + 0: exact in fp32, one rounding to f16 -- as v_mul_f32 +
+// v_cvt_pk_f16_f32 had).  Same values bit for bit (t - hi is exact either way; never -0).  The row-local steps of the
+// 16- / 32-row chains are VALU-bound -- a fifth of a decoder layer's vector instructions were these splits
+// (profiles/r6_valu_by_step.txt).
+#ifdef TC_AB_OLD
+__device__ __forceinline__ void split_t2(float t0, float t1, unsigned& hi, unsigned& lo) {
+  hi = pk_h2(t0, t1);
+  const f16x2 h = __builtin_bit_cast(f16x2, hi);
+  lo = pk_h2((t0 - (float)h[0]) * H_LO_SCALE, (t1 - (float)h[1]) * H_LO_SCALE);
+}
+#else
+__device__ __forceinline__ void split_t2(float t0, float t1, unsigned& hi, unsigned& lo) {
+  hi = pk_h2(t0, t1);
+  asm("" : "+v"(hi));
+  float m1 = -1.0f;
+  asm("" : "+s"(m1));
+  const f16x2 h = __builtin_bit_cast(f16x2, hi);
+  const float r0 = __builtin_fmaf((float)h[0], m1, t0), r1 = __builtin_fmaf((float)h[1], m1, t1);
+  const f16x2 l = {(_Float16)__builtin_fmaf(r0, H_LO_SCALE, 0.0f), (_Float16)__builtin_fmaf(r1, H_LO_SCALE, 0.0f)};
+  lo = __builtin_bit_cast(unsigned, l);
+}
+#endif
 // 8 consecutive k of one row -> the lane's operand fragments of the two planes
 __device__ __forceinline__ void split_h(const float4& a, const float4& b, float4& p1, float4& p2) {
   const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
   unsigned q1[4], q2[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float t0 = x[2 * i] * H_ACT_SCALE, t1 = x[2 * i + 1] * H_ACT_SCALE;
-    q1[i] = pk_h2(t0, t1);
-    const f16x2 h = __builtin_bit_cast(f16x2, q1[i]);
-    q2[i] = pk_h2((t0 - (float)h[0]) * H_LO_SCALE, (t1 - (float)h[1]) * H_LO_SCALE);
-  }
+  for (int i = 0; i < 4; ++i) split_t2(x[2 * i] * H_ACT_SCALE, x[2 * i + 1] * H_ACT_SCALE, q1[i], q2[i]);
   p1 = make_float4(__uint_as_float(q1[0]), __uint_as_float(q1[1]), __uint_as_float(q1[2]), __uint_as_float(q1[3]));
   p2 = make_float4(__uint_as_float(q2[0]), __uint_as_float(q2[1]), __uint_as_float(q2[2]), __uint_as_float(q2[3]));
 }
@@ -977,10 +998,8 @@ __device__ __forceinline__ void act_st4(float* row, int col, const float4& v) {
   } else {
     const float t0 = v.x * H_ACT_SCALE, t1 = v.y * H_ACT_SCALE, t2 = v.z * H_ACT_SCALE, t3 = v.w * H_ACT_SCALE;
     uint2 h, l;
-    h.x = pk_h2(t0, t1); h.y = pk_h2(t2, t3);
-    const f16x2 h0 = __builtin_bit_cast(f16x2, h.x), h1 = __builtin_bit_cast(f16x2, h.y);
-    l.x = pk_h2((t0 - (float)h0[0]) * H_LO_SCALE, (t1 - (float)h0[1]) * H_LO_SCALE);
-    l.y = pk_h2((t2 - (float)h1[0]) * H_LO_SCALE, (t3 - (float)h1[1]) * H_LO_SCALE);
+    split_t2(t0, t1, h.x, l.x);
+    split_t2(t2, t3, h.y, l.y);
     char* p = reinterpret_cast<char*>(row) + (col >> 3) * 32 + (col & 7) * 2;
     *reinterpret_cast<uint2*>(p) = h;
     *reinterpret_cast<uint2*>(p + 16) = l;
@@ -1103,10 +1122,8 @@ __device__ __forceinline__ void lin_epilogue32(const LinSpec& s, int colbase, co
       for (int v = 0; v < 4; ++v) {
         const int col = colb + 16 * (v & 1), rloc = 16 * (v >> 1) + c;
         uint2 h, l;
-        h.x = pk_h2(t[v][0], t[v][1]); h.y = pk_h2(t[v][2], t[v][3]);
-        const f16x2 h0 = __builtin_bit_cast(f16x2, h.x), h1 = __builtin_bit_cast(f16x2, h.y);
-        l.x = pk_h2((t[v][0] - (float)h0[0]) * H_LO_SCALE, (t[v][1] - (float)h0[1]) * H_LO_SCALE);
-        l.y = pk_h2((t[v][2] - (float)h1[0]) * H_LO_SCALE, (t[v][3] - (float)h1[1]) * H_LO_SCALE);
+        split_t2(t[v][0], t[v][1], h.x, l.x);
+        split_t2(t[v][2], t[v][3], h.y, l.y);
         char* p = reinterpret_cast<char*>(s.dst + rloc * s.dst_ld) + (col >> 3) * 32 + (col & 7) * 2;
         *reinterpret_cast<uint2*>(p) = h;
         *reinterpret_cast<uint2*>(p + 16) = l;
