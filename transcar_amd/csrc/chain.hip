@@ -940,13 +940,6 @@ __device__ __forceinline__ unsigned pk_h2(float a, float b) {
 // v_cvt_pk_f16_f32 had).  Same values bit for bit (t - hi is exact either way; never -0).  The row-local steps of the
 // 16- / 32-row chains are VALU-bound -- a fifth of a decoder layer's vector instructions were these splits
 // (profiles/r6_valu_by_step.txt).
-#ifdef TC_AB_OLD
-__device__ __forceinline__ void split_t2(float t0, float t1, unsigned& hi, unsigned& lo) {
-  hi = pk_h2(t0, t1);
-  const f16x2 h = __builtin_bit_cast(f16x2, hi);
-  lo = pk_h2((t0 - (float)h[0]) * H_LO_SCALE, (t1 - (float)h[1]) * H_LO_SCALE);
-}
-#else
 __device__ __forceinline__ void split_t2(float t0, float t1, unsigned& hi, unsigned& lo) {
   hi = pk_h2(t0, t1);
   asm("" : "+v"(hi));
@@ -957,7 +950,6 @@ __device__ __forceinline__ void split_t2(float t0, float t1, unsigned& hi, unsig
   const f16x2 l = {(_Float16)__builtin_fmaf(r0, H_LO_SCALE, 0.0f), (_Float16)__builtin_fmaf(r1, H_LO_SCALE, 0.0f)};
   lo = __builtin_bit_cast(unsigned, l);
 }
-#endif
 // 8 consecutive k of one row -> the lane's operand fragments of the two planes
 __device__ __forceinline__ void split_h(const float4& a, const float4& b, float4& p1, float4& p2) {
   const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};

@@ -310,12 +310,17 @@ struct SXState { f32x4 o0, o1, lsum, negm; float l; };
 // v_fma_mix{lo,hi}_f16 per element (the packed hi half is an operand as it stands)
 __device__ __forceinline__ void sx_split1(const float* x, float4& hi, float4& lo) {
   unsigned hh[4], ll[4];
+  float m1 = -1.0f;
+  asm("" : "+s"(m1));
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     hh[i] = sa_pk(x[2 * i], x[2 * i + 1]);
     asm volatile("" : "+v"(hh[i]));      // opaque: the halves are read out of the PACKED register, not re-converted
     const sa_f16x2 v = __builtin_bit_cast(sa_f16x2, hh[i]);
-    ll[i] = sa_pk(fmaf((float)v[0], -1.0f, x[2 * i]), fmaf((float)v[1], -1.0f, x[2 * i + 1]));
+    // (round 6: the multiplier opaque -- with a literal -1 hipcc turns fma(h, -1, x) into v_cvt_f32_f16 + v_sub_f32, two
+    // instructions per value; as it stands it is ONE v_fma_mix_f32 reading the half out of the packed register.  x - h is
+    // exact either way: same bits.)
+    ll[i] = sa_pk(fmaf((float)v[0], m1, x[2 * i]), fmaf((float)v[1], m1, x[2 * i + 1]));
   }
   hi = make_float4(__uint_as_float(hh[0]), __uint_as_float(hh[1]), __uint_as_float(hh[2]), __uint_as_float(hh[3]));
   lo = make_float4(__uint_as_float(ll[0]), __uint_as_float(ll[1]), __uint_as_float(ll[2]), __uint_as_float(ll[3]));
