@@ -978,9 +978,12 @@ __device__ __forceinline__ float4 act_ld4(const float* row, int col) {       // 
     const uint2 h = *reinterpret_cast<const uint2*>(p), l = *reinterpret_cast<const uint2*>(p + 16);
     const f16x2 h0 = __builtin_bit_cast(f16x2, h.x), h1 = __builtin_bit_cast(f16x2, h.y);
     const f16x2 l0 = __builtin_bit_cast(f16x2, l.x), l1 = __builtin_bit_cast(f16x2, l.y);
-    constexpr float UH = 1.0f / H_ACT_SCALE, UL = 1.0f / (H_ACT_SCALE * H_LO_SCALE);
-    return make_float4(fmaf((float)l0[0], UL, (float)h0[0] * UH), fmaf((float)l0[1], UL, (float)h0[1] * UH),
-                       fmaf((float)l1[0], UL, (float)h1[0] * UH), fmaf((float)l1[1], UL, (float)h1[1] * UH));
+    // x = (hi + lo 2^-11) / s: the sum as ONE v_fma_mix_f32 with both halves read as f16, then the exact power-of-two
+    // un-scaling -- two instructions per value (round 6; as fma(lo, 2^-11 / s, hi / s) hipcc needed three: v_cvt_f32_f16,
+    // v_mul_f32, v_fma_mix_f32).  Scaling by 2^6 commutes with the one rounding: same bits.
+    constexpr float US = 1.0f / H_ACT_SCALE, UL = 1.0f / H_LO_SCALE;
+    return make_float4(fmaf((float)l0[0], UL, (float)h0[0]) * US, fmaf((float)l0[1], UL, (float)h0[1]) * US,
+                       fmaf((float)l1[0], UL, (float)h1[0]) * US, fmaf((float)l1[1], UL, (float)h1[1]) * US);
   }
 }
 template <bool PL>
