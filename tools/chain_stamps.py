@@ -38,6 +38,9 @@ def main():
     lib.tc_debug_chain_sub.restype = C.c_int
     lib.tc_debug_chain_sub.argtypes = [C.c_int, C.c_void_p]
     lib.tc_debug_chain_sub(sub, None)
+    block2 = int(os.environ.get('STAMPS_BLOCK2', '-1'))      # a second stamped workgroup (radar, 9 frames: block 0 is a tile of hit rows)
+    lib.tc_debug_chain_stamps2.argtypes = [C.c_int, C.c_void_p]
+    lib.tc_debug_chain_stamps2(block2, None)
     rows_env = int(os.environ.get('STAMPS_ROWS', '0'))       # 0: automatic; 32: the 8-wave tiles
     from transcar_amd.detr3d_head import head_options
     NWV = 8 if rows_env == 32 else 4
@@ -140,6 +143,14 @@ def main():
             cols.append('%6d /%5d' % (work, wait))
         print('%-14s %s' % (names[i], '   '.join(cols)))
     print('total cycles (wave 0): %d = %.1f us at 2.4 GHz' % (t[0, 2 * n], t[0, 2 * n] / 2400.0))
+    if block2 >= 0:
+        b2 = np.zeros((8, 64), dtype=np.int64)
+        assert lib.tc_debug_chain_stamps2(0, b2.ctypes.data) == 0
+        t2 = b2 - b2[:, :1]
+        print('\nworkgroup %d:' % block2)
+        for i in range(n):
+            print('%-14s %s' % (names[i], '   '.join('%6d /%5d' % (t2[w, 1 + 2 * i] - t2[w, 2 * i], t2[w, 2 + 2 * i] - t2[w, 1 + 2 * i]) for w in range(NWV))))
+        print('total cycles (wave 0): %d' % t2[0, 2 * n])
 
 
 if __name__ == '__main__':

@@ -2158,6 +2158,8 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAllT<nw_
         // division in front of the first tap).  Same arithmetic per (row, camera): bit-identical.
         float pu, pv;
         unsigned long long vm;
+        int Hl, Wl;
+        cam_level_dims<4>(k.cam, lane, Hl, Wl);      // once per step, in flight with the projections (not once per row)
         {
           const int i = lane >> 4, c = lane & 15;
           const int prow = wave + NW * min(i, R / NW - 1);
@@ -2172,7 +2174,7 @@ __device__ __forceinline__ void chain_body(const ChainDev& k, const StepAllT<nw_
           const int grow = min(m0 + row, M - 1);
           const unsigned long long vmask = (vm >> (16 * i)) & 0xFFFFull;
           const float4 o = cam_sample_core<4>(k.cam, grow / k.Q, &S.l[row][0], lane, vmask, pu, pv,
-                                              [](int, int, int, const float* ptr) { return cam_tap_ld(ptr); }, 16 * i);
+                                              [](int, int, int, const float* ptr) { return cam_tap_ld(ptr); }, 16 * i, Hl, Wl);
           act_st4<PL>(buf_ptr(S, r.dst) + row * LD2, 4 * lane, o);
           if (m0 + row < M) pairs += __popcll(vmask);
         }

@@ -189,14 +189,24 @@ __device__ __forceinline__ unsigned long long cam_project(const CamK& p, int row
 // F.grid_sample, bilinear, zeros padding, align_corners=False) and the index of its
 // (clamped) pixel in the level's [B * num_cams, H, W] grid.  (With every lane computing all
 // 4 L taps the sampling step was instruction bound: ~700 VALU instructions per camera.)
+// the lane's level l = lane >> 2: its map's height and width.  Depends on the lane only: callers that walk several rows
+// fetch it ONCE (round 6: hipcc turns the select chain into an indexed load from the kernel-argument segment -- inside the
+// row loop of the chain's sampling step that was one more dependent memory round trip per row, in front of the taps)
+template <int L>
+__device__ __forceinline__ void cam_level_dims(const CamK& p, int lane, int& H, int& W) {
+  const int l = min(lane >> 2, L - 1);
+  H = p.H[0]; W = p.W[0];
+#pragma unroll
+  for (int i = 1; i < L; ++i) {
+    int hi = p.H[i], wi = p.W[i];
+    asm("" : "+s"(hi), "+s"(wi));          // (opaque scalars: selects between registers, no table in memory)
+    if (l == i) { H = hi; W = wi; }
+  }
+}
 template <int L>
 __device__ __forceinline__ void cam_tap_lane(const CamK& p, int b, int cam, float u_, float v_, int lane,
-                                             float& wgt, int& pix) {
-  const int l = min(lane >> 2, L - 1);
-  int H = p.H[0], W = p.W[0];
-#pragma unroll
-  for (int i = 1; i < L; ++i)
-    if (l == i) { H = p.H[i]; W = p.W[i]; }
+                                             float& wgt, int& pix, int H = -1, int W = -1) {
+  if (H < 0) cam_level_dims<L>(p, lane, H, W);
   const float ix = ((u_ + 1.0f) * (float)W - 1.0f) * 0.5f;
   const float iy = ((v_ + 1.0f) * (float)H - 1.0f) * 0.5f;
   const float xw = floorf(ix), yn = floorf(iy);
@@ -243,7 +253,7 @@ __device__ __forceinline__ float4 cam_level_value(const float4 (&tap)[4], const 
 template <int L, typename Fetch>
 __device__ __forceinline__ float4 cam_sample_core(const CamK& p, int b, const float* lg, int lane,
                                                   unsigned long long vmask, float u, float v, Fetch fetch,
-                                                  int lane0 = 0) {
+                                                  int lane0 = 0, int Hl = -1, int Wl = -1) {
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   int c = 0;
   // XFMR:370: the num_cams * L attention weights of the query, one per lane, ONCE (round 3: every lane evaluated
@@ -258,7 +268,7 @@ __device__ __forceinline__ float4 cam_sample_core(const CamK& p, int b, const fl
     float wgt[L][4];
     float w_lane;
     int pix_lane;
-    cam_tap_lane<L>(p, b, cam, u_, v_, lane, w_lane, pix_lane);
+    cam_tap_lane<L>(p, b, cam, u_, v_, lane, w_lane, pix_lane, Hl, Wl);
 #pragma unroll
     for (int l = 0; l < L; ++l) {
 #pragma unroll
@@ -299,6 +309,8 @@ struct PreGatherK {
 template <int L>
 __device__ __forceinline__ void cam_pregather_rows(const PreGatherK& g, int r0, int nrows, int lane) {
   const CamK& p = g.cam;
+  int Hl, Wl;
+  cam_level_dims<L>(p, lane, Hl, Wl);
 #pragma unroll 1
   for (int base = 0; base < nrows; base += 4) {
     // lane 16 i + c: row r0 + base + i, camera c -- the projections of four rows in one round trip
@@ -321,7 +333,7 @@ __device__ __forceinline__ void cam_pregather_rows(const PreGatherK& g, int r0, 
       const int grow = r0 + base + (bit >> 4);
       float w_lane;
       int pix_lane;
-      cam_tap_lane<L>(p, grow / p.Q, cam, lane_f(pu, bit), lane_f(pv, bit), lane, w_lane, pix_lane);
+      cam_tap_lane<L>(p, grow / p.Q, cam, lane_f(pu, bit), lane_f(pv, bit), lane, w_lane, pix_lane, Hl, Wl);
       // two levels (eight taps: 8 KiB per wave in flight) at a time: 32 tap registers instead of 64 -- the role must fit
       // the attention core's 128-register budget (four waves per SIMD: at 156 registers the core itself lost a quarter of
       // its occupancy and 5 us per launch, measured)
