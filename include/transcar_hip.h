@@ -398,6 +398,14 @@ int tc_radar_fusion_fwd(const tc_head_weights* packed_view, const float* hs_last
 int tc_radar_gate_selfcheck(int n_radii, unsigned long long seed, unsigned long long* mismatches,
                             tc_stream_t stream);
 
+/* Self-check of the row-local arithmetic of the 16- / 32-row chains (round 6; no reference line: an implementation
+ * invariant).  Three pieces were rewritten for fewer vector instructions and must give the same BITS as their plain forms:
+ * [0] LayerNorm of a wave's four rows through one packed reduction tree (against one row at a time), [1] the split of a
+ * value into two f16 planes, [2] a plane pair back to fp32.  n_blocks workgroups draw their own rows / values (magnitudes
+ * over 40 binades, constant rows, signed zeros, subnormals, f16 overflow, infinities, NaN); the numbers of differing results
+ * are ADDED to mismatches[0..2] (device, 24 bytes, zeroed by the caller). */
+int tc_rowops_selfcheck(int n_blocks, unsigned long long seed, unsigned long long* mismatches, tc_stream_t stream);
+
 /* NMSFreeCoder.decode_single + get_bboxes z-shift (CODER:39-90, UTIL:26-52,
  * HEAD:1018): sigmoid, top-`max_num` of Q*num_classes scores, gather,
  * denormalise, centre-range mask, z -= h/2.

@@ -1010,6 +1010,19 @@ def test_gate_predicate_without_square_roots_is_the_reference_comparison(T):
     assert int(bad.item()) == 0
 
 
+def test_instruction_count_forms_of_the_row_arithmetic_give_the_same_bits(T):
+    """Round 6 rewrote the LayerNorm of a wave's four rows (one packed reduction tree, one 1 / sqrt), the split of a value
+    into two f16 planes (v_fma_mix forms) and the way back (rowdev.hpp ln_rows<4>, chain.hip split_t2 / act_ld4) for fewer
+    vector instructions.  On the device: 2 048 workgroups x 4 waves of random and special rows / values (constant rows, a
+    mean far above the deviation, signed zeros, subnormals, f16 overflow, infinities, NaN) through both forms -- not one
+    differing bit."""
+    from transcar_amd import _lib as L
+    bad = torch.zeros(3, dtype=torch.int64, device=dev())
+    L.check(L.lib().tc_rowops_selfcheck(2048, 20261004, bad.data_ptr(), None), 'rowops selfcheck')
+    torch.cuda.synchronize()
+    assert bad.tolist() == [0, 0, 0], 'LayerNorm / split / un-split mismatches: %s' % bad.tolist()
+
+
 def test_pipelines_can_share_streams(T, head):
     """FramePipeline(streams=other.streams): a second pipeline on the (idle) first one's HIP streams -- the
     lanes of a third pipeline with streams of its own can end up on shared hardware queues -- gives the

@@ -160,6 +160,7 @@ SIGNATURES = {
     'tc_sdpa_fwd_f16x2': (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     'tc_radar_xattn_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'tc_radar_gate_selfcheck': (_i, [_i, C.c_ulonglong, _vp, _vp]),
+    'tc_rowops_selfcheck': (_i, [_i, C.c_ulonglong, _vp, _vp]),
     'tc_radar_gated_xattn_fwd': (_i, [_P(tc_mha), _vp, _vp, _vp, _i, _vp, _vp,
                                       _i, _i, _i, _i, _i, _i, _f, _f, _vp,
                                       _vp, _vp, _sz, _vp]),

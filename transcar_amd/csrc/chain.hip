@@ -3079,4 +3079,108 @@ int launch_radar_chain_bwd(const RadarBwdChainArgs& a, hipStream_t s) {
   return launch(k, s, "chain(radar backward)");
 }
 
+// ---- tc_rowops_selfcheck (round 6): the instruction-count forms of the row-local arithmetic against the plain ones ----------
+// Round 6 rewrote three pieces of the 16- / 32-row chains for fewer vector instructions and claims the same BITS:
+//   [0] ln_rows<4> (four rows through one packed reduction tree, one 1 / sqrt on the packed variances) against four
+//       ln_rows<1> (wave_sum per row);
+//   [1] split_t2 (v_fma_mix / v_fma_mixlo forms) against hi = f16(t), lo = f16((t - hi) 2^11) written out;
+//   [2] act_ld4<true> (one two-f16 v_fma_mix + the power-of-two un-scaling) against fma(lo, 2^-11 / s, hi / s).
+// Every workgroup draws its own rows / values (random magnitudes over 40 binades, constant rows, signed zeros, f16
+// overflow, subnormals, infinities, NaN) and adds the number of differing results to mismatches[0..2] (two NaNs agree).
+namespace {
+__device__ __forceinline__ unsigned long long sc_mix(unsigned long long h) {
+  h ^= h >> 30; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 27; h *= 0x94D049BB133111EBull; h ^= h >> 31;
+  return h;
+}
+__device__ __forceinline__ float sc_value(unsigned long long h, int kind) {
+  const float u = (float)(h >> 40) * (1.0f / 16777216.0f) * 2.0f - 1.0f;       // [-1, 1)
+  const int e = (int)((h >> 8) & 63) - 44;                                       // 2^-44 .. 2^19
+  switch (kind & 15) {
+    case 0: return 0.0f;
+    case 1: return -0.0f;
+    case 2: return __builtin_bit_cast(float, (unsigned)(h & 0x007FFFFFu));              // fp32 subnormal
+    case 3: return ldexpf(u, -20);                                                      // f16 subnormal range after the split
+    case 4: return u * 70000.0f * 64.0f;                                                // around the planes' range
+    case 5: return (h & 1) ? INFINITY : -INFINITY;
+    case 6: return __builtin_bit_cast(float, 0x7FC00000u | (unsigned)(h & 0xFFFFu));    // NaN
+    default: return ldexpf(u, e);
+  }
+}
+__device__ __forceinline__ bool sc_differ(float a, float b) {
+  if (a != a && b != b) return false;
+  return __builtin_bit_cast(unsigned, a) != __builtin_bit_cast(unsigned, b);
+}
+__global__ __launch_bounds__(256) void rowops_selfcheck_kernel(unsigned long long seed, unsigned long long* mismatches) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long bad0 = 0, bad1 = 0, bad2 = 0;
+  const unsigned long long base = sc_mix(seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(blockIdx.x * 4 + wave + 1));
+  // [0] LayerNorm of four rows: per row a magnitude, an offset (mean >> deviation is the hard case) and a flavour
+  {
+    float4 v[4], w1[4];
+    const unsigned long long hg = sc_mix(base + 77 + (unsigned long long)lane);
+    const float4 gg = make_float4(sc_value(hg, 8), sc_value(sc_mix(hg + 1), 8), sc_value(sc_mix(hg + 2), 8), sc_value(sc_mix(hg + 3), 8));
+    const float4 bb = make_float4(sc_value(sc_mix(hg + 4), 8), sc_value(sc_mix(hg + 5), 8), sc_value(sc_mix(hg + 6), 8), sc_value(sc_mix(hg + 7), 8));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned long long hr = sc_mix(base + 1000ull * (unsigned long long)(i + 1));
+      const float mag = ldexpf(1.0f, (int)(hr & 31) - 16), off = (hr & 32) ? mag * (float)((hr >> 6) & 1023) : 0.0f;
+      const int flavour = (int)((hr >> 20) & 7);       // 0: a constant row, 1: one outlier, else random
+      float x[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const unsigned long long he = sc_mix(hr + 16ull * (unsigned long long)lane + (unsigned long long)c);
+        const float u = (float)(he >> 40) * (1.0f / 16777216.0f) * 2.0f - 1.0f;
+        x[c] = flavour == 0 ? off + mag : flavour == 1 ? off + ((lane == 17 && c == 2) ? mag * 1000.0f : mag * 1e-3f * u) : off + mag * u;
+      }
+      v[i] = make_float4(x[0], x[1], x[2], x[3]);
+      w1[i] = v[i];
+    }
+    ln_rows<4>(v, gg, bb);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float4 one[1] = {w1[i]};
+      ln_rows<1>(one, gg, bb);
+      bad0 += sc_differ(one[0].x, v[i].x) + sc_differ(one[0].y, v[i].y) + sc_differ(one[0].z, v[i].z) + sc_differ(one[0].w, v[i].w);
+    }
+  }
+  // [1], [2]: values one by one
+  __shared__ float lds[4][64][8];
+  for (int it = 0; it < 64; ++it) {
+    const unsigned long long h0 = sc_mix(base + 31ull * (unsigned long long)(it * 64 + lane) + 5);
+    const unsigned long long h1 = sc_mix(h0 + 1);
+    const float t0 = sc_value(h0, (int)(h0 >> 4)), t1 = sc_value(h1, (int)(h1 >> 4));
+    unsigned hi, lo;
+    split_t2(t0, t1, hi, lo);
+    const unsigned rh = pk_h2(t0, t1);
+    const f16x2 hv = __builtin_bit_cast(f16x2, rh);
+    const f16x2 rl = {(_Float16)((t0 - (float)hv[0]) * H_LO_SCALE), (_Float16)((t1 - (float)hv[1]) * H_LO_SCALE)};
+    const f16x2 gh = __builtin_bit_cast(f16x2, hi), gl = __builtin_bit_cast(f16x2, lo);
+    bad1 += sc_differ((float)gh[0], (float)hv[0]) + sc_differ((float)gh[1], (float)hv[1]) +
+            sc_differ((float)gl[0], (float)rl[0]) + sc_differ((float)gl[1], (float)rl[1]);
+    // a plane pair as act_st4 lays it down (four values: 8 bytes of hi, 8 bytes of lo), read back both ways
+    const unsigned long long h2 = sc_mix(h0 + 2), h3 = sc_mix(h0 + 3);
+    const float4 x4 = make_float4(t0, t1, sc_value(h2, (int)(h2 >> 4)), sc_value(h3, (int)(h3 >> 4)));
+    float* row = &lds[wave][lane][0];
+    act_st4<true>(row, 0, x4);
+    const float4 g4 = act_ld4<true>(row, 0);
+    const char* pp = reinterpret_cast<const char*>(row);
+    const uint2 ph = *reinterpret_cast<const uint2*>(pp), pl = *reinterpret_cast<const uint2*>(pp + 16);
+    const f16x2 a0 = __builtin_bit_cast(f16x2, ph.x), a1 = __builtin_bit_cast(f16x2, ph.y);
+    const f16x2 b0 = __builtin_bit_cast(f16x2, pl.x), b1 = __builtin_bit_cast(f16x2, pl.y);
+    constexpr float UH = 1.0f / H_ACT_SCALE, UL = 1.0f / (H_ACT_SCALE * H_LO_SCALE);
+    bad2 += sc_differ(g4.x, fmaf((float)b0[0], UL, (float)a0[0] * UH)) + sc_differ(g4.y, fmaf((float)b0[1], UL, (float)a0[1] * UH)) +
+            sc_differ(g4.z, fmaf((float)b1[0], UL, (float)a1[0] * UH)) + sc_differ(g4.w, fmaf((float)b1[1], UL, (float)a1[1] * UH));
+  }
+  if (bad0) atomicAdd(mismatches + 0, bad0);
+  if (bad1) atomicAdd(mismatches + 1, bad1);
+  if (bad2) atomicAdd(mismatches + 2, bad2);
+}
+}  // namespace
+
+int launch_rowops_selfcheck(int n_blocks, unsigned long long seed, unsigned long long* mismatches, hipStream_t s) {
+  TC_REQUIRE(n_blocks > 0 && mismatches != nullptr, "rowops_selfcheck: bad arguments");
+  hipLaunchKernelGGL(rowops_selfcheck_kernel, dim3(n_blocks), dim3(256), 0, s, seed, mismatches);
+  return check_launch("rowops_selfcheck");
+}
+
 }  // namespace tc

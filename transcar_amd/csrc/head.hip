@@ -644,6 +644,10 @@ int tc_radar_gate_selfcheck(int n_radii, unsigned long long seed, unsigned long 
   return launch_gate_selfcheck(n_radii, seed, mismatches, as_stream(stream));
 }
 
+int tc_rowops_selfcheck(int n_blocks, unsigned long long seed, unsigned long long* mismatches, tc_stream_t stream) {
+  return launch_rowops_selfcheck(n_blocks, seed, mismatches, as_stream(stream));
+}
+
 size_t tc_box_decode_workspace_bytes(int B, int Q, int num_classes) {
   return box_decode_ws_bytes(B, Q, num_classes);
 }

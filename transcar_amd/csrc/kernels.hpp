@@ -178,6 +178,7 @@ int launch_radar_compact(const float* ref_last, const float* box, int code, int 
                          float rmin, float rmax, int* flags, int* perm, hipStream_t s);
 
 int launch_gate_selfcheck(int n_radii, unsigned long long seed, unsigned long long* mismatches, hipStream_t s);
+int launch_rowops_selfcheck(int n_blocks, unsigned long long seed, unsigned long long* mismatches, hipStream_t s);   // chain.hip
 
 // ---- self_attn.hip ---------------------------------------------------------
 // q,k: [B*Q, ld] token-major with head h at column h*32; vt: [B, C, ldt] (V transposed)
