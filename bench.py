@@ -554,7 +554,11 @@ def roofline(head, inp, dev, matrix_path='auto', tile_rows=0):
             # ... against what a CU's vector-memory path delivers (64 B / clk at 2.4 GHz): the resource the kernel's item
             # loops run against (inside them ~57 of 64 B / clk, tools/split_mfma_probe.hip; averaged over the whole
             # kernel -- sampling, LayerNorms, epilogues included -- the figure below)
-            weight_stream_peak_gbs_per_cu=L1_PATH_GBS_PER_CU),
+            weight_stream_peak_gbs_per_cu=L1_PATH_GBS_PER_CU,
+            # ... and what a CU GETS when all 32 CUs of its XCD stream the same layer out of the one L2 (254 workgroups of 8
+            # waves, one 16 KiB item in flight per wave: tools/wpolicy_probe.hip, profiles/r6_weight_stream_policy.txt, a
+            # committed measurement, not taken in this run): the stream alone is then ~26 us of a nine-frame layer
+            weight_stream_measured_ceiling_gbs_per_cu=124.0),
         'self_attn_kernel': dict(
             bound='mfma', achieved=attn_flop / attn_ms / 1e9, peak=chain_peak if f16x2 else F32_MFMA_PEAK_TFLOPS,
             unit='TFLOP/s', ms=attn_ms, per_frame=6, alg_flop=attn_flop,
